@@ -1,0 +1,161 @@
+/*
+ * ia_amd.h -- C ABI of libia_amd.so: the MI355X (gfx950) implementation of
+ * IntrinsicAvatar's volumetric render_step hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work
+ *     is enqueued on it, nothing synchronises unless stated;
+ *   - the caller owns every buffer; data-dependent output sizes use a two-phase
+ *     "count -> (caller allocates) -> fill" protocol;
+ *   - return value: IA_OK (0) or a negative IA_ERR_*; ia_last_error() gives text;
+ *   - bool tensors are 1 byte per element (torch.bool layout);
+ *   - tensors are contiguous, row-major, in the shapes the reference's Python
+ *     operator passes (cited per entry point as file:line under /root/reference).
+ *
+ * The reference has no C plugin ABI: its boundary is the Python operator surface
+ * of five modules.  Each entry point below names the reference
+ * operator it replaces; INTEGRATION.md shows the ctypes binding that maps the
+ * reference's call sites onto this ABI.
+ */
+#ifndef IA_AMD_H
+#define IA_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IA_OK 0
+#define IA_ERR_INVALID (-1)     /* bad argument (the reference would TORCH_CHECK) */
+#define IA_ERR_LAUNCH (-2)      /* HIP launch / runtime error */
+#define IA_ERR_UNSUPPORTED (-3) /* valid for the reference API but not on this path */
+
+typedef void* ia_stream_t;
+
+int ia_version(void);
+const char* ia_last_error(void);
+
+/* ------------------------------------------------------------------------- */
+/* Prefix sums (plumbing for the two-phase protocol).                          */
+/* out[i] = sum_{j<i} in[j]; total (1 element, device) = sum of all; tmp must  */
+/* hold ia_scan_tmp_bytes(n) bytes.                                            */
+int64_t ia_scan_tmp_bytes(int64_t n);
+int ia_exclusive_scan_i64(const int64_t* in, int64_t* out, int64_t* total, int64_t n, void* tmp, ia_stream_t stream);
+int ia_exclusive_scan_i32(const int32_t* in, int32_t* out, int32_t* total, int64_t n, void* tmp, ia_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* nerfacc.traverse_grids  (nerfacc==0.5.3; reference call sites
+ * models/occ_grid/temporal_occ_grid.py:166-175, models/intrinsic_avatar.py:84-93).
+ * One grid level (the reference always passes `binaries[t_idx:t_idx+1]`).
+ *
+ * ia_occgrid_pack_bits: binaries bool[rx*ry*rz] -> bit-packed uint32[(rx*ry*rz+31)/32]
+ * (bit c&31 of word c>>5 is cell c, c = (x*ry + y)*rz + z).
+ *
+ * Phase 1 (count): per-ray edge / sample counts (int64, like upstream's chunk_cnts).
+ * Phase 2 (fill):  caller passes exclusive scans of the counts and zero-filled flag
+ *                  arrays; writes RayIntervals{vals,is_left,is_right,ray_indices} and
+ *                  RaySamples{vals,ray_indices} and termination planes.
+ * Rays are independent; output order = ray order, then marching order.
+ */
+int ia_occgrid_pack_bits(const uint8_t* binaries, int64_t n_cells, uint32_t* bits, ia_stream_t stream);
+
+int ia_traverse_grids_count(
+    int64_t n_rays, const float* rays_o /*[n,3]*/, const float* rays_d /*[n,3]*/,
+    const uint32_t* grid_bits, int res_x, int res_y, int res_z, const float* aabb /*[6] device*/,
+    const float* near_planes /*[n]*/, const float* far_planes /*[n]*/, float step_size, float cone_angle,
+    int64_t* iv_cnt /*[n]*/, int64_t* sm_cnt /*[n]*/, ia_stream_t stream);
+
+int ia_traverse_grids_fill(
+    int64_t n_rays, const float* rays_o, const float* rays_d,
+    const uint32_t* grid_bits, int res_x, int res_y, int res_z, const float* aabb,
+    const float* near_planes, const float* far_planes, float step_size, float cone_angle,
+    const int64_t* iv_start /*[n]*/, const int64_t* sm_start /*[n]*/,
+    float* iv_vals /*[E]*/, uint8_t* iv_is_left /*[E] zeroed*/, uint8_t* iv_is_right /*[E] zeroed*/,
+    int64_t* iv_ray_indices /*[E]*/, float* sm_vals /*[S]*/, int64_t* sm_ray_indices /*[S]*/,
+    float* termination_planes /*[n] or NULL*/, ia_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* nerfacc.render_weight_from_alpha / accumulate_along_rays
+ * (call sites models/intrinsic_avatar.py:506,1199,1427-1453; models/volrend.py:162,176-187,764,783-797).
+ * packed_info is int32 [n_rays,2] = (start, count), samples sorted by ray.        */
+int ia_render_weight_from_alpha(int64_t n_rays, const int32_t* packed_info, const float* alphas,
+                                float* weights, float* trans, ia_stream_t stream);
+int ia_render_weight_from_alpha_bwd(int64_t n_rays, const int32_t* packed_info, const float* alphas,
+                                    const float* weights, const float* trans,
+                                    const float* g_weights /*or NULL*/, const float* g_trans /*or NULL*/,
+                                    float* g_alphas, ia_stream_t stream);
+/* out[r, :] = sum_{i in ray r} w_i * v_i   (values NULL => dim 1, v = 1), in sample order */
+int ia_accumulate_along_rays(int64_t n_rays, const int32_t* packed_info, int dim, const float* weights,
+                             const float* values /*[S,dim] or NULL*/, float* out /*[n,dim]*/, ia_stream_t stream);
+/* backward: g_w[i] = <g_out[r], v_i>,  g_v[i,:] = w_i g_out[r]  (either output may be NULL) */
+int ia_accumulate_along_rays_bwd(int64_t n_samples, int dim, const int64_t* ray_indices, const float* weights,
+                                 const float* values, const float* g_out, float* g_weights, float* g_values,
+                                 ia_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* lib.nerfacc pack / unpack  (lib/nerfacc/pack.py:12-190, cuda/csrc/pack.cu:7-164) */
+int ia_pack_info(int64_t n_samples, const int64_t* ray_indices, int64_t n_rays,
+                 int32_t* packed_info /*[n,2]*/, void* tmp /* ia_scan_tmp_bytes(n_rays)+4*n_rays+8 bytes */,
+                 ia_stream_t stream);
+int ia_unpack_info(int64_t n_rays, const int32_t* packed_info, int64_t* ray_indices, ia_stream_t stream);
+int ia_unpack_info_to_mask(int64_t n_rays, const int32_t* packed_info, int n_samples,
+                           uint8_t* masks /*[n,n_samples] zeroed*/, ia_stream_t stream);
+int ia_unpack_data(int64_t n_rays, const int32_t* packed_info, int data_dim, const float* data,
+                   int n_samples_per_ray, float* out /*[n,S,D] zeroed*/, ia_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* lib.nerfacc importance resampling (lib/nerfacc/cdf.py:13-244, cuda/csrc/cdf.cu).
+ * Prologue (cdf.cu:177-183): resample_packed_info[r] = (excl. cumsum, cnt),
+ *   cnt = (steps>0 ? n : 0) + (add_steps ? steps : 0); total -> 1 device int32.  */
+int ia_resample_packed_info(int64_t n_rays, const int32_t* packed_info, int n, int add_steps,
+                            int32_t* resample_packed_info, int32_t* total,
+                            void* tmp /* ia_scan_tmp_bytes(n_rays)+4*n_rays bytes */, ia_stream_t stream);
+/* K1 ray_resampling (cdf.cu:10-215): fg_counts/bg_counts zeroed, surface_idx = -1 by caller */
+int ia_ray_resampling(int64_t n_rays, const int32_t* packed_info, const float* starts, const float* ends,
+                      const float* weights, const float* sdfs, const int32_t* resample_packed_info,
+                      float* resample_ts, float* resample_offsets, int64_t* surface_idx,
+                      int64_t* resample_indices, int32_t* resample_fg_counts, int32_t* resample_bg_counts,
+                      ia_stream_t stream);
+/* K2 ray_resampling_merge (cdf.cu:217-401): every output zero-initialised by caller */
+int ia_ray_resampling_merge(int64_t n_rays, const int32_t* packed_info, const float* vals,
+                            const uint8_t* is_left, const uint8_t* is_right, const float* weights,
+                            const int32_t* resample_packed_info, float* resample_vals, float* resample_dists,
+                            uint8_t* resample_is_left, uint8_t* resample_is_right, uint8_t* is_resample,
+                            uint8_t* is_fg_sample, ia_stream_t stream);
+/* K3 ray_resampling_fine (cdf.cu:403-534): outputs zero-initialised by caller */
+int ia_ray_resampling_fine(int64_t n_rays, const int32_t* packed_info, const float* starts, const float* ends,
+                           const float* weights, const int32_t* resample_packed_info, float* resample_starts,
+                           float* resample_ends, uint8_t* is_fg_sample, ia_stream_t stream);
+/* K4 ray_resampling_sdf_fine (cdf.cu:536-696): outputs zero-initialised by caller */
+int ia_ray_resampling_sdf_fine(int64_t n_rays, const int32_t* packed_info, const float* starts,
+                               const float* ends, const float* alphas, const float* sdfs,
+                               const int32_t* resample_packed_info, float* resample_starts,
+                               float* resample_ends, uint8_t* is_fg_sample, ia_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* fast-SNARF deformer kernels (models/deformers/fast_snarf/deformer_torch.py:86-125,
+ * cuda/precompute/precompute.cu:24-103, cuda/fuse_kernel/fuse_cuda_kernel_fast.cu:250-452,
+ * cuda/filter/filter.cu:10-77).
+ * voxel_J layouts: IA_LAYOUT_NCDHW = the reference's [B,12,D,H,W];
+ *                  IA_LAYOUT_NDHWC = channel-last [B,D,H,W,12] (48 B per voxel, the
+ *                  MI355X-native layout: one trilinear corner pair = 96 contiguous bytes). */
+#define IA_LAYOUT_NCDHW 0
+#define IA_LAYOUT_NDHWC 1
+int ia_precompute(int B, int D, int H, int W, const float* voxel_w /*[1,24,D,H,W]*/, const float* tfs /*[B,24,4,4]*/,
+                  const float* offset /*[3]*/, const float* scale /*[3]*/,
+                  float* voxel_d /*[B,3,D,H,W] or NULL*/, float* voxel_J /*[B,12,D,H,W] or NULL*/,
+                  float* voxel_J_cl /*[B,D,H,W,12] or NULL*/, ia_stream_t stream);
+/* x, J_inv, is_valid are caller-zeroed (deformer_torch.py:113-115) */
+int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt /*[B,N,3]*/, const float* voxel_J, int layout,
+                    int D, int H, int W, const float* tfs, const int32_t* bone_ids /*[I]*/,
+                    const float* offset, const float* scale, float cvg_threshold, float dvg_threshold,
+                    float* x /*[B,N,I,3]*/, float* J_inv /*[B,N,I,3,3]*/, uint8_t* is_valid /*[B,N,I]*/,
+                    ia_stream_t stream);
+int ia_filter(int64_t N, int I, const float* x /*[1,N,I,3]*/, const uint8_t* mask, uint8_t* out, ia_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IA_AMD_H */

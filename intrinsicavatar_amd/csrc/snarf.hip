@@ -1,0 +1,281 @@
+// snarf.hip -- fast-SNARF deformer kernels for gfx950.
+// Replaces
+//   K10 precompute_kernel  models/deformers/fast_snarf/cuda/precompute/precompute.cu:24-103
+//   K8  broyden_kernel     models/deformers/fast_snarf/cuda/fuse_kernel/fuse_cuda_kernel_fast.cu:250-452
+//   K9  filter             models/deformers/fast_snarf/cuda/filter/filter.cu:10-77
+//
+// MI355X layout decision: the 12-channel voxel_J grid is kept CHANNEL-LAST
+// ([B,D,H,W,12], 48 B per voxel) next to the reference's [B,12,D,H,W].  A trilinear fetch then
+// touches 4 x 96 contiguous bytes (x0,x1 pairs) = 24 dwordx4 loads, instead of 96 scattered
+// dwords on 96 different cache lines; the 25 MB grid lives in the 256 MiB Infinity Cache.
+// No device synchronisation after the launches (the reference calls cudaDeviceSynchronize()).
+//
+// Arithmetic order is identical to oracle/ia_oracle.c (TU built with -ffp-contract=off), so
+// is_valid / filter masks are bit-exact and x, J_inv match bit-for-bit.
+#include "ia_common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+
+// ---- K10 ------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void precompute_kernel(int B, int D, int H, int W,
+                                                              const float* __restrict__ voxel_w,
+                                                              const float* __restrict__ tfs,
+                                                              const float* __restrict__ offset,
+                                                              const float* __restrict__ scale,
+                                                              float* __restrict__ voxel_d, float* __restrict__ voxel_J,
+                                                              float* __restrict__ voxel_J_cl)
+{
+    __shared__ float s_tfs[24 * 12];
+    const int64_t vol = (int64_t)D * H * W;
+    const int idx_b = blockIdx.y;
+    for (int t = threadIdx.x; t < 24 * 12; t += THREADS) {
+        const int j = t / 12, c = t % 12;
+        s_tfs[t] = tfs[((int64_t)idx_b * 24 + j) * 16 + c];   // rows 0..2 of the 4x4 = first 12 floats
+    }
+    __syncthreads();
+    const int64_t v = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (v >= vol) return;
+    const int idx_d = (int)(v / ((int64_t)H * W));
+    const int idx_h = (int)(v % ((int64_t)H * W) / W);
+    const int idx_w = (int)(v % ((int64_t)H * W) % W);
+    const float coord_x = (((float)idx_w) / (W - 1) * 2 - 1) / scale[0] - offset[0];
+    const float coord_y = (((float)idx_h) / (H - 1) * 2 - 1) / scale[1] - offset[1];
+    const float coord_z = (((float)idx_d) / (D - 1) * 2 - 1) / scale[2] - offset[2];
+    float J[12];
+#pragma unroll
+    for (int c = 0; c < 12; c++) J[c] = 0;
+    for (int j = 0; j < 24; j++) {
+        const float wj = voxel_w[j * vol + v];   // coalesced across lanes
+#pragma unroll
+        for (int c = 0; c < 12; c++) J[c] += wj * s_tfs[j * 12 + c];
+    }
+    if (voxel_J) {
+#pragma unroll
+        for (int c = 0; c < 12; c++) voxel_J[((int64_t)idx_b * 12 + c) * vol + v] = J[c];
+    }
+    if (voxel_J_cl) {
+        float4* dst = reinterpret_cast<float4*>(voxel_J_cl + ((int64_t)idx_b * vol + v) * 12);
+        dst[0] = make_float4(J[0], J[1], J[2], J[3]);
+        dst[1] = make_float4(J[4], J[5], J[6], J[7]);
+        dst[2] = make_float4(J[8], J[9], J[10], J[11]);
+    }
+    if (voxel_d) {
+#pragma unroll
+        for (int i0 = 0; i0 < 3; i0++) {
+            const float xi = J[i0 * 4 + 0] * coord_x + J[i0 * 4 + 1] * coord_y + J[i0 * 4 + 2] * coord_z + J[i0 * 4 + 3];
+            voxel_d[((int64_t)idx_b * 3 + i0) * vol + v] = xi;
+        }
+    }
+}
+
+// ---- trilinear 12-channel fetch -------------------------------------------------
+template <int LAYOUT>
+__device__ __forceinline__ void load_corner(const float* __restrict__ vJ, int64_t vol, int64_t lin, float c[12])
+{
+    if (LAYOUT == IA_LAYOUT_NDHWC) {
+        const float4* p = reinterpret_cast<const float4*>(vJ + lin * 12);
+        const float4 a = p[0], b = p[1], d = p[2];
+        c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
+        c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+        c[8] = d.x; c[9] = d.y; c[10] = d.z; c[11] = d.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; k++) c[k] = vJ[k * vol + lin];
+    }
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ void grid_sample_J(const float* __restrict__ vJ, int D, int H, int W, float gx, float gy,
+                                              float gz, float out[12])
+{
+    const int64_t vol = (int64_t)D * H * W;
+    float ix = ((gx + 1.f) / 2) * (W - 1);
+    float iy = ((gy + 1.f) / 2) * (H - 1);
+    float iz = ((gz + 1.f) / 2) * (D - 1);
+    if (ix > 2147483646.0f || ix < -2147483648.0f || !isfinite(ix)) ix = -100.0f;
+    if (iy > 2147483646.0f || iy < -2147483648.0f || !isfinite(iy)) iy = -100.0f;
+    if (iz > 2147483646.0f || iz < -2147483648.0f || !isfinite(iz)) iz = -100.0f;
+    const int x0 = (int)floorf(ix), y0 = (int)floorf(iy), z0 = (int)floorf(iz);
+    const int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+    const float wgt[8] = {
+        (x1 - ix) * (y1 - iy) * (z1 - iz), (ix - x0) * (y1 - iy) * (z1 - iz),
+        (x1 - ix) * (iy - y0) * (z1 - iz), (ix - x0) * (iy - y0) * (z1 - iz),
+        (x1 - ix) * (y1 - iy) * (iz - z0), (ix - x0) * (y1 - iy) * (iz - z0),
+        (x1 - ix) * (iy - y0) * (iz - z0), (ix - x0) * (iy - y0) * (iz - z0)};
+#pragma unroll
+    for (int k = 0; k < 12; k++) out[k] = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int x = (c & 1) ? x1 : x0, y = (c & 2) ? y1 : y0, z = (c & 4) ? z1 : z0;
+        if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) {
+            float v[12];
+            load_corner<LAYOUT>(vJ, vol, ((int64_t)z * H + y) * W + x, v);
+#pragma unroll
+            for (int k = 0; k < 12; k++) out[k] += v[k] * wgt[c];
+        }
+    }
+}
+
+__device__ __forceinline__ void J_inv_update(float Ji[9], float x0, float x1, float x2, float g0, float g1, float g2)
+{
+    const float J00 = Ji[0], J01 = Ji[1], J02 = Ji[2], J10 = Ji[3], J11 = Ji[4], J12 = Ji[5], J20 = Ji[6],
+                J21 = Ji[7], J22 = Ji[8];
+    const float c0 = J00 * x0 + J10 * x1 + J20 * x2;
+    const float c1 = J01 * x0 + J11 * x1 + J21 * x2;
+    const float c2 = J02 * x0 + J12 * x1 + J22 * x2;
+    const float s = c0 * g0 + c1 * g1 + c2 * g2;
+    const float r0 = -J00 * g0 - J01 * g1 - J02 * g2;
+    const float r1 = -J10 * g0 - J11 * g1 - J12 * g2;
+    const float r2 = -J20 * g0 - J21 * g1 - J22 * g2;
+    Ji[0] += c0 * (r0 + x0) / s;
+    Ji[1] += c1 * (r0 + x0) / s;
+    Ji[2] += c2 * (r0 + x0) / s;
+    Ji[3] += c0 * (r1 + x1) / s;
+    Ji[4] += c1 * (r1 + x1) / s;
+    Ji[5] += c2 * (r1 + x1) / s;
+    Ji[6] += c0 * (r2 + x2) / s;
+    Ji[7] += c1 * (r2 + x2) / s;
+    Ji[8] += c2 * (r2 + x2) / s;
+}
+
+// ---- K8 -------------------------------------------------------------------------
+template <int LAYOUT>
+__global__ __launch_bounds__(THREADS) void broyden_kernel(
+    int64_t total, int64_t N, int I, const float* __restrict__ xd_tgt, const float* __restrict__ voxel_J, int D, int H,
+    int W, const float* __restrict__ tfs, const int32_t* __restrict__ bone_ids, const float* __restrict__ offset_g,
+    const float* __restrict__ scale_g, float cvg_threshold, float dvg_threshold, float* __restrict__ x,
+    float* __restrict__ J_inv, uint8_t* __restrict__ is_valid)
+{
+    const int64_t index = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (index >= total) return;
+    const int64_t vol = (int64_t)D * H * W;
+    const int i_batch = (int)(index / (N * I));
+    const int64_t i_point = (index % (N * I)) / I;
+    const int i_init = (int)((index % (N * I)) % I);
+    const float* vJ = voxel_J + (int64_t)i_batch * 12 * vol;
+    const float offset[3] = {offset_g[0], offset_g[1], offset_g[2]};
+    const float scale[3] = {scale_g[0], scale_g[1], scale_g[2]};
+    float gx[3], gx_new[3] = {0, 0, 0}, xt[3], x_l[3];
+    xt[0] = xd_tgt[((int64_t)i_batch * N + i_point) * 3 + 0];
+    xt[1] = xd_tgt[((int64_t)i_batch * N + i_point) * 3 + 1];
+    xt[2] = xd_tgt[((int64_t)i_batch * N + i_point) * 3 + 2];
+    const int i_bone = bone_ids[i_init];
+    const float* T = tfs + ((int64_t)i_batch * 24 + i_bone) * 16;
+    const float ixd = xt[0] - T[0 * 4 + 3], iyd = xt[1] - T[1 * 4 + 3], izd = xt[2] - T[2 * 4 + 3];
+    x_l[0] = ixd * T[0 * 4 + 0] + iyd * T[1 * 4 + 0] + izd * T[2 * 4 + 0];
+    x_l[1] = ixd * T[0 * 4 + 1] + iyd * T[1 * 4 + 1] + izd * T[2 * 4 + 1];
+    x_l[2] = ixd * T[0 * 4 + 2] + iyd * T[1 * 4 + 2] + izd * T[2 * 4 + 2];
+
+    float Jl[12];
+    grid_sample_J<LAYOUT>(vJ, D, H, W, scale[0] * (x_l[0] + offset[0]), scale[1] * (x_l[1] + offset[1]),
+                          scale[2] * (x_l[2] + offset[2]), Jl);
+    float Ji[9];
+    Ji[0] = Jl[0]; Ji[3] = Jl[1]; Ji[6] = Jl[2];
+    Ji[1] = Jl[4]; Ji[4] = Jl[5]; Ji[7] = Jl[6];
+    Ji[2] = Jl[8]; Ji[5] = Jl[9]; Ji[8] = Jl[10];
+
+    for (int it = 0; it < 10; it++) {
+        const float J00 = Ji[0], J01 = Ji[1], J02 = Ji[2], J10 = Ji[3], J11 = Ji[4], J12 = Ji[5], J20 = Ji[6],
+                    J21 = Ji[7], J22 = Ji[8];
+        if (it == 0) {
+            gx[0] = Jl[0] * x_l[0] + Jl[1] * x_l[1] + Jl[2] * x_l[2] + Jl[3];
+            gx[1] = Jl[4] * x_l[0] + Jl[5] * x_l[1] + Jl[6] * x_l[2] + Jl[7];
+            gx[2] = Jl[8] * x_l[0] + Jl[9] * x_l[1] + Jl[10] * x_l[2] + Jl[11];
+            gx[0] = gx[0] - xt[0]; gx[1] = gx[1] - xt[1]; gx[2] = gx[2] - xt[2];
+        } else {
+            gx[0] = gx_new[0]; gx[1] = gx_new[1]; gx[2] = gx_new[2];
+        }
+        const float u0 = -J00 * gx[0] + -J01 * gx[1] + -J02 * gx[2];
+        const float u1 = -J10 * gx[0] + -J11 * gx[1] + -J12 * gx[2];
+        const float u2 = -J20 * gx[0] + -J21 * gx[1] + -J22 * gx[2];
+        x_l[0] += u0; x_l[1] += u1; x_l[2] += u2;
+        const float ix = scale[0] * (x_l[0] + offset[0]);
+        const float iy = scale[1] * (x_l[1] + offset[1]);
+        const float iz = scale[2] * (x_l[2] + offset[2]);
+        grid_sample_J<LAYOUT>(vJ, D, H, W, ix, iy, iz, Jl);
+        gx_new[0] = Jl[0] * x_l[0] + Jl[1] * x_l[1] + Jl[2] * x_l[2] + Jl[3] - xt[0];
+        gx_new[1] = Jl[4] * x_l[0] + Jl[5] * x_l[1] + Jl[6] * x_l[2] + Jl[7] - xt[1];
+        gx_new[2] = Jl[8] * x_l[0] + Jl[9] * x_l[1] + Jl[10] * x_l[2] + Jl[11] - xt[2];
+        const float norm_gx = gx_new[0] * gx_new[0] + gx_new[1] * gx_new[1] + gx_new[2] * gx_new[2];
+        if (norm_gx < cvg_threshold * cvg_threshold) {
+            const bool ok = ix >= -1 && ix <= 1 && iy >= -1 && iy <= 1 && iz >= -1 && iz <= 1;
+            is_valid[index] = ok ? 1 : 0;
+            if (ok) {
+                x[index * 3 + 0] = x_l[0]; x[index * 3 + 1] = x_l[1]; x[index * 3 + 2] = x_l[2];
+                float* Jo = J_inv + index * 9;
+                Jo[0] = J00; Jo[1] = J01; Jo[2] = J02; Jo[3] = J10; Jo[4] = J11; Jo[5] = J12;
+                Jo[6] = J20; Jo[7] = J21; Jo[8] = J22;
+            }
+            return;
+        } else if (norm_gx > dvg_threshold * dvg_threshold) {
+            is_valid[index] = 0;
+            return;
+        }
+        J_inv_update(Ji, u0, u1, u2, gx_new[0] - gx[0], gx_new[1] - gx[1], gx_new[2] - gx[2]);
+    }
+}
+
+// ---- K9 -------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void filter_kernel(int64_t N, int I, const float* __restrict__ x,
+                                                          const uint8_t* __restrict__ mask, uint8_t* __restrict__ out)
+{
+    const int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (p >= N) return;
+    for (int i = 0; i < I; i++) {
+        if (!mask[p * I + i]) { out[p * I + i] = 0; continue; }
+        const float xi0 = x[(p * I + i) * 3 + 0], xi1 = x[(p * I + i) * 3 + 1], xi2 = x[(p * I + i) * 3 + 2];
+        bool flag = true;
+        for (int j = i + 1; j < I; j++) {
+            if (!mask[p * I + j]) continue;
+            const float d0 = xi0 - x[(p * I + j) * 3 + 0];
+            const float d1 = xi1 - x[(p * I + j) * 3 + 1];
+            const float d2 = xi2 - x[(p * I + j) * 3 + 2];
+            const float dist = d0 * d0 + d1 * d1 + d2 * d2;
+            if ((double)dist < 0.0001 * 0.0001) { flag = false; break; }
+        }
+        out[p * I + i] = flag ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+IA_EXPORT int ia_precompute(int B, int D, int H, int W, const float* voxel_w, const float* tfs, const float* offset,
+                            const float* scale, float* voxel_d, float* voxel_J, float* voxel_J_cl, ia_stream_t stream)
+{
+    IA_REQUIRE(B > 0 && D > 1 && H > 1 && W > 1, "bad grid shape");
+    const int64_t vol = (int64_t)D * H * W;
+    dim3 grid(ia::cdiv(vol, THREADS), B);
+    precompute_kernel<<<grid, THREADS, 0, (hipStream_t)stream>>>(B, D, H, W, voxel_w, tfs, offset, scale, voxel_d,
+                                                                 voxel_J, voxel_J_cl);
+    return ia::check_launch("ia_precompute");
+}
+
+IA_EXPORT int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt, const float* voxel_J, int layout, int D,
+                              int H, int W, const float* tfs, const int32_t* bone_ids, const float* offset,
+                              const float* scale, float cvg_threshold, float dvg_threshold, float* x, float* J_inv,
+                              uint8_t* is_valid, ia_stream_t stream)
+{
+    const int64_t total = (int64_t)B * N * I;
+    if (total == 0) return IA_OK;
+    IA_REQUIRE(layout == IA_LAYOUT_NCDHW || layout == IA_LAYOUT_NDHWC, "unknown voxel_J layout");
+    const int grid = ia::cdiv(total, THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    if (layout == IA_LAYOUT_NDHWC)
+        broyden_kernel<IA_LAYOUT_NDHWC><<<grid, THREADS, 0, s>>>(total, N, I, xd_tgt, voxel_J, D, H, W, tfs, bone_ids,
+                                                                 offset, scale, cvg_threshold, dvg_threshold, x, J_inv,
+                                                                 is_valid);
+    else
+        broyden_kernel<IA_LAYOUT_NCDHW><<<grid, THREADS, 0, s>>>(total, N, I, xd_tgt, voxel_J, D, H, W, tfs, bone_ids,
+                                                                 offset, scale, cvg_threshold, dvg_threshold, x, J_inv,
+                                                                 is_valid);
+    return ia::check_launch("ia_fuse_broyden");
+}
+
+IA_EXPORT int ia_filter(int64_t N, int I, const float* x, const uint8_t* mask, uint8_t* out, ia_stream_t stream)
+{
+    if (N == 0) return IA_OK;
+    filter_kernel<<<ia::cdiv(N, THREADS), THREADS, 0, (hipStream_t)stream>>>(N, I, x, mask, out);
+    return ia::check_launch("ia_filter");
+}

@@ -1,0 +1,82 @@
+"""Drop-in for the three fast-SNARF JIT extension modules the reference loads at
+models/deformers/fast_snarf/deformer_torch.py:9-18:
+
+    fuse_kernel.fuse_broyden(...)   -> fuse_cuda_kernel_fast.cu:250-452
+    filter_cuda.filter(...)         -> filter.cu:10-77
+    precompute_cuda.precompute(...) -> precompute.cu:24-103
+
+Same positional signatures (in-place outputs, None return for fuse_broyden / precompute).
+`ChannelLastVoxelJ` is the MI355X-native extension: the channel-last copy of voxel_J that
+`precompute` can emit for free and `fuse_broyden` gathers 4x more efficiently.
+"""
+import torch
+from torch import Tensor
+
+from . import _lib as L
+
+
+class ChannelLastVoxelJ:
+    """[B,D,H,W,12] fp32 view of the Jacobian grid (48 B per voxel)."""
+
+    def __init__(self, data: Tensor):
+        assert data.dim() == 5 and data.shape[-1] == 12
+        self.data = data.contiguous()
+
+
+def precompute(voxel_w: Tensor, tfs: Tensor, voxel_d: Tensor, voxel_J: Tensor, offset: Tensor, scale: Tensor,
+               voxel_J_cl: Tensor = None) -> None:
+    """precompute_cuda.precompute (deformer_torch.py:86-92). voxel_d / voxel_J written in place.
+    Optional extension: voxel_J_cl [B,D,H,W,12] also written (channel-last copy)."""
+    B = tfs.shape[0]
+    _, C24, D, H, W = voxel_w.shape
+    assert C24 == 24 and tfs.shape[1:] == (24, 4, 4)
+    voxel_w, tfs = voxel_w.contiguous().float(), tfs.contiguous().float()
+    off, sc = offset.reshape(3).contiguous().float(), scale.reshape(3).contiguous().float()
+    for t in (voxel_d, voxel_J, voxel_J_cl):
+        if t is not None and (not t.is_contiguous() or t.dtype != torch.float32):
+            raise RuntimeError("output grids must be contiguous float32")
+    L.check(L.lib().ia_precompute(L.i32(B), L.i32(D), L.i32(H), L.i32(W), L.ptr(voxel_w), L.ptr(tfs), L.ptr(off),
+                                  L.ptr(sc), L.ptr(voxel_d), L.ptr(voxel_J), L.ptr(voxel_J_cl), L.stream()),
+            "ia_precompute")
+
+
+def fuse_broyden(x: Tensor, xd_tgt: Tensor, voxel: Tensor, voxel_J, tfs: Tensor, bone_ids: Tensor,
+                 align_corners: bool, J_inv: Tensor, is_valid: Tensor, offset: Tensor, scale: Tensor,
+                 cvg_threshold: float, dvg_threshold: float) -> None:
+    """fuse_kernel.fuse_broyden (deformer_torch.py:109-121). x, J_inv, is_valid are caller-zeroed
+    in/out tensors. `voxel` (voxel_d) and `align_corners` are accepted and ignored, exactly like
+    the reference kernel. voxel_J: Tensor [B,12,D,H,W] or ChannelLastVoxelJ."""
+    B, N, _ = xd_tgt.shape
+    I = bone_ids.shape[0]
+    if isinstance(voxel_J, ChannelLastVoxelJ):
+        vj, layout = voxel_J.data, 1
+        _, D, H, W, _ = vj.shape
+    else:
+        vj, layout = voxel_J.contiguous(), 0
+        _, _, D, H, W = vj.shape
+    for t in (x, J_inv, is_valid):
+        if not t.is_contiguous():
+            raise RuntimeError("outputs must be contiguous")
+    if x.shape != (B, N, I, 3) or J_inv.shape != (B, N, I, 3, 3) or is_valid.shape != (B, N, I):
+        raise RuntimeError("output shapes must be x[B,N,I,3], J_inv[B,N,I,3,3], is_valid[B,N,I]")
+    xd = xd_tgt.contiguous().float()
+    tfs = tfs.contiguous().float()
+    bones = bone_ids.contiguous().to(torch.int32)
+    off, sc = offset.reshape(3).contiguous().float(), scale.reshape(3).contiguous().float()
+    L.check(L.lib().ia_fuse_broyden(L.i32(B), L.i64(N), L.i32(I), L.ptr(xd), L.ptr(vj), L.i32(layout), L.i32(D),
+                                    L.i32(H), L.i32(W), L.ptr(tfs), L.ptr(bones), L.ptr(off), L.ptr(sc),
+                                    L.f32(cvg_threshold), L.f32(dvg_threshold), L.ptr(x), L.ptr(J_inv),
+                                    L.ptr(is_valid), L.stream()), "ia_fuse_broyden")
+
+
+def filter(x: Tensor, mask: Tensor) -> Tensor:
+    """filter_cuda.filter (deformer_torch.py:122, filter.cpp:12-18): drop candidate i if a later valid
+    candidate j lies within 1e-4 (keeps the last of a cluster). B must be 1 (filter.cu:21-22)."""
+    B, N, I = mask.shape
+    if B != 1:
+        raise NotImplementedError("filter: B == 1 only (the reference's index math is only valid for B == 1)")
+    x = x.contiguous().float()
+    mask = mask.contiguous()
+    out = torch.empty_like(mask)
+    L.check(L.lib().ia_filter(L.i64(N), L.i32(I), L.ptr(x), L.ptr(mask), L.ptr(out), L.stream()), "ia_filter")
+    return out

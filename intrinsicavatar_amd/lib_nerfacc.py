@@ -1,0 +1,216 @@
+"""Drop-in for the reference's customised `lib.nerfacc` package (lib/nerfacc/__init__.py:5-23):
+
+    ray_resampling, ray_resampling_merge, ray_resampling_fine, ray_resampling_sdf_fine,
+    pack_info, pack_data, unpack_info, unpack_data
+
+Signatures, dtypes, shapes and zero/-1 initialisation of outputs follow lib/nerfacc/cdf.py,
+lib/nerfacc/pack.py and the host launchers in lib/nerfacc/cuda/csrc/{cdf,pack}.cu.
+Compute is libia_amd.so (HIP, gfx950).
+"""
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+
+
+def _i32c(t: Tensor) -> Tensor:
+    if t.dim() != 2 or t.shape[-1] != 2:
+        raise RuntimeError("packed_info must be a 2D tensor with shape (n_rays, 2)")
+    return t.to(torch.int32).contiguous()
+
+
+def _resample_info(packed_info: Tensor, n: int, add_steps: bool) -> Tuple[Tensor, int]:
+    n_rays = packed_info.shape[0]
+    dev = packed_info.device
+    rpi = torch.empty((n_rays, 2), dtype=torch.int32, device=dev)
+    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    tmp = L.scan_tmp(n_rays, dev, extra_bytes=8 * n_rays + 64)
+    L.check(L.lib().ia_resample_packed_info(L.i64(n_rays), L.ptr(packed_info), L.i32(n), L.i32(int(add_steps)),
+                                            L.ptr(rpi), L.ptr(total), L.ptr(tmp), L.stream()),
+            "ia_resample_packed_info")
+    return rpi, int(total.item())     # the .item() of cdf.cu:183
+
+
+def _f32v(t: Tensor, n: Optional[int] = None) -> Tensor:
+    return t.contiguous().float()
+
+
+# ----------------------------------------------------------------------------- K1
+@torch.no_grad()
+def ray_resampling(packed_info: Tensor, t_starts: Tensor, t_ends: Tensor, weights: Tensor, sdfs: Tensor,
+                   n_samples: int):
+    """lib/nerfacc/cdf.py:13-76 -> cdf.cu:10-215."""
+    assert n_samples > 1  # the kernel does not handle n_samples == 1 (cdf.py:49)
+    packed_info = _i32c(packed_info)
+    if t_starts.dim() != 2 or t_starts.shape[1] != 1 or t_ends.dim() != 2 or t_ends.shape[1] != 1:
+        raise RuntimeError("starts/ends must have shape (n_samples_in, 1)")
+    if weights.dim() != 1:
+        raise RuntimeError("weights must be 1D")
+    st, en, w, sd = _f32v(t_starts), _f32v(t_ends), _f32v(weights), _f32v(sdfs)
+    n_rays, dev = packed_info.shape[0], packed_info.device
+    rpi, T = _resample_info(packed_info, n_samples, False)
+    ts = torch.empty((T, 1), dtype=torch.float32, device=dev)
+    offs = torch.empty((T, 1), dtype=torch.float32, device=dev)
+    idxs = torch.empty((T,), dtype=torch.int64, device=dev)
+    surface_idx = -torch.ones((n_rays,), dtype=torch.int64, device=dev)
+    fg = torch.zeros((w.shape[0],), dtype=torch.int32, device=dev)
+    bg = torch.zeros((n_rays,), dtype=torch.int32, device=dev)
+    L.check(L.lib().ia_ray_resampling(L.i64(n_rays), L.ptr(packed_info), L.ptr(st), L.ptr(en), L.ptr(w), L.ptr(sd),
+                                      L.ptr(rpi), L.ptr(ts), L.ptr(offs), L.ptr(surface_idx), L.ptr(idxs), L.ptr(fg),
+                                      L.ptr(bg), L.stream()), "ia_ray_resampling")
+    return rpi, ts, offs, idxs, fg, bg, surface_idx
+
+
+# ----------------------------------------------------------------------------- K2
+@torch.no_grad()
+def ray_resampling_merge(packed_info: Tensor, vals: Tensor, is_left: Tensor, is_right: Tensor, weights: Tensor,
+                         n_samples: int):
+    """lib/nerfacc/cdf.py:79-141 -> cdf.cu:217-401."""
+    packed_info = _i32c(packed_info)
+    for t in (vals, is_left, is_right, weights):
+        if t.dim() != 1:
+            raise RuntimeError("vals/is_left/is_right/weights must be 1D")
+    vals, w = _f32v(vals), _f32v(weights)
+    il, ir = is_left.contiguous(), is_right.contiguous()
+    if il.dtype != torch.bool or ir.dtype != torch.bool:
+        raise RuntimeError("is_left/is_right must be bool")
+    n_rays, dev = packed_info.shape[0], packed_info.device
+    rpi, T = _resample_info(packed_info, n_samples, True)
+    f = torch.zeros((2, T), dtype=torch.float32, device=dev)
+    b = torch.zeros((4, T), dtype=torch.bool, device=dev)
+    L.check(L.lib().ia_ray_resampling_merge(L.i64(n_rays), L.ptr(packed_info), L.ptr(vals), L.ptr(il), L.ptr(ir),
+                                            L.ptr(w), L.ptr(rpi), L.ptr(f[0]), L.ptr(f[1]), L.ptr(b[0]), L.ptr(b[1]),
+                                            L.ptr(b[2]), L.ptr(b[3]), L.stream()), "ia_ray_resampling_merge")
+    # (resampled_packed_info, vals, dists, is_left, is_right, is_resampled, is_fg_sample)
+    return rpi, f[0], f[1], b[0], b[1], b[2], b[3]
+
+
+# ----------------------------------------------------------------------------- K3 / K4
+def _fine(packed_info, t_starts, t_ends, wa, sdfs, n_samples, sdf_mode):
+    packed_info = _i32c(packed_info)
+    if t_starts.dim() != 2 or t_starts.shape[1] != 1 or t_ends.dim() != 2 or t_ends.shape[1] != 1:
+        raise RuntimeError("starts/ends must have shape (n_samples_in, 1)")
+    if wa.dim() != 1:
+        raise RuntimeError("weights/alphas must be 1D")
+    st, en, wa = _f32v(t_starts), _f32v(t_ends), _f32v(wa)
+    n_rays, dev = packed_info.shape[0], packed_info.device
+    rpi, T = _resample_info(packed_info, n_samples, False)
+    rs = torch.zeros((T, 1), dtype=torch.float32, device=dev)
+    re = torch.zeros((T, 1), dtype=torch.float32, device=dev)
+    fg = torch.zeros((T,), dtype=torch.bool, device=dev)
+    if sdf_mode:
+        sd = _f32v(sdfs)
+        L.check(L.lib().ia_ray_resampling_sdf_fine(L.i64(n_rays), L.ptr(packed_info), L.ptr(st), L.ptr(en), L.ptr(wa),
+                                                   L.ptr(sd), L.ptr(rpi), L.ptr(rs), L.ptr(re), L.ptr(fg), L.stream()),
+                "ia_ray_resampling_sdf_fine")
+    else:
+        L.check(L.lib().ia_ray_resampling_fine(L.i64(n_rays), L.ptr(packed_info), L.ptr(st), L.ptr(en), L.ptr(wa),
+                                               L.ptr(rpi), L.ptr(rs), L.ptr(re), L.ptr(fg), L.stream()),
+                "ia_ray_resampling_fine")
+    return rpi, rs, re, fg
+
+
+@torch.no_grad()
+def ray_resampling_fine(packed_info, t_starts, t_ends, weights, n_samples):
+    """lib/nerfacc/cdf.py:198-244 -> cdf.cu:403-534."""
+    return _fine(packed_info, t_starts, t_ends, weights, None, n_samples, False)
+
+
+@torch.no_grad()
+def ray_resampling_sdf_fine(packed_info, t_starts, t_ends, alphas, sdfs, n_samples):
+    """lib/nerfacc/cdf.py:144-195 -> cdf.cu:536-696."""
+    return _fine(packed_info, t_starts, t_ends, alphas, sdfs, n_samples, True)
+
+
+# ----------------------------------------------------------------------------- pack / unpack
+def pack_data(data: Tensor, mask: Tensor) -> Tuple[Tensor, Tensor]:
+    """lib/nerfacc/pack.py:12-43 (host-side torch ops in the reference too)."""
+    assert data.dim() == 3, "data must be with shape of (n_rays, n_samples, D)."
+    assert mask.shape == data.shape[:2], "mask must be with shape of (n_rays, n_samples)."
+    assert mask.dtype == torch.bool, "mask must be a boolean tensor."
+    packed_data = data[mask]
+    num_steps = mask.sum(dim=-1, dtype=torch.int32)
+    cum_steps = num_steps.cumsum(dim=0, dtype=torch.int32)
+    packed_info = torch.stack([cum_steps - num_steps, num_steps], dim=-1)
+    return packed_data, packed_info
+
+
+@torch.no_grad()
+def pack_info(ray_indices: Tensor, n_rays: int = None) -> Tensor:
+    """lib/nerfacc/pack.py:46-77: ray_indices (int64, [N]) -> packed_info (int32, [n_rays, 2])."""
+    assert ray_indices.dim() == 1, "ray_indices must be a 1D tensor with shape (n_samples)."
+    if not ray_indices.is_cuda:
+        raise NotImplementedError("Only support cuda inputs.")
+    if n_rays is None:
+        n_rays = int(ray_indices.max()) + 1
+    ray_indices = ray_indices.contiguous().to(torch.int64)
+    dev = ray_indices.device
+    out = torch.empty((n_rays, 2), dtype=torch.int32, device=dev)
+    tmp = L.scan_tmp(n_rays, dev, extra_bytes=8 * n_rays + 64)
+    L.check(L.lib().ia_pack_info(L.i64(ray_indices.shape[0]), L.ptr(ray_indices), L.i64(n_rays), L.ptr(out),
+                                 L.ptr(tmp), L.stream()), "ia_pack_info")
+    return out
+
+
+@torch.no_grad()
+def unpack_info(packed_info: Tensor, n_samples: int) -> Tensor:
+    """lib/nerfacc/pack.py:80-121 -> pack.cu:7-28,84-102."""
+    assert packed_info.dim() == 2 and packed_info.shape[-1] == 2, \
+        "packed_info must be a 2D tensor with shape (n_rays, 2)."
+    if not packed_info.is_cuda:
+        raise NotImplementedError("Only support cuda inputs.")
+    packed_info = _i32c(packed_info)
+    out = torch.empty((n_samples,), dtype=torch.int64, device=packed_info.device)
+    L.check(L.lib().ia_unpack_info(L.i64(packed_info.shape[0]), L.ptr(packed_info), L.ptr(out), L.stream()),
+            "ia_unpack_info")
+    return out
+
+
+def _unpack_info_to_mask(packed_info: Tensor, n_samples: int) -> Tensor:
+    masks = torch.zeros((packed_info.shape[0], n_samples), dtype=torch.bool, device=packed_info.device)
+    L.check(L.lib().ia_unpack_info_to_mask(L.i64(packed_info.shape[0]), L.ptr(packed_info), L.i32(n_samples),
+                                           L.ptr(masks), L.stream()), "ia_unpack_info_to_mask")
+    return masks
+
+
+class _UnpackData(torch.autograd.Function):
+    """lib/nerfacc/pack.py:170-190."""
+
+    @staticmethod
+    def forward(ctx, packed_info: Tensor, data: Tensor, n_samples: int):
+        packed_info = _i32c(packed_info)
+        orig_dtype = data.dtype
+        data = data.contiguous()
+        if ctx.needs_input_grad[1]:
+            ctx.save_for_backward(packed_info)
+            ctx.n_samples = n_samples
+        # the kernel moves 4-byte words; int64 payloads (the spp shuffle indices,
+        # intrinsic_avatar.py:1368-1377) go through as two words per element
+        if data.dtype in (torch.float32, torch.int32):
+            words, dim = data.view(torch.float32) if data.dtype == torch.int32 else data, data.shape[1]
+        elif data.dtype in (torch.int64, torch.float64):
+            words, dim = data.view(torch.float32), data.shape[1] * 2
+        else:
+            raise NotImplementedError(f"unpack_data: dtype {data.dtype}")
+        out = torch.zeros((packed_info.shape[0], n_samples, dim), dtype=torch.float32, device=data.device)
+        L.check(L.lib().ia_unpack_data(L.i64(packed_info.shape[0]), L.ptr(packed_info), L.i32(dim), L.ptr(words),
+                                       L.i32(n_samples), L.ptr(out), L.stream()), "ia_unpack_data")
+        return out.view(orig_dtype)
+
+    @staticmethod
+    def backward(ctx, grad: Tensor):
+        packed_info = ctx.saved_tensors[0]
+        mask = _unpack_info_to_mask(packed_info, ctx.n_samples)
+        return None, grad[mask].contiguous(), None
+
+
+def unpack_data(packed_info: Tensor, data: Tensor, n_samples: Optional[int] = None) -> Tensor:
+    """lib/nerfacc/pack.py:124-167."""
+    assert packed_info.dim() == 2 and packed_info.shape[-1] == 2, \
+        "packed_info must be a 2D tensor with shape (n_rays, 2)."
+    assert data.dim() == 2, "data must be a 2D tensor with shape (n_samples, D)."
+    if n_samples is None:
+        n_samples = packed_info[:, 1].max().item()
+    return _UnpackData.apply(packed_info, data, n_samples)

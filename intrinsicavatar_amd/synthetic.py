@@ -1,0 +1,173 @@
+"""Synthetic inputs for tests and bench: no dataset, checkpoint, SMPL .pkl or HDRI
+is available, so rays, a 24-bone rig, skinning-weight grids and occupancy grids are generated here
+(numpy, host side, seeded) with the shapes and magnitudes of the reference's PeopleSnapshot /
+animation configs:
+
+  * camera: K of load/animation/aist/cameras.npz (1080x1080) / downscale, identity extrinsic,
+    subject translated to (0, 0.15, 5) (datasets/animation.py:19-27,129-130);
+  * rays in SMPL space = transform_rays_w2s (models/deformers/snarf_deformer.py:128-147);
+  * scene AABB = cube around the posed body x1.2 (snarf_deformer.py:24-35);
+  * 64^3 occupancy grid of a union-of-capsules stick figure on the SMPL kinematic tree
+    (models/pose/pose_encoder.py:30-56).
+"""
+import numpy as np
+
+# rough SMPL rest-pose joints (metres, pelvis at origin, y up)
+JOINTS = np.array([
+    [0.00, 0.00, 0.00], [0.07, -0.09, 0.00], [-0.07, -0.09, 0.00], [0.00, 0.11, -0.02],
+    [0.10, -0.47, 0.00], [-0.10, -0.47, 0.00], [0.00, 0.25, -0.01], [0.09, -0.87, -0.03],
+    [-0.09, -0.87, -0.03], [0.00, 0.30, 0.00], [0.11, -0.93, 0.09], [-0.11, -0.93, 0.09],
+    [0.00, 0.52, -0.03], [0.08, 0.43, -0.02], [-0.08, 0.43, -0.02], [0.00, 0.60, 0.01],
+    [0.17, 0.45, -0.02], [-0.17, 0.45, -0.02], [0.43, 0.44, -0.04], [-0.43, 0.44, -0.04],
+    [0.68, 0.44, -0.04], [-0.68, 0.44, -0.04], [0.77, 0.43, -0.05], [-0.77, 0.43, -0.05]], np.float32)
+PARENTS = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21])
+RADII = np.array([0.12, 0.09, 0.09, 0.13, 0.07, 0.07, 0.14, 0.05, 0.05, 0.14, 0.04, 0.04, 0.06, 0.08, 0.08, 0.10,
+                  0.06, 0.06, 0.045, 0.045, 0.04, 0.04, 0.035, 0.035], np.float32)
+INIT_BONES = np.array([0, 1, 2, 4, 5, 10, 11, 12, 15, 16, 17, 18, 19], np.int32)   # deformer_torch.py:27
+
+K_1080 = np.array([[2664.23, 0, 511.78], [0, 2664.69, 567.13], [0, 0, 1]], np.float64)
+
+
+def rodrigues(rv):
+    th = np.linalg.norm(rv)
+    if th < 1e-8:
+        return np.eye(3)
+    k = rv / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def forward_kinematics(pose72, joints=JOINTS):
+    """SMPL-style FK: pose [72] axis-angle -> A [24,4,4] (rest -> posed bone transforms)."""
+    G = np.zeros((24, 4, 4))
+    for j in range(24):
+        R = rodrigues(pose72[3 * j:3 * j + 3])
+        T = np.eye(4)
+        T[:3, :3] = R
+        T[:3, 3] = joints[j] - (joints[PARENTS[j]] if PARENTS[j] >= 0 else 0)
+        G[j] = T if PARENTS[j] < 0 else G[PARENTS[j]] @ T
+    A = G.copy()
+    for j in range(24):
+        A[j, :3, 3] = G[j, :3, 3] - G[j, :3, :3] @ joints[j]
+    return A
+
+
+def make_pose(seed=0, amplitude=0.25):
+    rng = np.random.default_rng(seed)
+    pose = rng.normal(0, amplitude, 72)
+    pose[:3] = [np.pi, 0, 0]               # global orient: SMPL y-up -> camera y-down
+    pose[3 * 16 + 2] -= 0.9                # arms down a bit
+    pose[3 * 17 + 2] += 0.9
+    return pose.astype(np.float64)
+
+
+def make_rig(pose72=None, transl=(0.0, 0.15, 5.0)):
+    """returns dict(tfs [1,24,4,4] (w2s @ A, root = identity), w2s [4,4], joints_posed [24,3] in SMPL space)."""
+    if pose72 is None:
+        pose72 = np.zeros(72)
+        pose72[:3] = [np.pi, 0, 0]
+    A = forward_kinematics(pose72)
+    A[:, :3, 3] += np.asarray(transl)[None]
+    s2w = A[0]
+    w2s = np.linalg.inv(s2w)
+    tfs = (w2s[None] @ A).astype(np.float32)[None]
+    jp = (np.einsum("jab,jb->ja", tfs[0, :, :3, :3], JOINTS) + tfs[0, :, :3, 3]).astype(np.float32)
+    return dict(tfs=tfs, w2s=w2s.astype(np.float32), joints_posed=jp)
+
+
+def camera_rays(height, width, downscale_from_1080=None):
+    """datasets/animation.py:14-27 with identity c2w. returns rays [H*W, 8] in WORLD space (o, d, near, far)."""
+    ds = downscale_from_1080 if downscale_from_1080 is not None else 1080.0 / height
+    K = K_1080.copy()
+    K[:2] /= ds
+    x, y = np.meshgrid(np.arange(width), np.arange(height), indexing="xy")
+    xy = np.stack([x, y, np.ones_like(x)], -1).reshape(-1, 3).astype(np.float32)
+    d = xy @ np.linalg.inv(K).T
+    d = d / np.linalg.norm(d, axis=1, keepdims=True)
+    o = np.zeros_like(d)
+    near = np.zeros((d.shape[0], 1))
+    far = np.zeros((d.shape[0], 1))
+    return np.concatenate([o, d, near, far], -1).astype(np.float32)
+
+
+def rays_world_to_smpl(rays, w2s):
+    """snarf_deformer.py:128-147 transform_rays_w2s."""
+    o = rays[:, :3] @ w2s[:3, :3].T + w2s[None, :3, 3]
+    d = rays[:, 3:6] @ w2s[:3, :3].T
+    dist = np.linalg.norm(o, axis=-1, keepdims=True)
+    return np.concatenate([o, d, dist - 1, dist + 1], -1).astype(np.float32)
+
+
+def capsule_sdf(p, joints_posed):
+    """union-of-capsules SDF of the stick figure at points p [N,3] (SMPL space)."""
+    best = np.full(p.shape[0], 1e9, np.float32)
+    for j in range(1, 24):
+        a, b = joints_posed[PARENTS[j]], joints_posed[j]
+        ra, rb = RADII[PARENTS[j]], RADII[j]
+        ab = b - a
+        t = np.clip(((p - a) @ ab) / max(float(ab @ ab), 1e-12), 0, 1)
+        c = a[None] + t[:, None] * ab[None]
+        r = ra + (rb - ra) * t
+        best = np.minimum(best, np.linalg.norm(p - c, axis=1) - r)
+    return best
+
+
+def body_aabb(joints_posed, factor=1.2):
+    """get_bbox_from_smpl (snarf_deformer.py:24-35) on joints +- radii."""
+    lo = (joints_posed - RADII[:, None]).min(0)
+    hi = (joints_posed + RADII[:, None]).max(0)
+    c = (hi + lo) / 2
+    s = ((hi - lo) / 2).max() * factor
+    return np.concatenate([c - s, c + s]).astype(np.float32)
+
+
+def occupancy_grid(joints_posed, aabb, res=64, margin=0.02):
+    """bool [res,res,res]; cell (x,y,z) occupied if the capsule body comes within half a cell diagonal."""
+    cs = (aabb[3:] - aabb[:3]) / res
+    g = (np.arange(res) + 0.5)
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    p = np.stack([X, Y, Z], -1).reshape(-1, 3).astype(np.float32) * cs[None] + aabb[None, :3]
+    sd = capsule_sdf(p, joints_posed)
+    return (sd < 0.5 * np.linalg.norm(cs) + margin).reshape(res, res, res)
+
+
+def skinning_weight_grid(D=32, H=128, W=128, global_scale=1.2, smooth_iters=30, sigma=0.08):
+    """[1,24,D,H,W] canonical skinning weights + (offset_kernel [1,1,3], scale_kernel [1,1,3]) following
+    ForwardDeformer.switch_to_explicit (deformer_torch.py:139-197) on the rest-pose stick figure."""
+    import torch
+    verts_lo = (JOINTS - RADII[:, None]).min(0)
+    verts_hi = (JOINTS + RADII[:, None]).max(0)
+    offset = (verts_lo + verts_hi) * 0.5
+    scale = (verts_hi - verts_lo).max() / 2 * global_scale
+    ratio = H / D
+    zz, yy, xx = np.meshgrid(np.linspace(-1, 1, D), np.linspace(-1, 1, H), np.linspace(-1, 1, W), indexing="ij")
+    grid = np.stack([xx, yy, zz / ratio], -1).reshape(-1, 3).astype(np.float32) * scale + offset[None]
+    d2 = np.zeros((24, grid.shape[0]), np.float32)
+    for j in range(24):
+        a = JOINTS[PARENTS[j]] if PARENTS[j] >= 0 else JOINTS[j]
+        b = JOINTS[j]
+        ab = b - a
+        t = np.clip(((grid - a) @ ab) / max(float(ab @ ab), 1e-12), 0, 1)
+        d2[j] = ((grid - (a[None] + t[:, None] * ab[None])) ** 2).sum(1)
+    w = np.exp(-(d2 - d2.min(0, keepdims=True)) / (2 * sigma * sigma))
+    w /= w.sum(0, keepdims=True)
+    weights = torch.from_numpy(w.reshape(1, 24, D, H, W).astype(np.float32))
+    for _ in range(smooth_iters):      # deformer_torch.py:246-252
+        mean = (weights[:, :, 2:, 1:-1, 1:-1] + weights[:, :, :-2, 1:-1, 1:-1] + weights[:, :, 1:-1, 2:, 1:-1]
+                + weights[:, :, 1:-1, :-2, 1:-1] + weights[:, :, 1:-1, 1:-1, 2:] + weights[:, :, 1:-1, 1:-1, :-2]) / 6.0
+        weights[:, :, 1:-1, 1:-1, 1:-1] = (weights[:, :, 1:-1, 1:-1, 1:-1] - mean) * 0.7 + mean
+        weights = weights / weights.sum(1, keepdim=True)
+    offset_kernel = (-offset).reshape(1, 1, 3).astype(np.float32)
+    scale_kernel = np.full((1, 1, 3), 1.0 / scale, np.float32)
+    scale_kernel[..., 2] *= ratio
+    bbox = np.stack([offset - scale * np.array([1, 1, 1 / ratio]), offset + scale * np.array([1, 1, 1 / ratio])])
+    return weights.numpy(), offset_kernel, scale_kernel, bbox.astype(np.float32)
+
+
+def make_scene(height=128, width=128, pose_seed=0, res=64):
+    """everything traverse_grids needs for one frame."""
+    rig = make_rig(make_pose(pose_seed))
+    rays = rays_world_to_smpl(camera_rays(height, width), rig["w2s"])
+    aabb = body_aabb(rig["joints_posed"])
+    occ = occupancy_grid(rig["joints_posed"], aabb, res)
+    return dict(rays=rays, aabb=aabb, binaries=occ, rig=rig)

@@ -1,0 +1,57 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/ia_amd.h declares.
+(No compute calls here -- there is no GPU in the build container.)"""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def so_path():
+    from intrinsicavatar_amd import build
+    return build.build()
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "ia_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(ia_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_exported(so_path):
+    lib = ctypes.CDLL(so_path)
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, f"declared in include/ia_amd.h but not exported: {missing}"
+
+
+def test_version_and_error_string(so_path):
+    lib = ctypes.CDLL(so_path)
+    lib.ia_last_error.restype = ctypes.c_char_p
+    assert lib.ia_version() >= 100
+    assert isinstance(lib.ia_last_error(), bytes)
+    lib.ia_scan_tmp_bytes.restype = ctypes.c_int64
+    assert lib.ia_scan_tmp_bytes(ctypes.c_int64(10_000_000)) > 8 * 10_000_000 // 1024
+
+
+def test_no_cpu_fallback():
+    """the product path must fail loudly on CPU tensors instead of silently falling back."""
+    import torch
+    from intrinsicavatar_amd import lib_nerfacc, _lib
+    with pytest.raises((NotImplementedError, _lib.IaError)):
+        lib_nerfacc.unpack_info(torch.zeros((4, 2), dtype=torch.int32), 0)
+    with pytest.raises((NotImplementedError, _lib.IaError)):
+        lib_nerfacc.pack_info(torch.zeros(4, dtype=torch.int64), 2)
+
+
+def test_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "intrinsicavatar_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "libia_oracle" not in src, f

@@ -1,0 +1,320 @@
+"""GPU (MI355X): the HIP path, called through the C ABI (libia_amd.so via ctypes), against
+ (a) the CPU oracle on the same seeded inputs and (b) the committed golden vectors of the reference.
+
+Bit-exact for every integer / bool / index output AND for the float outputs of K1..K10 and
+traverse_grids (identical IEEE op order, no fma contraction on either side)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    from intrinsicavatar_amd import build
+    build.build()
+    from intrinsicavatar_amd import nerfacc, lib_nerfacc, fast_snarf
+    return dict(nerfacc=nerfacc, lib=lib_nerfacc, snarf=fast_snarf)
+
+
+# ----------------------------------------------------------------------------- traverse_grids
+@pytest.mark.parametrize("hw,seed,step", [(128, 0, 4.3301 / 64), (96, 3, 0.0338), (64, 5, 0.011)])
+def test_traverse_grids_vs_oracle(ops, oracle, hw, seed, step):
+    from intrinsicavatar_amd import synthetic as S
+    sc = S.make_scene(hw, hw, pose_seed=seed)
+    rays = sc["rays"]
+    n = rays.shape[0]
+    rng = np.random.default_rng(seed)
+    near = np.zeros(n, np.float32)
+    far = np.full(n, 1e10, np.float32)
+    if seed == 3:       # stratified jitter (temporal_occ_grid.py:162-163) and a far clip
+        near = (rng.random(n) * step).astype(np.float32)
+        far = np.full(n, 5.6, np.float32)
+    ref = oracle.traverse_grids(rays[:, :3], rays[:, 3:6], sc["binaries"], sc["aabb"], near, far, step)
+    iv, sm, term = ops["nerfacc"].traverse_grids(
+        T(rays[:, :3]), T(rays[:, 3:6]), T(sc["binaries"])[None], T(sc["aabb"])[None],
+        near_planes=T(near), far_planes=T(far), step_size=step, cone_angle=0.0)
+    assert ref["samples"]["vals"].shape[0] > 1000
+    np.testing.assert_array_equal(N(iv.packed_info), ref["intervals"]["packed_info"])
+    np.testing.assert_array_equal(N(sm.packed_info), ref["samples"]["packed_info"])
+    np.testing.assert_array_equal(N(iv.ray_indices), ref["intervals"]["ray_indices"])
+    np.testing.assert_array_equal(N(iv.is_left), ref["intervals"]["is_left"])
+    np.testing.assert_array_equal(N(iv.is_right), ref["intervals"]["is_right"])
+    np.testing.assert_array_equal(N(sm.ray_indices), ref["samples"]["ray_indices"])
+    np.testing.assert_array_equal(N(iv.vals), ref["intervals"]["vals"])      # bit-exact t values
+    np.testing.assert_array_equal(N(sm.vals), ref["samples"]["vals"])
+    np.testing.assert_array_equal(N(term), ref["termination_planes"])
+
+
+def test_traverse_grids_edge_cases(ops, oracle):
+    """empty grid, full grid, rays missing the box, rays starting inside, axis-parallel rays, zero rays."""
+    rng = np.random.default_rng(1)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    n = 4096
+    o = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o[:256] = rng.uniform(-0.9, 0.9, (256, 3))                 # inside the box
+    d[256:512] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 256)] * rng.choice([-1, 1], (256, 1))   # axis-parallel
+    near = np.zeros(n, np.float32)
+    far = np.full(n, 1e10, np.float32)
+    for name, grid in (("empty", np.zeros((16, 16, 16), bool)), ("full", np.ones((16, 16, 16), bool)),
+                       ("random", rng.random((16, 24, 8)) < 0.3)):
+        ref = oracle.traverse_grids(o, d, grid, aabb, near, far, 0.05)
+        iv, sm, term = ops["nerfacc"].traverse_grids(T(o), T(d), T(grid)[None], T(aabb)[None], T(near), T(far), 0.05, 0.0)
+        np.testing.assert_array_equal(N(iv.packed_info), ref["intervals"]["packed_info"], err_msg=name)
+        np.testing.assert_array_equal(N(iv.vals), ref["intervals"]["vals"], err_msg=name)
+        np.testing.assert_array_equal(N(iv.is_left), ref["intervals"]["is_left"], err_msg=name)
+        np.testing.assert_array_equal(N(sm.vals), ref["samples"]["vals"], err_msg=name)
+        if name == "empty":
+            assert iv.vals.numel() == 0 and sm.vals.numel() == 0
+    iv, sm, term = ops["nerfacc"].traverse_grids(T(o[:0]), T(d[:0]), T(np.ones((8, 8, 8), bool))[None], T(aabb)[None],
+                                                 T(near[:0]), T(far[:0]), 0.05, 0.0)
+    assert iv.vals.numel() == 0 and iv.packed_info.shape == (0, 2)
+
+
+def test_traverse_properties_full_size(ops):
+    """540x540 (BASELINE config 2) -- size-independent properties instead of the (slow) oracle."""
+    from intrinsicavatar_amd import synthetic as S
+    sc = S.make_scene(540, 540, pose_seed=0)
+    rays = sc["rays"]
+    n = rays.shape[0]
+    step = 4.3301 / 128
+    iv, sm, term = ops["nerfacc"].traverse_grids(
+        T(rays[:, :3]), T(rays[:, 3:6]), T(sc["binaries"])[None], T(sc["aabb"])[None],
+        near_planes=torch.zeros(n, device=DEV), far_planes=torch.full((n,), 1e10, device=DEV), step_size=step)
+    assert n == 291600
+    pi = iv.packed_info
+    assert int(pi[:, 1].sum()) == iv.vals.numel()
+    assert torch.equal(pi[:, 0], torch.cumsum(pi[:, 1], 0) - pi[:, 1])
+    assert int(iv.is_left.sum()) == int(iv.is_right.sum()) == sm.vals.numel()
+    ts, te = iv.vals[iv.is_left], iv.vals[iv.is_right]
+    assert torch.all(te > ts)
+    torch.testing.assert_close(te - ts, torch.full_like(ts, step), rtol=0, atol=2e-6)
+    assert torch.equal((ts + te) * 0.5, sm.vals)
+    # sorted by ray, increasing t within a ray
+    assert torch.all(sm.ray_indices[1:] >= sm.ray_indices[:-1])
+    same = sm.ray_indices[1:] == sm.ray_indices[:-1]
+    assert torch.all(sm.vals[1:][same] > sm.vals[:-1][same])
+    # every sample mid-point lies in an occupied cell of the grid
+    ro, rd = T(rays[:, :3])[sm.ray_indices], T(rays[:, 3:6])[sm.ray_indices]
+    p = ro + rd * sm.vals[:, None]
+    aabb = T(sc["aabb"])
+    cell = ((p - aabb[:3]) / (aabb[3:] - aabb[:3]) * 64).long().clamp(0, 63)
+    occ = T(sc["binaries"])[cell[:, 0], cell[:, 1], cell[:, 2]]
+    assert occ.float().mean() > 0.995      # (mid-points within 1e-6 of a face may round to the neighbour)
+
+
+# ----------------------------------------------------------------------------- compositing
+def _random_packed(rng, n_rays, max_steps):
+    steps = rng.integers(0, max_steps + 1, n_rays)
+    steps[rng.random(n_rays) < 0.3] = 0
+    cum = np.cumsum(steps)
+    return np.stack([cum - steps, steps], -1).astype(np.int32), int(cum[-1])
+
+
+def test_render_weight_and_accumulate_vs_oracle(ops, oracle):
+    rng = np.random.default_rng(7)
+    pi, S_ = _random_packed(rng, 5000, 48)
+    alphas = rng.uniform(0, 0.9, S_).astype(np.float32)
+    alphas[rng.random(S_) < 0.1] = 0.0
+    ray_idx = oracle.unpack_info(pi, S_)
+    w_ref, t_ref = oracle.render_weight_from_alpha(alphas, pi)
+    w, t = ops["nerfacc"].render_weight_from_alpha(T(alphas), ray_indices=T(ray_idx), n_rays=pi.shape[0])
+    np.testing.assert_array_equal(N(w), w_ref)
+    np.testing.assert_array_equal(N(t), t_ref)
+    w2, _ = ops["nerfacc"].render_weight_from_alpha(T(alphas), packed_info=T(pi))
+    np.testing.assert_array_equal(N(w2), w_ref)
+    for dim in (1, 3, 5):
+        vals = rng.normal(size=(S_, dim)).astype(np.float32)
+        ref = oracle.accumulate_along_rays(w_ref, vals, ray_idx, pi.shape[0])
+        out = ops["nerfacc"].accumulate_along_rays(T(w_ref), T(vals), T(ray_idx), pi.shape[0])
+        np.testing.assert_array_equal(N(out), ref)
+    ref = oracle.accumulate_along_rays(w_ref, None, ray_idx, pi.shape[0])
+    out = ops["nerfacc"].accumulate_along_rays(T(w_ref), None, T(ray_idx), pi.shape[0])
+    np.testing.assert_array_equal(N(out), ref)
+
+
+def test_compositing_backward_vs_torch_fp32(ops, oracle):
+    """floating-point kernel => plain torch fp32/fp64 autograd reference (tolerance 1e-5 rel)."""
+    rng = np.random.default_rng(11)
+    pi, S_ = _random_packed(rng, 700, 20)
+    alphas = rng.uniform(0.01, 0.8, S_).astype(np.float32)
+    vals = rng.normal(size=(S_, 3)).astype(np.float32)
+    ray_idx = oracle.unpack_info(pi, S_)
+    a = T(alphas).requires_grad_(True)
+    v = T(vals).requires_grad_(True)
+    w, tr = ops["nerfacc"].render_weight_from_alpha(a, ray_indices=T(ray_idx), n_rays=pi.shape[0])
+    col = ops["nerfacc"].accumulate_along_rays(w, v, T(ray_idx), pi.shape[0])
+    acc = ops["nerfacc"].accumulate_along_rays(w, None, T(ray_idx), pi.shape[0])
+    gcol = T(rng.normal(size=(pi.shape[0], 3)).astype(np.float32))
+    gacc = T(rng.normal(size=(pi.shape[0], 1)).astype(np.float32))
+    gtr = T(rng.normal(size=S_).astype(np.float32))
+    ((col * gcol).sum() + (acc * gacc).sum() + (tr * gtr).sum()).backward()
+    # reference in float64 on CPU
+    a64 = torch.from_numpy(alphas).double().requires_grad_(True)
+    v64 = torch.from_numpy(vals).double().requires_grad_(True)
+    ri = torch.from_numpy(ray_idx)
+    trs = []
+    for b, s in pi:
+        one = torch.ones(1, dtype=torch.float64)
+        trs.append(torch.cat([one, torch.cumprod(1 - a64[b:b + s], 0)[:-1]]) if s > 0 else a64[:0])
+    tr64 = torch.cat(trs)
+    w64 = tr64 * a64
+    col64 = torch.zeros(pi.shape[0], 3, dtype=torch.float64).index_add(0, ri, w64[:, None] * v64)
+    acc64 = torch.zeros(pi.shape[0], 1, dtype=torch.float64).index_add(0, ri, w64[:, None])
+    ((col64 * gcol.cpu().double()).sum() + (acc64 * gacc.cpu().double()).sum() + (tr64 * gtr.cpu().double()).sum()).backward()
+    np.testing.assert_allclose(N(a.grad), a64.grad.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(N(v.grad), v64.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- resampling / pack
+def test_resampling_vs_golden(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "golden_resampling.npz"))
+    lib = ops["lib"]
+    for c in range(int(g["n_cases"])):
+        k = f"c{c}_"
+        pi, st, en = T(g[k + "packed_info"]), T(g[k + "starts"])[:, None], T(g[k + "ends"])[:, None]
+        w, al, sd, n = T(g[k + "weights"]), T(g[k + "alphas"]), T(g[k + "sdfs"]), int(g[k + "n"])
+        r = lib.ray_resampling(pi, st, en, w, sd, n)
+        for nm, v in zip(("rpi", "ts", "offsets", "indices", "fg_counts", "bg_counts", "surface_idx"), r):
+            ref = g[k + "k1_" + nm]
+            assert tuple(v.shape) == ref.shape and N(v).dtype == ref.dtype, (c, nm)
+            np.testing.assert_array_equal(N(v), ref, err_msg=f"K1 case {c} {nm}")
+        r = lib.ray_resampling_fine(pi, st, en, w, n)
+        for nm, v in zip(("rpi", "starts", "ends", "is_fg"), r):
+            np.testing.assert_array_equal(N(v), g[k + "k3_" + nm], err_msg=f"K3 case {c} {nm}")
+        r = lib.ray_resampling_sdf_fine(pi, st, en, al, sd, n)
+        for nm, v in zip(("rpi", "starts", "ends", "is_fg"), r):
+            np.testing.assert_array_equal(N(v), g[k + "k4_" + nm], err_msg=f"K4 case {c} {nm}")
+    for c in range(int(g["n_edge_cases"])):
+        k = f"e{c}_"
+        r = lib.ray_resampling_merge(T(g[k + "packed_info"]), T(g[k + "vals"]), T(g[k + "is_left"]),
+                                     T(g[k + "is_right"]), T(g[k + "weights"]), int(g[k + "n"]))
+        for nm, v in zip(("rpi", "vals", "dists", "is_left", "is_right", "is_resample", "is_fg"), r):
+            np.testing.assert_array_equal(N(v), g[k + "k2_" + nm], err_msg=f"K2 case {c} {nm}")
+
+
+def test_pack_unpack_vs_golden(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "golden_pack.npz"))
+    lib = ops["lib"]
+    pi, data = T(g["packed_info"]), T(g["data"])
+    ri = lib.unpack_info(pi, data.shape[0])
+    np.testing.assert_array_equal(N(ri), g["unpack_info"])
+    np.testing.assert_array_equal(N(lib.pack_info(ri, pi.shape[0])), g["packed_info"])
+    d = data.clone().requires_grad_(True)
+    un = lib.unpack_data(pi, d, 32)
+    np.testing.assert_array_equal(N(un), g["unpack_data"])
+    gr = torch.randn_like(un)
+    (un * gr).sum().backward()
+    np.testing.assert_array_equal(N(d.grad), N(gr)[g["unpack_mask"]])
+    pd, pinfo = lib.pack_data(T(g["pack_data_in"]), T(g["pack_data_mask"]))
+    np.testing.assert_array_equal(N(pd), g["pack_data_out"])
+    np.testing.assert_array_equal(N(pinfo), g["pack_data_info"])
+    # int64 payload (spp shuffle indices, models/intrinsic_avatar.py:1368-1377)
+    idx = torch.arange(data.shape[0], device=DEV)[:, None]
+    un = lib.unpack_data(pi, idx, 32)
+    assert un.dtype == torch.int64
+    ref = g["unpack_mask"]
+    assert torch.equal(un[..., 0][T(ref)], idx[:, 0])
+
+
+def test_resampling_vs_oracle_large(ops, oracle):
+    """bigger, seeded, ragged case against the oracle (n = spp = 256)."""
+    rng = np.random.default_rng(5)
+    pi, S_ = _random_packed(rng, 3000, 64)
+    st = np.zeros(S_, np.float32)
+    en = np.zeros(S_, np.float32)
+    for b, s in pi:
+        if s:
+            dts = rng.uniform(0.005, 0.05, s).astype(np.float32)
+            t = rng.uniform(3, 5) + np.cumsum(dts) - dts
+            st[b:b + s] = t
+            en[b:b + s] = t + dts
+    al = rng.uniform(0, 0.4, S_).astype(np.float32)
+    sd = rng.normal(0.1, 0.2, S_).astype(np.float32)
+    w, _ = oracle.render_weight_from_alpha(al, pi)
+    ref = oracle.ray_resampling(pi, st, en, w, sd, 256)
+    out = ops["lib"].ray_resampling(T(pi), T(st)[:, None], T(en)[:, None], T(w), T(sd), 256)
+    for a, b in zip(out, ref):
+        np.testing.assert_array_equal(N(a), b)
+    ref = oracle.ray_resampling_sdf_fine(pi, st, en, al, sd, 4)
+    out = ops["lib"].ray_resampling_sdf_fine(T(pi), T(st)[:, None], T(en)[:, None], T(al), T(sd), 4)
+    for a, b in zip(out, ref):
+        np.testing.assert_array_equal(N(a), b)
+
+
+# ----------------------------------------------------------------------------- fast-SNARF
+def test_fast_snarf_vs_golden(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "golden_snarf.npz"))
+    sn = ops["snarf"]
+    vw = T(g["voxel_w"].astype(np.float32))
+    tfs, off, sc = T(g["tfs"]), T(g["offset"]), T(g["scale"])
+    _, _, D, H, W = vw.shape
+    vd = torch.zeros(1, 3, D, H, W, device=DEV)
+    vJ = torch.zeros(1, 12, D, H, W, device=DEV)
+    vJcl = torch.zeros(1, D, H, W, 12, device=DEV)
+    sn.precompute(vw, tfs, vd, vJ, off, sc, voxel_J_cl=vJcl)
+    np.testing.assert_array_equal(N(vd), g["voxel_d"])
+    np.testing.assert_array_equal(N(vJ), g["voxel_J"])
+    np.testing.assert_array_equal(N(vJcl.permute(0, 4, 1, 2, 3)), g["voxel_J"])
+    xd, bones = T(g["xd"]), T(g["bones"])
+    n = xd.shape[1]
+    for layout in ("ncdhw", "ndhwc"):
+        x = torch.zeros(1, n, 13, 3, device=DEV)
+        Ji = torch.zeros(1, n, 13, 3, 3, device=DEV)
+        valid = torch.zeros(1, n, 13, dtype=torch.bool, device=DEV)
+        grid = vJ if layout == "ncdhw" else sn.ChannelLastVoxelJ(vJcl)
+        ret = sn.fuse_broyden(x, xd, vd, grid, tfs, bones, True, Ji, valid, off, sc, 1e-5, 1e-1)
+        assert ret is None
+        np.testing.assert_array_equal(N(valid), g["valid"], err_msg=layout)
+        np.testing.assert_array_equal(N(x), g["x"], err_msg=layout)
+        np.testing.assert_array_equal(N(Ji), g["J_inv"], err_msg=layout)
+        np.testing.assert_array_equal(N(sn.filter(x, valid)), g["filtered"], err_msg=layout)
+
+
+def test_fast_snarf_roundtrip_property(ops):
+    """size-independent property at a large N: forward-skinning every valid root lands on the query point."""
+    from intrinsicavatar_amd import synthetic as S
+    sn = ops["snarf"]
+    w, offk, sck, bbox = S.skinning_weight_grid(D=16, H=64, W=64, smooth_iters=5)
+    rig = S.make_rig(S.make_pose(2, 0.2))
+    vw, tfs, off, sc = T(w), T(rig["tfs"]), T(offk), T(sck)
+    _, _, D, H, W = vw.shape
+    vd = torch.zeros(1, 3, D, H, W, device=DEV)
+    vJcl = torch.zeros(1, D, H, W, 12, device=DEV)
+    sn.precompute(vw, tfs, vd, None, off, sc, voxel_J_cl=vJcl)
+    n = 200_000
+    g = torch.Generator(device="cpu").manual_seed(0)
+    lo, hi = torch.from_numpy(S.body_aabb(rig["joints_posed"], 1.0)).split(3)
+    xd = (torch.rand(1, n, 3, generator=g) * (hi - lo) + lo).to(DEV)
+    x = torch.zeros(1, n, 13, 3, device=DEV)
+    Ji = torch.zeros(1, n, 13, 3, 3, device=DEV)
+    valid = torch.zeros(1, n, 13, dtype=torch.bool, device=DEV)
+    sn.fuse_broyden(x, xd, vd, sn.ChannelLastVoxelJ(vJcl), tfs, T(S.INIT_BONES), True, Ji, valid, off, sc, 1e-5, 1e-1)
+    assert 0.02 < valid.float().mean() < 0.98
+    # forward skinning of the roots with torch grid_sample on the channel-first grid
+    xc = x[valid]
+    norm = (xc + off.reshape(1, 3)) * sc.reshape(1, 3)
+    J = torch.nn.functional.grid_sample(vJcl.permute(0, 4, 1, 2, 3), norm[None, :, None, None, :], align_corners=True,
+                                        padding_mode="zeros")[0, :, :, 0, 0].T.reshape(-1, 3, 4)
+    xd_rec = (J[:, :, :3] @ xc[:, :, None])[:, :, 0] + J[:, :, 3]
+    tgt = xd[0][:, None, :].expand(-1, 13, -1)[valid[0]]
+    assert (xd_rec - tgt).norm(dim=-1).max() < 2e-5      # cvg threshold 1e-5 (+ fp32 interpolation noise)
+    mask = sn.filter(x, valid)
+    assert mask.sum() <= valid.sum() and torch.all(valid | ~mask)

@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Per-kernel timing of the hot-path operators at BASELINE config-2 sizes (540x540 frame).
+Used with rocprofv3 to produce the per-round profiles under profiles/."""
+import json
+import sys
+import os
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from intrinsicavatar_amd import build, synthetic as S   # noqa: E402
+
+build.build()
+from intrinsicavatar_amd import nerfacc, lib_nerfacc, fast_snarf, _lib as L   # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3   # us
+
+
+def main():
+    hw = int(os.environ.get("IA_HW", "540"))
+    res = {}
+    sc = S.make_scene(hw, hw, pose_seed=0)
+    rays = torch.from_numpy(sc["rays"]).to(DEV)
+    n = rays.shape[0]
+    ro, rd = rays[:, :3].contiguous(), rays[:, 3:6].contiguous()
+    binaries = torch.from_numpy(sc["binaries"]).to(DEV)[None]
+    aabb = torch.from_numpy(sc["aabb"]).to(DEV)[None]
+    near = torch.zeros(n, device=DEV)
+    far = torch.full((n,), 1e10, device=DEV)
+    step = 4.3301 / 128
+    bits = nerfacc.pack_occupancy_bits(binaries[0])
+    lib, st = L.lib(), L.stream()
+    cnt = torch.empty((2, n), dtype=torch.int64, device=DEV)
+    start = torch.empty((2, n), dtype=torch.int64, device=DEV)
+    tot = torch.zeros(2, dtype=torch.int64, device=DEV)
+    tmp = L.scan_tmp(n, DEV)
+    aabb0 = aabb[0].contiguous()
+
+    def count():
+        L.check(lib.ia_traverse_grids_count(L.i64(n), L.ptr(ro), L.ptr(rd), L.ptr(bits), 64, 64, 64, L.ptr(aabb0),
+                                            L.ptr(near), L.ptr(far), L.f32(step), L.f32(0.0), L.ptr(cnt[0]),
+                                            L.ptr(cnt[1]), st))
+
+    def scan():
+        lib.ia_exclusive_scan_i64(L.ptr(cnt[0]), L.ptr(start[0]), L.ptr(tot[0:1]), L.i64(n), L.ptr(tmp), st)
+        lib.ia_exclusive_scan_i64(L.ptr(cnt[1]), L.ptr(start[1]), L.ptr(tot[1:2]), L.i64(n), L.ptr(tmp), st)
+
+    count(); scan()
+    E, S_ = (int(v) for v in tot.tolist())
+    iv_vals = torch.empty(E, device=DEV)
+    fl = torch.zeros((2, E), dtype=torch.bool, device=DEV)
+    iv_ray = torch.empty(E, dtype=torch.int64, device=DEV)
+    sm_vals = torch.empty(S_, device=DEV)
+    sm_ray = torch.empty(S_, dtype=torch.int64, device=DEV)
+    term = torch.empty(n, device=DEV)
+
+    def fill():
+        L.check(lib.ia_traverse_grids_fill(L.i64(n), L.ptr(ro), L.ptr(rd), L.ptr(bits), 64, 64, 64, L.ptr(aabb0),
+                                           L.ptr(near), L.ptr(far), L.f32(step), L.f32(0.0), L.ptr(start[0]),
+                                           L.ptr(start[1]), L.ptr(iv_vals), L.ptr(fl[0]), L.ptr(fl[1]), L.ptr(iv_ray),
+                                           L.ptr(sm_vals), L.ptr(sm_ray), L.ptr(term), st))
+    t_count, t_scan, t_fill = timeit(count), timeit(scan), timeit(fill)
+    alg_bytes = 48 * n + 16 * S_ + 14 * E
+    res["traverse"] = dict(n_rays=n, E=E, S=S_, count_us=t_count, scan_us=t_scan, fill_us=t_fill,
+                           alg_bytes=alg_bytes, gbps_fill=alg_bytes / t_fill / 1e3,
+                           gbps_total=alg_bytes / (t_count + t_scan + t_fill) / 1e3)
+
+    # ---- K2 merge on the traversal's edge list + T2
+    iv_pi = torch.stack([start[0], cnt[0]], -1).int().contiguous()
+    w_e = torch.rand(E, device=DEV) * 0.1
+    t_k2 = timeit(lambda: lib_nerfacc.ray_resampling_merge(iv_pi, iv_vals, fl[0], fl[1], w_e, 16))
+    res["k2_merge"] = dict(E=E, us=t_k2)
+    al = torch.rand(E, device=DEV) * 0.3
+    wout, tout = torch.empty_like(al), torch.empty_like(al)
+    t_t2 = timeit(lambda: lib.ia_render_weight_from_alpha(L.i64(n), L.ptr(iv_pi), L.ptr(al), L.ptr(wout), L.ptr(tout), st))
+    res["t2_weights"] = dict(E=E, us=t_t2, gbps=E * 12 / t_t2 / 1e3)
+
+    # ---- Broyden on the edge positions
+    w, offk, sck, bbox = S.skinning_weight_grid(D=32, H=128, W=128, smooth_iters=2)
+    vw = torch.from_numpy(w).to(DEV)
+    tfs = torch.from_numpy(sc["rig"]["tfs"]).to(DEV)
+    off, scl = torch.from_numpy(offk).to(DEV), torch.from_numpy(sck).to(DEV)
+    vd = torch.zeros(1, 3, 32, 128, 128, device=DEV)
+    vJ = torch.zeros(1, 12, 32, 128, 128, device=DEV)
+    vJcl = torch.zeros(1, 32, 128, 128, 12, device=DEV)
+    t_pre = timeit(lambda: fast_snarf.precompute(vw, tfs, vd, vJ, off, scl, voxel_J_cl=vJcl))
+    res["precompute"] = dict(us=t_pre, gbps=(50.3e6 + 25.2e6 * 2 + 6.3e6) / t_pre / 1e3)
+    pts = (ro[iv_ray] + rd[iv_ray] * iv_vals[:, None])[None].contiguous()
+    P = pts.shape[1]
+    x = torch.zeros(1, P, 13, 3, device=DEV)
+    Ji = torch.zeros(1, P, 13, 3, 3, device=DEV)
+    valid = torch.zeros(1, P, 13, dtype=torch.bool, device=DEV)
+    bones = torch.from_numpy(S.INIT_BONES).to(DEV)
+    for name, grid in (("broyden_ncdhw", vJ), ("broyden_ndhwc", fast_snarf.ChannelLastVoxelJ(vJcl))):
+        t_b = timeit(lambda: fast_snarf.fuse_broyden(x, pts, vd, grid, tfs, bones, True, Ji, valid, off, scl, 1e-5, 1e-1), iters=5)
+        res[name] = dict(P=P, us=t_b, Mpts_per_s=P / t_b, valid_frac=float(valid.float().mean()))
+    t_f = timeit(lambda: fast_snarf.filter(x, valid), iters=5)
+    res["filter"] = dict(P=P, us=t_f)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
