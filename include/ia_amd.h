@@ -155,6 +155,44 @@ int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt /*[B,N,3]*/, co
                     ia_stream_t stream);
 int ia_filter(int64_t N, int I, const float* x /*[1,N,I,3]*/, const uint8_t* mask, uint8_t* out, ia_stream_t stream);
 
+/* ------------------------------------------------------------------------- */
+/* tinycudann.Encoding replacements (reference call sites models/network_utils.py:65,77,191;
+ * configs/geometry/progressive_hash_grid.yaml:9-24, configs/radiance/progressive_hash_grid.yaml:5-19).
+ * HashGrid: n_levels x 2 features, fp32 table [entries, 2], level-major output
+ * [l0f0, l0f1, l1f0, ...]; x in [0,1]^3.  out_stride lets the caller write the 32 features
+ * straight into a wider row (it must be even).  dy_dx (optional) = d out / d x, [n, L*2, 3]. */
+int64_t ia_hashgrid_n_entries(int n_levels, int log2_hashmap_size, int base_resolution, float per_level_scale);
+int ia_hashgrid_fwd(int64_t n, const float* x /*[n,3]*/, const float* params, int n_levels, int n_features,
+                    int log2_hashmap_size, int base_resolution, float per_level_scale,
+                    float* out, int out_stride, float* dy_dx /*or NULL*/, ia_stream_t stream);
+/* backward w.r.t. the table (atomic accumulate into grad_params, caller zeroes it):
+ *   grad[c] += g_enc[l,:] * w_c  +  g_jac[l,:] * sum_a q[a] * d w_c / d x_a
+ * The second term (g_jac, q both non-NULL) is the double-backward needed when a loss depends on
+ * the analytic normal d sdf / d x (eikonal, normal-conditioned radiance). */
+int ia_hashgrid_bwd(int64_t n, const float* x, int n_levels, int n_features, int log2_hashmap_size,
+                    int base_resolution, float per_level_scale, const float* g_enc /*[n,stride] or NULL*/,
+                    int g_enc_stride, const float* g_jac /*or NULL*/, int g_jac_stride, const float* q /*[n,3] or NULL*/,
+                    float* grad_params, ia_stream_t stream);
+/* SphericalHarmonics(degree=4): d01 in [0,1]^3 (tcnn maps to [-1,1]) -> 16 values */
+int ia_sh4_fwd(int64_t n, const float* d01, float* out, int out_stride, ia_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* Fused MLP evaluation on the matrix cores (fp32 MFMA).  kind:
+ *   0  SDF       35 -> 64 -> 13, Softplus(beta=100)   models/network_utils.py:201-244, rf/geometry.py:152-172
+ *   1  radiance  67 -> 64 -> 64 -> 3, ReLU, sigmoid   models/rf/radiance.py:111-135
+ *   2  material  48 -> 64 -> 64 -> 5, ReLU, sigmoid   models/pbr/material.py:31-51, network_utils.py:410-428
+ * The input row is the concatenation of n_segs (<=5) sources, each `seg_width[s]` columns read
+ * from seg_ptr[s] with row stride seg_stride[s] and mapped v*mul+add.  Weights are the EFFECTIVE
+ * row-major matrices (weight-norm / Lipschitz scaling / level masks / column order folded in by the
+ * host).  seg_* and inv_scale_host are HOST arrays; everything else is device memory.
+ * kind 0 with grad != NULL also returns the analytic d sdf / d x (needs jac = hash-grid dy_dx,
+ * segment 0 = the 32 hash features, xyz_col = first xyz column). */
+int ia_mlp_fwd(int kind, int64_t n, int n_segs, const float* const* seg_ptr, const int* seg_stride,
+               const int* seg_width, const float* seg_mul, const float* seg_add,
+               const float* W1, const float* b1, const float* W2, const float* b2, const float* Wo, const float* bo,
+               float* y, int y_stride, const float* jac, int xyz_col, const float* inv_scale_host, float* grad,
+               ia_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,8 @@ SOURCES = {
     "composite.hip": ["-ffp-contract=off"],
     "resample.hip": ["-ffp-contract=off"],
     "snarf.hip": ["-ffp-contract=off"],
+    "hashgrid.hip": ["-munsafe-fp-atomics"],
+    "mlp.hip": [],
 }
 
 

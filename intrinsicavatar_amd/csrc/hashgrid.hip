@@ -1,0 +1,247 @@
+// hashgrid.hip -- multiresolution hash-grid encoding (+ spherical harmonics deg 4) for gfx950.
+// Replaces tinycudann.Encoding(HashGrid) / Encoding(SphericalHarmonics) as used by the reference
+// (models/network_utils.py:58-100,191; configs/geometry/progressive_hash_grid.yaml:9-24;
+//  configs/radiance/progressive_hash_grid.yaml:5-19).  tiny-cuda-nn is not vendored in the
+// reference tree; semantics follow oracle/ia_oracle_field.c (Instant-NGP definitions).
+//
+// Mapping: one lane per (point, level), level fastest.  A wave covers 4 points x 16 levels, so
+//   * the 8 corner gathers of 64 lanes (512 independent 8-byte loads) are all in flight at once --
+//     the kernel is gather (L2 / Infinity-Cache) bound, never ALU bound;
+//   * each point's 32 outputs (16 levels x 2 features) are written by 16 adjacent lanes as one
+//     contiguous 128-byte row: fully coalesced stores;
+//   * per-level constants (scale, resolution, table offset/size) live in registers, computed once.
+// Tables are fp32 [entries, 2] (50.4 MB per grid): resident in the 256 MiB Infinity Cache.
+#include "ia_common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+constexpr int MAX_LEVELS = 32;
+
+struct HashCfg {
+    int n_levels;
+    uint32_t offsets[MAX_LEVELS + 1];
+    uint32_t res[MAX_LEVELS];
+    float scale[MAX_LEVELS];
+};
+
+__host__ void make_cfg(HashCfg& c, int n_levels, int log2_hashmap_size, int base_resolution, float per_level_scale)
+{
+    c.n_levels = n_levels;
+    uint32_t offset = 0;
+    const float l2 = log2f(per_level_scale);
+    for (int l = 0; l < n_levels; l++) {
+        const float sc = exp2f((float)l * l2) * (float)base_resolution - 1.0f;
+        const uint32_t res = (uint32_t)ceilf(sc) + 1u;
+        const uint32_t max_params = 0xFFFFFFFFu / 2;
+        uint32_t p = powf((float)res, 3.0f) > (float)max_params ? max_params : res * res * res;
+        p = (p + 7u) / 8u * 8u;
+        const uint32_t cap = 1u << log2_hashmap_size;
+        if (p > cap) p = cap;
+        c.offsets[l] = offset;
+        c.res[l] = res;
+        c.scale[l] = sc;
+        offset += p;
+    }
+    c.offsets[n_levels] = offset;
+}
+
+__device__ __forceinline__ uint32_t grid_index(uint32_t hsize, uint32_t res, uint32_t px, uint32_t py, uint32_t pz)
+{
+    // tiny-cuda-nn grid_index<3>: dense while the stride fits, else coherent prime hash
+    uint32_t stride = 1, index = 0;
+    bool hashed = false;
+    index += px * stride; stride *= res;
+    if (stride <= hsize) { index += py * stride; stride *= res; } else hashed = true;
+    if (!hashed && stride <= hsize) { index += pz * stride; stride *= res; } else hashed = true;
+    if (hsize < stride) index = (px * 1u) ^ (py * 2654435761u) ^ (pz * 805459861u);
+    return index % hsize;
+}
+
+// forward (+ optional analytic d enc / d x)
+template <bool WITH_JAC>
+__global__ __launch_bounds__(THREADS) void hash_fwd_kernel(int64_t n, const float* __restrict__ x,
+                                                            const float2* __restrict__ params, HashCfg cfg,
+                                                            float* __restrict__ out, int out_stride,
+                                                            float* __restrict__ dy_dx)
+{
+    const int L = cfg.n_levels;
+    const int64_t t = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    const int64_t i = t / L;
+    const int l = (int)(t % L);
+    if (i >= n) return;
+    const float sc = cfg.scale[l];
+    const uint32_t res = cfg.res[l], hsize = cfg.offsets[l + 1] - cfg.offsets[l];
+    const float2* tab = params + cfg.offsets[l];
+    float pos[3];
+    uint32_t pg[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const float p = fmaf(sc, x[i * 3 + d], 0.5f);
+        const float fl = floorf(p);
+        pg[d] = (uint32_t)(int)fl;
+        pos[d] = p - fl;
+    }
+    float2 v[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const uint32_t idx = grid_index(hsize, res, pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1));
+        v[c] = tab[idx];
+    }
+    float a0 = 0.f, a1 = 0.f;
+    float j0[3] = {0.f, 0.f, 0.f}, j1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const float wx = (c & 1) ? pos[0] : 1.0f - pos[0];
+        const float wy = (c & 2) ? pos[1] : 1.0f - pos[1];
+        const float wz = (c & 4) ? pos[2] : 1.0f - pos[2];
+        const float w = wx * wy * wz;
+        a0 += w * v[c].x;
+        a1 += w * v[c].y;
+        if (WITH_JAC) {
+            const float dx = ((c & 1) ? sc : -sc) * wy * wz;
+            const float dy = ((c & 2) ? sc : -sc) * wx * wz;
+            const float dz = ((c & 4) ? sc : -sc) * wx * wy;
+            j0[0] += dx * v[c].x; j0[1] += dy * v[c].x; j0[2] += dz * v[c].x;
+            j1[0] += dx * v[c].y; j1[1] += dy * v[c].y; j1[2] += dz * v[c].y;
+        }
+    }
+    *reinterpret_cast<float2*>(out + i * out_stride + l * 2) = make_float2(a0, a1);
+    if (WITH_JAC) {
+        float* J = dy_dx + (i * L * 2 + l * 2) * 3;
+        J[0] = j0[0]; J[1] = j0[1]; J[2] = j0[2];
+        J[3] = j1[0]; J[4] = j1[1]; J[5] = j1[2];
+    }
+}
+
+// backward w.r.t. the table:
+//   grad[c] += gE[l,:] * w_c  +  gG[l,:] * sum_a q[a] * d w_c / d x_a      (second term optional)
+template <bool SECOND>
+__global__ __launch_bounds__(THREADS) void hash_bwd_kernel(int64_t n, const float* __restrict__ x, HashCfg cfg,
+                                                            const float* __restrict__ gE, int gE_stride,
+                                                            const float* __restrict__ gG, int gG_stride,
+                                                            const float* __restrict__ q, float* __restrict__ grad)
+{
+    const int L = cfg.n_levels;
+    const int64_t t = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    const int64_t i = t / L;
+    const int l = (int)(t % L);
+    if (i >= n) return;
+    const float sc = cfg.scale[l];
+    const uint32_t res = cfg.res[l], hsize = cfg.offsets[l + 1] - cfg.offsets[l];
+    float* tab = grad + (int64_t)cfg.offsets[l] * 2;
+    float pos[3];
+    uint32_t pg[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const float p = fmaf(sc, x[i * 3 + d], 0.5f);
+        const float fl = floorf(p);
+        pg[d] = (uint32_t)(int)fl;
+        pos[d] = p - fl;
+    }
+    const float2 e = gE ? *reinterpret_cast<const float2*>(gE + i * gE_stride + l * 2) : make_float2(0.f, 0.f);
+    float2 g = make_float2(0.f, 0.f);
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (SECOND) {
+        g = *reinterpret_cast<const float2*>(gG + i * gG_stride + l * 2);
+        qx = q[i * 3 + 0]; qy = q[i * 3 + 1]; qz = q[i * 3 + 2];
+    }
+    if (e.x == 0.f && e.y == 0.f && g.x == 0.f && g.y == 0.f) return;   // masked-out levels (progressive bands)
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const float wx = (c & 1) ? pos[0] : 1.0f - pos[0];
+        const float wy = (c & 2) ? pos[1] : 1.0f - pos[1];
+        const float wz = (c & 4) ? pos[2] : 1.0f - pos[2];
+        float w0 = wx * wy * wz;
+        float vx = e.x * w0, vy = e.y * w0;
+        if (SECOND) {
+            const float dw = ((c & 1) ? sc : -sc) * wy * wz * qx + ((c & 2) ? sc : -sc) * wx * wz * qy +
+                             ((c & 4) ? sc : -sc) * wx * wy * qz;
+            vx += g.x * dw;
+            vy += g.y * dw;
+        }
+        const uint32_t idx = grid_index(hsize, res, pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1));
+        unsafeAtomicAdd(tab + (int64_t)idx * 2 + 0, vx);
+        unsafeAtomicAdd(tab + (int64_t)idx * 2 + 1, vy);
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void sh4_kernel(int64_t n, const float* __restrict__ d01, float* __restrict__ out,
+                                                       int out_stride)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float x = d01[i * 3 + 0] * 2.f - 1.f, y = d01[i * 3 + 1] * 2.f - 1.f, z = d01[i * 3 + 2] * 2.f - 1.f;
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    float* o = out + i * out_stride;
+    o[0] = 0.28209479177387814f;
+    o[1] = -0.48860251190291987f * y;
+    o[2] = 0.48860251190291987f * z;
+    o[3] = -0.48860251190291987f * x;
+    o[4] = 1.0925484305920792f * xy;
+    o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    o[7] = -1.0925484305920792f * xz;
+    o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    o[10] = 2.8906114426405538f * xy * z;
+    o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    o[14] = 1.4453057213202769f * z * (x2 - y2);
+    o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+}
+
+}  // namespace
+
+IA_EXPORT int64_t ia_hashgrid_n_entries(int n_levels, int log2_hashmap_size, int base_resolution, float per_level_scale)
+{
+    if (n_levels <= 0 || n_levels > MAX_LEVELS) return -1;
+    HashCfg c;
+    make_cfg(c, n_levels, log2_hashmap_size, base_resolution, per_level_scale);
+    return (int64_t)c.offsets[n_levels];
+}
+
+IA_EXPORT int ia_hashgrid_fwd(int64_t n, const float* x, const float* params, int n_levels, int n_features,
+                              int log2_hashmap_size, int base_resolution, float per_level_scale, float* out,
+                              int out_stride, float* dy_dx, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    IA_REQUIRE(n_features == 2, "n_features_per_level must be 2 on this path");
+    IA_REQUIRE(n_levels > 0 && n_levels <= MAX_LEVELS, "n_levels out of range");
+    IA_REQUIRE(out_stride >= n_levels * 2 && (out_stride % 2) == 0, "out_stride must be even and >= n_levels*2");
+    HashCfg c;
+    make_cfg(c, n_levels, log2_hashmap_size, base_resolution, per_level_scale);
+    const int grid = ia::cdiv(n * n_levels, THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    if (dy_dx) hash_fwd_kernel<true><<<grid, THREADS, 0, s>>>(n, x, (const float2*)params, c, out, out_stride, dy_dx);
+    else hash_fwd_kernel<false><<<grid, THREADS, 0, s>>>(n, x, (const float2*)params, c, out, out_stride, nullptr);
+    return ia::check_launch("ia_hashgrid_fwd");
+}
+
+IA_EXPORT int ia_hashgrid_bwd(int64_t n, const float* x, int n_levels, int n_features, int log2_hashmap_size,
+                              int base_resolution, float per_level_scale, const float* g_enc, int g_enc_stride,
+                              const float* g_jac, int g_jac_stride, const float* q, float* grad_params,
+                              ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    IA_REQUIRE(n_features == 2, "n_features_per_level must be 2 on this path");
+    IA_REQUIRE(n_levels > 0 && n_levels <= MAX_LEVELS, "n_levels out of range");
+    IA_REQUIRE(g_enc != nullptr || g_jac != nullptr, "need g_enc and/or g_jac");
+    IA_REQUIRE((g_jac == nullptr) == (q == nullptr), "g_jac and q go together");
+    HashCfg c;
+    make_cfg(c, n_levels, log2_hashmap_size, base_resolution, per_level_scale);
+    const int grid = ia::cdiv(n * n_levels, THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    if (g_jac) hash_bwd_kernel<true><<<grid, THREADS, 0, s>>>(n, x, c, g_enc, g_enc_stride, g_jac, g_jac_stride, q, grad_params);
+    else hash_bwd_kernel<false><<<grid, THREADS, 0, s>>>(n, x, c, g_enc, g_enc_stride, nullptr, 0, nullptr, grad_params);
+    return ia::check_launch("ia_hashgrid_bwd");
+}
+
+IA_EXPORT int ia_sh4_fwd(int64_t n, const float* d01, float* out, int out_stride, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    IA_REQUIRE(out_stride >= 16, "out_stride must be >= 16");
+    sh4_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, d01, out, out_stride);
+    return ia::check_launch("ia_sh4_fwd");
+}

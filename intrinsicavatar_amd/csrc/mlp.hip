@@ -1,0 +1,337 @@
+// mlp.hip -- fused small-MLP evaluation on the CDNA4 matrix cores (fp32-in / fp32-acc MFMA).
+// Replaces the PyTorch MLPs of the reference's field queries:
+//   VanillaMLP  35->64->13  (Softplus beta=100, weight-norm)  models/network_utils.py:201-244  (SDF, rf/geometry.py:152)
+//   VanillaMLP  67->64->64->3 (ReLU)                          models/rf/radiance.py:118-131
+//   LipshitzMLP 48->64->64->5 (ReLU)                          models/network_utils.py:360-431, pbr/material.py:31-51
+// and, for the SDF head, the analytic normal that the reference obtains with
+// torch.autograd.grad(create_graph=True) (rf/geometry.py:165-172).
+//
+// Design
+//   * one wave owns a tile of 64 points; its activations never leave LDS between layers;
+//   * the input row is ASSEMBLED in LDS from up to 5 source segments (hash features, xyz, geometry
+//     feature, SH, normal ...) so the concatenated [n, 67] tensor is never materialised in HBM;
+//   * hidden layers (N = 64): v_mfma_f32_32x32x2_f32, 2x2 tiles of 32x32 per wave;
+//     output layer (N <= 16): v_mfma_f32_16x16x4_f32 (4 tiles of 16 points);
+//     fp32 MFMA is bit-equal to an fmaf chain, so parity mode needs no reduced precision;
+//   * weights (effective: weight-norm / Lipschitz scaling / level masks folded in on the host) are
+//     staged once per workgroup in LDS, rows padded to an odd stride => conflict-free ds_read_b32
+//     for both operand patterns;
+//   * SDF head: g_z = softplus'(z) * W2[0,:], g_h = g_z W1 (one more MFMA GEMM), then a per-point
+//     epilogue contracts g_h with the hash-grid Jacobian (d enc / d x) -> analytic gradient.
+#include "ia_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int THREADS = 256;            // 4 waves, one 64-point tile each per iteration
+constexpr int HID = 64;
+constexpr int MAX_SEGS = 5;
+
+struct Seg {
+    const float* p;
+    int stride;   // floats between consecutive points
+    int width;    // columns taken from this source
+    float mul, add;
+};
+
+struct MlpArgs {
+    int64_t n;
+    int n_segs;
+    Seg segs[MAX_SEGS];
+    const float *W1, *b1, *W2, *b2, *Wo, *bo;    // W1 [64,IN], W2 [64,64] (NHID==2), Wo [OUT,64]
+    float* y;                                    // [n, y_stride] (first OUT columns written)
+    int y_stride;
+    // SDF head extras
+    const float* jac;        // [n, 32, 3] d enc / d x'
+    int xyz_col;             // column of the first xyz input in the assembled row
+    float inv_scale[3];      // 1 / bbox extent
+    float* grad;             // [n, 3]
+};
+
+__device__ __forceinline__ float act_hidden(float v, int hact)
+{
+    if (hact == 0) return fmaxf(v, 0.0f);
+    const float bx = 100.0f * v;                      // Softplus(beta=100, threshold=20)
+    return bx > 20.0f ? v : log1pf(__expf(bx)) * 0.01f;
+}
+
+template <int IN, int NHID, int OUT, int HACT, int OACT, bool SDF_GRAD>
+__global__ __launch_bounds__(THREADS) void mlp_fwd_kernel(MlpArgs a)
+{
+    constexpr int IN_PAD = (IN + 1) / 2 * 2;
+    constexpr int LDW1 = IN_PAD + 1;
+    constexpr int LDW = HID + 1;
+    constexpr int LDX = (IN_PAD > HID ? IN_PAD : HID) + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sW1 = smem;                                   // [64][LDW1]
+    float* sW2 = sW1 + HID * LDW1;                       // [64][LDW]   (NHID == 2)
+    float* sWo = sW2 + (NHID == 2 ? HID * LDW : 0);      // [16][LDW]
+    float* sB = sWo + 16 * LDW;                          // b1[64] b2[64] bo[16]
+    float* sXall = sB + 64 + 64 + 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* sX = sXall + wave * 64 * LDX;                 // this wave's [64][LDX] tile
+    float* sG = sX;                                      // SDF_GRAD: reused for g_z / g_h
+
+    // ---- stage weights (zero padded) ----
+    for (int i = tid; i < HID * LDW1; i += THREADS) {
+        const int r = i / LDW1, c = i % LDW1;
+        sW1[i] = (c < IN) ? a.W1[r * IN + c] : 0.0f;
+    }
+    if (NHID == 2)
+        for (int i = tid; i < HID * LDW; i += THREADS) {
+            const int r = i / LDW, c = i % LDW;
+            sW2[i] = (c < HID) ? a.W2[r * HID + c] : 0.0f;
+        }
+    for (int i = tid; i < 16 * LDW; i += THREADS) {
+        const int r = i / LDW, c = i % LDW;
+        sWo[i] = (r < OUT && c < HID) ? a.Wo[r * HID + c] : 0.0f;
+    }
+    if (tid < 64) { sB[tid] = a.b1[tid]; sB[64 + tid] = (NHID == 2) ? a.b2[tid] : 0.0f; }
+    if (tid < 16) sB[128 + tid] = (tid < OUT) ? a.bo[tid] : 0.0f;
+    __syncthreads();
+
+    const int64_t n_tiles = (a.n + 63) / 64;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t p0 = tile * 64;
+        // ---- assemble the input rows in LDS ----
+        int col0 = 0;
+        for (int s = 0; s < a.n_segs; s++) {
+            const Seg sg = a.segs[s];
+            const int tot = 64 * sg.width;
+            for (int i = lane; i < tot; i += 64) {
+                const int r = i / sg.width, c = i % sg.width;
+                const int64_t p = p0 + r;
+                float v = 0.0f;
+                if (p < a.n) v = sg.p[p * sg.stride + c] * sg.mul + sg.add;
+                sX[r * LDX + col0 + c] = v;
+            }
+            col0 += sg.width;
+        }
+        if (IN_PAD > IN) sX[lane * LDX + IN] = 0.0f;
+
+        const int lr = lane & 31, lk = lane >> 5;
+        // ---- layer 1: [64 x IN_PAD] x W1^T -> [64 x 64] ----
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[m][nt][r] = 0.0f;
+#pragma unroll 2
+        for (int kk = 0; kk < IN_PAD / 2; kk++) {
+            const int k = 2 * kk + lk;
+            const float a0 = sX[lr * LDX + k], a1 = sX[(32 + lr) * LDX + k];
+            const float b0 = sW1[lr * LDW1 + k], b1v = sW1[(32 + lr) * LDW1 + k];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1v, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1v, acc[1][1], 0, 0, 0);
+        }
+        // epilogue: bias + activation -> sX (in place: all reads of the old tile are complete)
+        // SDF_GRAD keeps z in registers to form softplus'(z) later
+        float sig[2][2][16];
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * lk, col = 32 * nt + lr;
+                    const float z = acc[m][nt][r] + sB[col];
+                    sX[row * LDX + col] = act_hidden(z, HACT);
+                    if (SDF_GRAD) sig[m][nt][r] = 1.0f / (1.0f + __expf(-100.0f * z));
+                }
+        // ---- layer 2 (optional) ----
+        if (NHID == 2) {
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[m][nt][r] = 0.0f;
+#pragma unroll 2
+            for (int kk = 0; kk < HID / 2; kk++) {
+                const int k = 2 * kk + lk;
+                const float a0 = sX[lr * LDX + k], a1 = sX[(32 + lr) * LDX + k];
+                const float b0 = sW2[lr * LDW + k], b1v = sW2[(32 + lr) * LDW + k];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1v, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1v, acc[1][1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * lk, col = 32 * nt + lr;
+                        sX[row * LDX + col] = act_hidden(acc[m][nt][r] + sB[64 + col], HACT);
+                    }
+        }
+        // ---- output layer: [64 x 64] x Wo^T -> [64 x 16] with 16x16x4 tiles ----
+        {
+            const int l15 = lane & 15, l4 = lane >> 4;
+            f32x4 o[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) o[m][r] = 0.0f;
+#pragma unroll 4
+            for (int kk = 0; kk < HID / 4; kk++) {
+                const int k = 4 * kk + l4;
+                const float b = sWo[l15 * LDW + k];
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+                    o[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(sX[(16 * m + l15) * LDX + k], b, o[m], 0, 0, 0);
+            }
+            if (l15 < OUT) {
+                const float bias = sB[128 + l15];
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int64_t p = p0 + 16 * m + l4 * 4 + r;
+                        float v = o[m][r] + bias;
+                        if (OACT == 1) v = 1.0f / (1.0f + __expf(-v));
+                        if (p < a.n) a.y[p * a.y_stride + l15] = v;
+                    }
+            }
+        }
+        // ---- SDF head: analytic gradient ----
+        if (SDF_GRAD) {
+            // g_z[p][o] = softplus'(z[p][o]) * Wo[0][o]  -> sG (over the hidden activations, now dead)
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * lk, col = 32 * nt + lr;
+                        sG[row * LDX + col] = sig[m][nt][r] * sWo[col];
+                    }
+            // g_h = g_z W1 : A = g_z [64 pts x 64], B[k][j] = W1[k][j], j < IN_PAD (<= 64)
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[m][nt][r] = 0.0f;
+#pragma unroll 2
+            for (int kk = 0; kk < HID / 2; kk++) {
+                const int k = 2 * kk + lk;
+                const float a0 = sG[lr * LDX + k], a1 = sG[(32 + lr) * LDX + k];
+                const float b0 = (lr < IN_PAD) ? sW1[k * LDW1 + lr] : 0.0f;
+                const float b1v = (32 + lr < IN_PAD) ? sW1[k * LDW1 + 32 + lr] : 0.0f;
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1v, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1v, acc[1][1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * lk, col = 32 * nt + lr;
+                        sG[row * LDX + col] = acc[m][nt][r];
+                    }
+            // per-point epilogue (lane = point): grad_a = (2 g_h[xyz_a] + sum_k g_h[k] J[k][a]) * inv_scale_a
+            const int64_t p = p0 + lane;
+            if (p < a.n) {
+                const float* gh = sG + lane * LDX;
+                const float* J = a.jac + p * 96;
+                float g0 = 2.0f * gh[a.xyz_col + 0], g1 = 2.0f * gh[a.xyz_col + 1], g2 = 2.0f * gh[a.xyz_col + 2];
+#pragma unroll 8
+                for (int k = 0; k < 32; k++) {
+                    const float g = gh[k];      // hash features occupy columns 0..31
+                    g0 = fmaf(g, J[k * 3 + 0], g0);
+                    g1 = fmaf(g, J[k * 3 + 1], g1);
+                    g2 = fmaf(g, J[k * 3 + 2], g2);
+                }
+                a.grad[p * 3 + 0] = g0 * a.inv_scale[0];
+                a.grad[p * 3 + 1] = g1 * a.inv_scale[1];
+                a.grad[p * 3 + 2] = g2 * a.inv_scale[2];
+            }
+        }
+    }
+}
+
+template <int IN, int NHID, int OUT, int HACT, int OACT, bool SDF_GRAD>
+int launch_fwd(const MlpArgs& a, hipStream_t s)
+{
+    constexpr int IN_PAD = (IN + 1) / 2 * 2;
+    constexpr int LDW1 = IN_PAD + 1, LDW = HID + 1, LDX = (IN_PAD > HID ? IN_PAD : HID) + 1;
+    constexpr size_t lds = sizeof(float) * (HID * LDW1 + (NHID == 2 ? HID * LDW : 0) + 16 * LDW + 144 + 4 * 64 * LDX);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = mlp_fwd_kernel<IN, NHID, OUT, HACT, OACT, SDF_GRAD>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int64_t n_tiles = (a.n + 63) / 64;
+    const int blocks_per_cu = (int)((160 * 1024) / lds) > 2 ? 2 : (int)((160 * 1024) / lds);
+    int grid = (int)((n_tiles + 3) / 4);
+    const int cap = 256 * (blocks_per_cu > 0 ? blocks_per_cu : 1);
+    if (grid > cap) grid = cap;
+    kern<<<grid, THREADS, lds, s>>>(a);
+    return ia::check_launch("ia_mlp_fwd");
+}
+
+}  // namespace
+
+static int fill_args(MlpArgs& a, int64_t n, int n_segs, const float* const* seg_ptr, const int* seg_stride,
+                     const int* seg_width, const float* seg_mul, const float* seg_add, int in_dim)
+{
+    IA_REQUIRE(n_segs >= 1 && n_segs <= MAX_SEGS, "1..5 input segments");
+    int tot = 0;
+    a.n = n;
+    a.n_segs = n_segs;
+    for (int s = 0; s < n_segs; s++) {
+        a.segs[s].p = seg_ptr[s];
+        a.segs[s].stride = seg_stride[s];
+        a.segs[s].width = seg_width[s];
+        a.segs[s].mul = seg_mul ? seg_mul[s] : 1.0f;
+        a.segs[s].add = seg_add ? seg_add[s] : 0.0f;
+        tot += seg_width[s];
+    }
+    IA_REQUIRE(tot == in_dim, "segment widths must sum to the MLP input width");
+    return IA_OK;
+}
+
+// kind: 0 = SDF 35->64->13 softplus100 (optionally with analytic gradient)
+//       1 = radiance 67->64->64->3 relu, sigmoid output
+//       2 = material 48->64->64->5 relu, sigmoid output
+IA_EXPORT int ia_mlp_fwd(int kind, int64_t n, int n_segs, const float* const* seg_ptr, const int* seg_stride,
+                         const int* seg_width, const float* seg_mul, const float* seg_add, const float* W1,
+                         const float* b1, const float* W2, const float* b2, const float* Wo, const float* bo,
+                         float* y, int y_stride, const float* jac, int xyz_col, const float* inv_scale_host,
+                         float* grad, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    MlpArgs a = {};
+    const int in_dim = kind == 0 ? 35 : (kind == 1 ? 67 : 48);
+    IA_REQUIRE(kind >= 0 && kind <= 2, "unknown MLP kind");
+    int r = fill_args(a, n, n_segs, seg_ptr, seg_stride, seg_width, seg_mul, seg_add, in_dim);
+    if (r != IA_OK) return r;
+    a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Wo = Wo; a.bo = bo;
+    a.y = y; a.y_stride = y_stride;
+    a.jac = jac; a.xyz_col = xyz_col; a.grad = grad;
+    if (inv_scale_host) for (int k = 0; k < 3; k++) a.inv_scale[k] = inv_scale_host[k];
+    hipStream_t s = (hipStream_t)stream;
+    if (kind == 0) {
+        if (grad) {
+            IA_REQUIRE(jac != nullptr && inv_scale_host != nullptr, "SDF gradient needs the hash-grid Jacobian and 1/scale");
+            IA_REQUIRE(seg_width[0] == 32, "SDF head: segment 0 must be the 32 hash features");
+            return launch_fwd<35, 1, 13, 1, 0, true>(a, s);
+        }
+        return launch_fwd<35, 1, 13, 1, 0, false>(a, s);
+    }
+    if (kind == 1) return launch_fwd<67, 2, 3, 0, 1, false>(a, s);
+    return launch_fwd<48, 2, 5, 0, 1, false>(a, s);
+}

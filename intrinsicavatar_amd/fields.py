@@ -1,0 +1,243 @@
+"""Neural-field queries of the render_step hot path on the MI355X kernels.
+
+Host-side mirrors of the reference modules, with the reference's parameter names so that its
+checkpoints load unchanged:
+
+  VolumeSDF             models/rf/geometry.py:107-235   (ProgressiveBandHashGrid + xyz -> VanillaMLP 35->64->13)
+  VolumeRefDirRadiance  models/rf/radiance.py:82-135    (hash grid #2 + feat + SH4(reflect) + normal -> 67->64->64->3)
+  VolumeMaterial        models/pbr/material.py:13-51    (LipshitzMLP 48->64->64->5)
+  LaplaceDensity        models/rf/density.py:19-34
+
+The kernels take EFFECTIVE weights; weight-norm, Lipschitz normalisation, progressive level masks
+and the kernels' column order ([hash 32 | xyz 3 | ...]) are folded in here with tiny torch ops on
+the (<= 64x67) matrices, which keeps them differentiable for training.
+"""
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import _lib as L
+
+HASH = dict(n_levels=16, n_features_per_level=2, log2_hashmap_size=19, base_resolution=16,
+            per_level_scale=1.447269237440378)
+
+
+def hash_n_entries(cfg=HASH) -> int:
+    lib = L.lib()
+    lib.ia_hashgrid_n_entries.restype = C.c_int64
+    return int(lib.ia_hashgrid_n_entries(L.i32(cfg["n_levels"]), L.i32(cfg["log2_hashmap_size"]),
+                                         L.i32(cfg["base_resolution"]), L.f32(cfg["per_level_scale"])))
+
+
+def hashgrid_forward(x01: Tensor, params: Tensor, cfg=HASH, with_jac: bool = False, out: Optional[Tensor] = None):
+    """x01 [n,3] in [0,1] -> enc [n,32] (+ jac [n,32,3]); `out` may be a wider [n,stride] buffer (cols 0..31 written)."""
+    n = x01.shape[0]
+    x01 = x01.contiguous().float()
+    LF = cfg["n_levels"] * cfg["n_features_per_level"]
+    if out is None:
+        out = torch.empty((n, LF), dtype=torch.float32, device=x01.device)
+    jac = torch.empty((n, LF, 3), dtype=torch.float32, device=x01.device) if with_jac else None
+    L.check(L.lib().ia_hashgrid_fwd(L.i64(n), L.ptr(x01), L.ptr(params), L.i32(cfg["n_levels"]),
+                                    L.i32(cfg["n_features_per_level"]), L.i32(cfg["log2_hashmap_size"]),
+                                    L.i32(cfg["base_resolution"]), L.f32(cfg["per_level_scale"]), L.ptr(out),
+                                    L.i32(out.stride(0)), L.ptr(jac), L.stream()), "ia_hashgrid_fwd")
+    return (out, jac) if with_jac else out
+
+
+def hashgrid_backward(x01: Tensor, g_enc: Optional[Tensor], grad_params: Tensor, cfg=HASH,
+                      g_jac: Optional[Tensor] = None, q: Optional[Tensor] = None):
+    """accumulate d L / d table into grad_params (see include/ia_amd.h ia_hashgrid_bwd)."""
+    n = x01.shape[0]
+    L.check(L.lib().ia_hashgrid_bwd(L.i64(n), L.ptr(x01), L.i32(cfg["n_levels"]), L.i32(cfg["n_features_per_level"]),
+                                    L.i32(cfg["log2_hashmap_size"]), L.i32(cfg["base_resolution"]),
+                                    L.f32(cfg["per_level_scale"]), L.ptr(g_enc),
+                                    L.i32(g_enc.stride(0) if g_enc is not None else 0), L.ptr(g_jac),
+                                    L.i32(g_jac.stride(0) if g_jac is not None else 0), L.ptr(q), L.ptr(grad_params),
+                                    L.stream()), "ia_hashgrid_bwd")
+
+
+def sh4(d01: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    n = d01.shape[0]
+    d01 = d01.contiguous().float()
+    if out is None:
+        out = torch.empty((n, 16), dtype=torch.float32, device=d01.device)
+    L.check(L.lib().ia_sh4_fwd(L.i64(n), L.ptr(d01), L.ptr(out), L.i32(out.stride(0)), L.stream()), "ia_sh4_fwd")
+    return out
+
+
+def mlp_forward(kind: int, segs, W1, b1, W2, b2, Wo, bo, out_dim: int, jac=None, xyz_col=0, inv_scale=None,
+                want_grad=False):
+    """segs: list of (tensor [n,w_total>=w], width, mul, add). Returns y [n,out_dim] (+ grad [n,3])."""
+    n = segs[0][0].shape[0]
+    dev = segs[0][0].device
+    ns = len(segs)
+    keep = []
+    ptrs = (C.c_void_p * ns)()
+    strides = (C.c_int * ns)()
+    widths = (C.c_int * ns)()
+    muls = (C.c_float * ns)()
+    adds = (C.c_float * ns)()
+    for i, (t, w, m, a) in enumerate(segs):
+        if t.stride(-1) != 1 or t.dtype != torch.float32 or not t.is_cuda:
+            raise L.IaError("MLP input segments must be float32 GPU tensors with unit inner stride")
+        keep.append(t)
+        ptrs[i] = t.data_ptr()
+        strides[i] = t.stride(0)
+        widths[i] = w
+        muls[i] = m
+        adds[i] = a
+    y = torch.empty((n, out_dim), dtype=torch.float32, device=dev)
+    grad = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_grad else None
+    inv = (C.c_float * 3)(*[float(v) for v in inv_scale]) if inv_scale is not None else None
+    cont = [t.contiguous().float() if t is not None else None for t in (W1, b1, W2, b2, Wo, bo)]
+    L.check(L.lib().ia_mlp_fwd(L.i32(kind), L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds,
+                               L.ptr(cont[0]), L.ptr(cont[1]), L.ptr(cont[2]), L.ptr(cont[3]), L.ptr(cont[4]),
+                               L.ptr(cont[5]), L.ptr(y), L.i32(out_dim), L.ptr(jac), L.i32(xyz_col), inv, L.ptr(grad),
+                               L.stream()), "ia_mlp_fwd")
+    return (y, grad) if want_grad else y
+
+
+# ----------------------------------------------------------------------------- modules
+def _weight_norm(g: Tensor, v: Tensor) -> Tensor:
+    return g * v / v.norm(dim=1, keepdim=True)
+
+
+class _WNLinear(nn.Module):
+    """nn.utils.weight_norm(nn.Linear) parameter layout: weight_g [out,1], weight_v [out,in], bias."""
+
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.weight_g = nn.Parameter(torch.ones(dim_out, 1))
+        self.weight_v = nn.Parameter(torch.zeros(dim_out, dim_in))
+        self.bias = nn.Parameter(torch.zeros(dim_out))
+
+    def effective(self):
+        return _weight_norm(self.weight_g, self.weight_v)
+
+
+class _Linear(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(dim_out, dim_in))
+        self.bias = nn.Parameter(torch.zeros(dim_out))
+
+
+class HashEncoding(nn.Module):
+    """`encoding.encoding.params`: flat fp32 table like tcnn.Encoding (network_utils.py:65)."""
+
+    def __init__(self, cfg=HASH, seed: Optional[int] = None):
+        super().__init__()
+        self.cfg = cfg
+        n = hash_n_entries(cfg) * cfg["n_features_per_level"]
+        g = torch.Generator().manual_seed(seed) if seed is not None else None
+        self.params = nn.Parameter((torch.rand(n, generator=g) * 2 - 1) * 1e-4)   # tcnn default U(-1e-4, 1e-4)
+        self.n_output_dims = cfg["n_levels"] * cfg["n_features_per_level"]
+
+
+class ProgressiveMask:
+    """ProgressiveBandHashGrid.update_step (network_utils.py:79-100), non_smooth mode."""
+
+    def __init__(self, n_levels=16, F_=2, start_level=4, start_step=500, update_steps=125):
+        self.n_levels, self.F, self.start_level, self.start_step, self.update_steps = n_levels, F_, start_level, start_step, update_steps
+        self.current_level = start_level
+
+    def mask(self, global_step: int, device) -> Tensor:
+        lvl = min(self.start_level + max(global_step - self.start_step, 0) // self.update_steps, self.n_levels)
+        self.current_level = lvl
+        m = torch.zeros(self.n_levels * self.F, device=device)
+        m[: lvl * self.F] = 1.0
+        return m
+
+
+class VolumeSDF(nn.Module):
+    """models/rf/geometry.py:107-235 on the HIP kernels.  forward(points) with points in canonical space."""
+
+    def __init__(self, seed: Optional[int] = 0, sphere_init_radius=0.5):
+        super().__init__()
+        self.encoding = nn.Module()
+        self.encoding.encoding = nn.Module()
+        self.encoding.encoding.encoding = HashEncoding(seed=seed)   # state-dict key: encoding.encoding.encoding.params
+        self.network = nn.Module()
+        self.network.layers = nn.ModuleList([_WNLinear(35, 64), nn.Identity(), _WNLinear(64, 13)])
+        self.prog = ProgressiveMask()
+        self.global_step = 25000
+        self._init(seed, sphere_init_radius)
+        self.register_buffer("center", torch.zeros(3), persistent=False)
+        self.register_buffer("scale", torch.ones(3), persistent=False)
+
+    def _init(self, seed, radius):
+        # VanillaMLP.make_linear sphere init (network_utils.py:219-231) then weight_norm
+        g = torch.Generator().manual_seed(seed if seed is not None else 0)
+        l0, l2 = self.network.layers[0], self.network.layers[2]
+        w0 = torch.zeros(64, 35)
+        w0[:, :3] = torch.randn(64, 3, generator=g) * (math.sqrt(2) / math.sqrt(64))
+        w2 = torch.randn(13, 64, generator=g) * 0.0001 + math.sqrt(math.pi) / math.sqrt(64)
+        with torch.no_grad():
+            l0.weight_v.copy_(w0); l0.weight_g.copy_(w0.norm(dim=1, keepdim=True)); l0.bias.zero_()
+            l2.weight_v.copy_(w2); l2.weight_g.copy_(w2.norm(dim=1, keepdim=True)); l2.bias.fill_(-radius)
+
+    def prepare_bbox(self, bbox: Tensor):
+        self.center = ((bbox[0] + bbox[1]) / 2).to(self.center)
+        self.scale = (bbox[1] - bbox[0]).to(self.scale)
+
+    def update_step(self, epoch, global_step):
+        self.global_step = global_step
+
+    @property
+    def grid_params(self):
+        return self.encoding.encoding.encoding.params
+
+    def effective_weights(self):
+        """kernel column order [hash(32) | xyz(3)], level mask folded into W1."""
+        W1 = self.network.layers[0].effective()                     # [64,35] reference order [xyz | hash]
+        mask = self.prog.mask(self.global_step, W1.device)
+        W1k = torch.cat([W1[:, 3:] * mask[None], W1[:, :3]], dim=1)
+        return W1k, self.network.layers[0].bias, self.network.layers[2].effective(), self.network.layers[2].bias
+
+    @torch.no_grad()
+    def forward(self, points: Tensor, with_grad=True, with_feature=True):
+        """returns [sdf, (grad), (feature)] like VolumeSDF.forward (eval / no-grad path)."""
+        n = points.shape[0]
+        if n == 0:
+            out = [points.new_empty(0)]
+            if with_grad:
+                out.append(points.new_empty(0, 3))
+            if with_feature:
+                out.append(points.new_empty(0, 13))
+            return out[0] if len(out) == 1 else out
+        xp = ((points - self.center) / self.scale + 0.5).contiguous()
+        if with_grad:
+            enc, jac = hashgrid_forward(xp, self.grid_params, with_jac=True)
+        else:
+            enc, jac = hashgrid_forward(xp, self.grid_params), None
+        W1k, b1, W2, b2 = self.effective_weights()
+        res = mlp_forward(0, [(enc, 32, 1.0, 0.0), (xp, 3, 2.0, -1.0)], W1k, b1, None, None, W2, b2, 13, jac=jac,
+                          xyz_col=32, inv_scale=(1.0 / self.scale).tolist() if with_grad else None, want_grad=with_grad)
+        y, grad = res if with_grad else (res, None)
+        out = [y[:, 0]]
+        if with_grad:
+            out.append(grad)
+        if with_feature:
+            out.append(y)
+        return out[0] if len(out) == 1 else out
+
+
+class LaplaceDensity(nn.Module):
+    """models/rf/density.py:19-34 (elementwise; fused into the alpha computation of the render path)."""
+
+    def __init__(self, beta_init=0.3, beta_min=1e-4):
+        super().__init__()
+        self.beta = nn.Parameter(torch.tensor(beta_init))
+        self.beta_min = beta_min
+
+    def get_beta(self):
+        return self.beta.abs() + self.beta_min
+
+    def forward(self, sdf):
+        beta = self.get_beta()
+        return torch.reciprocal(beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))

@@ -1,0 +1,168 @@
+"""GPU: neural-field kernels (hash grid, SH, fused MFMA MLPs) vs the CPU oracle / reference modules.
+Floating-point kernels => tolerance (stated per test); fp32 everywhere (reference: trainer.precision 32)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def fields():
+    from intrinsicavatar_amd import build
+    build.build()
+    from intrinsicavatar_amd import fields
+    return fields
+
+
+def _params(oracle, seed=0, amp=1e-1):
+    total, offs, res, sc = oracle.hashgrid_offsets()
+    rng = np.random.default_rng(seed)
+    return (rng.uniform(-amp, amp, total * 2)).astype(np.float32), total
+
+
+def test_hashgrid_layout_matches_instant_ngp(oracle, fields):
+    total, offs, res, sc = oracle.hashgrid_offsets()
+    assert list(res[:5]) == [16, 24, 34, 49, 71]
+    assert total == fields.hash_n_entries() and abs(total * 2 * 4 / 1e6 - 50.4) < 0.3
+    assert all(int(offs[l + 1] - offs[l]) == 1 << 19 for l in range(5, 16))
+
+
+def test_hashgrid_fwd_and_jacobian_vs_oracle(oracle, fields):
+    params, _ = _params(oracle)
+    rng = np.random.default_rng(1)
+    x = rng.random((20000, 3)).astype(np.float32)
+    x[:8] = [[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [0, 1, 0], [1, 0, 0], [0.999999, 0.5, 0.25], [1e-7, 0.3, 0.9], [0.25, 0.25, 0.25]]
+    ref, jref = oracle.hashgrid_fwd(x, params, with_jac=True)
+    enc, jac = fields.hashgrid_forward(T(x), T(params), with_jac=True)
+    np.testing.assert_allclose(N(enc), ref, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(N(jac), jref, rtol=1e-4, atol=2e-4)      # |J| ~ scale(4096) * amp
+    # known-answer: dense level 0 == trilinear interpolation of its 16^3 lattice
+    total, offs, res, sc = oracle.hashgrid_offsets()
+    lat = params[: 16 ** 3 * 2].reshape(16, 16, 16, 2)                     # index = x + y*16 + z*256
+    p = x[100:200] * sc[0] + 0.5
+    i0 = np.floor(p).astype(int)
+    f = p - i0
+    tri = np.zeros((100, 2), np.float32)
+    for c in range(8):
+        o = np.array([(c >> 0) & 1, (c >> 1) & 1, (c >> 2) & 1])
+        w = np.prod(np.where(o, f, 1 - f), axis=1)
+        idx = i0 + o
+        tri += w[:, None] * lat[idx[:, 2], idx[:, 1], idx[:, 0]]
+    np.testing.assert_allclose(N(enc)[100:200, :2], tri, rtol=1e-4, atol=1e-6)
+
+
+def test_hashgrid_bwd_vs_oracle(oracle, fields):
+    params, total = _params(oracle)
+    rng = np.random.default_rng(2)
+    x = rng.random((5000, 3)).astype(np.float32)
+    g = rng.normal(size=(5000, 32)).astype(np.float32)
+    ref = oracle.hashgrid_bwd_params(x, g, total * 2)
+    gp = torch.zeros(total * 2, device=DEV)
+    fields.hashgrid_backward(T(x), T(g), gp)
+    np.testing.assert_allclose(N(gp), ref, rtol=1e-4, atol=1e-5)            # atomics: order-dependent rounding
+
+
+def test_hashgrid_second_order_bwd_vs_autograd(oracle, fields):
+    """d/dparams of <g_jac, J q> must equal the scatter the kernel does (double-backward path);
+    checked against finite-difference-free autograd on a torch restatement of ONE dense level."""
+    params, total = _params(oracle, seed=4)
+    rng = np.random.default_rng(3)
+    n = 300
+    x = rng.random((n, 3)).astype(np.float32)
+    gj = rng.normal(size=(n, 32)).astype(np.float32)
+    q = rng.normal(size=(n, 3)).astype(np.float32)
+    gp = torch.zeros(total * 2, device=DEV)
+    fields.hashgrid_backward(T(x), None, gp, g_jac=T(gj), q=T(q))
+    # linearity in params: L(params) = sum_{i,k} gj[i,k] * (J(params)[i,k,:] . q[i]);  dL/dparams . params == L
+    _, jac = fields.hashgrid_forward(T(x), T(params), with_jac=True)
+    Lval = float((T(gj).double() * (jac.double() * T(q).double()[:, None, :]).sum(-1)).sum())
+    assert abs(float((gp.double() * T(params).double()).sum()) - Lval) < 1e-3 * max(1.0, abs(Lval))
+
+
+def test_sh4_vs_oracle_and_closed_form(oracle, fields):
+    rng = np.random.default_rng(5)
+    d = rng.normal(size=(4096, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d01 = (d + 1) / 2
+    out = N(fields.sh4(T(d01)))
+    np.testing.assert_allclose(out, oracle.sh4(d01), rtol=1e-5, atol=1e-6)
+    # orthonormality of the 16 real SH over the sphere (Monte-Carlo): E[Y_i Y_j] * 4pi ~ delta_ij
+    G = out.T.astype(np.float64) @ out.astype(np.float64) / d.shape[0] * 4 * np.pi
+    assert np.abs(G - np.eye(16)).max() < 0.15
+
+
+def _weight_norm(g, v):
+    return g * v / np.linalg.norm(v.astype(np.float64), axis=1, keepdims=True).astype(np.float32)
+
+
+def test_mlps_vs_reference_modules(fields, golden_dir):
+    """the three MLP shapes against outputs of the reference's own VanillaMLP / LipshitzMLP modules."""
+    g = np.load(os.path.join(golden_dir, "golden_mlp.npz"))
+    # SDF net: reference input order [xyz(3) | hash(32)]; kernel order [hash | xyz]
+    W1 = _weight_norm(g["sdf_sd_layers.0.weight_g"], g["sdf_sd_layers.0.weight_v"])
+    W2 = _weight_norm(g["sdf_sd_layers.2.weight_g"], g["sdf_sd_layers.2.weight_v"])
+    x = g["sdf_x"]
+    W1k = np.concatenate([W1[:, 3:], W1[:, :3]], 1)
+    enc, xyz = T(x[:, 3:]), T(x[:, :3])
+    y = fields.mlp_forward(0, [(enc, 32, 1.0, 0.0), (xyz, 3, 1.0, 0.0)], T(W1k), T(g["sdf_sd_layers.0.bias"]), None, None,
+                           T(W2), T(g["sdf_sd_layers.2.bias"]), 13)
+    np.testing.assert_allclose(N(y), g["sdf_y"], rtol=2e-5, atol=5e-6)
+    # radiance net (sigmoid applied by the kernel; reference applies it outside: radiance.py:132-133)
+    x = T(g["rad_x"])
+    y = fields.mlp_forward(1, [(x, 67, 1.0, 0.0)], *[T(g[f"rad_sd_layers.{i}.{k}"]) for i in (0, 2, 4) for k in ("weight", "bias")], 3)
+    ref = 1 / (1 + np.exp(-g["rad_y"].astype(np.float64)))
+    np.testing.assert_allclose(N(y), ref, rtol=2e-5, atol=2e-6)
+    # split the same input over 5 segments (as the render path does)
+    segs = [(x[:, :32].contiguous(), 32, 1.0, 0.0), (x[:, 32:35].contiguous(), 3, 1.0, 0.0), (x[:, 35:48].contiguous(), 13, 1.0, 0.0),
+            (x[:, 48:64].contiguous(), 16, 1.0, 0.0), (x[:, 64:67].contiguous(), 3, 1.0, 0.0)]
+    y2 = fields.mlp_forward(1, segs, *[T(g[f"rad_sd_layers.{i}.{k}"]) for i in (0, 2, 4) for k in ("weight", "bias")], 3)
+    assert torch.equal(y, y2)
+    # material net (LipshitzMLP normalisation folded on the host: network_utils.py:396-403)
+    Ws, bs = [], []
+    for i in range(3):
+        w = g[f"mat_sd_weights_per_layer.{i}"]
+        c = float(g[f"mat_sd_lipshitz_bound_per_layer.{i}"][0])
+        sp = np.log1p(np.exp(c)) if c < 20 else c
+        Ws.append((w * np.minimum(sp / np.abs(w).sum(1), 1.0)[:, None]).astype(np.float32))
+        bs.append(g[f"mat_sd_biases_per_layer.{i}"])
+    y = fields.mlp_forward(2, [(T(g["mat_x"]), 48, 1.0, 0.0)], T(Ws[0]), T(bs[0]), T(Ws[1]), T(bs[1]), T(Ws[2]), T(bs[2]), 5)
+    ref = 1 / (1 + np.exp(-g["mat_y"].astype(np.float64)))
+    np.testing.assert_allclose(N(y), ref, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 70001])
+def test_sdf_field_vs_oracle(oracle, fields, n):
+    """VolumeSDF (hash grid + xyz -> MLP) incl. the analytic normal, ragged sizes around the 64-point tile."""
+    geo = fields.VolumeSDF(seed=0).to(DEV)
+    with torch.no_grad():
+        geo.grid_params.copy_((torch.rand(geo.grid_params.shape, generator=torch.Generator().manual_seed(1)) * 2 - 1) * 0.05)
+        for p in geo.network.parameters():
+            p.add_(torch.randn(p.shape, generator=torch.Generator().manual_seed(2)).to(DEV) * 0.02)
+    bbox = torch.tensor([[-0.9, -1.2, -0.3], [0.9, 0.8, 0.3]], device=DEV)
+    geo.prepare_bbox(bbox)
+    geo.update_step(0, 1500)            # progressive mask: 4 + (1500-500)//125 = 12 levels active
+    rng = np.random.default_rng(n)
+    pts = (rng.random((n, 3)) * (N(bbox[1]) - N(bbox[0])) + N(bbox[0])).astype(np.float32)
+    sdf, grad, feat = geo(T(pts), with_grad=True, with_feature=True)
+    l0, l2 = geo.network.layers[0], geo.network.layers[2]
+    mask = N(geo.prog.mask(1500, "cpu"))
+    assert mask.sum() == 24
+    sr, gr, fr = oracle.sdf_field(pts, N(geo.center), N(geo.scale), N(geo.grid_params), mask, N(l0.effective()),
+                                  N(l0.bias), N(l2.effective()), N(l2.bias))
+    np.testing.assert_allclose(N(sdf), sr, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(N(feat), fr, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(N(grad), gr, rtol=2e-3, atol=2e-3)           # |grad| ~ 1..50, hash J ~ 4096*0.05
+    sdf2 = geo(T(pts), with_grad=False, with_feature=False)
+    np.testing.assert_allclose(N(sdf2), sr, rtol=1e-4, atol=2e-5)
