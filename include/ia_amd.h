@@ -152,6 +152,7 @@ int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt /*[B,N,3]*/, co
                     int D, int H, int W, const float* tfs, const int32_t* bone_ids /*[I]*/,
                     const float* offset, const float* scale, float cvg_threshold, float dvg_threshold,
                     float* x /*[B,N,I,3]*/, float* J_inv /*[B,N,I,3,3]*/, uint8_t* is_valid /*[B,N,I]*/,
+                    float* fwd_J /*[B,N,I,3,3] or NULL: forward LBS Jacobian at each root (= fwd_tfs, deformer_torch.py:49-52)*/,
                     ia_stream_t stream);
 int ia_filter(int64_t N, int I, const float* x /*[1,N,I,3]*/, const uint8_t* mask, uint8_t* out, ia_stream_t stream);
 
@@ -192,6 +193,36 @@ int ia_mlp_fwd(int kind, int64_t n, int n_segs, const float* const* seg_ptr, con
                const float* W1, const float* b1, const float* W2, const float* b2, const float* Wo, const float* bo,
                float* y, int y_stride, const float* jac, int xyz_col, const float* inv_scale_host, float* grad,
                ia_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* SNARF candidate bookkeeping + per-sample shading prep (replaces the mask-index / gather glue of
+ * models/deformers/snarf_deformer.py:187-261 and models/intrinsic_avatar.py:1032-1064,390-394).    */
+/* filter (K9) fused with the per-point count of surviving candidates */
+int ia_deform_filter_count(int64_t P, int I, const float* x /*[P,I,3]*/, const uint8_t* valid /*[P,I]*/,
+                           uint8_t* mask /*[P,I]*/, int32_t* cnt /*[P]*/, ia_stream_t stream);
+/* packed candidate list in (point, init) order; start = exclusive scan of cnt */
+int ia_deform_compact(int64_t P, int I, const float* x, const uint8_t* mask, const int32_t* start,
+                      float* cand_x /*[Q,3]*/, int32_t* cand_src /*[Q] = p*I+i*/, ia_stream_t stream);
+/* first-minimum SDF over each point's candidates (1e5 / zeros / [0,0,1] defaults when none),
+ * gradient pushed to posed space with c2w[cand_src] (3x3, row-major) */
+int ia_deform_select(int64_t P, const int32_t* start, const int32_t* cnt, const float* cand_x,
+                     const int32_t* cand_src, const float* cand_sdf, int sdf_stride, const float* cand_grad /*or NULL*/,
+                     const float* cand_feat /*or NULL*/, int feat_stride, int feat_dim, const float* c2w /*[P*I,9] or NULL*/,
+                     float* pts_cano /*[P,3]*/, float* sdf /*[P]*/, uint8_t* valid /*[P]*/, int32_t* sel /*[P] or NULL*/,
+                     float* grad_posed /*[P,3] or NULL*/, float* grad_cano /*[P,3] or NULL*/, float* feat /*[P,feat_dim] or NULL*/,
+                     ia_stream_t stream);
+/* pts = o[ray] + d[ray] * t,  t = t0 (t1 NULL) or (t0+t1)/2 */
+int ia_ray_points(int64_t n, const float* rays_o, const float* rays_d, const int64_t* ray_indices,
+                  const float* t0, const float* t1, float* pts, ia_stream_t stream);
+/* normals (SMPL + world), reflected view direction mapped to [0,1] for the SH encoding */
+int ia_shade_prep(int64_t n, const float* sdf_grad /*[n,3]*/, const float* rays_d, const int64_t* ray_indices,
+                  const float* w2s_rot /*[9] device*/, float* normal_smpl, float* normal_world, float* refl01,
+                  ia_stream_t stream);
+/* alpha = 1 - exp(-LaplaceDensity(sdf; beta) * dist); dists NULL => dist_const; beta: 1 device float */
+int ia_laplace_alpha(int64_t n, const float* sdf, const float* dists, float dist_const, const float* beta,
+                     float* alpha, ia_stream_t stream);
+int ia_laplace_alpha_bwd(int64_t n, const float* sdf, const float* dists, float dist_const, const float* beta,
+                         const float* g_alpha, float* g_sdf, float* g_beta /*1 float, accumulated*/, ia_stream_t stream);
 
 #ifdef __cplusplus
 }

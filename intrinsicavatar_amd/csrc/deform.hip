@@ -1,0 +1,279 @@
+// deform.hip -- candidate bookkeeping of the SNARF deformer + per-sample shading prep for gfx950.
+// Replaces the boolean-mask gathers / scatters / torch.gather chains of
+//   SNARFDeformer.deform          models/deformers/snarf_deformer.py:187-261
+//   ForwardDeformer.forward       models/deformers/fast_snarf/deformer_torch.py:35-55 (eval branch)
+//   rgb_normal_alpha_fn prologue  models/intrinsic_avatar.py:1032-1064 (positions, normals, reflected dirs)
+//   get_alpha + Laplace density   models/intrinsic_avatar.py:390-394, models/rf/density.py:25-30
+// with four small kernels and no host-side nonzero():
+//   1. filter (K9) fused with the per-point valid-candidate count,
+//   2. exclusive scan (core.hip) -> packed candidate list [Q] in (point, init) order (deterministic),
+//   3. the SDF network runs on the packed list (mlp.hip / hashgrid.hip),
+//   4. select: first-minimum SDF over each point's candidates, gather of position / feature /
+//      canonical gradient, push-forward of the gradient with the blended bone rotation.
+#include "ia_common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+
+// ---- 1. filter + count ---------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void filter_count_kernel(int64_t P, int I, const float* __restrict__ x,
+                                                                const uint8_t* __restrict__ valid,
+                                                                uint8_t* __restrict__ mask, int32_t* __restrict__ cnt)
+{
+    const int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (p >= P) return;
+    int c = 0;
+    for (int i = 0; i < I; i++) {
+        bool keep = valid[p * I + i] != 0;
+        if (keep) {
+            const float xi0 = x[(p * I + i) * 3 + 0], xi1 = x[(p * I + i) * 3 + 1], xi2 = x[(p * I + i) * 3 + 2];
+            for (int j = i + 1; j < I; j++) {
+                if (!valid[p * I + j]) continue;
+                const float d0 = xi0 - x[(p * I + j) * 3 + 0];
+                const float d1 = xi1 - x[(p * I + j) * 3 + 1];
+                const float d2 = xi2 - x[(p * I + j) * 3 + 2];
+                const float dist = d0 * d0 + d1 * d1 + d2 * d2;
+                if ((double)dist < 0.0001 * 0.0001) { keep = false; break; }
+            }
+        }
+        mask[p * I + i] = keep ? 1 : 0;
+        c += keep ? 1 : 0;
+    }
+    cnt[p] = c;
+}
+
+// ---- 2. packed candidate list --------------------------------------------------
+__global__ __launch_bounds__(THREADS) void compact_fill_kernel(int64_t P, int I, const float* __restrict__ x,
+                                                                const uint8_t* __restrict__ mask,
+                                                                const int32_t* __restrict__ start,
+                                                                float* __restrict__ cand_x, int32_t* __restrict__ cand_src)
+{
+    const int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (p >= P) return;
+    int q = start[p];
+    for (int i = 0; i < I; i++) {
+        if (!mask[p * I + i]) continue;
+        cand_x[(int64_t)q * 3 + 0] = x[(p * I + i) * 3 + 0];
+        cand_x[(int64_t)q * 3 + 1] = x[(p * I + i) * 3 + 1];
+        cand_x[(int64_t)q * 3 + 2] = x[(p * I + i) * 3 + 2];
+        cand_src[q] = (int32_t)(p * I + i);
+        q++;
+    }
+}
+
+// ---- 4. select ------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void select_kernel(
+    int64_t P, const int32_t* __restrict__ start, const int32_t* __restrict__ cnt, const float* __restrict__ cand_x,
+    const int32_t* __restrict__ cand_src, const float* __restrict__ cand_sdf, int sdf_stride,
+    const float* __restrict__ cand_grad, const float* __restrict__ cand_feat, int feat_stride, int feat_dim,
+    const float* __restrict__ c2w /*[P*I,3,3]*/, float* __restrict__ pts_cano, float* __restrict__ sdf_out,
+    uint8_t* __restrict__ valid_out, int32_t* __restrict__ sel_out, float* __restrict__ grad_posed,
+    float* __restrict__ grad_cano, float* __restrict__ feat_out)
+{
+    const int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (p >= P) return;
+    const int s = start[p], c = cnt[p];
+    float best = 1e5f;      // snarf_deformer.py:192
+    int bq = -1;
+    for (int j = 0; j < c; j++) {
+        const float v = cand_sdf[(int64_t)(s + j) * sdf_stride];
+        if (v < best) { best = v; bq = s + j; }
+    }
+    sdf_out[p] = best;
+    valid_out[p] = c > 0 ? 1 : 0;
+    if (sel_out) sel_out[p] = bq;
+    if (bq >= 0) {
+        pts_cano[p * 3 + 0] = cand_x[(int64_t)bq * 3 + 0];
+        pts_cano[p * 3 + 1] = cand_x[(int64_t)bq * 3 + 1];
+        pts_cano[p * 3 + 2] = cand_x[(int64_t)bq * 3 + 2];
+    } else {
+        // all candidates invalid (or none below 1e5): torch.min picks slot 0, whose x was zeroed
+        // (deformer_torch.py:47-48) unless slot 0 is itself a valid candidate with sdf >= 1e5
+        pts_cano[p * 3 + 0] = 0.f; pts_cano[p * 3 + 1] = 0.f; pts_cano[p * 3 + 2] = 0.f;
+    }
+    if (grad_posed) {
+        float g0 = 0.f, g1 = 0.f, g2 = 1.f;       // defaults [0,0,1]: snarf_deformer.py:211-218
+        float h0 = 0.f, h1 = 0.f, h2 = 1.f;
+        if (bq >= 0) {
+            h0 = cand_grad[(int64_t)bq * 3 + 0]; h1 = cand_grad[(int64_t)bq * 3 + 1]; h2 = cand_grad[(int64_t)bq * 3 + 2];
+            const float* R = c2w + (int64_t)cand_src[bq] * 9;
+            g0 = R[0] * h0 + R[1] * h1 + R[2] * h2;
+            g1 = R[3] * h0 + R[4] * h1 + R[5] * h2;
+            g2 = R[6] * h0 + R[7] * h1 + R[8] * h2;
+        }
+        grad_posed[p * 3 + 0] = g0; grad_posed[p * 3 + 1] = g1; grad_posed[p * 3 + 2] = g2;
+        if (grad_cano) { grad_cano[p * 3 + 0] = h0; grad_cano[p * 3 + 1] = h1; grad_cano[p * 3 + 2] = h2; }
+    }
+    if (feat_out)
+        for (int k = 0; k < feat_dim; k++)
+            feat_out[p * feat_dim + k] = bq >= 0 ? cand_feat[(int64_t)bq * feat_stride + k] : 0.0f;
+}
+
+// ---- ray points -----------------------------------------------------------------
+// positions = o[ray] + d[ray] * t,  t = t0 (t1 == NULL) or (t0 + t1) / 2
+__global__ __launch_bounds__(THREADS) void ray_points_kernel(int64_t n, const float* __restrict__ rays_o,
+                                                              const float* __restrict__ rays_d,
+                                                              const int64_t* __restrict__ ray_indices,
+                                                              const float* __restrict__ t0, const float* __restrict__ t1,
+                                                              float* __restrict__ pts)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = ray_indices[i];
+    const float t = t1 ? (t0[i] + t1[i]) / 2.0f : t0[i];
+    pts[i * 3 + 0] = rays_o[r * 3 + 0] + rays_d[r * 3 + 0] * t;
+    pts[i * 3 + 1] = rays_o[r * 3 + 1] + rays_d[r * 3 + 1] * t;
+    pts[i * 3 + 2] = rays_o[r * 3 + 2] + rays_d[r * 3 + 2] * t;
+}
+
+__device__ __forceinline__ void normalize3(float v[3], float eps)
+{
+    const float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float d = fmaxf(n, eps);
+    v[0] /= d; v[1] /= d; v[2] /= d;
+}
+
+// shading prep: normal_smpl = normalize(g), normal_world = normalize(g @ R), view_world = normalize(d @ R),
+// refl01 = (reflect(-view_world, normal_world) + 1) / 2    (R = w2s[:3,:3]; intrinsic_avatar.py:1059-1061,
+// snarf_deformer.py:157-160, radiance.py:123-124, models/utils.py:115-116)
+__global__ __launch_bounds__(THREADS) void shade_prep_kernel(int64_t n, const float* __restrict__ sdf_grad,
+                                                              const float* __restrict__ rays_d,
+                                                              const int64_t* __restrict__ ray_indices,
+                                                              const float* __restrict__ R, float* __restrict__ normal_smpl,
+                                                              float* __restrict__ normal_world, float* __restrict__ refl01)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = ray_indices[i];
+    float g[3] = {sdf_grad[i * 3 + 0], sdf_grad[i * 3 + 1], sdf_grad[i * 3 + 2]};
+    float d[3] = {rays_d[r * 3 + 0], rays_d[r * 3 + 1], rays_d[r * 3 + 2]};
+    float nw[3], vw[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        nw[c] = g[0] * R[0 * 3 + c] + g[1] * R[1 * 3 + c] + g[2] * R[2 * 3 + c];
+        vw[c] = d[0] * R[0 * 3 + c] + d[1] * R[1 * 3 + c] + d[2] * R[2 * 3 + c];
+    }
+    normalize3(nw, 1e-6f);
+    normalize3(vw, 1e-6f);
+    normalize3(g, 1e-6f);
+    // reflect(x = -vw, n) = 2 dot(x, n) n - x
+    const float dt = -(vw[0] * nw[0] + vw[1] * nw[1] + vw[2] * nw[2]);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        normal_smpl[i * 3 + c] = g[c];
+        normal_world[i * 3 + c] = nw[c];
+        refl01[i * 3 + c] = ((2.0f * dt * nw[c] + vw[c]) + 1.0f) / 2.0f;
+    }
+}
+
+// alpha = 1 - exp(-sigma(sdf) * dist), sigma = Laplace CDF density (density.py:25-30)
+__global__ __launch_bounds__(THREADS) void laplace_alpha_kernel(int64_t n, const float* __restrict__ sdf,
+                                                                 const float* __restrict__ dists, float dist_const,
+                                                                 const float* __restrict__ beta_p, float* __restrict__ alpha)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float beta = *beta_p;
+    const float s = sdf[i];
+    const float sg = (float)((s > 0.f) - (s < 0.f));
+    const float dens = (1.0f / beta) * (0.5f + 0.5f * sg * expm1f(-fabsf(s) / beta));
+    const float dist = dists ? dists[i] : dist_const;
+    alpha[i] = 1.0f - expf(-dens * dist);
+}
+
+// backward: g_sdf[i] = g_alpha * d alpha / d sdf ; g_beta partial sums -> atomicAdd
+__global__ __launch_bounds__(THREADS) void laplace_alpha_bwd_kernel(int64_t n, const float* __restrict__ sdf,
+                                                                     const float* __restrict__ dists, float dist_const,
+                                                                     const float* __restrict__ beta_p,
+                                                                     const float* __restrict__ g_alpha,
+                                                                     float* __restrict__ g_sdf, float* __restrict__ g_beta)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    float gb = 0.0f;
+    if (i < n) {
+        const float beta = *beta_p;
+        const float s = sdf[i], as = fabsf(s);
+        const float sg = (float)((s > 0.f) - (s < 0.f));
+        const float e = expf(-as / beta);                 // expm1 + 1
+        const float dens = (1.0f / beta) * (0.5f + 0.5f * sg * (e - 1.0f));
+        const float dist = dists ? dists[i] : dist_const;
+        const float ga = g_alpha[i] * dist * expf(-dens * dist);      // d alpha / d dens
+        // d dens / d s = (1/beta) * 0.5 * sg * e * (-sg/beta) = -e / (2 beta^2)   (s != 0)
+        g_sdf[i] = ga * (-(e) / (2.0f * beta * beta)) * (s == 0.f ? 0.f : 1.f);
+        // d dens / d beta = -dens/beta + (1/beta) * 0.5 * sg * e * (as / beta^2)
+        gb = ga * (-dens / beta + 0.5f * sg * e * as / (beta * beta * beta));
+    }
+    // wave reduce then one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gb += __shfl_down(gb, off, 64);
+    if ((threadIdx.x & 63) == 0 && g_beta && gb != 0.0f) atomicAdd(g_beta, gb);
+}
+
+}  // namespace
+
+IA_EXPORT int ia_deform_filter_count(int64_t P, int I, const float* x, const uint8_t* valid, uint8_t* mask,
+                                     int32_t* cnt, ia_stream_t stream)
+{
+    if (P == 0) return IA_OK;
+    filter_count_kernel<<<ia::cdiv(P, THREADS), THREADS, 0, (hipStream_t)stream>>>(P, I, x, valid, mask, cnt);
+    return ia::check_launch("ia_deform_filter_count");
+}
+
+IA_EXPORT int ia_deform_compact(int64_t P, int I, const float* x, const uint8_t* mask, const int32_t* start,
+                                float* cand_x, int32_t* cand_src, ia_stream_t stream)
+{
+    if (P == 0) return IA_OK;
+    compact_fill_kernel<<<ia::cdiv(P, THREADS), THREADS, 0, (hipStream_t)stream>>>(P, I, x, mask, start, cand_x, cand_src);
+    return ia::check_launch("ia_deform_compact");
+}
+
+IA_EXPORT int ia_deform_select(int64_t P, const int32_t* start, const int32_t* cnt, const float* cand_x,
+                               const int32_t* cand_src, const float* cand_sdf, int sdf_stride, const float* cand_grad,
+                               const float* cand_feat, int feat_stride, int feat_dim, const float* c2w,
+                               float* pts_cano, float* sdf, uint8_t* valid, int32_t* sel, float* grad_posed,
+                               float* grad_cano, float* feat, ia_stream_t stream)
+{
+    if (P == 0) return IA_OK;
+    IA_REQUIRE((grad_posed == nullptr) || (cand_grad != nullptr && c2w != nullptr), "grad_posed needs cand_grad and c2w");
+    select_kernel<<<ia::cdiv(P, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+        P, start, cnt, cand_x, cand_src, cand_sdf, sdf_stride, cand_grad, cand_feat, feat_stride, feat_dim, c2w,
+        pts_cano, sdf, valid, sel, grad_posed, grad_cano, feat);
+    return ia::check_launch("ia_deform_select");
+}
+
+IA_EXPORT int ia_ray_points(int64_t n, const float* rays_o, const float* rays_d, const int64_t* ray_indices,
+                            const float* t0, const float* t1, float* pts, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    ray_points_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, rays_o, rays_d, ray_indices, t0, t1, pts);
+    return ia::check_launch("ia_ray_points");
+}
+
+IA_EXPORT int ia_shade_prep(int64_t n, const float* sdf_grad, const float* rays_d, const int64_t* ray_indices,
+                            const float* w2s_rot, float* normal_smpl, float* normal_world, float* refl01,
+                            ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    shade_prep_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, sdf_grad, rays_d, ray_indices, w2s_rot,
+                                                                               normal_smpl, normal_world, refl01);
+    return ia::check_launch("ia_shade_prep");
+}
+
+IA_EXPORT int ia_laplace_alpha(int64_t n, const float* sdf, const float* dists, float dist_const, const float* beta,
+                               float* alpha, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    laplace_alpha_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, sdf, dists, dist_const, beta, alpha);
+    return ia::check_launch("ia_laplace_alpha");
+}
+
+IA_EXPORT int ia_laplace_alpha_bwd(int64_t n, const float* sdf, const float* dists, float dist_const,
+                                   const float* beta, const float* g_alpha, float* g_sdf, float* g_beta,
+                                   ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    laplace_alpha_bwd_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, sdf, dists, dist_const, beta,
+                                                                                      g_alpha, g_sdf, g_beta);
+    return ia::check_launch("ia_laplace_alpha_bwd");
+}

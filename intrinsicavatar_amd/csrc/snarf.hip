@@ -146,7 +146,7 @@ __global__ __launch_bounds__(THREADS) void broyden_kernel(
     int64_t total, int64_t N, int I, const float* __restrict__ xd_tgt, const float* __restrict__ voxel_J, int D, int H,
     int W, const float* __restrict__ tfs, const int32_t* __restrict__ bone_ids, const float* __restrict__ offset_g,
     const float* __restrict__ scale_g, float cvg_threshold, float dvg_threshold, float* __restrict__ x,
-    float* __restrict__ J_inv, uint8_t* __restrict__ is_valid)
+    float* __restrict__ J_inv, uint8_t* __restrict__ is_valid, float* __restrict__ fwd_J)
 {
     const int64_t index = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     if (index >= total) return;
@@ -207,6 +207,11 @@ __global__ __launch_bounds__(THREADS) void broyden_kernel(
                 float* Jo = J_inv + index * 9;
                 Jo[0] = J00; Jo[1] = J01; Jo[2] = J02; Jo[3] = J10; Jo[4] = J11; Jo[5] = J12;
                 Jo[6] = J20; Jo[7] = J21; Jo[8] = J22;
+                if (fwd_J) {   // forward LBS Jacobian at the root == blended bone rotation (fwd_tfs, deformer_torch.py:49-52)
+                    float* Fo = fwd_J + index * 9;
+                    Fo[0] = Jl[0]; Fo[1] = Jl[1]; Fo[2] = Jl[2]; Fo[3] = Jl[4]; Fo[4] = Jl[5]; Fo[5] = Jl[6];
+                    Fo[6] = Jl[8]; Fo[7] = Jl[9]; Fo[8] = Jl[10];
+                }
             }
             return;
         } else if (norm_gx > dvg_threshold * dvg_threshold) {
@@ -255,7 +260,7 @@ IA_EXPORT int ia_precompute(int B, int D, int H, int W, const float* voxel_w, co
 IA_EXPORT int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt, const float* voxel_J, int layout, int D,
                               int H, int W, const float* tfs, const int32_t* bone_ids, const float* offset,
                               const float* scale, float cvg_threshold, float dvg_threshold, float* x, float* J_inv,
-                              uint8_t* is_valid, ia_stream_t stream)
+                              uint8_t* is_valid, float* fwd_J, ia_stream_t stream)
 {
     const int64_t total = (int64_t)B * N * I;
     if (total == 0) return IA_OK;
@@ -265,11 +270,11 @@ IA_EXPORT int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt, cons
     if (layout == IA_LAYOUT_NDHWC)
         broyden_kernel<IA_LAYOUT_NDHWC><<<grid, THREADS, 0, s>>>(total, N, I, xd_tgt, voxel_J, D, H, W, tfs, bone_ids,
                                                                  offset, scale, cvg_threshold, dvg_threshold, x, J_inv,
-                                                                 is_valid);
+                                                                 is_valid, fwd_J);
     else
         broyden_kernel<IA_LAYOUT_NCDHW><<<grid, THREADS, 0, s>>>(total, N, I, xd_tgt, voxel_J, D, H, W, tfs, bone_ids,
                                                                  offset, scale, cvg_threshold, dvg_threshold, x, J_inv,
-                                                                 is_valid);
+                                                                 is_valid, fwd_J);
     return ia::check_launch("ia_fuse_broyden");
 }
 

@@ -1,0 +1,118 @@
+"""Host-side mirror of the reference's SNARF deformer on the MI355X kernels:
+
+  SNARFDeformer (models/deformers/snarf_deformer.py:38-264) + ForwardDeformer
+  (models/deformers/fast_snarf/deformer_torch.py:21-197), eval / no-pose-gradient path.
+
+One `deform()` call = Broyden root search for 13 bone initialisations (K8) -> duplicate filter fused
+with candidate counting (K9) -> packed candidate list -> SDF network on the candidates -> first-min
+select + gather + normal push-forward (ia_deform_select).  The only host sync is the read-back of
+the candidate count (the reference syncs twice per call with cudaDeviceSynchronize and once per
+boolean-mask index).
+"""
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+from . import fast_snarf
+
+
+class SNARFDeformer:
+    INIT_BONES = [0, 1, 2, 4, 5, 10, 11, 12, 15, 16, 17, 18, 19]    # deformer_torch.py:27
+
+    def __init__(self, lbs_voxel_final: Tensor, offset_kernel: Tensor, scale_kernel: Tensor, bbox: Tensor):
+        self.lbs_voxel_final = lbs_voxel_final.contiguous().float()          # [1,24,D,H,W]
+        self.offset_kernel = offset_kernel.reshape(3).contiguous().float()
+        self.scale_kernel = scale_kernel.reshape(3).contiguous().float()
+        self.bbox = bbox                                                     # [2,3] canonical bbox (deformer_torch.py:157)
+        self.device = self.lbs_voxel_final.device
+        self.init_bones = torch.tensor(self.INIT_BONES, dtype=torch.int32, device=self.device)
+        self.tfs = None
+        self.voxel_J_cl = None
+        self.voxel_d = None
+        self.w2s = None
+
+    # -- per frame -------------------------------------------------------------------
+    def prepare(self, tfs: Tensor, w2s: Tensor):
+        """prepare_deformer (snarf_deformer.py:81-126) minus the SMPL forward (out of scope: tfs are inputs)."""
+        _, _, D, H, W = self.lbs_voxel_final.shape
+        self.tfs = tfs.contiguous().float()
+        self.w2s = w2s.contiguous().float()
+        B = self.tfs.shape[0]
+        self.voxel_d = torch.empty((B, 3, D, H, W), device=self.device)
+        self.voxel_J_cl = torch.empty((B, D, H, W, 12), device=self.device)
+        fast_snarf.precompute(self.lbs_voxel_final, self.tfs, self.voxel_d, None, self.offset_kernel, self.scale_kernel,
+                              voxel_J_cl=self.voxel_J_cl)
+
+    def transform_rays_w2s(self, rays: Tensor) -> Tensor:
+        """snarf_deformer.py:128-147."""
+        w2s = self.w2s
+        rays_o = rays[:, :3] @ w2s[:3, :3].T + w2s[None, :3, 3]
+        rays_d = rays[:, 3:6] @ w2s[:3, :3].T
+        d = torch.linalg.norm(rays_o, dim=-1, keepdim=True)
+        return torch.cat([rays_o, rays_d, d - 1, d + 1], dim=-1)
+
+    # -- per query batch -------------------------------------------------------------
+    @torch.no_grad()
+    def search(self, pts: Tensor, want_fwd: bool = False):
+        """K8 for all 13 inits. returns x [P,13,3], valid [P,13] (pre-filter), fwd_J [P,13,3,3] or None."""
+        P = pts.shape[0]
+        I = self.init_bones.shape[0]
+        x = torch.zeros((1, P, I, 3), device=self.device)
+        Jinv = torch.zeros((1, P, I, 3, 3), device=self.device)
+        valid = torch.zeros((1, P, I), dtype=torch.bool, device=self.device)
+        fwd = torch.zeros((1, P, I, 3, 3), device=self.device) if want_fwd else None
+        fast_snarf.fuse_broyden(x, pts.reshape(1, P, 3), None, fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs,
+                                self.init_bones, True, Jinv, valid, self.offset_kernel, self.scale_kernel, 1e-5, 1e-1,
+                                fwd_J=fwd)
+        return x[0], valid[0], (fwd[0] if want_fwd else None)
+
+    @torch.no_grad()
+    def deform(self, pts: Tensor, geometry, with_grad: bool = False, with_feature: bool = False):
+        """SNARFDeformer.deform (snarf_deformer.py:187-261).
+        returns dict(pts_cano, sdf, valid[, sdf_grad, sdf_grad_cano][, feature], + bookkeeping)."""
+        pts = pts.contiguous().float()
+        P, I = pts.shape[0], self.init_bones.shape[0]
+        dev = self.device
+        lib, st = L.lib(), L.stream()
+        x, valid, fwd = self.search(pts, want_fwd=with_grad)
+        mask = torch.empty((P, I), dtype=torch.bool, device=dev)
+        cnt = torch.empty(P, dtype=torch.int32, device=dev)
+        start = torch.empty(P, dtype=torch.int32, device=dev)
+        total = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.check(lib.ia_deform_filter_count(L.i64(P), L.i32(I), L.ptr(x), L.ptr(valid), L.ptr(mask), L.ptr(cnt), st),
+                "ia_deform_filter_count")
+        tmp = L.scan_tmp(P, dev)
+        L.check(lib.ia_exclusive_scan_i32(L.ptr(cnt), L.ptr(start), L.ptr(total), L.i64(P), L.ptr(tmp), st), "scan")
+        Q = int(total.item())
+        cand_x = torch.empty((Q, 3), device=dev)
+        cand_src = torch.empty(Q, dtype=torch.int32, device=dev)
+        L.check(lib.ia_deform_compact(L.i64(P), L.i32(I), L.ptr(x), L.ptr(mask), L.ptr(start), L.ptr(cand_x),
+                                      L.ptr(cand_src), st), "ia_deform_compact")
+        # SDF network on the packed candidates
+        cg = cf = None
+        if with_grad or with_feature:
+            r = geometry(cand_x, with_grad=with_grad, with_feature=True)
+            if with_grad:
+                _, cg, cf = r
+            else:
+                _, cf = r
+            csdf, sdf_stride = cf, 13              # sdf == feature[:, 0]
+        else:
+            csdf, sdf_stride = geometry(cand_x, with_grad=False, with_feature=False), 1
+        out = dict(pts_cano=torch.empty((P, 3), device=dev), sdf=torch.empty(P, device=dev),
+                   valid=torch.empty(P, dtype=torch.bool, device=dev), sel=torch.empty(P, dtype=torch.int32, device=dev),
+                   cand_src=cand_src, n_candidates=Q)
+        if with_grad:
+            out["sdf_grad"] = torch.empty((P, 3), device=dev)
+            out["sdf_grad_cano"] = torch.empty((P, 3), device=dev)
+        if with_feature:
+            out["feature"] = torch.empty((P, 13), device=dev)
+        L.check(lib.ia_deform_select(
+            L.i64(P), L.ptr(start), L.ptr(cnt), L.ptr(cand_x), L.ptr(cand_src), L.ptr(csdf), L.i32(sdf_stride),
+            L.ptr(cg), L.ptr(cf if with_feature else None), L.i32(13), L.i32(13), L.ptr(fwd),
+            L.ptr(out["pts_cano"]), L.ptr(out["sdf"]), L.ptr(out["valid"]), L.ptr(out["sel"]),
+            L.ptr(out.get("sdf_grad")), L.ptr(out.get("sdf_grad_cano")), L.ptr(out.get("feature")), st),
+            "ia_deform_select")
+        return out

@@ -42,7 +42,7 @@ def precompute(voxel_w: Tensor, tfs: Tensor, voxel_d: Tensor, voxel_J: Tensor, o
 
 def fuse_broyden(x: Tensor, xd_tgt: Tensor, voxel: Tensor, voxel_J, tfs: Tensor, bone_ids: Tensor,
                  align_corners: bool, J_inv: Tensor, is_valid: Tensor, offset: Tensor, scale: Tensor,
-                 cvg_threshold: float, dvg_threshold: float) -> None:
+                 cvg_threshold: float, dvg_threshold: float, fwd_J: Tensor = None) -> None:
     """fuse_kernel.fuse_broyden (deformer_torch.py:109-121). x, J_inv, is_valid are caller-zeroed
     in/out tensors. `voxel` (voxel_d) and `align_corners` are accepted and ignored, exactly like
     the reference kernel. voxel_J: Tensor [B,12,D,H,W] or ChannelLastVoxelJ."""
@@ -66,7 +66,7 @@ def fuse_broyden(x: Tensor, xd_tgt: Tensor, voxel: Tensor, voxel_J, tfs: Tensor,
     L.check(L.lib().ia_fuse_broyden(L.i32(B), L.i64(N), L.i32(I), L.ptr(xd), L.ptr(vj), L.i32(layout), L.i32(D),
                                     L.i32(H), L.i32(W), L.ptr(tfs), L.ptr(bones), L.ptr(off), L.ptr(sc),
                                     L.f32(cvg_threshold), L.f32(dvg_threshold), L.ptr(x), L.ptr(J_inv),
-                                    L.ptr(is_valid), L.stream()), "ia_fuse_broyden")
+                                    L.ptr(is_valid), L.ptr(fwd_J), L.stream()), "ia_fuse_broyden")
 
 
 def filter(x: Tensor, mask: Tensor) -> Tensor:

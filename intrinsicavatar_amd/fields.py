@@ -241,3 +241,67 @@ class LaplaceDensity(nn.Module):
     def forward(self, sdf):
         beta = self.get_beta()
         return torch.reciprocal(beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
+
+
+class VolumeRefDirRadiance(nn.Module):
+    """models/rf/radiance.py:82-135: [hash#2(32)+xyz(3) | feat(13) | SH4(reflect(-d,n))*mask (16) | n_world (3)] -> 64 -> 64 -> 3."""
+
+    def __init__(self, seed: Optional[int] = 1):
+        super().__init__()
+        self.xyz_encoding = nn.Module()
+        self.xyz_encoding.encoding = nn.Module()
+        self.xyz_encoding.encoding.encoding = HashEncoding(seed=seed)
+        self.network = nn.Module()
+        self.network.layers = nn.ModuleList([_Linear(67, 64), nn.Identity(), _Linear(64, 64), nn.Identity(), _Linear(64, 3)])
+        g = torch.Generator().manual_seed(seed if seed is not None else 0)
+        for i in (0, 2, 4):        # VanillaMLP.make_linear, non-sphere init (network_utils.py:232-234)
+            lin = self.network.layers[i]
+            w = torch.empty_like(lin.weight)
+            bound = math.sqrt(6.0 / w.shape[1])      # kaiming_uniform_(nonlinearity='relu'): gain sqrt(2), bound = gain*sqrt(3/fan_in)
+            with torch.no_grad():
+                lin.weight.copy_((torch.rand(w.shape, generator=g) * 2 - 1) * bound)
+        self.prog = ProgressiveMask()
+        self.global_step = 25000
+        self.register_buffer("sh_mask", torch.ones(1, 16))
+        self.register_buffer("center", torch.zeros(3), persistent=False)
+        self.register_buffer("scale", torch.ones(3), persistent=False)
+        self.start_step, self.full_band_step = 0, 1
+
+    def prepare_bbox(self, bbox):
+        self.center = ((bbox[0] + bbox[1]) / 2).to(self.center)
+        self.scale = (bbox[1] - bbox[0]).to(self.scale)
+
+    def update_step(self, epoch, global_step):
+        self.global_step = global_step
+        t = max(global_step - self.start_step, 0.0)      # radiance.py:140-155
+        alpha = 4 * t / (self.full_band_step - self.start_step)
+        idx = 0
+        for deg in range(4):
+            w = (1.0 - math.cos(math.pi * min(max(alpha - deg, 0.0), 1.0))) / 2.0
+            self.sh_mask[..., idx:idx + deg * 2 + 1] = w
+            idx += deg * 2 + 1
+
+    @property
+    def grid_params(self):
+        return self.xyz_encoding.encoding.encoding.params
+
+    def effective_weights(self):
+        """kernel column order [hash(32) | xyz(3) | feat(13) | sh(16) | normal(3)]; masks folded into W1."""
+        W1 = self.network.layers[0].weight                     # reference order [xyz(3) hash(32) feat(13) sh(16) normal(3)]
+        m = self.prog.mask(self.global_step, W1.device)
+        W1k = torch.cat([W1[:, 3:35] * m[None], W1[:, :3], W1[:, 35:48], W1[:, 48:64] * self.sh_mask, W1[:, 64:67]], 1)
+        l = self.network.layers
+        return W1k, l[0].bias, l[2].weight, l[2].bias, l[4].weight, l[4].bias
+
+    @torch.no_grad()
+    def forward(self, points: Tensor, features: Tensor, refl01: Tensor, normal_world: Tensor):
+        """returns rgb [n,3] (sigmoid applied). `refl01` = (reflect(-view, n)+1)/2 from ia_shade_prep."""
+        n = points.shape[0]
+        if n == 0:
+            return points.new_empty(0, 3)
+        xp = ((points - self.center) / self.scale + 0.5).contiguous()
+        enc = hashgrid_forward(xp, self.grid_params)
+        sh = sh4(refl01)
+        segs = [(enc, 32, 1.0, 0.0), (xp, 3, 2.0, -1.0), (features.contiguous(), 13, 1.0, 0.0), (sh, 16, 1.0, 0.0),
+                (normal_world.contiguous(), 3, 1.0, 0.0)]
+        return mlp_forward(1, segs, *self.effective_weights(), 3)

@@ -1,0 +1,139 @@
+"""render_step on the MI355X kernels: host-side mirror of IntrinsicAvatarModel.forward_
+(models/intrinsic_avatar.py:950-1651), radiance + SDF-geometry part (BASELINE config 2):
+
+  1  rays world -> SMPL space                     snarf_deformer.py:128-147
+  2  primary march through the occupancy grid     intrinsic_avatar.py:1158-1182   -> ia_traverse_grids_*
+  3  2x importance re-sampling (no grad)          :1185-1238  coarse_alpha_fn :955-998, alpha_fn :1000-1030
+        SDF at edges / mid-points (deformer + SDF net) -> alpha -> T2 weights -> K2 merge(16) -> keep fg
+  4  intervals -> (t_starts, t_ends, ray_indices) :1242-1247
+  5  shade + composite                            :1272-1287  rendering_with_normals_sdf (volrend.py:638-807)
+        deformer + SDF(grad, feature) -> normals, alpha, radiance -> T2 -> T3 (rgb, normal, opacity, depth)
+
+Every random tensor of the reference is an explicit input: `jitter` for the
+stratified near plane.  All heavy work is in libia_amd.so; torch is used for allocation and the
+boolean-mask bookkeeping between the operators (exactly where the reference uses it).
+"""
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+from . import lib_nerfacc, nerfacc
+from .deformer import SNARFDeformer
+from .nerfacc import RayIntervals
+
+
+def ray_points(rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor, t0: Tensor, t1: Optional[Tensor] = None) -> Tensor:
+    n = ray_indices.shape[0]
+    pts = torch.empty((n, 3), device=rays_o.device)
+    L.check(L.lib().ia_ray_points(L.i64(n), L.ptr(rays_o), L.ptr(rays_d), L.ptr(ray_indices), L.ptr(t0), L.ptr(t1),
+                                  L.ptr(pts), L.stream()), "ia_ray_points")
+    return pts
+
+
+def laplace_alpha(sdf: Tensor, dists, beta: Tensor) -> Tensor:
+    """get_alpha (intrinsic_avatar.py:390-394); dists: tensor [n] or python float."""
+    n = sdf.shape[0]
+    alpha = torch.empty_like(sdf)
+    d_t, d_c = (dists, 0.0) if isinstance(dists, Tensor) else (None, float(dists))
+    L.check(L.lib().ia_laplace_alpha(L.i64(n), L.ptr(sdf), L.ptr(d_t), L.f32(d_c), L.ptr(beta), L.ptr(alpha), L.stream()),
+            "ia_laplace_alpha")
+    return alpha
+
+
+def shade_prep(sdf_grad: Tensor, rays_d: Tensor, ray_indices: Tensor, w2s_rot: Tensor):
+    n = sdf_grad.shape[0]
+    dev = sdf_grad.device
+    ns, nw, rf = (torch.empty((n, 3), device=dev) for _ in range(3))
+    L.check(L.lib().ia_shade_prep(L.i64(n), L.ptr(sdf_grad), L.ptr(rays_d), L.ptr(ray_indices), L.ptr(w2s_rot), L.ptr(ns),
+                                  L.ptr(nw), L.ptr(rf), L.stream()), "ia_shade_prep")
+    return ns, nw, rf
+
+
+class RenderStep:
+    """One frame's render_step.  `occ_binaries` [1,64,64,64] bool + `occ_aabb` [1,6] = the (test-time)
+    occupancy grid of the frame (prepare_test_occupancy_grid, intrinsic_avatar.py:360-381)."""
+
+    def __init__(self, geometry, radiance, density, deformer: SNARFDeformer, occ_binaries: Tensor, occ_aabb: Tensor,
+                 render_step_size: float, importance_sample: bool = True):
+        self.geometry, self.radiance, self.density, self.deformer = geometry, radiance, density, deformer
+        self.binaries, self.aabbs = occ_binaries, occ_aabb
+        self.grid_bits = nerfacc.pack_occupancy_bits(occ_binaries[0])
+        self.render_step_size = float(render_step_size)
+        self.importance_sample = importance_sample
+
+    # ------------------------------------------------------------------ helpers
+    def _beta(self) -> Tensor:
+        return self.density.get_beta().detach().reshape(1).float().contiguous()
+
+    @torch.no_grad()
+    def _sdf_at(self, pts: Tensor) -> Tensor:
+        return self.deformer.deform(pts, self.geometry)["sdf"]
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, rays: Tensor, jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        dfm = self.deformer
+        rays = dfm.transform_rays_w2s(rays.float())
+        n_rays = rays.shape[0]
+        rays_o, rays_d, far = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous(), rays[:, 7]
+        beta = self._beta()
+        # -- 2. primary march (sampling_override, intrinsic_avatar.py:49-141; near 0 / far 1e10)
+        near_planes = torch.zeros(n_rays, device=rays.device)
+        far_planes = torch.full((n_rays,), 1e10, device=rays.device)
+        if jitter is not None:
+            near_planes = near_planes + jitter * self.render_step_size
+        intervals, samples, _ = nerfacc.traverse_grids(rays_o, rays_d, self.binaries, self.aabbs, near_planes, far_planes,
+                                                       self.render_step_size, 0.0, grid_bits=self.grid_bits)
+        stats = dict(n_edges0=intervals.vals.shape[0], n_samples0=samples.vals.shape[0])
+        # -- 3. importance resampling
+        if self.importance_sample and samples.vals.numel() > 0:
+            for it in range(2):
+                if it == 0:        # coarse_alpha_fn: SDF at every edge, interval sdf = min(left, right)
+                    pts = ray_points(rays_o, rays_d, intervals.ray_indices, intervals.vals)
+                    sdf = self._sdf_at(pts)
+                    sdf_merge = torch.full_like(sdf, 1e10)
+                    sdf_merge[intervals.is_left] = torch.minimum(sdf[intervals.is_left], sdf[intervals.is_right])
+                    alphas = laplace_alpha(sdf_merge, self.render_step_size, beta)
+                else:              # alpha_fn: SDF at interval mid-points
+                    il, ir = intervals.is_left, intervals.is_right
+                    ts, te = intervals.vals[il], intervals.vals[ir]
+                    pts = ray_points(rays_o, rays_d, intervals.ray_indices[il], ts, te)
+                    sdf_curr = self._sdf_at(pts)
+                    sdf = torch.full_like(intervals.vals, 1e10)
+                    sdf[il] = sdf_curr
+                    dists = torch.zeros_like(intervals.vals)
+                    dists[il] = te - ts
+                    alphas = laplace_alpha(sdf, dists, beta)
+                weights, _ = nerfacc.render_weight_from_alpha(alphas, packed_info=intervals.packed_info)
+                rpi, rvals, rdists, ril, rir, is_res, is_fg = lib_nerfacc.ray_resampling_merge(
+                    intervals.packed_info, intervals.vals, intervals.is_left, intervals.is_right, weights, 16)
+                ray_idx = lib_nerfacc.unpack_info(rpi, rvals.shape[0])[is_fg]
+                intervals = RayIntervals(vals=rvals[is_fg], is_left=ril[is_fg], is_right=rir[is_fg], ray_indices=ray_idx,
+                                         packed_info=lib_nerfacc.pack_info(ray_idx, n_rays))
+        # -- 4.
+        t_starts = intervals.vals[intervals.is_left]
+        t_ends = intervals.vals[intervals.is_right]
+        ray_indices = intervals.ray_indices[intervals.is_left]
+        packed_info = lib_nerfacc.pack_info(ray_indices, n_rays)
+        S = t_starts.shape[0]
+        stats["n_samples"] = S
+        # -- 5. shade + composite (rgb_normal_alpha_fn + rendering_with_normals_sdf)
+        pts = ray_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
+        d = dfm.deform(pts, self.geometry, with_grad=True, with_feature=True)
+        w2s_rot = dfm.w2s[:3, :3].contiguous()
+        normal_smpl, normal_world, refl01 = shade_prep(d["sdf_grad"], rays_d, ray_indices, w2s_rot)
+        dists = t_ends - t_starts
+        alphas = laplace_alpha(d["sdf"], dists, beta)
+        rgbs = self.radiance(d["pts_cano"], d["feature"], refl01, normal_world)
+        weights, trans = nerfacc.render_weight_from_alpha(alphas, packed_info=packed_info)
+        acc = lambda v: nerfacc._Accumulate.apply(weights, v, ray_indices, packed_info)      # noqa: E731
+        colors, normals, opac = acc(rgbs), acc(normal_world), acc(None)
+        depths = acc(((t_starts + t_ends) / 2.0)[:, None])
+        depths = depths + (1.0 - opac) * far[:, None]                   # intrinsic_avatar.py:1287
+        stats["n_candidates"] = d["n_candidates"]
+        return dict(comp_rgb=colors, comp_normal=normals, opacity=opac, depth=depths, weights=weights, trans=trans,
+                    alphas=alphas, rgbs=rgbs, sdf=d["sdf"], sdf_grad=d["sdf_grad"], normals=normal_smpl,
+                    positions=d["pts_cano"], valid=d["valid"], t_starts=t_starts, t_ends=t_ends,
+                    ray_indices=ray_indices, packed_info=packed_info, stats=stats)

@@ -171,3 +171,62 @@ def make_scene(height=128, width=128, pose_seed=0, res=64):
     aabb = body_aabb(rig["joints_posed"])
     occ = occupancy_grid(rig["joints_posed"], aabb, res)
     return dict(rays=rays, aabb=aabb, binaries=occ, rig=rig)
+
+
+# ----------------------------------------------------------------------------- full synthetic frame (torch / GPU side)
+def build_frame(device="cuda:0", height=128, width=128, pose_seed=0, beta=0.01, hash_amp=1e-4, num_samples_per_ray=128,
+                grid_D=32, grid_H=128, grid_W=128, smooth_iters=30, occ_res=64, seed=0):
+    """Random-init model of the reference's architecture + synthetic rig + per-frame occupancy grid.
+    Returns (RenderStep, rays_world [H*W, 8] tensor, export dict of numpy arrays for the CPU oracle)."""
+    import torch
+    from . import fields, render
+    from .deformer import SNARFDeformer
+
+    w, offk, sck, bbox = skinning_weight_grid(grid_D, grid_H, grid_W, smooth_iters=smooth_iters)
+    rig = make_rig(make_pose(pose_seed))
+    dev = torch.device(device)
+    dfm = SNARFDeformer(torch.from_numpy(w).to(dev), torch.from_numpy(offk).to(dev), torch.from_numpy(sck).to(dev),
+                        torch.from_numpy(bbox).to(dev))
+    dfm.prepare(torch.from_numpy(rig["tfs"]).to(dev), torch.from_numpy(rig["w2s"]).to(dev))
+    geo = fields.VolumeSDF(seed=seed).to(dev)
+    rad = fields.VolumeRefDirRadiance(seed=seed + 1).to(dev)
+    if hash_amp != 1e-4:
+        with torch.no_grad():
+            geo.grid_params.mul_(hash_amp / 1e-4)
+            rad.grid_params.mul_(hash_amp / 1e-4)
+    geo.prepare_bbox(dfm.bbox)
+    rad.prepare_bbox(dfm.bbox)
+    dens = fields.LaplaceDensity(beta_init=beta).to(dev)
+    step = 4.330127018922194 / num_samples_per_ray     # |scene_aabb diag| / num_samples_per_ray, intrinsic_avatar.py:197-211
+    aabb = body_aabb(rig["joints_posed"])
+    # per-frame occupancy grid from the MODEL (prepare_test_occupancy_grid, intrinsic_avatar.py:307-381):
+    # 3 jittered samples per voxel -> alpha -> max -> 3^3 dilation -> threshold (largest-CC filter: SURVEY 8(f).1)
+    g = torch.Generator().manual_seed(seed + 7)
+    idx = torch.stack(torch.meshgrid([torch.arange(occ_res)] * 3, indexing="ij"), -1).reshape(-1, 1, 3).float()
+    xs = ((idx + torch.rand((occ_res ** 3, 3, 3), generator=g)) / occ_res).reshape(-1, 3)
+    lo, hi = torch.from_numpy(aabb[:3]), torch.from_numpy(aabb[3:])
+    xs = (xs * (hi - lo) + lo).to(dev)
+    sdf = dfm.deform(xs, geo)["sdf"]
+    alpha = render.laplace_alpha(sdf, step, dens.get_beta().detach().reshape(1))
+    occs = alpha.reshape(-1, 3).max(1)[0]
+    occs_ = torch.nn.functional.max_pool3d(occs.reshape(1, 1, occ_res, occ_res, occ_res), 3, 1, 1)[0, 0]
+    thre = torch.clamp(occs_[occs_ >= 0].mean(), max=0.01)
+    binaries = (occs_ > thre)[None].contiguous()
+    rs = render.RenderStep(geo, rad, dens, dfm, binaries, torch.from_numpy(aabb)[None].to(dev), step)
+    rays = torch.from_numpy(camera_rays(height, width)).to(dev)
+    N = lambda t: t.detach().cpu().numpy()      # noqa: E731
+    l0, l2 = geo.network.layers[0], geo.network.layers[2]
+    vJ = torch.empty((1, 12, grid_D, grid_H, grid_W), device=dev)
+    from . import fast_snarf
+    fast_snarf.precompute(dfm.lbs_voxel_final, dfm.tfs, None, vJ, dfm.offset_kernel, dfm.scale_kernel)
+    rl = rad.network.layers
+    export = dict(
+        w2s=rig["w2s"], tfs=rig["tfs"], voxel_J=N(vJ), offset_kernel=offk.reshape(3), scale_kernel=sck.reshape(3),
+        binaries=N(binaries[0]), aabb=aabb, step=step, beta=float(dens.get_beta()),
+        geo_center=N(geo.center), geo_scale=N(geo.scale), geo_params=N(geo.grid_params),
+        geo_mask=N(geo.prog.mask(geo.global_step, "cpu")), geo_W1=N(l0.effective()), geo_b1=N(l0.bias),
+        geo_W2=N(l2.effective()), geo_b2=N(l2.bias),
+        rad_center=N(rad.center), rad_scale=N(rad.scale), rad_params=N(rad.grid_params),
+        rad_mask=N(rad.prog.mask(rad.global_step, "cpu")), rad_sh_mask=N(rad.sh_mask[0]),
+        rad_W=[N(rl[i].weight) for i in (0, 2, 4)], rad_b=[N(rl[i].bias) for i in (0, 2, 4)])
+    return rs, rays, export

@@ -51,7 +51,8 @@ def test_hashgrid_fwd_and_jacobian_vs_oracle(oracle, fields):
     # known-answer: dense level 0 == trilinear interpolation of its 16^3 lattice
     total, offs, res, sc = oracle.hashgrid_offsets()
     lat = params[: 16 ** 3 * 2].reshape(16, 16, 16, 2)                     # index = x + y*16 + z*256
-    p = x[100:200] * sc[0] + 0.5
+    sel = np.where((x < 0.9).all(1))[0][:100]
+    p = x[sel] * sc[0] + 0.5
     i0 = np.floor(p).astype(int)
     f = p - i0
     tri = np.zeros((100, 2), np.float32)
@@ -60,7 +61,7 @@ def test_hashgrid_fwd_and_jacobian_vs_oracle(oracle, fields):
         w = np.prod(np.where(o, f, 1 - f), axis=1)
         idx = i0 + o
         tri += w[:, None] * lat[idx[:, 2], idx[:, 1], idx[:, 0]]
-    np.testing.assert_allclose(N(enc)[100:200, :2], tri, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(N(enc)[sel, :2], tri, rtol=1e-4, atol=1e-6)
 
 
 def test_hashgrid_bwd_vs_oracle(oracle, fields):
