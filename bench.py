@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- render_step throughput on MI355X (BASELINE.json metric: rays/sec at 540x540).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" is one pass of the render_step hot path over one 540x540 frame (291 600 primary rays) of
+synthetic input: BASELINE config 2 (128 samples/ray, radiance + SDF geometry, fast-SNARF deformer,
+random-init network of the reference's architecture, synthetic 24-bone rig; inputs resident in HBM).
+Multi-GPU: frames / ray batches shard across ranks with replicated parameters (weak scaling: one
+frame per rank per step).  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     -- the dominant kernel of the step (by HIP-event time measured live in the timed region)
+                  priced against its roofline with SURVEY.md 8(d)'s algorithmic bytes;
+  cpu_baseline -- the CPU oracle (oracle/render_ref.py, a port) on a bounded ray sample of the same frame,
+                  rank 0 / N == 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3     # fp32-in MFMA dense peak
+
+
+def algorithmic_bytes(name, stats):
+    """SURVEY.md 8(d) per-unit algorithmic bytes x units of ONE step, per C-ABI entry point."""
+    n, E0, S0 = stats["n_rays"], stats["n_edges0"], stats["n_samples0"]
+    trav = 48 * n + 16 * S0 + 14 * E0
+    P = stats["deform_points"]          # total points pushed through the deformer in one step
+    Q = stats["sdf_points"]             # total candidates through the SDF network
+    return {
+        "ia_traverse_grids_count": trav, "ia_traverse_grids_fill": trav,
+        # Broyden: per (point, init) 12 B + 64 B tfs row + <= 11 fetches x 8 corners x 48 B + 49 B out
+        "ia_fuse_broyden": P * 13 * (12 + 64 + 11 * 8 * 48 + 49),
+        # hash grid fwd: 12 B in + 16 levels x 8 corners x 8 B gathered + 128 B out (+384 B Jacobian when asked)
+        "ia_hashgrid_fwd": (Q + stats["n_samples"]) * (12 + 1024 + 128),
+        "ia_mlp_fwd": Q * (35 + 13) * 4 + stats["n_samples"] * (67 + 3) * 4,
+    }.get(name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--hw", type=int, default=540)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback in the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from intrinsicavatar_amd import build
+    if rank == 0:
+        build.build()
+    if world > 1:
+        dist.barrier()
+    from intrinsicavatar_amd import synthetic as S, _lib as L
+
+    # one frame per rank (frame-/ray-batch sharding, replicated parameters)
+    rs, rays, export = S.build_frame(dev, args.hw, args.hw, pose_seed=rank, beta=0.01, num_samples_per_ray=128)
+    n_rays = rays.shape[0]
+
+    def step():
+        return rs.forward(rays)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    lib = L.lib()
+    lib.start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    per_call = lib.report()
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * n_rays * args.steps / dt
+
+    if rank == 0:
+        stats = dict(out["stats"])
+        stats["n_rays"] = n_rays
+        # points through the deformer per step: edges (it0) + intervals (it1) + final samples
+        calls_b, ms_b = per_call.get("ia_fuse_broyden", (0, 0.0))
+        stats["deform_points"] = stats["n_edges0"] + 2 * stats["n_samples"]       # ~ (it1 has fewer intervals; upper est.)
+        stats["sdf_points"] = stats["deform_points"]                               # ~1 surviving candidate / point
+        total_ms = sum(v[1] for v in per_call.values())
+        dom = max(per_call.items(), key=lambda kv: kv[1][1])
+        dname, (dcalls, dms) = dom
+        launches_per_step = dcalls / args.steps
+        ab = algorithmic_bytes(dname, stats)
+        roofline = None
+        if ab:
+            per_launch_bytes = ab / launches_per_step
+            avg_us = dms / dcalls * 1e3
+            achieved = per_launch_bytes / (avg_us * 1e-6) / 1e9
+            roofline = dict(kernel=dname, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                            frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=None,
+                            avg_launch_us=round(avg_us, 1), launches_per_step=launches_per_step,
+                            algorithmic_bytes_per_launch=int(per_launch_bytes),
+                            share_of_kernel_time=round(dms / max(total_ms, 1e-9), 3))
+        breakdown = {k: dict(calls_per_step=v[0] / args.steps, ms_per_step=round(v[1] / args.steps, 3))
+                     for k, v in sorted(per_call.items(), key=lambda kv: -kv[1][1])[:10]}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import render_ref as R, oracle as O
+            O.build()
+            stride = max(1, n_rays // 12000)
+            sample = rays[::stride].cpu().numpy()
+            sc = R.Scene(**export)
+            tc = time.perf_counter()
+            R.render_step(sc, sample)
+            tcpu = time.perf_counter() - tc
+            cpu = dict(value=round(sample.shape[0] / tcpu, 1), unit="rays/s", cores=1, kind="port",
+                       sample=f"every {stride}th ray of the same 540x540 frame ({sample.shape[0]} rays), "
+                              f"oracle/render_ref.py render_step forward, {tcpu:.1f} s single-threaded")
+        line = {
+            "metric": "rays/sec at 540x540 (render_step, BASELINE config 2)", "value": round(value, 1), "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.hw}x{args.hw} frame ({n_rays} rays), 128 samples/ray, radiance + SDF geometry, "
+                                   "fast-SNARF deformer (13 inits), 2x importance resampling, random-init hash-grid/MLP "
+                                   "fields, synthetic 24-bone rig",
+                       "pass": "forward", "frames_per_step_per_gpu": 1, "parallelism": f"frame/ray-batch sharding x{world}",
+                       "samples": stats},
+            "roofline": roofline, "cpu_baseline": cpu, "kernel_breakdown_ms_per_step": breakdown,
+            "host_overhead_ms_per_step": round(ms_per_step - total_ms / args.steps, 3),
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

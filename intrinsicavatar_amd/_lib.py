@@ -17,6 +17,43 @@ class IaError(RuntimeError):
     pass
 
 
+class _Timed:
+    """optional per-entry-point HIP-event timing (bench.py): events are recorded on the stream the
+    kernels are launched on (torch's current stream), nothing synchronises until report()."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        self.enabled = False
+        self.events = {}
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)
+        if not name.startswith("ia_") or name in ("ia_last_error", "ia_scan_tmp_bytes", "ia_version", "ia_hashgrid_n_entries"):
+            return fn
+
+        def call(*args):
+            if not self.enabled:
+                return fn(*args)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            self.events.setdefault(name, []).append((e0, e1))
+            return rc
+        return call
+
+    def start(self):
+        self.events = {}
+        self.enabled = True
+
+    def report(self):
+        """-> {entry point: (n_calls, total_ms)}; synchronises."""
+        self.enabled = False
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.events.items()}
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -24,10 +61,12 @@ def lib():
             raise IaError(
                 f"{_SO} not found: build it with `python -m intrinsicavatar_amd.build` "
                 "(there is no CPU fallback for the MI355X hot path)")
-        _lib = C.CDLL(_SO)
-        _lib.ia_last_error.restype = C.c_char_p
-        _lib.ia_scan_tmp_bytes.restype = C.c_int64
-        _lib.ia_scan_tmp_bytes.argtypes = [C.c_int64]
+        cdll = C.CDLL(_SO)
+        cdll.ia_last_error.restype = C.c_char_p
+        cdll.ia_scan_tmp_bytes.restype = C.c_int64
+        cdll.ia_scan_tmp_bytes.argtypes = [C.c_int64]
+        cdll.ia_hashgrid_n_entries.restype = C.c_int64
+        _lib = _Timed(cdll)
     return _lib
 
 

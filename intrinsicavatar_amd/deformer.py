@@ -91,16 +91,13 @@ class SNARFDeformer:
         L.check(lib.ia_deform_compact(L.i64(P), L.i32(I), L.ptr(x), L.ptr(mask), L.ptr(start), L.ptr(cand_x),
                                       L.ptr(cand_src), st), "ia_deform_compact")
         # SDF network on the packed candidates
-        cg = cf = None
-        if with_grad or with_feature:
-            r = geometry(cand_x, with_grad=with_grad, with_feature=True)
-            if with_grad:
-                _, cg, cf = r
-            else:
-                _, cf = r
-            csdf, sdf_stride = cf, 13              # sdf == feature[:, 0]
+        cg = None
+        r = geometry(cand_x, with_grad=with_grad, with_feature=True)      # feature[:, 0] is the SDF
+        if with_grad:
+            _, cg, cf = r
         else:
-            csdf, sdf_stride = geometry(cand_x, with_grad=False, with_feature=False), 1
+            _, cf = r
+        csdf, sdf_stride = cf, 13
         out = dict(pts_cano=torch.empty((P, 3), device=dev), sdf=torch.empty(P, device=dev),
                    valid=torch.empty(P, dtype=torch.bool, device=dev), sel=torch.empty(P, dtype=torch.int32, device=dev),
                    cand_src=cand_src, n_candidates=Q)

@@ -29,7 +29,6 @@ HASH = dict(n_levels=16, n_features_per_level=2, log2_hashmap_size=19, base_reso
 
 def hash_n_entries(cfg=HASH) -> int:
     lib = L.lib()
-    lib.ia_hashgrid_n_entries.restype = C.c_int64
     return int(lib.ia_hashgrid_n_entries(L.i32(cfg["n_levels"]), L.i32(cfg["log2_hashmap_size"]),
                                          L.i32(cfg["base_resolution"]), L.f32(cfg["per_level_scale"])))
 
