@@ -224,6 +224,33 @@ int ia_laplace_alpha(int64_t n, const float* sdf, const float* dists, float dist
 int ia_laplace_alpha_bwd(int64_t n, const float* sdf, const float* dists, float dist_const, const float* beta,
                          const float* g_alpha, float* g_sdf, float* g_beta /*1 float, accumulated*/, ia_stream_t stream);
 
+/* ------------------------------------------------------------------------- */
+/* Backward (training step).  The reference obtains these from torch autograd through VanillaMLP /
+ * LipshitzMLP / tcnn, including the double backward through the analytic normal
+ * (models/rf/geometry.py:165-172, create_graph=True). */
+int ia_sh4_bwd(int64_t n, const float* d01, const float* g_sh, int g_stride, float* g_d01, ia_stream_t stream);
+int ia_shade_prep_bwd(int64_t n, const float* sdf_grad, const float* rays_d, const int64_t* ray_indices,
+                      const float* w2s_rot, const float* g_normal_world /*or NULL*/, const float* g_refl01,
+                      float* g_sdf_grad, ia_stream_t stream);
+/* data-path backward of the two-hidden-layer ReLU MLPs (kind 1 radiance, 2 material; sigmoid output):
+ * g_x [n, gx_stride] = d L / d assembled input row; X/A1/A2 (layer inputs) and G1/G2/G3 (pre-activation
+ * gradients) are emitted for the weight-gradient GEMMs dW_l = G_l^T A_{l-1} (plain library GEMM). */
+int ia_mlp_bwd(int kind, int64_t n, int n_segs, const float* const* seg_ptr, const int* seg_stride,
+               const int* seg_width, const float* seg_mul, const float* seg_add,
+               const float* W1, const float* b1, const float* W2, const float* b2, const float* Wo, const float* bo,
+               const float* g_y /*[n,OUT]*/, float* g_x, int gx_stride,
+               float* X /*[n,IN_PAD]*/, float* A1 /*[n,64]*/, float* A2 /*[n,64]*/,
+               float* G1 /*[n,64]*/, float* G2 /*[n,64]*/, float* G3 /*[n,16]*/, ia_stream_t stream);
+/* SDF head with first- and second-order terms (see csrc/mlp_bwd.hip):
+ * in : g_out [n,13] = d L / d out, q [n,3] = d L / d (d sdf / d x') ; jac = hash-grid dy_dx
+ * out: gE, gG [n,32] for ia_hashgrid_bwd(g_enc = gE, g_jac = gG, q); operand pairs
+ *      dW1 = DZ^T Hh + GZ^T U, db1 = sum DZ, dW2 = g_out^T A (+ row 0 += sum DGS), db2 = sum g_out */
+int ia_sdf_mlp_bwd(int64_t n, int n_segs, const float* const* seg_ptr, const int* seg_stride, const int* seg_width,
+                   const float* seg_mul, const float* seg_add, const float* W1, const float* b1, const float* Wo,
+                   const float* bo, const float* jac, const float* g_out, const float* q, float* gE, float* gG,
+                   float* Hh /*[n,36]*/, float* U /*[n,36]*/, float* DZ /*[n,64]*/, float* GZ /*[n,64]*/,
+                   float* A /*[n,64]*/, float* DGS /*[n,64]*/, ia_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

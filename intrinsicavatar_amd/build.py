@@ -24,6 +24,7 @@ SOURCES = {
     "snarf.hip": ["-ffp-contract=off"],
     "hashgrid.hip": ["-munsafe-fp-atomics"],
     "mlp.hip": [],
+    "mlp_bwd.hip": [],
     "deform.hip": ["-ffp-contract=off"],
 }
 

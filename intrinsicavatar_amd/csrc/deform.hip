@@ -167,6 +167,51 @@ __global__ __launch_bounds__(THREADS) void shade_prep_kernel(int64_t n, const fl
     }
 }
 
+// backward of shade_prep w.r.t. sdf_grad: g_nw (direct) and g_refl01 (through the SH input) -> g_sdf_grad
+__global__ __launch_bounds__(THREADS) void shade_prep_bwd_kernel(int64_t n, const float* __restrict__ sdf_grad,
+                                                                  const float* __restrict__ rays_d,
+                                                                  const int64_t* __restrict__ ray_indices,
+                                                                  const float* __restrict__ R, const float* __restrict__ g_nw,
+                                                                  const float* __restrict__ g_refl01,
+                                                                  float* __restrict__ g_sdf_grad)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = ray_indices[i];
+    const float g[3] = {sdf_grad[i * 3 + 0], sdf_grad[i * 3 + 1], sdf_grad[i * 3 + 2]};
+    const float d[3] = {rays_d[r * 3 + 0], rays_d[r * 3 + 1], rays_d[r * 3 + 2]};
+    float nwu[3], vw[3], nw[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        nwu[c] = g[0] * R[0 * 3 + c] + g[1] * R[1 * 3 + c] + g[2] * R[2 * 3 + c];
+        vw[c] = d[0] * R[0 * 3 + c] + d[1] * R[1 * 3 + c] + d[2] * R[2 * 3 + c];
+    }
+    normalize3(vw, 1e-6f);
+    const float len = sqrtf(nwu[0] * nwu[0] + nwu[1] * nwu[1] + nwu[2] * nwu[2]);
+    const float den = fmaxf(len, 1e-6f);
+#pragma unroll
+    for (int c = 0; c < 3; c++) nw[c] = nwu[c] / den;
+    const float dt = -(vw[0] * nw[0] + vw[1] * nw[1] + vw[2] * nw[2]);
+    float G[3];
+    float gr_dot_nw = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) gr_dot_nw += 0.5f * g_refl01[i * 3 + c] * nw[c];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+        G[c] = (g_nw ? g_nw[i * 3 + c] : 0.f) + 2.0f * dt * 0.5f * g_refl01[i * 3 + c] - 2.0f * gr_dot_nw * vw[c];
+    float Gu[3];
+    if (len > 1e-6f) {
+        const float dn = nw[0] * G[0] + nw[1] * G[1] + nw[2] * G[2];
+#pragma unroll
+        for (int c = 0; c < 3; c++) Gu[c] = (G[c] - nw[c] * dn) / len;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; c++) Gu[c] = G[c] / 1e-6f;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) g_sdf_grad[i * 3 + a] = Gu[0] * R[a * 3 + 0] + Gu[1] * R[a * 3 + 1] + Gu[2] * R[a * 3 + 2];
+}
+
 // alpha = 1 - exp(-sigma(sdf) * dist), sigma = Laplace CDF density (density.py:25-30)
 __global__ __launch_bounds__(THREADS) void laplace_alpha_kernel(int64_t n, const float* __restrict__ sdf,
                                                                  const float* __restrict__ dists, float dist_const,
@@ -258,6 +303,16 @@ IA_EXPORT int ia_shade_prep(int64_t n, const float* sdf_grad, const float* rays_
     shade_prep_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, sdf_grad, rays_d, ray_indices, w2s_rot,
                                                                                normal_smpl, normal_world, refl01);
     return ia::check_launch("ia_shade_prep");
+}
+
+IA_EXPORT int ia_shade_prep_bwd(int64_t n, const float* sdf_grad, const float* rays_d, const int64_t* ray_indices,
+                                const float* w2s_rot, const float* g_normal_world, const float* g_refl01,
+                                float* g_sdf_grad, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    shade_prep_bwd_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, sdf_grad, rays_d, ray_indices, w2s_rot,
+                                                                                   g_normal_world, g_refl01, g_sdf_grad);
+    return ia::check_launch("ia_shade_prep_bwd");
 }
 
 IA_EXPORT int ia_laplace_alpha(int64_t n, const float* sdf, const float* dists, float dist_const, const float* beta,

@@ -192,7 +192,49 @@ __global__ __launch_bounds__(THREADS) void sh4_kernel(int64_t n, const float* __
     o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
 }
 
+// d L / d d01 given d L / d sh (x = 2 d01 - 1 => factor 2)
+__global__ __launch_bounds__(THREADS) void sh4_bwd_kernel(int64_t n, const float* __restrict__ d01,
+                                                           const float* __restrict__ g, int g_stride,
+                                                           float* __restrict__ g_d01)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float x = d01[i * 3 + 0] * 2.f - 1.f, y = d01[i * 3 + 1] * 2.f - 1.f, z = d01[i * 3 + 2] * 2.f - 1.f;
+    const float x2 = x * x, y2 = y * y, z2 = z * z;
+    const float* go = g + i * g_stride;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    gy += go[1] * -0.48860251190291987f;
+    gz += go[2] * 0.48860251190291987f;
+    gx += go[3] * -0.48860251190291987f;
+    gx += go[4] * 1.0925484305920792f * y;           gy += go[4] * 1.0925484305920792f * x;
+    gy += go[5] * -1.0925484305920792f * z;          gz += go[5] * -1.0925484305920792f * y;
+    gz += go[6] * 2.0f * 0.94617469575755997f * z;
+    gx += go[7] * -1.0925484305920792f * z;          gz += go[7] * -1.0925484305920792f * x;
+    gx += go[8] * 2.0f * 0.54627421529603959f * x;   gy += go[8] * -2.0f * 0.54627421529603959f * y;
+    gx += go[9] * 0.59004358992664352f * y * (-6.0f * x);
+    gy += go[9] * 0.59004358992664352f * (-3.0f * x2 + 3.0f * y2);
+    gx += go[10] * 2.8906114426405538f * y * z;      gy += go[10] * 2.8906114426405538f * x * z;
+    gz += go[10] * 2.8906114426405538f * x * y;
+    gy += go[11] * 0.45704579946446572f * (1.0f - 5.0f * z2);
+    gz += go[11] * 0.45704579946446572f * y * (-10.0f * z);
+    gz += go[12] * 0.3731763325901154f * (15.0f * z2 - 3.0f);
+    gx += go[13] * 0.45704579946446572f * (1.0f - 5.0f * z2);
+    gz += go[13] * 0.45704579946446572f * x * (-10.0f * z);
+    gx += go[14] * 1.4453057213202769f * z * 2.0f * x; gy += go[14] * 1.4453057213202769f * z * -2.0f * y;
+    gz += go[14] * 1.4453057213202769f * (x2 - y2);
+    gx += go[15] * 0.59004358992664352f * (-3.0f * x2 + 3.0f * y2);
+    gy += go[15] * 0.59004358992664352f * x * 6.0f * y;
+    g_d01[i * 3 + 0] = 2.0f * gx; g_d01[i * 3 + 1] = 2.0f * gy; g_d01[i * 3 + 2] = 2.0f * gz;
+}
+
 }  // namespace
+
+IA_EXPORT int ia_sh4_bwd(int64_t n, const float* d01, const float* g_sh, int g_stride, float* g_d01, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    sh4_bwd_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, d01, g_sh, g_stride, g_d01);
+    return ia::check_launch("ia_sh4_bwd");
+}
 
 IA_EXPORT int64_t ia_hashgrid_n_entries(int n_levels, int log2_hashmap_size, int base_resolution, float per_level_scale)
 {

@@ -69,14 +69,14 @@ class SNARFDeformer:
         return x[0], valid[0], (fwd[0] if want_fwd else None)
 
     @torch.no_grad()
-    def deform(self, pts: Tensor, geometry, with_grad: bool = False, with_feature: bool = False):
+    def deform(self, pts: Tensor, geometry, with_grad: bool = False, with_feature: bool = False, want_fwd: bool = False):
         """SNARFDeformer.deform (snarf_deformer.py:187-261).
         returns dict(pts_cano, sdf, valid[, sdf_grad, sdf_grad_cano][, feature], + bookkeeping)."""
         pts = pts.contiguous().float()
         P, I = pts.shape[0], self.init_bones.shape[0]
         dev = self.device
         lib, st = L.lib(), L.stream()
-        x, valid, fwd = self.search(pts, want_fwd=with_grad)
+        x, valid, fwd = self.search(pts, want_fwd=with_grad or want_fwd)
         mask = torch.empty((P, I), dtype=torch.bool, device=dev)
         cnt = torch.empty(P, dtype=torch.int32, device=dev)
         start = torch.empty(P, dtype=torch.int32, device=dev)
@@ -100,7 +100,7 @@ class SNARFDeformer:
         csdf, sdf_stride = cf, 13
         out = dict(pts_cano=torch.empty((P, 3), device=dev), sdf=torch.empty(P, device=dev),
                    valid=torch.empty(P, dtype=torch.bool, device=dev), sel=torch.empty(P, dtype=torch.int32, device=dev),
-                   cand_src=cand_src, n_candidates=Q)
+                   cand_src=cand_src, n_candidates=Q, fwd_J=fwd)
         if with_grad:
             out["sdf_grad"] = torch.empty((P, 3), device=dev)
             out["sdf_grad_cano"] = torch.empty((P, 3), device=dev)

@@ -71,9 +71,11 @@ class RenderStep:
     def _sdf_at(self, pts: Tensor) -> Tensor:
         return self.deformer.deform(pts, self.geometry)["sdf"]
 
-    # ------------------------------------------------------------------ forward
+    # ------------------------------------------------------------------ sampling (no grad)
     @torch.no_grad()
-    def forward(self, rays: Tensor, jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    def sample(self, rays: Tensor, jitter: Optional[Tensor] = None):
+        """steps 1-4 of forward_: world->SMPL rays, primary march, 2x importance resampling.
+        returns (rays_o, rays_d, far, t_starts, t_ends, ray_indices, packed_info, stats)."""
         dfm = self.deformer
         rays = dfm.transform_rays_w2s(rays.float())
         n_rays = rays.shape[0]
@@ -117,8 +119,15 @@ class RenderStep:
         t_ends = intervals.vals[intervals.is_right]
         ray_indices = intervals.ray_indices[intervals.is_left]
         packed_info = lib_nerfacc.pack_info(ray_indices, n_rays)
-        S = t_starts.shape[0]
-        stats["n_samples"] = S
+        stats["n_samples"] = t_starts.shape[0]
+        return rays_o, rays_d, far, t_starts, t_ends, ray_indices, packed_info, stats
+
+    # ------------------------------------------------------------------ forward (eval)
+    @torch.no_grad()
+    def forward(self, rays: Tensor, jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        dfm = self.deformer
+        rays_o, rays_d, far, t_starts, t_ends, ray_indices, packed_info, stats = self.sample(rays, jitter)
+        beta = self._beta()
         # -- 5. shade + composite (rgb_normal_alpha_fn + rendering_with_normals_sdf)
         pts = ray_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
         d = dfm.deform(pts, self.geometry, with_grad=True, with_feature=True)
@@ -137,3 +146,20 @@ class RenderStep:
                     alphas=alphas, rgbs=rgbs, sdf=d["sdf"], sdf_grad=d["sdf_grad"], normals=normal_smpl,
                     positions=d["pts_cano"], valid=d["valid"], t_starts=t_starts, t_ends=t_ends,
                     ray_indices=ray_indices, packed_info=packed_info, stats=stats)
+
+    # ------------------------------------------------------------------ forward + backward (training step)
+    def parameters(self):
+        return list(self.geometry.parameters()) + list(self.radiance.parameters()) + list(self.density.parameters())
+
+    def forward_backward(self, rays: Tensor, target_rgb: Tensor, target_mask: Optional[Tensor] = None,
+                         jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        """one optimisation step's fwd+bwd (training_step, systems/intrinsic_avatar.py:160-251, rgb/eikonal/mask
+        terms): no-grad sampling, differentiable shading + compositing, loss, backward to every parameter."""
+        from . import train
+        rays_o, rays_d, far, t_starts, t_ends, ray_indices, packed_info, stats = self.sample(rays, jitter)
+        out = train.shade_differentiable(self, rays_o, rays_d, ray_indices, t_starts, t_ends, packed_info)
+        loss = train.training_loss(out, target_rgb, target_mask)
+        loss.backward()
+        out["loss"] = loss.detach()
+        out["stats"] = stats
+        return out

@@ -1,0 +1,205 @@
+"""Differentiable (training) form of the shading pass of render_step on the MI355X kernels.
+
+The reference trains through `rgb_normal_alpha_fn` + `rendering_with_normals_sdf`
+(models/intrinsic_avatar.py:1032-1064,1272-1287; models/volrend.py:638-807) with torch autograd,
+including the double backward through the analytic normal (models/rf/geometry.py:165-172).  Here
+each stage is a torch.autograd.Function whose forward AND backward are HIP kernels behind the C ABI:
+
+    _SDFField      hash grid + SDF MLP -> (feature[13], d sdf/d x)      ia_hashgrid_fwd/bwd, ia_mlp_fwd, ia_sdf_mlp_bwd
+    _ShadePrep     normals / reflected direction                         ia_shade_prep(_bwd)
+    _Alpha         Laplace density -> alpha                              ia_laplace_alpha(_bwd)
+    _Radiance      hash grid #2 + SH + radiance MLP                      ia_hashgrid_fwd/bwd, ia_sh4_fwd/bwd, ia_mlp_fwd/bwd
+    nerfacc._WeightFromAlpha / _Accumulate                               ia_render_weight_from_alpha(_bwd), ia_accumulate_*(_bwd)
+
+Sample positions, the candidate search and the winner selection are not differentiated, exactly as in the
+reference (resampling under no_grad; torch.gather passes gradients to the winning candidate only).  The tiny
+weight-gradient reductions dW = G^T A ([64 x n] x [n x <=68]) go through torch.matmul (rocBLAS), a plain library GEMM.
+"""
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from . import _lib as L
+from . import fields, lib_nerfacc, nerfacc, render
+
+
+def _segs(segs):
+    ns = len(segs)
+    ptrs = (C.c_void_p * ns)()
+    strides = (C.c_int * ns)()
+    widths = (C.c_int * ns)()
+    muls = (C.c_float * ns)()
+    adds = (C.c_float * ns)()
+    for i, (t, w, m, a) in enumerate(segs):
+        assert t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1
+        ptrs[i], strides[i], widths[i], muls[i], adds[i] = t.data_ptr(), t.stride(0), w, m, a
+    return ns, ptrs, strides, widths, muls, adds
+
+
+class _SDFField(Function):
+    """(x_cano, table, W1k, b1, W2, b2) -> (out[n,13], grad[n,3]); grads w.r.t. table and weights (1st + 2nd order)."""
+
+    @staticmethod
+    def forward(ctx, x, table, W1k, b1, W2, b2, center, scale):
+        xp = ((x - center) / scale + 0.5).contiguous()
+        enc, jac = fields.hashgrid_forward(xp, table, with_jac=True)
+        inv = (1.0 / scale).tolist()
+        y, grad = fields.mlp_forward(0, [(enc, 32, 1.0, 0.0), (xp, 3, 2.0, -1.0)], W1k, b1, None, None, W2, b2, 13,
+                                     jac=jac, xyz_col=32, inv_scale=inv, want_grad=True)
+        ctx.save_for_backward(xp, enc, jac, table, W1k.contiguous(), b1.contiguous(), W2.contiguous(), b2.contiguous(), scale)
+        return y, grad
+
+    @staticmethod
+    def backward(ctx, g_y, g_grad):
+        xp, enc, jac, table, W1k, b1, W2, b2, scale = ctx.saved_tensors
+        n, dev = xp.shape[0], xp.device
+        g_y = g_y.contiguous().float()
+        q = (g_grad / scale).contiguous().float()
+        gE, gG = torch.empty((n, 32), device=dev), torch.empty((n, 32), device=dev)
+        Hh, U = torch.empty((n, 36), device=dev), torch.empty((n, 36), device=dev)
+        DZ, GZ, A, DGS = (torch.empty((n, 64), device=dev) for _ in range(4))
+        ns, ptrs, strides, widths, muls, adds = _segs([(enc, 32, 1.0, 0.0), (xp, 3, 2.0, -1.0)])
+        L.check(L.lib().ia_sdf_mlp_bwd(L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds, L.ptr(W1k), L.ptr(b1),
+                                       L.ptr(W2), L.ptr(b2), L.ptr(jac), L.ptr(g_y), L.ptr(q), L.ptr(gE), L.ptr(gG),
+                                       L.ptr(Hh), L.ptr(U), L.ptr(DZ), L.ptr(GZ), L.ptr(A), L.ptr(DGS), L.stream()),
+                "ia_sdf_mlp_bwd")
+        g_table = torch.zeros_like(table)
+        fields.hashgrid_backward(xp, gE, g_table, g_jac=gG, q=q)
+        dW1k = DZ.t() @ Hh[:, :35] + GZ.t() @ U[:, :35]
+        db1 = DZ.sum(0)
+        dW2 = g_y.t() @ A
+        dW2[0] += DGS.sum(0)
+        db2 = g_y.sum(0)
+        return None, g_table, dW1k, db1, dW2, db2, None, None
+
+
+class _ShadePrep(Function):
+    @staticmethod
+    def forward(ctx, sdf_grad, rays_d, ray_indices, w2s_rot):
+        sdf_grad = sdf_grad.contiguous()
+        ns, nw, rf = render.shade_prep(sdf_grad, rays_d, ray_indices, w2s_rot)
+        ctx.save_for_backward(sdf_grad, rays_d, ray_indices, w2s_rot)
+        ctx.mark_non_differentiable(ns)
+        return ns, nw, rf
+
+    @staticmethod
+    def backward(ctx, _g_ns, g_nw, g_rf):
+        sdf_grad, rays_d, ray_indices, w2s_rot = ctx.saved_tensors
+        n = sdf_grad.shape[0]
+        g_nw = g_nw.contiguous() if g_nw is not None else None
+        g_rf = g_rf.contiguous() if g_rf is not None else torch.zeros_like(sdf_grad)
+        out = torch.empty_like(sdf_grad)
+        L.check(L.lib().ia_shade_prep_bwd(L.i64(n), L.ptr(sdf_grad), L.ptr(rays_d), L.ptr(ray_indices), L.ptr(w2s_rot),
+                                          L.ptr(g_nw), L.ptr(g_rf), L.ptr(out), L.stream()), "ia_shade_prep_bwd")
+        return out, None, None, None
+
+
+class _Alpha(Function):
+    @staticmethod
+    def forward(ctx, sdf, dists, beta):
+        sdf, dists = sdf.contiguous(), dists.contiguous()
+        b = beta.detach().reshape(1).float().contiguous()
+        ctx.save_for_backward(sdf, dists, b)
+        return render.laplace_alpha(sdf, dists, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        sdf, dists, b = ctx.saved_tensors
+        g = g.contiguous()
+        g_sdf = torch.empty_like(sdf)
+        g_beta = torch.zeros(1, device=sdf.device)
+        L.check(L.lib().ia_laplace_alpha_bwd(L.i64(sdf.shape[0]), L.ptr(sdf), L.ptr(dists), L.f32(0.0), L.ptr(b), L.ptr(g),
+                                             L.ptr(g_sdf), L.ptr(g_beta), L.stream()), "ia_laplace_alpha_bwd")
+        return g_sdf, None, g_beta.reshape(())
+
+
+class _Radiance(Function):
+    """(x_cano, table2, feat, refl01, normal_world, weights...) -> rgb[n,3] (sigmoid)."""
+
+    @staticmethod
+    def forward(ctx, x, table, feat, refl01, normal_world, W1k, b1, W2, b2, W3, b3, center, scale):
+        xp = ((x - center) / scale + 0.5).contiguous()
+        enc = fields.hashgrid_forward(xp, table)
+        refl01 = refl01.contiguous()
+        sh = fields.sh4(refl01)
+        feat, normal_world = feat.contiguous(), normal_world.contiguous()
+        segs = [(enc, 32, 1.0, 0.0), (xp, 3, 2.0, -1.0), (feat, 13, 1.0, 0.0), (sh, 16, 1.0, 0.0), (normal_world, 3, 1.0, 0.0)]
+        ws = [t.contiguous() for t in (W1k, b1, W2, b2, W3, b3)]
+        rgb = fields.mlp_forward(1, segs, *ws, 3)
+        ctx.save_for_backward(xp, enc, feat, refl01, sh, normal_world, table, *ws)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, g_rgb):
+        xp, enc, feat, refl01, sh, normal_world, table, W1k, b1, W2, b2, W3, b3 = ctx.saved_tensors
+        n, dev = xp.shape[0], xp.device
+        g_rgb = g_rgb.contiguous().float()
+        g_x = torch.empty((n, 68), device=dev)
+        X = torch.empty((n, 68), device=dev)
+        A1, A2, G1, G2 = (torch.empty((n, 64), device=dev) for _ in range(4))
+        G3 = torch.empty((n, 16), device=dev)
+        segs = [(enc, 32, 1.0, 0.0), (xp, 3, 2.0, -1.0), (feat, 13, 1.0, 0.0), (sh, 16, 1.0, 0.0), (normal_world, 3, 1.0, 0.0)]
+        ns, ptrs, strides, widths, muls, adds = _segs(segs)
+        L.check(L.lib().ia_mlp_bwd(L.i32(1), L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds, L.ptr(W1k), L.ptr(b1),
+                                   L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3), L.ptr(g_rgb), L.ptr(g_x), L.i32(68),
+                                   L.ptr(X), L.ptr(A1), L.ptr(A2), L.ptr(G1), L.ptr(G2), L.ptr(G3), L.stream()), "ia_mlp_bwd")
+        g_table = torch.zeros_like(table)
+        fields.hashgrid_backward(xp, g_x, g_table)                      # columns 0..31, row stride 68
+        g_feat = g_x[:, 35:48]
+        g_nw = g_x[:, 64:67]
+        g_sh = g_x[:, 48:64]
+        g_refl01 = torch.empty((n, 3), device=dev)
+        L.check(L.lib().ia_sh4_bwd(L.i64(n), L.ptr(refl01), C.c_void_p(g_sh.data_ptr()), L.i32(68), L.ptr(g_refl01),
+                                   L.stream()), "ia_sh4_bwd")
+        dW1 = G1.t() @ X[:, :67]
+        dW2 = G2.t() @ A1
+        dW3 = G3[:, :3].t() @ A2
+        return (None, g_table, g_feat, g_refl01, g_nw, dW1, G1.sum(0), dW2, G2.sum(0), dW3, G3[:, :3].sum(0), None, None)
+
+
+def shade_differentiable(rs, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor, t_starts: Tensor, t_ends: Tensor,
+                         packed_info: Tensor) -> Dict[str, Tensor]:
+    """differentiable rgb_normal_alpha_fn + rendering_with_normals_sdf for the samples found by the no-grad pass."""
+    dfm, geo, rad = rs.deformer, rs.geometry, rs.radiance
+    n_rays = packed_info.shape[0]
+    pts = render.ray_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
+    with torch.no_grad():
+        d = dfm.deform(pts, geo, with_grad=True, with_feature=False)       # candidate search + winner selection
+        valid = d["valid"]
+        sel = d["sel"].long().clamp(min=0)
+        c2w = d["fwd_J"].reshape(-1, 3, 3)[d["cand_src"].long()[sel]] if d["n_candidates"] > 0 else \
+            torch.zeros((pts.shape[0], 3, 3), device=pts.device)
+    W1k, b1, W2, b2 = geo.effective_weights()
+    out, grad_c = _SDFField.apply(d["pts_cano"], geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale)
+    vf = valid[:, None].float()
+    # invalid points: sdf 1e5, feature 0, gradient [0,0,1] (snarf_deformer.py:192-231)
+    dflt_g = torch.tensor([0.0, 0.0, 1.0], device=pts.device)
+    feat = out * vf
+    sdf = torch.where(valid, out[:, 0], torch.full_like(out[:, 0], 1e5))
+    sdf_grad = torch.where(valid[:, None], torch.einsum("bij,bj->bi", c2w, grad_c), dflt_g[None])
+    w2s_rot = dfm.w2s[:3, :3].contiguous()
+    normal_smpl, normal_world, refl01 = _ShadePrep.apply(sdf_grad, rays_d, ray_indices, w2s_rot)
+    alphas = _Alpha.apply(sdf, t_ends - t_starts, rs.density.get_beta())
+    rgbs = _Radiance.apply(d["pts_cano"], rad.grid_params, feat, refl01, normal_world, *rad.effective_weights(),
+                           rad.center, rad.scale)
+    weights, trans = nerfacc._WeightFromAlpha.apply(alphas, packed_info)
+    acc = lambda v: nerfacc._Accumulate.apply(weights, v, ray_indices, packed_info)      # noqa: E731
+    return dict(comp_rgb=acc(rgbs), comp_normal=acc(normal_world), opacity=acc(None),
+                depth=acc(((t_starts + t_ends) / 2.0)[:, None]), weights=weights, alphas=alphas, rgbs=rgbs, sdf=sdf,
+                sdf_grad=sdf_grad, valid=valid, n_samples=pts.shape[0], pts_cano=d["pts_cano"], c2w=c2w)
+
+
+def training_loss(out: Dict[str, Tensor], target_rgb: Tensor, target_mask: Optional[Tensor] = None,
+                  lambda_eik: float = 0.1, lambda_mask: float = 0.1) -> Tensor:
+    """the rgb / eikonal / mask terms of systems/intrinsic_avatar.py:167-251 (L1 rgb, (|grad|-1)^2, BCE opacity)."""
+    loss = (out["comp_rgb"] - target_rgb).abs().mean()
+    v = out["valid"]
+    if v.any():
+        loss = loss + lambda_eik * ((torch.linalg.norm(out["sdf_grad"][v], dim=-1) - 1.0) ** 2).mean()
+    if target_mask is not None:
+        op = out["opacity"][:, 0].clamp(1e-3, 1 - 1e-3)
+        loss = loss + lambda_mask * torch.nn.functional.binary_cross_entropy(op, target_mask)
+    return loss

@@ -1,0 +1,120 @@
+"""Plain-PyTorch (CPU, float64) reference of the differentiable shading pass, used ONLY to check the HIP
+backward kernels: hash grid, SH4, MLPs, analytic normal via autograd.grad(create_graph=True) exactly as
+models/rf/geometry.py:165-172 does, reflect / normalise, Laplace alpha, transmittance weights, accumulation."""
+import math
+
+import torch
+
+
+def hash_cfg(n_levels=16, log2_T=19, base=16, pls=1.447269237440378):
+    import numpy as np
+    offs, ress, scs, off = [], [], [], 0
+    l2 = np.log2(np.float32(pls))
+    for l in range(n_levels):
+        sc = np.float32(np.exp2(np.float32(l) * l2) * np.float32(base) - np.float32(1.0))
+        res = int(np.ceil(sc)) + 1
+        p = min((res ** 3 + 7) // 8 * 8, 1 << log2_T)
+        offs.append(off); ress.append(res); scs.append(float(sc)); off += p
+    offs.append(off)
+    return offs, ress, scs
+
+
+def hashgrid(x01, table, cfg=None):
+    """x01 [n,3] float64 (requires_grad ok), table [entries,2] -> [n,32]."""
+    offs, ress, scs = cfg or hash_cfg()
+    outs = []
+    for l in range(len(ress)):
+        sc, res, hs = scs[l], ress[l], offs[l + 1] - offs[l]
+        pos = x01 * sc + 0.5
+        pg = torch.floor(pos).detach()
+        w = pos - pg
+        pg = pg.long()
+        acc = 0
+        for c in range(8):
+            o = torch.tensor([(c >> 0) & 1, (c >> 1) & 1, (c >> 2) & 1])
+            p = pg + o
+            wc = torch.where(o.bool(), w, 1 - w).prod(-1, keepdim=True)
+            stride, dense_ok = 1, True
+            idx = p[:, 0] * 1
+            stride = res
+            if stride <= hs:
+                idx = idx + p[:, 1] * stride
+                stride *= res
+                if stride <= hs:
+                    idx = idx + p[:, 2] * stride
+                    stride *= res
+            if hs < stride:
+                M = 0xFFFFFFFF
+                idx = ((p[:, 0] * 1) & M) ^ ((p[:, 1] * 2654435761) & M) ^ ((p[:, 2] * 805459861) & M)
+            idx = (idx & 0xFFFFFFFF) % hs
+            acc = acc + wc * table[offs[l] + idx]
+        outs.append(acc)
+    return torch.cat(outs, -1)
+
+
+def sh4(d01):
+    x, y, z = (d01 * 2 - 1).unbind(-1)
+    xy, xz, yz, x2, y2, z2 = x * y, x * z, y * z, x * x, y * y, z * z
+    return torch.stack([
+        torch.full_like(x, 0.28209479177387814), -0.48860251190291987 * y, 0.48860251190291987 * z,
+        -0.48860251190291987 * x, 1.0925484305920792 * xy, -1.0925484305920792 * yz,
+        0.94617469575755997 * z2 - 0.31539156525251999, -1.0925484305920792 * xz,
+        0.54627421529603959 * x2 - 0.54627421529603959 * y2, 0.59004358992664352 * y * (-3.0 * x2 + y2),
+        2.8906114426405538 * xy * z, 0.45704579946446572 * y * (1.0 - 5.0 * z2), 0.3731763325901154 * z * (5.0 * z2 - 3.0),
+        0.45704579946446572 * x * (1.0 - 5.0 * z2), 1.4453057213202769 * z * (x2 - y2),
+        0.59004358992664352 * x * (-x2 + 3.0 * y2)], -1)
+
+
+def shade_reference(P, fixed, target_rgb, target_mask, lambda_eik=0.1, lambda_mask=0.1):
+    """P: dict of float64 leaf tensors (requires_grad) in the REFERENCE layout; fixed: sample set found by the GPU."""
+    x = fixed["pts_cano"].clone().requires_grad_(True)
+    valid = fixed["valid"]
+    # --- VolumeSDF.forward (geometry.py:152-172)
+    xp = (x - P["geo_center"]) / P["geo_scale"] + 0.5
+    enc = hashgrid(xp, P["geo_table"].reshape(-1, 2)) * P["geo_mask"]
+    h = torch.cat([xp * 2 - 1, enc], -1)
+    W1 = P["geo_g0"] * P["geo_v0"] / P["geo_v0"].norm(dim=1, keepdim=True)
+    W2 = P["geo_g2"] * P["geo_v2"] / P["geo_v2"].norm(dim=1, keepdim=True)
+    a = torch.nn.functional.softplus(h @ W1.T + P["geo_b0"], beta=100)
+    out = a @ W2.T + P["geo_b2"]
+    grad_c = torch.autograd.grad(out[:, 0], x, torch.ones_like(out[:, 0]), create_graph=True)[0]
+    vf = valid[:, None].double()
+    feat = out * vf
+    sdf = torch.where(valid, out[:, 0], torch.full_like(out[:, 0], 1e5))
+    sdf_grad = torch.where(valid[:, None], torch.einsum("bij,bj->bi", fixed["c2w"], grad_c), torch.tensor([0., 0., 1.], dtype=x.dtype))
+    # --- shade prep
+    R = fixed["w2s_rot"]
+    nrm = lambda v: v / v.norm(dim=-1, keepdim=True).clamp_min(1e-6)     # noqa: E731
+    nw = nrm(sdf_grad @ R)
+    vw = nrm(fixed["rays_d"][fixed["ray_indices"]] @ R)
+    xx = -vw
+    refl = 2 * (xx * nw).sum(-1, keepdim=True) * nw - xx
+    # --- alpha (density.py:25-30, intrinsic_avatar.py:390-394)
+    beta = P["beta"].abs() + 1e-4
+    dens = (1 / beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
+    alphas = 1 - torch.exp(-dens * (fixed["t_ends"] - fixed["t_starts"]))
+    # --- radiance (radiance.py:111-135)
+    xp2 = (x.detach() - P["rad_center"]) / P["rad_scale"] + 0.5
+    enc2 = hashgrid(xp2, P["rad_table"].reshape(-1, 2)) * P["rad_mask"]
+    inp = torch.cat([xp2 * 2 - 1, enc2, feat, sh4((refl + 1) / 2) * P["rad_sh_mask"], nw], -1)
+    hcur = torch.relu(inp @ P["rad_W0"].T + P["rad_b0"])
+    hcur = torch.relu(hcur @ P["rad_W2"].T + P["rad_b2"])
+    rgbs = torch.sigmoid(hcur @ P["rad_W4"].T + P["rad_b4"])
+    # --- T2 / T3
+    ri = fixed["ray_indices"]
+    n_rays = fixed["n_rays"]
+    trs = []
+    for b, s in fixed["packed_info"].tolist():
+        if s > 0:
+            trs.append(torch.cat([torch.ones(1, dtype=x.dtype), torch.cumprod(1 - alphas[b:b + s], 0)[:-1]]))
+    trans = torch.cat(trs) if trs else alphas[:0]
+    w = trans * alphas
+    comp = torch.zeros(n_rays, 3, dtype=x.dtype).index_add(0, ri, w[:, None] * rgbs)
+    opac = torch.zeros(n_rays, 1, dtype=x.dtype).index_add(0, ri, w[:, None])
+    loss = (comp - target_rgb).abs().mean()
+    if valid.any():
+        loss = loss + lambda_eik * ((sdf_grad[valid].norm(dim=-1) - 1.0) ** 2).mean()
+    if target_mask is not None:
+        op = opac[:, 0].clamp(1e-3, 1 - 1e-3)
+        loss = loss + lambda_mask * torch.nn.functional.binary_cross_entropy(op, target_mask)
+    return loss, dict(comp_rgb=comp, opacity=opac, sdf_grad=sdf_grad, rgbs=rgbs, alphas=alphas)
