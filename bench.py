@@ -44,6 +44,7 @@ def algorithmic_bytes(name, stats):
         "ia_fuse_broyden": P * 13 * (12 + 64 + 11 * 8 * 48 + 49),
         # hash grid fwd: 12 B in + 16 levels x 8 corners x 8 B gathered + 128 B out (+384 B Jacobian when asked)
         "ia_hashgrid_fwd": (Q + stats["n_samples"]) * (12 + 1024 + 128),
+        "ia_hashgrid_bwd": 2 * stats["n_samples"] * (12 + 128 + 1024 + 1024),     # read-modify-write atomics
         "ia_mlp_fwd": Q * (35 + 13) * 4 + stats["n_samples"] * (67 + 3) * 4,
     }.get(name)
 
@@ -55,6 +56,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--hw", type=int, default=540)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pass", dest="mode", choices=["fwd+bwd", "fwd"], default="fwd+bwd",
+                    help="fwd+bwd = training-step form of render_step (BASELINE metric); fwd = inference form")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -80,8 +83,32 @@ def main():
     rs, rays, export = S.build_frame(dev, args.hw, args.hw, pose_seed=rank, beta=0.01, num_samples_per_ray=128)
     n_rays = rays.shape[0]
 
+    params = rs.parameters()
+    g = torch.Generator().manual_seed(1234 + rank)
+    target_rgb = torch.rand((n_rays, 3), generator=g).to(dev)
+    target_mask = (torch.rand(n_rays, generator=g) > 0.5).float().to(dev)
+
     def step():
-        return rs.forward(rays)
+        if args.mode == "fwd":
+            return rs.forward(rays)
+        for p in params:
+            p.grad = None
+        out = rs.forward_backward(rays, target_rgb, target_mask)
+        if world > 1:
+            # the one exchange step of the path: all-reduce(sum) of the gradients over RCCL/xGMI;
+            # two 50.4 MB hash tables dominate, so they go as two large buckets + one small flat bucket
+            small = [p.grad for p in params if p.grad is not None and p.grad.numel() < (1 << 20)]
+            big = [p.grad for p in params if p.grad is not None and p.grad.numel() >= (1 << 20)]
+            hs = [dist.all_reduce(t, async_op=True) for t in big]
+            flat = torch.cat([t.reshape(-1) for t in small])
+            dist.all_reduce(flat)
+            for h in hs:
+                h.wait()
+            off = 0
+            for t in small:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+        return out
 
     for _ in range(args.warmup):
         out = step()
@@ -143,13 +170,13 @@ def main():
                        sample=f"every {stride}th ray of the same 540x540 frame ({sample.shape[0]} rays), "
                               f"oracle/render_ref.py render_step forward, {tcpu:.1f} s single-threaded")
         line = {
-            "metric": "rays/sec at 540x540 (render_step, BASELINE config 2)", "value": round(value, 1), "unit": "rays/s",
+            "metric": "rays/sec (fwd+bwd) at 540x540" if args.mode == "fwd+bwd" else "rays/sec (fwd) at 540x540", "value": round(value, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.hw}x{args.hw} frame ({n_rays} rays), 128 samples/ray, radiance + SDF geometry, "
                                    "fast-SNARF deformer (13 inits), 2x importance resampling, random-init hash-grid/MLP "
                                    "fields, synthetic 24-bone rig",
-                       "pass": "forward", "frames_per_step_per_gpu": 1, "parallelism": f"frame/ray-batch sharding x{world}",
+                       "pass": args.mode, "frames_per_step_per_gpu": 1, "parallelism": f"frame/ray-batch sharding x{world}",
                        "samples": stats},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_breakdown_ms_per_step": breakdown,
             "host_overhead_ms_per_step": round(ms_per_step - total_ms / args.steps, 3),

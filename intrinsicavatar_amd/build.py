@@ -24,7 +24,7 @@ SOURCES = {
     "snarf.hip": ["-ffp-contract=off"],
     "hashgrid.hip": ["-munsafe-fp-atomics"],
     "mlp.hip": [],
-    "mlp_bwd.hip": [],
+    "mlp_bwd.hip": ["-munsafe-fp-atomics"],
     "deform.hip": ["-ffp-contract=off"],
 }
 

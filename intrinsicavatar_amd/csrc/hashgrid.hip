@@ -166,6 +166,84 @@ __global__ __launch_bounds__(THREADS) void hash_bwd_kernel(int64_t n, const floa
     }
 }
 
+// backward w.r.t. the table, run-merged: one lane per POINT, loop over levels and corners.  Samples arrive
+// in marching order, so consecutive lanes very often fall into the same cell (always at the coarse
+// levels, where a plain atomic scatter serialises on a few thousand addresses).  Equal consecutive
+// addresses are merged with a wave-level segmented scan and only the last lane of each run issues
+// the atomics: 64x fewer atomics on the coarse levels, unchanged on the finest, identical result up to
+// summation order.
+template <bool SECOND>
+__global__ __launch_bounds__(THREADS) void hash_bwd_runs_kernel(int64_t n, const float* __restrict__ x, HashCfg cfg,
+                                                                 const float* __restrict__ gE, int gE_stride,
+                                                                 const float* __restrict__ gG, int gG_stride,
+                                                                 const float* __restrict__ q, float* __restrict__ grad)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool active = i < n;
+    const int64_t ii = active ? i : n - 1;
+    const float x0 = x[ii * 3 + 0], x1 = x[ii * 3 + 1], x2 = x[ii * 3 + 2];
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (SECOND) { qx = q[ii * 3 + 0]; qy = q[ii * 3 + 1]; qz = q[ii * 3 + 2]; }
+    for (int l = 0; l < cfg.n_levels; l++) {
+        const float sc = cfg.scale[l];
+        const uint32_t res = cfg.res[l], hsize = cfg.offsets[l + 1] - cfg.offsets[l];
+        float* tab = grad + (int64_t)cfg.offsets[l] * 2;
+        float2 e = make_float2(0.f, 0.f), g = make_float2(0.f, 0.f);
+        if (active) {
+            if (gE) e = *reinterpret_cast<const float2*>(gE + i * gE_stride + l * 2);
+            if (SECOND) g = *reinterpret_cast<const float2*>(gG + i * gG_stride + l * 2);
+        }
+        const bool any_here = (e.x != 0.f) || (e.y != 0.f) || (g.x != 0.f) || (g.y != 0.f);
+        if (!__any(any_here)) continue;                       // masked-out level for the whole wave
+        float pos[3];
+        uint32_t pg[3];
+        {
+            const float xs[3] = {x0, x1, x2};
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const float p = fmaf(sc, xs[d], 0.5f);
+                const float fl = floorf(p);
+                pg[d] = (uint32_t)(int)fl;
+                pos[d] = p - fl;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const float wx = (c & 1) ? pos[0] : 1.0f - pos[0];
+            const float wy = (c & 2) ? pos[1] : 1.0f - pos[1];
+            const float wz = (c & 4) ? pos[2] : 1.0f - pos[2];
+            const float w0 = wx * wy * wz;
+            float vx = e.x * w0, vy = e.y * w0;
+            if (SECOND) {
+                const float dw = ((c & 1) ? sc : -sc) * wy * wz * qx + ((c & 2) ? sc : -sc) * wx * wz * qy +
+                                 ((c & 4) ? sc : -sc) * wx * wy * qz;
+                vx += g.x * dw;
+                vy += g.y * dw;
+            }
+            uint32_t idx = grid_index(hsize, res, pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1));
+            if (!active) { idx = 0xFFFFFFFFu; vx = 0.f; vy = 0.f; }
+            // run heads: lane 0 or address differs from the previous lane
+            const uint32_t prev = __shfl_up(idx, 1, 64);
+            const bool head = (lane == 0) || (prev != idx);
+            const unsigned long long heads = __ballot(head);
+            // position of this lane's run head = highest set bit of heads at or below `lane`
+            const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+            const int hpos = 63 - __clzll(below);
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float ax = __shfl_up(vx, off, 64), ay = __shfl_up(vy, off, 64);
+                if (lane - off >= hpos) { vx += ax; vy += ay; }
+            }
+            const bool tail = (lane == 63) || ((heads >> (lane + 1)) & 1ull);
+            if (tail && active && (vx != 0.f || vy != 0.f)) {
+                unsafeAtomicAdd(tab + (int64_t)idx * 2 + 0, vx);
+                unsafeAtomicAdd(tab + (int64_t)idx * 2 + 1, vy);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(THREADS) void sh4_kernel(int64_t n, const float* __restrict__ d01, float* __restrict__ out,
                                                        int out_stride)
 {
@@ -273,10 +351,10 @@ IA_EXPORT int ia_hashgrid_bwd(int64_t n, const float* x, int n_levels, int n_fea
     IA_REQUIRE((g_jac == nullptr) == (q == nullptr), "g_jac and q go together");
     HashCfg c;
     make_cfg(c, n_levels, log2_hashmap_size, base_resolution, per_level_scale);
-    const int grid = ia::cdiv(n * n_levels, THREADS);
     hipStream_t s = (hipStream_t)stream;
-    if (g_jac) hash_bwd_kernel<true><<<grid, THREADS, 0, s>>>(n, x, c, g_enc, g_enc_stride, g_jac, g_jac_stride, q, grad_params);
-    else hash_bwd_kernel<false><<<grid, THREADS, 0, s>>>(n, x, c, g_enc, g_enc_stride, nullptr, 0, nullptr, grad_params);
+    const int grid = ia::cdiv(n, THREADS);     // run-merged kernel: one lane per point
+    if (g_jac) hash_bwd_runs_kernel<true><<<grid, THREADS, 0, s>>>(n, x, c, g_enc, g_enc_stride, g_jac, g_jac_stride, q, grad_params);
+    else hash_bwd_runs_kernel<false><<<grid, THREADS, 0, s>>>(n, x, c, g_enc, g_enc_stride, nullptr, 0, nullptr, grad_params);
     return ia::check_launch("ia_hashgrid_bwd");
 }
 

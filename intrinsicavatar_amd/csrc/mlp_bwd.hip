@@ -366,6 +366,75 @@ __global__ __launch_bounds__(THREADS) void sdf_bwd_kernel(SdfBwdArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// split-K weight gradient:  dW[M x N] += G[n x M]^T . A[n x N]   (M <= 64, N <= 96; K = n points)
+// rocBLAS maps this tall-skinny product to ONE output tile (a single workgroup walking K = millions);
+// here K is split over the whole chip: each wave owns 64-row slabs, keeps the 2 x 3 MFMA accumulator
+// tiles in registers across its slabs and flushes them once with atomics.  db (column sums of G) rides
+// along as the extra column N of dW (A is extended by a column of ones).
+__global__ __launch_bounds__(THREADS) void wgrad_kernel(int64_t n, const float* __restrict__ G, int gs, int M,
+                                                        const float* __restrict__ A, int as, int N,
+                                                        float* __restrict__ dW, int ldw, float* __restrict__ db)
+{
+    constexpr int LDG = 65, LDA = 97;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int ROWS = 32;     // rows (points) per slab: 4 waves x 32 x (65+97) floats = 81 KiB of LDS
+    float* sG = smem + wave * ROWS * (LDG + LDA);
+    float* sA = sG + ROWS * LDG;
+    const int lr = lane & 31, lk = lane >> 5;
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][nt][r] = 0.0f;
+    const int NC = N + 1;     // + ones column
+    const int64_t n_tiles = (n + ROWS - 1) / ROWS;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t p0 = tile * ROWS;
+        for (int i = lane; i < ROWS * 64; i += 64) {
+            const int r = i >> 6, c = i & 63;
+            const int64_t p = p0 + r;
+            sG[r * LDG + c] = (c < M && p < n) ? G[p * gs + c] : 0.0f;
+        }
+        for (int i = lane; i < ROWS * 96; i += 64) {
+            const int r = i / 96, c = i % 96;
+            const int64_t p = p0 + r;
+            float v = 0.0f;
+            if (p < n) v = c < N ? A[p * as + c] : (c == N ? 1.0f : 0.0f);
+            sA[r * LDA + c] = v;
+        }
+#pragma unroll 2
+        for (int kk = 0; kk < ROWS / 2; kk++) {
+            const int k = 2 * kk + lk;
+            const float a0 = sG[k * LDG + lr], a1 = sG[k * LDG + 32 + lr];
+            const float b0 = sA[k * LDA + lr], b1 = sA[k * LDA + 32 + lr], b2 = sA[k * LDA + 64 + lr];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, acc[0][2], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, acc[1][2], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * lk, col = 32 * nt + lr;
+                const float v = acc[m][nt][r];
+                if (row < M && v != 0.0f) {
+                    if (col < N) unsafeAtomicAdd(dW + row * ldw + col, v);
+                    else if (col == N && db) unsafeAtomicAdd(db + row, v);
+                }
+            }
+    (void)NC;
+}
+
 int fill_segs(Seg* segs, int n_segs, const float* const* seg_ptr, const int* seg_stride, const int* seg_width,
               const float* seg_mul, const float* seg_add, int in_dim)
 {
@@ -444,4 +513,20 @@ IA_EXPORT int ia_sdf_mlp_bwd(int64_t n, int n_segs, const float* const* seg_ptr,
     if (grid > 256) grid = 256;
     sdf_bwd_kernel<<<grid, THREADS, lds, (hipStream_t)stream>>>(a);
     return ia::check_launch("ia_sdf_mlp_bwd");
+}
+
+// dW[M, ldw] += G[:, :M]^T A[:, :N] ; db[M] += column sums of G (db may be NULL).  dW/db are accumulated into.
+IA_EXPORT int ia_wgrad(int64_t n, const float* G, int g_stride, int M, const float* A, int a_stride, int N, float* dW,
+                       int ldw, float* db, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    IA_REQUIRE(M >= 1 && M <= 64 && N >= 1 && N <= 95, "ia_wgrad: M <= 64, N <= 95");
+    constexpr size_t lds = sizeof(float) * 4 * 32 * (65 + 97);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    const int64_t n_tiles = (n + 31) / 32;
+    int grid = (int)((n_tiles + 3) / 4);
+    if (grid > 512) grid = 512;
+    wgrad_kernel<<<grid, THREADS, lds, (hipStream_t)stream>>>(n, G, g_stride, M, A, a_stride, N, dW, ldw, db);
+    return ia::check_launch("ia_wgrad");
 }

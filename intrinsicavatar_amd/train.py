@@ -13,7 +13,8 @@ each stage is a torch.autograd.Function whose forward AND backward are HIP kerne
 
 Sample positions, the candidate search and the winner selection are not differentiated, exactly as in the
 reference (resampling under no_grad; torch.gather passes gradients to the winning candidate only).  The tiny
-weight-gradient reductions dW = G^T A ([64 x n] x [n x <=68]) go through torch.matmul (rocBLAS), a plain library GEMM.
+weight-gradient reductions dW = G^T A ([64 x n] x [n x <=68]) use the split-K MFMA kernel ia_wgrad (rocBLAS maps this
+shape to a single output tile walking K = millions of points).
 """
 import ctypes as C
 from typing import Dict, Optional
@@ -24,6 +25,16 @@ from torch.autograd import Function
 
 from . import _lib as L
 from . import fields, lib_nerfacc, nerfacc, render
+
+
+def wgrad(G: Tensor, M: int, A: Tensor, N: int, want_bias: bool = True):
+    """dW [M,N] = G[:, :M]^T A[:, :N], db [M] = column sums of G -- split-K MFMA kernel (ia_wgrad)."""
+    dev = G.device
+    dW = torch.zeros((M, N), device=dev)
+    db = torch.zeros(M, device=dev) if want_bias else None
+    L.check(L.lib().ia_wgrad(L.i64(G.shape[0]), L.ptr(G), L.i32(G.stride(0)), L.i32(M), L.ptr(A), L.i32(A.stride(0)), L.i32(N),
+                             L.ptr(dW), L.i32(N), L.ptr(db), L.stream()), "ia_wgrad")
+    return dW, db
 
 
 def _segs(segs):
@@ -68,11 +79,10 @@ class _SDFField(Function):
                 "ia_sdf_mlp_bwd")
         g_table = torch.zeros_like(table)
         fields.hashgrid_backward(xp, gE, g_table, g_jac=gG, q=q)
-        dW1k = DZ.t() @ Hh[:, :35] + GZ.t() @ U[:, :35]
-        db1 = DZ.sum(0)
-        dW2 = g_y.t() @ A
+        dW1k, db1 = wgrad(DZ, 64, Hh, 35)
+        dW1k = dW1k + wgrad(GZ, 64, U, 35, want_bias=False)[0]
+        dW2, db2 = wgrad(g_y, 13, A, 64)
         dW2[0] += DGS.sum(0)
-        db2 = g_y.sum(0)
         return None, g_table, dW1k, db1, dW2, db2, None, None
 
 
@@ -154,10 +164,10 @@ class _Radiance(Function):
         g_refl01 = torch.empty((n, 3), device=dev)
         L.check(L.lib().ia_sh4_bwd(L.i64(n), L.ptr(refl01), C.c_void_p(g_sh.data_ptr()), L.i32(68), L.ptr(g_refl01),
                                    L.stream()), "ia_sh4_bwd")
-        dW1 = G1.t() @ X[:, :67]
-        dW2 = G2.t() @ A1
-        dW3 = G3[:, :3].t() @ A2
-        return (None, g_table, g_feat, g_refl01, g_nw, dW1, G1.sum(0), dW2, G2.sum(0), dW3, G3[:, :3].sum(0), None, None)
+        dW1, db1 = wgrad(G1, 64, X, 67)
+        dW2, db2 = wgrad(G2, 64, A1, 64)
+        dW3, db3 = wgrad(G3, 3, A2, 64)
+        return (None, g_table, g_feat, g_refl01, g_nw, dW1, db1, dW2, db2, dW3, db3, None, None)
 
 
 def shade_differentiable(rs, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor, t_starts: Tensor, t_ends: Tensor,
