@@ -77,7 +77,7 @@ def main():
         build.build()
     if world > 1:
         dist.barrier()
-    from intrinsicavatar_amd import synthetic as S, _lib as L
+    from intrinsicavatar_amd import synthetic as S, _lib as L, parallel
 
     # one frame per rank (frame-/ray-batch sharding, replicated parameters)
     rs, rays, export = S.build_frame(dev, args.hw, args.hw, pose_seed=rank, beta=0.01, num_samples_per_ray=128)
@@ -95,19 +95,8 @@ def main():
             p.grad = None
         out = rs.forward_backward(rays, target_rgb, target_mask)
         if world > 1:
-            # the one exchange step of the path: all-reduce(sum) of the gradients over RCCL/xGMI;
-            # two 50.4 MB hash tables dominate, so they go as two large buckets + one small flat bucket
-            small = [p.grad for p in params if p.grad is not None and p.grad.numel() < (1 << 20)]
-            big = [p.grad for p in params if p.grad is not None and p.grad.numel() >= (1 << 20)]
-            hs = [dist.all_reduce(t, async_op=True) for t in big]
-            flat = torch.cat([t.reshape(-1) for t in small])
-            dist.all_reduce(flat)
-            for h in hs:
-                h.wait()
-            off = 0
-            for t in small:
-                t.copy_(flat[off:off + t.numel()].view_as(t))
-                off += t.numel()
+            # the one exchange step of the path: all-reduce(sum) of the gradients over RCCL/xGMI
+            parallel.allreduce_gradients(params)
         return out
 
     for _ in range(args.warmup):

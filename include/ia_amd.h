@@ -251,10 +251,10 @@ int ia_sdf_mlp_bwd(int64_t n, int n_segs, const float* const* seg_ptr, const int
                    float* Hh /*[n,36]*/, float* U /*[n,36]*/, float* DZ /*[n,64]*/, float* GZ /*[n,64]*/,
                    float* A /*[n,64]*/, float* DGS /*[n,64]*/, ia_stream_t stream);
 
-/* split-K weight gradient on the matrix cores: dW[M,ldw] += G[:, :M]^T . A[:, :N], db[M] += colsum(G)
- * (M <= 64, N <= 95; accumulates with atomics into caller-zeroed dW / db) */
+/* split-K weight gradient on the matrix cores: dW[M,ldw] += G[:, :M]^T . A[:, :N]
+ * (M <= 64, N <= 96; strides <= 64 / 96 floats; accumulates with atomics into caller-zeroed dW) */
 int ia_wgrad(int64_t n, const float* G, int g_stride, int M, const float* A, int a_stride, int N, float* dW, int ldw,
-             float* db /*or NULL*/, ia_stream_t stream);
+             ia_stream_t stream);
 
 #ifdef __cplusplus
 }

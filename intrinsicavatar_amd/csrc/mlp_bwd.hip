@@ -369,19 +369,23 @@ __global__ __launch_bounds__(THREADS) void sdf_bwd_kernel(SdfBwdArgs a)
 // ------------------------------------------------------------------------------------------------
 // split-K weight gradient:  dW[M x N] += G[n x M]^T . A[n x N]   (M <= 64, N <= 96; K = n points)
 // rocBLAS maps this tall-skinny product to ONE output tile (a single workgroup walking K = millions);
-// here K is split over the whole chip: each wave owns 64-row slabs, keeps the 2 x 3 MFMA accumulator
-// tiles in registers across its slabs and flushes them once with atomics.  db (column sums of G) rides
-// along as the extra column N of dW (A is extended by a column of ones).
+// here K is split over the whole chip: each wave owns 16-row slabs, keeps the 2 x 3 MFMA accumulator
+// tiles in registers across its slabs and flushes them once with atomics.
+// The slabs are copied global -> LDS verbatim (row-major, caller's strides) with 16-byte loads: both MFMA
+// operand reads (a = G[k][i], b = A[k][j], k = point) walk consecutive columns across lanes, which is
+// conflict-free for ANY row stride, and columns beyond M / N only feed accumulator entries that are
+// discarded, so no padding or masking is needed.
+constexpr int WG_ROWS = 16;
 __global__ __launch_bounds__(THREADS) void wgrad_kernel(int64_t n, const float* __restrict__ G, int gs, int M,
                                                         const float* __restrict__ A, int as, int N,
-                                                        float* __restrict__ dW, int ldw, float* __restrict__ db)
+                                                        float* __restrict__ dW, int ldw)
 {
-    constexpr int LDG = 65, LDA = 97;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int ROWS = 32;     // rows (points) per slab: 4 waves x 32 x (65+97) floats = 81 KiB of LDS
-    float* sG = smem + wave * ROWS * (LDG + LDA);
-    float* sA = sG + ROWS * LDG;
+    const int g_tile = WG_ROWS * gs, a_tile = WG_ROWS * as;           // floats, multiples of 4
+    const int per_wave = g_tile + 64 + a_tile + 96;
+    float* sG = smem + wave * per_wave;
+    float* sA = sG + g_tile + 64;
     const int lr = lane & 31, lk = lane >> 5;
     f32x16 acc[2][3];
 #pragma unroll
@@ -390,27 +394,32 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(int64_t n, const float* 
         for (int nt = 0; nt < 3; nt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[m][nt][r] = 0.0f;
-    const int NC = N + 1;     // + ones column
-    const int64_t n_tiles = (n + ROWS - 1) / ROWS;
+    // slack words (read by out-of-range columns of the last rows) must be finite
+    for (int i = lane; i < 64; i += 64) sG[g_tile + i] = 0.0f;
+    for (int i = lane; i < 96; i += 64) sA[a_tile + i] = 0.0f;
+    const int64_t n_tiles = (n + WG_ROWS - 1) / WG_ROWS;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
-        const int64_t p0 = tile * ROWS;
-        for (int i = lane; i < ROWS * 64; i += 64) {
-            const int r = i >> 6, c = i & 63;
-            const int64_t p = p0 + r;
-            sG[r * LDG + c] = (c < M && p < n) ? G[p * gs + c] : 0.0f;
+        const int64_t p0 = tile * WG_ROWS;
+        const int rows = (int)((n - p0) < WG_ROWS ? (n - p0) : WG_ROWS);
+        {
+            const float4* src = reinterpret_cast<const float4*>(G + p0 * gs);
+            float4* dst = reinterpret_cast<float4*>(sG);
+            const int nv = rows * gs / 4;
+            for (int i = lane; i < g_tile / 4; i += 64) dst[i] = i < nv ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rows < WG_ROWS) for (int i = nv * 4 + lane; i < g_tile && i < rows * gs; i += 64) sG[i] = G[p0 * gs + i];
         }
-        for (int i = lane; i < ROWS * 96; i += 64) {
-            const int r = i / 96, c = i % 96;
-            const int64_t p = p0 + r;
-            float v = 0.0f;
-            if (p < n) v = c < N ? A[p * as + c] : (c == N ? 1.0f : 0.0f);
-            sA[r * LDA + c] = v;
+        {
+            const float4* src = reinterpret_cast<const float4*>(A + p0 * as);
+            float4* dst = reinterpret_cast<float4*>(sA);
+            const int nv = rows * as / 4;
+            for (int i = lane; i < a_tile / 4; i += 64) dst[i] = i < nv ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rows < WG_ROWS) for (int i = nv * 4 + lane; i < a_tile && i < rows * as; i += 64) sA[i] = A[p0 * as + i];
         }
-#pragma unroll 2
-        for (int kk = 0; kk < ROWS / 2; kk++) {
+#pragma unroll
+        for (int kk = 0; kk < WG_ROWS / 2; kk++) {
             const int k = 2 * kk + lk;
-            const float a0 = sG[k * LDG + lr], a1 = sG[k * LDG + 32 + lr];
-            const float b0 = sA[k * LDA + lr], b1 = sA[k * LDA + 32 + lr], b2 = sA[k * LDA + 64 + lr];
+            const float a0 = sG[k * gs + lr], a1 = sG[k * gs + 32 + lr];
+            const float b0 = sA[k * as + lr], b1 = sA[k * as + 32 + lr], b2 = sA[k * as + 64 + lr];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, acc[0][2], 0, 0, 0);
@@ -427,12 +436,8 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(int64_t n, const float* 
             for (int r = 0; r < 16; r++) {
                 const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * lk, col = 32 * nt + lr;
                 const float v = acc[m][nt][r];
-                if (row < M && v != 0.0f) {
-                    if (col < N) unsafeAtomicAdd(dW + row * ldw + col, v);
-                    else if (col == N && db) unsafeAtomicAdd(db + row, v);
-                }
+                if (row < M && col < N && v != 0.0f) unsafeAtomicAdd(dW + row * ldw + col, v);
             }
-    (void)NC;
 }
 
 int fill_segs(Seg* segs, int n_segs, const float* const* seg_ptr, const int* seg_stride, const int* seg_width,
@@ -515,18 +520,19 @@ IA_EXPORT int ia_sdf_mlp_bwd(int64_t n, int n_segs, const float* const* seg_ptr,
     return ia::check_launch("ia_sdf_mlp_bwd");
 }
 
-// dW[M, ldw] += G[:, :M]^T A[:, :N] ; db[M] += column sums of G (db may be NULL).  dW/db are accumulated into.
+// dW[M, ldw] += G[:, :M]^T A[:, :N]   (accumulated into; caller zeroes).  g_stride / a_stride in floats; rows must be
+// 16-byte aligned per 16-row slab (any stride that is a multiple of 1 float works: 16 * stride * 4 B is a multiple of 16).
 IA_EXPORT int ia_wgrad(int64_t n, const float* G, int g_stride, int M, const float* A, int a_stride, int N, float* dW,
-                       int ldw, float* db, ia_stream_t stream)
+                       int ldw, ia_stream_t stream)
 {
     if (n == 0) return IA_OK;
-    IA_REQUIRE(M >= 1 && M <= 64 && N >= 1 && N <= 95, "ia_wgrad: M <= 64, N <= 95");
-    constexpr size_t lds = sizeof(float) * 4 * 32 * (65 + 97);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    const int64_t n_tiles = (n + 31) / 32;
+    IA_REQUIRE(M >= 1 && M <= 64 && N >= 1 && N <= 96, "ia_wgrad: M <= 64, N <= 96");
+    IA_REQUIRE(g_stride >= M && a_stride >= N && g_stride <= 64 && a_stride <= 96, "ia_wgrad: strides must be in [M,64] / [N,96]");
+    IA_REQUIRE(((uintptr_t)G % 16) == 0 && ((uintptr_t)A % 16) == 0, "ia_wgrad: operands must be 16-byte aligned");
+    const size_t lds = sizeof(float) * 4 * (WG_ROWS * g_stride + 64 + WG_ROWS * a_stride + 96);
+    const int64_t n_tiles = (n + WG_ROWS - 1) / WG_ROWS;
     int grid = (int)((n_tiles + 3) / 4);
-    if (grid > 512) grid = 512;
-    wgrad_kernel<<<grid, THREADS, lds, (hipStream_t)stream>>>(n, G, g_stride, M, A, a_stride, N, dW, ldw, db);
+    if (grid > 768) grid = 768;
+    wgrad_kernel<<<grid, THREADS, lds, (hipStream_t)stream>>>(n, G, g_stride, M, A, a_stride, N, dW, ldw);
     return ia::check_launch("ia_wgrad");
 }

@@ -31,9 +31,9 @@ def wgrad(G: Tensor, M: int, A: Tensor, N: int, want_bias: bool = True):
     """dW [M,N] = G[:, :M]^T A[:, :N], db [M] = column sums of G -- split-K MFMA kernel (ia_wgrad)."""
     dev = G.device
     dW = torch.zeros((M, N), device=dev)
-    db = torch.zeros(M, device=dev) if want_bias else None
     L.check(L.lib().ia_wgrad(L.i64(G.shape[0]), L.ptr(G), L.i32(G.stride(0)), L.i32(M), L.ptr(A), L.i32(A.stride(0)), L.i32(N),
-                             L.ptr(dW), L.i32(N), L.ptr(db), L.stream()), "ia_wgrad")
+                             L.ptr(dW), L.i32(N), L.stream()), "ia_wgrad")
+    db = G[:, :M].sum(0) if want_bias else None       # column sums: one streaming reduction
     return dW, db
 
 
@@ -189,7 +189,7 @@ def shade_differentiable(rs, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor
     dflt_g = torch.tensor([0.0, 0.0, 1.0], device=pts.device)
     feat = out * vf
     sdf = torch.where(valid, out[:, 0], torch.full_like(out[:, 0], 1e5))
-    sdf_grad = torch.where(valid[:, None], torch.einsum("bij,bj->bi", c2w, grad_c), dflt_g[None])
+    sdf_grad = torch.where(valid[:, None], (c2w * grad_c[:, None, :]).sum(-1), dflt_g[None])
     w2s_rot = dfm.w2s[:3, :3].contiguous()
     normal_smpl, normal_world, refl01 = _ShadePrep.apply(sdf_grad, rays_d, ray_indices, w2s_rot)
     alphas = _Alpha.apply(sdf, t_ends - t_starts, rs.density.get_beta())
