@@ -151,7 +151,7 @@ int ia_precompute(int B, int D, int H, int W, const float* voxel_w /*[1,24,D,H,W
 int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt /*[B,N,3]*/, const float* voxel_J, int layout,
                     int D, int H, int W, const float* tfs, const int32_t* bone_ids /*[I]*/,
                     const float* offset, const float* scale, float cvg_threshold, float dvg_threshold,
-                    float* x /*[B,N,I,3]*/, float* J_inv /*[B,N,I,3,3]*/, uint8_t* is_valid /*[B,N,I]*/,
+                    float* x /*[B,N,I,3]*/, float* J_inv /*[B,N,I,3,3] or NULL (not needed when use_j_inv=false)*/, uint8_t* is_valid /*[B,N,I]*/,
                     float* fwd_J /*[B,N,I,3,3] or NULL: forward LBS Jacobian at each root (= fwd_tfs, deformer_torch.py:49-52)*/,
                     ia_stream_t stream);
 int ia_filter(int64_t N, int I, const float* x /*[1,N,I,3]*/, const uint8_t* mask, uint8_t* out, ia_stream_t stream);
@@ -255,6 +255,21 @@ int ia_sdf_mlp_bwd(int64_t n, int n_segs, const float* const* seg_ptr, const int
  * (M <= 64, N <= 96; strides <= 64 / 96 floats; accumulates with atomics into caller-zeroed dW) */
 int ia_wgrad(int64_t n, const float* G, int g_stride, int M, const float* A, int a_stride, int N, float* dW, int ldw,
              ia_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* lib.torch_pbr call chain of pbr_light_forward (models/intrinsic_avatar.py:755-861), fused:
+ * scatterer.eval (Lambert + GGX multi-lobe, incl. cosine) + emitter.eval + emitter.pdf + Li/Lo assembly for F
+ * foreground shading samples.  normals / view_dirs / light_dirs are SMPL-space; w2s_rot = w2s[:3,:3] (device, 9
+ * floats) maps light dirs to world for the equirect lookup; transmittance [F] and indirect_rgb [F,3] (or NULL) come
+ * from compute_indirect_radiance.  env_base [H,W,3], env_pmf [H,W] (luminance x sin(theta), sums to 1). */
+int ia_pbr_light_shade(int64_t F, const float* normal, const float* albedo, const float* roughness,
+                       const float* metallic, const float* view_dirs, const float* light_dirs,
+                       const float* transmittance, const float* indirect_rgb, const float* env_base,
+                       const float* env_pmf, int env_h, int env_w, const float* w2s_rot,
+                       float* Lo, float* Lo_diff, float* Lo_spec, ia_stream_t stream);
+/* emitter.eval / emitter.pdf on world-space unit directions (either output may be NULL) */
+int ia_envlight_eval(int64_t n, const float* dirs_world, const float* env_base, const float* env_pmf, int env_h,
+                     int env_w, float* rgb /*[n,3]*/, float* pdf /*[n]*/, ia_stream_t stream);
 
 #ifdef __cplusplus
 }

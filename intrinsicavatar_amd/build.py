@@ -26,6 +26,7 @@ SOURCES = {
     "mlp.hip": [],
     "mlp_bwd.hip": ["-munsafe-fp-atomics"],
     "deform.hip": ["-ffp-contract=off"],
+    "pbr.hip": [],
 }
 
 

@@ -204,9 +204,11 @@ __global__ __launch_bounds__(THREADS) void broyden_kernel(
             is_valid[index] = ok ? 1 : 0;
             if (ok) {
                 x[index * 3 + 0] = x_l[0]; x[index * 3 + 1] = x_l[1]; x[index * 3 + 2] = x_l[2];
-                float* Jo = J_inv + index * 9;
-                Jo[0] = J00; Jo[1] = J01; Jo[2] = J02; Jo[3] = J10; Jo[4] = J11; Jo[5] = J12;
-                Jo[6] = J20; Jo[7] = J21; Jo[8] = J22;
+                if (J_inv) {
+                    float* Jo = J_inv + index * 9;
+                    Jo[0] = J00; Jo[1] = J01; Jo[2] = J02; Jo[3] = J10; Jo[4] = J11; Jo[5] = J12;
+                    Jo[6] = J20; Jo[7] = J21; Jo[8] = J22;
+                }
                 if (fwd_J) {   // forward LBS Jacobian at the root == blended bone rotation (fwd_tfs, deformer_torch.py:49-52)
                     float* Fo = fwd_J + index * 9;
                     Fo[0] = Jl[0]; Fo[1] = Jl[1]; Fo[2] = Jl[2]; Fo[3] = Jl[4]; Fo[4] = Jl[5]; Fo[5] = Jl[6];

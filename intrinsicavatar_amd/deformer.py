@@ -60,7 +60,7 @@ class SNARFDeformer:
         P = pts.shape[0]
         I = self.init_bones.shape[0]
         x = torch.zeros((1, P, I, 3), device=self.device)
-        Jinv = torch.zeros((1, P, I, 3, 3), device=self.device)
+        Jinv = None      # use_j_inv: false (configs/deformer/snarf_deformer.yaml:11): the kernel skips the store
         valid = torch.zeros((1, P, I), dtype=torch.bool, device=self.device)
         fwd = torch.zeros((1, P, I, 3, 3), device=self.device) if want_fwd else None
         fast_snarf.fuse_broyden(x, pts.reshape(1, P, 3), None, fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs,

@@ -55,9 +55,9 @@ def fuse_broyden(x: Tensor, xd_tgt: Tensor, voxel: Tensor, voxel_J, tfs: Tensor,
         vj, layout = voxel_J.contiguous(), 0
         _, _, D, H, W = vj.shape
     for t in (x, J_inv, is_valid):
-        if not t.is_contiguous():
+        if t is not None and not t.is_contiguous():
             raise RuntimeError("outputs must be contiguous")
-    if x.shape != (B, N, I, 3) or J_inv.shape != (B, N, I, 3, 3) or is_valid.shape != (B, N, I):
+    if x.shape != (B, N, I, 3) or (J_inv is not None and J_inv.shape != (B, N, I, 3, 3)) or is_valid.shape != (B, N, I):
         raise RuntimeError("output shapes must be x[B,N,I,3], J_inv[B,N,I,3,3], is_valid[B,N,I]")
     xd = xd_tgt.contiguous().float()
     tfs = tfs.contiguous().float()

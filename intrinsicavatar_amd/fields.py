@@ -293,14 +293,65 @@ class VolumeRefDirRadiance(nn.Module):
         return W1k, l[0].bias, l[2].weight, l[2].bias, l[4].weight, l[4].bias
 
     @torch.no_grad()
-    def forward(self, points: Tensor, features: Tensor, refl01: Tensor, normal_world: Tensor):
-        """returns rgb [n,3] (sigmoid applied). `refl01` = (reflect(-view, n)+1)/2 from ia_shade_prep."""
+    def forward(self, points: Tensor, features: Tensor, refl01: Tensor, normal_world: Tensor, return_embedding=False):
+        """returns rgb [n,3] (sigmoid applied). `refl01` = (reflect(-view, n)+1)/2 from ia_shade_prep.
+        return_embedding: also return (hash features [n,32], normalised coords [n,3]) = rgb_feature for the material net."""
         n = points.shape[0]
         if n == 0:
-            return points.new_empty(0, 3)
+            e = points.new_empty(0, 3)
+            return (e, points.new_empty(0, 32), e) if return_embedding else e
         xp = ((points - self.center) / self.scale + 0.5).contiguous()
         enc = hashgrid_forward(xp, self.grid_params)
         sh = sh4(refl01)
         segs = [(enc, 32, 1.0, 0.0), (xp, 3, 2.0, -1.0), (features.contiguous(), 13, 1.0, 0.0), (sh, 16, 1.0, 0.0),
                 (normal_world.contiguous(), 3, 1.0, 0.0)]
-        return mlp_forward(1, segs, *self.effective_weights(), 3)
+        rgb = mlp_forward(1, segs, *self.effective_weights(), 3)
+        return (rgb, enc, xp) if return_embedding else rgb
+
+
+class VolumeMaterial(nn.Module):
+    """models/pbr/material.py:13-51 with LipshitzMLP (network_utils.py:360-431): [hash#2(32)+xyz(3) | feat(13)] -> 64 -> 64 -> 5,
+    sigmoid, affine to albedo / roughness / metallic.  Parameter names follow LipshitzMLP's ParameterLists."""
+
+    def __init__(self, seed: Optional[int] = 2):
+        super().__init__()
+        self.network = nn.Module()
+        g = torch.Generator().manual_seed(seed if seed is not None else 0)
+        dims = [(48, 64), (64, 64), (64, 5)]
+        ws, bs, cs = [], [], []
+        for di, do in dims:                       # torch.nn.Linear default init
+            bound = 1.0 / math.sqrt(di)
+            w = (torch.rand((do, di), generator=g) * 2 - 1) * bound
+            b = (torch.rand((do,), generator=g) * 2 - 1) * bound
+            ws.append(nn.Parameter(w)); bs.append(nn.Parameter(b))
+            cs.append(nn.Parameter(torch.ones(1) * w.abs().sum(1).max() * 2))      # network_utils.py:380-385
+        self.network.weights_per_layer = nn.ParameterList(ws)
+        self.network.biases_per_layer = nn.ParameterList(bs)
+        self.network.lipshitz_bound_per_layer = nn.ParameterList(cs)
+        self.albedo_scale, self.albedo_bias = 0.77, 0.03
+        self.roughness_scale, self.roughness_bias = 0.9, 0.09
+        self.metallic_scale, self.metallic_bias = 1.0, 0.0
+
+    def effective_weights(self, hash_mask: Tensor):
+        """Lipschitz normalisation (network_utils.py:396-403) + kernel column order [hash(32) | xyz(3) | feat(13)]."""
+        out = []
+        for i in range(3):
+            w = self.network.weights_per_layer[i]
+            c = torch.nn.functional.softplus(self.network.lipshitz_bound_per_layer[i])
+            scale = torch.clamp(c / w.abs().sum(dim=1), max=1.0)
+            w = w * scale[:, None]
+            if i == 0:      # reference input order: [xyz(3) hash(32) | feat(13)]
+                w = torch.cat([w[:, 3:35] * hash_mask[None], w[:, :3], w[:, 35:48]], 1)
+            out += [w, self.network.biases_per_layer[i]]
+        return out
+
+    @torch.no_grad()
+    def forward(self, enc2: Tensor, xp2: Tensor, feat: Tensor, hash_mask: Tensor) -> Tensor:
+        """-> [n,5] = albedo(3), roughness(1), metallic(1)"""
+        if enc2.shape[0] == 0:
+            return enc2.new_empty(0, 5)
+        segs = [(enc2, 32, 1.0, 0.0), (xp2, 3, 2.0, -1.0), (feat.contiguous(), 13, 1.0, 0.0)]
+        m = mlp_forward(2, segs, *self.effective_weights(hash_mask), 5)
+        scale = m.new_tensor([self.albedo_scale] * 3 + [self.roughness_scale, self.metallic_scale])
+        bias = m.new_tensor([self.albedo_bias] * 3 + [self.roughness_bias, self.metallic_bias])
+        return m * scale + bias

@@ -1,0 +1,121 @@
+"""Physically based shading part of render_step on the MI355X kernels (BASELINE configs 3 / 5):
+
+  EnvironmentLightTensor   lib.torch_pbr emitter as used at models/intrinsic_avatar.py:292-305,777-786,819-833
+  pbr_light_shade          pbr_light_forward's BRDF / light evaluation (:796-859)            -> ia_pbr_light_shade
+  sample_volume_interaction models/pbr/utils.py:70-229 (K1 resampling + attribute gathers)   -> ia_ray_resampling
+  light_shuffle            per-ray permutation of the spp light directions (:1356-1378)
+
+lib/torch_pbr is an empty submodule in the reference tree; semantics are those of oracle/pbr_ref.py
+(standard Lambert + GGX multi-lobe BRDF, luminance x sin(theta) importance-sampled equirect light).
+Random numbers are explicit inputs."""
+import math
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+from . import lib_nerfacc
+
+
+class EnvironmentLightTensor:
+    """`emitter` with attributes .base [H,W,3], .pdf_scale and methods update_pdf / sample / eval / pdf."""
+
+    def __init__(self, base: Tensor):
+        self.base = base.contiguous().float()
+        self.pdf_scale = self.base.shape[0] * self.base.shape[1] / (2 * math.pi * math.pi)
+        self.pmf = None
+        self._cdf = None
+
+    @torch.no_grad()
+    def update_pdf(self):
+        H, W, _ = self.base.shape
+        sin_t = torch.sin((torch.arange(H, device=self.base.device) + 0.5) * math.pi / H)[:, None]
+        lum = (0.2126 * self.base[..., 0] + 0.7152 * self.base[..., 1] + 0.0722 * self.base[..., 2]).clamp_min(0).double()
+        w = lum * sin_t
+        self.pmf = (w / w.sum()).float().contiguous()
+        self._cdf = torch.cumsum(self.pmf.reshape(-1).double(), 0)
+
+    @torch.no_grad()
+    def sample(self, k: int, u: Optional[Tensor] = None) -> Tensor:
+        """k world-space directions proportional to luminance x sin(theta); u [k,3] uniforms (explicit RNG)."""
+        H, W, _ = self.base.shape
+        if u is None:
+            u = torch.rand((k, 3), device=self.base.device)
+        u = u.to(self.base.device).double()
+        idx = torch.searchsorted(self._cdf, u[:, 0] * self._cdf[-1], right=True).clamp(max=H * W - 1)
+        y, x = idx // W, idx % W
+        uu, vv = (x + u[:, 1]) / W, (y + u[:, 2]) / H
+        phi, th = (uu - 0.5) * 2 * math.pi, vv * math.pi
+        return torch.stack([torch.sin(th) * torch.sin(phi), torch.cos(th), -torch.sin(th) * torch.cos(phi)], -1).float()
+
+    def _eval(self, d: Tensor, want_rgb: bool, want_pdf: bool):
+        d = d.contiguous().float()
+        n = d.shape[0]
+        rgb = torch.empty((n, 3), device=d.device) if want_rgb else None
+        pdf = torch.empty((n,), device=d.device) if want_pdf else None
+        H, W, _ = self.base.shape
+        L.check(L.lib().ia_envlight_eval(L.i64(n), L.ptr(d), L.ptr(self.base), L.ptr(self.pmf), L.i32(H), L.i32(W), L.ptr(rgb),
+                                         L.ptr(pdf), L.stream()), "ia_envlight_eval")
+        return rgb, pdf
+
+    def eval(self, d_world: Tensor) -> Tensor:
+        return self._eval(d_world, True, False)[0]
+
+    def pdf(self, d_world: Tensor) -> Tensor:
+        return self._eval(d_world, False, True)[1][:, None]
+
+
+def pbr_light_shade(normal, albedo, roughness, metallic, view_dirs, light_dirs, transmittance, indirect_rgb,
+                    emitter: EnvironmentLightTensor, w2s_rot):
+    """fused scatterer.eval + emitter.eval/pdf + Lo assembly for F foreground shading samples."""
+    F_ = normal.shape[0]
+    dev = normal.device
+    Lo, Ld, Ls = (torch.empty((F_, 3), device=dev) for _ in range(3))
+    H, W, _ = emitter.base.shape
+    c = lambda t: None if t is None else t.contiguous().float()     # noqa: E731
+    L.check(L.lib().ia_pbr_light_shade(
+        L.i64(F_), L.ptr(c(normal)), L.ptr(c(albedo)), L.ptr(c(roughness.reshape(-1))), L.ptr(c(metallic.reshape(-1))),
+        L.ptr(c(view_dirs)), L.ptr(c(light_dirs)), L.ptr(c(transmittance.reshape(-1))), L.ptr(c(indirect_rgb)),
+        L.ptr(emitter.base), L.ptr(emitter.pmf), L.i32(H), L.i32(W), L.ptr(c(w2s_rot)), L.ptr(Lo), L.ptr(Ld), L.ptr(Ls),
+        L.stream()), "ia_pbr_light_shade")
+    return Lo, Ld, Ls
+
+
+@torch.no_grad()
+def sample_volume_interaction(rays_o, rays_d, ray_indices, t_starts, t_ends, n_rays: int, spp: int, transmittance_map,
+                              extras: Dict[str, Tensor]):
+    """models/pbr/utils.py:70-229: spp stratified samples of the un-normalised weight CDF per ray (+ background bin),
+    zero-crossing clamp, per-interval counts, gathers of the per-sample attributes."""
+    weights, sdfs = extras["weights"], extras["sdf"]
+    packed_info = lib_nerfacc.pack_info(ray_indices, n_rays)
+    rpi, mid, offs, sampled_idx, fg_cnt, bg_cnt, surface_idx = lib_nerfacc.ray_resampling(
+        packed_info, t_starts[:, None], t_ends[:, None], weights, sdfs, spp)
+    fg_indices = torch.nonzero(offs[:, 0] < 1e4)[:, 0]
+    bg_indices = torch.nonzero(offs[:, 0] >= 1e4)[:, 0]
+    rri = lib_nerfacc.unpack_info(rpi, mid.shape[0])
+    fg_rri, bg_rri = rri[fg_indices], rri[bg_indices]
+    fg_sidx = sampled_idx[fg_indices]
+    ex = {}
+    if fg_sidx.numel() > 0:
+        rw = torch.zeros_like(mid[:, 0])
+        rw[fg_indices] = weights[fg_sidx] / fg_cnt[fg_sidx].float()
+        rw[bg_indices] = transmittance_map[bg_rri][:, 0] / bg_cnt[bg_rri].float()
+        t = mid[fg_indices]
+        ex = dict(sdf=sdfs[fg_sidx], alphas=extras["alphas"][fg_sidx], dists=(t_ends - t_starts)[:, None][fg_sidx],
+                  positions=rays_o[fg_rri] + rays_d[fg_rri] * t, normals=extras["normals"][fg_sidx],
+                  albedo=extras["albedo"][fg_sidx], roughness=extras["roughness"][fg_sidx],
+                  metallic=extras["metallic"][fg_sidx], t_dirs=rays_d[fg_rri])
+    else:
+        rw = torch.zeros((0,), device=rays_o.device)
+    return rpi, rri, rw, fg_indices, bg_indices, ex
+
+
+@torch.no_grad()
+def light_shuffle(n_rays: int, spp: int, resampled_packed_info: Tensor, fg_indices: Tensor, shuffle_u: Tensor) -> Tensor:
+    """intrinsic_avatar.py:1356-1378: independent permutation of [0, spp) per ray (argsort of uniforms, here an explicit
+    device tensor instead of the reference's CPU torch.rand), packed to the resampled points, restricted to fg points."""
+    col = torch.argsort(shuffle_u, dim=-1)                                  # [n_rays, spp]
+    has = resampled_packed_info[:, 1] > 0                                   # rays that own spp resampled points
+    packed = col[has].reshape(-1)                                           # every such ray owns exactly spp points, in order
+    return packed[fg_indices]

@@ -163,3 +163,111 @@ class RenderStep:
         out["loss"] = loss.detach()
         out["stats"] = stats
         return out
+
+    # ------------------------------------------------------------------ secondary rays (compute_indirect_radiance)
+    @torch.no_grad()
+    def compute_indirect_radiance(self, rays_o: Tensor, rays_d: Tensor, near: float = 0.0, far: float = 1.5,
+                                  n_secondary: int = 64, chunk: int = 1 << 21):
+        """models/intrinsic_avatar.py:396-545 (eval): march each secondary ray over [near, far] (step (far-near)/63),
+        SDF at the sample starts, zero-crossing resampling to 4 intervals (K4), shade them, composite.
+        returns (transmittance [M,1], indirect rgb [M,3]).  Rays are processed in chunks of `chunk` rays."""
+        M = rays_o.shape[0]
+        dev = rays_o.device
+        tr = torch.ones((M, 1), device=dev)
+        rgb = torch.zeros((M, 3), device=dev)
+        step = (far - near) / (n_secondary - 1)
+        beta = self._beta()
+        w2s_rot = self.deformer.w2s[:3, :3].contiguous()
+        for c0 in range(0, M, chunk):
+            ro, rd = rays_o[c0:c0 + chunk].contiguous(), rays_d[c0:c0 + chunk].contiguous()
+            m = ro.shape[0]
+            intervals, samples, _ = nerfacc.traverse_grids(
+                ro, rd, self.binaries, self.aabbs, torch.full((m,), near, device=dev), torch.full((m,), far, device=dev),
+                step, 0.0, grid_bits=self.grid_bits)
+            t_starts, t_ends = intervals.vals[intervals.is_left], intervals.vals[intervals.is_right]
+            ray_indices = samples.ray_indices
+            if t_starts.numel() == 0:
+                continue
+            # coarse_alpha_sdf_fn (:399-428): SDF at the interval STARTS
+            sdf = self._sdf_at(ray_points(ro, rd, ray_indices, t_starts))
+            alphas = laplace_alpha(sdf, t_ends - t_starts, beta)
+            pinfo = lib_nerfacc.pack_info(ray_indices, m)
+            rpi, rs, re, is_fg = lib_nerfacc.ray_resampling_sdf_fine(pinfo, t_starts[:, None], t_ends[:, None], alphas, sdf, 4)
+            rri = lib_nerfacc.unpack_info(rpi, rs.shape[0])
+            ray_indices, t_starts, t_ends = rri[is_fg], rs[is_fg, 0], re[is_fg, 0]
+            if t_starts.numel() == 0:
+                continue                                   # no zero crossing anywhere: fully transmissive
+            # rendering(rgb_alpha_fn) (:430-456, volrend.py:19-194)
+            d = self.deformer.deform(ray_points(ro, rd, ray_indices, t_starts, t_ends), self.geometry, with_grad=True,
+                                     with_feature=True)
+            _, normal_world, refl01 = shade_prep(d["sdf_grad"], rd, ray_indices, w2s_rot)
+            a = laplace_alpha(d["sdf"], t_ends - t_starts, beta)
+            rgbs = self.radiance(d["pts_cano"], d["feature"], refl01, normal_world)
+            pinfo = lib_nerfacc.pack_info(ray_indices, m)
+            w, _ = nerfacc.render_weight_from_alpha(a, packed_info=pinfo)
+            acc = nerfacc._Accumulate.apply(w, None, ray_indices, pinfo)
+            tr[c0:c0 + m] = 1.0 - acc
+            rgb[c0:c0 + m] = nerfacc._Accumulate.apply(w, rgbs, ray_indices, pinfo)
+        return tr, rgb
+
+    # ------------------------------------------------------------------ relighting (render_mode = light)
+    @torch.no_grad()
+    def relight(self, rays: Tensor, material, emitter, spp: int, light_u: Tensor, shuffle_u: Tensor,
+                background_color: Optional[Tensor] = None, global_illumination: bool = False,
+                jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        """forward_ with enable_phys and render_mode='light' (BASELINE configs 3 / 5):
+        rendering_with_normals_mats_sdf (volrend.py:810-1020) -> sample_volume_interaction (pbr/utils.py:70-229)
+        -> per-ray shuffled light directions (:1356-1378) -> secondary rays (:396-545) -> pbr_light_forward (:755-861)
+        -> accumulate(resampled_weights, Lo) (:1427-1466).  light_u [spp,3], shuffle_u [n_rays,spp]: explicit RNG."""
+        from . import pbr
+        dfm = self.deformer
+        rays_o, rays_d, far, t_starts, t_ends, ray_indices, packed_info, stats = self.sample(rays, jitter)
+        n_rays = rays_o.shape[0]
+        dev = rays_o.device
+        beta = self._beta()
+        w2s_rot = dfm.w2s[:3, :3].contiguous()
+        if background_color is None:
+            background_color = torch.ones(3, device=dev)
+        # -- shade with materials (rgb_normal_mats_alpha_fn, :1066-1156)
+        pts = ray_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
+        d = dfm.deform(pts, self.geometry, with_grad=True, with_feature=True)
+        normal_smpl, normal_world, refl01 = shade_prep(d["sdf_grad"], rays_d, ray_indices, w2s_rot)
+        alphas = laplace_alpha(d["sdf"], t_ends - t_starts, beta)
+        rgbs, enc2, xp2 = self.radiance(d["pts_cano"], d["feature"], refl01, normal_world, return_embedding=True)
+        mats = material(enc2, xp2, d["feature"], self.radiance.prog.mask(self.radiance.global_step, dev))
+        weights, trans = nerfacc.render_weight_from_alpha(alphas, packed_info=packed_info)
+        acc = lambda v: nerfacc._Accumulate.apply(weights, v, ray_indices, packed_info)      # noqa: E731
+        out = dict(comp_rgb=acc(rgbs), comp_normal=acc(normal_world), albedo=acc(mats[:, :3].contiguous()),
+                   roughness=acc(mats[:, 3:4].contiguous()), metallic=acc(mats[:, 4:5].contiguous()), opacity=acc(None))
+        out["depth"] = acc(((t_starts + t_ends) / 2.0)[:, None]) + (1.0 - out["opacity"]) * far[:, None]
+        extras = dict(weights=weights, sdf=d["sdf"], alphas=alphas, normals=normal_smpl, albedo=mats[:, :3],
+                      roughness=mats[:, 3:4], metallic=mats[:, 4:5])
+        rgb_phys = background_color[None].expand(n_rays, 3).clone()
+        stats.update(n_resampled=0, n_fg=0, n_secondary=0)
+        if ray_indices.numel() > 0:
+            rpi, rri, rw, fg_idx, bg_idx, ex = pbr.sample_volume_interaction(
+                rays_o, rays_d, ray_indices, t_starts, t_ends, n_rays, spp, 1.0 - out["opacity"], extras)
+            stats["n_resampled"], stats["n_fg"] = int(rri.shape[0]), int(fg_idx.shape[0])
+            if fg_idx.numel() > 0:
+                # light directions: sampled once per frame (prepare, :292-305), permuted per ray
+                dirs_world = emitter.sample(spp, light_u)
+                dirs_smpl = torch.nn.functional.normalize(dirs_world @ dfm.w2s[:3, :3].T, dim=-1, eps=1e-6)   # transform_dirs_w2s
+                shuffled = pbr.light_shuffle(n_rays, spp, rpi, fg_idx, shuffle_u)
+                light_dirs = dirs_smpl[shuffled].contiguous()
+                cos_mask = (ex["normals"] * light_dirs).sum(-1) > 1e-6
+                sec_tr = torch.zeros((fg_idx.shape[0], 1), device=dev)
+                sec_rgb = torch.zeros((fg_idx.shape[0], 3), device=dev)
+                stats["n_secondary"] = int(cos_mask.sum())
+                if stats["n_secondary"] > 0:
+                    t_, c_ = self.compute_indirect_radiance(ex["positions"][cos_mask], light_dirs[cos_mask])
+                    sec_tr[cos_mask], sec_rgb[cos_mask] = t_.clamp(0.0, 1.0), c_
+                fg_Lo, fg_Ld, fg_Ls = pbr.pbr_light_shade(
+                    ex["normals"], ex["albedo"], ex["roughness"], ex["metallic"], ex["t_dirs"], light_dirs, sec_tr,
+                    sec_rgb if global_illumination else None, emitter, w2s_rot)
+                Lo = torch.zeros((rri.shape[0], 3), device=dev)
+                Lo[fg_idx] = fg_Lo
+                rgb_phys = nerfacc.accumulate_along_rays(rw, Lo, rri, n_rays)
+                out["secondary_tr"], out["fg_Lo"] = sec_tr, fg_Lo
+            rgb_phys[rpi[:, 1] <= 0] = background_color[None]
+        out.update(comp_rgb_phys=rgb_phys, stats=stats)
+        return out
