@@ -12,6 +12,8 @@
 //
 // Arithmetic order is identical to oracle/ia_oracle.c (TU built with -ffp-contract=off), so
 // is_valid / filter masks are bit-exact and x, J_inv match bit-for-bit.
+#include <stdlib.h>
+
 #include "ia_common.h"
 
 namespace {
@@ -224,6 +226,128 @@ __global__ __launch_bounds__(THREADS) void broyden_kernel(
     }
 }
 
+// ---- K8, lane-persistent form ---------------------------------------------------------
+// The (point, init) searches have wildly different lengths (most of the 13 bone initialisations diverge after
+// 1-3 Broyden steps, the good ones run 4-10), so "one item per lane" leaves a wave idling behind its slowest
+// item.  Here each wave owns a contiguous chunk of items and every lane runs a state machine whose body is
+// exactly ONE trilinear fetch + its post-processing; a lane that finishes pulls the wave's next item
+// (ballot + popcount, wave-private cursor: no atomics, deterministic).  Per-item arithmetic is the same
+// operation sequence as broyden_kernel / the oracle, so results stay bit-exact.
+constexpr int BR_CHUNK = 1024;      // items per wave
+
+template <int LAYOUT>
+__global__ __launch_bounds__(THREADS) void broyden_persistent_kernel(
+    int64_t total, int64_t N, int I, const float* __restrict__ xd_tgt, const float* __restrict__ voxel_J, int D, int H,
+    int W, const float* __restrict__ tfs, const int32_t* __restrict__ bone_ids, const float* __restrict__ offset_g,
+    const float* __restrict__ scale_g, float cvg_threshold, float dvg_threshold, float* __restrict__ x,
+    float* __restrict__ J_inv, uint8_t* __restrict__ is_valid, float* __restrict__ fwd_J)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = ((int64_t)blockIdx.x * THREADS + threadIdx.x) >> 6;
+    int64_t cursor = wave_id * BR_CHUNK;                                  // wave-uniform
+    const int64_t chunk_end = (cursor + BR_CHUNK < total) ? cursor + BR_CHUNK : total;
+    if (cursor >= total) return;
+    const int64_t vol = (int64_t)D * H * W;
+    const float offset[3] = {offset_g[0], offset_g[1], offset_g[2]};
+    const float scale[3] = {scale_g[0], scale_g[1], scale_g[2]};
+    const float cvg2 = cvg_threshold * cvg_threshold, dvg2 = dvg_threshold * dvg_threshold;
+
+    bool have = false;
+    int64_t index = 0;
+    int it = -1;                  // -1: waiting for the initial fetch
+    float xt[3] = {0, 0, 0}, x_l[3] = {0, 0, 0}, gx[3] = {0, 0, 0}, u[3] = {0, 0, 0};
+    float Ji[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float* vJ = voxel_J;
+
+    for (;;) {
+        // ---- refill idle lanes from the wave's chunk ----
+        const unsigned long long need = __ballot(!have);
+        if (need) {
+            const int rank = __popcll(need & ((1ull << lane) - 1ull));
+            if (!have) {
+                const int64_t cand = cursor + rank;
+                if (cand < chunk_end) {
+                    have = true;
+                    index = cand;
+                    it = -1;
+                    const int i_batch = (int)(index / (N * I));
+                    const int64_t i_point = (index % (N * I)) / I;
+                    const int i_init = (int)((index % (N * I)) % I);
+                    vJ = voxel_J + (int64_t)i_batch * 12 * vol;
+                    xt[0] = xd_tgt[((int64_t)i_batch * N + i_point) * 3 + 0];
+                    xt[1] = xd_tgt[((int64_t)i_batch * N + i_point) * 3 + 1];
+                    xt[2] = xd_tgt[((int64_t)i_batch * N + i_point) * 3 + 2];
+                    const float* T = tfs + ((int64_t)i_batch * 24 + bone_ids[i_init]) * 16;
+                    const float ixd = xt[0] - T[0 * 4 + 3], iyd = xt[1] - T[1 * 4 + 3], izd = xt[2] - T[2 * 4 + 3];
+                    x_l[0] = ixd * T[0 * 4 + 0] + iyd * T[1 * 4 + 0] + izd * T[2 * 4 + 0];
+                    x_l[1] = ixd * T[0 * 4 + 1] + iyd * T[1 * 4 + 1] + izd * T[2 * 4 + 1];
+                    x_l[2] = ixd * T[0 * 4 + 2] + iyd * T[1 * 4 + 2] + izd * T[2 * 4 + 2];
+                }
+            }
+            cursor += __popcll(need);
+            if (cursor > chunk_end) cursor = chunk_end;
+        }
+        if (!__any(have)) break;
+        if (!have) continue;
+        // ---- one fetch at the current x_l ----
+        const float ix = scale[0] * (x_l[0] + offset[0]);
+        const float iy = scale[1] * (x_l[1] + offset[1]);
+        const float iz = scale[2] * (x_l[2] + offset[2]);
+        float Jl[12];
+        grid_sample_J<LAYOUT>(vJ, D, H, W, ix, iy, iz, Jl);
+        if (it < 0) {
+            // initial fetch: J_inv guess and g(x0)   (fuse_cuda_kernel_fast.cu:295-331)
+            Ji[0] = Jl[0]; Ji[3] = Jl[1]; Ji[6] = Jl[2];
+            Ji[1] = Jl[4]; Ji[4] = Jl[5]; Ji[7] = Jl[6];
+            Ji[2] = Jl[8]; Ji[5] = Jl[9]; Ji[8] = Jl[10];
+            gx[0] = Jl[0] * x_l[0] + Jl[1] * x_l[1] + Jl[2] * x_l[2] + Jl[3];
+            gx[1] = Jl[4] * x_l[0] + Jl[5] * x_l[1] + Jl[6] * x_l[2] + Jl[7];
+            gx[2] = Jl[8] * x_l[0] + Jl[9] * x_l[1] + Jl[10] * x_l[2] + Jl[11];
+            gx[0] = gx[0] - xt[0]; gx[1] = gx[1] - xt[1]; gx[2] = gx[2] - xt[2];
+            it = 0;
+        } else {
+            // fetch of iteration `it` (x_l already updated): residual, tests, Broyden update (:352-411)
+            float gn[3];
+            gn[0] = Jl[0] * x_l[0] + Jl[1] * x_l[1] + Jl[2] * x_l[2] + Jl[3] - xt[0];
+            gn[1] = Jl[4] * x_l[0] + Jl[5] * x_l[1] + Jl[6] * x_l[2] + Jl[7] - xt[1];
+            gn[2] = Jl[8] * x_l[0] + Jl[9] * x_l[1] + Jl[10] * x_l[2] + Jl[11] - xt[2];
+            const float norm_gx = gn[0] * gn[0] + gn[1] * gn[1] + gn[2] * gn[2];
+            if (norm_gx < cvg2) {
+                const bool ok = ix >= -1 && ix <= 1 && iy >= -1 && iy <= 1 && iz >= -1 && iz <= 1;
+                is_valid[index] = ok ? 1 : 0;
+                if (ok) {
+                    x[index * 3 + 0] = x_l[0]; x[index * 3 + 1] = x_l[1]; x[index * 3 + 2] = x_l[2];
+                    if (J_inv) {
+                        float* Jo = J_inv + index * 9;
+#pragma unroll
+                        for (int k = 0; k < 9; k++) Jo[k] = Ji[k];
+                    }
+                    if (fwd_J) {
+                        float* Fo = fwd_J + index * 9;
+                        Fo[0] = Jl[0]; Fo[1] = Jl[1]; Fo[2] = Jl[2]; Fo[3] = Jl[4]; Fo[4] = Jl[5]; Fo[5] = Jl[6];
+                        Fo[6] = Jl[8]; Fo[7] = Jl[9]; Fo[8] = Jl[10];
+                    }
+                }
+                have = false;
+                continue;
+            } else if (norm_gx > dvg2) {
+                is_valid[index] = 0;
+                have = false;
+                continue;
+            }
+            J_inv_update(Ji, u[0], u[1], u[2], gn[0] - gx[0], gn[1] - gx[1], gn[2] - gx[2]);
+            gx[0] = gn[0]; gx[1] = gn[1]; gx[2] = gn[2];
+            it++;
+            if (it >= 10) { have = false; continue; }       // not converged: is_valid stays 0 (pre-zeroed)
+        }
+        // step: update = -J_inv g, x += update
+        u[0] = -Ji[0] * gx[0] + -Ji[1] * gx[1] + -Ji[2] * gx[2];
+        u[1] = -Ji[3] * gx[0] + -Ji[4] * gx[1] + -Ji[5] * gx[2];
+        u[2] = -Ji[6] * gx[0] + -Ji[7] * gx[1] + -Ji[8] * gx[2];
+        x_l[0] += u[0]; x_l[1] += u[1]; x_l[2] += u[2];
+    }
+}
+
 // ---- K9 -------------------------------------------------------------------------
 __global__ __launch_bounds__(THREADS) void filter_kernel(int64_t N, int I, const float* __restrict__ x,
                                                           const uint8_t* __restrict__ mask, uint8_t* __restrict__ out)
@@ -267,16 +391,34 @@ IA_EXPORT int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt, cons
     const int64_t total = (int64_t)B * N * I;
     if (total == 0) return IA_OK;
     IA_REQUIRE(layout == IA_LAYOUT_NCDHW || layout == IA_LAYOUT_NDHWC, "unknown voxel_J layout");
-    const int grid = ia::cdiv(total, THREADS);
     hipStream_t s = (hipStream_t)stream;
-    if (layout == IA_LAYOUT_NDHWC)
-        broyden_kernel<IA_LAYOUT_NDHWC><<<grid, THREADS, 0, s>>>(total, N, I, xd_tgt, voxel_J, D, H, W, tfs, bone_ids,
-                                                                 offset, scale, cvg_threshold, dvg_threshold, x, J_inv,
-                                                                 is_valid, fwd_J);
-    else
-        broyden_kernel<IA_LAYOUT_NCDHW><<<grid, THREADS, 0, s>>>(total, N, I, xd_tgt, voxel_J, D, H, W, tfs, bone_ids,
-                                                                 offset, scale, cvg_threshold, dvg_threshold, x, J_inv,
-                                                                 is_valid, fwd_J);
+    // Two bit-identical schedules.  Measured on MI355X (profiles/r01_*): primary-ray batches (most searches converge,
+    // uniform length) are ~20 % faster with one item per lane; the huge secondary-ray batches (most searches diverge
+    // after 1-3 steps) are ~8 % faster with the lane-persistent schedule.  Both sit near the L2-gather roofline.
+    bool persistent = total >= (int64_t)32 << 20;
+    if (const char* e = getenv("IA_BROYDEN_SCHEDULE")) persistent = (e[0] == 'p');     // test hook: "persistent" / "simple"
+    if (persistent) {
+        const int64_t n_waves = (total + BR_CHUNK - 1) / BR_CHUNK;
+        const int grid = ia::cdiv(n_waves * 64, THREADS);
+        if (layout == IA_LAYOUT_NDHWC)
+            broyden_persistent_kernel<IA_LAYOUT_NDHWC><<<grid, THREADS, 0, s>>>(total, N, I, xd_tgt, voxel_J, D, H, W, tfs,
+                                                                                bone_ids, offset, scale, cvg_threshold,
+                                                                                dvg_threshold, x, J_inv, is_valid, fwd_J);
+        else
+            broyden_persistent_kernel<IA_LAYOUT_NCDHW><<<grid, THREADS, 0, s>>>(total, N, I, xd_tgt, voxel_J, D, H, W, tfs,
+                                                                                bone_ids, offset, scale, cvg_threshold,
+                                                                                dvg_threshold, x, J_inv, is_valid, fwd_J);
+    } else {
+        const int grid = ia::cdiv(total, THREADS);
+        if (layout == IA_LAYOUT_NDHWC)
+            broyden_kernel<IA_LAYOUT_NDHWC><<<grid, THREADS, 0, s>>>(total, N, I, xd_tgt, voxel_J, D, H, W, tfs, bone_ids,
+                                                                     offset, scale, cvg_threshold, dvg_threshold, x, J_inv,
+                                                                     is_valid, fwd_J);
+        else
+            broyden_kernel<IA_LAYOUT_NCDHW><<<grid, THREADS, 0, s>>>(total, N, I, xd_tgt, voxel_J, D, H, W, tfs, bone_ids,
+                                                                     offset, scale, cvg_threshold, dvg_threshold, x, J_inv,
+                                                                     is_valid, fwd_J);
+    }
     return ia::check_launch("ia_fuse_broyden");
 }
 

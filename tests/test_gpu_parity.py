@@ -260,7 +260,9 @@ def test_resampling_vs_oracle_large(ops, oracle):
 
 
 # ----------------------------------------------------------------------------- fast-SNARF
-def test_fast_snarf_vs_golden(ops, golden_dir):
+@pytest.mark.parametrize("schedule", ["simple", "persistent"])
+def test_fast_snarf_vs_golden(ops, golden_dir, schedule, monkeypatch):
+    monkeypatch.setenv("IA_BROYDEN_SCHEDULE", schedule)     # both Broyden schedules must be bit-identical
     g = np.load(os.path.join(golden_dir, "golden_snarf.npz"))
     sn = ops["snarf"]
     vw = T(g["voxel_w"].astype(np.float32))
