@@ -18,24 +18,18 @@
 //     for both operand patterns;
 //   * SDF head: g_z = softplus'(z) * W2[0,:], g_h = g_z W1 (one more MFMA GEMM), then a per-point
 //     epilogue contracts g_h with the hash-grid Jacobian (d enc / d x) -> analytic gradient.
-#include "ia_common.h"
+#include "mlp_tile.h"
 
 namespace {
+
+using mlp::Seg;
+using mlp::MAX_SEGS;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int THREADS = 256;            // 4 waves, one 64-point tile each per iteration
 constexpr int HID = 64;
-constexpr int MAX_SEGS = 5;
-
-struct Seg {
-    const float* p;
-    int stride;   // floats between consecutive points
-    int width;    // columns taken from this source
-    float mul, add;
-};
-
 struct MlpArgs {
     int64_t n;
     int n_segs;
@@ -57,7 +51,7 @@ __device__ __forceinline__ float act_hidden(float v, int hact)
     return bx > 20.0f ? v : log1pf(__expf(bx)) * 0.01f;
 }
 
-template <int IN, int NHID, int OUT, int HACT, int OACT, bool SDF_GRAD>
+template <int KIND, int IN, int NHID, int OUT, int HACT, int OACT, bool SDF_GRAD>
 __global__ __launch_bounds__(THREADS) void mlp_fwd_kernel(MlpArgs a)
 {
     constexpr int IN_PAD = (IN + 1) / 2 * 2;
@@ -96,20 +90,7 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_kernel(MlpArgs a)
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t p0 = tile * 64;
         // ---- assemble the input rows in LDS ----
-        int col0 = 0;
-        for (int s = 0; s < a.n_segs; s++) {
-            const Seg sg = a.segs[s];
-            const int tot = 64 * sg.width;
-            for (int i = lane; i < tot; i += 64) {
-                const int r = i / sg.width, c = i % sg.width;
-                const int64_t p = p0 + r;
-                float v = 0.0f;
-                if (p < a.n) v = sg.p[p * sg.stride + c] * sg.mul + sg.add;
-                sX[r * LDX + col0 + c] = v;
-            }
-            col0 += sg.width;
-        }
-        if (IN_PAD > IN) sX[lane * LDX + IN] = 0.0f;
+        mlp::assemble<KIND, IN>(sX, LDX, a.segs, p0, a.n, lane);
 
         const int lr = lane & 31, lk = lane >> 5;
         // ---- layer 1: [64 x IN_PAD] x W1^T -> [64 x 64] ----
@@ -141,8 +122,13 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_kernel(MlpArgs a)
                 for (int r = 0; r < 16; r++) {
                     const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * lk, col = 32 * nt + lr;
                     const float z = acc[m][nt][r] + sB[col];
-                    sX[row * LDX + col] = act_hidden(z, HACT);
-                    if (SDF_GRAD) sig[m][nt][r] = 1.0f / (1.0f + __expf(-100.0f * z));
+                    if (HACT == 1) {
+                        float sg;
+                        sX[row * LDX + col] = mlp::softplus100(z, sg);
+                        if (SDF_GRAD) sig[m][nt][r] = sg;
+                    } else {
+                        sX[row * LDX + col] = fmaxf(z, 0.0f);
+                    }
                 }
         // ---- layer 2 (optional) ----
         if (NHID == 2) {
@@ -261,14 +247,14 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_kernel(MlpArgs a)
     }
 }
 
-template <int IN, int NHID, int OUT, int HACT, int OACT, bool SDF_GRAD>
+template <int KIND, int IN, int NHID, int OUT, int HACT, int OACT, bool SDF_GRAD>
 int launch_fwd(const MlpArgs& a, hipStream_t s)
 {
     constexpr int IN_PAD = (IN + 1) / 2 * 2;
     constexpr int LDW1 = IN_PAD + 1, LDW = HID + 1, LDX = (IN_PAD > HID ? IN_PAD : HID) + 1;
     constexpr size_t lds = sizeof(float) * (HID * LDW1 + (NHID == 2 ? HID * LDW : 0) + 16 * LDW + 144 + 4 * 64 * LDX);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = mlp_fwd_kernel<IN, NHID, OUT, HACT, OACT, SDF_GRAD>;
+    auto kern = mlp_fwd_kernel<KIND, IN, NHID, OUT, HACT, OACT, SDF_GRAD>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -285,25 +271,6 @@ int launch_fwd(const MlpArgs& a, hipStream_t s)
 
 }  // namespace
 
-static int fill_args(MlpArgs& a, int64_t n, int n_segs, const float* const* seg_ptr, const int* seg_stride,
-                     const int* seg_width, const float* seg_mul, const float* seg_add, int in_dim)
-{
-    IA_REQUIRE(n_segs >= 1 && n_segs <= MAX_SEGS, "1..5 input segments");
-    int tot = 0;
-    a.n = n;
-    a.n_segs = n_segs;
-    for (int s = 0; s < n_segs; s++) {
-        a.segs[s].p = seg_ptr[s];
-        a.segs[s].stride = seg_stride[s];
-        a.segs[s].width = seg_width[s];
-        a.segs[s].mul = seg_mul ? seg_mul[s] : 1.0f;
-        a.segs[s].add = seg_add ? seg_add[s] : 0.0f;
-        tot += seg_width[s];
-    }
-    IA_REQUIRE(tot == in_dim, "segment widths must sum to the MLP input width");
-    return IA_OK;
-}
-
 // kind: 0 = SDF 35->64->13 softplus100 (optionally with analytic gradient)
 //       1 = radiance 67->64->64->3 relu, sigmoid output
 //       2 = material 48->64->64->5 relu, sigmoid output
@@ -317,8 +284,11 @@ IA_EXPORT int ia_mlp_fwd(int kind, int64_t n, int n_segs, const float* const* se
     MlpArgs a = {};
     const int in_dim = kind == 0 ? 35 : (kind == 1 ? 67 : 48);
     IA_REQUIRE(kind >= 0 && kind <= 2, "unknown MLP kind");
-    int r = fill_args(a, n, n_segs, seg_ptr, seg_stride, seg_width, seg_mul, seg_add, in_dim);
+    a.n = n;
+    a.n_segs = n_segs;
+    int r = mlp::fill_segs(a.segs, kind, n_segs, seg_ptr, seg_stride, seg_width, seg_mul, seg_add);
     if (r != IA_OK) return r;
+    (void)in_dim;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Wo = Wo; a.bo = bo;
     a.y = y; a.y_stride = y_stride;
     a.jac = jac; a.xyz_col = xyz_col; a.grad = grad;
@@ -328,10 +298,10 @@ IA_EXPORT int ia_mlp_fwd(int kind, int64_t n, int n_segs, const float* const* se
         if (grad) {
             IA_REQUIRE(jac != nullptr && inv_scale_host != nullptr, "SDF gradient needs the hash-grid Jacobian and 1/scale");
             IA_REQUIRE(seg_width[0] == 32, "SDF head: segment 0 must be the 32 hash features");
-            return launch_fwd<35, 1, 13, 1, 0, true>(a, s);
+            return launch_fwd<0, 35, 1, 13, 1, 0, true>(a, s);
         }
-        return launch_fwd<35, 1, 13, 1, 0, false>(a, s);
+        return launch_fwd<0, 35, 1, 13, 1, 0, false>(a, s);
     }
-    if (kind == 1) return launch_fwd<67, 2, 3, 0, 1, false>(a, s);
-    return launch_fwd<48, 2, 5, 0, 1, false>(a, s);
+    if (kind == 1) return launch_fwd<1, 67, 2, 3, 0, 1, false>(a, s);
+    return launch_fwd<2, 48, 2, 5, 0, 1, false>(a, s);
 }

@@ -13,18 +13,18 @@
 // d sdf / d x is an output that losses depend on (eikonal, normal-conditioned radiance): the
 // reference gets them from autograd's double backward through VanillaMLP + tcnn
 // (models/rf/geometry.py:165-172 with create_graph=True).
-#include "ia_common.h"
+#include "mlp_tile.h"
 
 namespace {
+
+using mlp::Seg;
+using mlp::MAX_SEGS;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int THREADS = 256;
 constexpr int HID = 64;
-constexpr int MAX_SEGS = 5;
-
-struct Seg { const float* p; int stride; int width; float mul, add; };
 
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2])
 {
@@ -89,24 +89,6 @@ __device__ __forceinline__ void stage_matrix(float* dst, int ld, const float* sr
     }
 }
 
-template <int IN>
-__device__ __forceinline__ void assemble(float* sT, int ldx, int n_segs, const Seg* segs, int64_t p0, int64_t n, int lane)
-{
-    constexpr int IN_PAD = (IN + 1) / 2 * 2;
-    int col0 = 0;
-    for (int s = 0; s < n_segs; s++) {
-        const Seg sg = segs[s];
-        const int tot = 64 * sg.width;
-        for (int i = lane; i < tot; i += 64) {
-            const int r = i / sg.width, c = i % sg.width;
-            const int64_t p = p0 + r;
-            sT[r * ldx + col0 + c] = (p < n) ? sg.p[p * sg.stride + c] * sg.mul + sg.add : 0.0f;
-        }
-        col0 += sg.width;
-    }
-    if (IN_PAD > IN) sT[lane * ldx + IN] = 0.0f;
-}
-
 // copy the [64 x cols] LDS tile to global [n, gstride] (rows beyond n skipped); coalesced along columns
 __device__ __forceinline__ void tile_to_global(const float* sT, int ldx, float* g, int gstride, int cols, int64_t p0,
                                                int64_t n, int lane)
@@ -135,7 +117,7 @@ struct Bwd2Args {
     float *G1, *G2, *G3;  // [n,64], [n,64], [n,16]
 };
 
-template <int IN, int OUT>
+template <int KIND, int IN, int OUT>
 __global__ __launch_bounds__(THREADS) void mlp2_bwd_kernel(Bwd2Args a)
 {
     constexpr int IN_PAD = (IN + 1) / 2 * 2;
@@ -157,7 +139,7 @@ __global__ __launch_bounds__(THREADS) void mlp2_bwd_kernel(Bwd2Args a)
     const int64_t n_tiles = (a.n + 63) / 64;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t p0 = tile * 64;
-        assemble<IN>(sT, LDX, a.n_segs, a.segs, p0, a.n, lane);
+        mlp::assemble<KIND, IN>(sT, LDX, a.segs, p0, a.n, lane);
         tile_to_global(sT, LDX, a.X, IN_PAD, IN_PAD, p0, a.n, lane);
         f32x16 acc[2][2];
         unsigned long long m1 = 0ull, m2 = 0ull;      // relu masks in accumulator-fragment order
@@ -299,15 +281,15 @@ __global__ __launch_bounds__(THREADS) void sdf_bwd_kernel(SdfBwdArgs a)
         f32x16 acc[2][2];
         float sig[2][2][16];
         // ---- forward: h -> z -> (a, s) ----
-        assemble<IN>(sT, LDX, a.n_segs, a.segs, p0, a.n, lane);
+        mlp::assemble<0, IN>(sT, LDX, a.segs, p0, a.n, lane);
         tile_to_global(sT, LDX, a.Hh, IN_PAD, IN_PAD, p0, a.n, lane);
         zero_acc(acc);
         gemm_xwT<IN_PAD / 2>(sT, LDX, sW1, LDW1, acc, lane);
         ACC_FOREACH(m, nt, r, row, col, lane) {
             const float z = acc[m][nt][r] + sB[col];
-            const float bx = 100.0f * z;
-            sT[row * LDX + col] = bx > 20.0f ? z : log1pf(__expf(bx)) * 0.01f;
-            sig[m][nt][r] = 1.0f / (1.0f + __expf(-bx));
+            float sg;
+            sT[row * LDX + col] = mlp::softplus100(z, sg);
+            sig[m][nt][r] = sg;
         }
         tile_to_global(sT, LDX, a.A, HID, HID, p0, a.n, lane);
         // ---- gz = s * W2[0,:]  -> tile, global ; gh = gz W1 -> gG ----
@@ -440,31 +422,14 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(int64_t n, const float* 
             }
 }
 
-int fill_segs(Seg* segs, int n_segs, const float* const* seg_ptr, const int* seg_stride, const int* seg_width,
-              const float* seg_mul, const float* seg_add, int in_dim)
-{
-    IA_REQUIRE(n_segs >= 1 && n_segs <= MAX_SEGS, "1..5 input segments");
-    int tot = 0;
-    for (int s = 0; s < n_segs; s++) {
-        segs[s].p = seg_ptr[s];
-        segs[s].stride = seg_stride[s];
-        segs[s].width = seg_width[s];
-        segs[s].mul = seg_mul ? seg_mul[s] : 1.0f;
-        segs[s].add = seg_add ? seg_add[s] : 0.0f;
-        tot += seg_width[s];
-    }
-    IA_REQUIRE(tot == in_dim, "segment widths must sum to the MLP input width");
-    return IA_OK;
-}
-
-template <int IN, int OUT>
+template <int KIND, int IN, int OUT>
 int launch_bwd2(const Bwd2Args& a, hipStream_t s)
 {
     constexpr int IN_PAD = (IN + 1) / 2 * 2;
     constexpr int LDW1 = IN_PAD + 1, LDW = HID + 1, LDX = (IN_PAD > HID ? IN_PAD : HID) + 1;
     constexpr size_t lds = sizeof(float) * (HID * LDW1 + HID * LDW + 16 * LDW + 144 + 4 * 64 * LDX);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = mlp2_bwd_kernel<IN, OUT>;
+    auto kern = mlp2_bwd_kernel<KIND, IN, OUT>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     const int64_t n_tiles = (a.n + 63) / 64;
@@ -487,12 +452,12 @@ IA_EXPORT int ia_mlp_bwd(int kind, int64_t n, int n_segs, const float* const* se
     IA_REQUIRE(kind == 1 || kind == 2, "ia_mlp_bwd: kind must be 1 (radiance) or 2 (material)");
     Bwd2Args a = {};
     a.n = n; a.n_segs = n_segs;
-    int r = fill_segs(a.segs, n_segs, seg_ptr, seg_stride, seg_width, seg_mul, seg_add, kind == 1 ? 67 : 48);
+    int r = mlp::fill_segs(a.segs, kind, n_segs, seg_ptr, seg_stride, seg_width, seg_mul, seg_add);
     if (r != IA_OK) return r;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Wo = Wo; a.bo = bo;
     a.g_y = g_y; a.g_x = g_x; a.gx_stride = gx_stride;
     a.X = X; a.A1 = A1; a.A2 = A2; a.G1 = G1; a.G2 = G2; a.G3 = G3;
-    return kind == 1 ? launch_bwd2<67, 3>(a, (hipStream_t)stream) : launch_bwd2<48, 5>(a, (hipStream_t)stream);
+    return kind == 1 ? launch_bwd2<1, 67, 3>(a, (hipStream_t)stream) : launch_bwd2<2, 48, 5>(a, (hipStream_t)stream);
 }
 
 IA_EXPORT int ia_sdf_mlp_bwd(int64_t n, int n_segs, const float* const* seg_ptr, const int* seg_stride,
@@ -504,9 +469,8 @@ IA_EXPORT int ia_sdf_mlp_bwd(int64_t n, int n_segs, const float* const* seg_ptr,
     if (n == 0) return IA_OK;
     SdfBwdArgs a = {};
     a.n = n; a.n_segs = n_segs;
-    int r = fill_segs(a.segs, n_segs, seg_ptr, seg_stride, seg_width, seg_mul, seg_add, 35);
+    int r = mlp::fill_segs(a.segs, 0, n_segs, seg_ptr, seg_stride, seg_width, seg_mul, seg_add);
     if (r != IA_OK) return r;
-    IA_REQUIRE(seg_width[0] == 32, "segment 0 must be the 32 hash features");
     a.W1 = W1; a.b1 = b1; a.Wo = Wo; a.bo = bo; a.jac = jac; a.g_out = g_out; a.q = q;
     a.gE = gE; a.gG = gG; a.Hh = Hh; a.U = U; a.DZ = DZ; a.GZ = GZ; a.A = A; a.DGS = DGS;
     constexpr int LDW1 = 37, LDW = 65, LDX = 65;

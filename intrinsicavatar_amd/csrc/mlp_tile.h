@@ -1,0 +1,97 @@
+// mlp_tile.h -- shared pieces of the fused MLP kernels (mlp.hip, mlp_bwd.hip): input-row assembly in LDS.
+#pragma once
+#include "ia_common.h"
+
+namespace mlp {
+
+constexpr int MAX_SEGS = 5;
+
+struct Seg {
+    const float* p;
+    int stride;   // floats between consecutive points
+    int width;    // columns taken from this source
+    float mul, add;
+};
+
+// compile-time segment widths per MLP kind (0 SDF, 1 radiance, 2 material): lets the compiler turn the
+// index arithmetic into shifts / multiply-high and issue all loads of a segment back to back
+template <int KIND> struct SegWidths;
+template <> struct SegWidths<0> { static constexpr int n = 2; static constexpr int w[MAX_SEGS] = {32, 3, 0, 0, 0}; };
+template <> struct SegWidths<1> { static constexpr int n = 5; static constexpr int w[MAX_SEGS] = {32, 3, 13, 16, 3}; };
+template <> struct SegWidths<2> { static constexpr int n = 3; static constexpr int w[MAX_SEGS] = {32, 3, 13, 0, 0}; };
+
+template <int WIDTH>
+__device__ __forceinline__ void load_segment(float* sT, int ldx, int col0, const Seg& sg, int64_t p0, int64_t n, int lane)
+{
+    if constexpr (WIDTH == 0) return;
+    if constexpr (WIDTH % 4 == 0) {
+        // 16-byte loads when the rows allow it (hash features: 32 wide, SH: 16 wide)
+        const bool vec_ok = ((sg.stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(sg.p) & 15) == 0);
+        if (vec_ok) {
+            constexpr int V = WIDTH / 4;
+#pragma unroll
+            for (int i0 = 0; i0 < 64 * V; i0 += 64) {
+                const int i = i0 + lane;
+                const int r = i / V, c4 = i % V;
+                const int64_t p = p0 + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < n) v = *reinterpret_cast<const float4*>(sg.p + p * sg.stride + c4 * 4);
+                float* d = sT + r * ldx + col0 + c4 * 4;
+                d[0] = v.x * sg.mul + sg.add; d[1] = v.y * sg.mul + sg.add;
+                d[2] = v.z * sg.mul + sg.add; d[3] = v.w * sg.mul + sg.add;
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < 64 * WIDTH; i0 += 64) {
+        const int i = i0 + lane;
+        const int r = i / WIDTH, c = i % WIDTH;
+        const int64_t p = p0 + r;
+        sT[r * ldx + col0 + c] = (p < n) ? sg.p[p * sg.stride + c] * sg.mul + sg.add : 0.0f;
+    }
+}
+
+template <int KIND, int IN>
+__device__ __forceinline__ void assemble(float* sT, int ldx, const Seg* segs, int64_t p0, int64_t n, int lane)
+{
+    using SW = SegWidths<KIND>;
+    constexpr int IN_PAD = (IN + 1) / 2 * 2;
+    load_segment<SW::w[0]>(sT, ldx, 0, segs[0], p0, n, lane);
+    load_segment<SW::w[1]>(sT, ldx, SW::w[0], segs[1], p0, n, lane);
+    load_segment<SW::w[2]>(sT, ldx, SW::w[0] + SW::w[1], segs[2], p0, n, lane);
+    load_segment<SW::w[3]>(sT, ldx, SW::w[0] + SW::w[1] + SW::w[2], segs[3], p0, n, lane);
+    load_segment<SW::w[4]>(sT, ldx, SW::w[0] + SW::w[1] + SW::w[2] + SW::w[3], segs[4], p0, n, lane);
+    if (IN_PAD > IN) sT[lane * ldx + IN] = 0.0f;
+}
+
+inline int fill_segs(Seg* segs, int kind, int n_segs, const float* const* seg_ptr, const int* seg_stride,
+                     const int* seg_width, const float* seg_mul, const float* seg_add)
+{
+    static const int W[3][MAX_SEGS] = {{32, 3, 0, 0, 0}, {32, 3, 13, 16, 3}, {32, 3, 13, 0, 0}};
+    static const int NS[3] = {2, 5, 3};
+    if (kind < 0 || kind > 2) { ia::set_error("unknown MLP kind"); return IA_ERR_INVALID; }
+    if (n_segs != NS[kind]) { ia::set_error("MLP kind %d takes exactly %d input segments", kind, NS[kind]); return IA_ERR_INVALID; }
+    for (int s = 0; s < MAX_SEGS; s++) { segs[s].p = nullptr; segs[s].stride = 0; segs[s].width = 0; segs[s].mul = 1.f; segs[s].add = 0.f; }
+    for (int s = 0; s < n_segs; s++) {
+        if (seg_width[s] != W[kind][s]) { ia::set_error("MLP kind %d: segment %d must be %d wide", kind, s, W[kind][s]); return IA_ERR_INVALID; }
+        segs[s].p = seg_ptr[s];
+        segs[s].stride = seg_stride[s];
+        segs[s].width = seg_width[s];
+        segs[s].mul = seg_mul ? seg_mul[s] : 1.0f;
+        segs[s].add = seg_add ? seg_add[s] : 0.0f;
+    }
+    return IA_OK;
+}
+
+// Softplus(beta=100, threshold=20) and its derivative with the hardware exp/log units
+__device__ __forceinline__ float softplus100(float z, float& sig)
+{
+    const float bx = 100.0f * z;
+    const float e = __expf(-fabsf(bx));                 // in (0, 1]
+    const float l = (e < 1e-4f) ? e * (1.0f - 0.5f * e) : __logf(1.0f + e);     // log1p(e)
+    sig = bx >= 0.0f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+    return bx > 20.0f ? z : (fmaxf(bx, 0.0f) + l) * 0.01f;
+}
+
+}  // namespace mlp

@@ -122,13 +122,18 @@ def test_mlps_vs_reference_modules(fields, golden_dir):
     np.testing.assert_allclose(N(y), g["sdf_y"], rtol=2e-5, atol=5e-6)
     # radiance net (sigmoid applied by the kernel; reference applies it outside: radiance.py:132-133)
     x = T(g["rad_x"])
-    y = fields.mlp_forward(1, [(x, 67, 1.0, 0.0)], *[T(g[f"rad_sd_layers.{i}.{k}"]) for i in (0, 2, 4) for k in ("weight", "bias")], 3)
-    ref = 1 / (1 + np.exp(-g["rad_y"].astype(np.float64)))
-    np.testing.assert_allclose(N(y), ref, rtol=2e-5, atol=2e-6)
-    # split the same input over 5 segments (as the render path does)
+    # the kernel takes the 67-wide row as its five sources (as the render path does)
     segs = [(x[:, :32].contiguous(), 32, 1.0, 0.0), (x[:, 32:35].contiguous(), 3, 1.0, 0.0), (x[:, 35:48].contiguous(), 13, 1.0, 0.0),
             (x[:, 48:64].contiguous(), 16, 1.0, 0.0), (x[:, 64:67].contiguous(), 3, 1.0, 0.0)]
-    y2 = fields.mlp_forward(1, segs, *[T(g[f"rad_sd_layers.{i}.{k}"]) for i in (0, 2, 4) for k in ("weight", "bias")], 3)
+    y = fields.mlp_forward(1, segs, *[T(g[f"rad_sd_layers.{i}.{k}"]) for i in (0, 2, 4) for k in ("weight", "bias")], 3)
+    ref = 1 / (1 + np.exp(-g["rad_y"].astype(np.float64)))
+    np.testing.assert_allclose(N(y), ref, rtol=2e-5, atol=2e-6)
+    # strided (non-vectorisable) sources give the same result as the 16-byte-load path
+    xs = torch.zeros((x.shape[0], 71), device=DEV)
+    xs[:, 1:68] = x
+    segs2 = [(xs[:, 1:33], 32, 1.0, 0.0), (xs[:, 33:36], 3, 1.0, 0.0), (xs[:, 36:49], 13, 1.0, 0.0), (xs[:, 49:65], 16, 1.0, 0.0),
+             (xs[:, 65:68], 3, 1.0, 0.0)]
+    y2 = fields.mlp_forward(1, segs2, *[T(g[f"rad_sd_layers.{i}.{k}"]) for i in (0, 2, 4) for k in ("weight", "bias")], 3)
     assert torch.equal(y, y2)
     # material net (LipshitzMLP normalisation folded on the host: network_utils.py:396-403)
     Ws, bs = [], []
@@ -138,7 +143,9 @@ def test_mlps_vs_reference_modules(fields, golden_dir):
         sp = np.log1p(np.exp(c)) if c < 20 else c
         Ws.append((w * np.minimum(sp / np.abs(w).sum(1), 1.0)[:, None]).astype(np.float32))
         bs.append(g[f"mat_sd_biases_per_layer.{i}"])
-    y = fields.mlp_forward(2, [(T(g["mat_x"]), 48, 1.0, 0.0)], T(Ws[0]), T(bs[0]), T(Ws[1]), T(bs[1]), T(Ws[2]), T(bs[2]), 5)
+    xm = T(g["mat_x"])
+    msegs = [(xm[:, :32].contiguous(), 32, 1.0, 0.0), (xm[:, 32:35].contiguous(), 3, 1.0, 0.0), (xm[:, 35:48].contiguous(), 13, 1.0, 0.0)]
+    y = fields.mlp_forward(2, msegs, T(Ws[0]), T(bs[0]), T(Ws[1]), T(bs[1]), T(Ws[2]), T(bs[2]), 5)
     ref = 1 / (1 + np.exp(-g["mat_y"].astype(np.float64)))
     np.testing.assert_allclose(N(y), ref, rtol=2e-5, atol=2e-6)
 
