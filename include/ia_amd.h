@@ -251,10 +251,10 @@ int ia_sdf_mlp_bwd(int64_t n, int n_segs, const float* const* seg_ptr, const int
                    float* Hh /*[n,36]*/, float* U /*[n,36]*/, float* DZ /*[n,64]*/, float* GZ /*[n,64]*/,
                    float* A /*[n,64]*/, float* DGS /*[n,64]*/, ia_stream_t stream);
 
-/* split-K weight gradient on the matrix cores: dW[M,ldw] += G[:, :M]^T . A[:, :N]
- * (M <= 64, N <= 96; strides <= 64 / 96 floats; accumulates with atomics into caller-zeroed dW) */
+/* split-K weight gradient on the matrix cores: dW[M,ldw] += G[:, :M]^T . A[:, :N], db[M] += column sums of G
+ * (M <= 64, N <= 96; strides <= 64 / 96 floats; accumulates with atomics into caller-zeroed dW / db; db may be NULL) */
 int ia_wgrad(int64_t n, const float* G, int g_stride, int M, const float* A, int a_stride, int N, float* dW, int ldw,
-             ia_stream_t stream);
+             float* db, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* lib.torch_pbr call chain of pbr_light_forward (models/intrinsic_avatar.py:755-861), fused:

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(THREADS) void sdf_bwd_kernel(SdfBwdArgs a)
 constexpr int WG_ROWS = 16;
 __global__ __launch_bounds__(THREADS) void wgrad_kernel(int64_t n, const float* __restrict__ G, int gs, int M,
                                                         const float* __restrict__ A, int as, int N,
-                                                        float* __restrict__ dW, int ldw)
+                                                        float* __restrict__ dW, int ldw, float* __restrict__ db)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -370,12 +370,14 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(int64_t n, const float* 
     float* sA = sG + g_tile + 64;
     const int lr = lane & 31, lk = lane >> 5;
     f32x16 acc[2][3];
+    float colsum = 0.0f;      // db: lane c accumulates column c of G over all slabs of this wave
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+    for (int m = 0; m < 2; m++) {
 #pragma unroll
         for (int nt = 0; nt < 3; nt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[m][nt][r] = 0.0f;
+    }
     // slack words (read by out-of-range columns of the last rows) must be finite
     for (int i = lane; i < 64; i += 64) sG[g_tile + i] = 0.0f;
     for (int i = lane; i < 96; i += 64) sA[a_tile + i] = 0.0f;
@@ -409,7 +411,12 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(int64_t n, const float* 
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
             acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, acc[1][2], 0, 0, 0);
         }
+        if (db && lane < M) {
+#pragma unroll
+            for (int k = 0; k < WG_ROWS; k++) colsum += sG[k * gs + lane];
+        }
     }
+    if (db && lane < M && colsum != 0.0f) unsafeAtomicAdd(db + lane, colsum);
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -487,7 +494,7 @@ IA_EXPORT int ia_sdf_mlp_bwd(int64_t n, int n_segs, const float* const* seg_ptr,
 // dW[M, ldw] += G[:, :M]^T A[:, :N]   (accumulated into; caller zeroes).  g_stride / a_stride in floats; rows must be
 // 16-byte aligned per 16-row slab (any stride that is a multiple of 1 float works: 16 * stride * 4 B is a multiple of 16).
 IA_EXPORT int ia_wgrad(int64_t n, const float* G, int g_stride, int M, const float* A, int a_stride, int N, float* dW,
-                       int ldw, ia_stream_t stream)
+                       int ldw, float* db, ia_stream_t stream)
 {
     if (n == 0) return IA_OK;
     IA_REQUIRE(M >= 1 && M <= 64 && N >= 1 && N <= 96, "ia_wgrad: M <= 64, N <= 96");
@@ -497,6 +504,6 @@ IA_EXPORT int ia_wgrad(int64_t n, const float* G, int g_stride, int M, const flo
     const int64_t n_tiles = (n + WG_ROWS - 1) / WG_ROWS;
     int grid = (int)((n_tiles + 3) / 4);
     if (grid > 768) grid = 768;
-    wgrad_kernel<<<grid, THREADS, lds, (hipStream_t)stream>>>(n, G, g_stride, M, A, a_stride, N, dW, ldw);
+    wgrad_kernel<<<grid, THREADS, lds, (hipStream_t)stream>>>(n, G, g_stride, M, A, a_stride, N, dW, ldw, db);
     return ia::check_launch("ia_wgrad");
 }

@@ -190,6 +190,11 @@ def build_frame(device="cuda:0", height=128, width=128, pose_seed=0, beta=0.01, 
     dfm.prepare(torch.from_numpy(rig["tfs"]).to(dev), torch.from_numpy(rig["w2s"]).to(dev))
     geo = fields.VolumeSDF(seed=seed).to(dev)
     rad = fields.VolumeRefDirRadiance(seed=seed + 1).to(dev)
+    with torch.no_grad():
+        # sphere init zeroes the hash-feature columns of the first SDF layer (network_utils.py:222-226); a trained
+        # network has them populated, and the backward pass is only representative if they are non-zero
+        gw = torch.Generator().manual_seed(seed + 3)
+        geo.network.layers[0].weight_v[:, 3:] = (torch.randn((64, 32), generator=gw) * 0.02).to(dev)
     if hash_amp != 1e-4:
         with torch.no_grad():
             geo.grid_params.mul_(hash_amp / 1e-4)

@@ -31,9 +31,9 @@ def wgrad(G: Tensor, M: int, A: Tensor, N: int, want_bias: bool = True):
     """dW [M,N] = G[:, :M]^T A[:, :N], db [M] = column sums of G -- split-K MFMA kernel (ia_wgrad)."""
     dev = G.device
     dW = torch.zeros((M, N), device=dev)
+    db = torch.zeros(M, device=dev) if want_bias else None
     L.check(L.lib().ia_wgrad(L.i64(G.shape[0]), L.ptr(G), L.i32(G.stride(0)), L.i32(M), L.ptr(A), L.i32(A.stride(0)), L.i32(N),
-                             L.ptr(dW), L.i32(N), L.stream()), "ia_wgrad")
-    db = G[:, :M].sum(0) if want_bias else None       # column sums: one streaming reduction
+                             L.ptr(dW), L.i32(N), L.ptr(db), L.stream()), "ia_wgrad")
     return dW, db
 
 
@@ -82,7 +82,7 @@ class _SDFField(Function):
         dW1k, db1 = wgrad(DZ, 64, Hh, 35)
         dW1k = dW1k + wgrad(GZ, 64, U, 35, want_bias=False)[0]
         dW2, db2 = wgrad(g_y, 13, A, 64)
-        dW2[0] += DGS.sum(0)
+        dW2[0] += wgrad(DGS, 64, DGS, 1)[1]          # column sums of DGS
         return None, g_table, dW1k, db1, dW2, db2, None, None
 
 
