@@ -53,25 +53,30 @@ int ia_exclusive_scan_i32(const int32_t* in, int32_t* out, int32_t* total, int64
  * ia_occgrid_pack_bits: binaries bool[rx*ry*rz] -> bit-packed uint32[(rx*ry*rz+31)/32]
  * (bit c&31 of word c>>5 is cell c, c = (x*ry + y)*rz + z).
  *
- * Phase 1 (count): per-ray edge / sample counts (int64, like upstream's chunk_cnts).
- * Phase 2 (fill):  caller passes exclusive scans of the counts and zero-filled flag
- *                  arrays; writes RayIntervals{vals,is_left,is_right,ray_indices} and
- *                  RaySamples{vals,ray_indices} and termination planes.
- * Rays are independent; output order = ray order, then marching order.
+ * Phase 1 (count): one DDA walk per ray; per-ray counts packed as  n_edges | (n_samples << 32)  in one int64 (so a
+ *                  single ia_exclusive_scan_i64 serves both) and per-ray run descriptors into `scratch`
+ *                  (ia_traverse_scratch_bytes(n_rays) bytes).
+ * Phase 2 (fill):  caller passes the exclusive scan of the packed counts and zero-filled flag arrays; expands the
+ *                  run descriptors into RayIntervals{vals,is_left,is_right,ray_indices,packed_info[n,2] i64} and
+ *                  RaySamples{vals,ray_indices,packed_info[n,2] i64} and termination planes.
+ * Rays are independent; output order = ray order, then marching order.  step_size must be > 0.
  */
 int ia_occgrid_pack_bits(const uint8_t* binaries, int64_t n_cells, uint32_t* bits, ia_stream_t stream);
+
+int64_t ia_traverse_scratch_bytes(int64_t n_rays);
 
 int ia_traverse_grids_count(
     int64_t n_rays, const float* rays_o /*[n,3]*/, const float* rays_d /*[n,3]*/,
     const uint32_t* grid_bits, int res_x, int res_y, int res_z, const float* aabb /*[6] device*/,
     const float* near_planes /*[n]*/, const float* far_planes /*[n]*/, float step_size, float cone_angle,
-    int64_t* iv_cnt /*[n]*/, int64_t* sm_cnt /*[n]*/, ia_stream_t stream);
+    void* scratch, int64_t* packed_counts /*[n]*/, ia_stream_t stream);
 
 int ia_traverse_grids_fill(
     int64_t n_rays, const float* rays_o, const float* rays_d,
     const uint32_t* grid_bits, int res_x, int res_y, int res_z, const float* aabb,
     const float* near_planes, const float* far_planes, float step_size, float cone_angle,
-    const int64_t* iv_start /*[n]*/, const int64_t* sm_start /*[n]*/,
+    const void* scratch, const int64_t* packed_counts /*[n]*/, const int64_t* packed_starts /*[n]*/,
+    int64_t* iv_packed_info /*[n,2] or NULL*/, int64_t* sm_packed_info /*[n,2] or NULL*/,
     float* iv_vals /*[E]*/, uint8_t* iv_is_left /*[E] zeroed*/, uint8_t* iv_is_right /*[E] zeroed*/,
     int64_t* iv_ray_indices /*[E]*/, float* sm_vals /*[S]*/, int64_t* sm_ray_indices /*[S]*/,
     float* termination_planes /*[n] or NULL*/, ia_stream_t stream);

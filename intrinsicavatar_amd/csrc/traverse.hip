@@ -6,8 +6,13 @@
 //     with coalesced 16-byte loads; every cell test of the DDA is then a ds_read_b32 + bit test;
 //   * one ray per lane, 256 rays per workgroup; rays of one workgroup are pixel-neighbours, so
 //     a wave's lanes walk neighbouring cells (LDS broadcast / few bank conflicts);
-//   * two passes (count, fill) with an exclusive scan in between -- output order is
-//     ray order then marching order, exactly as upstream.
+//   * two passes with ONE exclusive scan in between (edge and sample counts travel packed in one int64):
+//       pass 1 walks the DDA once and records, per ray, its runs of contiguous samples as
+//              (t at run start, #samples) descriptors in a scratch buffer (8 runs inline);
+//       pass 2 is a pure expansion: it replays t_{k+1} = t_k + dt from each run start (the same float
+//              recurrence as the marching loop, so values stay bit-exact) and streams the packed outputs --
+//              no second DDA, no LDS grid.  Rays with more than 8 runs (rare) re-walk the DDA in pass 2.
+//     Output order is ray order then marching order, exactly as upstream.
 // Arithmetic is kept operation-for-operation identical to oracle/ia_oracle.c (this TU is
 // built with -ffp-contract=off) so edge/sample counts and t values are bit-exact.
 #include "ia_common.h"
@@ -15,6 +20,15 @@
 namespace {
 
 constexpr int TR_THREADS = 256;
+constexpr int TR_RUNS = 8;          // run descriptors kept inline per ray
+
+struct RayScratch {                 // 80 bytes per ray
+    float t_first[TR_RUNS];
+    int32_t n_samples[TR_RUNS];
+    int32_t n_runs;                 // may exceed TR_RUNS (=> pass 2 re-walks this ray)
+    float t_term;                   // termination plane
+    int32_t pad[2];
+};
 
 __device__ __forceinline__ float calc_dt(float t, float cone_angle, float dt_min, float dt_max)
 {
@@ -63,14 +77,20 @@ __global__ __launch_bounds__(TR_THREADS) void traverse_kernel(
     int64_t n_rays, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const uint32_t* __restrict__ grid_bits, int rx, int ry, int rz, const float* __restrict__ aabb_g,
     const float* __restrict__ near_planes, const float* __restrict__ far_planes, float step_size, float cone_angle,
-    int64_t* __restrict__ iv_cnt, int64_t* __restrict__ sm_cnt,
-    const int64_t* __restrict__ iv_start, const int64_t* __restrict__ sm_start,
+    RayScratch* __restrict__ scratch, int64_t* __restrict__ packed_cnt, bool only_overflow,
+    const int64_t* __restrict__ packed_start,
     float* __restrict__ iv_vals, uint8_t* __restrict__ iv_is_left, uint8_t* __restrict__ iv_is_right,
     int64_t* __restrict__ iv_ray, float* __restrict__ sm_vals, int64_t* __restrict__ sm_ray,
     float* __restrict__ term_planes)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
     const int n_words = (rx * ry * rz + 31) >> 5;
+    // pass 2 only needs the grid for rays whose runs overflowed the inline descriptors
+    if (!FIRST_PASS) {
+        const int64_t t0 = (int64_t)blockIdx.x * TR_THREADS + threadIdx.x;
+        const bool ovf = t0 < n_rays && scratch[t0].n_runs > TR_RUNS;
+        if (!__syncthreads_or(ovf)) return;
+    }
     // stage the bit grid: 16 B per lane per step when the word count allows
     {
         const int n_vec = n_words >> 2;
@@ -83,6 +103,7 @@ __global__ __launch_bounds__(TR_THREADS) void traverse_kernel(
 
     const int64_t tid = (int64_t)blockIdx.x * TR_THREADS + threadIdx.x;
     if (tid >= n_rays) return;
+    if (!FIRST_PASS && scratch[tid].n_runs <= TR_RUNS) return;       // expanded by expand_kernel
 
     float aabb[6];
 #pragma unroll
@@ -95,7 +116,9 @@ __global__ __launch_bounds__(TR_THREADS) void traverse_kernel(
 
     int64_t n_samples = 0, n_intervals = 0;
     int64_t iv_base = 0, sm_base = 0;
-    if (!FIRST_PASS) { iv_base = iv_start[tid]; sm_base = sm_start[tid]; }
+    if (!FIRST_PASS) { const int64_t ps = packed_start[tid]; iv_base = ps & 0xFFFFFFFFll; sm_base = ps >> 32; }
+    int n_runs = 0, run_len = 0;
+    RayScratch sc;
     bool continuous = false;
     float t_last = near_plane;
     float tmin, tmax;
@@ -155,6 +178,11 @@ __global__ __launch_bounds__(TR_THREADS) void traverse_kernel(
                                 const int64_t idx = iv_base + n_intervals;
                                 iv_vals[idx] = t_last; iv_ray[idx] = tid; iv_is_left[idx] = 1;
                                 iv_vals[idx + 1] = t_next; iv_ray[idx + 1] = tid; iv_is_right[idx + 1] = 1;
+                            } else {
+                                if (n_runs > 0 && n_runs <= TR_RUNS) sc.n_samples[n_runs - 1] = run_len;
+                                if (n_runs < TR_RUNS) sc.t_first[n_runs] = t_last;
+                                n_runs++;
+                                run_len = 0;
                             }
                             n_intervals += 2;
                         } else {
@@ -170,6 +198,7 @@ __global__ __launch_bounds__(TR_THREADS) void traverse_kernel(
                             sm_vals[idx] = (t_next + t_last) * 0.5f; sm_ray[idx] = tid;
                         }
                         n_samples++;
+                        run_len++;
                         continuous = true;
                         t_last = t_next;
                         if (t_next >= t_traverse) break;
@@ -188,8 +217,53 @@ __global__ __launch_bounds__(TR_THREADS) void traverse_kernel(
             }
         }
     }
-    if (FIRST_PASS) { iv_cnt[tid] = n_intervals; sm_cnt[tid] = n_samples; }
-    else if (term_planes) term_planes[tid] = t_last;
+    if (FIRST_PASS) {
+        if (n_runs > 0 && n_runs <= TR_RUNS) sc.n_samples[n_runs - 1] = run_len;
+        sc.n_runs = n_runs;
+        sc.t_term = t_last;
+        RayScratch* dst = scratch + tid;
+#pragma unroll
+        for (int k = 0; k < TR_RUNS; k++)
+            if (k < n_runs) { dst->t_first[k] = sc.t_first[k]; dst->n_samples[k] = sc.n_samples[k]; }
+        dst->n_runs = n_runs;
+        dst->t_term = t_last;
+        packed_cnt[tid] = (int64_t)n_intervals | ((int64_t)n_samples << 32);
+    }
+}
+
+// pass 2: expansion of the run descriptors (no DDA).  One ray per lane.
+__global__ __launch_bounds__(TR_THREADS) void expand_kernel(
+    int64_t n_rays, const RayScratch* __restrict__ scratch, const int64_t* __restrict__ packed_cnt,
+    const int64_t* __restrict__ packed_start, float step_size, float cone_angle,
+    int64_t* __restrict__ iv_pinfo, int64_t* __restrict__ sm_pinfo, float* __restrict__ iv_vals,
+    uint8_t* __restrict__ iv_is_left, uint8_t* __restrict__ iv_is_right, int64_t* __restrict__ iv_ray,
+    float* __restrict__ sm_vals, int64_t* __restrict__ sm_ray, float* __restrict__ term_planes)
+{
+    const int64_t tid = (int64_t)blockIdx.x * TR_THREADS + threadIdx.x;
+    if (tid >= n_rays) return;
+    const int64_t pc = packed_cnt[tid], ps = packed_start[tid];
+    int64_t iv = ps & 0xFFFFFFFFll, sm = ps >> 32;
+    if (iv_pinfo) { iv_pinfo[2 * tid] = iv; iv_pinfo[2 * tid + 1] = pc & 0xFFFFFFFFll; }
+    if (sm_pinfo) { sm_pinfo[2 * tid] = sm; sm_pinfo[2 * tid + 1] = pc >> 32; }
+    const RayScratch* sc = scratch + tid;
+    if (term_planes) term_planes[tid] = sc->t_term;
+    const int n_runs = sc->n_runs;
+    if (n_runs > TR_RUNS) return;                                   // re-walked by traverse_kernel<false>
+    for (int r = 0; r < n_runs; r++) {
+        float t = sc->t_first[r];
+        const int n = sc->n_samples[r];
+        iv_vals[iv] = t; iv_ray[iv] = tid; iv_is_left[iv] = 1;      // flags are caller-zeroed
+        iv++;
+        for (int k = 0; k < n; k++) {
+            const float t_next = step_size <= 0.0f ? t : t + calc_dt(t, cone_angle, step_size, 1e10f);
+            iv_vals[iv] = t_next; iv_ray[iv] = tid; iv_is_right[iv] = 1;
+            if (k + 1 < n) iv_is_left[iv] = 1;
+            iv++;
+            sm_vals[sm] = (t_next + t) * 0.5f; sm_ray[sm] = tid;
+            sm++;
+            t = t_next;
+        }
+    }
 }
 
 }  // namespace
@@ -206,36 +280,46 @@ static int check_grid(int rx, int ry, int rz, size_t* lds_bytes)
     IA_REQUIRE(rx > 0 && ry > 0 && rz > 0, "grid resolution must be positive");
     const int64_t cells = (int64_t)rx * ry * rz;
     const int64_t bytes = ((cells + 31) / 32) * 4;
-    IA_REQUIRE(bytes <= 160 * 1024, "bit-packed grid must fit the 160 KiB LDS (<= 1.3M cells)");
+    IA_REQUIRE(bytes <= 128 * 1024, "bit-packed grid must fit in 128 KiB of LDS (<= 1M cells)");
     *lds_bytes = (size_t)((bytes + 15) / 16 * 16);
     return IA_OK;
+}
+
+IA_EXPORT int64_t ia_traverse_scratch_bytes(int64_t n_rays) { return (int64_t)sizeof(RayScratch) * (n_rays > 0 ? n_rays : 1); }
+
+static void set_attrs()
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)traverse_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute((const void*)traverse_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipGetLastError();
+        attr_set = true;
+    }
 }
 
 IA_EXPORT int ia_traverse_grids_count(int64_t n_rays, const float* rays_o, const float* rays_d,
                                       const uint32_t* grid_bits, int rx, int ry, int rz, const float* aabb,
                                       const float* near_planes, const float* far_planes, float step_size,
-                                      float cone_angle, int64_t* iv_cnt, int64_t* sm_cnt, ia_stream_t stream)
+                                      float cone_angle, void* scratch, int64_t* packed_counts, ia_stream_t stream)
 {
     if (n_rays == 0) return IA_OK;
     size_t lds;
     int r = check_grid(rx, ry, rz, &lds);
     if (r != IA_OK) return r;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)traverse_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)traverse_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    IA_REQUIRE(step_size > 0.0f, "step_size must be > 0 (the render_step path always marches with a positive step)");
+    set_attrs();
     traverse_kernel<true><<<ia::cdiv(n_rays, TR_THREADS), TR_THREADS, lds, (hipStream_t)stream>>>(
-        n_rays, rays_o, rays_d, grid_bits, rx, ry, rz, aabb, near_planes, far_planes, step_size, cone_angle, iv_cnt,
-        sm_cnt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        n_rays, rays_o, rays_d, grid_bits, rx, ry, rz, aabb, near_planes, far_planes, step_size, cone_angle,
+        (RayScratch*)scratch, packed_counts, false, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     return ia::check_launch("ia_traverse_grids_count");
 }
 
 IA_EXPORT int ia_traverse_grids_fill(int64_t n_rays, const float* rays_o, const float* rays_d,
                                      const uint32_t* grid_bits, int rx, int ry, int rz, const float* aabb,
                                      const float* near_planes, const float* far_planes, float step_size,
-                                     float cone_angle, const int64_t* iv_start, const int64_t* sm_start,
+                                     float cone_angle, const void* scratch, const int64_t* packed_counts,
+                                     const int64_t* packed_starts, int64_t* iv_packed_info, int64_t* sm_packed_info,
                                      float* iv_vals, uint8_t* iv_is_left, uint8_t* iv_is_right,
                                      int64_t* iv_ray_indices, float* sm_vals, int64_t* sm_ray_indices,
                                      float* termination_planes, ia_stream_t stream)
@@ -244,10 +328,15 @@ IA_EXPORT int ia_traverse_grids_fill(int64_t n_rays, const float* rays_o, const 
     size_t lds;
     int r = check_grid(rx, ry, rz, &lds);
     if (r != IA_OK) return r;
-    (void)hipFuncSetAttribute((const void*)traverse_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    traverse_kernel<false><<<ia::cdiv(n_rays, TR_THREADS), TR_THREADS, lds, (hipStream_t)stream>>>(
-        n_rays, rays_o, rays_d, grid_bits, rx, ry, rz, aabb, near_planes, far_planes, step_size, cone_angle, nullptr,
-        nullptr, iv_start, sm_start, iv_vals, iv_is_left, iv_is_right, iv_ray_indices, sm_vals, sm_ray_indices,
-        termination_planes);
+    set_attrs();
+    const int grid = ia::cdiv(n_rays, TR_THREADS);
+    expand_kernel<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(
+        n_rays, (const RayScratch*)scratch, packed_counts, packed_starts, step_size, cone_angle, iv_packed_info,
+        sm_packed_info, iv_vals, iv_is_left, iv_is_right, iv_ray_indices, sm_vals, sm_ray_indices, termination_planes);
+    // rays with more than TR_RUNS runs: workgroups without any such ray exit before staging the grid
+    traverse_kernel<false><<<grid, TR_THREADS, lds, (hipStream_t)stream>>>(
+        n_rays, rays_o, rays_d, grid_bits, rx, ry, rz, aabb, near_planes, far_planes, step_size, cone_angle,
+        (RayScratch*)scratch, nullptr, true, packed_starts, iv_vals, iv_is_left, iv_is_right, iv_ray_indices, sm_vals,
+        sm_ray_indices, nullptr);
     return ia::check_launch("ia_traverse_grids_fill");
 }

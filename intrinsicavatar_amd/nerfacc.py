@@ -91,19 +91,17 @@ def traverse_grids(
         grid_bits = pack_occupancy_bits(binaries[0])
     lib, st = L.lib(), L.stream()
 
-    cnt = torch.empty((2, n_rays), dtype=torch.int64, device=dev)      # [iv_cnt; sm_cnt]
-    start = torch.empty((2, n_rays), dtype=torch.int64, device=dev)
-    totals = torch.zeros(2, dtype=torch.int64, device=dev)
-    L.check(lib.ia_traverse_grids_count(
-        L.i64(n_rays), L.ptr(rays_o), L.ptr(rays_d), L.ptr(grid_bits), L.i32(rx), L.i32(ry), L.i32(rz), L.ptr(aabb),
-        L.ptr(near_planes), L.ptr(far_planes), L.f32(step_size), L.f32(cone_angle),
-        L.ptr(cnt[0]), L.ptr(cnt[1]), st), "ia_traverse_grids_count")
+    scratch = torch.empty(int(lib.ia_traverse_scratch_bytes(L.i64(n_rays))), dtype=torch.uint8, device=dev)
+    pcnt = torch.empty(n_rays, dtype=torch.int64, device=dev)          # n_edges | n_samples << 32
+    pstart = torch.empty(n_rays, dtype=torch.int64, device=dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    args = (L.i64(n_rays), L.ptr(rays_o), L.ptr(rays_d), L.ptr(grid_bits), L.i32(rx), L.i32(ry), L.i32(rz), L.ptr(aabb),
+            L.ptr(near_planes), L.ptr(far_planes), L.f32(step_size), L.f32(cone_angle))
+    L.check(lib.ia_traverse_grids_count(*args, L.ptr(scratch), L.ptr(pcnt), st), "ia_traverse_grids_count")
     tmp = L.scan_tmp(n_rays, dev)
-    L.check(lib.ia_exclusive_scan_i64(L.ptr(cnt[0]), L.ptr(start[0]), L.ptr(totals[0:1]), L.i64(n_rays), L.ptr(tmp), st),
-            "scan")
-    L.check(lib.ia_exclusive_scan_i64(L.ptr(cnt[1]), L.ptr(start[1]), L.ptr(totals[1:2]), L.i64(n_rays), L.ptr(tmp), st),
-            "scan")
-    E, S = (int(v) for v in totals.tolist())      # the one host sync of the two-phase protocol
+    L.check(lib.ia_exclusive_scan_i64(L.ptr(pcnt), L.ptr(pstart), L.ptr(total), L.i64(n_rays), L.ptr(tmp), st), "scan")
+    tot = int(total.item())                      # the one host sync of the two-phase protocol
+    E, S = tot & 0xFFFFFFFF, tot >> 32
 
     iv_vals = torch.empty(E, dtype=torch.float32, device=dev)
     iv_flags = torch.zeros((2, E), dtype=torch.bool, device=dev)
@@ -111,14 +109,13 @@ def traverse_grids(
     sm_vals = torch.empty(S, dtype=torch.float32, device=dev)
     sm_ray = torch.empty(S, dtype=torch.int64, device=dev)
     term = torch.empty(n_rays, dtype=torch.float32, device=dev)
-    L.check(lib.ia_traverse_grids_fill(
-        L.i64(n_rays), L.ptr(rays_o), L.ptr(rays_d), L.ptr(grid_bits), L.i32(rx), L.i32(ry), L.i32(rz), L.ptr(aabb),
-        L.ptr(near_planes), L.ptr(far_planes), L.f32(step_size), L.f32(cone_angle),
-        L.ptr(start[0]), L.ptr(start[1]), L.ptr(iv_vals), L.ptr(iv_flags[0]), L.ptr(iv_flags[1]), L.ptr(iv_ray),
-        L.ptr(sm_vals), L.ptr(sm_ray), L.ptr(term), st), "ia_traverse_grids_fill")
-    intervals = RayIntervals(vals=iv_vals, packed_info=torch.stack([start[0], cnt[0]], -1), ray_indices=iv_ray,
+    pinfo = torch.empty((2, n_rays, 2), dtype=torch.int64, device=dev)
+    L.check(lib.ia_traverse_grids_fill(*args, L.ptr(scratch), L.ptr(pcnt), L.ptr(pstart), L.ptr(pinfo[0]), L.ptr(pinfo[1]),
+                                       L.ptr(iv_vals), L.ptr(iv_flags[0]), L.ptr(iv_flags[1]), L.ptr(iv_ray),
+                                       L.ptr(sm_vals), L.ptr(sm_ray), L.ptr(term), st), "ia_traverse_grids_fill")
+    intervals = RayIntervals(vals=iv_vals, packed_info=pinfo[0], ray_indices=iv_ray,
                              is_left=iv_flags[0], is_right=iv_flags[1])
-    samples = RaySamples(vals=sm_vals, packed_info=torch.stack([start[1], cnt[1]], -1), ray_indices=sm_ray,
+    samples = RaySamples(vals=sm_vals, packed_info=pinfo[1], ray_indices=sm_ray,
                          is_valid=torch.ones(S, dtype=torch.bool, device=dev))
     return intervals, samples, term
 

@@ -45,35 +45,35 @@ def main():
     step = 4.3301 / 128
     bits = nerfacc.pack_occupancy_bits(binaries[0])
     lib, st = L.lib(), L.stream()
-    cnt = torch.empty((2, n), dtype=torch.int64, device=DEV)
-    start = torch.empty((2, n), dtype=torch.int64, device=DEV)
-    tot = torch.zeros(2, dtype=torch.int64, device=DEV)
+    scratch = torch.empty(int(lib.ia_traverse_scratch_bytes(L.i64(n))), dtype=torch.uint8, device=DEV)
+    pcnt = torch.empty(n, dtype=torch.int64, device=DEV)
+    pstart = torch.empty(n, dtype=torch.int64, device=DEV)
+    tot = torch.zeros(1, dtype=torch.int64, device=DEV)
     tmp = L.scan_tmp(n, DEV)
     aabb0 = aabb[0].contiguous()
+    args = (L.i64(n), L.ptr(ro), L.ptr(rd), L.ptr(bits), 64, 64, 64, L.ptr(aabb0), L.ptr(near), L.ptr(far), L.f32(step), L.f32(0.0))
 
     def count():
-        L.check(lib.ia_traverse_grids_count(L.i64(n), L.ptr(ro), L.ptr(rd), L.ptr(bits), 64, 64, 64, L.ptr(aabb0),
-                                            L.ptr(near), L.ptr(far), L.f32(step), L.f32(0.0), L.ptr(cnt[0]),
-                                            L.ptr(cnt[1]), st))
+        L.check(lib.ia_traverse_grids_count(*args, L.ptr(scratch), L.ptr(pcnt), st))
 
     def scan():
-        lib.ia_exclusive_scan_i64(L.ptr(cnt[0]), L.ptr(start[0]), L.ptr(tot[0:1]), L.i64(n), L.ptr(tmp), st)
-        lib.ia_exclusive_scan_i64(L.ptr(cnt[1]), L.ptr(start[1]), L.ptr(tot[1:2]), L.i64(n), L.ptr(tmp), st)
+        lib.ia_exclusive_scan_i64(L.ptr(pcnt), L.ptr(pstart), L.ptr(tot), L.i64(n), L.ptr(tmp), st)
 
     count(); scan()
-    E, S_ = (int(v) for v in tot.tolist())
+    t_ = int(tot.item())
+    E, S_ = t_ & 0xFFFFFFFF, t_ >> 32
     iv_vals = torch.empty(E, device=DEV)
     fl = torch.zeros((2, E), dtype=torch.bool, device=DEV)
     iv_ray = torch.empty(E, dtype=torch.int64, device=DEV)
     sm_vals = torch.empty(S_, device=DEV)
     sm_ray = torch.empty(S_, dtype=torch.int64, device=DEV)
     term = torch.empty(n, device=DEV)
+    pinfo = torch.empty((2, n, 2), dtype=torch.int64, device=DEV)
 
     def fill():
-        L.check(lib.ia_traverse_grids_fill(L.i64(n), L.ptr(ro), L.ptr(rd), L.ptr(bits), 64, 64, 64, L.ptr(aabb0),
-                                           L.ptr(near), L.ptr(far), L.f32(step), L.f32(0.0), L.ptr(start[0]),
-                                           L.ptr(start[1]), L.ptr(iv_vals), L.ptr(fl[0]), L.ptr(fl[1]), L.ptr(iv_ray),
-                                           L.ptr(sm_vals), L.ptr(sm_ray), L.ptr(term), st))
+        L.check(lib.ia_traverse_grids_fill(*args, L.ptr(scratch), L.ptr(pcnt), L.ptr(pstart), L.ptr(pinfo[0]), L.ptr(pinfo[1]),
+                                           L.ptr(iv_vals), L.ptr(fl[0]), L.ptr(fl[1]), L.ptr(iv_ray), L.ptr(sm_vals), L.ptr(sm_ray),
+                                           L.ptr(term), st))
     t_count, t_scan, t_fill = timeit(count), timeit(scan), timeit(fill)
     alg_bytes = 48 * n + 16 * S_ + 14 * E
     res["traverse"] = dict(n_rays=n, E=E, S=S_, count_us=t_count, scan_us=t_scan, fill_us=t_fill,
@@ -81,7 +81,7 @@ def main():
                            gbps_total=alg_bytes / (t_count + t_scan + t_fill) / 1e3)
 
     # ---- K2 merge on the traversal's edge list + T2
-    iv_pi = torch.stack([start[0], cnt[0]], -1).int().contiguous()
+    iv_pi = pinfo[0].int().contiguous()
     w_e = torch.rand(E, device=DEV) * 0.1
     t_k2 = timeit(lambda: lib_nerfacc.ray_resampling_merge(iv_pi, iv_vals, fl[0], fl[1], w_e, 16))
     res["k2_merge"] = dict(E=E, us=t_k2)
