@@ -276,6 +276,18 @@ int ia_pbr_light_shade(int64_t F, const float* normal, const float* albedo, cons
 int ia_envlight_eval(int64_t n, const float* dirs_world, const float* env_base, const float* env_pmf, int env_h,
                      int env_w, float* rgb /*[n,3]*/, float* pdf /*[n]*/, ia_stream_t stream);
 
+/* ------------------------------------------------------------------------- */
+/* Occupancy-grid maintenance (TemporalOccGridEstimator._update, models/occ_grid/temporal_occ_grid.py:369-411;
+ * _compute_occupancy_grid, models/intrinsic_avatar.py:307-358; max_connected_component, models/utils.py:152-163). */
+/* occs = max(occs * ema_decay, occ_new) */
+int ia_occgrid_ema(int64_t n_cells, float* occs, const float* occ_new, float ema_decay, ia_stream_t stream);
+int64_t ia_occgrid_tmp_bytes(int res_x, int res_y, int res_z);
+/* 3^3 max-pool dilation -> thre = min(mean(pooled >= 0), thre_max) -> binaries = pooled > thre ->
+ * (optional) keep the largest 26-connected component (res_z*3 label-propagation sweeps, most frequent label).
+ * thre_out: 1 device float or NULL. */
+int ia_occgrid_binarize(int res_x, int res_y, int res_z, const float* occs, float thre_max, int keep_largest_component,
+                        uint8_t* binaries, float* thre_out, void* tmp, ia_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

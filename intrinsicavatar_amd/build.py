@@ -27,6 +27,7 @@ SOURCES = {
     "mlp_bwd.hip": ["-munsafe-fp-atomics"],
     "deform.hip": ["-ffp-contract=off"],
     "pbr.hip": [],
+    "occgrid.hip": [],
 }
 
 

@@ -1,0 +1,75 @@
+"""GPU: occupancy-grid maintenance kernels vs the numpy oracle (oracle/occgrid_ref.py); bool grids bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def og():
+    from intrinsicavatar_amd import build
+    build.build()
+    from intrinsicavatar_amd import occ_grid
+    return occ_grid
+
+
+def _blobs(rng, res, n_blobs):
+    g = np.stack(np.meshgrid(*[np.arange(r) for r in res], indexing="ij"), -1).astype(np.float32)
+    occ = np.zeros(res, np.float32)
+    for _ in range(n_blobs):
+        c = rng.uniform(0.15, 0.85, 3) * np.array(res)
+        r = rng.uniform(2, 7)
+        occ = np.maximum(occ, np.exp(-((g - c) ** 2).sum(-1) / (2 * r * r)) * rng.uniform(0.2, 1.0))
+    occ[occ < 0.05] = 0
+    return occ
+
+
+@pytest.mark.parametrize("res,seed,n_blobs", [((64, 64, 64), 0, 5), ((32, 48, 16), 1, 3), ((64, 64, 64), 2, 1), ((16, 16, 16), 3, 0)])
+def test_binarize_vs_oracle(og, res, seed, n_blobs):
+    from oracle import occgrid_ref as R
+    rng = np.random.default_rng(seed)
+    occ = _blobs(rng, res, n_blobs) + (rng.random(res) < 0.002) * 0.5          # + isolated specks (pruned by the CC filter)
+    occ = occ.astype(np.float32)
+    for keep in (False, True):
+        ref, thre_ref = R.binarize(occ, res, 0.01, keep)
+        b, thre = og.binarize(torch.from_numpy(occ).to(DEV).reshape(-1), res, 0.01, keep)
+        assert abs(float(thre) - float(thre_ref)) <= 1e-7 * max(1.0, abs(float(thre_ref)))
+        np.testing.assert_array_equal(b.cpu().numpy(), ref, err_msg=f"keep={keep}")
+    if n_blobs > 1:
+        assert ref.sum() < R.binarize(occ, res, 0.01, False)[0].sum()          # something was pruned
+
+
+def test_estimator_update_and_sampling(og):
+    """_update (EMA + binarise) on an analytic occupancy function, then marching through the updated level."""
+    from oracle import occgrid_ref as R, oracle as O
+    est = og.TemporalOccGridEstimator([-1, -1, -1, 1, 1, 1], resolution=32, levels=3).to(DEV)
+    g = torch.Generator().manual_seed(0)
+    rand = torch.rand((32 ** 3, 3), generator=g).to(DEV)
+
+    def occ_fn(x):                                        # a ball of radius 0.5
+        return (x.norm(dim=-1) < 0.5).float() * 0.3
+
+    est.occs[32 ** 3:2 * 32 ** 3] = 0.05                   # stale EMA state on level 1
+    est.train()
+    est.update_every_n_steps(step=20, t_idx=0.4, occ_eval_fn=occ_fn, occ_thre=0.001, ema_decay=0.8, n=20, rand=rand)
+    gc = est.grid_coords.float().numpy()
+    x = (gc + rand.cpu().numpy()) / 32 * 2 - 1
+    occ_new = (np.linalg.norm(x, axis=-1) < 0.5).astype(np.float32) * np.float32(0.3)
+    occs_ref = np.maximum(np.float32(0.05) * np.float32(0.8), occ_new)
+    np.testing.assert_array_equal(est.occs[32 ** 3:2 * 32 ** 3].cpu().numpy(), occs_ref)
+    ref, _ = R.binarize(occs_ref, (32, 32, 32), 0.001, True)
+    np.testing.assert_array_equal(est.binaries[1].cpu().numpy(), ref)
+    assert not est.binaries[0].any() and not est.binaries[2].any()
+    # marching through level 1 == oracle traversal of that grid
+    rng = np.random.default_rng(1)
+    o = rng.uniform(-2, 2, (2048, 3)).astype(np.float32)
+    d = rng.normal(size=(2048, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    iv, ri, ts, te = est.sampling(torch.from_numpy(o).to(DEV), torch.from_numpy(d).to(DEV), t_idx=0.4, render_step_size=0.05)
+    tr = O.traverse_grids(o, d, ref, np.array([-1, -1, -1, 1, 1, 1], np.float32), np.zeros(2048, np.float32),
+                          np.full(2048, 1e10, np.float32), 0.05)
+    np.testing.assert_array_equal(iv.vals.cpu().numpy(), tr["intervals"]["vals"])
+    np.testing.assert_array_equal(ri.cpu().numpy(), tr["samples"]["ray_indices"])
+    assert ts.numel() > 100
