@@ -206,17 +206,16 @@ def build_frame(device="cuda:0", height=128, width=128, pose_seed=0, beta=0.01, 
     aabb = body_aabb(rig["joints_posed"])
     # per-frame occupancy grid from the MODEL (prepare_test_occupancy_grid, intrinsic_avatar.py:307-381):
     # 3 jittered samples per voxel -> alpha -> max -> 3^3 dilation -> threshold (largest-CC filter: SURVEY 8(f).1)
+    from . import occ_grid
     g = torch.Generator().manual_seed(seed + 7)
-    idx = torch.stack(torch.meshgrid([torch.arange(occ_res)] * 3, indexing="ij"), -1).reshape(-1, 1, 3).float()
-    xs = ((idx + torch.rand((occ_res ** 3, 3, 3), generator=g)) / occ_res).reshape(-1, 3)
-    lo, hi = torch.from_numpy(aabb[:3]), torch.from_numpy(aabb[3:])
-    xs = (xs * (hi - lo) + lo).to(dev)
-    sdf = dfm.deform(xs, geo)["sdf"]
-    alpha = render.laplace_alpha(sdf, step, dens.get_beta().detach().reshape(1))
-    occs = alpha.reshape(-1, 3).max(1)[0]
-    occs_ = torch.nn.functional.max_pool3d(occs.reshape(1, 1, occ_res, occ_res, occ_res), 3, 1, 1)[0, 0]
-    thre = torch.clamp(occs_[occs_ >= 0].mean(), max=0.01)
-    binaries = (occs_ > thre)[None].contiguous()
+    rand = torch.rand((occ_res ** 3, 3, 3), generator=g).to(dev)
+    beta_t = dens.get_beta().detach().reshape(1)
+
+    def occ_eval_fn(x):
+        return render.laplace_alpha(dfm.deform(x, geo)["sdf"], step, beta_t)
+
+    _, binaries = occ_grid.compute_test_occupancy_grid(occ_eval_fn, torch.from_numpy(aabb).to(dev), occ_res, 3, 0.01, rand)
+    binaries = binaries.contiguous()
     rs = render.RenderStep(geo, rad, dens, dfm, binaries, torch.from_numpy(aabb)[None].to(dev), step)
     rays = torch.from_numpy(camera_rays(height, width)).to(dev)
     N = lambda t: t.detach().cpu().numpy()      # noqa: E731
@@ -227,7 +226,7 @@ def build_frame(device="cuda:0", height=128, width=128, pose_seed=0, beta=0.01, 
     rl = rad.network.layers
     export = dict(
         w2s=rig["w2s"], tfs=rig["tfs"], voxel_J=N(vJ), offset_kernel=offk.reshape(3), scale_kernel=sck.reshape(3),
-        binaries=N(binaries[0]), aabb=aabb, step=step, beta=float(dens.get_beta()),
+        binaries=N(binaries[0]), aabb=aabb, step=step, beta=float(dens.get_beta().detach()),
         geo_center=N(geo.center), geo_scale=N(geo.scale), geo_params=N(geo.grid_params),
         geo_mask=N(geo.prog.mask(geo.global_step, "cpu")), geo_W1=N(l0.effective()), geo_b1=N(l0.bias),
         geo_W2=N(l2.effective()), geo_b2=N(l2.bias),

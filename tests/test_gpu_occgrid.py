@@ -54,7 +54,7 @@ def test_estimator_update_and_sampling(og):
     est.occs[32 ** 3:2 * 32 ** 3] = 0.05                   # stale EMA state on level 1
     est.train()
     est.update_every_n_steps(step=20, t_idx=0.4, occ_eval_fn=occ_fn, occ_thre=0.001, ema_decay=0.8, n=20, rand=rand)
-    gc = est.grid_coords.float().numpy()
+    gc = est.grid_coords.float().cpu().numpy()
     x = (gc + rand.cpu().numpy()) / 32 * 2 - 1
     occ_new = (np.linalg.norm(x, axis=-1) < 0.5).astype(np.float32) * np.float32(0.3)
     occs_ref = np.maximum(np.float32(0.05) * np.float32(0.8), occ_new)
