@@ -179,6 +179,10 @@ int ia_hashgrid_bwd(int64_t n, const float* x, int n_levels, int n_features, int
                     int base_resolution, float per_level_scale, const float* g_enc /*[n,stride] or NULL*/,
                     int g_enc_stride, const float* g_jac /*or NULL*/, int g_jac_stride, const float* q /*[n,3] or NULL*/,
                     float* grad_params, ia_stream_t stream);
+/* contractions with the stored Jacobian dy_dx [n,K,3]: mode 0: out[n,3] = sum_k v[n,k] J[n,k,:] (input gradient);
+ * mode 1: out[n,K] = J[n,k,:] . v[n,:3] (JVP).  Used by the tinycudann.Encoding drop-in's (double) backward. */
+int ia_hashgrid_jac_contract(int mode, int64_t n, int K, const float* jac, const float* v, int v_stride, float* out,
+                             int out_stride, ia_stream_t stream);
 /* SphericalHarmonics(degree=4): d01 in [0,1]^3 (tcnn maps to [-1,1]) -> 16 values */
 int ia_sh4_fwd(int64_t n, const float* d01, float* out, int out_stride, ia_stream_t stream);
 

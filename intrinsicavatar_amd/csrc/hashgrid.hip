@@ -305,7 +305,47 @@ __global__ __launch_bounds__(THREADS) void sh4_bwd_kernel(int64_t n, const float
     g_d01[i * 3 + 0] = 2.0f * gx; g_d01[i * 3 + 1] = 2.0f * gy; g_d01[i * 3 + 2] = 2.0f * gz;
 }
 
+// contractions with the stored Jacobian J [n, K, 3] (K = n_levels * 2):
+//   MODE 0: out[n,3]  = sum_k v[n,k] * J[n,k,:]      (d L / d x   from d L / d enc)
+//   MODE 1: out[n,K]  = J[n,k,:] . q[n,:]            (JVP of the encoding along q)
+template <int MODE>
+__global__ __launch_bounds__(THREADS) void jac_contract_kernel(int64_t n, int K, const float* __restrict__ jac,
+                                                                const float* __restrict__ v, int v_stride,
+                                                                float* __restrict__ out, int out_stride)
+{
+    if (MODE == 0) {
+        const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+        if (i >= n) return;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        const float* J = jac + i * K * 3;
+        for (int k = 0; k < K; k++) {
+            const float g = v[i * v_stride + k];
+            a0 = fmaf(g, J[k * 3 + 0], a0); a1 = fmaf(g, J[k * 3 + 1], a1); a2 = fmaf(g, J[k * 3 + 2], a2);
+        }
+        out[i * out_stride + 0] = a0; out[i * out_stride + 1] = a1; out[i * out_stride + 2] = a2;
+    } else {
+        const int64_t t = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+        const int64_t i = t / K;
+        const int k = (int)(t % K);
+        if (i >= n) return;
+        const float* J = jac + (i * K + k) * 3;
+        out[i * out_stride + k] = J[0] * v[i * v_stride + 0] + J[1] * v[i * v_stride + 1] + J[2] * v[i * v_stride + 2];
+    }
+}
+
 }  // namespace
+
+IA_EXPORT int ia_hashgrid_jac_contract(int mode, int64_t n, int K, const float* jac, const float* v, int v_stride,
+                                       float* out, int out_stride, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    IA_REQUIRE(mode == 0 || mode == 1, "mode 0 (J^T v) or 1 (J q)");
+    if (mode == 0)
+        jac_contract_kernel<0><<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, K, jac, v, v_stride, out, out_stride);
+    else
+        jac_contract_kernel<1><<<ia::cdiv(n * K, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, K, jac, v, v_stride, out, out_stride);
+    return ia::check_launch("ia_hashgrid_jac_contract");
+}
 
 IA_EXPORT int ia_sh4_bwd(int64_t n, const float* d01, const float* g_sh, int g_stride, float* g_d01, ia_stream_t stream)
 {

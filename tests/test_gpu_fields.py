@@ -174,3 +174,46 @@ def test_sdf_field_vs_oracle(oracle, fields, n):
     np.testing.assert_allclose(N(grad), gr, rtol=2e-3, atol=2e-3)           # |grad| ~ 1..50, hash J ~ 4096*0.05
     sdf2 = geo(T(pts), with_grad=False, with_feature=False)
     np.testing.assert_allclose(N(sdf2), sr, rtol=1e-4, atol=2e-5)
+
+
+def test_tcnn_encoding_dropin_first_and_second_order(fields):
+    """tinycudann.Encoding drop-in: forward, d/dparams, d/dx, and the DOUBLE backward the reference triggers with
+    torch.autograd.grad(sdf, x, create_graph=True) (rf/geometry.py:165-172) -- vs float64 torch autograd."""
+    from intrinsicavatar_amd import tinycudann as tcnn
+    from tests import torch_ref as TR
+    cfg = dict(otype="HashGrid", n_levels=16, n_features_per_level=2, log2_hashmap_size=19, base_resolution=16,
+               per_level_scale=1.447269237440378, interpolation="Linear")
+    enc = tcnn.Encoding(3, cfg, dtype=torch.float32).to(DEV)
+    assert enc.n_output_dims == 32 and enc.params.numel() == fields.hash_n_entries() * 2
+    with torch.no_grad():
+        enc.params.mul_(300.0)                              # amplitude 3e-2 so that gradients are well above fp32 noise
+    g = torch.Generator().manual_seed(0)
+    n = 2000
+    x = torch.rand((n, 3), generator=g).to(DEV).requires_grad_(True)
+    W = torch.randn((32, 4), generator=g).to(DEV)
+    y = enc(x)
+    s = torch.tanh(y @ W).sum(-1)                           # a small "network" on top
+    gx = torch.autograd.grad(s, x, torch.ones_like(s), create_graph=True)[0]
+    loss = ((gx.norm(dim=-1) - 1.0) ** 2).mean() + y.pow(2).mean()      # eikonal-like term + a first-order term
+    loss.backward()
+    # reference
+    x64 = x.detach().cpu().double().requires_grad_(True)
+    p64 = enc.params.detach().cpu().double().requires_grad_(True)
+    y64 = TR.hashgrid(x64, p64.reshape(-1, 2))
+    s64 = torch.tanh(y64 @ W.cpu().double()).sum(-1)
+    gx64 = torch.autograd.grad(s64, x64, torch.ones_like(s64), create_graph=True)[0]
+    loss64 = ((gx64.norm(dim=-1) - 1.0) ** 2).mean() + y64.pow(2).mean()
+    loss64.backward()
+    np.testing.assert_allclose(N(y), y64.detach().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(N(gx), gx64.detach().numpy(), rtol=2e-3, atol=2e-3)
+    assert abs(float(loss) - float(loss64)) < 1e-3 * abs(float(loss64))
+    a, b = enc.params.grad.cpu().double(), p64.grad
+    assert float(b.norm()) > 0 and float((a - b).norm() / b.norm()) < 2e-2
+    # SH drop-in incl. input gradient
+    sh = tcnn.Encoding(3, dict(otype="SphericalHarmonics", degree=4))
+    d = torch.rand((500, 3), generator=g).to(DEV).requires_grad_(True)
+    (sh(d) * torch.arange(16, device=DEV)).sum().backward()
+    d64 = d.detach().cpu().double().requires_grad_(True)
+    (TR.sh4(d64) * torch.arange(16).double()).sum().backward()
+    np.testing.assert_allclose(N(d.grad), d64.grad.numpy(), rtol=1e-4, atol=1e-4)
+    assert tcnn.free_temporary_memory() is None
