@@ -276,6 +276,20 @@ int ia_pbr_light_shade(int64_t F, const float* normal, const float* albedo, cons
                        const float* transmittance, const float* indirect_rgb, const float* env_base,
                        const float* env_pmf, int env_h, int env_w, const float* w2s_rot,
                        float* Lo, float* Lo_diff, float* Lo_spec, ia_stream_t stream);
+/* all four estimators of the reference with one kernel: mode 0 light (:755-861, == ia_pbr_light_shade), 1 uniform_light
+ * (:654-753; inv_pdf [F] from the stratified sphere, vis [F,3] = 2*tr output), 2 mis (:547-652; weight 1/(pdf_scatter +
+ * pdf_light), call once on the 2F concatenated scatter+light directions and sum the halves), 3 mats (:863-948). */
+int ia_pbr_shade(int mode, int64_t F, const float* normal, const float* albedo, const float* roughness,
+                 const float* metallic, const float* view_dirs, const float* out_dirs, const float* transmittance,
+                 const float* indirect_rgb, const float* inv_pdf, const float* env_base, const float* env_pmf,
+                 int env_h, int env_w, const float* w2s_rot, float* Lo, float* Lo_diff, float* Lo_spec, float* vis,
+                 ia_stream_t stream);
+/* scatterer.sample / scatterer.pdf of the multi-lobe BRDF (1/2 cosine hemisphere + 1/2 GGX half-vector sampling);
+ * u [F,3] uniforms = (lobe selector, u1, u2): explicit RNG */
+int ia_brdf_sample(int64_t F, const float* normal, const float* view_dirs, const float* roughness, const float* u,
+                   float* out_dirs, ia_stream_t stream);
+int ia_brdf_pdf(int64_t F, const float* normal, const float* view_dirs, const float* out_dirs, const float* roughness,
+                float* pdf, ia_stream_t stream);
 /* emitter.eval / emitter.pdf on world-space unit directions (either output may be NULL) */
 int ia_envlight_eval(int64_t n, const float* dirs_world, const float* env_base, const float* env_pmf, int env_h,
                      int env_w, float* rgb /*[n,3]*/, float* pdf /*[n]*/, ia_stream_t stream);

@@ -95,9 +95,97 @@ __device__ __forceinline__ void brdf_eval(const float n[3], const float wi[3], c
     }
 }
 
-// light-importance-sampling estimator (pbr_light_forward): one lane per fg shading sample
+// MultiLobe sampling density (solid angle): 1/2 cosine-weighted hemisphere + 1/2 GGX half-vector sampling
+__device__ __forceinline__ float brdf_pdf(const float n[3], const float wi[3], const float wo[3], float alpha)
+{
+    const float NoL = n[0] * wo[0] + n[1] * wo[1] + n[2] * wo[2];
+    if (NoL <= 0.0f) return 0.0f;
+    float p = 0.5f * NoL * (1.0f / PI_F);
+    float h[3] = {wi[0] + wo[0], wi[1] + wo[1], wi[2] + wo[2]};
+    const float hl = sqrtf(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+    if (hl >= 1e-12f) {
+        h[0] /= hl; h[1] /= hl; h[2] /= hl;
+        const float NoH = n[0] * h[0] + n[1] * h[1] + n[2] * h[2];
+        const float VoH = wi[0] * h[0] + wi[1] * h[1] + wi[2] * h[2];
+        if (NoH > 0.0f && VoH > 0.0f) {
+            const float a2 = alpha * alpha;
+            const float dd = NoH * NoH * (a2 - 1.0f) + 1.0f;
+            p += 0.5f * (a2 / (PI_F * dd * dd)) * NoH / (4.0f * VoH);
+        }
+    }
+    return p;
+}
+
+// orthonormal frame around n (Frisvad / Duff et al.)
+__device__ __forceinline__ void frame(const float n[3], float t[3], float b[3])
+{
+    const float sg = copysignf(1.0f, n[2]);
+    const float a = -1.0f / (sg + n[2]);
+    const float c = n[0] * n[1] * a;
+    t[0] = 1.0f + sg * n[0] * n[0] * a; t[1] = sg * c; t[2] = -sg * n[0];
+    b[0] = c; b[1] = sg + n[1] * n[1] * a; b[2] = -n[1];
+}
+
+// scatterer.sample: u = (lobe selector, u1, u2)
+__device__ __forceinline__ void brdf_sample(const float n[3], const float wi[3], float alpha, const float u[3], float wo[3])
+{
+    float t[3], b[3];
+    frame(n, t, b);
+    const float phi = 2.0f * PI_F * u[2];
+    if (u[0] < 0.5f) {                               // cosine-weighted hemisphere
+        const float r = sqrtf(u[1]), z = sqrtf(fmaxf(1.0f - u[1], 0.0f));
+        const float x = r * cosf(phi), y = r * sinf(phi);
+#pragma unroll
+        for (int c = 0; c < 3; c++) wo[c] = x * t[c] + y * b[c] + z * n[c];
+    } else {                                         // GGX normal distribution: cos^2(theta_h) = (1-u)/(1+(a^2-1)u)
+        const float a2 = alpha * alpha;
+        const float ct = sqrtf(fmaxf((1.0f - u[1]) / (1.0f + (a2 - 1.0f) * u[1]), 0.0f));
+        const float st = sqrtf(fmaxf(1.0f - ct * ct, 0.0f));
+        float h[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) h[c] = st * cosf(phi) * t[c] + st * sinf(phi) * b[c] + ct * n[c];
+        const float VoH = wi[0] * h[0] + wi[1] * h[1] + wi[2] * h[2];
+#pragma unroll
+        for (int c = 0; c < 3; c++) wo[c] = 2.0f * VoH * h[c] - wi[c];
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void brdf_sample_kernel(int64_t F, const float* __restrict__ normal,
+                                                               const float* __restrict__ view_dirs,
+                                                               const float* __restrict__ roughness,
+                                                               const float* __restrict__ u, float* __restrict__ wo_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= F) return;
+    const float n[3] = {normal[i * 3], normal[i * 3 + 1], normal[i * 3 + 2]};
+    const float wi[3] = {-view_dirs[i * 3], -view_dirs[i * 3 + 1], -view_dirs[i * 3 + 2]};
+    const float uu[3] = {u[i * 3], u[i * 3 + 1], u[i * 3 + 2]};
+    float wo[3];
+    brdf_sample(n, wi, roughness[i], uu, wo);
+    wo_out[i * 3] = wo[0]; wo_out[i * 3 + 1] = wo[1]; wo_out[i * 3 + 2] = wo[2];
+}
+
+__global__ __launch_bounds__(THREADS) void brdf_pdf_kernel(int64_t F, const float* __restrict__ normal,
+                                                            const float* __restrict__ view_dirs,
+                                                            const float* __restrict__ wo, const float* __restrict__ roughness,
+                                                            float* __restrict__ pdf)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= F) return;
+    const float n[3] = {normal[i * 3], normal[i * 3 + 1], normal[i * 3 + 2]};
+    const float wi[3] = {-view_dirs[i * 3], -view_dirs[i * 3 + 1], -view_dirs[i * 3 + 2]};
+    const float w[3] = {wo[i * 3], wo[i * 3 + 1], wo[i * 3 + 2]};
+    pdf[i] = brdf_pdf(n, wi, w, roughness[i]);
+}
+
+// Monte-Carlo estimators (one lane per shading sample).  MODE:
+//   0 light          pbr_light_forward         :755-861  weight 1/pdf_light (pdf<=0 -> 1), cosine + tr masks
+//   1 uniform_light  pbr_uniform_light_forward :654-753  weight inv_pdf[i] (stratified sphere), cosine + tr masks, vis
+//   2 mis            pbr_mis_forward           :547-652  weight 1/(pdf_scatter + pdf_light) (0 if <= 1e-6)
+//   3 mats           pbr_mats_forward          :863-948  weight 1/pdf_scatter (pdf<=0 -> 1)
+template <int MODE>
 __global__ __launch_bounds__(THREADS) void pbr_light_kernel(
-    int64_t F, const float* __restrict__ normal, const float* __restrict__ albedo, const float* __restrict__ roughness,
+    int64_t F, const float* __restrict__ inv_pdf, float* __restrict__ vis, const float* __restrict__ normal, const float* __restrict__ albedo, const float* __restrict__ roughness,
     const float* __restrict__ metallic, const float* __restrict__ view_dirs /* t_dirs: wi = -t_dirs */,
     const float* __restrict__ light_dirs /* SMPL space */, const float* __restrict__ tr /* [F] transmittance */,
     const float* __restrict__ ind_rgb /* [F,3] or NULL */, EnvMap env, const float* __restrict__ Rw /* w2s[:3,:3] */,
@@ -109,16 +197,22 @@ __global__ __launch_bounds__(THREADS) void pbr_light_kernel(
     const float wo[3] = {light_dirs[i * 3], light_dirs[i * 3 + 1], light_dirs[i * 3 + 2]};
     float lo[3] = {0, 0, 0}, ld[3] = {0, 0, 0}, ls[3] = {0, 0, 0};
     const float cosv = n[0] * wo[0] + n[1] * wo[1] + n[2] * wo[2];
-    if (cosv > 1e-6f) {                                            // cosine_mask (intrinsic_avatar.py:788)
+    const bool masked = (MODE == 0 || MODE == 1) ? !(cosv > 1e-6f) : false;       // cosine_mask (:788, :692)
+    float t = tr[i];
+    if (MODE <= 1) t = fminf(fmaxf(t, 0.0f), 1.0f);                      // secondary_tr.clamp_(0, 1) only in light / uniform_light
+    if (masked) t = 0.0f;
+    if (MODE == 1 && vis) { vis[i * 3] = 2.0f * t; vis[i * 3 + 1] = 2.0f * t; vis[i * 3 + 2] = 2.0f * t; }
+    if (!masked) {
         const float wi[3] = {-view_dirs[i * 3], -view_dirs[i * 3 + 1], -view_dirs[i * 3 + 2]};
         const float alb[3] = {albedo[i * 3], albedo[i * 3 + 1], albedo[i * 3 + 2]};
         const float met = metallic[i];
         float diff, spec[3];
         brdf_eval(n, wi, wo, roughness[i], alb, met, diff, spec);
-        const float t = fminf(fmaxf(tr[i], 0.0f), 1.0f);
         float em[3] = {0, 0, 0};
-        float pdf = 1.0f;
-        if (t > 0.0f) {                                            // tr_mask
+        float w = 1.0f;
+        const bool need_env = (MODE >= 2) || (t > 0.0f);                  // tr_mask only in the light / uniform modes
+        float pdf_l = 0.0f;
+        if (need_env) {
             // transform_dirs_s2w: normalize(d @ w2s[:3,:3])
             float dw[3];
 #pragma unroll
@@ -126,15 +220,21 @@ __global__ __launch_bounds__(THREADS) void pbr_light_kernel(
             const float l = fmaxf(sqrtf(dw[0] * dw[0] + dw[1] * dw[1] + dw[2] * dw[2]), 1e-6f);
             dw[0] /= l; dw[1] /= l; dw[2] /= l;
             env_eval(env, dw, em);
-            pdf = env_pdf(env, dw);
-            if (!(pdf > 0.0f)) pdf = 1.0f;
+            if (MODE == 0 || MODE == 2) pdf_l = env_pdf(env, dw);
+        }
+        if (MODE == 0) { w = (need_env && pdf_l > 0.0f) ? 1.0f / pdf_l : 1.0f; }
+        else if (MODE == 1) { w = inv_pdf[i]; }
+        else {
+            const float pdf_s = brdf_pdf(n, wi, wo, roughness[i]);
+            if (MODE == 2) { const float sum = pdf_s + pdf_l; w = sum > 1e-6f ? 1.0f / sum : 0.0f; }
+            else { w = pdf_s > 0.0f ? 1.0f / pdf_s : 1.0f; }
         }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const float Li = em[c] * t + (ind_rgb ? ind_rgb[i * 3 + c] : 0.0f);
-            ld[c] = Li * diff / pdf;
-            ls[c] = Li * spec[c] / pdf;
-            lo[c] = (1.0f - met) * alb[c] * ld[c] + ls[c];          // kd = (1-m) albedo, ks = 1  (:849-857)
+            ld[c] = Li * diff * w;
+            ls[c] = Li * spec[c] * w;
+            lo[c] = (1.0f - met) * alb[c] * ld[c] + ls[c];          // kd = (1-m) albedo, ks = 1
         }
     }
 #pragma unroll
@@ -153,19 +253,53 @@ __global__ __launch_bounds__(THREADS) void env_eval_kernel(int64_t n, const floa
 
 }  // namespace
 
+IA_EXPORT int ia_pbr_shade(int mode, int64_t F, const float* normal, const float* albedo, const float* roughness,
+                           const float* metallic, const float* view_dirs, const float* out_dirs, const float* transmittance,
+                           const float* indirect_rgb, const float* inv_pdf, const float* env_base, const float* env_pmf,
+                           int env_h, int env_w, const float* w2s_rot, float* Lo, float* Lo_diff, float* Lo_spec,
+                           float* vis, ia_stream_t stream)
+{
+    if (F == 0) return IA_OK;
+    IA_REQUIRE(env_h > 0 && env_w > 0, "environment map must be non-empty");
+    IA_REQUIRE(mode >= 0 && mode <= 3, "mode: 0 light, 1 uniform_light, 2 mis, 3 mats");
+    IA_REQUIRE(mode != 1 || inv_pdf != nullptr, "uniform_light needs inv_pdf");
+    EnvMap e{env_base, env_pmf, env_h, env_w};
+    const int grid = ia::cdiv(F, THREADS);
+    hipStream_t s = (hipStream_t)stream;
+#define IA_PBR_LAUNCH(M) pbr_light_kernel<M><<<grid, THREADS, 0, s>>>(F, inv_pdf, vis, normal, albedo, roughness, metallic, \
+        view_dirs, out_dirs, transmittance, indirect_rgb, e, w2s_rot, Lo, Lo_diff, Lo_spec)
+    if (mode == 0) IA_PBR_LAUNCH(0);
+    else if (mode == 1) IA_PBR_LAUNCH(1);
+    else if (mode == 2) IA_PBR_LAUNCH(2);
+    else IA_PBR_LAUNCH(3);
+#undef IA_PBR_LAUNCH
+    return ia::check_launch("ia_pbr_shade");
+}
+
 IA_EXPORT int ia_pbr_light_shade(int64_t F, const float* normal, const float* albedo, const float* roughness,
                                  const float* metallic, const float* view_dirs, const float* light_dirs,
                                  const float* transmittance, const float* indirect_rgb, const float* env_base,
                                  const float* env_pmf, int env_h, int env_w, const float* w2s_rot, float* Lo,
                                  float* Lo_diff, float* Lo_spec, ia_stream_t stream)
 {
+    return ia_pbr_shade(0, F, normal, albedo, roughness, metallic, view_dirs, light_dirs, transmittance, indirect_rgb, nullptr,
+                        env_base, env_pmf, env_h, env_w, w2s_rot, Lo, Lo_diff, Lo_spec, nullptr, stream);
+}
+
+IA_EXPORT int ia_brdf_sample(int64_t F, const float* normal, const float* view_dirs, const float* roughness, const float* u,
+                             float* out_dirs, ia_stream_t stream)
+{
     if (F == 0) return IA_OK;
-    IA_REQUIRE(env_h > 0 && env_w > 0, "environment map must be non-empty");
-    EnvMap e{env_base, env_pmf, env_h, env_w};
-    pbr_light_kernel<<<ia::cdiv(F, THREADS), THREADS, 0, (hipStream_t)stream>>>(
-        F, normal, albedo, roughness, metallic, view_dirs, light_dirs, transmittance, indirect_rgb, e, w2s_rot, Lo, Lo_diff,
-        Lo_spec);
-    return ia::check_launch("ia_pbr_light_shade");
+    brdf_sample_kernel<<<ia::cdiv(F, THREADS), THREADS, 0, (hipStream_t)stream>>>(F, normal, view_dirs, roughness, u, out_dirs);
+    return ia::check_launch("ia_brdf_sample");
+}
+
+IA_EXPORT int ia_brdf_pdf(int64_t F, const float* normal, const float* view_dirs, const float* out_dirs, const float* roughness,
+                          float* pdf, ia_stream_t stream)
+{
+    if (F == 0) return IA_OK;
+    brdf_pdf_kernel<<<ia::cdiv(F, THREADS), THREADS, 0, (hipStream_t)stream>>>(F, normal, view_dirs, out_dirs, roughness, pdf);
+    return ia::check_launch("ia_brdf_pdf");
 }
 
 IA_EXPORT int ia_envlight_eval(int64_t n, const float* dirs_world, const float* env_base, const float* env_pmf,

@@ -66,6 +66,61 @@ class EnvironmentLightTensor:
         return self._eval(d_world, False, True)[1][:, None]
 
 
+MODES = {"light": 0, "uniform_light": 1, "mis": 2, "mats": 3}
+
+
+def pbr_shade(mode: str, normal, albedo, roughness, metallic, view_dirs, out_dirs, transmittance, indirect_rgb,
+              emitter: "EnvironmentLightTensor", w2s_rot, inv_pdf=None):
+    """one of the four Monte-Carlo estimators (pbr_{light,uniform_light,mis,mats}_forward) for F shading samples and
+    their already-traced secondary rays.  returns (Lo, Lo_diff, Lo_spec[, vis])."""
+    F_ = normal.shape[0]
+    dev = normal.device
+    Lo, Ld, Ls = (torch.empty((F_, 3), device=dev) for _ in range(3))
+    vis = torch.empty((F_, 3), device=dev) if mode == "uniform_light" else None
+    H, W, _ = emitter.base.shape
+    c = lambda t: None if t is None else t.contiguous().float()     # noqa: E731
+    L.check(L.lib().ia_pbr_shade(
+        L.i32(MODES[mode]), L.i64(F_), L.ptr(c(normal)), L.ptr(c(albedo)), L.ptr(c(roughness.reshape(-1))),
+        L.ptr(c(metallic.reshape(-1))), L.ptr(c(view_dirs)), L.ptr(c(out_dirs)), L.ptr(c(transmittance.reshape(-1))),
+        L.ptr(c(indirect_rgb)), L.ptr(c(inv_pdf.reshape(-1)) if inv_pdf is not None else None), L.ptr(emitter.base),
+        L.ptr(emitter.pmf), L.i32(H), L.i32(W), L.ptr(c(w2s_rot)), L.ptr(Lo), L.ptr(Ld), L.ptr(Ls), L.ptr(vis), L.stream()),
+        "ia_pbr_shade")
+    return (Lo, Ld, Ls, vis) if mode == "uniform_light" else (Lo, Ld, Ls)
+
+
+def brdf_sample(normal, view_dirs, roughness, u):
+    """scatterer.sample: out directions from the multi-lobe BRDF (u [F,3] uniforms)."""
+    F_ = normal.shape[0]
+    out = torch.empty((F_, 3), device=normal.device)
+    L.check(L.lib().ia_brdf_sample(L.i64(F_), L.ptr(normal.contiguous().float()), L.ptr(view_dirs.contiguous().float()),
+                                   L.ptr(roughness.reshape(-1).contiguous().float()), L.ptr(u.contiguous().float()), L.ptr(out),
+                                   L.stream()), "ia_brdf_sample")
+    return out
+
+
+def brdf_pdf(normal, view_dirs, out_dirs, roughness):
+    F_ = normal.shape[0]
+    out = torch.empty((F_,), device=normal.device)
+    L.check(L.lib().ia_brdf_pdf(L.i64(F_), L.ptr(normal.contiguous().float()), L.ptr(view_dirs.contiguous().float()),
+                                L.ptr(out_dirs.contiguous().float()), L.ptr(roughness.reshape(-1).contiguous().float()),
+                                L.ptr(out), L.stream()), "ia_brdf_pdf")
+    return out[:, None]
+
+
+def uniform_sphere_stratified(n_theta: int, n_phi: int, u: Tensor):
+    """emitter.sample_uniform_sphere_stratified restricted to the 16x32 stratum set that the reference actually indexes
+    (shuffled indices are in [0, 512): intrinsic_avatar.py:1393-1401,680-689).  Equal-area strata in (cos theta, phi),
+    one jittered direction per stratum (u [n_theta*n_phi, 2]); pdf = 1/(4 pi).  returns (dirs [K,3], inv_pdf [K,1])."""
+    dev = u.device
+    i = torch.arange(n_theta, device=dev).repeat_interleave(n_phi).float()
+    j = torch.arange(n_phi, device=dev).repeat(n_theta).float()
+    z = 1.0 - 2.0 * (i + u[:, 0]) / n_theta
+    phi = 2.0 * math.pi * (j + u[:, 1]) / n_phi
+    r = torch.sqrt((1.0 - z * z).clamp_min(0.0))
+    dirs = torch.stack([r * torch.cos(phi), r * torch.sin(phi), z], -1)
+    return dirs, torch.full((n_theta * n_phi, 1), 4.0 * math.pi, device=dev)
+
+
 def pbr_light_shade(normal, albedo, roughness, metallic, view_dirs, light_dirs, transmittance, indirect_rgb,
                     emitter: EnvironmentLightTensor, w2s_rot):
     """fused scatterer.eval + emitter.eval/pdf + Lo assembly for F foreground shading samples."""

@@ -214,7 +214,8 @@ class RenderStep:
     @torch.no_grad()
     def relight(self, rays: Tensor, material, emitter, spp: int, light_u: Tensor, shuffle_u: Tensor,
                 background_color: Optional[Tensor] = None, global_illumination: bool = False,
-                jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
+                jitter: Optional[Tensor] = None, render_mode: str = "light", scatter_u: Optional[Tensor] = None
+                ) -> Dict[str, Tensor]:
         """forward_ with enable_phys and render_mode='light' (BASELINE configs 3 / 5):
         rendering_with_normals_mats_sdf (volrend.py:810-1020) -> sample_volume_interaction (pbr/utils.py:70-229)
         -> per-ray shuffled light directions (:1356-1378) -> secondary rays (:396-545) -> pbr_light_forward (:755-861)
@@ -249,21 +250,54 @@ class RenderStep:
                 rays_o, rays_d, ray_indices, t_starts, t_ends, n_rays, spp, 1.0 - out["opacity"], extras)
             stats["n_resampled"], stats["n_fg"] = int(rri.shape[0]), int(fg_idx.shape[0])
             if fg_idx.numel() > 0:
-                # light directions: sampled once per frame (prepare, :292-305), permuted per ray
-                dirs_world = emitter.sample(spp, light_u)
-                dirs_smpl = torch.nn.functional.normalize(dirs_world @ dfm.w2s[:3, :3].T, dim=-1, eps=1e-6)   # transform_dirs_w2s
-                shuffled = pbr.light_shuffle(n_rays, spp, rpi, fg_idx, shuffle_u)
-                light_dirs = dirs_smpl[shuffled].contiguous()
-                cos_mask = (ex["normals"] * light_dirs).sum(-1) > 1e-6
-                sec_tr = torch.zeros((fg_idx.shape[0], 1), device=dev)
-                sec_rgb = torch.zeros((fg_idx.shape[0], 3), device=dev)
-                stats["n_secondary"] = int(cos_mask.sum())
-                if stats["n_secondary"] > 0:
-                    t_, c_ = self.compute_indirect_radiance(ex["positions"][cos_mask], light_dirs[cos_mask])
-                    sec_tr[cos_mask], sec_rgb[cos_mask] = t_.clamp(0.0, 1.0), c_
-                fg_Lo, fg_Ld, fg_Ls = pbr.pbr_light_shade(
-                    ex["normals"], ex["albedo"], ex["roughness"], ex["metallic"], ex["t_dirs"], light_dirs, sec_tr,
-                    sec_rgb if global_illumination else None, emitter, w2s_rot)
+                F_ = fg_idx.shape[0]
+                ind = lambda c: c if global_illumination else None      # noqa: E731
+                s2 = dfm.w2s[:3, :3].T
+                if render_mode in ("light", "uniform_light"):
+                    if render_mode == "light":
+                        # light directions: sampled once per frame (prepare, :292-305), permuted per ray (:1356-1378)
+                        dirs_world = emitter.sample(spp, light_u)
+                        dirs_smpl = torch.nn.functional.normalize(dirs_world @ s2, dim=-1, eps=1e-6)      # transform_dirs_w2s
+                        inv_pdf = None
+                    else:
+                        # stratified uniform sphere (:680-689); directions are used as-is in SMPL space
+                        assert spp == 512, "uniform_light asserts samples_per_pixel == 512 (:1392)"
+                        dirs_smpl, inv_pdf_all = pbr.uniform_sphere_stratified(16, 32, light_u[:, :2])
+                    shuffled = pbr.light_shuffle(n_rays, spp, rpi, fg_idx, shuffle_u)
+                    out_dirs = dirs_smpl[shuffled].contiguous()
+                    inv_pdf = inv_pdf_all[shuffled] if render_mode == "uniform_light" else None
+                    cos_mask = (ex["normals"] * out_dirs).sum(-1) > 1e-6
+                    sec_tr = torch.zeros((F_, 1), device=dev)
+                    sec_rgb = torch.zeros((F_, 3), device=dev)
+                    stats["n_secondary"] = int(cos_mask.sum())
+                    if stats["n_secondary"] > 0:
+                        t_, c_ = self.compute_indirect_radiance(ex["positions"][cos_mask], out_dirs[cos_mask])
+                        sec_tr[cos_mask], sec_rgb[cos_mask] = t_.clamp(0.0, 1.0), c_
+                    res = pbr.pbr_shade(render_mode, ex["normals"], ex["albedo"], ex["roughness"], ex["metallic"], ex["t_dirs"],
+                                        out_dirs, sec_tr, ind(sec_rgb), emitter, w2s_rot, inv_pdf=inv_pdf)
+                    fg_Lo = res[0]
+                    if render_mode == "uniform_light":
+                        vis = torch.zeros((rri.shape[0], 3), device=dev)
+                        vis[fg_idx] = res[3]
+                        out["visibility"] = nerfacc.accumulate_along_rays(rw, vis, rri, n_rays).mean(-1, keepdim=True)
+                elif render_mode in ("mats", "mis"):
+                    # scatterer.sample (+ emitter.sample per point for mis), :547-652 / :863-948; explicit uniforms scatter_u
+                    assert scatter_u is not None and scatter_u.shape[0] >= F_, "mats / mis need scatter_u [n_fg, 6]"
+                    sc_dirs = pbr.brdf_sample(ex["normals"], ex["t_dirs"], ex["roughness"], scatter_u[:F_, :3])
+                    if render_mode == "mis":
+                        li_dirs = torch.nn.functional.normalize(emitter.sample(F_, scatter_u[:F_, 3:6]) @ s2, dim=-1, eps=1e-6)
+                        out_dirs = torch.cat([sc_dirs, li_dirs], 0)
+                        rep = lambda t: t.repeat(2, 1)      # noqa: E731
+                    else:
+                        out_dirs, rep = sc_dirs, (lambda t: t)
+                    stats["n_secondary"] = int(out_dirs.shape[0])
+                    sec_tr, sec_rgb = self.compute_indirect_radiance(rep(ex["positions"]).contiguous(), out_dirs.contiguous())
+                    Lo2, _, _ = pbr.pbr_shade(render_mode, rep(ex["normals"]), rep(ex["albedo"]), rep(ex["roughness"]),
+                                              rep(ex["metallic"]), rep(ex["t_dirs"]), out_dirs, sec_tr, ind(sec_rgb), emitter,
+                                              w2s_rot)
+                    fg_Lo = Lo2.reshape(2, F_, 3).sum(0) if render_mode == "mis" else Lo2
+                else:
+                    raise NotImplementedError(f"Render mode {render_mode} not supported.")
                 Lo = torch.zeros((rri.shape[0], 3), device=dev)
                 Lo[fg_idx] = fg_Lo
                 rgb_phys = nerfacc.accumulate_along_rays(rw, Lo, rri, n_rays)

@@ -103,3 +103,41 @@ def pbr_light_shade(normal, albedo, roughness, metallic, view_dirs, light_dirs, 
     Ls = np.where(cos_mask[:, None], Li * spec / pdf[:, None], 0.0)
     Lo = (1 - metallic[:, None]) * albedo * Ld + Ls
     return Lo.astype(np.float32), Ld.astype(np.float32), Ls.astype(np.float32)
+
+
+def brdf_pdf(n, wi, wo, alpha):
+    """sampling density of the multi-lobe BRDF: 1/2 cosine hemisphere + 1/2 GGX half-vector sampling."""
+    NoL = (n * wo).sum(-1)
+    p = np.where(NoL > 0, 0.5 * NoL / np.pi, 0.0)
+    h = wi + wo
+    hl = np.linalg.norm(h, axis=-1, keepdims=True)
+    h = h / np.maximum(hl, 1e-30)
+    NoH = (n * h).sum(-1)
+    VoH = (wi * h).sum(-1)
+    a2 = alpha ** 2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ps = 0.5 * (a2 / (np.pi * (NoH ** 2 * (a2 - 1) + 1) ** 2)) * NoH / (4 * VoH)
+    ok = (NoL > 0) & (hl[:, 0] >= 1e-12) & (NoH > 0) & (VoH > 0)
+    return (p + np.where(ok, ps, 0.0)).astype(np.float32)
+
+
+def frame(n):
+    sg = np.copysign(1.0, n[:, 2])
+    a = -1.0 / (sg + n[:, 2])
+    c = n[:, 0] * n[:, 1] * a
+    t = np.stack([1.0 + sg * n[:, 0] ** 2 * a, sg * c, -sg * n[:, 0]], -1)
+    b = np.stack([c, sg + n[:, 1] ** 2 * a, -n[:, 1]], -1)
+    return t, b
+
+
+def brdf_sample(n, wi, alpha, u):
+    t, b = frame(n.astype(np.float64))
+    phi = 2 * np.pi * u[:, 2]
+    r, z = np.sqrt(u[:, 1]), np.sqrt(np.maximum(1 - u[:, 1], 0))
+    wo_d = (r * np.cos(phi))[:, None] * t + (r * np.sin(phi))[:, None] * b + z[:, None] * n
+    a2 = alpha.astype(np.float64) ** 2
+    ct = np.sqrt(np.maximum((1 - u[:, 1]) / (1 + (a2 - 1) * u[:, 1]), 0))
+    st = np.sqrt(np.maximum(1 - ct * ct, 0))
+    h = (st * np.cos(phi))[:, None] * t + (st * np.sin(phi))[:, None] * b + ct[:, None] * n
+    wo_s = 2 * (wi * h).sum(-1, keepdims=True) * h - wi
+    return np.where((u[:, 0] < 0.5)[:, None], wo_d, wo_s).astype(np.float32)
