@@ -301,7 +301,7 @@ class RenderStep:
                 Lo = torch.zeros((rri.shape[0], 3), device=dev)
                 Lo[fg_idx] = fg_Lo
                 rgb_phys = nerfacc.accumulate_along_rays(rw, Lo, rri, n_rays)
-                out["secondary_tr"], out["fg_Lo"] = sec_tr, fg_Lo
+                out["secondary_tr"], out["fg_Lo"], out["fg_extras"] = sec_tr, fg_Lo, ex
             rgb_phys[rpi[:, 1] <= 0] = background_color[None]
         out.update(comp_rgb_phys=rgb_phys, stats=stats)
         return out
