@@ -45,6 +45,7 @@ def algorithmic_bytes(name, stats):
         # hash grid fwd: 12 B in + 16 levels x 8 corners x 8 B gathered + 128 B out (+384 B Jacobian when asked)
         "ia_hashgrid_fwd": (Q + stats["n_samples"]) * (12 + 1024 + 128),
         "ia_hashgrid_bwd": 2 * stats["n_samples"] * (12 + 128 + 1024 + 1024),     # read-modify-write atomics
+        "ia_hashgrid_bwd_binned": 2 * stats["n_samples"] * (12 + 128 + 1024 + 1024),
         "ia_mlp_fwd": Q * (35 + 13) * 4 + stats["n_samples"] * (67 + 3) * 4,
     }.get(name)
 

@@ -179,6 +179,15 @@ int ia_hashgrid_bwd(int64_t n, const float* x, int n_levels, int n_features, int
                     int base_resolution, float per_level_scale, const float* g_enc /*[n,stride] or NULL*/,
                     int g_enc_stride, const float* g_jac /*or NULL*/, int g_jac_stride, const float* q /*[n,3] or NULL*/,
                     float* grad_params, ia_stream_t stream);
+/* same result (up to fp32 summation order) without the fabric atomics: multisplit of the (index, value) records into
+ * (level, 8192-entry slice) buckets + LDS reduction per bucket (see csrc/hashgrid.hip).  scratch: device buffer of
+ * ia_hashgrid_bwd_scratch_bytes(n, ...) bytes (~1.3 KB per point); n * n_levels * 8 must be < 2^31. */
+int64_t ia_hashgrid_bwd_scratch_bytes(int64_t n, int n_levels, int log2_hashmap_size, int base_resolution,
+                                      float per_level_scale);
+int ia_hashgrid_bwd_binned(int64_t n, const float* x, int n_levels, int n_features, int log2_hashmap_size,
+                           int base_resolution, float per_level_scale, const float* g_enc, int g_enc_stride,
+                           const float* g_jac, int g_jac_stride, const float* q, float* grad_params, void* scratch,
+                           int64_t scratch_bytes, ia_stream_t stream);
 /* contractions with the stored Jacobian dy_dx [n,K,3]: mode 0: out[n,3] = sum_k v[n,k] J[n,k,:] (input gradient);
  * mode 1: out[n,K] = J[n,k,:] . v[n,:3] (JVP).  Used by the tinycudann.Encoding drop-in's (double) backward. */
 int ia_hashgrid_jac_contract(int mode, int64_t n, int K, const float* jac, const float* v, int v_stride, float* out,

@@ -244,6 +244,232 @@ __global__ __launch_bounds__(THREADS) void hash_bwd_runs_kernel(int64_t n, const
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward w.r.t. the table, BINNED (multisplit + LDS reduction) -- the default for large batches.
+//
+// A device-scope fp32 atomic costs the same wherever it lands (they execute at the memory side of the fabric:
+// ~21 G atomics/s measured on MI355X), so the scatter above is pinned at n*L*8*2 atomics no matter how it is
+// scheduled.  This path issues (almost) none.  The table of every level is cut into slices of 8192 entries (64 KB of
+// float2 -- one LDS-resident accumulator per workgroup); a "bucket" is one (level, slice):
+//   1. count : per workgroup (1024 points) an LDS histogram of its records per bucket -> counts[bucket][wg]
+//   2. scan  : exclusive scan of that matrix in bucket-major order = the base of every (bucket, wg) run
+//   3. fill  : records (13-bit local index as u16, float2 value) are written to their run (wave-level run merging
+//              first: consecutive samples of a ray falling into the same cell become one record)
+//   4. reduce: one workgroup per (bucket, part) streams its records (coalesced 10 B / record), accumulates them
+//              with LDS atomics (ds_add_f32), and adds the slice to the gradient table -- plain read-modify-write
+//              when it owns the whole bucket, atomics only for the few buckets split in parts (coarse dense levels).
+// HBM traffic ~ 2 x 10 B per record instead of 2 fabric atomics per record.
+constexpr int SLICE_LOG2 = 13;
+constexpr int SLICE = 1 << SLICE_LOG2;
+constexpr int BIN_ROUNDS = 4;
+constexpr int BIN_TILE = THREADS * BIN_ROUNDS;      // points per workgroup
+constexpr int MAX_BUCKETS = 1024;
+constexpr int MAX_PARTS = 64;
+constexpr int PART_RECORDS = 1 << 19;
+
+struct BinCfg {
+    int n_buckets;
+    int bstart[MAX_LEVELS + 1];
+};
+
+__host__ void make_bins(BinCfg& b, const HashCfg& c)
+{
+    int k = 0;
+    for (int l = 0; l < c.n_levels; l++) {
+        b.bstart[l] = k;
+        k += (int)((c.offsets[l + 1] - c.offsets[l] + SLICE - 1) >> SLICE_LOG2);
+    }
+    b.bstart[c.n_levels] = k;
+    b.n_buckets = k;
+}
+
+template <bool SECOND, bool FILL>
+__global__ __launch_bounds__(THREADS) void hash_bin_kernel(int64_t n, const float* __restrict__ x, HashCfg cfg, BinCfg bins,
+                                                            const float* __restrict__ gE, int gE_stride,
+                                                            const float* __restrict__ gG, int gG_stride,
+                                                            const float* __restrict__ q, int nwg,
+                                                            int32_t* __restrict__ counts, uint16_t* __restrict__ rec_idx,
+                                                            float2* __restrict__ rec_val)
+{
+    __shared__ int hist[MAX_BUCKETS];
+    __shared__ int base[FILL ? MAX_BUCKETS : 1];
+    const int lane = threadIdx.x & 63;
+    for (int b = threadIdx.x; b < bins.n_buckets; b += THREADS) {
+        hist[b] = 0;
+        if (FILL) base[b] = counts[(int64_t)b * nwg + blockIdx.x];
+    }
+    __syncthreads();
+    for (int r = 0; r < BIN_ROUNDS; r++) {
+        const int64_t i = (int64_t)blockIdx.x * BIN_TILE + r * THREADS + threadIdx.x;
+        const bool active = i < n;
+        const int64_t ii = active ? i : n - 1;
+        const float x0 = x[ii * 3 + 0], x1 = x[ii * 3 + 1], x2 = x[ii * 3 + 2];
+        float qx = 0.f, qy = 0.f, qz = 0.f;
+        if (SECOND && FILL) { qx = q[ii * 3 + 0]; qy = q[ii * 3 + 1]; qz = q[ii * 3 + 2]; }
+        for (int l = 0; l < cfg.n_levels; l++) {
+            const float sc = cfg.scale[l];
+            const uint32_t res = cfg.res[l], hsize = cfg.offsets[l + 1] - cfg.offsets[l];
+            float2 e = make_float2(0.f, 0.f), g = make_float2(0.f, 0.f);
+            if (active) {
+                if (gE) e = *reinterpret_cast<const float2*>(gE + i * gE_stride + l * 2);
+                if (SECOND) g = *reinterpret_cast<const float2*>(gG + i * gG_stride + l * 2);
+            }
+            const bool any_here = (e.x != 0.f) || (e.y != 0.f) || (g.x != 0.f) || (g.y != 0.f);
+            if (!__any(any_here)) continue;                       // masked-out level for the whole wave
+            float pos[3];
+            uint32_t pg[3];
+            {
+                const float xs[3] = {x0, x1, x2};
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const float p = fmaf(sc, xs[d], 0.5f);
+                    const float fl = floorf(p);
+                    pg[d] = (uint32_t)(int)fl;
+                    pos[d] = p - fl;
+                }
+            }
+            const int b0 = bins.bstart[l];
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                uint32_t idx = grid_index(hsize, res, pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1));
+                if (!active) idx = 0xFFFFFFFFu;
+                const uint32_t prev = __shfl_up(idx, 1, 64);
+                const bool head = (lane == 0) || (prev != idx);
+                const unsigned long long heads = __ballot(head);
+                const bool tail = (lane == 63) || ((heads >> (lane + 1)) & 1ull);
+                float vx = 0.f, vy = 0.f;
+                if (FILL) {
+                    const float wx = (c & 1) ? pos[0] : 1.0f - pos[0];
+                    const float wy = (c & 2) ? pos[1] : 1.0f - pos[1];
+                    const float wz = (c & 4) ? pos[2] : 1.0f - pos[2];
+                    const float w0 = wx * wy * wz;
+                    vx = e.x * w0; vy = e.y * w0;
+                    if (SECOND) {
+                        const float dw = ((c & 1) ? sc : -sc) * wy * wz * qx + ((c & 2) ? sc : -sc) * wx * wz * qy +
+                                         ((c & 4) ? sc : -sc) * wx * wy * qz;
+                        vx += g.x * dw;
+                        vy += g.y * dw;
+                    }
+                    if (!active) { vx = 0.f; vy = 0.f; }
+                    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+                    const int hpos = 63 - __clzll(below);
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const float ax = __shfl_up(vx, off, 64), ay = __shfl_up(vy, off, 64);
+                        if (lane - off >= hpos) { vx += ax; vy += ay; }
+                    }
+                }
+                if (tail && active) {
+                    const int b = b0 + (int)(idx >> SLICE_LOG2);
+                    const int rank = atomicAdd(&hist[b], 1);
+                    if (FILL) {
+                        const int64_t p = (int64_t)base[b] + rank;
+                        rec_idx[p] = (uint16_t)(idx & (SLICE - 1));
+                        rec_val[p] = make_float2(vx, vy);
+                    }
+                }
+            }
+        }
+    }
+    if (!FILL) {
+        __syncthreads();
+        for (int b = threadIdx.x; b < bins.n_buckets; b += THREADS) counts[(int64_t)b * nwg + blockIdx.x] = hist[b];
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void hash_reduce_kernel(HashCfg cfg, BinCfg bins, int nwg,
+                                                               const int32_t* __restrict__ scan,
+                                                               const int32_t* __restrict__ total,
+                                                               const uint16_t* __restrict__ rec_idx,
+                                                               const float2* __restrict__ rec_val, float* __restrict__ grad)
+{
+    __shared__ float2 acc[SLICE];
+    const int b = blockIdx.x % bins.n_buckets, part = blockIdx.x / bins.n_buckets;
+    const int start = scan[(int64_t)b * nwg];
+    const int end = (b + 1 < bins.n_buckets) ? scan[(int64_t)(b + 1) * nwg] : *total;
+    const int cnt = end - start;
+    if (cnt <= 0) return;
+    int nparts = (cnt + PART_RECORDS - 1) / PART_RECORDS;
+    nparts = nparts > MAX_PARTS ? MAX_PARTS : nparts;
+    if (part >= nparts) return;
+    const int per = (cnt + nparts - 1) / nparts;
+    const int s = start + part * per;
+    const int e = (s + per < end) ? s + per : end;
+    int l = 0;
+    while (b >= bins.bstart[l + 1]) l++;
+    const int slice = b - bins.bstart[l];
+    const uint32_t hsize = cfg.offsets[l + 1] - cfg.offsets[l];
+    const int first = slice << SLICE_LOG2;
+    const int entries = ((int)hsize - first < SLICE) ? (int)hsize - first : SLICE;
+    for (int k = threadIdx.x; k < entries; k += THREADS) acc[k] = make_float2(0.f, 0.f);
+    __syncthreads();
+    float* a = reinterpret_cast<float*>(acc);
+    // head up to the first multiple of 4, then 4 consecutive records per lane (8-byte index load, 2 x 16-byte value
+    // loads), two groups in flight per lane; tail one by one.
+    const int s4 = (s + 3) & ~3, e4 = e & ~3;
+    if (s4 >= e4) {
+        for (int j = s + threadIdx.x; j < e; j += THREADS) {
+            const uint32_t i0 = rec_idx[j];
+            const float2 v0 = rec_val[j];
+            unsafeAtomicAdd(a + 2 * i0, v0.x); unsafeAtomicAdd(a + 2 * i0 + 1, v0.y);
+        }
+    } else {
+        if ((int)threadIdx.x < s4 - s) {
+            const int j = s + threadIdx.x;
+            const uint32_t i0 = rec_idx[j];
+            const float2 v0 = rec_val[j];
+            unsafeAtomicAdd(a + 2 * i0, v0.x); unsafeAtomicAdd(a + 2 * i0 + 1, v0.y);
+        }
+        if ((int)threadIdx.x < e - e4) {
+            const int j = e4 + threadIdx.x;
+            const uint32_t i0 = rec_idx[j];
+            const float2 v0 = rec_val[j];
+            unsafeAtomicAdd(a + 2 * i0, v0.x); unsafeAtomicAdd(a + 2 * i0 + 1, v0.y);
+        }
+        const ushort4* ri = reinterpret_cast<const ushort4*>(rec_idx);
+        const float4* rv = reinterpret_cast<const float4*>(rec_val);
+        const int g0 = s4 >> 2, g1 = e4 >> 2;
+        int gq = g0 + threadIdx.x;
+        for (; gq + THREADS < g1; gq += 2 * THREADS) {
+            const ushort4 ia = ri[gq], ib = ri[gq + THREADS];
+            const float4 a0 = rv[2 * gq], a1 = rv[2 * gq + 1];
+            const float4 b0 = rv[2 * (gq + THREADS)], b1 = rv[2 * (gq + THREADS) + 1];
+            unsafeAtomicAdd(a + 2 * ia.x, a0.x); unsafeAtomicAdd(a + 2 * ia.x + 1, a0.y);
+            unsafeAtomicAdd(a + 2 * ia.y, a0.z); unsafeAtomicAdd(a + 2 * ia.y + 1, a0.w);
+            unsafeAtomicAdd(a + 2 * ia.z, a1.x); unsafeAtomicAdd(a + 2 * ia.z + 1, a1.y);
+            unsafeAtomicAdd(a + 2 * ia.w, a1.z); unsafeAtomicAdd(a + 2 * ia.w + 1, a1.w);
+            unsafeAtomicAdd(a + 2 * ib.x, b0.x); unsafeAtomicAdd(a + 2 * ib.x + 1, b0.y);
+            unsafeAtomicAdd(a + 2 * ib.y, b0.z); unsafeAtomicAdd(a + 2 * ib.y + 1, b0.w);
+            unsafeAtomicAdd(a + 2 * ib.z, b1.x); unsafeAtomicAdd(a + 2 * ib.z + 1, b1.y);
+            unsafeAtomicAdd(a + 2 * ib.w, b1.z); unsafeAtomicAdd(a + 2 * ib.w + 1, b1.w);
+        }
+        for (; gq < g1; gq += THREADS) {
+            const ushort4 ia = ri[gq];
+            const float4 a0 = rv[2 * gq], a1 = rv[2 * gq + 1];
+            unsafeAtomicAdd(a + 2 * ia.x, a0.x); unsafeAtomicAdd(a + 2 * ia.x + 1, a0.y);
+            unsafeAtomicAdd(a + 2 * ia.y, a0.z); unsafeAtomicAdd(a + 2 * ia.y + 1, a0.w);
+            unsafeAtomicAdd(a + 2 * ia.z, a1.x); unsafeAtomicAdd(a + 2 * ia.z + 1, a1.y);
+            unsafeAtomicAdd(a + 2 * ia.w, a1.z); unsafeAtomicAdd(a + 2 * ia.w + 1, a1.w);
+        }
+    }
+    __syncthreads();
+    float* tab = grad + ((int64_t)cfg.offsets[l] + first) * 2;
+    for (int k = threadIdx.x; k < entries; k += THREADS) {
+        const float2 v = acc[k];
+        if (v.x == 0.f && v.y == 0.f) continue;
+        if (nparts == 1) {
+            float2* t = reinterpret_cast<float2*>(tab) + k;
+            float2 o = *t;
+            o.x += v.x; o.y += v.y;
+            *t = o;
+        } else {
+            unsafeAtomicAdd(tab + 2 * k, v.x);
+            unsafeAtomicAdd(tab + 2 * k + 1, v.y);
+        }
+    }
+}
+
 __global__ __launch_bounds__(THREADS) void sh4_kernel(int64_t n, const float* __restrict__ d01, float* __restrict__ out,
                                                        int out_stride)
 {
@@ -396,6 +622,76 @@ IA_EXPORT int ia_hashgrid_bwd(int64_t n, const float* x, int n_levels, int n_fea
     if (g_jac) hash_bwd_runs_kernel<true><<<grid, THREADS, 0, s>>>(n, x, c, g_enc, g_enc_stride, g_jac, g_jac_stride, q, grad_params);
     else hash_bwd_runs_kernel<false><<<grid, THREADS, 0, s>>>(n, x, c, g_enc, g_enc_stride, nullptr, 0, nullptr, grad_params);
     return ia::check_launch("ia_hashgrid_bwd");
+}
+
+
+namespace {
+struct BinLayout {
+    int nwg; int64_t m, records;
+    int64_t off_counts, off_total, off_tmp, off_val, off_idx, bytes;
+};
+BinLayout bin_layout(int64_t n, int n_levels, int n_buckets)
+{
+    BinLayout L;
+    L.nwg = ia::cdiv(n, BIN_TILE);
+    L.m = (int64_t)n_buckets * L.nwg;
+    L.records = n * n_levels * 8;
+    auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
+    L.off_counts = 0;
+    L.off_total = up(L.m * 4);
+    L.off_tmp = L.off_total + 256;
+    L.off_val = up(L.off_tmp + ia_scan_tmp_bytes(L.m));
+    L.off_idx = up(L.off_val + L.records * 8);
+    L.bytes = up(L.off_idx + L.records * 2);
+    return L;
+}
+}  // namespace
+
+IA_EXPORT int64_t ia_hashgrid_bwd_scratch_bytes(int64_t n, int n_levels, int log2_hashmap_size, int base_resolution,
+                                                float per_level_scale)
+{
+    if (n_levels <= 0 || n_levels > MAX_LEVELS || n < 0) return -1;
+    HashCfg c;
+    make_cfg(c, n_levels, log2_hashmap_size, base_resolution, per_level_scale);
+    BinCfg b;
+    make_bins(b, c);
+    if (b.n_buckets > MAX_BUCKETS) return -1;
+    return bin_layout(n, n_levels, b.n_buckets).bytes;
+}
+
+IA_EXPORT int ia_hashgrid_bwd_binned(int64_t n, const float* x, int n_levels, int n_features, int log2_hashmap_size,
+                                     int base_resolution, float per_level_scale, const float* g_enc, int g_enc_stride,
+                                     const float* g_jac, int g_jac_stride, const float* q, float* grad_params,
+                                     void* scratch, int64_t scratch_bytes, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    IA_REQUIRE(n_features == 2, "n_features_per_level must be 2 on this path");
+    IA_REQUIRE(n_levels > 0 && n_levels <= MAX_LEVELS, "n_levels out of range");
+    IA_REQUIRE(g_enc != nullptr || g_jac != nullptr, "need g_enc and/or g_jac");
+    IA_REQUIRE((g_jac == nullptr) == (q == nullptr), "g_jac and q go together");
+    IA_REQUIRE(n * n_levels * 8 < (int64_t)0x7FFFFFFF, "n too large for 32-bit record offsets: split the batch");
+    HashCfg c;
+    make_cfg(c, n_levels, log2_hashmap_size, base_resolution, per_level_scale);
+    BinCfg b;
+    make_bins(b, c);
+    IA_REQUIRE(b.n_buckets <= MAX_BUCKETS, "too many (level, slice) buckets");
+    const BinLayout L = bin_layout(n, n_levels, b.n_buckets);
+    IA_REQUIRE(scratch != nullptr && scratch_bytes >= L.bytes, "scratch smaller than ia_hashgrid_bwd_scratch_bytes(n)");
+    char* base = (char*)scratch;
+    int32_t* counts = (int32_t*)(base + L.off_counts);
+    int32_t* total = (int32_t*)(base + L.off_total);
+    void* tmp = base + L.off_tmp;
+    float2* rec_val = (float2*)(base + L.off_val);
+    uint16_t* rec_idx = (uint16_t*)(base + L.off_idx);
+    hipStream_t s = (hipStream_t)stream;
+    if (g_jac) hash_bin_kernel<true, false><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, g_jac, g_jac_stride, q, L.nwg, counts, rec_idx, rec_val);
+    else hash_bin_kernel<false, false><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, nullptr, 0, nullptr, L.nwg, counts, rec_idx, rec_val);
+    int r = ia_exclusive_scan_i32(counts, counts, total, L.m, tmp, stream);
+    if (r != IA_OK) return r;
+    if (g_jac) hash_bin_kernel<true, true><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, g_jac, g_jac_stride, q, L.nwg, counts, rec_idx, rec_val);
+    else hash_bin_kernel<false, true><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, nullptr, 0, nullptr, L.nwg, counts, rec_idx, rec_val);
+    hash_reduce_kernel<<<b.n_buckets * MAX_PARTS, THREADS, 0, s>>>(c, b, L.nwg, counts, total, rec_idx, rec_val, grad_params);
+    return ia::check_launch("ia_hashgrid_bwd_binned");
 }
 
 IA_EXPORT int ia_sh4_fwd(int64_t n, const float* d01, float* out, int out_stride, ia_stream_t stream)

@@ -13,6 +13,7 @@ and the kernels' column order ([hash 32 | xyz 3 | ...]) are folded in here with 
 the (<= 64x67) matrices, which keeps them differentiable for training.
 """
 import ctypes as C
+import os
 import math
 from typing import Optional
 
@@ -48,16 +49,35 @@ def hashgrid_forward(x01: Tensor, params: Tensor, cfg=HASH, with_jac: bool = Fal
     return (out, jac) if with_jac else out
 
 
+HASH_BWD_BINNED_MIN = 1 << 15        # below this the 4-kernel binned path is launch-bound; plain run-merged atomics
+HASH_BWD_CHUNK = 1 << 23             # points per binned call (scratch ~1.3 KB / point, 32-bit record offsets)
+
+
 def hashgrid_backward(x01: Tensor, g_enc: Optional[Tensor], grad_params: Tensor, cfg=HASH,
-                      g_jac: Optional[Tensor] = None, q: Optional[Tensor] = None):
-    """accumulate d L / d table into grad_params (see include/ia_amd.h ia_hashgrid_bwd)."""
+                      g_jac: Optional[Tensor] = None, q: Optional[Tensor] = None, method: Optional[str] = None):
+    """accumulate d L / d table into grad_params (see include/ia_amd.h ia_hashgrid_bwd / ia_hashgrid_bwd_binned).
+    method: None (by batch size; env IA_HASH_BWD overrides) | 'atomic' | 'binned'."""
     n = x01.shape[0]
-    L.check(L.lib().ia_hashgrid_bwd(L.i64(n), L.ptr(x01), L.i32(cfg["n_levels"]), L.i32(cfg["n_features_per_level"]),
-                                    L.i32(cfg["log2_hashmap_size"]), L.i32(cfg["base_resolution"]),
-                                    L.f32(cfg["per_level_scale"]), L.ptr(g_enc),
-                                    L.i32(g_enc.stride(0) if g_enc is not None else 0), L.ptr(g_jac),
-                                    L.i32(g_jac.stride(0) if g_jac is not None else 0), L.ptr(q), L.ptr(grad_params),
-                                    L.stream()), "ia_hashgrid_bwd")
+    method = method or os.environ.get("IA_HASH_BWD") or ("binned" if n >= HASH_BWD_BINNED_MIN else "atomic")
+    cargs = (L.i32(cfg["n_levels"]), L.i32(cfg["n_features_per_level"]), L.i32(cfg["log2_hashmap_size"]),
+             L.i32(cfg["base_resolution"]), L.f32(cfg["per_level_scale"]))
+    if method == "atomic":
+        L.check(L.lib().ia_hashgrid_bwd(L.i64(n), L.ptr(x01), *cargs, L.ptr(g_enc),
+                                        L.i32(g_enc.stride(0) if g_enc is not None else 0), L.ptr(g_jac),
+                                        L.i32(g_jac.stride(0) if g_jac is not None else 0), L.ptr(q), L.ptr(grad_params),
+                                        L.stream()), "ia_hashgrid_bwd")
+        return
+    for c0 in range(0, n, HASH_BWD_CHUNK):
+        m = min(HASH_BWD_CHUNK, n - c0)
+        nb = int(L.lib().ia_hashgrid_bwd_scratch_bytes(L.i64(m), L.i32(cfg["n_levels"]), L.i32(cfg["log2_hashmap_size"]),
+                                                       L.i32(cfg["base_resolution"]), L.f32(cfg["per_level_scale"])))
+        scratch = torch.empty(nb, dtype=torch.uint8, device=x01.device)
+        sl = lambda t: None if t is None else t[c0:c0 + m]      # noqa: E731  (row slices keep stride / contiguity)
+        ge, gj = sl(g_enc), sl(g_jac)
+        L.check(L.lib().ia_hashgrid_bwd_binned(
+            L.i64(m), L.ptr(sl(x01)), *cargs, L.ptr(ge), L.i32(ge.stride(0) if ge is not None else 0), L.ptr(gj),
+            L.i32(gj.stride(0) if gj is not None else 0), L.ptr(sl(q)), L.ptr(grad_params), L.ptr(scratch), L.i64(nb),
+            L.stream()), "ia_hashgrid_bwd_binned")
 
 
 def sh4(d01: Tensor, out: Optional[Tensor] = None) -> Tensor:

@@ -75,6 +75,35 @@ def test_hashgrid_bwd_vs_oracle(oracle, fields):
     np.testing.assert_allclose(N(gp), ref, rtol=1e-4, atol=1e-5)            # atomics: order-dependent rounding
 
 
+@pytest.mark.parametrize("second", [False, True])
+def test_hashgrid_bwd_binned_equals_atomic_scatter(oracle, fields, second):
+    """the multisplit + LDS-reduction backward computes the same table gradient as the atomic scatter (and as the
+    oracle): ray-ordered points (run merging active), masked levels, accumulation into a non-zero table, ragged n."""
+    params, total = _params(oracle)
+    rng = np.random.default_rng(7)
+    n_r, per = 1237, 37
+    o = rng.random((n_r, 1, 3)) * 0.6 + 0.2
+    d = rng.normal(size=(n_r, 1, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    x = np.clip(o + d * (np.arange(per)[None, :, None] * 0.004), 0, 1).reshape(-1, 3).astype(np.float32)
+    n = x.shape[0]
+    g = rng.normal(size=(n, 32)).astype(np.float32)
+    g[:, 24:] = 0.0                                                          # progressive mask: finest 4 levels off
+    gj = rng.normal(size=(n, 32)).astype(np.float32) if second else None
+    q = rng.normal(size=(n, 3)).astype(np.float32) if second else None
+    init = rng.normal(size=total * 2).astype(np.float32) * 0.1
+    ga, gb = T(init.copy()), T(init.copy())
+    kw = dict(g_jac=T(gj), q=T(q)) if second else {}
+    fields.hashgrid_backward(T(x), T(g), ga, method="atomic", **kw)
+    fields.hashgrid_backward(T(x), T(g), gb, method="binned", **kw)
+    da, db = N(ga) - init, N(gb) - init
+    scale = np.abs(da).max()
+    assert np.abs(da - db).max() < 2e-5 * scale + 1e-5, np.abs(da - db).max()
+    assert np.all((db != 0) == (da != 0)) or np.abs(db[(db != 0) != (da != 0)]).max() < 1e-6
+    if not second:
+        ref = oracle.hashgrid_bwd_params(x, g, total * 2)
+        np.testing.assert_allclose(db, ref, rtol=1e-3, atol=2e-5 * scale)
+
+
 def test_hashgrid_second_order_bwd_vs_autograd(oracle, fields):
     """d/dparams of <g_jac, J q> must equal the scatter the kernel does (double-backward path);
     checked against finite-difference-free autograd on a torch restatement of ONE dense level."""
