@@ -81,6 +81,20 @@ int ia_traverse_grids_fill(
     int64_t* iv_ray_indices /*[E]*/, float* sm_vals /*[S]*/, int64_t* sm_ray_indices /*[S]*/,
     float* termination_planes /*[n] or NULL*/, ia_stream_t stream);
 
+/* Single-launch variant for callers that can bound the output size (count + look-back scan + coalesced fill in one
+ * kernel; identical outputs).  cap_edges / cap_samples = element capacity of the output arrays (< 2^31); totals[3]
+ * (device) receives {n_edges, n_samples, overflow}: when overflow != 0 the outputs are incomplete and the caller must
+ * fall back to the two-phase protocol above.  The flag arrays need NOT be zeroed.  scratch:
+ * ia_traverse_fused_scratch_bytes(n_rays) bytes. */
+int64_t ia_traverse_fused_scratch_bytes(int64_t n_rays);
+int ia_traverse_grids_fused(int64_t n_rays, const float* rays_o, const float* rays_d, const uint32_t* grid_bits,
+                            int rx, int ry, int rz, const float* aabb, const float* near_planes,
+                            const float* far_planes, float step_size, float cone_angle, void* scratch,
+                            int64_t cap_edges, int64_t cap_samples, int64_t* totals, int64_t* iv_packed_info,
+                            int64_t* sm_packed_info, float* iv_vals, uint8_t* iv_is_left, uint8_t* iv_is_right,
+                            int64_t* iv_ray_indices, float* sm_vals, int64_t* sm_ray_indices,
+                            float* termination_planes, ia_stream_t stream);
+
 /* ------------------------------------------------------------------------- */
 /* nerfacc.render_weight_from_alpha / accumulate_along_rays
  * (call sites models/intrinsic_avatar.py:506,1199,1427-1453; models/volrend.py:162,176-187,764,783-797).

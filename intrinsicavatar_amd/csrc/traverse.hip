@@ -16,6 +16,7 @@
 // Arithmetic is kept operation-for-operation identical to oracle/ia_oracle.c (this TU is
 // built with -ffp-contract=off) so edge/sample counts and t values are bit-exact.
 #include "ia_common.h"
+#include "t_advance.h"
 
 namespace {
 
@@ -266,6 +267,401 @@ __global__ __launch_bounds__(TR_THREADS) void expand_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Single-pass traversal (count + scan + fill in ONE launch) for callers that can bound the output size.
+//
+//   * tiles of 256 consecutive rays; the tile id is a ticket taken at workgroup start, so a tile's predecessors are
+//     always resident or finished (forward progress for the look-back below);
+//   * phase 1: the DDA walk of pass 1, run descriptors go to LDS (SoA, conflict-free) instead of HBM;
+//   * phase 2: workgroup scan of the packed (edges | samples << 32) counts -> local offsets;
+//   * phase 3: decoupled look-back over one 64-bit word per tile {flag:2, samples:31, edges:31}: wave 0 inspects 64
+//     predecessors per step and publishes the tile's inclusive prefix -- the global offsets without a second kernel;
+//   * phase 4: element-parallel expansion: one lane per output EDGE (binary search of the owning ray in the LDS
+//     offsets, replay of t_{k+1} = t_k + dt from the run start -- the marching recurrence, bit-exact), so every
+//     store instruction of a wave covers 64 consecutive elements: coalesced 256/512-byte writes.
+// HBM traffic = 32 B/ray in + the outputs; no scratch descriptors, no zero-fill of the flag arrays.
+constexpr uint64_t TS_AGG = 1ull << 62, TS_PREFIX = 2ull << 62, TS_MASK = (1ull << 62) - 1;
+constexpr int FT_OFFS = TR_THREADS + 1;
+
+struct LdsRunSink {
+    float* tfirst;      // [TR_RUNS][TR_THREADS]
+    int* nsamp;         // [TR_RUNS][TR_THREADS]
+    int lane;
+    int n_runs = 0, run_len = 0, n_samples = 0, n_intervals = 0;
+    __device__ __forceinline__ void emit(float t_last, float, bool continuous)
+    {
+        if (!continuous) {
+            if (n_runs > 0 && n_runs <= TR_RUNS) nsamp[(n_runs - 1) * TR_THREADS + lane] = run_len;
+            if (n_runs < TR_RUNS) tfirst[n_runs * TR_THREADS + lane] = t_last;
+            n_runs++;
+            run_len = 0;
+            n_intervals += 2;
+        } else {
+            n_intervals++;
+        }
+        n_samples++;
+        run_len++;
+    }
+    __device__ __forceinline__ void finish()
+    {
+        if (n_runs > 0 && n_runs <= TR_RUNS) nsamp[(n_runs - 1) * TR_THREADS + lane] = run_len;
+    }
+};
+
+struct DirectWriteSink {       // in-order writes of one ray (rays with more than TR_RUNS runs); writes every flag
+    float* iv_vals; uint8_t* iv_is_left; uint8_t* iv_is_right; int64_t* iv_ray; float* sm_vals; int64_t* sm_ray;
+    int64_t iv_base, sm_base, tid;
+    int64_t n_samples = 0, n_intervals = 0;
+    __device__ __forceinline__ void emit(float t_last, float t_next, bool continuous)
+    {
+        const int64_t idx = iv_base + n_intervals;
+        if (!continuous) {
+            iv_vals[idx] = t_last; iv_ray[idx] = tid; iv_is_left[idx] = 1; iv_is_right[idx] = 0;
+            iv_vals[idx + 1] = t_next; iv_ray[idx + 1] = tid; iv_is_left[idx + 1] = 0; iv_is_right[idx + 1] = 1;
+            n_intervals += 2;
+        } else {
+            iv_vals[idx] = t_next; iv_ray[idx] = tid; iv_is_left[idx] = 0; iv_is_right[idx] = 1;
+            iv_is_left[idx - 1] = 1;
+            n_intervals++;
+        }
+        const int64_t si = sm_base + n_samples;
+        sm_vals[si] = (t_next + t_last) * 0.5f; sm_ray[si] = tid;
+        n_samples++;
+    }
+};
+
+// the marching loop of traverse_kernel, operation for operation, with the per-sample action factored out
+template <class Sink>
+__device__ __forceinline__ float dda_walk(const float o[3], const float d[3], const float aabb[6], int rx, int ry, int rz,
+                                          float near_plane, float far_plane, float step_size, float cone_angle,
+                                          const uint32_t* s_bits, Sink& sink)
+{
+    const int res[3] = {rx, ry, rz};
+    bool continuous = false;
+    float t_last = near_plane;
+    float tmin, tmax;
+    const float eps = 1e-6f;
+    if (!ray_aabb(o, d, aabb, tmin, tmax)) return t_last;
+    const float this_tmin = fmaxf(tmin, near_plane);
+    const float this_tmax = fminf(tmax, far_plane);
+    if (!(this_tmin < this_tmax)) return t_last;
+    for (;;) {
+        float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
+        if (t_last + dt * 0.5f >= this_tmin) break;
+        t_last += dt;
+    }
+    float tdist[3], delta[3];
+    int cur[3], stp[3], ovf[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float vs = (aabb[3 + a] - aabb[a]) / (float)res[a];
+        const float rs = o[a] + d[a] * (this_tmin + eps);
+        const float re = o[a] + d[a] * (this_tmax - eps);
+        cur[a] = clampi((int)((rs - aabb[a]) / (aabb[3 + a] - aabb[a]) * (float)res[a]), 0, res[a] - 1);
+        const int fin = clampi((int)((re - aabb[a]) / (aabb[3 + a] - aabb[a]) * (float)res[a]), 0, res[a] - 1);
+        const int start_index = cur[a] + (d[a] > 0 ? 1 : 0);
+        const float tmax_a = ((aabb[a] + ((float)start_index * vs - rs)) / d[a]) + this_tmin;
+        const float sf = (d[a] == 0.0f) ? 0.0f : (d[a] > 0.0f ? 1.0f : -1.0f);
+        tdist[a] = (d[a] == 0.0f) ? this_tmax : tmax_a;
+        stp[a] = (int)sf;
+        delta[a] = (d[a] == 0.0f) ? this_tmax : vs / d[a] * sf;
+        ovf[a] = fin + stp[a];
+    }
+    for (;;) {
+        float t_traverse = fminf(tdist[0], fminf(tdist[1], tdist[2]));
+        t_traverse = fminf(t_traverse, this_tmax);
+        const int cell = (cur[0] * ry + cur[1]) * rz + cur[2];
+        const bool occ = (s_bits[cell >> 5] >> (cell & 31)) & 1u;
+        if (!occ) {
+            for (;;) {
+                float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
+                if (t_last + dt * 0.5f >= t_traverse) break;
+                t_last += dt;
+            }
+            continuous = false;
+        } else {
+            for (;;) {
+                float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
+                if (t_last + dt * 0.5f >= t_traverse) break;
+                const float t_next = t_last + dt;
+                sink.emit(t_last, t_next, continuous);
+                continuous = true;
+                t_last = t_next;
+                if (t_next >= t_traverse) break;
+            }
+        }
+        int a;
+        if (tdist[0] < tdist[1] && tdist[0] < tdist[2]) a = 0;
+        else if (tdist[1] < tdist[2]) a = 1;
+        else a = 2;
+        bool done;
+        if (a == 0) { cur[0] += stp[0]; tdist[0] += delta[0]; done = cur[0] == ovf[0]; }
+        else if (a == 1) { cur[1] += stp[1]; tdist[1] += delta[1]; done = cur[1] == ovf[1]; }
+        else { cur[2] += stp[2]; tdist[2] += delta[2]; done = cur[2] == ovf[2]; }
+        if (done) break;
+    }
+    return t_last;
+}
+
+
+// cone_angle == 0 specialisation of dda_walk (dt == step_size for every sample), restructured to cut the instruction
+// count of the EMPTY part of the grid, where rays spend most of their cells:
+//   * marching through an empty cell only moves t_last up to that cell's exit time, and "march until mid >= A, then
+//     until mid >= B" equals "march until mid >= max(A, B)": the catch-up is deferred to the next occupied cell (or the
+//     end of the ray), so an empty cell costs one DDA step + one LDS bit test and nothing else;
+//   * long catch-ups (the stretch in front of the box: ~120 steps for a primary ray) jump with ia_advance() -- the
+//     exact closed form of the recurrence -- to a conservative k0 <= k*, verified, then finish with the plain loop;
+//   * the DDA step is predicated (selects, no divergent three-way branch);
+//   * `if (t_next >= t_traverse) break` of the reference loop is implied by its loop condition (t_next + dt/2 >= t_next).
+// Same float operations on the same operands in the same order for everything that reaches an output.
+__device__ __forceinline__ float catch_up(float t, float step, float half, float target)
+{
+    if (!(t + half >= target)) {
+        const float est = (target - half - t) / step;
+        if (est > 24.0f && est < 1.0e9f) {
+            const int e = (int)est;
+            const int k0 = e - 2 - (e >> 14);
+            const float tj = ia_advance(t, step, k0);
+            if (!(tj + half >= target)) t = tj;                     // k0 <= k*: safe to continue from there
+        }
+        while (!(t + half >= target)) t += step;
+    }
+    return t;
+}
+
+template <class Sink>
+__device__ __forceinline__ float dda_walk_fast(const float o[3], const float d[3], const float aabb[6], int rx, int ry,
+                                               int rz, float near_plane, float far_plane, float step, const uint32_t* s_bits,
+                                               Sink& sink)
+{
+    const int res[3] = {rx, ry, rz};
+    float t_last = near_plane;
+    float tmin, tmax;
+    const float eps = 1e-6f;
+    if (!ray_aabb(o, d, aabb, tmin, tmax)) return t_last;
+    const float this_tmin = fmaxf(tmin, near_plane);
+    const float this_tmax = fminf(tmax, far_plane);
+    if (!(this_tmin < this_tmax)) return t_last;
+    const float half = step * 0.5f;
+    float tdist[3], delta[3];
+    int cur[3], stp[3], ovf[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float vs = (aabb[3 + a] - aabb[a]) / (float)res[a];
+        const float rs = o[a] + d[a] * (this_tmin + eps);
+        const float re = o[a] + d[a] * (this_tmax - eps);
+        cur[a] = clampi((int)((rs - aabb[a]) / (aabb[3 + a] - aabb[a]) * (float)res[a]), 0, res[a] - 1);
+        const int fin = clampi((int)((re - aabb[a]) / (aabb[3 + a] - aabb[a]) * (float)res[a]), 0, res[a] - 1);
+        const int start_index = cur[a] + (d[a] > 0 ? 1 : 0);
+        const float tmax_a = ((aabb[a] + ((float)start_index * vs - rs)) / d[a]) + this_tmin;
+        const float sf = (d[a] == 0.0f) ? 0.0f : (d[a] > 0.0f ? 1.0f : -1.0f);
+        tdist[a] = (d[a] == 0.0f) ? this_tmax : tmax_a;
+        stp[a] = (int)sf;
+        delta[a] = (d[a] == 0.0f) ? this_tmax : vs / d[a] * sf;
+        ovf[a] = fin + stp[a];
+    }
+    // the stretch in front of the box: every lane does it here, together (closed-form jump), so the divergent code in
+    // the cell loop below stays tiny; `pending` = max of the deferred empty-cell thresholds inside the box
+    t_last = catch_up(t_last, step, half, this_tmin);
+    float pending = this_tmin;
+    bool continuous = false;
+    // linear cell index kept incrementally (integer multiplies are quarter rate)
+    int cell = (cur[0] * ry + cur[1]) * rz + cur[2];
+    const int cs0 = stp[0] * ry * rz, cs1 = stp[1] * rz, cs2 = stp[2];
+    for (;;) {
+        float t_traverse = fminf(tdist[0], fminf(tdist[1], tdist[2]));
+        t_traverse = fminf(t_traverse, this_tmax);
+        const bool occ = (s_bits[cell >> 5] >> (cell & 31)) & 1u;
+        if (occ) {
+            while (!(t_last + half >= pending)) t_last += step;
+            while (!(t_last + half >= t_traverse)) {
+                const float t_next = t_last + step;
+                sink.emit(t_last, t_next, continuous);
+                continuous = true;
+                t_last = t_next;
+            }
+        } else {
+            pending = fmaxf(pending, t_traverse);
+            continuous = false;
+        }
+        const bool a0 = (tdist[0] < tdist[1]) && (tdist[0] < tdist[2]);
+        const bool a1 = !a0 && (tdist[1] < tdist[2]);
+        const bool a2 = !a0 && !a1;
+        const float n0 = tdist[0] + delta[0], n1 = tdist[1] + delta[1], n2 = tdist[2] + delta[2];
+        tdist[0] = a0 ? n0 : tdist[0]; tdist[1] = a1 ? n1 : tdist[1]; tdist[2] = a2 ? n2 : tdist[2];
+        cur[0] += a0 ? stp[0] : 0; cur[1] += a1 ? stp[1] : 0; cur[2] += a2 ? stp[2] : 0;
+        cell += a0 ? cs0 : (a1 ? cs1 : cs2);
+        const bool done = a0 ? (cur[0] == ovf[0]) : (a1 ? (cur[1] == ovf[1]) : (cur[2] == ovf[2]));
+        if (done) break;
+    }
+    while (!(t_last + half >= pending)) t_last += step;
+    return t_last;
+}
+
+__device__ __forceinline__ uint64_t ts_load(const uint64_t* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ts_store(uint64_t* p, uint64_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(TR_THREADS) void traverse_fused_kernel(
+    int64_t n_rays, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    const uint32_t* __restrict__ grid_bits, int rx, int ry, int rz, const float* __restrict__ aabb_g,
+    const float* __restrict__ near_planes, const float* __restrict__ far_planes, float step_size, float cone_angle,
+    uint64_t* __restrict__ tile_state /*[n_tiles] zeroed*/, uint32_t* __restrict__ ticket /*zeroed*/, int n_tiles,
+    int64_t cap_edges, int64_t cap_samples, int64_t* __restrict__ totals /*[3]: edges, samples, overflow*/,
+    int64_t* __restrict__ iv_pinfo, int64_t* __restrict__ sm_pinfo, float* __restrict__ iv_vals,
+    uint8_t* __restrict__ iv_is_left, uint8_t* __restrict__ iv_is_right, int64_t* __restrict__ iv_ray,
+    float* __restrict__ sm_vals, int64_t* __restrict__ sm_ray, float* __restrict__ term_planes)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
+    __shared__ float s_tfirst[TR_RUNS * TR_THREADS];
+    __shared__ int s_nsamp[TR_RUNS * TR_THREADS];
+    __shared__ int s_nruns[TR_THREADS];
+    __shared__ int s_offE[FT_OFFS], s_offS[FT_OFFS];
+    __shared__ unsigned long long s_wave_tot[TR_THREADS / 64];
+    __shared__ unsigned long long s_base;
+    __shared__ uint32_t s_tile;
+    const int lane_wg = threadIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane_wg == 0) s_tile = atomicAdd(ticket, 1u);
+    {
+        const int n_words = (rx * ry * rz + 31) >> 5;
+        const int n_vec = n_words >> 2;
+        const uint4* src = reinterpret_cast<const uint4*>(grid_bits);
+        uint4* dst = reinterpret_cast<uint4*>(s_bits);
+        for (int i = threadIdx.x; i < n_vec; i += TR_THREADS) dst[i] = src[i];
+        for (int i = (n_vec << 2) + threadIdx.x; i < n_words; i += TR_THREADS) s_bits[i] = grid_bits[i];
+    }
+    __syncthreads();
+    const int tile = (int)s_tile;
+    const int64_t tid = (int64_t)tile * TR_THREADS + lane_wg;
+    const bool active = tid < n_rays;
+
+    // ---- phase 1: walk
+    float aabb[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) aabb[k] = aabb_g[k];
+    float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 1.f};
+    float near_plane = 0.f, far_plane = 0.f, t_term = 0.f;
+    LdsRunSink sink{s_tfirst, s_nsamp, lane_wg};
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { o[k] = rays_o[tid * 3 + k]; d[k] = rays_d[tid * 3 + k]; }
+        near_plane = near_planes[tid]; far_plane = far_planes[tid];
+        t_term = (cone_angle == 0.0f)
+                     ? dda_walk_fast(o, d, aabb, rx, ry, rz, near_plane, far_plane, step_size, s_bits, sink)
+                     : dda_walk(o, d, aabb, rx, ry, rz, near_plane, far_plane, step_size, cone_angle, s_bits, sink);
+        sink.finish();
+    }
+    s_nruns[lane_wg] = sink.n_runs;
+
+    // ---- phase 2: workgroup exclusive scan of the packed counts
+    const unsigned long long mine = (unsigned long long)sink.n_intervals | ((unsigned long long)sink.n_samples << 32);
+    unsigned long long inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long v = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += v;
+    }
+    if (lane == 63) s_wave_tot[wid] = inc;
+    __syncthreads();
+    unsigned long long wave_off = 0, wg_total = 0;
+#pragma unroll
+    for (int w = 0; w < TR_THREADS / 64; w++) {
+        const unsigned long long t = s_wave_tot[w];
+        if (w < wid) wave_off += t;
+        wg_total += t;
+    }
+    const unsigned long long excl = wave_off + inc - mine;
+    s_offE[lane_wg] = (int)(excl & 0xFFFFFFFFull);
+    s_offS[lane_wg] = (int)(excl >> 32);
+    if (lane_wg == 0) { s_offE[TR_THREADS] = (int)(wg_total & 0xFFFFFFFFull); s_offS[TR_THREADS] = (int)(wg_total >> 32); }
+    const int E_wg = (int)(wg_total & 0xFFFFFFFFull), S_wg = (int)(wg_total >> 32);
+
+    // ---- phase 3: decoupled look-back (wave 0); word = flag | samples << 31 | edges
+    if (wid == 0) {
+        const uint64_t agg = (uint64_t)E_wg | ((uint64_t)S_wg << 31);
+        uint64_t exclusive = 0;
+        if (tile > 0) {
+            if (lane == 0) ts_store(tile_state + tile, TS_AGG | agg);
+            int pos = tile - 1;
+            for (;;) {
+                const int idx = pos - lane;
+                uint64_t v = TS_PREFIX;                              // virtual tiles before tile 0: prefix 0
+                if (idx >= 0) {
+                    v = ts_load(tile_state + idx);
+                    while ((v >> 62) == 0) { __builtin_amdgcn_s_sleep(1); v = ts_load(tile_state + idx); }
+                }
+                const unsigned long long is_p = __ballot((v >> 62) == 2);
+                const int first_p = is_p ? __builtin_ctzll(is_p) : 64;
+                uint64_t val = (lane <= first_p) ? (v & TS_MASK) : 0;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off, 64);
+                exclusive += val;
+                if (is_p) break;
+                pos -= 64;
+            }
+        }
+        if (lane == 0) {
+            ts_store(tile_state + tile, TS_PREFIX | (exclusive + agg));
+            s_base = exclusive;
+            if (tile == n_tiles - 1) {
+                const uint64_t tot = exclusive + agg;
+                totals[0] = (int64_t)(tot & 0x7FFFFFFFull);
+                totals[1] = (int64_t)(tot >> 31);
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t baseE = (int64_t)(s_base & 0x7FFFFFFFull), baseS = (int64_t)(s_base >> 31);
+    if (baseE + E_wg > cap_edges || baseS + S_wg > cap_samples) {
+        if (lane_wg == 0) totals[2] = 1;
+        return;
+    }
+
+    // ---- phase 4: per-ray records, then element-parallel expansion
+    if (active) {
+        if (iv_pinfo) { iv_pinfo[2 * tid] = baseE + s_offE[lane_wg]; iv_pinfo[2 * tid + 1] = sink.n_intervals; }
+        if (sm_pinfo) { sm_pinfo[2 * tid] = baseS + s_offS[lane_wg]; sm_pinfo[2 * tid + 1] = sink.n_samples; }
+        if (term_planes) term_planes[tid] = t_term;
+    }
+    for (int j = lane_wg; j < E_wg; j += TR_THREADS) {
+        int lo = 0, hi = TR_THREADS;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int mid = (lo + hi) >> 1;
+            if (s_offE[mid] <= j) lo = mid; else hi = mid;
+        }
+        const int r = lo;
+        if (s_nruns[r] > TR_RUNS) continue;                         // written in order by its own lane below
+        int k = j - s_offE[r];
+        int sidx = s_offS[r];
+        int qn = 0;
+        int n = s_nsamp[r];
+        while (k > n) { k -= n + 1; sidx += n; qn++; n = s_nsamp[qn * TR_THREADS + r]; }
+        float t = s_tfirst[qn * TR_THREADS + r];
+        if (cone_angle == 0.0f) t = ia_advance(t, step_size, k);     // exact closed form of the k-fold recurrence (dt == step)
+        else for (int i = 0; i < k; i++) t = t + calc_dt(t, cone_angle, step_size, 1e10f);
+        const int64_t ray = (int64_t)tile * TR_THREADS + r;
+        const int64_t gi = baseE + j;
+        iv_vals[gi] = t; iv_ray[gi] = ray; iv_is_left[gi] = k < n; iv_is_right[gi] = k > 0;
+        if (k < n) {
+            const float t_next = t + calc_dt(t, cone_angle, step_size, 1e10f);
+            const int64_t gs = baseS + sidx + k;
+            sm_vals[gs] = (t_next + t) * 0.5f; sm_ray[gs] = ray;
+        }
+    }
+    if (active && sink.n_runs > TR_RUNS) {
+        DirectWriteSink w{iv_vals, iv_is_left, iv_is_right, iv_ray, sm_vals, sm_ray, baseE + s_offE[lane_wg],
+                          baseS + s_offS[lane_wg], tid};
+        (void)dda_walk(o, d, aabb, rx, ry, rz, near_plane, far_plane, step_size, cone_angle, s_bits, w);
+    }
+}
+
 }  // namespace
 
 IA_EXPORT int ia_occgrid_pack_bits(const uint8_t* binaries, int64_t n_cells, uint32_t* bits, ia_stream_t stream)
@@ -339,4 +735,44 @@ IA_EXPORT int ia_traverse_grids_fill(int64_t n_rays, const float* rays_o, const 
         (RayScratch*)scratch, nullptr, true, packed_starts, iv_vals, iv_is_left, iv_is_right, iv_ray_indices, sm_vals,
         sm_ray_indices, nullptr);
     return ia::check_launch("ia_traverse_grids_fill");
+}
+
+IA_EXPORT int64_t ia_traverse_fused_scratch_bytes(int64_t n_rays)
+{
+    const int64_t tiles = (n_rays + TR_THREADS - 1) / TR_THREADS;
+    return (tiles + 2) * 8 + 64;
+}
+
+IA_EXPORT int ia_traverse_grids_fused(int64_t n_rays, const float* rays_o, const float* rays_d,
+                                      const uint32_t* grid_bits, int rx, int ry, int rz, const float* aabb,
+                                      const float* near_planes, const float* far_planes, float step_size,
+                                      float cone_angle, void* scratch, int64_t cap_edges, int64_t cap_samples,
+                                      int64_t* totals, int64_t* iv_packed_info, int64_t* sm_packed_info, float* iv_vals,
+                                      uint8_t* iv_is_left, uint8_t* iv_is_right, int64_t* iv_ray_indices, float* sm_vals,
+                                      int64_t* sm_ray_indices, float* termination_planes, ia_stream_t stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(totals, 0, 3 * sizeof(int64_t), s) != hipSuccess) return ia::check_launch("ia_traverse_grids_fused(memset)");
+    if (n_rays == 0) return IA_OK;
+    size_t lds;
+    int r = check_grid(rx, ry, rz, &lds);
+    if (r != IA_OK) return r;
+    IA_REQUIRE(step_size > 0.0f, "step_size must be > 0");
+    IA_REQUIRE(cap_edges < (1ll << 31) && cap_samples < (1ll << 31), "capacities must be < 2^31 (split the ray batch)");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)traverse_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipGetLastError();
+        attr_set = true;
+    }
+    const int tiles = ia::cdiv(n_rays, TR_THREADS);
+    const int64_t sb = ia_traverse_fused_scratch_bytes(n_rays);
+    if (hipMemsetAsync(scratch, 0, (size_t)sb, s) != hipSuccess) return ia::check_launch("ia_traverse_grids_fused(memset)");
+    uint64_t* state = (uint64_t*)scratch;
+    uint32_t* ticket = (uint32_t*)(state + tiles + 1);
+    traverse_fused_kernel<<<tiles, TR_THREADS, lds, s>>>(
+        n_rays, rays_o, rays_d, grid_bits, rx, ry, rz, aabb, near_planes, far_planes, step_size, cone_angle, state, ticket,
+        tiles, cap_edges, cap_samples, totals, iv_packed_info, sm_packed_info, iv_vals, iv_is_left, iv_is_right,
+        iv_ray_indices, sm_vals, sm_ray_indices, termination_planes);
+    return ia::check_launch("ia_traverse_grids_fused");
 }

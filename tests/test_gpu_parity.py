@@ -88,6 +88,44 @@ def test_traverse_grids_edge_cases(ops, oracle):
     assert iv.vals.numel() == 0 and iv.packed_info.shape == (0, 2)
 
 
+def test_traverse_fused_equals_two_pass(ops, oracle):
+    """the single-launch traversal (ticketed tiles + look-back scan + element-parallel expansion) returns exactly the
+    two-phase outputs: many-run rays (> 8 runs: in-order slow path), secondary-march style rays starting inside the box
+    with a far clip, a ragged last tile, and the capacity-overflow fallback."""
+    rng = np.random.default_rng(11)
+    aabb = np.array([-1.25, -1.55, -1.25, 1.25, 0.95, 1.25], np.float32)
+    n = 50_000 + 37
+    o = rng.uniform(-1.2, 0.9, (n, 3)).astype(np.float32)
+    o[: n // 4] = rng.uniform(-4, 4, (n // 4, 3))
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    near = np.zeros(n, np.float32)
+    far = np.full(n, 1.5, np.float32)
+    tr = ops["nerfacc"].traverse_grids
+    for name, grid, step in (("checker", (np.indices((32, 32, 32)).sum(0) % 2).astype(bool), 1.5 / 63),
+                             ("blob", rng.random((64, 64, 64)) < 0.08, 1.5 / 63),
+                             ("dense", rng.random((64, 64, 64)) < 0.7, 0.011)):
+        a = tr(T(o), T(d), T(grid)[None], T(aabb)[None], T(near), T(far), step, 0.0, method="two_pass")
+        b = tr(T(o), T(d), T(grid)[None], T(aabb)[None], T(near), T(far), step, 0.0, method="fused", max_extent=1.5)
+        assert a[1].vals.numel() > 10_000, name
+        for k in ("vals", "packed_info", "ray_indices", "is_left", "is_right"):
+            assert torch.equal(getattr(a[0], k), getattr(b[0], k)), (name, "intervals", k)
+        for k in ("vals", "packed_info", "ray_indices"):
+            assert torch.equal(getattr(a[1], k), getattr(b[1], k)), (name, "samples", k)
+        assert torch.equal(a[2], b[2]), name
+        if name == "checker":
+            assert int((a[0].packed_info[:, 1] - a[1].packed_info[:, 1]).max()) > 8      # rays with more than 8 runs
+    # capacity overflow (a deliberately wrong extent hint) -> transparent fallback to the two-phase protocol
+    c = tr(T(o), T(d), T(grid)[None], T(aabb)[None], T(near), T(far), step, 0.0, method="fused", max_extent=0.02)
+    assert torch.equal(a[0].vals, c[0].vals) and torch.equal(a[1].ray_indices, c[1].ray_indices)
+    ref = oracle.traverse_grids(o[:3000], d[:3000], grid, aabb, near[:3000], far[:3000], step)
+    e = tr(T(o[:3000]), T(d[:3000]), T(grid)[None], T(aabb)[None], T(near[:3000]), T(far[:3000]), step, 0.0, max_extent=1.5)
+    np.testing.assert_array_equal(N(e[0].vals), ref["intervals"]["vals"])
+    np.testing.assert_array_equal(N(e[1].vals), ref["samples"]["vals"])
+    np.testing.assert_array_equal(N(e[0].is_left), ref["intervals"]["is_left"])
+    np.testing.assert_array_equal(N(e[0].is_right), ref["intervals"]["is_right"])
+
+
 def test_traverse_properties_full_size(ops):
     """540x540 (BASELINE config 2) -- size-independent properties instead of the (slow) oracle."""
     from intrinsicavatar_amd import synthetic as S

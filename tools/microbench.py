@@ -80,6 +80,51 @@ def main():
                            alg_bytes=alg_bytes, gbps_fill=alg_bytes / t_fill / 1e3,
                            gbps_total=alg_bytes / (t_count + t_scan + t_fill) / 1e3)
 
+    # ---- single-launch traversal, primary rays and a secondary-march batch (2M rays leaving occupied cells, [0, 1.5])
+    def fused_case(tag, ro_, rd_, near_, far_, step_, extent):
+        nonlocal bits
+        m = ro_.shape[0]
+        a_ = (L.i64(m), L.ptr(ro_), L.ptr(rd_), L.ptr(bits), 64, 64, 64, L.ptr(aabb0), L.ptr(near_), L.ptr(far_), L.f32(step_), L.f32(0.0))
+        smax = int(np.ceil(extent / step_)) + 2
+        cs, ce = m * smax, m * smax + 8 * m
+        fs = torch.empty(int(lib.ia_traverse_fused_scratch_bytes(L.i64(m))), dtype=torch.uint8, device=DEV)
+        totals = torch.empty(3, dtype=torch.int64, device=DEV)
+        b_iv, b_fl, b_ir = torch.empty(ce, device=DEV), torch.empty((2, ce), dtype=torch.bool, device=DEV), torch.empty(ce, dtype=torch.int64, device=DEV)
+        b_sv, b_sr = torch.empty(cs, device=DEV), torch.empty(cs, dtype=torch.int64, device=DEV)
+        b_t, b_pi = torch.empty(m, device=DEV), torch.empty((2, m, 2), dtype=torch.int64, device=DEV)
+
+        def fused():
+            L.check(lib.ia_traverse_grids_fused(*a_, L.ptr(fs), L.i64(ce), L.i64(cs), L.ptr(totals), L.ptr(b_pi[0]), L.ptr(b_pi[1]),
+                                                L.ptr(b_iv), L.ptr(b_fl[0]), L.ptr(b_fl[1]), L.ptr(b_ir), L.ptr(b_sv), L.ptr(b_sr),
+                                                L.ptr(b_t), st))
+        us = timeit(fused)
+        E_, S__, ovf = totals.tolist()
+        ab = 48 * m + 16 * S__ + 14 * E_
+        res[tag] = dict(n_rays=m, E=E_, S=S__, overflow=ovf, us=us, alg_bytes=ab, gbps=ab / us / 1e3, frac_of_8TBps=ab / us / 1e3 / 8000)
+
+    fused_case("traverse_fused_primary", ro, rd, near, far, step, 4.3301)
+    M = int(os.environ.get("IA_SECONDARY", "2097152"))
+    gsec = torch.Generator().manual_seed(3)
+    occ = torch.nonzero(binaries[0])                     # [K,3] occupied cells
+    pick = occ[torch.randint(0, occ.shape[0], (M,), generator=gsec).to(DEV)]
+    # consecutive rays leave neighbouring surface points (as the shading points of one pixel row do): sort by cell
+    pick = pick[torch.argsort(pick[:, 0] * 4096 + pick[:, 1] * 64 + pick[:, 2])]
+    cellsz = (aabb0[3:] - aabb0[:3]) / 64
+    so = (aabb0[:3] + (pick.float() + torch.rand((M, 3), generator=gsec).to(DEV)) * cellsz).contiguous()
+    sd = torch.nn.functional.normalize(torch.randn((M, 3), generator=gsec), dim=-1).to(DEV).contiguous()
+    fused_case("traverse_fused_secondary", so, sd, torch.zeros(M, device=DEV), torch.full((M,), 1.5, device=DEV), 1.5 / 63, 1.5)
+    zn, fr = torch.zeros(M, device=DEV), torch.full((M,), 1.5, device=DEV)
+    for meth in ("two_pass", "fused"):      # whole operator incl. allocation and the size sync
+        res[f"traverse_op_secondary_{meth}"] = dict(us=timeit(lambda: nerfacc.traverse_grids(
+            so, sd, binaries, aabb, zn, fr, 1.5 / 63, 0.0, grid_bits=bits, max_extent=1.5, method=meth), iters=5))
+        res[f"traverse_op_primary_{meth}"] = dict(us=timeit(lambda: nerfacc.traverse_grids(
+            ro, rd, binaries, aabb, near, far, step, 0.0, grid_bits=bits, method=meth), iters=5))
+    full = torch.ones_like(binaries)
+    bits_full = nerfacc.pack_occupancy_bits(full[0])
+    bits_save, bits = bits, bits_full
+    fused_case("traverse_fused_primary_dense_grid", ro, rd, near, far, step, 4.3301)
+    bits = bits_save
+
     # ---- K2 merge on the traversal's edge list + T2
     iv_pi = pinfo[0].int().contiguous()
     w_e = torch.rand(E, device=DEV) * 0.1
