@@ -40,8 +40,10 @@ def algorithmic_bytes(name, stats):
     Q = stats["sdf_points"]             # total candidates through the SDF network
     return {
         "ia_traverse_grids_count": trav, "ia_traverse_grids_fill": trav,
-        # Broyden: per (point, init) 12 B + 64 B tfs row + <= 11 fetches x 8 corners x 48 B + 49 B out
-        "ia_fuse_broyden": P * 13 * (12 + 64 + 11 * 8 * 48 + 49),
+        # Broyden: compulsory HBM traffic only -- 12 B point in, 13 inits x 49 B out (x 12, J_inv 36, valid 1) and the
+        # 25.2 MB voxel_J grid once per launch; the <= 11 x 8-corner x 48 B gathers per (point, init) of SURVEY 8(d) are
+        # served by L2 / Infinity Cache (the grid is resident), they are reported as gather traffic in DESIGN.md
+        "ia_fuse_broyden": P * (12 + 13 * 49) + 3 * 25_165_824,
         # hash grid fwd: 12 B in + 16 levels x 8 corners x 8 B gathered + 128 B out (+384 B Jacobian when asked)
         "ia_hashgrid_fwd": (Q + stats["n_samples"]) * (12 + 1024 + 128),
         "ia_hashgrid_bwd": 2 * stats["n_samples"] * (12 + 128 + 1024 + 1024),     # read-modify-write atomics
@@ -106,7 +108,7 @@ def main():
     if world > 1:
         dist.barrier()
     lib = L.lib()
-    lib.start()
+    # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides, nothing else running
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -114,6 +116,15 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    # ---- the same K steps again with a HIP-event pair around every C-ABI launch (on the launch stream): per-kernel
+    # durations for the roofline / breakdown.  Kept out of the throughput region because the ~600 event records per step
+    # cost host time that the un-instrumented step does not pay (ms_per_step_instrumented is reported next to it).
+    lib.start()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt_instr = time.perf_counter() - t1
     per_call = lib.report()
     if world > 1:
         t = torch.tensor([dt], device=dev)
@@ -169,7 +180,8 @@ def main():
                        "pass": args.mode, "frames_per_step_per_gpu": 1, "parallelism": f"frame/ray-batch sharding x{world}",
                        "samples": stats},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_breakdown_ms_per_step": breakdown,
-            "host_overhead_ms_per_step": round(ms_per_step - total_ms / args.steps, 3),
+            "ms_per_step_instrumented": round(dt_instr / args.steps * 1e3, 3),
+            "abi_kernel_ms_per_step": round(total_ms / args.steps, 3),
         }
         print(json.dumps(line))
     if world > 1:

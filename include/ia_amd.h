@@ -194,14 +194,16 @@ int ia_hashgrid_bwd(int64_t n, const float* x, int n_levels, int n_features, int
                     int g_enc_stride, const float* g_jac /*or NULL*/, int g_jac_stride, const float* q /*[n,3] or NULL*/,
                     float* grad_params, ia_stream_t stream);
 /* same result (up to fp32 summation order) without the fabric atomics: multisplit of the (index, value) records into
- * (level, 8192-entry slice) buckets + LDS reduction per bucket (see csrc/hashgrid.hip).  scratch: device buffer of
+ * (level, 8192-entry slice) buckets + LDS reduction per bucket in 64-bit fixed point with integer atomics (exact,
+ * order-independent sums of values quantised to 2^-40 of the level's largest |value|; see csrc/hashgrid.hip).  scratch: device buffer of
  * ia_hashgrid_bwd_scratch_bytes(n, ...) bytes (~1.3 KB per point); n * n_levels * 8 must be < 2^31. */
 int64_t ia_hashgrid_bwd_scratch_bytes(int64_t n, int n_levels, int log2_hashmap_size, int base_resolution,
                                       float per_level_scale);
 int ia_hashgrid_bwd_binned(int64_t n, const float* x, int n_levels, int n_features, int log2_hashmap_size,
                            int base_resolution, float per_level_scale, const float* g_enc, int g_enc_stride,
-                           const float* g_jac, int g_jac_stride, const float* q, float* grad_params, void* scratch,
-                           int64_t scratch_bytes, ia_stream_t stream);
+                           const float* g_jac, int g_jac_stride, const float* q, float* grad_params,
+                           uint32_t level_mask /* bit l = level l takes part (progressive bands); ~0u = all */,
+                           void* scratch, int64_t scratch_bytes, ia_stream_t stream);
 /* contractions with the stored Jacobian dy_dx [n,K,3]: mode 0: out[n,3] = sum_k v[n,k] J[n,k,:] (input gradient);
  * mode 1: out[n,K] = J[n,k,:] . v[n,:3] (JVP).  Used by the tinycudann.Encoding drop-in's (double) backward. */
 int ia_hashgrid_jac_contract(int mode, int64_t n, int K, const float* jac, const float* v, int v_stride, float* out,
@@ -282,6 +284,20 @@ int ia_sdf_mlp_bwd(int64_t n, int n_segs, const float* const* seg_ptr, const int
                    const float* bo, const float* jac, const float* g_out, const float* q, float* gE, float* gG,
                    float* Hh /*[n,36]*/, float* U /*[n,36]*/, float* DZ /*[n,64]*/, float* GZ /*[n,64]*/,
                    float* A /*[n,64]*/, float* DGS /*[n,64]*/, ia_stream_t stream);
+
+/* Fused training backward (csrc/mlp_train.hip): the same gradients as ia_mlp_bwd / ia_sdf_mlp_bwd + ia_wgrad, but the
+ * layer operands never leave LDS and the weight gradients are accumulated in MFMA accumulator registers across the whole
+ * batch.  All d* buffers are ACCUMULATED INTO (caller zeroes): dW1 [64,IN], db1 [64], dW2 [64,64], db2 [64],
+ * dWo [OUT,64], dbo [OUT] (row-major, effective-weight layout).  g_x [n, gx_stride] receives d L / d input row. */
+int ia_mlp_bwd_fused(int kind, int64_t n, int n_segs, const float* const* seg_ptr, const int* seg_stride,
+                     const int* seg_width, const float* seg_mul, const float* seg_add, const float* W1, const float* b1,
+                     const float* W2, const float* b2, const float* Wo, const float* bo, const float* g_y, float* g_x,
+                     int gx_stride, float* dW1, float* db1, float* dW2, float* db2, float* dWo, float* dbo,
+                     ia_stream_t stream);
+int ia_sdf_mlp_bwd_fused(int64_t n, int n_segs, const float* const* seg_ptr, const int* seg_stride, const int* seg_width,
+                         const float* seg_mul, const float* seg_add, const float* W1, const float* b1, const float* Wo,
+                         const float* bo, const float* jac, const float* g_out, const float* q, float* gE, float* gG,
+                         float* dW1 /*[64,35]*/, float* db1, float* dWo /*[13,64]*/, float* dbo, ia_stream_t stream);
 
 /* split-K weight gradient on the matrix cores: dW[M,ldw] += G[:, :M]^T . A[:, :N], db[M] += column sums of G
  * (M <= 64, N <= 96; strides <= 64 / 96 floats; accumulates with atomics into caller-zeroed dW / db; db may be NULL) */

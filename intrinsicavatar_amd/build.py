@@ -25,6 +25,7 @@ SOURCES = {
     "hashgrid.hip": ["-munsafe-fp-atomics"],
     "mlp.hip": [],
     "mlp_bwd.hip": ["-munsafe-fp-atomics"],
+    "mlp_train.hip": ["-munsafe-fp-atomics"],
     "deform.hip": ["-ffp-contract=off"],
     "pbr.hip": [],
     "occgrid.hip": [],

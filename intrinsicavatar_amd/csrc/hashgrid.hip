@@ -290,8 +290,13 @@ __global__ __launch_bounds__(THREADS) void hash_bin_kernel(int64_t n, const floa
                                                             const float* __restrict__ gG, int gG_stride,
                                                             const float* __restrict__ q, int nwg,
                                                             int32_t* __restrict__ counts, uint16_t* __restrict__ rec_idx,
-                                                            float2* __restrict__ rec_val)
+                                                            float2* __restrict__ rec_val, uint32_t level_mask,
+                                                            unsigned* __restrict__ level_max)
 {
+    // Loop order: level-major over the workgroup's 1024 points (4 per lane), so that at any time a workgroup appends to
+    // the <= 64 runs of ONE level only (64 x 2 open cache lines instead of 771 x 2): the scattered 2- and 8-byte record
+    // stores then merge in L2 into full lines before they are evicted to HBM.  Gradient rows are fetched 4 levels at a
+    // time (one 32-byte piece per point and array), positions once.
     __shared__ int hist[MAX_BUCKETS];
     __shared__ int base[FILL ? MAX_BUCKETS : 1];
     const int lane = threadIdx.x & 63;
@@ -300,75 +305,104 @@ __global__ __launch_bounds__(THREADS) void hash_bin_kernel(int64_t n, const floa
         if (FILL) base[b] = counts[(int64_t)b * nwg + blockIdx.x];
     }
     __syncthreads();
+    float px[BIN_ROUNDS][3], pq[BIN_ROUNDS][3];
+    bool act[BIN_ROUNDS];
+    int64_t pi[BIN_ROUNDS];
+#pragma unroll
     for (int r = 0; r < BIN_ROUNDS; r++) {
         const int64_t i = (int64_t)blockIdx.x * BIN_TILE + r * THREADS + threadIdx.x;
-        const bool active = i < n;
-        const int64_t ii = active ? i : n - 1;
-        const float x0 = x[ii * 3 + 0], x1 = x[ii * 3 + 1], x2 = x[ii * 3 + 2];
-        float qx = 0.f, qy = 0.f, qz = 0.f;
-        if (SECOND && FILL) { qx = q[ii * 3 + 0]; qy = q[ii * 3 + 1]; qz = q[ii * 3 + 2]; }
-        for (int l = 0; l < cfg.n_levels; l++) {
+        act[r] = i < n;
+        pi[r] = act[r] ? i : n - 1;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            px[r][d] = x[pi[r] * 3 + d];
+            pq[r][d] = (SECOND && FILL) ? q[pi[r] * 3 + d] : 0.0f;
+        }
+    }
+    constexpr int LG = 4;                                     // levels per gradient fetch
+    for (int l0 = 0; l0 < cfg.n_levels; l0 += LG) {
+        float2 ev[BIN_ROUNDS][LG], gv[BIN_ROUNDS][LG];
+#pragma unroll
+        for (int r = 0; r < BIN_ROUNDS; r++)
+#pragma unroll
+            for (int j = 0; j < LG; j++) {
+                ev[r][j] = make_float2(0.f, 0.f);
+                gv[r][j] = make_float2(0.f, 0.f);
+                if (FILL && act[r] && l0 + j < cfg.n_levels && ((level_mask >> (l0 + j)) & 1u)) {
+                    if (gE) ev[r][j] = *reinterpret_cast<const float2*>(gE + pi[r] * gE_stride + (l0 + j) * 2);
+                    if (SECOND) gv[r][j] = *reinterpret_cast<const float2*>(gG + pi[r] * gG_stride + (l0 + j) * 2);
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < LG; j++) {
+            const int l = l0 + j;
+            if (l >= cfg.n_levels) break;
+            if (!((level_mask >> l) & 1u)) continue;              // level switched off by the caller (progressive bands)
+            float lmax = 0.0f;
             const float sc = cfg.scale[l];
             const uint32_t res = cfg.res[l], hsize = cfg.offsets[l + 1] - cfg.offsets[l];
-            float2 e = make_float2(0.f, 0.f), g = make_float2(0.f, 0.f);
-            if (active) {
-                if (gE) e = *reinterpret_cast<const float2*>(gE + i * gE_stride + l * 2);
-                if (SECOND) g = *reinterpret_cast<const float2*>(gG + i * gG_stride + l * 2);
-            }
-            const bool any_here = (e.x != 0.f) || (e.y != 0.f) || (g.x != 0.f) || (g.y != 0.f);
-            if (!__any(any_here)) continue;                       // masked-out level for the whole wave
-            float pos[3];
-            uint32_t pg[3];
-            {
-                const float xs[3] = {x0, x1, x2};
+            const int b0 = bins.bstart[l];
+#pragma unroll
+            for (int r = 0; r < BIN_ROUNDS; r++) {
+                const float2 e = ev[r][j], g = gv[r][j];
+                const bool active = act[r];
+                float pos[3];
+                uint32_t pg[3];
 #pragma unroll
                 for (int d = 0; d < 3; d++) {
-                    const float p = fmaf(sc, xs[d], 0.5f);
+                    const float p = fmaf(sc, px[r][d], 0.5f);
                     const float fl = floorf(p);
                     pg[d] = (uint32_t)(int)fl;
                     pos[d] = p - fl;
                 }
-            }
-            const int b0 = bins.bstart[l];
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
-                uint32_t idx = grid_index(hsize, res, pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1));
-                if (!active) idx = 0xFFFFFFFFu;
-                const uint32_t prev = __shfl_up(idx, 1, 64);
-                const bool head = (lane == 0) || (prev != idx);
-                const unsigned long long heads = __ballot(head);
-                const bool tail = (lane == 63) || ((heads >> (lane + 1)) & 1ull);
-                float vx = 0.f, vy = 0.f;
-                if (FILL) {
-                    const float wx = (c & 1) ? pos[0] : 1.0f - pos[0];
-                    const float wy = (c & 2) ? pos[1] : 1.0f - pos[1];
-                    const float wz = (c & 4) ? pos[2] : 1.0f - pos[2];
-                    const float w0 = wx * wy * wz;
-                    vx = e.x * w0; vy = e.y * w0;
-                    if (SECOND) {
-                        const float dw = ((c & 1) ? sc : -sc) * wy * wz * qx + ((c & 2) ? sc : -sc) * wx * wz * qy +
-                                         ((c & 4) ? sc : -sc) * wx * wy * qz;
-                        vx += g.x * dw;
-                        vy += g.y * dw;
-                    }
-                    if (!active) { vx = 0.f; vy = 0.f; }
-                    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
-                    const int hpos = 63 - __clzll(below);
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const float ax = __shfl_up(vx, off, 64), ay = __shfl_up(vy, off, 64);
-                        if (lane - off >= hpos) { vx += ax; vy += ay; }
-                    }
-                }
-                if (tail && active) {
-                    const int b = b0 + (int)(idx >> SLICE_LOG2);
-                    const int rank = atomicAdd(&hist[b], 1);
+                for (int c = 0; c < 8; c++) {
+                    uint32_t idx = grid_index(hsize, res, pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1));
+                    if (!active) idx = 0xFFFFFFFFu;
+                    const uint32_t prev = __shfl_up(idx, 1, 64);
+                    const bool head = (lane == 0) || (prev != idx);
+                    const unsigned long long heads = __ballot(head);
+                    const bool tail = (lane == 63) || ((heads >> (lane + 1)) & 1ull);
+                    float vx = 0.f, vy = 0.f;
                     if (FILL) {
-                        const int64_t p = (int64_t)base[b] + rank;
-                        rec_idx[p] = (uint16_t)(idx & (SLICE - 1));
-                        rec_val[p] = make_float2(vx, vy);
+                        const float wx = (c & 1) ? pos[0] : 1.0f - pos[0];
+                        const float wy = (c & 2) ? pos[1] : 1.0f - pos[1];
+                        const float wz = (c & 4) ? pos[2] : 1.0f - pos[2];
+                        const float w0 = wx * wy * wz;
+                        vx = e.x * w0; vy = e.y * w0;
+                        if (SECOND) {
+                            const float dw = ((c & 1) ? sc : -sc) * wy * wz * pq[r][0] + ((c & 2) ? sc : -sc) * wx * wz * pq[r][1] +
+                                             ((c & 4) ? sc : -sc) * wx * wy * pq[r][2];
+                            vx += g.x * dw;
+                            vy += g.y * dw;
+                        }
+                        if (!active) { vx = 0.f; vy = 0.f; }
+                        const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+                        const int hpos = 63 - __clzll(below);
+                        if (heads != ~0ull) {                           // wave-uniform: some run is longer than one lane
+#pragma unroll
+                            for (int off = 1; off < 64; off <<= 1) {
+                                const float ax = __shfl_up(vx, off, 64), ay = __shfl_up(vy, off, 64);
+                                if (lane - off >= hpos) { vx += ax; vy += ay; }
+                            }
+                        }
+                    }
+                    if (tail && active) {
+                        const int b = b0 + (int)(idx >> SLICE_LOG2);
+                        const int rank = atomicAdd(&hist[b], 1);
+                        if (FILL) {
+                            lmax = fmaxf(lmax, fmaxf(fabsf(vx), fabsf(vy)));
+                            const int64_t p = (int64_t)base[b] + rank;
+                            rec_idx[p] = (uint16_t)(idx & (SLICE - 1));
+                            rec_val[p] = make_float2(vx, vy);
+                        }
                     }
                 }
+            }
+            if (FILL) {                                           // per-level max |value| -> fixed-point scale of the reduction
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off, 64));
+                if (lane == 0 && lmax > 0.0f) atomicMax(level_max + l, __float_as_uint(lmax));
             }
         }
     }
@@ -378,96 +412,141 @@ __global__ __launch_bounds__(THREADS) void hash_bin_kernel(int64_t n, const floa
     }
 }
 
-__global__ __launch_bounds__(THREADS) void hash_reduce_kernel(HashCfg cfg, BinCfg bins, int nwg,
-                                                               const int32_t* __restrict__ scan,
-                                                               const int32_t* __restrict__ total,
-                                                               const uint16_t* __restrict__ rec_idx,
-                                                               const float2* __restrict__ rec_val, float* __restrict__ grad)
+// LDS accumulation in 64-bit FIXED POINT with integer atomics.  Measured on MI355X (tools/probes/lds_atomic_probe.hip):
+// ds_add_f32 retires 0.17 updates / clk / CU, ds_add_u64 5.6 -- the float LDS atomic is ~30x slower than the integer
+// one, and it alone made this kernel 6x slower than its HBM-read time.  Each level gets a power-of-two scale from the
+// largest |value| of its records (2^40 / 2^ceil(log2 max)): every record is converted with at most 2^-40 max relative
+// quantisation (exact for |v| >= 2^-16 max), the sums themselves are exact integer sums -- order independent, hence
+// bit-reproducible run to run, which the float atomics never were.
+constexpr int RTHREADS = 512;
+__device__ __forceinline__ void fx_add(unsigned long long* a, uint32_t i, float vx, float vy, float scale)
 {
-    __shared__ float2 acc[SLICE];
-    const int b = blockIdx.x % bins.n_buckets, part = blockIdx.x / bins.n_buckets;
+    atomicAdd(a + 2 * i, (unsigned long long)__float2ll_rn(vx * scale));
+    atomicAdd(a + 2 * i + 1, (unsigned long long)__float2ll_rn(vy * scale));
+}
+
+// work plan of the reduction: parts per bucket (buckets larger than PART_RECORDS are split), exclusive prefix in
+// plan[0 .. n_buckets], work-item counter in plan[n_buckets + 1].  One workgroup.
+__global__ __launch_bounds__(1024) void hash_plan_kernel(BinCfg bins, int nwg, const int32_t* __restrict__ scan,
+                                                          const int32_t* __restrict__ total, int32_t* __restrict__ plan)
+{
+    __shared__ int parts[MAX_BUCKETS];
+    const int b = threadIdx.x;
+    int np = 0;
+    if (b < bins.n_buckets) {
+        const int start = scan[(int64_t)b * nwg];
+        const int end = (b + 1 < bins.n_buckets) ? scan[(int64_t)(b + 1) * nwg] : *total;
+        const int cnt = end - start;
+        np = cnt <= 0 ? 0 : (cnt + PART_RECORDS - 1) / PART_RECORDS;
+        np = np > MAX_PARTS ? MAX_PARTS : np;
+    }
+    parts[b] = np;
+    __syncthreads();
+    if (b == 0) {
+        int run = 0;
+        for (int k = 0; k < bins.n_buckets; k++) { plan[k] = run; run += parts[k]; }
+        plan[bins.n_buckets] = run;
+        plan[bins.n_buckets + 1] = 0;
+    }
+}
+
+// persistent: one workgroup per CU pulls (bucket, part) items off the plan
+__global__ __launch_bounds__(RTHREADS) void hash_reduce_kernel(HashCfg cfg, BinCfg bins, int nwg,
+                                                                const int32_t* __restrict__ scan,
+                                                                const int32_t* __restrict__ total,
+                                                                const uint16_t* __restrict__ rec_idx,
+                                                                const float2* __restrict__ rec_val,
+                                                                const unsigned* __restrict__ level_max,
+                                                                int32_t* __restrict__ plan, float* __restrict__ grad)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];      // [SLICE][2]
+    __shared__ int s_item;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_item = atomicAdd(plan + bins.n_buckets + 1, 1);
+    __syncthreads();
+    const int item = s_item;
+    if (item >= plan[bins.n_buckets]) return;
+    int lo = 0, hi = bins.n_buckets;                                              // last bucket with plan[b] <= item
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (plan[mid] <= item) lo = mid; else hi = mid; }
+    const int b = lo, part = item - plan[lo];
     const int start = scan[(int64_t)b * nwg];
     const int end = (b + 1 < bins.n_buckets) ? scan[(int64_t)(b + 1) * nwg] : *total;
     const int cnt = end - start;
-    if (cnt <= 0) return;
     int nparts = (cnt + PART_RECORDS - 1) / PART_RECORDS;
     nparts = nparts > MAX_PARTS ? MAX_PARTS : nparts;
-    if (part >= nparts) return;
     const int per = (cnt + nparts - 1) / nparts;
     const int s = start + part * per;
     const int e = (s + per < end) ? s + per : end;
     int l = 0;
     while (b >= bins.bstart[l + 1]) l++;
+    const float lmax = __uint_as_float(level_max[l]);
+    if (!(lmax > 0.0f) || !(lmax < 3.0e38f)) continue;          // all-zero level (or non-finite gradients: nothing sane to add)
+    int ex;
+    (void)frexpf(lmax, &ex);                                    // lmax < 2^ex
+    const float scale = ldexpf(1.0f, 40 - ex), inv_scale = ldexpf(1.0f, ex - 40);
     const int slice = b - bins.bstart[l];
     const uint32_t hsize = cfg.offsets[l + 1] - cfg.offsets[l];
     const int first = slice << SLICE_LOG2;
     const int entries = ((int)hsize - first < SLICE) ? (int)hsize - first : SLICE;
-    for (int k = threadIdx.x; k < entries; k += THREADS) acc[k] = make_float2(0.f, 0.f);
+    for (int k = threadIdx.x; k < 2 * entries; k += RTHREADS) acc[k] = 0ull;
     __syncthreads();
-    float* a = reinterpret_cast<float*>(acc);
     // head up to the first multiple of 4, then 4 consecutive records per lane (8-byte index load, 2 x 16-byte value
     // loads), two groups in flight per lane; tail one by one.
     const int s4 = (s + 3) & ~3, e4 = e & ~3;
     if (s4 >= e4) {
-        for (int j = s + threadIdx.x; j < e; j += THREADS) {
-            const uint32_t i0 = rec_idx[j];
+        for (int j = s + threadIdx.x; j < e; j += RTHREADS) {
             const float2 v0 = rec_val[j];
-            unsafeAtomicAdd(a + 2 * i0, v0.x); unsafeAtomicAdd(a + 2 * i0 + 1, v0.y);
+            fx_add(acc, rec_idx[j], v0.x, v0.y, scale);
         }
     } else {
         if ((int)threadIdx.x < s4 - s) {
             const int j = s + threadIdx.x;
-            const uint32_t i0 = rec_idx[j];
             const float2 v0 = rec_val[j];
-            unsafeAtomicAdd(a + 2 * i0, v0.x); unsafeAtomicAdd(a + 2 * i0 + 1, v0.y);
+            fx_add(acc, rec_idx[j], v0.x, v0.y, scale);
         }
         if ((int)threadIdx.x < e - e4) {
             const int j = e4 + threadIdx.x;
-            const uint32_t i0 = rec_idx[j];
             const float2 v0 = rec_val[j];
-            unsafeAtomicAdd(a + 2 * i0, v0.x); unsafeAtomicAdd(a + 2 * i0 + 1, v0.y);
+            fx_add(acc, rec_idx[j], v0.x, v0.y, scale);
         }
         const ushort4* ri = reinterpret_cast<const ushort4*>(rec_idx);
         const float4* rv = reinterpret_cast<const float4*>(rec_val);
         const int g0 = s4 >> 2, g1 = e4 >> 2;
         int gq = g0 + threadIdx.x;
-        for (; gq + THREADS < g1; gq += 2 * THREADS) {
-            const ushort4 ia = ri[gq], ib = ri[gq + THREADS];
+        for (; gq + RTHREADS < g1; gq += 2 * RTHREADS) {
+            const ushort4 ia = ri[gq], ib = ri[gq + RTHREADS];
             const float4 a0 = rv[2 * gq], a1 = rv[2 * gq + 1];
-            const float4 b0 = rv[2 * (gq + THREADS)], b1 = rv[2 * (gq + THREADS) + 1];
-            unsafeAtomicAdd(a + 2 * ia.x, a0.x); unsafeAtomicAdd(a + 2 * ia.x + 1, a0.y);
-            unsafeAtomicAdd(a + 2 * ia.y, a0.z); unsafeAtomicAdd(a + 2 * ia.y + 1, a0.w);
-            unsafeAtomicAdd(a + 2 * ia.z, a1.x); unsafeAtomicAdd(a + 2 * ia.z + 1, a1.y);
-            unsafeAtomicAdd(a + 2 * ia.w, a1.z); unsafeAtomicAdd(a + 2 * ia.w + 1, a1.w);
-            unsafeAtomicAdd(a + 2 * ib.x, b0.x); unsafeAtomicAdd(a + 2 * ib.x + 1, b0.y);
-            unsafeAtomicAdd(a + 2 * ib.y, b0.z); unsafeAtomicAdd(a + 2 * ib.y + 1, b0.w);
-            unsafeAtomicAdd(a + 2 * ib.z, b1.x); unsafeAtomicAdd(a + 2 * ib.z + 1, b1.y);
-            unsafeAtomicAdd(a + 2 * ib.w, b1.z); unsafeAtomicAdd(a + 2 * ib.w + 1, b1.w);
+            const float4 b0 = rv[2 * (gq + RTHREADS)], b1 = rv[2 * (gq + RTHREADS) + 1];
+            fx_add(acc, ia.x, a0.x, a0.y, scale); fx_add(acc, ia.y, a0.z, a0.w, scale);
+            fx_add(acc, ia.z, a1.x, a1.y, scale); fx_add(acc, ia.w, a1.z, a1.w, scale);
+            fx_add(acc, ib.x, b0.x, b0.y, scale); fx_add(acc, ib.y, b0.z, b0.w, scale);
+            fx_add(acc, ib.z, b1.x, b1.y, scale); fx_add(acc, ib.w, b1.z, b1.w, scale);
         }
-        for (; gq < g1; gq += THREADS) {
+        for (; gq < g1; gq += RTHREADS) {
             const ushort4 ia = ri[gq];
             const float4 a0 = rv[2 * gq], a1 = rv[2 * gq + 1];
-            unsafeAtomicAdd(a + 2 * ia.x, a0.x); unsafeAtomicAdd(a + 2 * ia.x + 1, a0.y);
-            unsafeAtomicAdd(a + 2 * ia.y, a0.z); unsafeAtomicAdd(a + 2 * ia.y + 1, a0.w);
-            unsafeAtomicAdd(a + 2 * ia.z, a1.x); unsafeAtomicAdd(a + 2 * ia.z + 1, a1.y);
-            unsafeAtomicAdd(a + 2 * ia.w, a1.z); unsafeAtomicAdd(a + 2 * ia.w + 1, a1.w);
+            fx_add(acc, ia.x, a0.x, a0.y, scale); fx_add(acc, ia.y, a0.z, a0.w, scale);
+            fx_add(acc, ia.z, a1.x, a1.y, scale); fx_add(acc, ia.w, a1.z, a1.w, scale);
         }
     }
     __syncthreads();
     float* tab = grad + ((int64_t)cfg.offsets[l] + first) * 2;
-    for (int k = threadIdx.x; k < entries; k += THREADS) {
-        const float2 v = acc[k];
-        if (v.x == 0.f && v.y == 0.f) continue;
+    for (int k = threadIdx.x; k < entries; k += RTHREADS) {
+        const long long ix = (long long)acc[2 * k], iy = (long long)acc[2 * k + 1];
+        if (ix == 0 && iy == 0) continue;
+        const float vx = (float)ix * inv_scale, vy = (float)iy * inv_scale;
         if (nparts == 1) {
             float2* t = reinterpret_cast<float2*>(tab) + k;
             float2 o = *t;
-            o.x += v.x; o.y += v.y;
+            o.x += vx; o.y += vy;
             *t = o;
         } else {
-            unsafeAtomicAdd(tab + 2 * k, v.x);
-            unsafeAtomicAdd(tab + 2 * k + 1, v.y);
+            unsafeAtomicAdd(tab + 2 * k, vx);
+            unsafeAtomicAdd(tab + 2 * k + 1, vy);
         }
     }
+  }
 }
 
 __global__ __launch_bounds__(THREADS) void sh4_kernel(int64_t n, const float* __restrict__ d01, float* __restrict__ out,
@@ -639,7 +718,7 @@ BinLayout bin_layout(int64_t n, int n_levels, int n_buckets)
     auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
     L.off_counts = 0;
     L.off_total = up(L.m * 4);
-    L.off_tmp = L.off_total + 256;
+    L.off_tmp = L.off_total + 512 + 4 * (MAX_BUCKETS + 64);      // total (4 B), level_max[32] at +256, plan at +512
     L.off_val = up(L.off_tmp + ia_scan_tmp_bytes(L.m));
     L.off_idx = up(L.off_val + L.records * 8);
     L.bytes = up(L.off_idx + L.records * 2);
@@ -662,7 +741,7 @@ IA_EXPORT int64_t ia_hashgrid_bwd_scratch_bytes(int64_t n, int n_levels, int log
 IA_EXPORT int ia_hashgrid_bwd_binned(int64_t n, const float* x, int n_levels, int n_features, int log2_hashmap_size,
                                      int base_resolution, float per_level_scale, const float* g_enc, int g_enc_stride,
                                      const float* g_jac, int g_jac_stride, const float* q, float* grad_params,
-                                     void* scratch, int64_t scratch_bytes, ia_stream_t stream)
+                                     uint32_t level_mask, void* scratch, int64_t scratch_bytes, ia_stream_t stream)
 {
     if (n == 0) return IA_OK;
     IA_REQUIRE(n_features == 2, "n_features_per_level must be 2 on this path");
@@ -684,13 +763,24 @@ IA_EXPORT int ia_hashgrid_bwd_binned(int64_t n, const float* x, int n_levels, in
     float2* rec_val = (float2*)(base + L.off_val);
     uint16_t* rec_idx = (uint16_t*)(base + L.off_idx);
     hipStream_t s = (hipStream_t)stream;
-    if (g_jac) hash_bin_kernel<true, false><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, g_jac, g_jac_stride, q, L.nwg, counts, rec_idx, rec_val);
-    else hash_bin_kernel<false, false><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, nullptr, 0, nullptr, L.nwg, counts, rec_idx, rec_val);
+    unsigned* level_max = (unsigned*)(base + L.off_total + 256);
+    if (hipMemsetAsync(level_max, 0, MAX_LEVELS * sizeof(unsigned), s) != hipSuccess) return ia::check_launch("ia_hashgrid_bwd_binned(memset)");
+    if (g_jac) hash_bin_kernel<true, false><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, g_jac, g_jac_stride, q, L.nwg, counts, rec_idx, rec_val, level_mask, level_max);
+    else hash_bin_kernel<false, false><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, nullptr, 0, nullptr, L.nwg, counts, rec_idx, rec_val, level_mask, level_max);
     int r = ia_exclusive_scan_i32(counts, counts, total, L.m, tmp, stream);
     if (r != IA_OK) return r;
-    if (g_jac) hash_bin_kernel<true, true><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, g_jac, g_jac_stride, q, L.nwg, counts, rec_idx, rec_val);
-    else hash_bin_kernel<false, true><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, nullptr, 0, nullptr, L.nwg, counts, rec_idx, rec_val);
-    hash_reduce_kernel<<<b.n_buckets * MAX_PARTS, THREADS, 0, s>>>(c, b, L.nwg, counts, total, rec_idx, rec_val, grad_params);
+    if (g_jac) hash_bin_kernel<true, true><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, g_jac, g_jac_stride, q, L.nwg, counts, rec_idx, rec_val, level_mask, level_max);
+    else hash_bin_kernel<false, true><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, nullptr, 0, nullptr, L.nwg, counts, rec_idx, rec_val, level_mask, level_max);
+    static bool attr = false;
+    constexpr size_t red_lds = (size_t)SLICE * 2 * sizeof(unsigned long long);      // 128 KB
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)hash_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)red_lds);
+        (void)hipGetLastError();
+        attr = true;
+    }
+    int32_t* plan = (int32_t*)(base + L.off_total + 512);
+    hash_plan_kernel<<<1, 1024, 0, s>>>(b, L.nwg, counts, total, plan);
+    hash_reduce_kernel<<<256, RTHREADS, red_lds, s>>>(c, b, L.nwg, counts, total, rec_idx, rec_val, level_max, plan, grad_params);
     return ia::check_launch("ia_hashgrid_bwd_binned");
 }
 

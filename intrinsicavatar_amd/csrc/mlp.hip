@@ -7,11 +7,14 @@
 // torch.autograd.grad(create_graph=True) (rf/geometry.py:165-172).
 //
 // Design
-//   * one wave owns a tile of 64 points; its activations never leave LDS between layers;
+//   * one wave owns a tile of 32 points; its activations never leave LDS between layers.  Small tiles on purpose:
+//     a 32 x 69 float tile is 8.8 KB, so 12 waves (3 per SIMD) fit next to the weights in one CU's LDS and the
+//     global-load latency of one wave's input assembly hides behind the MFMA chains of the other two
+//     (the 64-point / 1-wave-per-SIMD version of this kernel sat at ~20 % of the MFMA-bound time);
 //   * the input row is ASSEMBLED in LDS from up to 5 source segments (hash features, xyz, geometry
 //     feature, SH, normal ...) so the concatenated [n, 67] tensor is never materialised in HBM;
-//   * hidden layers (N = 64): v_mfma_f32_32x32x2_f32, 2x2 tiles of 32x32 per wave;
-//     output layer (N <= 16): v_mfma_f32_16x16x4_f32 (4 tiles of 16 points);
+//   * hidden layers (N = 64): v_mfma_f32_32x32x2_f32, 1x2 tiles of 32x32 per wave;
+//     output layer (N <= 16): v_mfma_f32_16x16x4_f32 (2 tiles of 16 points);
 //     fp32 MFMA is bit-equal to an fmaf chain, so parity mode needs no reduced precision;
 //   * weights (effective: weight-norm / Lipschitz scaling / level masks folded in on the host) are
 //     staged once per workgroup in LDS, rows padded to an odd stride => conflict-free ds_read_b32
@@ -28,7 +31,8 @@ using mlp::MAX_SEGS;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int THREADS = 256;            // 4 waves, one 64-point tile each per iteration
+constexpr int TM = 32;                  // points per wave tile
+constexpr int MT = TM / 32;
 constexpr int HID = 64;
 struct MlpArgs {
     int64_t n;
@@ -51,9 +55,10 @@ __device__ __forceinline__ float act_hidden(float v, int hact)
     return bx > 20.0f ? v : log1pf(__expf(bx)) * 0.01f;
 }
 
-template <int KIND, int IN, int NHID, int OUT, int HACT, int OACT, bool SDF_GRAD>
-__global__ __launch_bounds__(THREADS) void mlp_fwd_kernel(MlpArgs a)
+template <int KIND, int IN, int NHID, int OUT, int HACT, int OACT, bool SDF_GRAD, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void mlp_fwd_kernel(MlpArgs a)
 {
+    constexpr int THREADS = WAVES * 64;
     constexpr int IN_PAD = (IN + 1) / 2 * 2;
     constexpr int LDW1 = IN_PAD + 1;
     constexpr int LDW = HID + 1;
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_kernel(MlpArgs a)
     float* sB = sWo + 16 * LDW;                          // b1[64] b2[64] bo[16]
     float* sXall = sB + 64 + 64 + 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* sX = sXall + wave * 64 * LDX;                 // this wave's [64][LDX] tile
+    float* sX = sXall + wave * TM * LDX;                 // this wave's [TM][LDX] tile
     float* sG = sX;                                      // SDF_GRAD: reused for g_z / g_h
 
     // ---- stage weights (zero padded) ----
@@ -86,17 +91,17 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_kernel(MlpArgs a)
     if (tid < 16) sB[128 + tid] = (tid < OUT) ? a.bo[tid] : 0.0f;
     __syncthreads();
 
-    const int64_t n_tiles = (a.n + 63) / 64;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
-        const int64_t p0 = tile * 64;
+    const int64_t n_tiles = (a.n + TM - 1) / TM;
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WAVES) {
+        const int64_t p0 = tile * TM;
         // ---- assemble the input rows in LDS ----
-        mlp::assemble<KIND, IN>(sX, LDX, a.segs, p0, a.n, lane);
+        mlp::assemble<KIND, IN, TM>(sX, LDX, a.segs, p0, a.n, lane);
 
         const int lr = lane & 31, lk = lane >> 5;
         // ---- layer 1: [64 x IN_PAD] x W1^T -> [64 x 64] ----
-        f32x16 acc[2][2];
+        f32x16 acc[MT][2];
 #pragma unroll
-        for (int m = 0; m < 2; m++)
+        for (int m = 0; m < MT; m++)
 #pragma unroll
             for (int nt = 0; nt < 2; nt++)
 #pragma unroll
@@ -104,18 +109,19 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_kernel(MlpArgs a)
 #pragma unroll 2
         for (int kk = 0; kk < IN_PAD / 2; kk++) {
             const int k = 2 * kk + lk;
-            const float a0 = sX[lr * LDX + k], a1 = sX[(32 + lr) * LDX + k];
             const float b0 = sW1[lr * LDW1 + k], b1v = sW1[(32 + lr) * LDW1 + k];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1v, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1v, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const float av = sX[(32 * m + lr) * LDX + k];
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1v, acc[m][1], 0, 0, 0);
+            }
         }
         // epilogue: bias + activation -> sX (in place: all reads of the old tile are complete)
         // SDF_GRAD keeps z in registers to form softplus'(z) later
-        float sig[2][2][16];
+        float sig[MT][2][16];
 #pragma unroll
-        for (int m = 0; m < 2; m++)
+        for (int m = 0; m < MT; m++)
 #pragma unroll
             for (int nt = 0; nt < 2; nt++)
 #pragma unroll
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_kernel(MlpArgs a)
         // ---- layer 2 (optional) ----
         if (NHID == 2) {
 #pragma unroll
-            for (int m = 0; m < 2; m++)
+            for (int m = 0; m < MT; m++)
 #pragma unroll
                 for (int nt = 0; nt < 2; nt++)
 #pragma unroll
@@ -141,15 +147,16 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_kernel(MlpArgs a)
 #pragma unroll 2
             for (int kk = 0; kk < HID / 2; kk++) {
                 const int k = 2 * kk + lk;
-                const float a0 = sX[lr * LDX + k], a1 = sX[(32 + lr) * LDX + k];
                 const float b0 = sW2[lr * LDW + k], b1v = sW2[(32 + lr) * LDW + k];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1v, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1v, acc[1][1], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; m++) {
+                    const float av = sX[(32 * m + lr) * LDX + k];
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1v, acc[m][1], 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (int m = 0; m < 2; m++)
+            for (int m = 0; m < MT; m++)
 #pragma unroll
                 for (int nt = 0; nt < 2; nt++)
 #pragma unroll
@@ -161,9 +168,10 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_kernel(MlpArgs a)
         // ---- output layer: [64 x 64] x Wo^T -> [64 x 16] with 16x16x4 tiles ----
         {
             const int l15 = lane & 15, l4 = lane >> 4;
-            f32x4 o[4];
+            constexpr int OT = TM / 16;
+            f32x4 o[OT];
 #pragma unroll
-            for (int m = 0; m < 4; m++)
+            for (int m = 0; m < OT; m++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) o[m][r] = 0.0f;
 #pragma unroll 4
@@ -171,13 +179,13 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_kernel(MlpArgs a)
                 const int k = 4 * kk + l4;
                 const float b = sWo[l15 * LDW + k];
 #pragma unroll
-                for (int m = 0; m < 4; m++)
+                for (int m = 0; m < OT; m++)
                     o[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(sX[(16 * m + l15) * LDX + k], b, o[m], 0, 0, 0);
             }
             if (l15 < OUT) {
                 const float bias = sB[128 + l15];
 #pragma unroll
-                for (int m = 0; m < 4; m++)
+                for (int m = 0; m < OT; m++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int64_t p = p0 + 16 * m + l4 * 4 + r;
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_kernel(MlpArgs a)
         if (SDF_GRAD) {
             // g_z[p][o] = softplus'(z[p][o]) * Wo[0][o]  -> sG (over the hidden activations, now dead)
 #pragma unroll
-            for (int m = 0; m < 2; m++)
+            for (int m = 0; m < MT; m++)
 #pragma unroll
                 for (int nt = 0; nt < 2; nt++)
 #pragma unroll
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_kernel(MlpArgs a)
                     }
             // g_h = g_z W1 : A = g_z [64 pts x 64], B[k][j] = W1[k][j], j < IN_PAD (<= 64)
 #pragma unroll
-            for (int m = 0; m < 2; m++)
+            for (int m = 0; m < MT; m++)
 #pragma unroll
                 for (int nt = 0; nt < 2; nt++)
 #pragma unroll
@@ -209,16 +217,17 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_kernel(MlpArgs a)
 #pragma unroll 2
             for (int kk = 0; kk < HID / 2; kk++) {
                 const int k = 2 * kk + lk;
-                const float a0 = sG[lr * LDX + k], a1 = sG[(32 + lr) * LDX + k];
                 const float b0 = (lr < IN_PAD) ? sW1[k * LDW1 + lr] : 0.0f;
                 const float b1v = (32 + lr < IN_PAD) ? sW1[k * LDW1 + 32 + lr] : 0.0f;
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1v, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1v, acc[1][1], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; m++) {
+                    const float av = sG[(32 * m + lr) * LDX + k];
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1v, acc[m][1], 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (int m = 0; m < 2; m++)
+            for (int m = 0; m < MT; m++)
 #pragma unroll
                 for (int nt = 0; nt < 2; nt++)
 #pragma unroll
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_kernel(MlpArgs a)
                     }
             // per-point epilogue (lane = point): grad_a = (2 g_h[xyz_a] + sum_k g_h[k] J[k][a]) * inv_scale_a
             const int64_t p = p0 + lane;
-            if (p < a.n) {
+            if (lane < TM && p < a.n) {
                 const float* gh = sG + lane * LDX;
                 const float* J = a.jac + p * 96;
                 float g0 = 2.0f * gh[a.xyz_col + 0], g1 = 2.0f * gh[a.xyz_col + 1], g2 = 2.0f * gh[a.xyz_col + 2];
@@ -250,22 +259,21 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_kernel(MlpArgs a)
 template <int KIND, int IN, int NHID, int OUT, int HACT, int OACT, bool SDF_GRAD>
 int launch_fwd(const MlpArgs& a, hipStream_t s)
 {
+    constexpr int WAVES = 12;                 // 3 waves per SIMD, one workgroup per CU
     constexpr int IN_PAD = (IN + 1) / 2 * 2;
     constexpr int LDW1 = IN_PAD + 1, LDW = HID + 1, LDX = (IN_PAD > HID ? IN_PAD : HID) + 1;
-    constexpr size_t lds = sizeof(float) * (HID * LDW1 + (NHID == 2 ? HID * LDW : 0) + 16 * LDW + 144 + 4 * 64 * LDX);
+    constexpr size_t lds = sizeof(float) * (HID * LDW1 + (NHID == 2 ? HID * LDW : 0) + 16 * LDW + 144 + WAVES * TM * LDX);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = mlp_fwd_kernel<KIND, IN, NHID, OUT, HACT, OACT, SDF_GRAD>;
+    auto kern = mlp_fwd_kernel<KIND, IN, NHID, OUT, HACT, OACT, SDF_GRAD, WAVES>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    const int64_t n_tiles = (a.n + 63) / 64;
-    const int blocks_per_cu = (int)((160 * 1024) / lds) > 2 ? 2 : (int)((160 * 1024) / lds);
-    int grid = (int)((n_tiles + 3) / 4);
-    const int cap = 256 * (blocks_per_cu > 0 ? blocks_per_cu : 1);
-    if (grid > cap) grid = cap;
-    kern<<<grid, THREADS, lds, s>>>(a);
+    const int64_t n_tiles = (a.n + TM - 1) / TM;
+    int grid = (int)((n_tiles + WAVES - 1) / WAVES);
+    if (grid > 256) grid = 256;               // persistent: one workgroup per CU, tiles strided over the grid
+    kern<<<grid, WAVES * 64, lds, s>>>(a);
     return ia::check_launch("ia_mlp_fwd");
 }
 

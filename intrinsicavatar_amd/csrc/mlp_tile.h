@@ -20,7 +20,7 @@ template <> struct SegWidths<0> { static constexpr int n = 2; static constexpr i
 template <> struct SegWidths<1> { static constexpr int n = 5; static constexpr int w[MAX_SEGS] = {32, 3, 13, 16, 3}; };
 template <> struct SegWidths<2> { static constexpr int n = 3; static constexpr int w[MAX_SEGS] = {32, 3, 13, 0, 0}; };
 
-template <int WIDTH>
+template <int WIDTH, int ROWS = 64>
 __device__ __forceinline__ void load_segment(float* sT, int ldx, int col0, const Seg& sg, int64_t p0, int64_t n, int lane)
 {
     if constexpr (WIDTH == 0) return;
@@ -30,10 +30,11 @@ __device__ __forceinline__ void load_segment(float* sT, int ldx, int col0, const
         if (vec_ok) {
             constexpr int V = WIDTH / 4;
 #pragma unroll
-            for (int i0 = 0; i0 < 64 * V; i0 += 64) {
+            for (int i0 = 0; i0 < ROWS * V; i0 += 64) {
                 const int i = i0 + lane;
                 const int r = i / V, c4 = i % V;
                 const int64_t p = p0 + r;
+                if ((ROWS * V) % 64 != 0 && i >= ROWS * V) break;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (p < n) v = *reinterpret_cast<const float4*>(sg.p + p * sg.stride + c4 * 4);
                 float* d = sT + r * ldx + col0 + c4 * 4;
@@ -44,25 +45,26 @@ __device__ __forceinline__ void load_segment(float* sT, int ldx, int col0, const
         }
     }
 #pragma unroll
-    for (int i0 = 0; i0 < 64 * WIDTH; i0 += 64) {
+    for (int i0 = 0; i0 < ROWS * WIDTH; i0 += 64) {
         const int i = i0 + lane;
         const int r = i / WIDTH, c = i % WIDTH;
         const int64_t p = p0 + r;
+        if ((ROWS * WIDTH) % 64 != 0 && i >= ROWS * WIDTH) break;
         sT[r * ldx + col0 + c] = (p < n) ? sg.p[p * sg.stride + c] * sg.mul + sg.add : 0.0f;
     }
 }
 
-template <int KIND, int IN>
+template <int KIND, int IN, int ROWS = 64>
 __device__ __forceinline__ void assemble(float* sT, int ldx, const Seg* segs, int64_t p0, int64_t n, int lane)
 {
     using SW = SegWidths<KIND>;
     constexpr int IN_PAD = (IN + 1) / 2 * 2;
-    load_segment<SW::w[0]>(sT, ldx, 0, segs[0], p0, n, lane);
-    load_segment<SW::w[1]>(sT, ldx, SW::w[0], segs[1], p0, n, lane);
-    load_segment<SW::w[2]>(sT, ldx, SW::w[0] + SW::w[1], segs[2], p0, n, lane);
-    load_segment<SW::w[3]>(sT, ldx, SW::w[0] + SW::w[1] + SW::w[2], segs[3], p0, n, lane);
-    load_segment<SW::w[4]>(sT, ldx, SW::w[0] + SW::w[1] + SW::w[2] + SW::w[3], segs[4], p0, n, lane);
-    if (IN_PAD > IN) sT[lane * ldx + IN] = 0.0f;
+    load_segment<SW::w[0], ROWS>(sT, ldx, 0, segs[0], p0, n, lane);
+    load_segment<SW::w[1], ROWS>(sT, ldx, SW::w[0], segs[1], p0, n, lane);
+    load_segment<SW::w[2], ROWS>(sT, ldx, SW::w[0] + SW::w[1], segs[2], p0, n, lane);
+    load_segment<SW::w[3], ROWS>(sT, ldx, SW::w[0] + SW::w[1] + SW::w[2], segs[3], p0, n, lane);
+    load_segment<SW::w[4], ROWS>(sT, ldx, SW::w[0] + SW::w[1] + SW::w[2] + SW::w[3], segs[4], p0, n, lane);
+    if (IN_PAD > IN && lane < ROWS) sT[lane * ldx + IN] = 0.0f;
 }
 
 inline int fill_segs(Seg* segs, int kind, int n_segs, const float* const* seg_ptr, const int* seg_stride,

@@ -54,7 +54,8 @@ HASH_BWD_CHUNK = 1 << 23             # points per binned call (scratch ~1.3 KB /
 
 
 def hashgrid_backward(x01: Tensor, g_enc: Optional[Tensor], grad_params: Tensor, cfg=HASH,
-                      g_jac: Optional[Tensor] = None, q: Optional[Tensor] = None, method: Optional[str] = None):
+                      g_jac: Optional[Tensor] = None, q: Optional[Tensor] = None, method: Optional[str] = None,
+                      level_mask: int = 0xFFFFFFFF):
     """accumulate d L / d table into grad_params (see include/ia_amd.h ia_hashgrid_bwd / ia_hashgrid_bwd_binned).
     method: None (by batch size; env IA_HASH_BWD overrides) | 'atomic' | 'binned'."""
     n = x01.shape[0]
@@ -76,7 +77,8 @@ def hashgrid_backward(x01: Tensor, g_enc: Optional[Tensor], grad_params: Tensor,
         ge, gj = sl(g_enc), sl(g_jac)
         L.check(L.lib().ia_hashgrid_bwd_binned(
             L.i64(m), L.ptr(sl(x01)), *cargs, L.ptr(ge), L.i32(ge.stride(0) if ge is not None else 0), L.ptr(gj),
-            L.i32(gj.stride(0) if gj is not None else 0), L.ptr(sl(q)), L.ptr(grad_params), L.ptr(scratch), L.i64(nb),
+            L.i32(gj.stride(0) if gj is not None else 0), L.ptr(sl(q)), L.ptr(grad_params), C.c_uint32(level_mask & 0xFFFFFFFF),
+            L.ptr(scratch), L.i64(nb),
             L.stream()), "ia_hashgrid_bwd_binned")
 
 

@@ -17,6 +17,7 @@ weight-gradient reductions dW = G^T A ([64 x n] x [n x <=68]) use the split-K MF
 shape to a single output tile walking K = millions of points).
 """
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
@@ -25,6 +26,10 @@ from torch.autograd import Function
 
 from . import _lib as L
 from . import fields, lib_nerfacc, nerfacc, render
+
+
+# fused data + weight backward (csrc/mlp_train.hip); False = operand pairs through HBM + ia_wgrad (csrc/mlp_bwd.hip)
+FUSED_WGRAD = os.environ.get("IA_FUSED_WGRAD", "1") != "0"
 
 
 def wgrad(G: Tensor, M: int, A: Tensor, N: int, want_bias: bool = True):
@@ -70,14 +75,23 @@ class _SDFField(Function):
         g_y = g_y.contiguous().float()
         q = (g_grad / scale).contiguous().float()
         gE, gG = torch.empty((n, 32), device=dev), torch.empty((n, 32), device=dev)
+        ns, ptrs, strides, widths, muls, adds = _segs([(enc, 32, 1.0, 0.0), (xp, 3, 2.0, -1.0)])
+        g_table = torch.zeros_like(table)
+        if FUSED_WGRAD:
+            dW1k, db1 = torch.zeros((64, 35), device=dev), torch.zeros(64, device=dev)
+            dW2, db2 = torch.zeros((13, 64), device=dev), torch.zeros(13, device=dev)
+            L.check(L.lib().ia_sdf_mlp_bwd_fused(L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds, L.ptr(W1k), L.ptr(b1),
+                                                 L.ptr(W2), L.ptr(b2), L.ptr(jac), L.ptr(g_y), L.ptr(q), L.ptr(gE), L.ptr(gG),
+                                                 L.ptr(dW1k), L.ptr(db1), L.ptr(dW2), L.ptr(db2), L.stream()),
+                    "ia_sdf_mlp_bwd_fused")
+            fields.hashgrid_backward(xp, gE, g_table, g_jac=gG, q=q)
+            return None, g_table, dW1k, db1, dW2, db2, None, None
         Hh, U = torch.empty((n, 36), device=dev), torch.empty((n, 36), device=dev)
         DZ, GZ, A, DGS = (torch.empty((n, 64), device=dev) for _ in range(4))
-        ns, ptrs, strides, widths, muls, adds = _segs([(enc, 32, 1.0, 0.0), (xp, 3, 2.0, -1.0)])
         L.check(L.lib().ia_sdf_mlp_bwd(L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds, L.ptr(W1k), L.ptr(b1),
                                        L.ptr(W2), L.ptr(b2), L.ptr(jac), L.ptr(g_y), L.ptr(q), L.ptr(gE), L.ptr(gG),
                                        L.ptr(Hh), L.ptr(U), L.ptr(DZ), L.ptr(GZ), L.ptr(A), L.ptr(DGS), L.stream()),
                 "ia_sdf_mlp_bwd")
-        g_table = torch.zeros_like(table)
         fields.hashgrid_backward(xp, gE, g_table, g_jac=gG, q=q)
         dW1k, db1 = wgrad(DZ, 64, Hh, 35)
         dW1k = dW1k + wgrad(GZ, 64, U, 35, want_bias=False)[0]
@@ -148,14 +162,26 @@ class _Radiance(Function):
         n, dev = xp.shape[0], xp.device
         g_rgb = g_rgb.contiguous().float()
         g_x = torch.empty((n, 68), device=dev)
-        X = torch.empty((n, 68), device=dev)
-        A1, A2, G1, G2 = (torch.empty((n, 64), device=dev) for _ in range(4))
-        G3 = torch.empty((n, 16), device=dev)
         segs = [(enc, 32, 1.0, 0.0), (xp, 3, 2.0, -1.0), (feat, 13, 1.0, 0.0), (sh, 16, 1.0, 0.0), (normal_world, 3, 1.0, 0.0)]
         ns, ptrs, strides, widths, muls, adds = _segs(segs)
-        L.check(L.lib().ia_mlp_bwd(L.i32(1), L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds, L.ptr(W1k), L.ptr(b1),
-                                   L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3), L.ptr(g_rgb), L.ptr(g_x), L.i32(68),
-                                   L.ptr(X), L.ptr(A1), L.ptr(A2), L.ptr(G1), L.ptr(G2), L.ptr(G3), L.stream()), "ia_mlp_bwd")
+        if FUSED_WGRAD:
+            dW1, db1 = torch.zeros((64, 67), device=dev), torch.zeros(64, device=dev)
+            dW2, db2 = torch.zeros((64, 64), device=dev), torch.zeros(64, device=dev)
+            dW3, db3 = torch.zeros((3, 64), device=dev), torch.zeros(3, device=dev)
+            L.check(L.lib().ia_mlp_bwd_fused(L.i32(1), L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds, L.ptr(W1k),
+                                             L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3), L.ptr(g_rgb), L.ptr(g_x),
+                                             L.i32(68), L.ptr(dW1), L.ptr(db1), L.ptr(dW2), L.ptr(db2), L.ptr(dW3), L.ptr(db3),
+                                             L.stream()), "ia_mlp_bwd_fused")
+        else:
+            X = torch.empty((n, 68), device=dev)
+            A1, A2, G1, G2 = (torch.empty((n, 64), device=dev) for _ in range(4))
+            G3 = torch.empty((n, 16), device=dev)
+            L.check(L.lib().ia_mlp_bwd(L.i32(1), L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds, L.ptr(W1k), L.ptr(b1),
+                                       L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3), L.ptr(g_rgb), L.ptr(g_x), L.i32(68),
+                                       L.ptr(X), L.ptr(A1), L.ptr(A2), L.ptr(G1), L.ptr(G2), L.ptr(G3), L.stream()), "ia_mlp_bwd")
+            dW1, db1 = wgrad(G1, 64, X, 67)
+            dW2, db2 = wgrad(G2, 64, A1, 64)
+            dW3, db3 = wgrad(G3, 3, A2, 64)
         g_table = torch.zeros_like(table)
         fields.hashgrid_backward(xp, g_x, g_table)                      # columns 0..31, row stride 68
         g_feat = g_x[:, 35:48]
@@ -164,9 +190,6 @@ class _Radiance(Function):
         g_refl01 = torch.empty((n, 3), device=dev)
         L.check(L.lib().ia_sh4_bwd(L.i64(n), L.ptr(refl01), C.c_void_p(g_sh.data_ptr()), L.i32(68), L.ptr(g_refl01),
                                    L.stream()), "ia_sh4_bwd")
-        dW1, db1 = wgrad(G1, 64, X, 67)
-        dW2, db2 = wgrad(G2, 64, A1, 64)
-        dW3, db3 = wgrad(G3, 3, A2, 64)
         return (None, g_table, g_feat, g_refl01, g_nw, dW1, db1, dW2, db2, dW3, db3, None, None)
 
 

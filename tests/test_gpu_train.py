@@ -6,6 +6,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
 
 
 @pytest.fixture(scope="module")
@@ -84,3 +85,63 @@ def test_forward_backward_vs_torch_autograd(frame):
     print(worst)
     bad = {k: v for k, v in worst.items() if v > (3e-2 if k.endswith('_table') else 5e-3)}
     assert not bad, worst
+
+
+def test_fused_mlp_backward_matches_operand_path():
+    """csrc/mlp_train.hip (operands in LDS, dW in MFMA accumulators) == csrc/mlp_bwd.hip + ia_wgrad (operands through
+    HBM) for the radiance head and the SDF head incl. its second-order terms; ragged n (not a multiple of 32)."""
+    import ctypes as C
+    from intrinsicavatar_amd import build
+    build.build()
+    from intrinsicavatar_amd import _lib as L, train
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: (torch.randn(*s, generator=g) * 0.3).to(DEV)      # noqa: E731
+    n = 100_003
+    enc, xyz, feat, sh, nrm = r(n, 32), r(n, 3), r(n, 13), r(n, 16), r(n, 3)
+    W1, b1, W2, b2, W3, b3 = r(64, 67), r(64), r(64, 64), r(64), r(3, 64), r(3)
+    g_rgb = r(n, 3)
+    segs = [(enc, 32, 1.0, 0.0), (xyz, 3, 2.0, -1.0), (feat, 13, 1.0, 0.0), (sh, 16, 1.0, 0.0), (nrm, 3, 1.0, 0.0)]
+    ns, ptrs, strides, widths, muls, adds = train._segs(segs)
+    z = lambda *s: torch.zeros(*s, device=DEV)      # noqa: E731
+    gx_a, gx_b = torch.empty((n, 68), device=DEV), torch.empty((n, 68), device=DEV)
+    X = torch.empty((n, 68), device=DEV)
+    A1, A2, G1, G2 = (torch.empty((n, 64), device=DEV) for _ in range(4))
+    G3 = torch.empty((n, 16), device=DEV)
+    lib = L.lib()
+    L.check(lib.ia_mlp_bwd(L.i32(1), L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds, L.ptr(W1), L.ptr(b1), L.ptr(W2),
+                           L.ptr(b2), L.ptr(W3), L.ptr(b3), L.ptr(g_rgb), L.ptr(gx_a), L.i32(68), L.ptr(X), L.ptr(A1), L.ptr(A2),
+                           L.ptr(G1), L.ptr(G2), L.ptr(G3), L.stream()))
+    ref = [train.wgrad(G1, 64, X, 67), train.wgrad(G2, 64, A1, 64), train.wgrad(G3, 3, A2, 64)]
+    d = [z(64, 67), z(64), z(64, 64), z(64), z(3, 64), z(3)]
+    L.check(lib.ia_mlp_bwd_fused(L.i32(1), L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds, L.ptr(W1), L.ptr(b1),
+                                 L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3), L.ptr(g_rgb), L.ptr(gx_b), L.i32(68),
+                                 *[L.ptr(t) for t in d], L.stream()))
+
+    def close(a, b, what):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) < 2e-4 * scale, (what, float((a - b).abs().max()), scale)
+    assert torch.equal(gx_a[:, :67], gx_b[:, :67])                       # same MFMA chain per point: bit-equal
+    for i, (dw, db) in enumerate(ref):
+        close(d[2 * i], dw, f"dW{i + 1}")
+        close(d[2 * i + 1], db, f"db{i + 1}")
+    # ---- SDF head
+    W1s, b1s, Wo, bo = r(64, 35), r(64), r(13, 64), r(13)
+    jac, g_out, q = r(n, 32, 3), r(n, 13), r(n, 3)
+    ns, ptrs, strides, widths, muls, adds = train._segs([(enc, 32, 1.0, 0.0), (xyz, 3, 2.0, -1.0)])
+    gE_a, gG_a, gE_b, gG_b = (torch.empty((n, 32), device=DEV) for _ in range(4))
+    Hh, U = torch.empty((n, 36), device=DEV), torch.empty((n, 36), device=DEV)
+    DZ, GZ, A, DGS = (torch.empty((n, 64), device=DEV) for _ in range(4))
+    L.check(lib.ia_sdf_mlp_bwd(L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds, L.ptr(W1s), L.ptr(b1s), L.ptr(Wo),
+                               L.ptr(bo), L.ptr(jac), L.ptr(g_out), L.ptr(q), L.ptr(gE_a), L.ptr(gG_a), L.ptr(Hh), L.ptr(U),
+                               L.ptr(DZ), L.ptr(GZ), L.ptr(A), L.ptr(DGS), L.stream()))
+    dW1, db1 = train.wgrad(DZ, 64, Hh, 35)
+    dW1 = dW1 + train.wgrad(GZ, 64, U, 35, want_bias=False)[0]
+    dWo, dbo = train.wgrad(g_out, 13, A, 64)
+    dWo[0] += train.wgrad(DGS, 64, DGS, 1)[1]
+    e = [z(64, 35), z(64), z(13, 64), z(13)]
+    L.check(lib.ia_sdf_mlp_bwd_fused(L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds, L.ptr(W1s), L.ptr(b1s), L.ptr(Wo),
+                                     L.ptr(bo), L.ptr(jac), L.ptr(g_out), L.ptr(q), L.ptr(gE_b), L.ptr(gG_b),
+                                     *[L.ptr(t) for t in e], L.stream()))
+    assert torch.equal(gE_a, gE_b) and torch.equal(gG_a, gG_b)
+    for got, want, what in zip(e, (dW1, db1, dWo, dbo), ("dW1", "db1", "dWo", "dbo")):
+        close(got, want, "sdf " + what)
