@@ -14,7 +14,7 @@
 //       g_x = G1 W1 -> global
 //     dW* live in 176 accumulator registers per lane (6 + 4 tiles of 32x32, 4 tiles of 16x16); one wave per SIMD
 //     (4 waves / CU, 150 KB of LDS), which is enough here because a tile now carries ~30 k MFMA cycles of work for one
-//     input fetch.  At the end the four waves of a workgroup reduce their accumulators through LDS (ds_add_f32) and
+//     input fetch.  At the end the four waves of a workgroup reduce their accumulators through LDS (plain read-modify-writes, one wave at a time) and
 //     the workgroup adds its partial sums to the global dW with one atomic per element.
 //
 // The SDF head follows the same scheme with its second-order terms (see mlp_bwd.hip for the derivation):
@@ -135,26 +135,31 @@ __device__ __forceinline__ float col_sum(const float* sT, int ld, int col)
 }
 
 // workgroup reduction of per-wave accumulator tiles through an LDS scratch [64][LDR], then one global atomic per
-// element (rows < M, cols < N).  Called by all threads.
+// element (rows < M, cols < N).  Called by all threads.  The waves take turns adding their fragments with plain
+// read-modify-writes: float LDS atomics (ds_add_f32) retire ~30x slower than integer ones on gfx950
+// (tools/probes/lds_atomic_probe.hip), and a wave's fragment never aliases itself.
 constexpr int LDR = 97;
 template <int NT>
 __device__ __forceinline__ void flush_w(float* sRed, const f32x16 (&accW)[2][NT], float* __restrict__ dW, int M, int N,
                                         int ldw, int tid)
 {
-    const int lane = tid & 63, lr = lane & 31, lk = lane >> 5;
+    const int lane = tid & 63, wave = tid >> 6, lr = lane & 31, lk = lane >> 5;
     __syncthreads();
-    for (int i = tid; i < 64 * LDR; i += THREADS) sRed[i] = 0.0f;
-    __syncthreads();
+    for (int w = 0; w < WAVES; w++) {
+        if (wave == w) {
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+            for (int m = 0; m < 2; m++)
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++)
+                for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * lk, col = 32 * nt + lr;
-                unsafeAtomicAdd(sRed + row * LDR + col, accW[m][nt][r]);
-            }
-    __syncthreads();
+                    for (int r = 0; r < 16; r++) {
+                        const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * lk, col = 32 * nt + lr;
+                        float* d = sRed + row * LDR + col;
+                        *d = (w == 0) ? accW[m][nt][r] : *d + accW[m][nt][r];
+                    }
+        }
+        __syncthreads();
+    }
     for (int i = tid; i < M * N; i += THREADS) {
         const int row = i / N, col = i % N;
         const float v = sRed[row * LDR + col];
@@ -164,15 +169,20 @@ __device__ __forceinline__ void flush_w(float* sRed, const f32x16 (&accW)[2][NT]
 
 __device__ __forceinline__ void flush_o(float* sRed, const f32x4 (&accO)[4], float* __restrict__ dWo, int OUT, int tid)
 {
-    const int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     __syncthreads();
-    for (int i = tid; i < 16 * LDR; i += THREADS) sRed[i] = 0.0f;
-    __syncthreads();
+    for (int w = 0; w < WAVES; w++) {
+        if (wave == w) {
 #pragma unroll
-    for (int nt = 0; nt < 4; nt++)
+            for (int nt = 0; nt < 4; nt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) unsafeAtomicAdd(sRed + (l4 * 4 + r) * LDR + 16 * nt + l15, accO[nt][r]);
-    __syncthreads();
+                for (int r = 0; r < 4; r++) {
+                    float* d = sRed + (l4 * 4 + r) * LDR + 16 * nt + l15;
+                    *d = (w == 0) ? accO[nt][r] : *d + accO[nt][r];
+                }
+        }
+        __syncthreads();
+    }
     for (int i = tid; i < OUT * HID; i += THREADS) {
         const int row = i / HID, col = i % HID;
         const float v = sRed[row * LDR + col];
