@@ -323,6 +323,16 @@ int ia_pbr_shade(int mode, int64_t F, const float* normal, const float* albedo, 
                  const float* indirect_rgb, const float* inv_pdf, const float* env_base, const float* env_pmf,
                  int env_h, int env_w, const float* w2s_rot, float* Lo, float* Lo_diff, float* Lo_spec, float* vis,
                  ia_stream_t stream);
+/* backward of modes 0 / 1 w.r.t. the per-point surface attributes and the environment texels (autograd through
+ * scatterer.eval + emitter.eval in the reference; directions, transmittance, masks and sampling weights are constants).
+ * g_Lo / g_Lo_diff / g_Lo_spec: incoming gradients of the three outputs (any may be NULL); g_env_base [H,W,3] is
+ * accumulated into with atomics (may be NULL). */
+int ia_pbr_shade_bwd(int mode, int64_t F, const float* normal, const float* albedo, const float* roughness,
+                     const float* metallic, const float* view_dirs, const float* out_dirs, const float* transmittance,
+                     const float* indirect_rgb, const float* inv_pdf, const float* env_base, const float* env_pmf,
+                     int env_h, int env_w, const float* w2s_rot, const float* g_Lo, const float* g_Lo_diff,
+                     const float* g_Lo_spec, float* g_normal, float* g_albedo, float* g_roughness, float* g_metallic,
+                     float* g_env_base, ia_stream_t stream);
 /* scatterer.sample / scatterer.pdf of the multi-lobe BRDF (1/2 cosine hemisphere + 1/2 GGX half-vector sampling);
  * u [F,3] uniforms = (lobe selector, u1, u2): explicit RNG */
 int ia_brdf_sample(int64_t F, const float* normal, const float* view_dirs, const float* roughness, const float* u,

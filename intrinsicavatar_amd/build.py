@@ -27,7 +27,7 @@ SOURCES = {
     "mlp_bwd.hip": ["-munsafe-fp-atomics"],
     "mlp_train.hip": ["-munsafe-fp-atomics"],
     "deform.hip": ["-ffp-contract=off"],
-    "pbr.hip": [],
+    "pbr.hip": ["-munsafe-fp-atomics"],
     "occgrid.hip": [],
 }
 

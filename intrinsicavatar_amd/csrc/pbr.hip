@@ -241,6 +241,144 @@ __global__ __launch_bounds__(THREADS) void pbr_light_kernel(
     for (int c = 0; c < 3; c++) { Lo[i * 3 + c] = lo[c]; Lo_diff[i * 3 + c] = ld[c]; Lo_spec[i * 3 + c] = ls[c]; }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the light / uniform_light estimators (training with PBR losses, BASELINE config 4).  The reference gets
+// these gradients from autograd through scatterer.eval and emitter.eval (intrinsic_avatar.py:705-745, :806-859);
+// directions, transmittance, masks and sampling weights are constants (computed under no_grad there).
+//   Lo_c = (kd_c diff + spec_c) Li_c w ,  kd = (1-m) albedo ,  Li = em(dir) tr (+ indirect)
+//   spec_c = common (F0_c + (1 - F0_c) f5) ,  common = D G1(NoL) G1(NoV) / (4 NoV) ,  F0 = 0.04 (1-m) + albedo m
+// outputs: d/d normal [F,3], albedo [F,3], roughness [F], metallic [F]; d/d env texels accumulated with atomics.
+__device__ __forceinline__ void env_scatter(const EnvMap& e, float* __restrict__ g_base, const float d[3], const float g[3])
+{
+    float u, v;
+    dir_to_uv(d, u, v);
+    const float fx = u * e.W - 0.5f, fy = v * e.H - 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float ax = fx - x0f, ay = fy - y0f;
+    int x0 = (int)x0f, y0 = (int)y0f;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    x0 = ((x0 % e.W) + e.W) % e.W;
+    x1 = ((x1 % e.W) + e.W) % e.W;
+    y0 = min(max(y0, 0), e.H - 1);
+    y1 = min(max(y1, 0), e.H - 1);
+    const float w00 = (1 - ax) * (1 - ay), w10 = ax * (1 - ay), w01 = (1 - ax) * ay, w11 = ax * ay;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        if (g[c] == 0.0f) continue;
+        unsafeAtomicAdd(g_base + ((int64_t)y0 * e.W + x0) * 3 + c, w00 * g[c]);
+        unsafeAtomicAdd(g_base + ((int64_t)y0 * e.W + x1) * 3 + c, w10 * g[c]);
+        unsafeAtomicAdd(g_base + ((int64_t)y1 * e.W + x0) * 3 + c, w01 * g[c]);
+        unsafeAtomicAdd(g_base + ((int64_t)y1 * e.W + x1) * 3 + c, w11 * g[c]);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(THREADS) void pbr_light_bwd_kernel(
+    int64_t F, const float* __restrict__ inv_pdf, const float* __restrict__ normal, const float* __restrict__ albedo,
+    const float* __restrict__ roughness, const float* __restrict__ metallic, const float* __restrict__ view_dirs,
+    const float* __restrict__ light_dirs, const float* __restrict__ tr, const float* __restrict__ ind_rgb, EnvMap env,
+    const float* __restrict__ Rw, const float* __restrict__ g_Lo, const float* __restrict__ g_Ld,
+    const float* __restrict__ g_Ls, float* __restrict__ g_normal, float* __restrict__ g_albedo,
+    float* __restrict__ g_rough, float* __restrict__ g_metal, float* __restrict__ g_base)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= F) return;
+    float gn[3] = {0, 0, 0}, ga[3] = {0, 0, 0}, gr = 0.0f, gm = 0.0f;
+    const float n[3] = {normal[i * 3], normal[i * 3 + 1], normal[i * 3 + 2]};
+    const float wo[3] = {light_dirs[i * 3], light_dirs[i * 3 + 1], light_dirs[i * 3 + 2]};
+    const float NoL = n[0] * wo[0] + n[1] * wo[1] + n[2] * wo[2];
+    if (NoL > 1e-6f) {                                                    // cosine_mask
+        const float t = fminf(fmaxf(tr[i], 0.0f), 1.0f);
+        const float wi[3] = {-view_dirs[i * 3], -view_dirs[i * 3 + 1], -view_dirs[i * 3 + 2]};
+        const float alb[3] = {albedo[i * 3], albedo[i * 3 + 1], albedo[i * 3 + 2]};
+        const float met = metallic[i], alpha = roughness[i];
+        float em[3] = {0, 0, 0}, dw[3] = {0, 0, 1};
+        float w = 1.0f;
+        if (t > 0.0f) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) dw[c] = wo[0] * Rw[0 * 3 + c] + wo[1] * Rw[1 * 3 + c] + wo[2] * Rw[2 * 3 + c];
+            const float l = fmaxf(sqrtf(dw[0] * dw[0] + dw[1] * dw[1] + dw[2] * dw[2]), 1e-6f);
+            dw[0] /= l; dw[1] /= l; dw[2] /= l;
+            env_eval(env, dw, em);
+            if (MODE == 0) { const float p = env_pdf(env, dw); w = p > 0.0f ? 1.0f / p : 1.0f; }
+        }
+        if (MODE == 1) w = inv_pdf[i];
+        float diff, spec[3];
+        brdf_eval(n, wi, wo, alpha, alb, met, diff, spec);
+        // c_c = d L / d (kd diff + spec)_c ; gradients that arrive on Lo_diff / Lo_spec directly are folded in
+        float gLi[3], cd[3], cs[3];
+        float gdiff = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float Li = em[c] * t + (ind_rgb ? ind_rgb[i * 3 + c] : 0.0f);
+            const float glo = g_Lo ? g_Lo[i * 3 + c] : 0.0f;
+            const float gld = (g_Ld ? g_Ld[i * 3 + c] : 0.0f) + glo * (1.0f - met) * alb[c];     // on Li diff w
+            const float gls = (g_Ls ? g_Ls[i * 3 + c] : 0.0f) + glo;                              // on Li spec w
+            cd[c] = gld * Li * w;              // d / d diff   (per channel, summed below)
+            cs[c] = gls * Li * w;              // d / d spec_c
+            gdiff += cd[c];
+            gLi[c] = (gld * diff + gls * spec[c]) * w;
+            // kd = (1-m) albedo multiplies Li diff w inside Lo only
+            const float ldw = Li * diff * w;
+            ga[c] += glo * (1.0f - met) * ldw;
+            gm += glo * (-alb[c]) * ldw;
+        }
+        float gNoL = gdiff * (1.0f / PI_F), gNoV = 0.0f, gNoH = 0.0f;
+        const float NoV = n[0] * wi[0] + n[1] * wi[1] + n[2] * wi[2];
+        float h[3] = {wi[0] + wo[0], wi[1] + wo[1], wi[2] + wo[2]};
+        const float hl = sqrtf(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+        if (NoV > 0.0f && hl >= 1e-12f) {
+            h[0] /= hl; h[1] /= hl; h[2] /= hl;
+            const float NoH = n[0] * h[0] + n[1] * h[1] + n[2] * h[2];
+            const float VoH = fmaxf(wi[0] * h[0] + wi[1] * h[1] + wi[2] * h[2], 0.0f);
+            const float a2 = alpha * alpha;
+            const float dd = NoH * NoH * (a2 - 1.0f) + 1.0f;
+            const float D = a2 / (PI_F * dd * dd);
+            const float sl = sqrtf(a2 + (1.0f - a2) * NoL * NoL), sv = sqrtf(a2 + (1.0f - a2) * NoV * NoV);
+            const float G1l = 2.0f * NoL / (NoL + sl), G1v = 2.0f * NoV / (NoV + sv);
+            const float om = 1.0f - VoH;
+            const float f5 = om * om * om * om * om;
+            const float common = D * G1l * G1v / (4.0f * NoV);
+            float gcommon = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float F0 = 0.04f * (1.0f - met) + alb[c] * met;
+                const float Fr = F0 + (1.0f - F0) * f5;
+                gcommon += cs[c] * Fr;
+                const float gF0 = cs[c] * common * (1.0f - f5);
+                ga[c] += gF0 * met;
+                gm += gF0 * (alb[c] - 0.04f);
+            }
+            const float k = gcommon / (4.0f * NoV);
+            const float gD = k * G1l * G1v, gG1l = k * D * G1v, gG1v = k * D * G1l;
+            gNoV += -gcommon * common / NoV;
+            float ga2 = gD * (1.0f / (PI_F * dd * dd) - 2.0f * a2 * NoH * NoH / (PI_F * dd * dd * dd));
+            gNoH += gD * (-4.0f * a2 * NoH * (a2 - 1.0f) / (PI_F * dd * dd * dd));
+            {   // G1(x) = 2x / (x + s), s = sqrt(a2 + (1 - a2) x^2)
+                const float dl = (NoL + sl) * (NoL + sl), dv = (NoV + sv) * (NoV + sv);
+                gNoL += gG1l * (2.0f * (NoL + sl) - 2.0f * NoL * (1.0f + (1.0f - a2) * NoL / sl)) / dl;
+                gNoV += gG1v * (2.0f * (NoV + sv) - 2.0f * NoV * (1.0f + (1.0f - a2) * NoV / sv)) / dv;
+                ga2 += gG1l * (-2.0f * NoL / dl) * (1.0f - NoL * NoL) / (2.0f * sl);
+                ga2 += gG1v * (-2.0f * NoV / dv) * (1.0f - NoV * NoV) / (2.0f * sv);
+            }
+            gr = 2.0f * alpha * ga2;
+#pragma unroll
+            for (int c = 0; c < 3; c++) gn[c] += gNoH * h[c] + gNoV * wi[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) gn[c] += gNoL * wo[c];
+        if (g_base && t > 0.0f) {
+            const float ge[3] = {gLi[0] * t, gLi[1] * t, gLi[2] * t};
+            env_scatter(env, g_base, dw, ge);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) { g_normal[i * 3 + c] = gn[c]; g_albedo[i * 3 + c] = ga[c]; }
+    g_rough[i] = gr;
+    g_metal[i] = gm;
+}
+
 __global__ __launch_bounds__(THREADS) void env_eval_kernel(int64_t n, const float* __restrict__ dirs_world, EnvMap env,
                                                             float* __restrict__ rgb, float* __restrict__ pdf)
 {
@@ -274,6 +412,31 @@ IA_EXPORT int ia_pbr_shade(int mode, int64_t F, const float* normal, const float
     else IA_PBR_LAUNCH(3);
 #undef IA_PBR_LAUNCH
     return ia::check_launch("ia_pbr_shade");
+}
+
+
+IA_EXPORT int ia_pbr_shade_bwd(int mode, int64_t F, const float* normal, const float* albedo, const float* roughness,
+                               const float* metallic, const float* view_dirs, const float* out_dirs,
+                               const float* transmittance, const float* indirect_rgb, const float* inv_pdf,
+                               const float* env_base, const float* env_pmf, int env_h, int env_w, const float* w2s_rot,
+                               const float* g_Lo, const float* g_Lo_diff, const float* g_Lo_spec, float* g_normal,
+                               float* g_albedo, float* g_roughness, float* g_metallic, float* g_env_base,
+                               ia_stream_t stream)
+{
+    if (F == 0) return IA_OK;
+    IA_REQUIRE(mode == 0 || mode == 1, "backward is provided for the training estimators: 0 light, 1 uniform_light");
+    IA_REQUIRE(mode != 1 || inv_pdf != nullptr, "uniform_light needs inv_pdf");
+    IA_REQUIRE(g_normal && g_albedo && g_roughness && g_metallic, "all four per-point gradient outputs are required");
+    EnvMap e{env_base, env_pmf, env_h, env_w};
+    const int grid = ia::cdiv(F, THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0)
+        pbr_light_bwd_kernel<0><<<grid, THREADS, 0, s>>>(F, inv_pdf, normal, albedo, roughness, metallic, view_dirs, out_dirs,
+            transmittance, indirect_rgb, e, w2s_rot, g_Lo, g_Lo_diff, g_Lo_spec, g_normal, g_albedo, g_roughness, g_metallic, g_env_base);
+    else
+        pbr_light_bwd_kernel<1><<<grid, THREADS, 0, s>>>(F, inv_pdf, normal, albedo, roughness, metallic, view_dirs, out_dirs,
+            transmittance, indirect_rgb, e, w2s_rot, g_Lo, g_Lo_diff, g_Lo_spec, g_normal, g_albedo, g_roughness, g_metallic, g_env_base);
+    return ia::check_launch("ia_pbr_shade_bwd");
 }
 
 IA_EXPORT int ia_pbr_light_shade(int64_t F, const float* normal, const float* albedo, const float* roughness,

@@ -88,6 +88,56 @@ def pbr_shade(mode: str, normal, albedo, roughness, metallic, view_dirs, out_dir
     return (Lo, Ld, Ls, vis) if mode == "uniform_light" else (Lo, Ld, Ls)
 
 
+class _PbrShade(torch.autograd.Function):
+    """differentiable light / uniform_light estimator: gradients w.r.t. normal, albedo, roughness, metallic and the
+    environment texels (ia_pbr_shade_bwd); directions, transmittance, indirect radiance and weights are constants."""
+
+    @staticmethod
+    def forward(ctx, mode, normal, albedo, roughness, metallic, env_base, view_dirs, out_dirs, tr, ind, inv_pdf, env_pmf, w2s_rot):
+        c = lambda t: None if t is None else t.detach().contiguous().float()     # noqa: E731
+        normal, albedo, view_dirs, out_dirs, ind, w2s_rot = (c(t) for t in (normal, albedo, view_dirs, out_dirs, ind, w2s_rot))
+        roughness, metallic, tr = (c(t.reshape(-1)) for t in (roughness, metallic, tr))
+        inv_pdf = c(inv_pdf.reshape(-1)) if inv_pdf is not None else None
+        env_base = c(env_base)
+        F_ = normal.shape[0]
+        Lo, Ld, Ls = (torch.empty((F_, 3), device=normal.device) for _ in range(3))
+        H, W, _ = env_base.shape
+        L.check(L.lib().ia_pbr_shade(L.i32(mode), L.i64(F_), L.ptr(normal), L.ptr(albedo), L.ptr(roughness), L.ptr(metallic),
+                                     L.ptr(view_dirs), L.ptr(out_dirs), L.ptr(tr), L.ptr(ind), L.ptr(inv_pdf), L.ptr(env_base),
+                                     L.ptr(env_pmf), L.i32(H), L.i32(W), L.ptr(w2s_rot), L.ptr(Lo), L.ptr(Ld), L.ptr(Ls),
+                                     L.ptr(None), L.stream()), "ia_pbr_shade")
+        ctx.mode = mode
+        ctx.save_for_backward(normal, albedo, roughness, metallic, env_base, view_dirs, out_dirs, tr, ind, inv_pdf, env_pmf, w2s_rot)
+        return Lo, Ld, Ls
+
+    @staticmethod
+    def backward(ctx, g_Lo, g_Ld, g_Ls):
+        normal, albedo, roughness, metallic, env_base, view_dirs, out_dirs, tr, ind, inv_pdf, env_pmf, w2s_rot = ctx.saved_tensors
+        F_ = normal.shape[0]
+        dev = normal.device
+        c = lambda t: None if t is None else t.contiguous().float()     # noqa: E731
+        g_n, g_a = torch.empty((F_, 3), device=dev), torch.empty((F_, 3), device=dev)
+        g_r, g_m = torch.empty(F_, device=dev), torch.empty(F_, device=dev)
+        g_base = torch.zeros_like(env_base) if ctx.needs_input_grad[5] else None
+        H, W, _ = env_base.shape
+        L.check(L.lib().ia_pbr_shade_bwd(
+            L.i32(ctx.mode), L.i64(F_), L.ptr(normal), L.ptr(albedo), L.ptr(roughness), L.ptr(metallic), L.ptr(view_dirs),
+            L.ptr(out_dirs), L.ptr(tr), L.ptr(ind), L.ptr(inv_pdf), L.ptr(env_base), L.ptr(env_pmf), L.i32(H), L.i32(W),
+            L.ptr(w2s_rot), L.ptr(c(g_Lo)), L.ptr(c(g_Ld)), L.ptr(c(g_Ls)), L.ptr(g_n), L.ptr(g_a), L.ptr(g_r), L.ptr(g_m),
+            L.ptr(g_base), L.stream()), "ia_pbr_shade_bwd")
+        return (None, g_n, g_a, g_r[:, None], g_m[:, None], g_base, None, None, None, None, None, None, None)
+
+
+def pbr_shade_differentiable(mode: str, normal, albedo, roughness, metallic, view_dirs, out_dirs, transmittance, indirect_rgb,
+                             emitter: "EnvironmentLightTensor", w2s_rot, inv_pdf=None, env_base: Optional[Tensor] = None):
+    """training form of pbr_shade (modes 'light' and 'uniform_light'); roughness / metallic are [F,1];
+    env_base: a differentiable [H,W,3] image (e.g. generated from SG lobes) to evaluate instead of emitter.base."""
+    assert mode in ("light", "uniform_light")
+    base = emitter.base if env_base is None else env_base
+    return _PbrShade.apply(MODES[mode], normal, albedo, roughness, metallic, base, view_dirs, out_dirs, transmittance,
+                           indirect_rgb, inv_pdf, emitter.pmf, w2s_rot)
+
+
 def brdf_sample(normal, view_dirs, roughness, u):
     """scatterer.sample: out directions from the multi-lobe BRDF (u [F,3] uniforms)."""
     F_ = normal.shape[0]
@@ -137,11 +187,12 @@ def pbr_light_shade(normal, albedo, roughness, metallic, view_dirs, light_dirs, 
     return Lo, Ld, Ls
 
 
-@torch.no_grad()
 def sample_volume_interaction(rays_o, rays_d, ray_indices, t_starts, t_ends, n_rays: int, spp: int, transmittance_map,
                               extras: Dict[str, Tensor]):
     """models/pbr/utils.py:70-229: spp stratified samples of the un-normalised weight CDF per ray (+ background bin),
-    zero-crossing clamp, per-interval counts, gathers of the per-sample attributes."""
+    zero-crossing clamp, per-interval counts, gathers of the per-sample attributes.  The re-sampling itself is not
+    differentiated (no_grad in the reference too); the gathers and the re-sampled weights are plain torch ops, so under
+    autograd the gradients flow back to weights / normals / albedo / roughness / metallic (training, train_phys.py)."""
     weights, sdfs = extras["weights"], extras["sdf"]
     packed_info = lib_nerfacc.pack_info(ray_indices, n_rays)
     rpi, mid, offs, sampled_idx, fg_cnt, bg_cnt, surface_idx = lib_nerfacc.ray_resampling(

@@ -164,6 +164,23 @@ class RenderStep:
         out["stats"] = stats
         return out
 
+    def forward_backward_phys(self, rays: Tensor, target_rgb: Tensor, material, emitter, spp: int, light_u: Tensor,
+                              shuffle_u: Tensor, target_mask: Optional[Tensor] = None, jitter: Optional[Tensor] = None,
+                              render_mode: str = "uniform_light", env_base: Optional[Tensor] = None,
+                              background_color: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        """BASELINE config 4: training step with the PBR branch (material head, volume scattering, secondary rays,
+        light / uniform_light estimator) -- fwd + bwd to geometry, radiance, material and environment-light parameters."""
+        from . import train_phys
+        rays_o, rays_d, far, t_starts, t_ends, ray_indices, packed_info, stats = self.sample(rays, jitter)
+        out = train_phys.shade_differentiable_phys(self, material, emitter, rays_o, rays_d, ray_indices, t_starts, t_ends,
+                                                   packed_info, spp, light_u, shuffle_u, render_mode=render_mode,
+                                                   env_base=env_base, background_color=background_color)
+        loss = train_phys.training_loss_phys(out, target_rgb, target_mask)
+        loss.backward()
+        out["loss"] = loss.detach()
+        out["stats"].update(stats)
+        return out
+
     # ------------------------------------------------------------------ secondary rays (compute_indirect_radiance)
     @torch.no_grad()
     def compute_indirect_radiance(self, rays_o: Tensor, rays_d: Tensor, near: float = 0.0, far: float = 1.5,

@@ -105,19 +105,21 @@ class _ShadePrep(Function):
     def forward(ctx, sdf_grad, rays_d, ray_indices, w2s_rot):
         sdf_grad = sdf_grad.contiguous()
         ns, nw, rf = render.shade_prep(sdf_grad, rays_d, ray_indices, w2s_rot)
-        ctx.save_for_backward(sdf_grad, rays_d, ray_indices, w2s_rot)
-        ctx.mark_non_differentiable(ns)
+        ctx.save_for_backward(sdf_grad, rays_d, ray_indices, w2s_rot, ns)
         return ns, nw, rf
 
     @staticmethod
-    def backward(ctx, _g_ns, g_nw, g_rf):
-        sdf_grad, rays_d, ray_indices, w2s_rot = ctx.saved_tensors
+    def backward(ctx, g_ns, g_nw, g_rf):
+        sdf_grad, rays_d, ray_indices, w2s_rot, ns = ctx.saved_tensors
         n = sdf_grad.shape[0]
         g_nw = g_nw.contiguous() if g_nw is not None else None
         g_rf = g_rf.contiguous() if g_rf is not None else torch.zeros_like(sdf_grad)
         out = torch.empty_like(sdf_grad)
         L.check(L.lib().ia_shade_prep_bwd(L.i64(n), L.ptr(sdf_grad), L.ptr(rays_d), L.ptr(ray_indices), L.ptr(w2s_rot),
                                           L.ptr(g_nw), L.ptr(g_rf), L.ptr(out), L.stream()), "ia_shade_prep_bwd")
+        if g_ns is not None:      # normal_smpl = g / max(|g|, 1e-6): used by the BRDF of the PBR branch only
+            nrm = torch.linalg.norm(sdf_grad, dim=-1, keepdim=True).clamp_min(1e-6)
+            out = out + (g_ns - (g_ns * ns).sum(-1, keepdim=True) * ns) / nrm
         return out, None, None, None
 
 

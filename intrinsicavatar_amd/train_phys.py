@@ -1,0 +1,167 @@
+"""Training step WITH the physically based branch (BASELINE config 4): differentiable form of forward_ with enable_phys
+(models/intrinsic_avatar.py:1066-1156 rgb_normal_mats_alpha_fn, :1290-1470 volume scattering) on the MI355X kernels.
+
+On top of train.py (SDF field with first+second order terms, alpha, compositing) this adds, each a torch.autograd.Function
+whose forward AND backward are HIP kernels behind the C ABI:
+
+    _HashEncode   hash grid #2 once, shared by the radiance and the material heads        ia_hashgrid_fwd / _bwd_binned
+    _MLP2         radiance 67->64->64->3 and Lipschitz material 48->64->64->5             ia_mlp_fwd / ia_mlp_bwd_fused
+    pbr._PbrShade light / uniform_light estimator: BRDF + env lookup + Lo                 ia_pbr_shade / ia_pbr_shade_bwd
+    volume-interaction re-sampling (K1, no grad) + differentiable gathers / weights       ia_ray_resampling + torch indexing
+
+What is constant w.r.t. the parameters follows the reference: sample positions, the candidate search, the re-sampled
+interval indices, the secondary rays (directions, transmittance, indirect radiance) and the sampling weights are all
+computed under no_grad there (:672-703, :772-795).
+"""
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from . import _lib as L
+from . import fields, lib_nerfacc, nerfacc, pbr, render, train
+from .tinycudann import _SH4
+
+
+class _HashEncode(Function):
+    @staticmethod
+    def forward(ctx, xp, table):
+        xp = xp.contiguous()
+        ctx.save_for_backward(xp, table)
+        return fields.hashgrid_forward(xp, table)
+
+    @staticmethod
+    def backward(ctx, g_enc):
+        xp, table = ctx.saved_tensors
+        g_table = torch.zeros_like(table)
+        fields.hashgrid_backward(xp, g_enc.contiguous(), g_table)
+        return None, g_table
+
+
+class _MLP2(Function):
+    """kind 1 (radiance: enc, xp, feat, sh, normal) / kind 2 (material: enc, xp, feat); sigmoid output.
+    Gradients for every input segment (views of one [n, IN_PAD] buffer) and the six effective weights."""
+
+    @staticmethod
+    def forward(ctx, kind, out_dim, W1, b1, W2, b2, W3, b3, *segs):
+        spec = {1: ((32, 1.0, 0.0), (3, 2.0, -1.0), (13, 1.0, 0.0), (16, 1.0, 0.0), (3, 1.0, 0.0)),
+                2: ((32, 1.0, 0.0), (3, 2.0, -1.0), (13, 1.0, 0.0))}[kind]
+        segs = [s.contiguous().float() for s in segs]
+        ws = [t.contiguous().float() for t in (W1, b1, W2, b2, W3, b3)]
+        y = fields.mlp_forward(kind, [(s, w, m, a) for s, (w, m, a) in zip(segs, spec)], *ws, out_dim)
+        ctx.kind, ctx.out_dim, ctx.spec = kind, out_dim, spec
+        ctx.save_for_backward(*ws, *segs)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        saved = ctx.saved_tensors
+        ws, segs = saved[:6], saved[6:]
+        n, dev = segs[0].shape[0], segs[0].device
+        in_dim = sum(w for w, _, _ in ctx.spec)
+        pad = (in_dim + 1) // 2 * 2
+        g_x = torch.empty((n, pad), device=dev)
+        ns, ptrs, strides, widths, muls, adds = train._segs([(s, w, m, a) for s, (w, m, a) in zip(segs, ctx.spec)])
+        d = [torch.zeros((64, in_dim), device=dev), torch.zeros(64, device=dev), torch.zeros((64, 64), device=dev),
+             torch.zeros(64, device=dev), torch.zeros((ctx.out_dim, 64), device=dev), torch.zeros(ctx.out_dim, device=dev)]
+        L.check(L.lib().ia_mlp_bwd_fused(L.i32(ctx.kind), L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds,
+                                         *[L.ptr(w) for w in ws], L.ptr(g_y.contiguous().float()), L.ptr(g_x), L.i32(pad),
+                                         *[L.ptr(t) for t in d], L.stream()), "ia_mlp_bwd_fused")
+        g_segs, c0 = [], 0
+        for w, m, _ in ctx.spec:
+            g_segs.append(g_x[:, c0:c0 + w] * m if m != 1.0 else g_x[:, c0:c0 + w])
+            c0 += w
+        return (None, None, *d, *g_segs)
+
+
+def shade_differentiable_phys(rs, material, emitter, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor, t_starts: Tensor,
+                              t_ends: Tensor, packed_info: Tensor, spp: int, light_u: Tensor, shuffle_u: Tensor,
+                              render_mode: str = "uniform_light", env_base: Optional[Tensor] = None,
+                              background_color: Optional[Tensor] = None, global_illumination: bool = False
+                              ) -> Dict[str, Tensor]:
+    """differentiable rgb_normal_mats_alpha_fn + rendering_with_normals_mats_sdf + volume scattering."""
+    dfm, geo, rad = rs.deformer, rs.geometry, rs.radiance
+    n_rays = packed_info.shape[0]
+    dev = rays_o.device
+    pts = render.ray_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
+    with torch.no_grad():
+        d = dfm.deform(pts, geo, with_grad=True, with_feature=False)
+        valid = d["valid"]
+        sel = d["sel"].long().clamp(min=0)
+        c2w = d["fwd_J"].reshape(-1, 3, 3)[d["cand_src"].long()[sel]] if d["n_candidates"] > 0 else \
+            torch.zeros((pts.shape[0], 3, 3), device=dev)
+    W1k, b1, W2, b2 = geo.effective_weights()
+    out, grad_c = train._SDFField.apply(d["pts_cano"], geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale)
+    vf = valid[:, None].float()
+    feat = out * vf
+    sdf = torch.where(valid, out[:, 0], torch.full_like(out[:, 0], 1e5))
+    dflt_g = torch.zeros((1, 3), device=dev)
+    dflt_g[0, 2] = 1.0
+    sdf_grad = torch.where(valid[:, None], (c2w * grad_c[:, None, :]).sum(-1), dflt_g)
+    w2s_rot = dfm.w2s[:3, :3].contiguous()
+    normal_smpl, normal_world, refl01 = train._ShadePrep.apply(sdf_grad, rays_d, ray_indices, w2s_rot)
+    alphas = train._Alpha.apply(sdf, t_ends - t_starts, rs.density.get_beta())
+    # hash grid #2 once; radiance and material heads
+    xp2 = ((d["pts_cano"] - rad.center) / rad.scale + 0.5).detach().contiguous()
+    enc2 = _HashEncode.apply(xp2, rad.grid_params)
+    sh = _SH4.apply(refl01)
+    rgbs = _MLP2.apply(1, 3, *rad.effective_weights(), enc2, xp2, feat, sh, normal_world)
+    mask = rad.prog.mask(rad.global_step, dev)
+    mraw = _MLP2.apply(2, 5, *material.effective_weights(mask), enc2, xp2, feat)
+    albedo = mraw[:, :3] * material.albedo_scale + material.albedo_bias
+    rough = mraw[:, 3:4] * material.roughness_scale + material.roughness_bias
+    metal = mraw[:, 4:5] * material.metallic_scale + material.metallic_bias
+    weights, trans = nerfacc._WeightFromAlpha.apply(alphas, packed_info)
+    acc = lambda v: nerfacc._Accumulate.apply(weights, v, ray_indices, packed_info)      # noqa: E731
+    res = dict(comp_rgb=acc(rgbs), comp_normal=acc(normal_world), opacity=acc(None), albedo=acc(albedo.contiguous()),
+               roughness=acc(rough.contiguous()), metallic=acc(metal.contiguous()), weights=weights, alphas=alphas, sdf=sdf,
+               sdf_grad=sdf_grad, valid=valid, n_samples=pts.shape[0])
+    # ---- volume scattering (enable_phys)
+    if background_color is None:
+        background_color = torch.ones(3, device=dev)
+    rgb_phys = background_color[None].expand(n_rays, 3)
+    stats = dict(n_resampled=0, n_fg=0, n_secondary=0)
+    if ray_indices.numel() > 0:
+        extras = dict(weights=weights, sdf=sdf.detach(), alphas=alphas, normals=normal_smpl, albedo=albedo, roughness=rough,
+                      metallic=metal)
+        rpi, rri, rw, fg_idx, bg_idx, ex = pbr.sample_volume_interaction(
+            rays_o, rays_d, ray_indices, t_starts, t_ends, n_rays, spp, (1.0 - res["opacity"]), extras)
+        stats["n_resampled"], stats["n_fg"] = int(rri.shape[0]), int(fg_idx.shape[0])
+        if fg_idx.numel() > 0:
+            F_ = fg_idx.shape[0]
+            with torch.no_grad():
+                s2 = dfm.w2s[:3, :3].T
+                if render_mode == "light":
+                    dirs_smpl = torch.nn.functional.normalize(emitter.sample(spp, light_u) @ s2, dim=-1, eps=1e-6)
+                    inv_pdf_all = None
+                else:
+                    assert spp == 512, "uniform_light asserts samples_per_pixel == 512 (:1392)"
+                    dirs_smpl, inv_pdf_all = pbr.uniform_sphere_stratified(16, 32, light_u[:, :2])
+                shuffled = pbr.light_shuffle(n_rays, spp, rpi, fg_idx, shuffle_u)
+                out_dirs = dirs_smpl[shuffled].contiguous()
+                inv_pdf = inv_pdf_all[shuffled] if inv_pdf_all is not None else None
+                nrm = ex["normals"].detach()
+                cos_mask = (nrm * out_dirs).sum(-1) > 1e-6
+                sec_tr = torch.zeros((F_, 1), device=dev)
+                sec_rgb = torch.zeros((F_, 3), device=dev)
+                stats["n_secondary"] = int(cos_mask.sum())
+                if stats["n_secondary"] > 0:
+                    t_, c_ = rs.compute_indirect_radiance(ex["positions"].detach()[cos_mask], out_dirs[cos_mask])
+                    sec_tr[cos_mask], sec_rgb[cos_mask] = t_.clamp(0.0, 1.0), c_
+            fg_Lo, fg_Ld, fg_Ls = pbr.pbr_shade_differentiable(
+                render_mode, ex["normals"], ex["albedo"], ex["roughness"], ex["metallic"], ex["t_dirs"], out_dirs, sec_tr,
+                sec_rgb if global_illumination else None, emitter, w2s_rot, inv_pdf=inv_pdf, env_base=env_base)
+            Lo = torch.zeros((rri.shape[0], 3), device=dev).index_put((fg_idx,), fg_Lo)
+            rgb_phys = nerfacc.accumulate_along_rays(rw, Lo, rri, n_rays)
+            no_samples = (rpi[:, 1] <= 0)[:, None]
+            rgb_phys = torch.where(no_samples, background_color[None].expand(n_rays, 3), rgb_phys)
+            res.update(fg_Lo=fg_Lo, secondary_tr=sec_tr)
+    res.update(comp_rgb_phys=rgb_phys, stats=stats)
+    return res
+
+
+def training_loss_phys(out: Dict[str, Tensor], target_rgb: Tensor, target_mask: Optional[Tensor] = None,
+                       lambda_phys: float = 1.0, **kw) -> Tensor:
+    """train.training_loss + the L1 term on the physically based image (systems/intrinsic_avatar.py:180-190)."""
+    return train.training_loss(out, target_rgb, target_mask, **kw) + lambda_phys * (out["comp_rgb_phys"] - target_rgb).abs().mean()

@@ -244,3 +244,46 @@ def test_relight_all_render_modes(frame):
     #  re-sample, pbr/utils.py:148-163, so low-spp images are darker -- reference behaviour, reproduced.)
     m = {k: float(o["fg_Lo"].mean()) for k, o in outs.items()}
     assert max(m.values()) / max(min(m.values()), 1e-9) < 1.15, m
+
+
+
+def test_pbr_shade_backward_vs_autograd(env):
+    """ia_pbr_shade_bwd (uniform_light): gradients w.r.t. normal / albedo / roughness / metallic / environment texels vs
+    fp64 torch autograd on a torch restatement of the same estimator."""
+    from tests import torch_ref as TR
+    from intrinsicavatar_amd import pbr
+    rng = np.random.default_rng(9)
+    F = 20000
+    n = _unit(rng, F)
+    v = -_unit(rng, F)
+    flip = (n * -v).sum(-1) < 0.05                       # keep NoV away from the kink
+    v[flip] = -(n[flip] + 0.3 * _unit(rng, int(flip.sum())))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    wo = _unit(rng, F)
+    alb = rng.uniform(0.05, 0.9, (F, 3)).astype(np.float32)
+    rough = rng.uniform(0.15, 0.9, F).astype(np.float32)
+    met = rng.uniform(0.0, 1.0, F).astype(np.float32)
+    tr = rng.uniform(-0.1, 1.1, F).astype(np.float32)
+    inv_pdf = np.full(F, 4 * math.pi, np.float32)
+    Rm = np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32)
+    base = (0.2 + rng.random((16, 32, 3))).astype(np.float32)
+    e = pbr.EnvironmentLightTensor(T(base)); e.update_pdf()
+    gl = rng.normal(size=(F, 3)).astype(np.float32)
+    leaf = lambda a: T(a).clone().requires_grad_(True)      # noqa: E731
+    tn, ta, tro, tm, tb = leaf(n), leaf(alb), leaf(rough[:, None]), leaf(met[:, None]), leaf(base)
+    Lo, Ld, Ls = pbr.pbr_shade_differentiable("uniform_light", tn, ta, tro, tm, T(v), T(wo), T(tr), None, e, T(Rm),
+                                              inv_pdf=T(inv_pdf), env_base=tb)
+    (Lo * T(gl)).sum().backward()
+    d = lambda a: torch.from_numpy(a).double().requires_grad_(True)      # noqa: E731
+    rn, ra, rr, rm, rb = d(n), d(alb), d(rough), d(met), d(base)
+    Lo_r, _, _ = TR.pbr_uniform_light_t(rn, ra, rr, rm, torch.from_numpy(v).double(), torch.from_numpy(wo).double(),
+                                         torch.from_numpy(tr).double(), rb, torch.from_numpy(Rm).double(),
+                                         torch.from_numpy(inv_pdf).double())
+    np.testing.assert_allclose(N(Lo), Lo_r.detach().numpy(), rtol=2e-3, atol=2e-4)
+    (Lo_r * torch.from_numpy(gl).double()).sum().backward()
+    for name, got, want in (("normal", tn.grad, rn.grad), ("albedo", ta.grad, ra.grad), ("roughness", tro.grad[:, 0], rr.grad),
+                            ("metallic", tm.grad[:, 0], rm.grad), ("env", tb.grad, rb.grad)):
+        g, w = got.detach().cpu().double().numpy(), want.numpy()
+        scale = np.abs(w).max()
+        bad = np.abs(g - w) > 2e-3 * scale + 2e-3 * np.abs(w)
+        assert bad.mean() < 2e-3, (name, float(bad.mean()), float(np.abs(g - w).max()), scale)

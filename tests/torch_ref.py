@@ -118,3 +118,54 @@ def shade_reference(P, fixed, target_rgb, target_mask, lambda_eik=0.1, lambda_ma
         op = opac[:, 0].clamp(1e-3, 1 - 1e-3)
         loss = loss + lambda_mask * torch.nn.functional.binary_cross_entropy(op, target_mask)
     return loss, dict(comp_rgb=comp, opacity=opac, sdf_grad=sdf_grad, rgbs=rgbs, alphas=alphas)
+
+
+# ----------------------------------------------------------------------------- PBR (fp64, differentiable)
+def brdf_eval_t(n, wi, wo, alpha, albedo, metallic):
+    """oracle/pbr_ref.brdf_eval in torch: (diff [F], spec [F,3]) incl. cosine."""
+    NoL = (n * wo).sum(-1)
+    NoV = (n * wi).sum(-1)
+    h = wi + wo
+    hl = h.norm(dim=-1, keepdim=True)
+    h = h / hl.clamp_min(1e-30)
+    NoH = (n * h).sum(-1)
+    VoH = (wi * h).sum(-1).clamp_min(0.0)
+    a2 = alpha ** 2
+    dd = NoH ** 2 * (a2 - 1) + 1
+    D = a2 / (math.pi * dd ** 2)
+    G1 = lambda x: 2 * x / (x + torch.sqrt(a2 + (1 - a2) * x ** 2))      # noqa: E731
+    common = D * G1(NoL) * G1(NoV) / (4 * NoV)
+    F0 = 0.04 * (1 - metallic[:, None]) + albedo * metallic[:, None]
+    Fr = F0 + (1 - F0) * ((1 - VoH) ** 5)[:, None]
+    lit = NoL > 0
+    diff = torch.where(lit, NoL / math.pi, torch.zeros_like(NoL))
+    ok = lit & (NoV > 0) & (hl[:, 0] >= 1e-12)
+    spec = torch.where(ok[:, None], common[:, None] * Fr, torch.zeros_like(Fr))
+    return diff, spec
+
+
+def env_eval_t(base, d):
+    """bilinear equirect lookup (wrap in u, clamp in v) of base [H,W,3] at world directions d [F,3]."""
+    H, W, _ = base.shape
+    u = torch.atan2(d[:, 0], -d[:, 2]) / (2 * math.pi) + 0.5
+    v = torch.acos(d[:, 1].clamp(-1, 1)) / math.pi
+    fx, fy = u * W - 0.5, v * H - 0.5
+    x0, y0 = torch.floor(fx), torch.floor(fy)
+    ax, ay = (fx - x0)[:, None], (fy - y0)[:, None]
+    x0, y0 = x0.long(), y0.long()
+    x1, y1 = (x0 + 1) % W, (y0 + 1).clamp(0, H - 1)
+    x0, y0 = x0 % W, y0.clamp(0, H - 1)
+    return (1 - ax) * (1 - ay) * base[y0, x0] + ax * (1 - ay) * base[y0, x1] + (1 - ax) * ay * base[y1, x0] + ax * ay * base[y1, x1]
+
+
+def pbr_uniform_light_t(n, albedo, rough, metal, view_dirs, wo, tr, base, R, inv_pdf):
+    """pbr_uniform_light_forward (intrinsic_avatar.py:654-753) on given directions / transmittance, fp64."""
+    cosm = (n * wo).sum(-1) > 1e-6
+    t = tr.clamp(0, 1) * cosm
+    diff, spec = brdf_eval_t(n, -view_dirs, wo, rough, albedo, metal)
+    dw = torch.nn.functional.normalize(wo @ R, dim=-1)
+    em = env_eval_t(base, dw)
+    Li = em * t[:, None]
+    w = (inv_pdf * cosm)[:, None]
+    Ld, Ls = Li * diff[:, None] * w, Li * spec * w
+    return ((1 - metal[:, None]) * albedo) * Ld + Ls, Ld, Ls
