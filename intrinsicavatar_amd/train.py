@@ -17,6 +17,7 @@ weight-gradient reductions dW = G^T A ([64 x n] x [n x <=68]) use the split-K MF
 shape to a single output tile walking K = millions of points).
 """
 import ctypes as C
+import math
 import os
 from typing import Dict, Optional
 
@@ -195,9 +196,27 @@ class _Radiance(Function):
         return (None, g_table, g_feat, g_refl01, g_nw, dW1, db1, dW2, db2, dW3, db3, None, None)
 
 
+def curvature_laplace(geo, pts_cano: Tensor, grad_c: Tensor, rand_u: Tensor, eps: float = 1e-4) -> Tensor:
+    """curvature term of VolumeSDF.forward(with_laplace=True) (models/rf/geometry.py:173-203, from PermutoSDF): angle / pi
+    between the analytic normal at x and at x + eps * tangent, tangent = normal x normalize(rand_u).  rand_u [n,3] in
+    [0,1) is an explicit input (torch.rand_like in the reference).  Both normals come out of _SDFField, so the loss
+    back-propagates through the second-order path of ia_sdf_mlp_bwd_fused / ia_hashgrid_bwd like the eikonal term.
+    Deviation: the dependence of the probe position x + eps * tangent on the parameters (an eps-scaled term that needs
+    d^2 enc / d x^2, which tiny-cuda-nn does not provide either) is dropped: the probe point is a constant."""
+    W1k, b1, W2, b2 = geo.effective_weights()
+    nrm = torch.nn.functional.normalize
+    with torch.no_grad():
+        tangent = torch.cross(nrm(grad_c, dim=-1, eps=1e-6), nrm(rand_u, dim=-1, eps=1e-6), dim=-1)
+        x_d = (pts_cano + eps * tangent).contiguous()
+    _, grad_d = _SDFField.apply(x_d, geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale)
+    dot = (nrm(grad_c, dim=-1, eps=1e-6) * nrm(grad_d, dim=-1, eps=1e-6)).sum(-1)
+    return torch.acos(dot.clamp(-1.0 + 1e-6, 1.0 - 1e-6)) / math.pi
+
+
 def shade_differentiable(rs, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor, t_starts: Tensor, t_ends: Tensor,
-                         packed_info: Tensor) -> Dict[str, Tensor]:
-    """differentiable rgb_normal_alpha_fn + rendering_with_normals_sdf for the samples found by the no-grad pass."""
+                         packed_info: Tensor, curv_u: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """differentiable rgb_normal_alpha_fn + rendering_with_normals_sdf for the samples found by the no-grad pass.
+    curv_u [n_samples,3]: uniforms for the curvature probe directions (enables out["sdf_laplace"])."""
     dfm, geo, rad = rs.deformer, rs.geometry, rs.radiance
     n_rays = packed_info.shape[0]
     pts = render.ray_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
@@ -222,13 +241,16 @@ def shade_differentiable(rs, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor
                            rad.center, rad.scale)
     weights, trans = nerfacc._WeightFromAlpha.apply(alphas, packed_info)
     acc = lambda v: nerfacc._Accumulate.apply(weights, v, ray_indices, packed_info)      # noqa: E731
-    return dict(comp_rgb=acc(rgbs), comp_normal=acc(normal_world), opacity=acc(None),
-                depth=acc(((t_starts + t_ends) / 2.0)[:, None]), weights=weights, alphas=alphas, rgbs=rgbs, sdf=sdf,
-                sdf_grad=sdf_grad, valid=valid, n_samples=pts.shape[0], pts_cano=d["pts_cano"], c2w=c2w)
+    res = dict(comp_rgb=acc(rgbs), comp_normal=acc(normal_world), opacity=acc(None),
+               depth=acc(((t_starts + t_ends) / 2.0)[:, None]), weights=weights, alphas=alphas, rgbs=rgbs, sdf=sdf,
+               sdf_grad=sdf_grad, valid=valid, n_samples=pts.shape[0], pts_cano=d["pts_cano"], c2w=c2w)
+    if curv_u is not None:       # laplace = 0 for points without a valid candidate (snarf_deformer.py:233-235)
+        res["sdf_laplace"] = curvature_laplace(geo, d["pts_cano"], grad_c, curv_u) * valid.float()
+    return res
 
 
 def training_loss(out: Dict[str, Tensor], target_rgb: Tensor, target_mask: Optional[Tensor] = None,
-                  lambda_eik: float = 0.1, lambda_mask: float = 0.1) -> Tensor:
+                  lambda_eik: float = 0.1, lambda_mask: float = 0.1, lambda_curv: float = 0.0) -> Tensor:
     """the rgb / eikonal / mask terms of systems/intrinsic_avatar.py:167-251 (L1 rgb, (|grad|-1)^2, BCE opacity)."""
     loss = (out["comp_rgb"] - target_rgb).abs().mean()
     v = out["valid"]
@@ -237,4 +259,6 @@ def training_loss(out: Dict[str, Tensor], target_rgb: Tensor, target_mask: Optio
     if target_mask is not None:
         op = out["opacity"][:, 0].clamp(1e-3, 1 - 1e-3)
         loss = loss + lambda_mask * torch.nn.functional.binary_cross_entropy(op, target_mask)
+    if lambda_curv > 0.0 and "sdf_laplace" in out:            # systems/intrinsic_avatar.py:265-268
+        loss = loss + lambda_curv * out["sdf_laplace"].abs().mean()
     return loss

@@ -16,6 +16,7 @@ def frame():
     from intrinsicavatar_amd import synthetic as S
     rs, rays, export = S.build_frame("cuda:0", 48, 48, pose_seed=1, beta=0.05, num_samples_per_ray=32, grid_D=16, grid_H=64,
                                      grid_W=64, smooth_iters=3, hash_amp=3e-2)
+    torch.manual_seed(1234)                    # the perturbation below defines the problem instance: keep it fixed
     with torch.no_grad():                      # make every weight matter
         for p in rs.radiance.network.parameters():
             p.add_(torch.randn_like(p) * 0.05)
@@ -26,16 +27,19 @@ def frame():
     return rs, rays
 
 
-def test_forward_backward_vs_torch_autograd(frame):
+@pytest.mark.parametrize("lambda_curv", [0.0, 0.5])
+def test_forward_backward_vs_torch_autograd(frame, lambda_curv):
+    """lambda_curv > 0 adds the curvature regulariser (second SDF evaluation at x + 1e-4 tangent, geometry.py:173-203)."""
     from tests import torch_ref as TR
     rs, rays = frame
     n = rays.shape[0]
     g = torch.Generator().manual_seed(0)
     target = torch.rand((n, 3), generator=g).cuda()
     tmask = (torch.rand(n, generator=g) > 0.5).float().cuda()
+    curv_u = torch.rand((200000, 3), generator=g).cuda() if lambda_curv > 0 else None
     for p in rs.parameters():
         p.grad = None
-    out = rs.forward_backward(rays, target, tmask)
+    out = rs.forward_backward(rays, target, tmask, curv_u=curv_u, lambda_curv=lambda_curv)
     assert out["n_samples"] > 3000 and bool(out["valid"].any())
     geo, rad, dens = rs.geometry, rs.radiance, rs.density
     D = lambda t: t.detach().cpu().double()      # noqa: E731
@@ -59,7 +63,9 @@ def test_forward_backward_vs_torch_autograd(frame):
     _, _, _, ts, te, ri, pi2, _ = rs.sample(rays)
     assert ts.shape[0] == out["n_samples"]
     fixed.update(ray_indices=ri.cpu(), t_starts=D(ts), t_ends=D(te), packed_info=pi2.cpu())
-    loss_ref, ref = TR.shade_reference(P, fixed, D(target), D(tmask))
+    if lambda_curv > 0:
+        fixed["curv_u"] = D(curv_u[:ts.shape[0]])
+    loss_ref, ref = TR.shade_reference(P, fixed, D(target), D(tmask), lambda_curv=lambda_curv)
     loss_ref.backward()
     assert abs(float(out["loss"]) - float(loss_ref)) < 2e-4 * max(1.0, abs(float(loss_ref)))
     # fp32 (kernels) vs fp64 (reference): a sample within rounding distance of a hash-cell face lands in the

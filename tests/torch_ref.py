@@ -65,7 +65,7 @@ def sh4(d01):
         0.59004358992664352 * x * (-x2 + 3.0 * y2)], -1)
 
 
-def shade_reference(P, fixed, target_rgb, target_mask, lambda_eik=0.1, lambda_mask=0.1):
+def shade_reference(P, fixed, target_rgb, target_mask, lambda_eik=0.1, lambda_mask=0.1, lambda_curv=0.0):
     """P: dict of float64 leaf tensors (requires_grad) in the REFERENCE layout; fixed: sample set found by the GPU."""
     x = fixed["pts_cano"].clone().requires_grad_(True)
     valid = fixed["valid"]
@@ -78,6 +78,17 @@ def shade_reference(P, fixed, target_rgb, target_mask, lambda_eik=0.1, lambda_ma
     a = torch.nn.functional.softplus(h @ W1.T + P["geo_b0"], beta=100)
     out = a @ W2.T + P["geo_b2"]
     grad_c = torch.autograd.grad(out[:, 0], x, torch.ones_like(out[:, 0]), create_graph=True)[0]
+    laplace = None
+    if lambda_curv > 0.0:        # geometry.py:173-203 with the probe point treated as a constant
+        nz = torch.nn.functional.normalize
+        tang = torch.cross(nz(grad_c.detach(), dim=-1, eps=1e-6), nz(fixed["curv_u"], dim=-1, eps=1e-6), dim=-1)
+        x_d = (x.detach() + 1e-4 * tang).requires_grad_(True)
+        xp_d = (x_d - P["geo_center"]) / P["geo_scale"] + 0.5
+        h_d = torch.cat([xp_d * 2 - 1, hashgrid(xp_d, P["geo_table"].reshape(-1, 2)) * P["geo_mask"]], -1)
+        sdf_d = (torch.nn.functional.softplus(h_d @ W1.T + P["geo_b0"], beta=100) @ W2.T + P["geo_b2"])[:, 0]
+        grad_d = torch.autograd.grad(sdf_d, x_d, torch.ones_like(sdf_d), create_graph=True)[0]
+        dot = (nz(grad_c, dim=-1, eps=1e-6) * nz(grad_d, dim=-1, eps=1e-6)).sum(-1)
+        laplace = torch.acos(dot.clamp(-1 + 1e-6, 1 - 1e-6)) / math.pi * valid.double()
     vf = valid[:, None].double()
     feat = out * vf
     sdf = torch.where(valid, out[:, 0], torch.full_like(out[:, 0], 1e5))
@@ -117,6 +128,8 @@ def shade_reference(P, fixed, target_rgb, target_mask, lambda_eik=0.1, lambda_ma
     if target_mask is not None:
         op = opac[:, 0].clamp(1e-3, 1 - 1e-3)
         loss = loss + lambda_mask * torch.nn.functional.binary_cross_entropy(op, target_mask)
+    if laplace is not None:
+        loss = loss + lambda_curv * laplace.abs().mean()
     return loss, dict(comp_rgb=comp, opacity=opac, sdf_grad=sdf_grad, rgbs=rgbs, alphas=alphas)
 
 
