@@ -92,9 +92,11 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fwd_kernel(MlpArgs a)
     __syncthreads();
 
     const int64_t n_tiles = (a.n + TM - 1) / TM;
+    // (tried: register prefetch of the next tile's segments -- at 12 waves / CU it spills (168-register budget), at
+    //  8 waves / CU it loses more to the missing third wave than it gains: 0.48 / 0.46 vs 0.50 / 0.56 MFMA utilisation)
     for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WAVES) {
         const int64_t p0 = tile * TM;
-        // ---- assemble the input rows in LDS ----
+        // ---- assemble the input rows in LDS (all global loads of the tile in flight together) ----
         mlp::assemble<KIND, IN, TM>(sX, LDX, a.segs, p0, a.n, lane);
 
         const int lr = lane & 31, lk = lane >> 5;
@@ -106,15 +108,27 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fwd_kernel(MlpArgs a)
             for (int nt = 0; nt < 2; nt++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[m][nt][r] = 0.0f;
-#pragma unroll 2
-        for (int kk = 0; kk < IN_PAD / 2; kk++) {
-            const int k = 2 * kk + lk;
-            const float b0 = sW1[lr * LDW1 + k], b1v = sW1[(32 + lr) * LDW1 + k];
+        {   // software-pipelined: the operands of k-step kk+1 are fetched from LDS while the MFMAs of kk run
+            float b0n = sW1[lr * LDW1 + lk], b1n = sW1[(32 + lr) * LDW1 + lk], an[MT];
 #pragma unroll
-            for (int m = 0; m < MT; m++) {
-                const float av = sX[(32 * m + lr) * LDX + k];
-                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[m][0], 0, 0, 0);
-                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1v, acc[m][1], 0, 0, 0);
+            for (int m = 0; m < MT; m++) an[m] = sX[(32 * m + lr) * LDX + lk];
+#pragma unroll 2
+            for (int kk = 0; kk < IN_PAD / 2; kk++) {
+                const float b0 = b0n, b1v = b1n;
+                float av[MT];
+#pragma unroll
+                for (int m = 0; m < MT; m++) av[m] = an[m];
+                if (kk + 1 < IN_PAD / 2) {
+                    const int k = 2 * (kk + 1) + lk;
+                    b0n = sW1[lr * LDW1 + k]; b1n = sW1[(32 + lr) * LDW1 + k];
+#pragma unroll
+                    for (int m = 0; m < MT; m++) an[m] = sX[(32 * m + lr) * LDX + k];
+                }
+#pragma unroll
+                for (int m = 0; m < MT; m++) {
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], b0, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], b1v, acc[m][1], 0, 0, 0);
+                }
             }
         }
         // epilogue: bias + activation -> sX (in place: all reads of the old tile are complete)
@@ -144,15 +158,27 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fwd_kernel(MlpArgs a)
                 for (int nt = 0; nt < 2; nt++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) acc[m][nt][r] = 0.0f;
-#pragma unroll 2
-            for (int kk = 0; kk < HID / 2; kk++) {
-                const int k = 2 * kk + lk;
-                const float b0 = sW2[lr * LDW + k], b1v = sW2[(32 + lr) * LDW + k];
+            {
+                float b0n = sW2[lr * LDW + lk], b1n = sW2[(32 + lr) * LDW + lk], an[MT];
 #pragma unroll
-                for (int m = 0; m < MT; m++) {
-                    const float av = sX[(32 * m + lr) * LDX + k];
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1v, acc[m][1], 0, 0, 0);
+                for (int m = 0; m < MT; m++) an[m] = sX[(32 * m + lr) * LDX + lk];
+#pragma unroll 2
+                for (int kk = 0; kk < HID / 2; kk++) {
+                    const float b0 = b0n, b1v = b1n;
+                    float av[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; m++) av[m] = an[m];
+                    if (kk + 1 < HID / 2) {
+                        const int k = 2 * (kk + 1) + lk;
+                        b0n = sW2[lr * LDW + k]; b1n = sW2[(32 + lr) * LDW + k];
+#pragma unroll
+                        for (int m = 0; m < MT; m++) an[m] = sX[(32 * m + lr) * LDX + k];
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; m++) {
+                        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], b0, acc[m][0], 0, 0, 0);
+                        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], b1v, acc[m][1], 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll
@@ -174,13 +200,23 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fwd_kernel(MlpArgs a)
             for (int m = 0; m < OT; m++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) o[m][r] = 0.0f;
+            float bn = sWo[l15 * LDW + l4], xn[OT];
+#pragma unroll
+            for (int m = 0; m < OT; m++) xn[m] = sX[(16 * m + l15) * LDX + l4];
 #pragma unroll 4
             for (int kk = 0; kk < HID / 4; kk++) {
-                const int k = 4 * kk + l4;
-                const float b = sWo[l15 * LDW + k];
+                const float b = bn;
+                float xv[OT];
 #pragma unroll
-                for (int m = 0; m < OT; m++)
-                    o[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(sX[(16 * m + l15) * LDX + k], b, o[m], 0, 0, 0);
+                for (int m = 0; m < OT; m++) xv[m] = xn[m];
+                if (kk + 1 < HID / 4) {
+                    const int k = 4 * (kk + 1) + l4;
+                    bn = sWo[l15 * LDW + k];
+#pragma unroll
+                    for (int m = 0; m < OT; m++) xn[m] = sX[(16 * m + l15) * LDX + k];
+                }
+#pragma unroll
+                for (int m = 0; m < OT; m++) o[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[m], b, o[m], 0, 0, 0);
             }
             if (l15 < OUT) {
                 const float bias = sB[128 + l15];
@@ -214,16 +250,29 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fwd_kernel(MlpArgs a)
                 for (int nt = 0; nt < 2; nt++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) acc[m][nt][r] = 0.0f;
-#pragma unroll 2
-            for (int kk = 0; kk < HID / 2; kk++) {
-                const int k = 2 * kk + lk;
-                const float b0 = (lr < IN_PAD) ? sW1[k * LDW1 + lr] : 0.0f;
-                const float b1v = (32 + lr < IN_PAD) ? sW1[k * LDW1 + 32 + lr] : 0.0f;
+            {
+                const bool c0ok = lr < IN_PAD, c1ok = 32 + lr < IN_PAD;
+                float b0n = c0ok ? sW1[lk * LDW1 + lr] : 0.0f, b1n = c1ok ? sW1[lk * LDW1 + 32 + lr] : 0.0f, an[MT];
 #pragma unroll
-                for (int m = 0; m < MT; m++) {
-                    const float av = sG[(32 * m + lr) * LDX + k];
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1v, acc[m][1], 0, 0, 0);
+                for (int m = 0; m < MT; m++) an[m] = sG[(32 * m + lr) * LDX + lk];
+#pragma unroll 2
+                for (int kk = 0; kk < HID / 2; kk++) {
+                    const float b0 = b0n, b1v = b1n;
+                    float av[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; m++) av[m] = an[m];
+                    if (kk + 1 < HID / 2) {
+                        const int k = 2 * (kk + 1) + lk;
+                        b0n = c0ok ? sW1[k * LDW1 + lr] : 0.0f;
+                        b1n = c1ok ? sW1[k * LDW1 + 32 + lr] : 0.0f;
+#pragma unroll
+                        for (int m = 0; m < MT; m++) an[m] = sG[(32 * m + lr) * LDX + k];
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; m++) {
+                        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], b0, acc[m][0], 0, 0, 0);
+                        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], b1v, acc[m][1], 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll

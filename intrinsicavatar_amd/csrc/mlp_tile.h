@@ -20,37 +20,74 @@ template <> struct SegWidths<0> { static constexpr int n = 2; static constexpr i
 template <> struct SegWidths<1> { static constexpr int n = 5; static constexpr int w[MAX_SEGS] = {32, 3, 13, 16, 3}; };
 template <> struct SegWidths<2> { static constexpr int n = 3; static constexpr int w[MAX_SEGS] = {32, 3, 13, 0, 0}; };
 
-template <int WIDTH, int ROWS = 64>
-__device__ __forceinline__ void load_segment(float* sT, int ldx, int col0, const Seg& sg, int64_t p0, int64_t n, int lane)
+// Two-phase segment transfer: all global loads of a tile are issued into registers first (SegRegs), the LDS stores
+// follow -- one exposed global-load latency per tile instead of one per segment.
+template <int WIDTH, int ROWS>
+struct SegRegs {
+    static constexpr int NV = (WIDTH % 4 == 0) ? (ROWS * (WIDTH / 4) + 63) / 64 : 0;     // float4 pieces per lane
+    static constexpr int NS = (ROWS * WIDTH + 63) / 64;                                  // scalars per lane
+    float4 q[NV > 0 ? NV : 1];
+    float v[NS > 0 ? NS : 1];
+    bool vec;
+};
+
+template <int WIDTH, int ROWS>
+__device__ __forceinline__ void seg_load(SegRegs<WIDTH, ROWS>& r, const Seg& sg, int64_t p0, int64_t n, int lane)
 {
     if constexpr (WIDTH == 0) return;
+    r.vec = false;
     if constexpr (WIDTH % 4 == 0) {
         // 16-byte loads when the rows allow it (hash features: 32 wide, SH: 16 wide)
-        const bool vec_ok = ((sg.stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(sg.p) & 15) == 0);
-        if (vec_ok) {
+        r.vec = ((sg.stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(sg.p) & 15) == 0);
+        if (r.vec) {
             constexpr int V = WIDTH / 4;
 #pragma unroll
-            for (int i0 = 0; i0 < ROWS * V; i0 += 64) {
-                const int i = i0 + lane;
-                const int r = i / V, c4 = i % V;
-                const int64_t p = p0 + r;
-                if ((ROWS * V) % 64 != 0 && i >= ROWS * V) break;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p < n) v = *reinterpret_cast<const float4*>(sg.p + p * sg.stride + c4 * 4);
-                float* d = sT + r * ldx + col0 + c4 * 4;
-                d[0] = v.x * sg.mul + sg.add; d[1] = v.y * sg.mul + sg.add;
-                d[2] = v.z * sg.mul + sg.add; d[3] = v.w * sg.mul + sg.add;
+            for (int j = 0; j < SegRegs<WIDTH, ROWS>::NV; j++) {
+                const int i = j * 64 + lane;
+                const int row = i / V, c4 = i % V;
+                const int64_t p = p0 + row;
+                r.q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < ROWS * V && p < n) r.q[j] = *reinterpret_cast<const float4*>(sg.p + p * sg.stride + c4 * 4);
             }
             return;
         }
     }
 #pragma unroll
-    for (int i0 = 0; i0 < ROWS * WIDTH; i0 += 64) {
-        const int i = i0 + lane;
-        const int r = i / WIDTH, c = i % WIDTH;
-        const int64_t p = p0 + r;
-        if ((ROWS * WIDTH) % 64 != 0 && i >= ROWS * WIDTH) break;
-        sT[r * ldx + col0 + c] = (p < n) ? sg.p[p * sg.stride + c] * sg.mul + sg.add : 0.0f;
+    for (int j = 0; j < SegRegs<WIDTH, ROWS>::NS; j++) {
+        const int i = j * 64 + lane;
+        const int row = i / WIDTH, c = i % WIDTH;
+        const int64_t p = p0 + row;
+        r.v[j] = (i < ROWS * WIDTH && p < n) ? sg.p[p * sg.stride + c] : 0.0f;
+    }
+}
+
+template <int WIDTH, int ROWS>
+__device__ __forceinline__ void seg_store(const SegRegs<WIDTH, ROWS>& r, float* sT, int ldx, int col0, const Seg& sg,
+                                          int64_t p0, int64_t n, int lane)
+{
+    if constexpr (WIDTH == 0) return;
+    if constexpr (WIDTH % 4 == 0) {
+        if (r.vec) {
+            constexpr int V = WIDTH / 4;
+#pragma unroll
+            for (int j = 0; j < SegRegs<WIDTH, ROWS>::NV; j++) {
+                const int i = j * 64 + lane;
+                if (i >= ROWS * V) break;
+                const int row = i / V, c4 = i % V;
+                const bool ok = p0 + row < n;           // rows beyond n: zeros (NOT add), as the one-phase path did
+                float* d = sT + row * ldx + col0 + c4 * 4;
+                d[0] = ok ? r.q[j].x * sg.mul + sg.add : 0.0f; d[1] = ok ? r.q[j].y * sg.mul + sg.add : 0.0f;
+                d[2] = ok ? r.q[j].z * sg.mul + sg.add : 0.0f; d[3] = ok ? r.q[j].w * sg.mul + sg.add : 0.0f;
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < SegRegs<WIDTH, ROWS>::NS; j++) {
+        const int i = j * 64 + lane;
+        if (i >= ROWS * WIDTH) break;
+        const int row = i / WIDTH, c = i % WIDTH;
+        sT[row * ldx + col0 + c] = (p0 + row < n) ? r.v[j] * sg.mul + sg.add : 0.0f;
     }
 }
 
@@ -59,11 +96,15 @@ __device__ __forceinline__ void assemble(float* sT, int ldx, const Seg* segs, in
 {
     using SW = SegWidths<KIND>;
     constexpr int IN_PAD = (IN + 1) / 2 * 2;
-    load_segment<SW::w[0], ROWS>(sT, ldx, 0, segs[0], p0, n, lane);
-    load_segment<SW::w[1], ROWS>(sT, ldx, SW::w[0], segs[1], p0, n, lane);
-    load_segment<SW::w[2], ROWS>(sT, ldx, SW::w[0] + SW::w[1], segs[2], p0, n, lane);
-    load_segment<SW::w[3], ROWS>(sT, ldx, SW::w[0] + SW::w[1] + SW::w[2], segs[3], p0, n, lane);
-    load_segment<SW::w[4], ROWS>(sT, ldx, SW::w[0] + SW::w[1] + SW::w[2] + SW::w[3], segs[4], p0, n, lane);
+    SegRegs<SW::w[0], ROWS> r0; SegRegs<SW::w[1], ROWS> r1; SegRegs<SW::w[2], ROWS> r2;
+    SegRegs<SW::w[3], ROWS> r3; SegRegs<SW::w[4], ROWS> r4;
+    seg_load(r0, segs[0], p0, n, lane); seg_load(r1, segs[1], p0, n, lane); seg_load(r2, segs[2], p0, n, lane);
+    seg_load(r3, segs[3], p0, n, lane); seg_load(r4, segs[4], p0, n, lane);
+    seg_store(r0, sT, ldx, 0, segs[0], p0, n, lane);
+    seg_store(r1, sT, ldx, SW::w[0], segs[1], p0, n, lane);
+    seg_store(r2, sT, ldx, SW::w[0] + SW::w[1], segs[2], p0, n, lane);
+    seg_store(r3, sT, ldx, SW::w[0] + SW::w[1] + SW::w[2], segs[3], p0, n, lane);
+    seg_store(r4, sT, ldx, SW::w[0] + SW::w[1] + SW::w[2] + SW::w[3], segs[4], p0, n, lane);
     if (IN_PAD > IN && lane < ROWS) sT[lane * ldx + IN] = 0.0f;
 }
 
