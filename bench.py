@@ -55,8 +55,8 @@ def algorithmic_bytes(name, stats):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--hw", type=int, default=540)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pass", dest="mode", choices=["fwd+bwd", "fwd"], default="fwd+bwd",

@@ -17,30 +17,60 @@ namespace {
 constexpr int THREADS = 256;
 
 // ---- 1. filter + count ---------------------------------------------------------
+// The candidates of a workgroup's 256 points are one contiguous 40 KB block: it is staged into LDS with coalesced
+// 16-byte loads (a lane-per-point read of 12-byte pieces at a 156-byte stride fetched ~5x the bytes from the fabric),
+// the O(I^2) pair test then runs out of LDS (row stride 39 words: conflict-free).  Same arithmetic as before.
+constexpr int FC_MAX_I = 16;
 __global__ __launch_bounds__(THREADS) void filter_count_kernel(int64_t P, int I, const float* __restrict__ x,
                                                                 const uint8_t* __restrict__ valid,
                                                                 uint8_t* __restrict__ mask, int32_t* __restrict__ cnt)
 {
-    const int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (p >= P) return;
+    extern __shared__ __attribute__((aligned(16))) float s_x[];       // [THREADS][I*3]
+    uint8_t* s_v = reinterpret_cast<uint8_t*>(s_x + THREADS * I * 3);  // [THREADS][I]
+    const int64_t p0 = (int64_t)blockIdx.x * THREADS;
+    const int rows = (int)((P - p0) < THREADS ? (P - p0) : THREADS);
+    const int nf = rows * I * 3, nb = rows * I;
+    const float* gx = x + p0 * I * 3;
+    const uint8_t* gv = valid + p0 * I;
+    if ((reinterpret_cast<uintptr_t>(gx) & 15) == 0) {
+        const float4* g4 = reinterpret_cast<const float4*>(gx);
+        float4* s4 = reinterpret_cast<float4*>(s_x);
+        for (int i = threadIdx.x; i < nf / 4; i += THREADS) s4[i] = g4[i];
+        for (int i = (nf / 4) * 4 + threadIdx.x; i < nf; i += THREADS) s_x[i] = gx[i];
+    } else {
+        for (int i = threadIdx.x; i < nf; i += THREADS) s_x[i] = gx[i];
+    }
+    for (int i = threadIdx.x; i < nb; i += THREADS) s_v[i] = gv[i];
+    __syncthreads();
+    const int t = threadIdx.x;
+    const bool live = t < rows;
+    const float* xr = s_x + t * I * 3;
+    const uint8_t* vr = s_v + t * I;
     int c = 0;
-    for (int i = 0; i < I; i++) {
-        bool keep = valid[p * I + i] != 0;
+    unsigned keep_bits = 0;
+    for (int i = 0; live && i < I; i++) {
+        bool keep = vr[i] != 0;
         if (keep) {
-            const float xi0 = x[(p * I + i) * 3 + 0], xi1 = x[(p * I + i) * 3 + 1], xi2 = x[(p * I + i) * 3 + 2];
+            const float xi0 = xr[i * 3 + 0], xi1 = xr[i * 3 + 1], xi2 = xr[i * 3 + 2];
             for (int j = i + 1; j < I; j++) {
-                if (!valid[p * I + j]) continue;
-                const float d0 = xi0 - x[(p * I + j) * 3 + 0];
-                const float d1 = xi1 - x[(p * I + j) * 3 + 1];
-                const float d2 = xi2 - x[(p * I + j) * 3 + 2];
+                if (!vr[j]) continue;
+                const float d0 = xi0 - xr[j * 3 + 0];
+                const float d1 = xi1 - xr[j * 3 + 1];
+                const float d2 = xi2 - xr[j * 3 + 2];
                 const float dist = d0 * d0 + d1 * d1 + d2 * d2;
                 if ((double)dist < 0.0001 * 0.0001) { keep = false; break; }
             }
         }
-        mask[p * I + i] = keep ? 1 : 0;
+        keep_bits |= (keep ? 1u : 0u) << i;
         c += keep ? 1 : 0;
     }
-    cnt[p] = c;
+    if (live) cnt[p0 + t] = c;
+    // mask rows back through LDS so that the byte stores are coalesced too
+    __syncthreads();
+    for (int i = 0; live && i < I; i++) s_v[t * I + i] = (keep_bits >> i) & 1u;
+    __syncthreads();
+    uint8_t* gm = mask + p0 * I;
+    for (int i = threadIdx.x; i < nb; i += THREADS) gm[i] = s_v[i];
 }
 
 // ---- 2. packed candidate list --------------------------------------------------
@@ -261,7 +291,9 @@ IA_EXPORT int ia_deform_filter_count(int64_t P, int I, const float* x, const uin
                                      int32_t* cnt, ia_stream_t stream)
 {
     if (P == 0) return IA_OK;
-    filter_count_kernel<<<ia::cdiv(P, THREADS), THREADS, 0, (hipStream_t)stream>>>(P, I, x, valid, mask, cnt);
+    IA_REQUIRE(I >= 1 && I <= FC_MAX_I, "ia_deform_filter_count: at most 16 initialisations per point");
+    const size_t lds = (size_t)THREADS * I * 3 * sizeof(float) + (size_t)THREADS * I + 16;
+    filter_count_kernel<<<ia::cdiv(P, THREADS), THREADS, lds, (hipStream_t)stream>>>(P, I, x, valid, mask, cnt);
     return ia::check_launch("ia_deform_filter_count");
 }
 
