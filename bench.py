@@ -52,6 +52,34 @@ def algorithmic_bytes(name, stats):
     }.get(name)
 
 
+# C-ABI entry point -> kernels it launches (substring match on the rocprofv3 kernel names); "alt": one of them runs per
+# call, "seq": all of them run once per call
+PMC_KERNELS = {
+    "ia_fuse_broyden": ("alt", ["broyden_persistent_kernel", "broyden_kernel"]),
+    "ia_hashgrid_fwd": ("alt", ["hash_fwd_kernel<false>", "hash_fwd_kernel<true>"]),
+    "ia_hashgrid_bwd_binned": ("seq", ["hash_bin_kernel", "hash_reduce_kernel"]),
+    "ia_mlp_fwd": ("alt", ["mlp_fwd_kernel"]),
+    "ia_mlp_bwd_fused": ("alt", ["mlp2_train_kernel"]),
+    "ia_sdf_mlp_bwd_fused": ("alt", ["sdf_train_kernel"]),
+}
+
+
+def pmc_traffic(entry):
+    """HBM-side bytes per launch of `entry` from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
+    2 x FETCH_SIZE + WRITE_SIZE, per MI355X_MICROARCH.md), or None when the entry point has not been profiled."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if entry not in PMC_KERNELS or not os.path.exists(path):
+        return None
+    mode, subs = PMC_KERNELS[entry]
+    ks = json.load(open(path))["kernels"]
+    hits = [v for k, v in ks.items() if any(sub in k for sub in subs)]
+    if not hits:
+        return None
+    tot = sum(v["hbm_side_bytes_per_launch"] * v["launches"] for v in hits)
+    calls = sum(v["launches"] for v in hits) if mode == "alt" else max(v["launches"] for v in hits)
+    return int(tot / max(calls, 1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,7 +179,9 @@ def main():
             avg_us = dms / dcalls * 1e3
             achieved = per_launch_bytes / (avg_us * 1e-6) / 1e9
             roofline = dict(kernel=dname, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                            frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=None,
+                            frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=pmc_traffic(dname),
+                            traffic_source="profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per "
+                                           "launch, separate passes, tools/pmc_collect.sh)",
                             avg_launch_us=round(avg_us, 1), launches_per_step=launches_per_step,
                             algorithmic_bytes_per_launch=int(per_launch_bytes),
                             share_of_kernel_time=round(dms / max(total_ms, 1e-9), 3))
