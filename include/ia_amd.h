@@ -185,6 +185,13 @@ int64_t ia_hashgrid_n_entries(int n_levels, int log2_hashmap_size, int base_reso
 int ia_hashgrid_fwd(int64_t n, const float* x /*[n,3]*/, const float* params, int n_levels, int n_features,
                     int log2_hashmap_size, int base_resolution, float per_level_scale,
                     float* out, int out_stride, float* dy_dx /*or NULL*/, ia_stream_t stream);
+/* XCD-partitioned variant for large batches (same outputs): each XCD gathers from ONE level's table, which then
+ * fits its 4 MiB L2, instead of sixteen; level-major intermediate in `scratch` (ia_hashgrid_fwd_scratch_bytes) +
+ * a transpose pass.  Relies on the observed block -> XCD round-robin for speed only. */
+int64_t ia_hashgrid_fwd_scratch_bytes(int64_t n, int n_levels, int with_jac);
+int ia_hashgrid_fwd_xcd(int64_t n, const float* x, const float* params, int n_levels, int n_features,
+                        int log2_hashmap_size, int base_resolution, float per_level_scale, float* out, int out_stride,
+                        float* dy_dx, void* scratch, ia_stream_t stream);
 /* backward w.r.t. the table (atomic accumulate into grad_params, caller zeroes it):
  *   grad[c] += g_enc[l,:] * w_c  +  g_jac[l,:] * sum_a q[a] * d w_c / d x_a
  * The second term (g_jac, q both non-NULL) is the double-backward needed when a loss depends on

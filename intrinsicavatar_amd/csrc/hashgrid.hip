@@ -114,6 +114,117 @@ __global__ __launch_bounds__(THREADS) void hash_fwd_kernel(int64_t n, const floa
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward, XCD-PARTITIONED (large batches).  The level-major kernel above pulls ~4 KB per point through the fabric
+// (every 8-byte gather of a fine level drags a 64-byte sector out of the Infinity Cache: measured 18 GB per 4.4 M
+// points at 6.2 TB/s, L2 hit rate 0.6), because each XCD's 4 MiB L2 sees all sixteen 4 MB level tables.  Here a
+// workgroup's levels are chosen by the XCD it runs on (block b -> XCD b % 8, observed dispatch order; used for speed
+// only -- any placement computes the same result): pass A gives each XCD ONE hashed level for all points, pass B
+// splits the remaining levels over XCD pairs (half the points each), so the table an XCD gathers from fits its L2.
+// Lanes are consecutive points (coalesced 12-byte reads, 8-byte level-major writes); a transpose kernel then builds
+// the [n, 2L] rows (and the Jacobian rows) the consumers expect.
+struct XcdPlan {
+    int first_level[8], n_level[8];     // levels handled by the workgroups of this XCD slot
+    int part[8], nparts[8];             // this slot covers points [part, part+1) / nparts of the batch
+};
+
+template <bool WITH_JAC>
+__global__ __launch_bounds__(THREADS) void hash_fwd_xcd_kernel(int64_t n, const float* __restrict__ x,
+                                                                const float2* __restrict__ params, HashCfg cfg, XcdPlan plan,
+                                                                float2* __restrict__ tmp /*[L][n]*/,
+                                                                float* __restrict__ tmp_jac /*[L][n][6]*/)
+{
+    const int slot = blockIdx.x & 7;
+    const int64_t chunk = blockIdx.x >> 3, nchunks = gridDim.x >> 3;
+    const int np = plan.nparts[slot];
+    const int64_t per = (n + np - 1) / np;
+    const int64_t lo = per * plan.part[slot], hi = (lo + per < n) ? lo + per : n;
+    for (int64_t i = lo + chunk * THREADS + threadIdx.x; i < hi; i += nchunks * THREADS) {
+        const float xs[3] = {x[i * 3 + 0], x[i * 3 + 1], x[i * 3 + 2]};
+        for (int l = plan.first_level[slot]; l < plan.first_level[slot] + plan.n_level[slot]; l++) {
+            const float sc = cfg.scale[l];
+            const uint32_t res = cfg.res[l], hsize = cfg.offsets[l + 1] - cfg.offsets[l];
+            const float2* tab = params + cfg.offsets[l];
+            float pos[3];
+            uint32_t pg[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const float p = fmaf(sc, xs[d], 0.5f);
+                const float fl = floorf(p);
+                pg[d] = (uint32_t)(int)fl;
+                pos[d] = p - fl;
+            }
+            float2 v[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const uint32_t idx = grid_index(hsize, res, pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1));
+                v[c] = tab[idx];
+            }
+            float a0 = 0.f, a1 = 0.f;
+            float j0[3] = {0.f, 0.f, 0.f}, j1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const float wx = (c & 1) ? pos[0] : 1.0f - pos[0];
+                const float wy = (c & 2) ? pos[1] : 1.0f - pos[1];
+                const float wz = (c & 4) ? pos[2] : 1.0f - pos[2];
+                const float w = wx * wy * wz;
+                a0 += w * v[c].x;
+                a1 += w * v[c].y;
+                if (WITH_JAC) {
+                    const float dx = ((c & 1) ? sc : -sc) * wy * wz;
+                    const float dy = ((c & 2) ? sc : -sc) * wx * wz;
+                    const float dz = ((c & 4) ? sc : -sc) * wx * wy;
+                    j0[0] += dx * v[c].x; j0[1] += dy * v[c].x; j0[2] += dz * v[c].x;
+                    j1[0] += dx * v[c].y; j1[1] += dy * v[c].y; j1[2] += dz * v[c].y;
+                }
+            }
+            tmp[(int64_t)l * n + i] = make_float2(a0, a1);
+            if (WITH_JAC) {
+                float2* J = reinterpret_cast<float2*>(tmp_jac + ((int64_t)l * n + i) * 6);
+                J[0] = make_float2(j0[0], j0[1]); J[1] = make_float2(j0[2], j1[0]); J[2] = make_float2(j1[1], j1[2]);
+            }
+        }
+    }
+}
+
+// level-major [L][n] -> rows [n, 2L] (+ Jacobian [L][n][6] -> [n, 2L, 3]); one workgroup = 256 points, through LDS
+template <bool WITH_JAC>
+__global__ __launch_bounds__(THREADS) void hash_transpose_kernel(int64_t n, int L, const float2* __restrict__ tmp,
+                                                                  const float* __restrict__ tmp_jac, float* __restrict__ out,
+                                                                  int out_stride, float* __restrict__ dy_dx)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_t[];      // [256][2L+1]  (and [256][6L+1] for the Jacobian)
+    const int64_t p0 = (int64_t)blockIdx.x * THREADS;
+    const int rows = (int)((n - p0) < THREADS ? (n - p0) : THREADS);
+    const int ld = 2 * L + 1;
+    for (int l = 0; l < L; l++)
+        if ((int)threadIdx.x < rows) {
+            const float2 v = tmp[(int64_t)l * n + p0 + threadIdx.x];
+            s_t[threadIdx.x * ld + 2 * l] = v.x; s_t[threadIdx.x * ld + 2 * l + 1] = v.y;
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows * 2 * L; i += THREADS) {
+        const int r = i / (2 * L), c = i % (2 * L);
+        out[(p0 + r) * out_stride + c] = s_t[r * ld + c];
+    }
+    if (WITH_JAC) {
+        __syncthreads();
+        const int ldj = 6 * L + 1;
+        for (int l = 0; l < L; l++)
+            if ((int)threadIdx.x < rows) {
+                const float* J = tmp_jac + ((int64_t)l * n + p0 + threadIdx.x) * 6;
+#pragma unroll
+                for (int k = 0; k < 6; k++) s_t[threadIdx.x * ldj + 6 * l + k] = J[k];
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < rows * 6 * L; i += THREADS) {
+            const int r = i / (6 * L), c = i % (6 * L);
+            dy_dx[(p0 + r) * 6 * L + c] = s_t[r * ldj + c];
+        }
+    }
+}
+
 // backward w.r.t. the table:
 //   grad[c] += gE[l,:] * w_c  +  gG[l,:] * sum_a q[a] * d w_c / d x_a      (second term optional)
 template <bool SECOND>
@@ -682,6 +793,77 @@ IA_EXPORT int ia_hashgrid_fwd(int64_t n, const float* x, const float* params, in
     if (dy_dx) hash_fwd_kernel<true><<<grid, THREADS, 0, s>>>(n, x, (const float2*)params, c, out, out_stride, dy_dx);
     else hash_fwd_kernel<false><<<grid, THREADS, 0, s>>>(n, x, (const float2*)params, c, out, out_stride, nullptr);
     return ia::check_launch("ia_hashgrid_fwd");
+}
+
+
+IA_EXPORT int64_t ia_hashgrid_fwd_scratch_bytes(int64_t n, int n_levels, int with_jac)
+{
+    if (n < 0 || n_levels <= 0 || n_levels > MAX_LEVELS) return -1;
+    return n * n_levels * 8 + (with_jac ? n * n_levels * 24 : 0) + 256;
+}
+
+// same outputs as ia_hashgrid_fwd; scratch = ia_hashgrid_fwd_scratch_bytes(n, n_levels, dy_dx != NULL) bytes
+IA_EXPORT int ia_hashgrid_fwd_xcd(int64_t n, const float* x, const float* params, int n_levels, int n_features,
+                                  int log2_hashmap_size, int base_resolution, float per_level_scale, float* out,
+                                  int out_stride, float* dy_dx, void* scratch, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    IA_REQUIRE(n_features == 2, "n_features_per_level must be 2 on this path");
+    IA_REQUIRE(n_levels > 0 && n_levels <= MAX_LEVELS, "n_levels out of range");
+    IA_REQUIRE(scratch != nullptr, "scratch required");
+    HashCfg c;
+    make_cfg(c, n_levels, log2_hashmap_size, base_resolution, per_level_scale);
+    float2* tmp = (float2*)scratch;
+    float* tmp_jac = dy_dx ? (float*)((char*)scratch + ((n * n_levels * 8 + 255) / 256) * 256) : nullptr;
+    // level sets: "big" levels own a full 2^log2_hashmap_size table (one L2 each), the rest are the small dense ones
+    const uint32_t cap = 1u << log2_hashmap_size;
+    int n_small = 0;
+    while (n_small < n_levels && c.offsets[n_small + 1] - c.offsets[n_small] < cap) n_small++;
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = 256;                                     // workgroups per XCD slot
+    int l = n_small;
+    bool small_done = (n_small == 0);
+    while (l < n_levels || !small_done) {
+        XcdPlan plan;
+        const int big_left = n_levels - l;
+        if (big_left >= 8) {                                    // pass A: one big level per XCD, all points
+            for (int k = 0; k < 8; k++) { plan.first_level[k] = l + k; plan.n_level[k] = 1; plan.part[k] = 0; plan.nparts[k] = 1; }
+            l += 8;
+        } else {                                                // pass B: remaining big levels + the small set
+            // XCD slots in proportion to the work of each unit (a big level = 1, the small set = its level count),
+            // every unit at least one slot; a unit with several slots splits the points between them
+            const int units = big_left + (small_done ? 0 : 1);
+            int w[9], share[9], wsum = 0;
+            for (int u = 0; u < units; u++) { w[u] = (!small_done && u == units - 1) ? n_small : 1; wsum += w[u]; }
+            int used = 0;
+            for (int u = 0; u < units; u++) { share[u] = (8 * w[u]) / wsum; if (share[u] < 1) share[u] = 1; used += share[u]; }
+            for (int u = units - 1; used > 8; u = (u + units - 1) % units) if (share[u] > 1) { share[u]--; used--; }
+            for (int u = units - 1; used < 8; u = (u + units - 1) % units) { share[u]++; used++; }
+            int k = 0;
+            for (int u = 0; u < units; u++) {
+                const bool is_small = (!small_done && u == units - 1);
+                for (int j = 0; j < share[u]; j++, k++) {
+                    plan.first_level[k] = is_small ? 0 : l + u;
+                    plan.n_level[k] = is_small ? n_small : 1;
+                    plan.part[k] = j; plan.nparts[k] = share[u];
+                }
+            }
+            l = n_levels;
+            small_done = true;
+        }
+        if (dy_dx) hash_fwd_xcd_kernel<true><<<8 * chunks, THREADS, 0, s>>>(n, x, (const float2*)params, c, plan, tmp, tmp_jac);
+        else hash_fwd_xcd_kernel<false><<<8 * chunks, THREADS, 0, s>>>(n, x, (const float2*)params, c, plan, tmp, nullptr);
+    }
+    const size_t lds = sizeof(float) * THREADS * (dy_dx ? 6 * n_levels + 1 : 2 * n_levels + 1);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)hash_transpose_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipGetLastError();
+        attr = true;
+    }
+    if (dy_dx) hash_transpose_kernel<true><<<ia::cdiv(n, THREADS), THREADS, lds, s>>>(n, n_levels, tmp, tmp_jac, out, out_stride, dy_dx);
+    else hash_transpose_kernel<false><<<ia::cdiv(n, THREADS), THREADS, lds, s>>>(n, n_levels, tmp, nullptr, out, out_stride, nullptr);
+    return ia::check_launch("ia_hashgrid_fwd_xcd");
 }
 
 IA_EXPORT int ia_hashgrid_bwd(int64_t n, const float* x, int n_levels, int n_features, int log2_hashmap_size,
