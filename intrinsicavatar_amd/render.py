@@ -89,35 +89,38 @@ class RenderStep:
         intervals, samples, _ = nerfacc.traverse_grids(rays_o, rays_d, self.binaries, self.aabbs, near_planes, far_planes,
                                                        self.render_step_size, 0.0, grid_bits=self.grid_bits)
         stats = dict(n_edges0=intervals.vals.shape[0], n_samples0=samples.vals.shape[0])
-        # -- 3. importance resampling
+        # -- 3. importance resampling.  Host syncs are kept to the data-dependent sizes: boolean-mask indexing (one
+        # nonzero + sync per use in the reference) is replaced by ONE index list per edge set, and the pairing
+        # "k-th left edge <-> k-th right edge" by "right edge = left edge + 1" (consecutive samples share edges).
         if self.importance_sample and samples.vals.numel() > 0:
             for it in range(2):
+                vals = intervals.vals
                 if it == 0:        # coarse_alpha_fn: SDF at every edge, interval sdf = min(left, right)
-                    pts = ray_points(rays_o, rays_d, intervals.ray_indices, intervals.vals)
+                    pts = ray_points(rays_o, rays_d, intervals.ray_indices, vals)
                     sdf = self._sdf_at(pts)
-                    sdf_merge = torch.full_like(sdf, 1e10)
-                    sdf_merge[intervals.is_left] = torch.minimum(sdf[intervals.is_left], sdf[intervals.is_right])
+                    nxt = torch.cat([sdf[1:], sdf[-1:]])
+                    sdf_merge = torch.where(intervals.is_left, torch.minimum(sdf, nxt), torch.full_like(sdf, 1e10))
                     alphas = laplace_alpha(sdf_merge, self.render_step_size, beta)
                 else:              # alpha_fn: SDF at interval mid-points
-                    il, ir = intervals.is_left, intervals.is_right
-                    ts, te = intervals.vals[il], intervals.vals[ir]
-                    pts = ray_points(rays_o, rays_d, intervals.ray_indices[il], ts, te)
+                    il_idx = torch.nonzero(intervals.is_left)[:, 0]
+                    ts, te = vals[il_idx], vals[il_idx + 1]
+                    pts = ray_points(rays_o, rays_d, intervals.ray_indices[il_idx], ts, te)
                     sdf_curr = self._sdf_at(pts)
-                    sdf = torch.full_like(intervals.vals, 1e10)
-                    sdf[il] = sdf_curr
-                    dists = torch.zeros_like(intervals.vals)
-                    dists[il] = te - ts
+                    sdf = torch.full_like(vals, 1e10).index_put_((il_idx,), sdf_curr)
+                    dists = torch.zeros_like(vals).index_put_((il_idx,), te - ts)
                     alphas = laplace_alpha(sdf, dists, beta)
                 weights, _ = nerfacc.render_weight_from_alpha(alphas, packed_info=intervals.packed_info)
                 rpi, rvals, rdists, ril, rir, is_res, is_fg = lib_nerfacc.ray_resampling_merge(
-                    intervals.packed_info, intervals.vals, intervals.is_left, intervals.is_right, weights, 16)
-                ray_idx = lib_nerfacc.unpack_info(rpi, rvals.shape[0])[is_fg]
-                intervals = RayIntervals(vals=rvals[is_fg], is_left=ril[is_fg], is_right=rir[is_fg], ray_indices=ray_idx,
+                    intervals.packed_info, vals, intervals.is_left, intervals.is_right, weights, 16)
+                fg_idx = torch.nonzero(is_fg)[:, 0]
+                ray_idx = lib_nerfacc.unpack_info(rpi, rvals.shape[0])[fg_idx]
+                intervals = RayIntervals(vals=rvals[fg_idx], is_left=ril[fg_idx], is_right=rir[fg_idx], ray_indices=ray_idx,
                                          packed_info=lib_nerfacc.pack_info(ray_idx, n_rays))
         # -- 4.
-        t_starts = intervals.vals[intervals.is_left]
-        t_ends = intervals.vals[intervals.is_right]
-        ray_indices = intervals.ray_indices[intervals.is_left]
+        il_idx = torch.nonzero(intervals.is_left)[:, 0]
+        t_starts = intervals.vals[il_idx]
+        t_ends = intervals.vals[il_idx + 1] if il_idx.numel() > 0 else intervals.vals[il_idx]
+        ray_indices = intervals.ray_indices[il_idx]
         packed_info = lib_nerfacc.pack_info(ray_indices, n_rays)
         stats["n_samples"] = t_starts.shape[0]
         return rays_o, rays_d, far, t_starts, t_ends, ray_indices, packed_info, stats
