@@ -32,10 +32,10 @@ sample = rays[::stride].cpu().numpy()
 t0 = time.perf_counter(); R.render_step(R.Scene(**export), sample); tcpu = time.perf_counter() - t0
 scale = n / sample.shape[0]
 rows = [
-    ("occupancy-grid marching (T1)", ["traverse_grids"], ["ia_traverse_grids_count", "ia_exclusive_scan_i64", "ia_traverse_grids_fill"]),
+    ("occupancy-grid marching (T1)", ["traverse_grids"], ["ia_traverse_grids_count", "ia_exclusive_scan_i64", "ia_traverse_grids_fill", "ia_traverse_grids_fused"]),
     ("Broyden root search (K8)", ["fuse_broyden"], ["ia_fuse_broyden"]),
     ("candidate filter / compaction / select (K9 + glue)", ["filter"], ["ia_deform_filter_count", "ia_deform_compact", "ia_deform_select", "ia_exclusive_scan_i32"]),
-    ("hash-grid encode + SDF/radiance MLPs (T4, T5, F1, F2)", ["sdf_field", "hashgrid_fwd", "sh4", "mlp_fwd"], ["ia_hashgrid_fwd", "ia_sh4_fwd", "ia_mlp_fwd"]),
+    ("hash-grid encode + SDF/radiance MLPs (T4, T5, F1, F2)", ["sdf_field", "hashgrid_fwd", "sh4", "mlp_fwd"], ["ia_hashgrid_fwd", "ia_hashgrid_fwd_xcd", "ia_sh4_fwd", "ia_mlp_fwd"]),
     ("alpha / transmittance weights / accumulation (T2, T3)", ["laplace_alpha", "render_weight_from_alpha", "accumulate_along_rays"], ["ia_laplace_alpha", "ia_render_weight_from_alpha", "ia_accumulate_along_rays", "ia_ray_points", "ia_shade_prep"]),
     ("importance resampling + pack/unpack (K2, K5, pack_info)", ["ray_resampling_merge", "unpack_info", "pack_info"], ["ia_resample_packed_info", "ia_ray_resampling_merge", "ia_unpack_info", "ia_pack_info"]),
 ]
