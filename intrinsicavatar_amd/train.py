@@ -221,7 +221,7 @@ def shade_differentiable(rs, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor
     n_rays = packed_info.shape[0]
     pts = render.ray_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
     with torch.no_grad():
-        d = dfm.deform(pts, geo, with_grad=True, with_feature=False)       # candidate search + winner selection
+        d = dfm.deform(pts, geo, with_grad=False, with_feature=False, want_fwd=True)      # candidate search + winner selection (the gradient is evaluated once, on the winners, by _SDFField)
         valid = d["valid"]
         sel = d["sel"].long().clamp(min=0)
         c2w = d["fwd_J"].reshape(-1, 3, 3)[d["cand_src"].long()[sel]] if d["n_candidates"] > 0 else \

@@ -86,7 +86,7 @@ def shade_differentiable_phys(rs, material, emitter, rays_o: Tensor, rays_d: Ten
     dev = rays_o.device
     pts = render.ray_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
     with torch.no_grad():
-        d = dfm.deform(pts, geo, with_grad=True, with_feature=False)
+        d = dfm.deform(pts, geo, with_grad=False, with_feature=False, want_fwd=True)
         valid = d["valid"]
         sel = d["sel"].long().clamp(min=0)
         c2w = d["fwd_J"].reshape(-1, 3, 3)[d["cand_src"].long()[sel]] if d["n_candidates"] > 0 else \
