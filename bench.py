@@ -119,15 +119,18 @@ def main():
     target_rgb = torch.rand((n_rays, 3), generator=g).to(dev)
     target_mask = (torch.rand(n_rays, generator=g) > 0.5).float().to(dev)
 
+    # the one exchange step of the path: all-reduce(sum) of the gradients over RCCL/xGMI; the two 50 MB
+    # hash-table gradients are launched from autograd hooks as soon as they are complete (overlap with the rest of backward)
+    sync = parallel.OverlappedGradientAllReduce(params) if (world > 1 and args.mode != "fwd") else None
+
     def step():
         if args.mode == "fwd":
             return rs.forward(rays)
         for p in params:
             p.grad = None
         out = rs.forward_backward(rays, target_rgb, target_mask)
-        if world > 1:
-            # the one exchange step of the path: all-reduce(sum) of the gradients over RCCL/xGMI
-            parallel.allreduce_gradients(params)
+        if sync is not None:
+            sync.finish()
         return out
 
     for _ in range(args.warmup):

@@ -59,3 +59,68 @@ def allreduce_scalars(values: List[float], device) -> List[float]:
     t = torch.tensor(values, dtype=torch.float64, device=device)
     dist.all_reduce(t)
     return t.tolist()
+
+
+class OverlappedGradientAllReduce:
+    """all-reduce of the big (hash-table) gradients started from autograd's post-accumulate hooks, i.e. while the rest
+    of the backward pass is still running: the radiance table's gradient is complete half-way through backward, its
+    50 MB all-reduce over xGMI then hides behind the SDF-head backward.  `finish()` (after loss.backward()) launches
+    whatever is left, waits, and reduces the small tensors as one bucket.  Same result as allreduce_gradients().
+
+    Collectives must be issued in the SAME order on every rank, also when a rank produced no gradient for some table
+    (no ray hit anything): the launch order is therefore fixed up front -- reverse parameter order, i.e. the order in
+    which autograd normally completes them -- and a ready gradient waits for its predecessors in that order."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params = [p for p in params if p.requires_grad]
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.order = [p for p in reversed(self.params) if p.numel() >= BIG]
+        self._ready = set()
+        self._next = 0
+        self._handles = []
+        self._hooks = []
+        if self.active:
+            for p in self.order:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_ready))
+
+    def _pump(self):
+        while self._next < len(self.order) and id(self.order[self._next]) in self._ready:
+            self._handles.append(dist.all_reduce(self.order[self._next].grad, async_op=True))
+            self._next += 1
+
+    def _on_ready(self, p):
+        self._ready.add(id(p))
+        self._pump()
+
+    def finish(self) -> int:
+        if not self.active:
+            return 0
+        nbytes = 0
+        small = []
+        for p in self.params:
+            if p.grad is None:                      # no gradient arrived on this rank: contribute zeros
+                p.grad = torch.zeros_like(p)
+            if p.numel() >= BIG:
+                self._ready.add(id(p))
+                nbytes += p.grad.numel() * p.grad.element_size()
+            else:
+                small.append(p.grad)
+        self._pump()
+        if small:
+            flat = torch.cat([t.reshape(-1) for t in small])
+            dist.all_reduce(flat)
+            off = 0
+            for t in small:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+            nbytes += flat.numel() * flat.element_size()
+        for h in self._handles:
+            h.wait()
+        self._handles, self._next = [], 0
+        self._ready.clear()
+        return nbytes
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

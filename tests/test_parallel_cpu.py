@@ -52,6 +52,39 @@ def test_allreduce_gradients_and_sharding_world2(tmp_path):
     assert r[0]["scal"] == r[1]["scal"] == [3.0, 20.0]
 
 
+def _worker_overlap(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from intrinsicavatar_amd import parallel
+    torch.manual_seed(0)
+    big1, big2 = torch.nn.Parameter(torch.randn(parallel.BIG + 3)), torch.nn.Parameter(torch.randn(parallel.BIG))
+    small = torch.nn.Parameter(torch.randn(64, 35))
+    unused = torch.nn.Parameter(torch.randn(parallel.BIG))       # big parameter that gets no gradient on any rank
+    sync = parallel.OverlappedGradientAllReduce([big1, big2, small, unused])
+    g = torch.Generator().manual_seed(7 + rank)
+    w1, w2, w3 = torch.randn(big1.shape, generator=g), torch.randn(big2.shape, generator=g), torch.randn(small.shape, generator=g)
+    for _ in range(2):                                            # two steps: hooks must survive zeroed grads
+        for p in (big1, big2, small, unused):
+            p.grad = None
+        loss = (big1 * w1).sum() + (big2 * w2).sum() + (small * w3).sum()
+        loss.backward()                                           # hooks fire here
+        nbytes = sync.finish()
+    torch.save(dict(local=[w1, w2, w3], reduced=[big1.grad.clone(), big2.grad.clone(), small.grad.clone()],
+                    unused=float(unused.grad.abs().sum()), nbytes=nbytes), os.path.join(out_dir, f"o{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_overlapped_gradient_allreduce_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker_overlap, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"o{k}.pt") for k in range(world)]
+    for i in range(3):
+        expect = r[0]["local"][i] + r[1]["local"][i]
+        for k in range(world):
+            torch.testing.assert_close(r[k]["reduced"][i], expect)
+    assert r[0]["unused"] == r[1]["unused"] == 0.0
+
+
 def test_shard_range_covers_everything():
     from intrinsicavatar_amd.parallel import shard_range
     for n in (0, 1, 7, 4096, 291600):
