@@ -35,12 +35,23 @@ __global__ __launch_bounds__(THREADS) void stack_info_kernel(int64_t n_rays, con
     reinterpret_cast<int2*>(out)[r] = make_int2(start[r], cnt[r]);
 }
 
+// samples per ray (scatter_add of ones, lib/nerfacc/pack.py:70-74).  Integer atomics: exact for any input order; for the
+// usual ray-sorted input the wave first merges runs of equal indices (ballot) and issues one atomic per run.
 __global__ __launch_bounds__(THREADS) void count_rays_kernel(int64_t n_samples, const int64_t* __restrict__ ray_indices,
                                                               int32_t* __restrict__ cnt)
 {
     const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (i >= n_samples) return;
-    atomicAdd(&cnt[ray_indices[i]], 1);
+    const int lane = threadIdx.x & 63;
+    const bool active = i < n_samples;
+    const int64_t r = active ? ray_indices[i] : -1;
+    const int64_t prev = __shfl_up(r, 1, 64);
+    const bool head = (lane == 0) || (prev != r);
+    const unsigned long long heads = __ballot(head);
+    if (head && active) {
+        const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1));
+        const int len = above ? (__builtin_ctzll(above) + 1) : (64 - lane);
+        atomicAdd(&cnt[r], len);
+    }
 }
 
 // ---- K5..K7 -------------------------------------------------------------------
