@@ -264,9 +264,11 @@ __global__ __launch_bounds__(THREADS) void laplace_alpha_bwd_kernel(int64_t n, c
                                                                      const float* __restrict__ g_alpha,
                                                                      float* __restrict__ g_sdf, float* __restrict__ g_beta)
 {
-    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    // grid-stride: a workgroup accumulates its share of d L / d beta in registers and issues ONE atomic at the end
+    // (one atomic per wave on a single address serialised at ~12 ns each: 69 k of them = 0.8 ms for 4.4 M samples)
+    __shared__ float s_part[THREADS / 64];
     float gb = 0.0f;
-    if (i < n) {
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) {
         const float beta = *beta_p;
         const float s = sdf[i], as = fabsf(s);
         const float sg = (float)((s > 0.f) - (s < 0.f));
@@ -279,10 +281,16 @@ __global__ __launch_bounds__(THREADS) void laplace_alpha_bwd_kernel(int64_t n, c
         // d dens / d beta = -dens/beta + (1/beta) * 0.5 * sg * e * (as / beta^2)
         gb = ga * (-dens / beta + 0.5f * sg * e * as / (beta * beta * beta));
     }
-    // wave reduce then one atomic per wave
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) gb += __shfl_down(gb, off, 64);
-    if ((threadIdx.x & 63) == 0 && g_beta && gb != 0.0f) atomicAdd(g_beta, gb);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = gb;
+    __syncthreads();
+    if (threadIdx.x == 0 && g_beta) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; w++) t += s_part[w];
+        if (t != 0.0f) atomicAdd(g_beta, t);
+    }
 }
 
 }  // namespace
@@ -360,7 +368,8 @@ IA_EXPORT int ia_laplace_alpha_bwd(int64_t n, const float* sdf, const float* dis
                                    ia_stream_t stream)
 {
     if (n == 0) return IA_OK;
-    laplace_alpha_bwd_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, sdf, dists, dist_const, beta,
-                                                                                      g_alpha, g_sdf, g_beta);
+    int grid = ia::cdiv(n, THREADS);
+    if (grid > 2048) grid = 2048;
+    laplace_alpha_bwd_kernel<<<grid, THREADS, 0, (hipStream_t)stream>>>(n, sdf, dists, dist_const, beta, g_alpha, g_sdf, g_beta);
     return ia::check_launch("ia_laplace_alpha_bwd");
 }

@@ -253,9 +253,11 @@ def training_loss(out: Dict[str, Tensor], target_rgb: Tensor, target_mask: Optio
                   lambda_eik: float = 0.1, lambda_mask: float = 0.1, lambda_curv: float = 0.0) -> Tensor:
     """the rgb / eikonal / mask terms of systems/intrinsic_avatar.py:167-251 (L1 rgb, (|grad|-1)^2, BCE opacity)."""
     loss = (out["comp_rgb"] - target_rgb).abs().mean()
-    v = out["valid"]
-    if v.any():
-        loss = loss + lambda_eik * ((torch.linalg.norm(out["sdf_grad"][v], dim=-1) - 1.0) ** 2).mean()
+    # eikonal term: mean over the valid samples, written as a masked sum (boolean-mask indexing costs a host sync forward
+    # and a 1.3 ms index_put in backward for 4.4 M samples)
+    vf = out["valid"].float()
+    eik = ((torch.linalg.norm(out["sdf_grad"], dim=-1) - 1.0) ** 2 * vf).sum() / vf.sum().clamp_min(1.0)
+    loss = loss + lambda_eik * eik
     if target_mask is not None:
         op = out["opacity"][:, 0].clamp(1e-3, 1 - 1e-3)
         loss = loss + lambda_mask * torch.nn.functional.binary_cross_entropy(op, target_mask)
