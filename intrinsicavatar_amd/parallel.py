@@ -89,6 +89,10 @@ class OverlappedGradientAllReduce:
             self._next += 1
 
     def _on_ready(self, p):
+        if id(p) in self._ready:
+            raise RuntimeError("OverlappedGradientAllReduce: a table received a second gradient in the same backward pass "
+                               "(e.g. the curvature term evaluates the SDF grid twice); its all-reduce is already in "
+                               "flight -- use allreduce_gradients() after backward for such steps")
         self._ready.add(id(p))
         self._pump()
 
