@@ -527,7 +527,6 @@ __global__ __launch_bounds__(TR_THREADS) void traverse_fused_kernel(
     __shared__ unsigned long long s_base;
     __shared__ uint32_t s_tile;
     const int lane_wg = threadIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (lane_wg == 0) s_tile = atomicAdd(ticket, 1u);
     {
         const int n_words = (rx * ry * rz + 31) >> 5;
         const int n_vec = n_words >> 2;
@@ -536,15 +535,21 @@ __global__ __launch_bounds__(TR_THREADS) void traverse_fused_kernel(
         for (int i = threadIdx.x; i < n_vec; i += TR_THREADS) dst[i] = src[i];
         for (int i = (n_vec << 2) + threadIdx.x; i < n_words; i += TR_THREADS) s_bits[i] = grid_bits[i];
     }
+    float aabb[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) aabb[k] = aabb_g[k];
+    // persistent workgroups: the bit grid is staged once, tiles are pulled off the ticket counter until none is left
+    // (per-tile staging + workgroup launch were 141 us of the 674 us of a 2 M-ray batch)
+  for (;;) {
+    __syncthreads();                       // previous tile fully written; LDS descriptors free
+    if (lane_wg == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();
     const int tile = (int)s_tile;
+    if (tile >= n_tiles) break;
     const int64_t tid = (int64_t)tile * TR_THREADS + lane_wg;
     const bool active = tid < n_rays;
 
     // ---- phase 1: walk
-    float aabb[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) aabb[k] = aabb_g[k];
     float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 1.f};
     float near_plane = 0.f, far_plane = 0.f, t_term = 0.f;
     LdsRunSink sink{s_tfirst, s_nsamp, lane_wg};
@@ -620,7 +625,7 @@ __global__ __launch_bounds__(TR_THREADS) void traverse_fused_kernel(
     const int64_t baseE = (int64_t)(s_base & 0x7FFFFFFFull), baseS = (int64_t)(s_base >> 31);
     if (baseE + E_wg > cap_edges || baseS + S_wg > cap_samples) {
         if (lane_wg == 0) totals[2] = 1;
-        return;
+        continue;
     }
 
     // ---- phase 4: per-ray records, then element-parallel expansion
@@ -660,6 +665,7 @@ __global__ __launch_bounds__(TR_THREADS) void traverse_fused_kernel(
                           baseS + s_offS[lane_wg], tid};
         (void)dda_walk(o, d, aabb, rx, ry, rz, near_plane, far_plane, step_size, cone_angle, s_bits, w);
     }
+  }
 }
 
 }  // namespace
@@ -770,7 +776,8 @@ IA_EXPORT int ia_traverse_grids_fused(int64_t n_rays, const float* rays_o, const
     if (hipMemsetAsync(scratch, 0, (size_t)sb, s) != hipSuccess) return ia::check_launch("ia_traverse_grids_fused(memset)");
     uint64_t* state = (uint64_t*)scratch;
     uint32_t* ticket = (uint32_t*)(state + tiles + 1);
-    traverse_fused_kernel<<<tiles, TR_THREADS, lds, s>>>(
+    const int grid = tiles < 768 ? tiles : 768;        // 3 resident workgroups per CU (53 KB of LDS each)
+    traverse_fused_kernel<<<grid, TR_THREADS, lds, s>>>(
         n_rays, rays_o, rays_d, grid_bits, rx, ry, rz, aabb, near_planes, far_planes, step_size, cone_angle, state, ticket,
         tiles, cap_edges, cap_samples, totals, iv_packed_info, sm_packed_info, iv_vals, iv_is_left, iv_is_right,
         iv_ray_indices, sm_vals, sm_ray_indices, termination_planes);
