@@ -66,6 +66,45 @@ class EnvironmentLightTensor:
         return self._eval(d_world, False, True)[1][:, None]
 
 
+class EnvironmentLightSG(torch.nn.Module):
+    """`envlight-SG` (configs/light/envlight_SG.yaml: num_SGs 64, base_res 256): the training-time emitter.  lib/torch_pbr
+    is an empty submodule, so the parametrisation is the standard spherical-Gaussian mixture (PhySG / nvdiffrecmc):
+        L(d) = sum_k softplus(mu_k) * exp(lambda_k * (d . xi_k - 1)),   xi_k = normalize(axis_k), lambda_k = exp(log_lambda_k)
+    rendered into an equirectangular [base_res, 2 base_res, 3] image (`generate_image`, differentiable) that the kernels
+    evaluate like any EnvironmentLightTensor (`as_tensor_light()`, `env_base=` of pbr_shade_differentiable)."""
+
+    def __init__(self, num_SGs: int = 64, base_res: int = 256, seed: int = 0):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        i = torch.arange(num_SGs, dtype=torch.float32) + 0.5                    # Fibonacci sphere: even lobe coverage
+        phi = math.pi * (1 + 5 ** 0.5) * i
+        z = 1 - 2 * i / num_SGs
+        r = torch.sqrt((1 - z * z).clamp_min(0))
+        self.axis = torch.nn.Parameter(torch.stack([r * torch.cos(phi), z, r * torch.sin(phi)], -1))
+        self.log_lambda = torch.nn.Parameter(torch.full((num_SGs,), math.log(20.0)) + 0.2 * torch.randn(num_SGs, generator=g))
+        self.mu = torch.nn.Parameter(torch.full((num_SGs, 3), 0.2) + 0.05 * torch.randn((num_SGs, 3), generator=g))
+        self.base_res = base_res
+
+    def _dirs(self, device):
+        H, W = self.base_res, 2 * self.base_res
+        v = (torch.arange(H, device=device) + 0.5) / H
+        u = (torch.arange(W, device=device) + 0.5) / W
+        th, ph = (v * math.pi)[:, None], ((u - 0.5) * 2 * math.pi)[None, :]
+        return torch.stack([torch.sin(th) * torch.sin(ph), torch.cos(th).expand(H, W), -torch.sin(th) * torch.cos(ph)], -1)
+
+    def generate_image(self) -> Tensor:
+        d = self._dirs(self.axis.device)                                          # [H,W,3], same convention as the kernels
+        xi = torch.nn.functional.normalize(self.axis, dim=-1)
+        lam = torch.exp(self.log_lambda)
+        w = torch.exp(lam * (d.reshape(-1, 3) @ xi.T - 1.0))                       # [HW,K]
+        return (w @ torch.nn.functional.softplus(self.mu)).reshape(d.shape)
+
+    def as_tensor_light(self) -> "EnvironmentLightTensor":
+        e = EnvironmentLightTensor(self.generate_image().detach())
+        e.update_pdf()
+        return e
+
+
 MODES = {"light": 0, "uniform_light": 1, "mis": 2, "mats": 3}
 
 
