@@ -78,9 +78,11 @@ class _MLP2(Function):
 def shade_differentiable_phys(rs, material, emitter, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor, t_starts: Tensor,
                               t_ends: Tensor, packed_info: Tensor, spp: int, light_u: Tensor, shuffle_u: Tensor,
                               render_mode: str = "uniform_light", env_base: Optional[Tensor] = None,
-                              background_color: Optional[Tensor] = None, global_illumination: bool = False
-                              ) -> Dict[str, Tensor]:
-    """differentiable rgb_normal_mats_alpha_fn + rendering_with_normals_mats_sdf + volume scattering."""
+                              background_color: Optional[Tensor] = None, global_illumination: bool = False,
+                              jitter_n: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """differentiable rgb_normal_mats_alpha_fn + rendering_with_normals_mats_sdf + volume scattering.
+    jitter_n [n_samples,3]: standard-normal noise of the material jitter pass (torch.randn_like in the reference,
+    :1116-1140): materials are re-evaluated at x_cano + 0.01 * jitter_n for the relative smoothness maps (:1546-1597)."""
     dfm, geo, rad = rs.deformer, rs.geometry, rs.radiance
     n_rays = packed_info.shape[0]
     dev = rays_o.device
@@ -114,9 +116,30 @@ def shade_differentiable_phys(rs, material, emitter, rays_o: Tensor, rays_d: Ten
     metal = mraw[:, 4:5] * material.metallic_scale + material.metallic_bias
     weights, trans = nerfacc._WeightFromAlpha.apply(alphas, packed_info)
     acc = lambda v: nerfacc._Accumulate.apply(weights, v, ray_indices, packed_info)      # noqa: E731
+    extra_maps = {}
+    if jitter_n is not None:
+        # material jitter pass: geometry feature + radiance embedding + material head at the jittered canonical points
+        # (material_feature = hybrid); no deformer, no validity mask, exactly as the reference evaluates it
+        x_j = (d["pts_cano"] + 0.01 * jitter_n[:pts.shape[0]]).detach().contiguous()
+        out_j, _ = train._SDFField.apply(x_j, geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale)
+        xp2_j = ((x_j - rad.center) / rad.scale + 0.5).contiguous()
+        enc2_j = _HashEncode.apply(xp2_j, rad.grid_params)
+        mraw_j = _MLP2.apply(2, 5, *material.effective_weights(mask), enc2_j, xp2_j, out_j)
+        alb_j = mraw_j[:, :3] * material.albedo_scale + material.albedo_bias
+        rough_j = mraw_j[:, 3:4] * material.roughness_scale + material.roughness_bias
+        metal_j = mraw_j[:, 4:5] * material.metallic_scale + material.metallic_bias
+
+        def rel(v, vj):            # compute_relative_smoothness_loss (:383-388)
+            base = torch.maximum(v, vj).clamp_min(1e-6)
+            return (((v - vj) / base) ** 2).sum(-1, keepdim=True)
+        orient = (rays_d[ray_indices] * normal_smpl).sum(-1, keepdim=True).clamp_min(0.0)
+        extra_maps = dict(normals_orientation_loss_map=acc(orient.contiguous()),
+                          albedo_smoothness_loss_map=acc(rel(albedo, alb_j).contiguous()),
+                          roughness_smoothness_loss_map=acc(rel(rough, rough_j).contiguous()),
+                          metallic_smoothness_loss_map=acc(rel(metal, metal_j).contiguous()))
     res = dict(comp_rgb=acc(rgbs), comp_normal=acc(normal_world), opacity=acc(None), albedo=acc(albedo.contiguous()),
                roughness=acc(rough.contiguous()), metallic=acc(metal.contiguous()), weights=weights, alphas=alphas, sdf=sdf,
-               sdf_grad=sdf_grad, valid=valid, n_samples=pts.shape[0])
+               sdf_grad=sdf_grad, valid=valid, n_samples=pts.shape[0], **extra_maps)
     # ---- volume scattering (enable_phys)
     if background_color is None:
         background_color = torch.ones(3, device=dev)
@@ -162,6 +185,14 @@ def shade_differentiable_phys(rs, material, emitter, rays_o: Tensor, rays_d: Ten
 
 
 def training_loss_phys(out: Dict[str, Tensor], target_rgb: Tensor, target_mask: Optional[Tensor] = None,
-                       lambda_phys: float = 1.0, **kw) -> Tensor:
-    """train.training_loss + the L1 term on the physically based image (systems/intrinsic_avatar.py:180-190)."""
-    return train.training_loss(out, target_rgb, target_mask, **kw) + lambda_phys * (out["comp_rgb_phys"] - target_rgb).abs().mean()
+                       lambda_phys: float = 1.0, lambda_smooth: float = 0.0, lambda_orient: float = 0.0, **kw) -> Tensor:
+    """train.training_loss + the L1 term on the physically based image (systems/intrinsic_avatar.py:180-190) and, when
+    the jitter pass ran, the material smoothness / normal orientation maps."""
+    loss = train.training_loss(out, target_rgb, target_mask, **kw) + lambda_phys * (out["comp_rgb_phys"] - target_rgb).abs().mean()
+    if "albedo_smoothness_loss_map" in out:
+        if lambda_smooth > 0.0:
+            loss = loss + lambda_smooth * (out["albedo_smoothness_loss_map"].mean() + out["roughness_smoothness_loss_map"].mean()
+                                           + out["metallic_smoothness_loss_map"].mean())
+        if lambda_orient > 0.0:
+            loss = loss + lambda_orient * out["normals_orientation_loss_map"].mean()
+    return loss

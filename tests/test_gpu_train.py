@@ -175,14 +175,15 @@ def test_phys_training_step_gradients():
     shuffle_u = torch.rand((n, spp), generator=g).to(DEV)
     env_base = env.base.clone().requires_grad_(True)
     params = rs.parameters() + list(mat.parameters())
+    jitter_n = torch.randn((400000, 3), generator=g).to(DEV)          # material jitter pass noise (explicit)
 
     def run(backward):
         s = rs.sample(rays, None)
         rays_o, rays_d, far, t_starts, t_ends, ray_indices, packed_info, _ = s
         out = train_phys.shade_differentiable_phys(rs, mat, env, rays_o, rays_d, ray_indices, t_starts, t_ends, packed_info, spp,
                                                    light_u, shuffle_u, render_mode="uniform_light", env_base=env_base,
-                                                   background_color=torch.zeros(3, device=DEV))
-        loss = train_phys.training_loss_phys(out, target, None, lambda_eik=0.0)
+                                                   background_color=torch.zeros(3, device=DEV), jitter_n=jitter_n)
+        loss = train_phys.training_loss_phys(out, target, None, lambda_eik=0.0, lambda_smooth=0.05, lambda_orient=0.05)
         if backward:
             loss.backward()
         return float(loss.detach().double()), out
@@ -192,6 +193,9 @@ def test_phys_training_step_gradients():
     l0, out = run(True)
     assert out["stats"]["n_fg"] > 1000 and out["stats"]["n_secondary"] > 100
     assert torch.isfinite(out["comp_rgb_phys"]).all()
+    for k in ("albedo_smoothness_loss_map", "roughness_smoothness_loss_map", "metallic_smoothness_loss_map",
+              "normals_orientation_loss_map"):
+        assert torch.isfinite(out[k]).all() and float(out[k].detach().max()) > 0, k
     grads = {id(p): p.grad.clone() for p in params if p.grad is not None}
     for name, p in [("env", env_base)] + [(f"mat{i}", q) for i, q in enumerate(mat.parameters())] + \
                    [("rad_table", rs.radiance.grid_params), ("geo_table", rs.geometry.grid_params)]:
