@@ -186,6 +186,10 @@ class ProgressiveMask:
         m[: lvl * self.F] = 1.0
         return m
 
+    def level_bits(self) -> int:
+        """bit l set = level l active at the step of the last mask() call (for ia_hashgrid_bwd_binned's level_mask)."""
+        return (1 << int(self.current_level)) - 1
+
 
 class VolumeSDF(nn.Module):
     """models/rf/geometry.py:107-235 on the HIP kernels.  forward(points) with points in canonical space."""

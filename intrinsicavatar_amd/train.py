@@ -60,7 +60,8 @@ class _SDFField(Function):
     """(x_cano, table, W1k, b1, W2, b2) -> (out[n,13], grad[n,3]); grads w.r.t. table and weights (1st + 2nd order)."""
 
     @staticmethod
-    def forward(ctx, x, table, W1k, b1, W2, b2, center, scale):
+    def forward(ctx, x, table, W1k, b1, W2, b2, center, scale, level_bits=0xFFFFFFFF):
+        ctx.level_bits = int(level_bits)
         xp = ((x - center) / scale + 0.5).contiguous()
         enc, jac = fields.hashgrid_forward(xp, table, with_jac=True)
         inv = (1.0 / scale).tolist()
@@ -85,20 +86,20 @@ class _SDFField(Function):
                                                  L.ptr(W2), L.ptr(b2), L.ptr(jac), L.ptr(g_y), L.ptr(q), L.ptr(gE), L.ptr(gG),
                                                  L.ptr(dW1k), L.ptr(db1), L.ptr(dW2), L.ptr(db2), L.stream()),
                     "ia_sdf_mlp_bwd_fused")
-            fields.hashgrid_backward(xp, gE, g_table, g_jac=gG, q=q)
-            return None, g_table, dW1k, db1, dW2, db2, None, None
+            fields.hashgrid_backward(xp, gE, g_table, g_jac=gG, q=q, level_mask=ctx.level_bits)
+            return None, g_table, dW1k, db1, dW2, db2, None, None, None
         Hh, U = torch.empty((n, 36), device=dev), torch.empty((n, 36), device=dev)
         DZ, GZ, A, DGS = (torch.empty((n, 64), device=dev) for _ in range(4))
         L.check(L.lib().ia_sdf_mlp_bwd(L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds, L.ptr(W1k), L.ptr(b1),
                                        L.ptr(W2), L.ptr(b2), L.ptr(jac), L.ptr(g_y), L.ptr(q), L.ptr(gE), L.ptr(gG),
                                        L.ptr(Hh), L.ptr(U), L.ptr(DZ), L.ptr(GZ), L.ptr(A), L.ptr(DGS), L.stream()),
                 "ia_sdf_mlp_bwd")
-        fields.hashgrid_backward(xp, gE, g_table, g_jac=gG, q=q)
+        fields.hashgrid_backward(xp, gE, g_table, g_jac=gG, q=q, level_mask=ctx.level_bits)
         dW1k, db1 = wgrad(DZ, 64, Hh, 35)
         dW1k = dW1k + wgrad(GZ, 64, U, 35, want_bias=False)[0]
         dW2, db2 = wgrad(g_y, 13, A, 64)
         dW2[0] += wgrad(DGS, 64, DGS, 1)[1]          # column sums of DGS
-        return None, g_table, dW1k, db1, dW2, db2, None, None
+        return None, g_table, dW1k, db1, dW2, db2, None, None, None
 
 
 class _ShadePrep(Function):
@@ -147,7 +148,8 @@ class _Radiance(Function):
     """(x_cano, table2, feat, refl01, normal_world, weights...) -> rgb[n,3] (sigmoid)."""
 
     @staticmethod
-    def forward(ctx, x, table, feat, refl01, normal_world, W1k, b1, W2, b2, W3, b3, center, scale):
+    def forward(ctx, x, table, feat, refl01, normal_world, W1k, b1, W2, b2, W3, b3, center, scale, level_bits=0xFFFFFFFF):
+        ctx.level_bits = int(level_bits)
         xp = ((x - center) / scale + 0.5).contiguous()
         enc = fields.hashgrid_forward(xp, table)
         refl01 = refl01.contiguous()
@@ -186,14 +188,14 @@ class _Radiance(Function):
             dW2, db2 = wgrad(G2, 64, A1, 64)
             dW3, db3 = wgrad(G3, 3, A2, 64)
         g_table = torch.zeros_like(table)
-        fields.hashgrid_backward(xp, g_x, g_table)                      # columns 0..31, row stride 68
+        fields.hashgrid_backward(xp, g_x, g_table, level_mask=ctx.level_bits)      # columns 0..31, row stride 68
         g_feat = g_x[:, 35:48]
         g_nw = g_x[:, 64:67]
         g_sh = g_x[:, 48:64]
         g_refl01 = torch.empty((n, 3), device=dev)
         L.check(L.lib().ia_sh4_bwd(L.i64(n), L.ptr(refl01), C.c_void_p(g_sh.data_ptr()), L.i32(68), L.ptr(g_refl01),
                                    L.stream()), "ia_sh4_bwd")
-        return (None, g_table, g_feat, g_refl01, g_nw, dW1, db1, dW2, db2, dW3, db3, None, None)
+        return (None, g_table, g_feat, g_refl01, g_nw, dW1, db1, dW2, db2, dW3, db3, None, None, None)
 
 
 def curvature_laplace(geo, pts_cano: Tensor, grad_c: Tensor, rand_u: Tensor, eps: float = 1e-4) -> Tensor:
@@ -208,7 +210,7 @@ def curvature_laplace(geo, pts_cano: Tensor, grad_c: Tensor, rand_u: Tensor, eps
     with torch.no_grad():
         tangent = torch.cross(nrm(grad_c, dim=-1, eps=1e-6), nrm(rand_u, dim=-1, eps=1e-6), dim=-1)
         x_d = (pts_cano + eps * tangent).contiguous()
-    _, grad_d = _SDFField.apply(x_d, geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale)
+    _, grad_d = _SDFField.apply(x_d, geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale, geo.prog.level_bits())
     dot = (nrm(grad_c, dim=-1, eps=1e-6) * nrm(grad_d, dim=-1, eps=1e-6)).sum(-1)
     return torch.acos(dot.clamp(-1.0 + 1e-6, 1.0 - 1e-6)) / math.pi
 
@@ -227,7 +229,7 @@ def shade_differentiable(rs, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor
         c2w = d["fwd_J"].reshape(-1, 3, 3)[d["cand_src"].long()[sel]] if d["n_candidates"] > 0 else \
             torch.zeros((pts.shape[0], 3, 3), device=pts.device)
     W1k, b1, W2, b2 = geo.effective_weights()
-    out, grad_c = _SDFField.apply(d["pts_cano"], geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale)
+    out, grad_c = _SDFField.apply(d["pts_cano"], geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale, geo.prog.level_bits())
     vf = valid[:, None].float()
     # invalid points: sdf 1e5, feature 0, gradient [0,0,1] (snarf_deformer.py:192-231)
     dflt_g = torch.tensor([0.0, 0.0, 1.0], device=pts.device)
@@ -238,7 +240,7 @@ def shade_differentiable(rs, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor
     normal_smpl, normal_world, refl01 = _ShadePrep.apply(sdf_grad, rays_d, ray_indices, w2s_rot)
     alphas = _Alpha.apply(sdf, t_ends - t_starts, rs.density.get_beta())
     rgbs = _Radiance.apply(d["pts_cano"], rad.grid_params, feat, refl01, normal_world, *rad.effective_weights(),
-                           rad.center, rad.scale)
+                           rad.center, rad.scale, rad.prog.level_bits())
     weights, trans = nerfacc._WeightFromAlpha.apply(alphas, packed_info)
     acc = lambda v: nerfacc._Accumulate.apply(weights, v, ray_indices, packed_info)      # noqa: E731
     res = dict(comp_rgb=acc(rgbs), comp_normal=acc(normal_world), opacity=acc(None),
