@@ -222,3 +222,34 @@ def test_phys_training_step_gradients():
             want = fd(p, d, eps * float(p.detach().abs().mean() + 1e-3))
         got = float((gr * d).sum())
         assert abs(got - want) < 0.08 * abs(want) + 1e-6, (name, got, want)
+
+
+def test_gradients_are_additive_over_ray_shards(frame):
+    """the multi-GPU contract: with a sum-reduced loss, the gradient of a ray batch equals the SUM of the gradients of its
+    shards (what all-reduce(sum) over ray-batch-sharded ranks computes) -- for every parameter incl. both hash tables."""
+    from intrinsicavatar_amd import train
+    rs, rays = frame
+    n = rays.shape[0]
+    g = torch.Generator().manual_seed(11)
+    target = torch.rand((n, 3), generator=g).cuda()
+
+    def grads(sel):
+        for p in rs.parameters():
+            p.grad = None
+        r = rays[sel].contiguous()
+        rays_o, rays_d, far, ts, te, ri, pi, _ = rs.sample(r, None)
+        out = train.shade_differentiable(rs, rays_o, rays_d, ri, ts, te, pi)
+        loss = (out["comp_rgb"] - target[sel]).abs().sum() + 0.1 * ((torch.linalg.norm(out["sdf_grad"], dim=-1) - 1.0) ** 2
+                                                                      * out["valid"].float()).sum()
+        loss.backward()
+        return [p.grad.detach().double().clone() if p.grad is not None else None for p in rs.parameters()]
+
+    idx = torch.arange(n, device="cuda")
+    full = grads(idx)
+    parts = [grads(idx[: n // 3]), grads(idx[n // 3: n // 3 + 777]), grads(idx[n // 3 + 777:])]
+    for k, gf in enumerate(full):
+        if gf is None:
+            continue
+        gs = sum(p[k] for p in parts)
+        scale = float(gf.abs().max()) + 1e-30
+        assert float((gf - gs).abs().max()) < 2e-5 * scale + 1e-9, (k, float((gf - gs).abs().max()), scale)
