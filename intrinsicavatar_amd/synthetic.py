@@ -166,7 +166,7 @@ def skinning_weight_grid(D=32, H=128, W=128, global_scale=1.2, smooth_iters=30, 
 
 def make_scene(height=128, width=128, pose_seed=0, res=64):
     """everything traverse_grids needs for one frame."""
-    rig = make_rig(make_pose(pose_seed))
+    rig = make_rig(None if pose_seed is None else make_pose(pose_seed))      # None: static neutral pose (tfs == identity)
     rays = rays_world_to_smpl(camera_rays(height, width), rig["w2s"])
     aabb = body_aabb(rig["joints_posed"])
     occ = occupancy_grid(rig["joints_posed"], aabb, res)
@@ -183,7 +183,7 @@ def build_frame(device="cuda:0", height=128, width=128, pose_seed=0, beta=0.01, 
     from .deformer import SNARFDeformer
 
     w, offk, sck, bbox = skinning_weight_grid(grid_D, grid_H, grid_W, smooth_iters=smooth_iters)
-    rig = make_rig(make_pose(pose_seed))
+    rig = make_rig(None if pose_seed is None else make_pose(pose_seed))      # None: static neutral pose (tfs == identity)
     dev = torch.device(device)
     dfm = SNARFDeformer(torch.from_numpy(w).to(dev), torch.from_numpy(offk).to(dev), torch.from_numpy(sck).to(dev),
                         torch.from_numpy(bbox).to(dev))

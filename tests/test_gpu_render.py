@@ -113,3 +113,26 @@ def test_ray_batch_sharding_invariance_full_size():
     assert sum(p["stats"]["n_edges0"] for p in parts) == full["stats"]["n_edges0"]
     hit = full["opacity"][:, 0] > 0.5
     assert 0.05 < float(hit.float().mean()) < 0.6 and full["stats"]["n_samples"] > 2_000_000
+
+
+
+def test_config1_static_neutral_pose_vs_oracle(oracle):
+    """BASELINE configs[0]: single 128x128 frame, static SMPL neutral pose (all bone transforms identity), 64 samples/ray,
+    radiance only, against the CPU restatement of forward_ end to end."""
+    from intrinsicavatar_amd import build
+    build.build()
+    from intrinsicavatar_amd import synthetic as S
+    from oracle import render_ref as R
+    rs, rays, export = S.build_frame(DEV, 128, 128, pose_seed=None, beta=0.01, num_samples_per_ray=64, grid_D=16, grid_H=64,
+                                     grid_W=64, smooth_iters=5, hash_amp=2e-3)
+    tfs = rs.deformer.tfs[0]
+    assert torch.allclose(tfs, torch.eye(4, device=DEV).expand_as(tfs), atol=1e-6)      # neutral pose
+    out = rs.forward(rays)
+    ref = R.render_step(R.Scene(**export), rays.cpu().numpy())
+    assert out["stats"]["n_edges0"] == ref["stats"]["n_edges0"] and out["stats"]["n_samples0"] == ref["stats"]["n_samples0"]
+    cnt, cnt_ref = out["packed_info"][:, 1].cpu().numpy(), ref["packed_info"][:, 1]
+    assert (cnt == cnt_ref).mean() >= 0.995
+    for k, tol in (("comp_rgb", 2e-3), ("opacity", 2e-3), ("comp_normal", 4e-3), ("depth", 5e-3)):
+        err = np.abs(out[k].cpu().numpy() - ref[k]).max(-1)
+        assert (err < tol).mean() >= 0.985 and err.mean() < 2e-4, (k, float(err.max()), float(err.mean()))
+    assert 0.02 < (ref["opacity"][:, 0] > 0.5).mean() < 0.9
