@@ -327,3 +327,22 @@ def test_sg_environment_light_trains_through_the_estimator():
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < 0.6 * losses[0], losses
+
+
+def test_relight_global_illumination_adds_indirect_light(frame, env):
+    """config 5 switch: global_illumination=True adds the secondary rays' own radiance (Li = env * tr + indirect rgb,
+    :735-738) -- never darker than direct-only, strictly brighter where secondary rays hit the body."""
+    rs, rays, mat = frame
+    n = rays.shape[0]
+    g = torch.Generator().manual_seed(2)
+    spp = 64
+    light_u = torch.rand((spp, 3), generator=g).to(DEV)
+    shuffle_u = torch.rand((n, spp), generator=g).to(DEV)
+    bg = torch.zeros(3, device=DEV)
+    a = rs.relight(rays, mat, env, spp, light_u, shuffle_u, background_color=bg, global_illumination=False)
+    b = rs.relight(rays, mat, env, spp, light_u, shuffle_u, background_color=bg, global_illumination=True)
+    assert torch.equal(a["secondary_tr"], b["secondary_tr"])                       # same secondary rays
+    d = b["fg_Lo"] - a["fg_Lo"]
+    assert float(d.min()) >= -1e-6 and float(d.max()) > 1e-4
+    occluded = a["secondary_tr"][:, 0] < 0.5
+    assert float(d[occluded].mean()) > float(d[~occluded].mean())
