@@ -106,18 +106,26 @@ __device__ __forceinline__ void grid_sample_J(const float* __restrict__ vJ, int 
         (x1 - ix) * (iy - y0) * (z1 - iz), (ix - x0) * (iy - y0) * (z1 - iz),
         (x1 - ix) * (y1 - iy) * (iz - z0), (ix - x0) * (y1 - iy) * (iz - z0),
         (x1 - ix) * (iy - y0) * (iz - z0), (ix - x0) * (iy - y0) * (iz - z0)};
+    // accumulation on packed fp32 pairs (v_pk_mul_f32 / v_pk_add_f32: two IEEE-exact operations per instruction, same
+    // rounding as the scalar mul and add of the reference -- this TU is built without FMA contraction -- so results stay
+    // bit-exact while the 96 mul + 96 add of a fetch become 48 + 48 instructions; the kernel is ~70 % issue-bound)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f acc2[6];
 #pragma unroll
-    for (int k = 0; k < 12; k++) out[k] = 0;
+    for (int k = 0; k < 6; k++) acc2[k] = (v2f){0.0f, 0.0f};
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         const int x = (c & 1) ? x1 : x0, y = (c & 2) ? y1 : y0, z = (c & 4) ? z1 : z0;
         if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) {
             float v[12];
             load_corner<LAYOUT>(vJ, vol, ((int64_t)z * H + y) * W + x, v);
+            const v2f w2 = (v2f){wgt[c], wgt[c]};
 #pragma unroll
-            for (int k = 0; k < 12; k++) out[k] += v[k] * wgt[c];
+            for (int k = 0; k < 6; k++) acc2[k] = acc2[k] + (v2f){v[2 * k], v[2 * k + 1]} * w2;
         }
     }
+#pragma unroll
+    for (int k = 0; k < 6; k++) { out[2 * k] = acc2[k].x; out[2 * k + 1] = acc2[k].y; }
 }
 
 __device__ __forceinline__ void J_inv_update(float Ji[9], float x0, float x1, float x2, float g0, float g1, float g2)
