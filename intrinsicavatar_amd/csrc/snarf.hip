@@ -113,12 +113,18 @@ __device__ __forceinline__ void grid_sample_J(const float* __restrict__ vJ, int 
     v2f acc2[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) acc2[k] = (v2f){0.0f, 0.0f};
+    // per-axis range flags and ONE 32-bit base index (the grid has < 2^31 voxels, checked at the entry point): the
+    // per-corner 64-bit multiply-adds were quarter-rate instructions on an issue-bound kernel
+    const bool okx[2] = {x0 >= 0 && x0 < W, x1 >= 0 && x1 < W};
+    const bool oky[2] = {y0 >= 0 && y0 < H, y1 >= 0 && y1 < H};
+    const bool okz[2] = {z0 >= 0 && z0 < D, z1 >= 0 && z1 < D};
+    const int lin0 = (z0 * H + y0) * W + x0;
+    const int sy = W, sz = H * W;
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        const int x = (c & 1) ? x1 : x0, y = (c & 2) ? y1 : y0, z = (c & 4) ? z1 : z0;
-        if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) {
+        if (okx[c & 1] && oky[(c >> 1) & 1] && okz[(c >> 2) & 1]) {
             float v[12];
-            load_corner<LAYOUT>(vJ, vol, ((int64_t)z * H + y) * W + x, v);
+            load_corner<LAYOUT>(vJ, vol, (int64_t)(lin0 + (c & 1) + ((c >> 1) & 1) * sy + ((c >> 2) & 1) * sz), v);
             const v2f w2 = (v2f){wgt[c], wgt[c]};
 #pragma unroll
             for (int k = 0; k < 6; k++) acc2[k] = acc2[k] + (v2f){v[2 * k], v[2 * k + 1]} * w2;
@@ -399,6 +405,7 @@ IA_EXPORT int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt, cons
     const int64_t total = (int64_t)B * N * I;
     if (total == 0) return IA_OK;
     IA_REQUIRE(layout == IA_LAYOUT_NCDHW || layout == IA_LAYOUT_NDHWC, "unknown voxel_J layout");
+    IA_REQUIRE((int64_t)D * H * W < ((int64_t)1 << 30), "voxel grid too large for 32-bit voxel indices");
     hipStream_t s = (hipStream_t)stream;
     // Two bit-identical schedules.  Measured on MI355X (profiles/r01_*): primary-ray batches (most searches converge,
     // uniform length) are ~20 % faster with one item per lane; the huge secondary-ray batches (most searches diverge
