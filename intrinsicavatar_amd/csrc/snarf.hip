@@ -77,8 +77,13 @@ template <int LAYOUT>
 __device__ __forceinline__ void load_corner(const float* __restrict__ vJ, int64_t vol, int64_t lin, float c[12])
 {
     if (LAYOUT == IA_LAYOUT_NDHWC) {
-        const float4* p = reinterpret_cast<const float4*>(vJ + lin * 12);
-        const float4 a = p[0], b = p[1], d = p[2];
+        // vJ is the kernel-uniform grid base and `lin` a 32-bit voxel index (batch offset included): the loads use the
+        // scalar-base + 32-bit vector-offset addressing mode instead of a 64-bit multiply-add per corner
+        const char* base = reinterpret_cast<const char*>(vJ);
+        const uint32_t boff = (uint32_t)lin * 48u;                 // byte offset < 2^32 (checked at the entry point)
+        const float4 a = *reinterpret_cast<const float4*>(base + boff);
+        const float4 b = *reinterpret_cast<const float4*>(base + boff + 16u);
+        const float4 d = *reinterpret_cast<const float4*>(base + boff + 32u);
         c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
         c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
         c[8] = d.x; c[9] = d.y; c[10] = d.z; c[11] = d.w;
@@ -89,7 +94,7 @@ __device__ __forceinline__ void load_corner(const float* __restrict__ vJ, int64_
 }
 
 template <int LAYOUT>
-__device__ __forceinline__ void grid_sample_J(const float* __restrict__ vJ, int D, int H, int W, float gx, float gy,
+__device__ __forceinline__ void grid_sample_J(const float* __restrict__ vJ, int vox0, int D, int H, int W, float gx, float gy,
                                               float gz, float out[12])
 {
     const int64_t vol = (int64_t)D * H * W;
@@ -118,7 +123,7 @@ __device__ __forceinline__ void grid_sample_J(const float* __restrict__ vJ, int 
     const bool okx[2] = {x0 >= 0 && x0 < W, x1 >= 0 && x1 < W};
     const bool oky[2] = {y0 >= 0 && y0 < H, y1 >= 0 && y1 < H};
     const bool okz[2] = {z0 >= 0 && z0 < D, z1 >= 0 && z1 < D};
-    const int lin0 = (z0 * H + y0) * W + x0;
+    const int lin0 = vox0 + (z0 * H + y0) * W + x0;
     const int sy = W, sz = H * W;
 #pragma unroll
     for (int c = 0; c < 8; c++) {
@@ -170,7 +175,9 @@ __global__ __launch_bounds__(THREADS) void broyden_kernel(
     const int i_batch = (int)(index / (N * I));
     const int64_t i_point = (index % (N * I)) / I;
     const int i_init = (int)((index % (N * I)) % I);
-    const float* vJ = voxel_J + (int64_t)i_batch * 12 * vol;
+    // channel-last: uniform base + per-item voxel offset; reference layout: per-batch base pointer
+    const float* vJ = (LAYOUT == IA_LAYOUT_NDHWC) ? voxel_J : voxel_J + (int64_t)i_batch * 12 * vol;
+    const int vox0 = (LAYOUT == IA_LAYOUT_NDHWC) ? (int)(i_batch * vol) : 0;
     const float offset[3] = {offset_g[0], offset_g[1], offset_g[2]};
     const float scale[3] = {scale_g[0], scale_g[1], scale_g[2]};
     float gx[3], gx_new[3] = {0, 0, 0}, xt[3], x_l[3];
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(THREADS) void broyden_kernel(
     x_l[2] = ixd * T[0 * 4 + 2] + iyd * T[1 * 4 + 2] + izd * T[2 * 4 + 2];
 
     float Jl[12];
-    grid_sample_J<LAYOUT>(vJ, D, H, W, scale[0] * (x_l[0] + offset[0]), scale[1] * (x_l[1] + offset[1]),
+    grid_sample_J<LAYOUT>(vJ, vox0, D, H, W, scale[0] * (x_l[0] + offset[0]), scale[1] * (x_l[1] + offset[1]),
                           scale[2] * (x_l[2] + offset[2]), Jl);
     float Ji[9];
     Ji[0] = Jl[0]; Ji[3] = Jl[1]; Ji[6] = Jl[2];
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(THREADS) void broyden_kernel(
         const float ix = scale[0] * (x_l[0] + offset[0]);
         const float iy = scale[1] * (x_l[1] + offset[1]);
         const float iz = scale[2] * (x_l[2] + offset[2]);
-        grid_sample_J<LAYOUT>(vJ, D, H, W, ix, iy, iz, Jl);
+        grid_sample_J<LAYOUT>(vJ, vox0, D, H, W, ix, iy, iz, Jl);
         gx_new[0] = Jl[0] * x_l[0] + Jl[1] * x_l[1] + Jl[2] * x_l[2] + Jl[3] - xt[0];
         gx_new[1] = Jl[4] * x_l[0] + Jl[5] * x_l[1] + Jl[6] * x_l[2] + Jl[7] - xt[1];
         gx_new[2] = Jl[8] * x_l[0] + Jl[9] * x_l[1] + Jl[10] * x_l[2] + Jl[11] - xt[2];
@@ -272,6 +279,7 @@ __global__ __launch_bounds__(THREADS) void broyden_persistent_kernel(
     float xt[3] = {0, 0, 0}, x_l[3] = {0, 0, 0}, gx[3] = {0, 0, 0}, u[3] = {0, 0, 0};
     float Ji[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const float* vJ = voxel_J;
+    int vox0 = 0;
 
     for (;;) {
         // ---- refill idle lanes from the wave's chunk ----
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(THREADS) void broyden_persistent_kernel(
                     const int i_batch = (int)(index / (N * I));
                     const int64_t i_point = (index % (N * I)) / I;
                     const int i_init = (int)((index % (N * I)) % I);
-                    vJ = voxel_J + (int64_t)i_batch * 12 * vol;
+                    if (LAYOUT == IA_LAYOUT_NDHWC) vox0 = (int)(i_batch * vol); else vJ = voxel_J + (int64_t)i_batch * 12 * vol;
                     xt[0] = xd_tgt[((int64_t)i_batch * N + i_point) * 3 + 0];
                     xt[1] = xd_tgt[((int64_t)i_batch * N + i_point) * 3 + 1];
                     xt[2] = xd_tgt[((int64_t)i_batch * N + i_point) * 3 + 2];
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(THREADS) void broyden_persistent_kernel(
         const float iy = scale[1] * (x_l[1] + offset[1]);
         const float iz = scale[2] * (x_l[2] + offset[2]);
         float Jl[12];
-        grid_sample_J<LAYOUT>(vJ, D, H, W, ix, iy, iz, Jl);
+        grid_sample_J<LAYOUT>(vJ, vox0, D, H, W, ix, iy, iz, Jl);
         if (it < 0) {
             // initial fetch: J_inv guess and g(x0)   (fuse_cuda_kernel_fast.cu:295-331)
             Ji[0] = Jl[0]; Ji[3] = Jl[1]; Ji[6] = Jl[2];
@@ -405,7 +413,7 @@ IA_EXPORT int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt, cons
     const int64_t total = (int64_t)B * N * I;
     if (total == 0) return IA_OK;
     IA_REQUIRE(layout == IA_LAYOUT_NCDHW || layout == IA_LAYOUT_NDHWC, "unknown voxel_J layout");
-    IA_REQUIRE((int64_t)D * H * W < ((int64_t)1 << 30), "voxel grid too large for 32-bit voxel indices");
+    IA_REQUIRE((int64_t)B * D * H * W < ((int64_t)1 << 28), "voxel grid too large for 32-bit voxel indices");
     hipStream_t s = (hipStream_t)stream;
     // Two bit-identical schedules.  Measured on MI355X (profiles/r01_*): primary-ray batches (most searches converge,
     // uniform length) are ~20 % faster with one item per lane; the huge secondary-ray batches (most searches diverge
