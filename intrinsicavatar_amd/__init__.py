@@ -4,8 +4,26 @@ render_step hot path, exposed through the operator surface the reference imports
     intrinsicavatar_amd.nerfacc       <- `nerfacc` (traverse_grids, render_weight_from_alpha, ...)
     intrinsicavatar_amd.lib_nerfacc   <- `lib.nerfacc` (ray_resampling*, pack/unpack)
     intrinsicavatar_amd.fast_snarf    <- fast-SNARF JIT modules (fuse_broyden, filter, precompute)
+    intrinsicavatar_amd.tinycudann    <- `tinycudann` (Encoding: HashGrid / SphericalHarmonics, incl. double backward)
+    intrinsicavatar_amd.pbr           <- `lib.torch_pbr` call chains (estimators, BRDF sample / pdf, environment lights)
 
 All compute runs in hand-written HIP kernels behind the C ABI of include/ia_amd.h
 (libia_amd.so); PyTorch is used for device memory, streams and torch.distributed only.
 """
 __version__ = "0.1.0"
+
+
+def install_aliases() -> None:
+    """make the reference's own import statements resolve to this package:
+    `import nerfacc`, `from nerfacc.volrend import ...`, `from lib.nerfacc import ...`, `import tinycudann as tcnn`.
+    Call it before the reference's modules are imported (top of launch.py / sitecustomize.py)."""
+    import sys
+    import types
+    from . import lib_nerfacc, nerfacc, tinycudann
+    sys.modules["nerfacc"] = nerfacc
+    sys.modules["nerfacc.volrend"] = nerfacc
+    lib = sys.modules.get("lib") or types.ModuleType("lib")
+    lib.nerfacc = lib_nerfacc
+    sys.modules["lib"] = lib
+    sys.modules["lib.nerfacc"] = lib_nerfacc
+    sys.modules["tinycudann"] = tinycudann

@@ -55,3 +55,17 @@ def test_package_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "libia_oracle" not in src, f
+
+
+def test_install_aliases_resolves_the_reference_imports():
+    """the import statements of the reference (models/intrinsic_avatar.py:20-46, models/volrend.py:10-14,
+    models/network_utils.py:7) land in this package after install_aliases(); no GPU needed to import."""
+    import subprocess, sys
+    code = ("import intrinsicavatar_amd as ia; ia.install_aliases();"
+            "import nerfacc; from nerfacc import traverse_grids, render_weight_from_alpha, accumulate_along_rays, OccGridEstimator;"
+            "from nerfacc.volrend import render_weight_from_alpha as r2;"
+            "from lib.nerfacc import ray_resampling, ray_resampling_merge, ray_resampling_fine, ray_resampling_sdf_fine, pack_info, unpack_info;"
+            "import tinycudann as tcnn; assert hasattr(tcnn, 'Encoding') and hasattr(tcnn, 'free_temporary_memory');"
+            "assert nerfacc.__name__ == 'intrinsicavatar_amd.nerfacc'; print('ok')")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:]
