@@ -19,11 +19,13 @@ def install_aliases() -> None:
     Call it before the reference's modules are imported (top of launch.py / sitecustomize.py)."""
     import sys
     import types
-    from . import lib_nerfacc, nerfacc, tinycudann
+    from . import lib_nerfacc, nerfacc, pbr, tinycudann
     sys.modules["nerfacc"] = nerfacc
     sys.modules["nerfacc.volrend"] = nerfacc
     lib = sys.modules.get("lib") or types.ModuleType("lib")
     lib.nerfacc = lib_nerfacc
     sys.modules["lib"] = lib
     sys.modules["lib.nerfacc"] = lib_nerfacc
+    lib.torch_pbr = pbr                     # rgb_to_srgb, luminance, luma, max_value (+ the estimator kernels)
+    sys.modules["lib.torch_pbr"] = pbr
     sys.modules["tinycudann"] = tinycudann

@@ -218,6 +218,37 @@ def render_transmittance_from_alpha(alphas, packed_info=None, ray_indices=None, 
     return render_weight_from_alpha(alphas, packed_info, ray_indices, n_rays)[1]
 
 
+def render_weight_from_density(t_starts: Tensor, t_ends: Tensor, sigmas: Tensor, packed_info: Optional[Tensor] = None,
+                               ray_indices: Optional[Tensor] = None, n_rays: Optional[int] = None
+                               ) -> Tuple[Tensor, Tensor, Tensor]:
+    """nerfacc.render_weight_from_density (imported by models/volrend.py:10-14, density-based `rendering` variant):
+    alpha_i = 1 - exp(-sigma_i (t_end_i - t_start_i)), then the alpha compositing kernel.  Returns (weights, trans, alphas).
+    Not exercised by the SDF path of render_step (Laplace density -> get_alpha); parity unpinned (nerfacc is not in tree)."""
+    alphas = 1.0 - torch.exp(-sigmas * (t_ends - t_starts))
+    w, tr = render_weight_from_alpha(alphas, packed_info, ray_indices, n_rays)
+    return w, tr, alphas
+
+
+def render_visibility_from_alpha(alphas: Tensor, packed_info: Optional[Tensor] = None, ray_indices: Optional[Tensor] = None,
+                                 n_rays: Optional[int] = None, early_stop_eps: float = 1e-4, alpha_thre: float = 0.0) -> Tensor:
+    """nerfacc.render_visibility_from_alpha (imported at models/intrinsic_avatar.py:24, occ_grid/temporal_occ_grid.py:10;
+    its call site is behind `alpha_fn is not None`, which the model never passes): visible = T >= early_stop_eps
+    [and alpha >= alpha_thre]."""
+    trans = render_transmittance_from_alpha(alphas.detach(), packed_info, ray_indices, n_rays)
+    vis = trans >= early_stop_eps
+    if alpha_thre > 0:
+        vis = vis & (alphas >= alpha_thre)
+    return vis
+
+
+def render_visibility_from_density(t_starts: Tensor, t_ends: Tensor, sigmas: Tensor, packed_info: Optional[Tensor] = None,
+                                   ray_indices: Optional[Tensor] = None, n_rays: Optional[int] = None,
+                                   early_stop_eps: float = 1e-4, alpha_thre: float = 0.0) -> Tensor:
+    """nerfacc.render_visibility_from_density: the same test on alphas derived from densities."""
+    alphas = 1.0 - torch.exp(-sigmas * (t_ends - t_starts))
+    return render_visibility_from_alpha(alphas, packed_info, ray_indices, n_rays, early_stop_eps, alpha_thre)
+
+
 class _Accumulate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weights, values, ray_indices, packed_info):

@@ -105,6 +105,28 @@ class EnvironmentLightSG(torch.nn.Module):
         return e
 
 
+# ----------------------------------------------------------------------------- colour helpers of lib.torch_pbr
+def rgb_to_srgb(f: Tensor) -> Tensor:
+    """linear -> sRGB OETF (models/intrinsic_avatar.py:18,1626-1637; same formula as models/utils.py:98)."""
+    f = f.clamp(0.0, 1.0)
+    return torch.where(f <= 0.0031308, f * 12.92, torch.pow(f.clamp_min(0.0031308), 1.0 / 2.4) * 1.055 - 0.055)
+
+
+def luminance(rgb: Tensor) -> Tensor:
+    """Rec. 709 luminance, [..., 3] -> [..., 1] (models/pbr/material.py:9)."""
+    return 0.2126 * rgb[..., 0:1] + 0.7152 * rgb[..., 1:2] + 0.0722 * rgb[..., 2:3]
+
+
+def luma(x: Tensor) -> Tensor:
+    """channel mean broadcast back to 3 channels (nvdiffrecmc convention; systems/intrinsic_avatar.py:13)."""
+    return ((x[..., 0:1] + x[..., 1:2] + x[..., 2:3]) / 3.0).expand_as(x)
+
+
+def max_value(x: Tensor) -> Tensor:
+    """channel maximum broadcast back to 3 channels (nvdiffrecmc convention)."""
+    return torch.max(x, dim=-1, keepdim=True)[0].expand_as(x)
+
+
 MODES = {"light": 0, "uniform_light": 1, "mis": 2, "mats": 3}
 
 

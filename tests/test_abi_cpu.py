@@ -62,9 +62,12 @@ def test_install_aliases_resolves_the_reference_imports():
     models/network_utils.py:7) land in this package after install_aliases(); no GPU needed to import."""
     import subprocess, sys
     code = ("import intrinsicavatar_amd as ia; ia.install_aliases();"
-            "import nerfacc; from nerfacc import traverse_grids, render_weight_from_alpha, accumulate_along_rays, OccGridEstimator;"
-            "from nerfacc.volrend import render_weight_from_alpha as r2;"
-            "from lib.nerfacc import ray_resampling, ray_resampling_merge, ray_resampling_fine, ray_resampling_sdf_fine, pack_info, unpack_info;"
+            "import nerfacc; from nerfacc import (RayIntervals, OccGridEstimator, traverse_grids, render_visibility_from_alpha,"
+            " render_visibility_from_density, render_weight_from_alpha, accumulate_along_rays);"
+            "from nerfacc.volrend import render_weight_from_density, render_weight_from_alpha as r2, accumulate_along_rays as a2;"
+            "from lib.torch_pbr import rgb_to_srgb, luminance, luma, max_value; import lib.torch_pbr;"
+            "from lib.nerfacc import (ray_resampling, ray_resampling_merge, ray_resampling_fine, ray_resampling_sdf_fine, pack_info,"
+            " pack_data, unpack_info, unpack_data);"
             "import tinycudann as tcnn; assert hasattr(tcnn, 'Encoding') and hasattr(tcnn, 'free_temporary_memory');"
             "assert nerfacc.__name__ == 'intrinsicavatar_amd.nerfacc'; print('ok')")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)

@@ -358,3 +358,33 @@ def test_fast_snarf_roundtrip_property(ops):
     assert (xd_rec - tgt).norm(dim=-1).max() < 2e-5      # cvg threshold 1e-5 (+ fp32 interpolation noise)
     mask = sn.filter(x, valid)
     assert mask.sum() <= valid.sum() and torch.all(valid | ~mask)
+
+
+def test_density_and_visibility_wrappers(ops):
+    """nerfacc.render_weight_from_density / render_visibility_from_alpha / _from_density (imported by the reference,
+    off the SDF path): definitions checked against a per-ray fp64 loop."""
+    rng = np.random.default_rng(12)
+    n_rays = 300
+    steps = rng.integers(0, 20, n_rays)
+    packed = np.stack([np.cumsum(steps) - steps, steps], -1).astype(np.int64)
+    S = int(steps.sum())
+    ts = np.sort(rng.random(S)).astype(np.float32)
+    te = (ts + rng.random(S) * 0.05).astype(np.float32)
+    sig = (rng.random(S) * 30).astype(np.float32)
+    ri = np.repeat(np.arange(n_rays), steps)
+    na = ops["nerfacc"]
+    w, tr, al = na.render_weight_from_density(T(ts), T(te), T(sig), ray_indices=T(ri), n_rays=n_rays)
+    vis_a = na.render_visibility_from_alpha(al, ray_indices=T(ri), n_rays=n_rays, early_stop_eps=1e-2, alpha_thre=0.05)
+    vis_d = na.render_visibility_from_density(T(ts), T(te), T(sig), ray_indices=T(ri), n_rays=n_rays, early_stop_eps=1e-2,
+                                              alpha_thre=0.05)
+    a64 = 1 - np.exp(-sig.astype(np.float64) * (te.astype(np.float64) - ts))
+    t64 = np.ones(S)
+    for b, s in packed:
+        if s > 0:
+            t64[b:b + s] = np.concatenate([[1.0], np.cumprod(1 - a64[b:b + s])[:-1]])
+    np.testing.assert_allclose(N(al), a64, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(N(tr), t64, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(N(w), t64 * a64, rtol=1e-4, atol=1e-6)
+    ref_vis = (t64 >= 1e-2) & (a64 >= 0.05)
+    safe = (np.abs(t64 - 1e-2) > 1e-5) & (np.abs(a64 - 0.05) > 1e-5)
+    assert np.array_equal(N(vis_a)[safe], ref_vis[safe]) and torch.equal(vis_a, vis_d)
