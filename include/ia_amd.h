@@ -304,7 +304,9 @@ int ia_mlp_bwd_fused(int kind, int64_t n, int n_segs, const float* const* seg_pt
 int ia_sdf_mlp_bwd_fused(int64_t n, int n_segs, const float* const* seg_ptr, const int* seg_stride, const int* seg_width,
                          const float* seg_mul, const float* seg_add, const float* W1, const float* b1, const float* Wo,
                          const float* bo, const float* jac, const float* g_out, const float* q, float* gE, float* gG,
-                         float* dW1 /*[64,35]*/, float* db1, float* dWo /*[13,64]*/, float* dbo, ia_stream_t stream);
+                         float* dW1 /*[64,35]*/, float* db1, float* dWo /*[13,64]*/, float* dbo,
+                         float* g_xyz /*[n,3] or NULL: first-order gradient w.r.t. the xyz input columns (pose gradients)*/,
+                         ia_stream_t stream);
 
 /* split-K weight gradient on the matrix cores: dW[M,ldw] += G[:, :M]^T . A[:, :N], db[M] += column sums of G
  * (M <= 64, N <= 96; strides <= 64 / 96 floats; accumulates with atomics into caller-zeroed dW / db; db may be NULL) */

@@ -374,6 +374,7 @@ struct SdfTrainArgs {
     const float* g_out;    // [n,13]
     const float* q;        // [n,3]
     float *gE, *gG;        // [n,32] each
+    float* gXYZ;           // [n,3] or NULL: first-order d L / d (2 x' - 1) (the xyz columns of dz W1), for d L / d x
     float *dW1, *db1, *dWo, *dbo;      // [64,35] [64] [13,64] [13]  accumulated into
 };
 
@@ -482,6 +483,7 @@ __global__ __launch_bounds__(THREADS) void sdf_train_kernel(SdfTrainArgs a)
         ACC2_FOREACH(nt, r, row, col, lane) {
             const int64_t p = p0 + row;
             if (col < 32 && p < a.n) a.gE[p * 32 + col] = acc[nt][r];
+            if (a.gXYZ && col >= 32 && col < 35 && p < a.n) a.gXYZ[p * 3 + (col - 32)] = acc[nt][r];
         }
     }
     float* sRed = sTiles;
@@ -519,7 +521,7 @@ IA_EXPORT int ia_sdf_mlp_bwd_fused(int64_t n, int n_segs, const float* const* se
                                    const int* seg_width, const float* seg_mul, const float* seg_add, const float* W1,
                                    const float* b1, const float* Wo, const float* bo, const float* jac,
                                    const float* g_out, const float* q, float* gE, float* gG, float* dW1, float* db1,
-                                   float* dWo, float* dbo, ia_stream_t stream)
+                                   float* dWo, float* dbo, float* g_xyz, ia_stream_t stream)
 {
     if (n == 0) return IA_OK;
     IA_REQUIRE(dW1 && db1 && dWo && dbo && gE && gG, "ia_sdf_mlp_bwd_fused: all output buffers are required");
@@ -528,7 +530,7 @@ IA_EXPORT int ia_sdf_mlp_bwd_fused(int64_t n, int n_segs, const float* const* se
     int r = mlp::fill_segs(a.segs, 0, n_segs, seg_ptr, seg_stride, seg_width, seg_mul, seg_add);
     if (r != IA_OK) return r;
     a.W1 = W1; a.b1 = b1; a.Wo = Wo; a.bo = bo; a.jac = jac; a.g_out = g_out; a.q = q;
-    a.gE = gE; a.gG = gG; a.dW1 = dW1; a.db1 = db1; a.dWo = dWo; a.dbo = dbo;
+    a.gE = gE; a.gG = gG; a.dW1 = dW1; a.db1 = db1; a.dWo = dWo; a.dbo = dbo; a.gXYZ = g_xyz;
     constexpr int PER_WAVE = TM * (2 * 37 + 2 * 65 + 17);
     constexpr int TILES = WAVES * PER_WAVE > 64 * LDR ? WAVES * PER_WAVE : 64 * LDR;
     constexpr size_t lds = sizeof(float) * (HID * 37 + 16 * 65 + 144 + TILES);

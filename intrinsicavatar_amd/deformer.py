@@ -55,28 +55,62 @@ class SNARFDeformer:
 
     # -- per query batch -------------------------------------------------------------
     @torch.no_grad()
-    def search(self, pts: Tensor, want_fwd: bool = False):
-        """K8 for all 13 inits. returns x [P,13,3], valid [P,13] (pre-filter), fwd_J [P,13,3,3] or None."""
+    def search(self, pts: Tensor, want_fwd: bool = False, want_jinv: bool = False):
+        """K8 for all 13 inits. returns x [P,13,3], valid [P,13] (pre-filter), fwd_J [P,13,3,3] or None
+        (, J_inv [P,13,3,3] -- Broyden's inverse-Jacobian estimate at the returned root -- when want_jinv)."""
         P = pts.shape[0]
         I = self.init_bones.shape[0]
         x = torch.zeros((1, P, I, 3), device=self.device)
-        Jinv = None      # use_j_inv: false (configs/deformer/snarf_deformer.yaml:11): the kernel skips the store
+        # use_j_inv: false (configs/deformer/snarf_deformer.yaml:11): inference never reads J_inv and the kernel skips the
+        # store; training with pose gradients needs it for the implicit-differentiation correction (deformer_torch.py:57-76)
+        Jinv = torch.zeros((1, P, I, 3, 3), device=self.device) if want_jinv else None
         valid = torch.zeros((1, P, I), dtype=torch.bool, device=self.device)
         fwd = torch.zeros((1, P, I, 3, 3), device=self.device) if want_fwd else None
         fast_snarf.fuse_broyden(x, pts.reshape(1, P, 3), None, fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs,
                                 self.init_bones, True, Jinv, valid, self.offset_kernel, self.scale_kernel, 1e-5, 1e-1,
                                 fwd_J=fwd)
+        if want_jinv:
+            return x[0], valid[0], (fwd[0] if want_fwd else None), Jinv[0]
         return x[0], valid[0], (fwd[0] if want_fwd else None)
 
+    def query_weights(self, xc: Tensor) -> Tensor:
+        """skinning weights [P,24] at canonical points: trilinear, align_corners, border-clamped lookup of lbs_voxel_final
+        (deformer_torch.py:198-209)."""
+        g = ((xc + self.offset_kernel) * self.scale_kernel).reshape(1, -1, 1, 1, 3)
+        w = torch.nn.functional.grid_sample(self.lbs_voxel_final, g, align_corners=True, mode="bilinear",
+                                            padding_mode="border")
+        return w.reshape(w.shape[1], -1).t()
+
+    def implicit_pose_terms(self, xc: Tensor, J_inv: Tensor, valid: Tensor):
+        """the two places the bone transforms enter the training graph (ForwardDeformer.forward, version 1,
+        deformer_torch.py:57-76, and SNARFDeformer.deform_, snarf_deformer.py:176-184), for the winning roots only:
+          * xc + correction, correction = -J_inv (LBS(xc, tfs) - stopgrad(LBS(xc, tfs))): zero in value, and its derivative
+            with respect to tfs is the implicit-function derivative of the root;
+          * the linearly blended rotation block T[:, :3, :3] that pushes normals to observation space.
+        xc, J_inv, valid are constants (no_grad search results); self.tfs carries the graph."""
+        with torch.no_grad():
+            w = self.query_weights(xc)                                          # [P,24]
+        T = (w @ self.tfs[0].reshape(w.shape[1], 16)).reshape(-1, 4, 4)
+        R = T[:, :3, :3]
+        xd = (R * xc[:, None, :]).sum(-1) + T[:, :3, 3]
+        corr = -(J_inv * (xd - xd.detach())[:, None, :]).sum(-1)
+        corr = corr * valid[:, None].to(corr.dtype)
+        return xc + corr, R
+
     @torch.no_grad()
-    def deform(self, pts: Tensor, geometry, with_grad: bool = False, with_feature: bool = False, want_fwd: bool = False):
+    def deform(self, pts: Tensor, geometry, with_grad: bool = False, with_feature: bool = False, want_fwd: bool = False,
+               want_jinv: bool = False):
         """SNARFDeformer.deform (snarf_deformer.py:187-261).
         returns dict(pts_cano, sdf, valid[, sdf_grad, sdf_grad_cano][, feature], + bookkeeping)."""
         pts = pts.contiguous().float()
         P, I = pts.shape[0], self.init_bones.shape[0]
         dev = self.device
         lib, st = L.lib(), L.stream()
-        x, valid, fwd = self.search(pts, want_fwd=with_grad or want_fwd)
+        J_inv = None
+        if want_jinv:
+            x, valid, fwd, J_inv = self.search(pts, want_fwd=with_grad or want_fwd, want_jinv=True)
+        else:
+            x, valid, fwd = self.search(pts, want_fwd=with_grad or want_fwd)
         mask = torch.empty((P, I), dtype=torch.bool, device=dev)
         cnt = torch.empty(P, dtype=torch.int32, device=dev)
         start = torch.empty(P, dtype=torch.int32, device=dev)
@@ -100,7 +134,7 @@ class SNARFDeformer:
         csdf, sdf_stride = cf, 13
         out = dict(pts_cano=torch.empty((P, 3), device=dev), sdf=torch.empty(P, device=dev),
                    valid=torch.empty(P, dtype=torch.bool, device=dev), sel=torch.empty(P, dtype=torch.int32, device=dev),
-                   cand_src=cand_src, n_candidates=Q, fwd_J=fwd)
+                   cand_src=cand_src, n_candidates=Q, fwd_J=fwd, J_inv=J_inv)
         if with_grad:
             out["sdf_grad"] = torch.empty((P, 3), device=dev)
             out["sdf_grad_cano"] = torch.empty((P, 3), device=dev)

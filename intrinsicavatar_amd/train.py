@@ -43,6 +43,15 @@ def wgrad(G: Tensor, M: int, A: Tensor, N: int, want_bias: bool = True):
     return dW, db
 
 
+def _jac_contract_T(jac: Tensor, v: Tensor) -> Tensor:
+    """out[n,3] = sum_k v[n,k] * jac[n,k,:]   (d L / d x' from d L / d enc; ia_hashgrid_jac_contract mode 0)."""
+    n, K = jac.shape[0], jac.shape[1]
+    out = torch.empty((n, 3), device=jac.device)
+    L.check(L.lib().ia_hashgrid_jac_contract(L.i32(0), L.i64(n), L.i32(K), L.ptr(jac), C.c_void_p(v.data_ptr()),
+                                             L.i32(v.stride(0)), L.ptr(out), L.i32(3), L.stream()), "ia_hashgrid_jac_contract")
+    return out
+
+
 def _segs(segs):
     ns = len(segs)
     ptrs = (C.c_void_p * ns)()
@@ -82,12 +91,21 @@ class _SDFField(Function):
         if FUSED_WGRAD:
             dW1k, db1 = torch.zeros((64, 35), device=dev), torch.zeros(64, device=dev)
             dW2, db2 = torch.zeros((13, 64), device=dev), torch.zeros(13, device=dev)
+            want_x = ctx.needs_input_grad[0]
+            g_xyz = torch.empty((n, 3), device=dev) if want_x else None
             L.check(L.lib().ia_sdf_mlp_bwd_fused(L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds, L.ptr(W1k), L.ptr(b1),
                                                  L.ptr(W2), L.ptr(b2), L.ptr(jac), L.ptr(g_y), L.ptr(q), L.ptr(gE), L.ptr(gG),
-                                                 L.ptr(dW1k), L.ptr(db1), L.ptr(dW2), L.ptr(db2), L.stream()),
+                                                 L.ptr(dW1k), L.ptr(db1), L.ptr(dW2), L.ptr(db2), L.ptr(g_xyz), L.stream()),
                     "ia_sdf_mlp_bwd_fused")
             fields.hashgrid_backward(xp, gE, g_table, g_jac=gG, q=q, level_mask=ctx.level_bits)
-            return None, g_table, dW1k, db1, dW2, db2, None, None, None
+            g_x = None
+            if want_x:
+                # first-order d L / d x (pose gradients, SNARF's implicit differentiation): J_enc^T gE + 2 g_xyz, / scale.
+                # The dependence of the analytic normal on x (a Hessian term; tiny-cuda-nn returns zero for it too) is dropped.
+                g_x = (_jac_contract_T(jac, gE) + 2.0 * g_xyz) / scale
+            return g_x, g_table, dW1k, db1, dW2, db2, None, None, None
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("pose gradients (d L / d x_cano) are only produced by the fused backward (FUSED_WGRAD)")
         Hh, U = torch.empty((n, 36), device=dev), torch.empty((n, 36), device=dev)
         DZ, GZ, A, DGS = (torch.empty((n, 64), device=dev) for _ in range(4))
         L.check(L.lib().ia_sdf_mlp_bwd(L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds, L.ptr(W1k), L.ptr(b1),
@@ -150,6 +168,7 @@ class _Radiance(Function):
     @staticmethod
     def forward(ctx, x, table, feat, refl01, normal_world, W1k, b1, W2, b2, W3, b3, center, scale, level_bits=0xFFFFFFFF):
         ctx.level_bits = int(level_bits)
+        ctx.scale = scale
         xp = ((x - center) / scale + 0.5).contiguous()
         enc = fields.hashgrid_forward(xp, table)
         refl01 = refl01.contiguous()
@@ -195,7 +214,12 @@ class _Radiance(Function):
         g_refl01 = torch.empty((n, 3), device=dev)
         L.check(L.lib().ia_sh4_bwd(L.i64(n), L.ptr(refl01), C.c_void_p(g_sh.data_ptr()), L.i32(68), L.ptr(g_refl01),
                                    L.stream()), "ia_sh4_bwd")
-        return (None, g_table, g_feat, g_refl01, g_nw, dW1, db1, dW2, db2, dW3, db3, None, None, None)
+        g_pos = None
+        if ctx.needs_input_grad[0]:       # pose gradients: the hash Jacobian of grid #2 is recomputed here (not kept in forward)
+            scale = ctx.scale
+            _, jac2 = fields.hashgrid_forward(xp, table, with_jac=True)
+            g_pos = (_jac_contract_T(jac2, g_x) + 2.0 * g_x[:, 32:35]) / scale
+        return (g_pos, g_table, g_feat, g_refl01, g_nw, dW1, db1, dW2, db2, dW3, db3, None, None, None)
 
 
 def curvature_laplace(geo, pts_cano: Tensor, grad_c: Tensor, rand_u: Tensor, eps: float = 1e-4) -> Tensor:
@@ -222,14 +246,23 @@ def shade_differentiable(rs, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor
     dfm, geo, rad = rs.deformer, rs.geometry, rs.radiance
     n_rays = packed_info.shape[0]
     pts = render.ray_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
+    pose_grad = dfm.tfs.requires_grad and torch.is_grad_enabled()
     with torch.no_grad():
-        d = dfm.deform(pts, geo, with_grad=False, with_feature=False, want_fwd=True)      # candidate search + winner selection (the gradient is evaluated once, on the winners, by _SDFField)
+        d = dfm.deform(pts, geo, with_grad=False, with_feature=False, want_fwd=True, want_jinv=pose_grad)      # candidate search + winner selection (the gradient is evaluated once, on the winners, by _SDFField)
         valid = d["valid"]
         sel = d["sel"].long().clamp(min=0)
-        c2w = d["fwd_J"].reshape(-1, 3, 3)[d["cand_src"].long()[sel]] if d["n_candidates"] > 0 else \
-            torch.zeros((pts.shape[0], 3, 3), device=pts.device)
+        win = d["cand_src"].long()[sel] if d["n_candidates"] > 0 else None
+        c2w = d["fwd_J"].reshape(-1, 3, 3)[win] if win is not None else torch.zeros((pts.shape[0], 3, 3), device=pts.device)
+    pts_cano = d["pts_cano"]
+    if pose_grad and win is not None:
+        # pose_correction / SMPL parameters are being optimised (configs/config.yaml: pose_correction.enable_pose_correction):
+        # the roots get their implicit-function derivative and the normal push-forward its blended-rotation derivative;
+        # the forward VALUES stay the ones the search kernels produced.
+        J_inv_win = d["J_inv"].reshape(-1, 3, 3)[win]
+        pts_cano, R = dfm.implicit_pose_terms(pts_cano, J_inv_win, valid)
+        c2w = c2w + (R - R.detach()) * valid[:, None, None].to(R.dtype)
     W1k, b1, W2, b2 = geo.effective_weights()
-    out, grad_c = _SDFField.apply(d["pts_cano"], geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale, geo.prog.level_bits())
+    out, grad_c = _SDFField.apply(pts_cano, geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale, geo.prog.level_bits())
     vf = valid[:, None].float()
     # invalid points: sdf 1e5, feature 0, gradient [0,0,1] (snarf_deformer.py:192-231)
     dflt_g = torch.tensor([0.0, 0.0, 1.0], device=pts.device)
@@ -239,13 +272,15 @@ def shade_differentiable(rs, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor
     w2s_rot = dfm.w2s[:3, :3].contiguous()
     normal_smpl, normal_world, refl01 = _ShadePrep.apply(sdf_grad, rays_d, ray_indices, w2s_rot)
     alphas = _Alpha.apply(sdf, t_ends - t_starts, rs.density.get_beta())
-    rgbs = _Radiance.apply(d["pts_cano"], rad.grid_params, feat, refl01, normal_world, *rad.effective_weights(),
+    rgbs = _Radiance.apply(pts_cano, rad.grid_params, feat, refl01, normal_world, *rad.effective_weights(),
                            rad.center, rad.scale, rad.prog.level_bits())
     weights, trans = nerfacc._WeightFromAlpha.apply(alphas, packed_info)
     acc = lambda v: nerfacc._Accumulate.apply(weights, v, ray_indices, packed_info)      # noqa: E731
     res = dict(comp_rgb=acc(rgbs), comp_normal=acc(normal_world), opacity=acc(None),
                depth=acc(((t_starts + t_ends) / 2.0)[:, None]), weights=weights, alphas=alphas, rgbs=rgbs, sdf=sdf,
                sdf_grad=sdf_grad, valid=valid, n_samples=pts.shape[0], pts_cano=d["pts_cano"], c2w=c2w)
+    if pose_grad and win is not None:
+        res["J_inv"] = J_inv_win
     if curv_u is not None:       # laplace = 0 for points without a valid candidate (snarf_deformer.py:233-235)
         res["sdf_laplace"] = curvature_laplace(geo, d["pts_cano"], grad_c, curv_u) * valid.float()
     return res

@@ -93,6 +93,67 @@ def test_forward_backward_vs_torch_autograd(frame, lambda_curv):
     assert not bad, worst
 
 
+def test_pose_gradients_vs_torch_autograd(frame):
+    """bone transforms as an optimised input (pose_correction, snarf_deformer.py:93-105): d loss / d tfs through the
+    implicit-function correction of the canonical roots (ForwardDeformer.forward version 1, deformer_torch.py:57-76) and the
+    blended-rotation normal push-forward, against fp64 autograd of the same formulas on the same sample set.  The second
+    derivative of the hash encoding w.r.t. its input is dropped on both sides (tests/torch_ref.py:_HashEncRef)."""
+    from tests import torch_ref as TR
+    rs, rays = frame
+    n = rays.shape[0]
+    g = torch.Generator().manual_seed(5)
+    target = torch.rand((n, 3), generator=g).cuda()
+    tmask = (torch.rand(n, generator=g) > 0.5).float().cuda()
+    dfm = rs.deformer
+    tfs0 = dfm.tfs
+    try:
+        dfm.tfs = tfs0.detach().clone().requires_grad_(True)
+        for p in rs.parameters():
+            p.grad = None
+        out = rs.forward_backward(rays, target, tmask)
+        got = dfm.tfs.grad.detach().cpu().double()[0]
+        table_grad_pose = rs.geometry.grid_params.grad.detach().clone()
+        assert "J_inv" in out and out["n_samples"] > 3000
+        geo, rad, dens = rs.geometry, rs.radiance, rs.density
+        D = lambda t: t.detach().cpu().double()      # noqa: E731
+        l0, l2 = geo.network.layers[0], geo.network.layers[2]
+        rl = rad.network.layers
+        P = dict(geo_center=D(geo.center), geo_scale=D(geo.scale), geo_table=D(geo.grid_params),
+                 geo_mask=D(geo.prog.mask(1500, "cpu")), geo_g0=D(l0.weight_g), geo_v0=D(l0.weight_v), geo_b0=D(l0.bias),
+                 geo_g2=D(l2.weight_g), geo_v2=D(l2.weight_v), geo_b2=D(l2.bias), beta=D(dens.beta), rad_center=D(rad.center),
+                 rad_scale=D(rad.scale), rad_table=D(rad.grid_params), rad_mask=D(rad.prog.mask(1500, "cpu")),
+                 rad_sh_mask=D(rad.sh_mask[0]), rad_W0=D(rl[0].weight), rad_b0=D(rl[0].bias), rad_W2=D(rl[2].weight),
+                 rad_b2=D(rl[2].bias), rad_W4=D(rl[4].weight), rad_b4=D(rl[4].bias), tfs=D(dfm.tfs[0]))
+        P["tfs"].requires_grad_(True)
+        P["geo_table"].requires_grad_(True)
+        rays_s = dfm.transform_rays_w2s(rays.float())
+        _, _, _, ts, te, ri, pi, _ = rs.sample(rays)
+        assert ts.shape[0] == out["n_samples"]
+        with torch.no_grad():
+            lbs_w = dfm.query_weights(out["pts_cano"].detach())
+        c2w0 = out["c2w"].detach()
+        fixed = dict(pts_cano=D(out["pts_cano"]), valid=out["valid"].cpu(), c2w=D(c2w0), w2s_rot=D(dfm.w2s[:3, :3]),
+                     rays_d=D(rays_s[:, 3:6]), ray_indices=ri.cpu(), t_starts=D(ts), t_ends=D(te), n_rays=n,
+                     packed_info=pi.cpu(), lbs_w=D(lbs_w), J_inv=D(out["J_inv"]))
+        loss_ref, _ = TR.shade_reference(P, fixed, D(target), D(tmask))
+        loss_ref.backward()
+        want = P["tfs"].grad
+        assert abs(float(out["loss"]) - float(loss_ref)) < 2e-4 * max(1.0, abs(float(loss_ref)))
+        scale = float(want.abs().max())
+        assert scale > 0 and bool(torch.isfinite(got).all())
+        # the bottom row of each 4x4 never enters LBS of a point (x_h[3] = 1 multiplies column 3 only of rows 0..2)
+        assert float(got[:, 3, :].abs().max()) == 0.0 and float(want[:, 3, :].abs().max()) == 0.0
+        err = float((got - want).abs().max()) / scale
+        rel = float((got - want).norm() / want.norm())
+        print("pose grad: max err / max", err, "rel L2", rel, "scale", scale)
+        assert err < 2e-2 and rel < 2e-2, (err, rel)
+        # the parameter gradients are unaffected by the (zero-valued) correction
+        tg = P["geo_table"].grad
+        assert float((table_grad_pose.cpu().double() - tg).norm() / tg.norm()) < 3e-2
+    finally:
+        dfm.tfs = tfs0
+
+
 def test_fused_mlp_backward_matches_operand_path():
     """csrc/mlp_train.hip (operands in LDS, dW in MFMA accumulators) == csrc/mlp_bwd.hip + ia_wgrad (operands through
     HBM) for the radiance head and the SDF head incl. its second-order terms; ragged n (not a multiple of 32)."""
@@ -147,7 +208,7 @@ def test_fused_mlp_backward_matches_operand_path():
     e = [z(64, 35), z(64), z(13, 64), z(13)]
     L.check(lib.ia_sdf_mlp_bwd_fused(L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds, L.ptr(W1s), L.ptr(b1s), L.ptr(Wo),
                                      L.ptr(bo), L.ptr(jac), L.ptr(g_out), L.ptr(q), L.ptr(gE_b), L.ptr(gG_b),
-                                     *[L.ptr(t) for t in e], L.stream()))
+                                     *[L.ptr(t) for t in e], L.ptr(None), L.stream()))
     assert torch.equal(gE_a, gE_b) and torch.equal(gG_a, gG_b)
     for got, want, what in zip(e, (dW1, db1, dWo, dbo), ("dW1", "db1", "dWo", "dbo")):
         close(got, want, "sdf " + what)

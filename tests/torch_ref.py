@@ -65,13 +65,66 @@ def sh4(d01):
         0.59004358992664352 * x * (-x2 + 3.0 * y2)], -1)
 
 
+class _HashInputGradRef(torch.autograd.Function):
+    """J(x)^T g as a function of (g, table) only: its own backward has no x term -- the second derivative of the encoding
+    with respect to its input is dropped, as in the kernels (pose gradients)."""
+
+    @staticmethod
+    def forward(ctx, g, x, table):
+        ctx.save_for_backward(g, x, table)
+        with torch.enable_grad():
+            x_ = x.detach().requires_grad_(True)
+            return torch.autograd.grad(hashgrid(x_, table.detach()), x_, g.detach())[0]
+
+    @staticmethod
+    def backward(ctx, v):
+        g, x, table = ctx.saved_tensors
+        with torch.enable_grad():
+            x_ = x.detach().requires_grad_(True)
+            t_ = table.detach().requires_grad_(True)
+            u = g.detach().requires_grad_(True)
+            s = torch.autograd.grad(hashgrid(x_, t_), x_, u, create_graph=True)[0]
+            Jv, gt = torch.autograd.grad((s * v.detach()).sum(), (u, t_))
+        return Jv, None, gt
+
+
+class _HashEncRef(torch.autograd.Function):
+    """hash encoding whose input gradient is differentiable in (upstream gradient, table) but not in x."""
+
+    @staticmethod
+    def forward(ctx, x, table):
+        ctx.save_for_backward(x, table)
+        return hashgrid(x.detach(), table.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, table = ctx.saved_tensors
+        with torch.enable_grad():
+            t_ = table.detach().requires_grad_(True)
+            gt = torch.autograd.grad(hashgrid(x.detach(), t_), t_, g.detach())[0]
+        return _HashInputGradRef.apply(g, x, table), gt
+
+
 def shade_reference(P, fixed, target_rgb, target_mask, lambda_eik=0.1, lambda_mask=0.1, lambda_curv=0.0):
     """P: dict of float64 leaf tensors (requires_grad) in the REFERENCE layout; fixed: sample set found by the GPU."""
     x = fixed["pts_cano"].clone().requires_grad_(True)
     valid = fixed["valid"]
+    pose = "tfs" in P
+    c2w = fixed["c2w"]
+    x_in = x
+    if pose:      # ForwardDeformer.forward version 1 (deformer_torch.py:57-76) on the winners + blended-rotation push-forward
+        T = (fixed["lbs_w"] @ P["tfs"].reshape(-1, 16)).reshape(-1, 4, 4)
+        Rb = T[:, :3, :3]
+        xd = (Rb * fixed["pts_cano"][:, None, :]).sum(-1) + T[:, :3, 3]
+        corr = -(fixed["J_inv"] * (xd - xd.detach())[:, None, :]).sum(-1) * valid[:, None].double()
+        x_in = x + corr
+        c2w = c2w + (Rb - Rb.detach()) * valid[:, None, None].double()
     # --- VolumeSDF.forward (geometry.py:152-172)
-    xp = (x - P["geo_center"]) / P["geo_scale"] + 0.5
-    enc = hashgrid(xp, P["geo_table"].reshape(-1, 2)) * P["geo_mask"]
+    xp = (x_in - P["geo_center"]) / P["geo_scale"] + 0.5
+    if pose:
+        enc = _HashEncRef.apply(xp, P["geo_table"].reshape(-1, 2)) * P["geo_mask"]
+    else:
+        enc = hashgrid(xp, P["geo_table"].reshape(-1, 2)) * P["geo_mask"]
     h = torch.cat([xp * 2 - 1, enc], -1)
     W1 = P["geo_g0"] * P["geo_v0"] / P["geo_v0"].norm(dim=1, keepdim=True)
     W2 = P["geo_g2"] * P["geo_v2"] / P["geo_v2"].norm(dim=1, keepdim=True)
@@ -92,7 +145,7 @@ def shade_reference(P, fixed, target_rgb, target_mask, lambda_eik=0.1, lambda_ma
     vf = valid[:, None].double()
     feat = out * vf
     sdf = torch.where(valid, out[:, 0], torch.full_like(out[:, 0], 1e5))
-    sdf_grad = torch.where(valid[:, None], torch.einsum("bij,bj->bi", fixed["c2w"], grad_c), torch.tensor([0., 0., 1.], dtype=x.dtype))
+    sdf_grad = torch.where(valid[:, None], torch.einsum("bij,bj->bi", c2w, grad_c), torch.tensor([0., 0., 1.], dtype=x.dtype))
     # --- shade prep
     R = fixed["w2s_rot"]
     nrm = lambda v: v / v.norm(dim=-1, keepdim=True).clamp_min(1e-6)     # noqa: E731
@@ -105,7 +158,7 @@ def shade_reference(P, fixed, target_rgb, target_mask, lambda_eik=0.1, lambda_ma
     dens = (1 / beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
     alphas = 1 - torch.exp(-dens * (fixed["t_ends"] - fixed["t_starts"]))
     # --- radiance (radiance.py:111-135)
-    xp2 = (x.detach() - P["rad_center"]) / P["rad_scale"] + 0.5
+    xp2 = ((x_in if pose else x.detach()) - P["rad_center"]) / P["rad_scale"] + 0.5
     enc2 = hashgrid(xp2, P["rad_table"].reshape(-1, 2)) * P["rad_mask"]
     inp = torch.cat([xp2 * 2 - 1, enc2, feat, sh4((refl + 1) / 2) * P["rad_sh_mask"], nw], -1)
     hcur = torch.relu(inp @ P["rad_W0"].T + P["rad_b0"])
