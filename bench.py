@@ -96,12 +96,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback in the product path)"
+    # test hook for 1-GPU boxes: IA_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo (RCCL refuses two ranks on
+    # one device) so the N>1 control flow can be exercised without an 8-GPU node; such a run is not a measurement
+    share_gpu = os.environ.get("IA_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
 
     from intrinsicavatar_amd import build
     if rank == 0:
@@ -194,7 +202,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import render_ref as R, oracle as O
             O.build()
-            stride = max(1, n_rays // 12000)
+            stride = max(1, n_rays // 24000)
             sample = rays[::stride].cpu().numpy()
             sc = R.Scene(**export)
             tc = time.perf_counter()
