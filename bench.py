@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--hw", type=int, default=540)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd only (no Adam step)")
     ap.add_argument("--pass", dest="mode", choices=["fwd+bwd", "fwd"], default="fwd+bwd",
                     help="fwd+bwd = training-step form of render_step (BASELINE metric); fwd = inference form")
     args = ap.parse_args()
@@ -130,6 +131,13 @@ def main():
     # the one exchange step of the path: all-reduce(sum) of the gradients over RCCL/xGMI; the two 50 MB
     # hash-table gradients are launched from autograd hooks as soon as they are complete (overlap with the rest of backward)
     sync = parallel.OverlappedGradientAllReduce(params) if (world > 1 and args.mode != "fwd") else None
+    # the optimiser step of the iteration is inside the timed region: torch.optim.Adam semantics with the reference's
+    # parameter groups and linear warm-up (configs/config.yaml:110-148), one fused launch; the summed all-reduce becomes
+    # DDP's mean through grad_scale = 1/world
+    opt = sched = None
+    if args.mode != "fwd" and not args.no_optimizer:
+        from intrinsicavatar_amd import optim
+        opt, sched = optim.reference_optimizer(rs, grad_scale=1.0 / world)
 
     def step():
         if args.mode == "fwd":
@@ -139,6 +147,9 @@ def main():
         out = rs.forward_backward(rays, target_rgb, target_mask)
         if sync is not None:
             sync.finish()
+        if opt is not None:
+            opt.step()
+            sched.step()
         return out
 
     for _ in range(args.warmup):
@@ -218,7 +229,7 @@ def main():
             "config": {"workload": f"{args.hw}x{args.hw} frame ({n_rays} rays), 128 samples/ray, radiance + SDF geometry, "
                                    "fast-SNARF deformer (13 inits), 2x importance resampling, random-init hash-grid/MLP "
                                    "fields, synthetic 24-bone rig",
-                       "pass": args.mode, "frames_per_step_per_gpu": 1, "parallelism": f"frame/ray-batch sharding x{world}",
+                       "pass": args.mode, "optimizer_step_in_timed_region": bool(opt is not None), "frames_per_step_per_gpu": 1, "parallelism": f"frame/ray-batch sharding x{world}",
                        "samples": stats},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_breakdown_ms_per_step": breakdown,
             "ms_per_step_instrumented": round(dt_instr / args.steps * 1e3, 3),

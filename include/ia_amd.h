@@ -364,6 +364,19 @@ int64_t ia_occgrid_tmp_bytes(int res_x, int res_y, int res_z);
 int ia_occgrid_binarize(int res_x, int res_y, int res_z, const float* occs, float thre_max, int keep_largest_component,
                         uint8_t* binaries, float* thre_out, void* tmp, ia_stream_t stream);
 
+/* ------------------------------------------------------------------------- */
+/* Optimiser step.  torch.optim.Adam exactly as the reference builds it (configs/config.yaml:110-136,
+ * systems/utils.py:314-325: Adam, betas (0.9, 0.99), eps 1e-15, per-group lr and L2 weight_decay), for n_tensors
+ * parameter tensors in ONE launch (40 per launch internally).  params/grads/exp_avg/exp_avg_sq/numel/step_size/
+ * weight_decay are HOST arrays of length n_tensors; the pointers they hold are device memory (fp32, contiguous).
+ *   g = grad * grad_scale (+ weight_decay p);  m += (g - m)(1 - beta1);  v = v beta2 + (1 - beta2) g g;
+ *   p -= step_size * m / (sqrt(v) / bias_correction2_sqrt + eps)
+ * step_size[t] = lr_t / (1 - beta1^step) and bias_correction2_sqrt = sqrt(1 - beta2^step) are formed by the caller in
+ * double precision, as torch/optim/adam.py:_single_tensor_adam does.  grad_scale folds in DDP's 1/world averaging. */
+int ia_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                 float* const* exp_avg_sq, const int64_t* numel, const float* step_size, const float* weight_decay,
+                 float beta1, float beta2, float eps, float bias_correction2_sqrt, float grad_scale, ia_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

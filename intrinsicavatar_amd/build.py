@@ -29,6 +29,7 @@ SOURCES = {
     "deform.hip": ["-ffp-contract=off"],
     "pbr.hip": ["-munsafe-fp-atomics"],
     "occgrid.hip": [],
+    "optim.hip": ["-ffp-contract=off"],
 }
 
 

@@ -245,6 +245,7 @@ __global__ __launch_bounds__(THREADS) void broyden_kernel(
         }
         J_inv_update(Ji, u0, u1, u2, gx_new[0] - gx[0], gx_new[1] - gx[1], gx_new[2] - gx[2]);
     }
+    is_valid[index] = 0;      // not converged after 10 steps (same value the caller's zero-fill gives; lets internal callers skip the fill)
 }
 
 // ---- K8, lane-persistent form ---------------------------------------------------------
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(THREADS) void broyden_persistent_kernel(
             J_inv_update(Ji, u[0], u[1], u[2], gn[0] - gx[0], gn[1] - gx[1], gn[2] - gx[2]);
             gx[0] = gn[0]; gx[1] = gn[1]; gx[2] = gn[2];
             it++;
-            if (it >= 10) { have = false; continue; }       // not converged: is_valid stays 0 (pre-zeroed)
+            if (it >= 10) { is_valid[index] = 0; have = false; continue; }       // not converged
         }
         // step: update = -J_inv g, x += update
         u[0] = -Ji[0] * gx[0] + -Ji[1] * gx[1] + -Ji[2] * gx[2];
