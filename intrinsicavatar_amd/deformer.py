@@ -35,7 +35,9 @@ class SNARFDeformer:
 
     # -- per frame -------------------------------------------------------------------
     def prepare(self, tfs: Tensor, w2s: Tensor):
-        """prepare_deformer (snarf_deformer.py:81-126) minus the SMPL forward (out of scope: tfs are inputs)."""
+        """prepare_deformer (snarf_deformer.py:81-126) from the bone transforms on: tfs [B,24,4,4] and w2s [4,4] come from
+        smpl.SMPLKinematics + smpl.deformer_transforms (or any other rig).  tfs may carry an autograd graph (pose
+        optimisation): the kernels read its values, train.shade_differentiable adds the implicit pose terms."""
         _, _, D, H, W = self.lbs_voxel_final.shape
         self.tfs = tfs.contiguous().float()
         self.w2s = w2s.contiguous().float()
