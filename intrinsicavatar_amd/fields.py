@@ -300,6 +300,11 @@ class VolumeRefDirRadiance(nn.Module):
         self.prog = ProgressiveMask()
         self.global_step = 25000
         self.register_buffer("sh_mask", torch.ones(1, 16))
+        # checkpoint-key compatibility: the reference's dir_encoding wraps a tcnn SphericalHarmonics encoding whose (empty)
+        # `params` vector is part of the state_dict (tests/golden/golden_state_keys.json)
+        self.dir_encoding = nn.Module()
+        self.dir_encoding.encoding = nn.Module()
+        self.dir_encoding.encoding.params = nn.Parameter(torch.zeros(0), requires_grad=False)
         self.register_buffer("center", torch.zeros(3), persistent=False)
         self.register_buffer("scale", torch.ones(3), persistent=False)
         self.start_step, self.full_band_step = 0, 1
@@ -363,6 +368,14 @@ class VolumeMaterial(nn.Module):
             b = (torch.rand((do,), generator=g) * 2 - 1) * bound
             ws.append(nn.Parameter(w)); bs.append(nn.Parameter(b))
             cs.append(nn.Parameter(torch.ones(1) * w.abs().sum(1).max() * 2))      # network_utils.py:380-385
+        # the reference registers every weight twice -- as layers[i].weight and as weights_per_layer[i], one Parameter under
+        # two names (network_utils.py:365-377) -- and its checkpoints carry both keys; same aliasing here
+        lin = []
+        for (di, do), w, b in zip(dims, ws, bs):
+            l = nn.Linear(di, do)
+            l.weight, l.bias = w, b
+            lin.append(l)
+        self.network.layers = nn.ModuleList(lin)
         self.network.weights_per_layer = nn.ParameterList(ws)
         self.network.biases_per_layer = nn.ParameterList(bs)
         self.network.lipshitz_bound_per_layer = nn.ParameterList(cs)

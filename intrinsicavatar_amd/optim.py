@@ -93,7 +93,7 @@ def reference_param_groups(rs, lr: float = 1e-3, color_grid_wd: float = 0.0, mat
     (lr 1e-3), and, for the PBR branch, material / emitter."""
     geo, rad = rs.geometry, rs.radiance
     rad_grid = [rad.grid_params]
-    rad_net = [p for p in rad.parameters() if p is not rad.grid_params]
+    rad_net = [p for p in rad.parameters() if p is not rad.grid_params and p.requires_grad]
     groups = [dict(params=list(geo.parameters()), name="geometry", lr=lr),
               dict(params=rad_net, name="radiance.network", lr=lr),
               dict(params=rad_grid, name="radiance.xyz_encoding", lr=lr, weight_decay=color_grid_wd),

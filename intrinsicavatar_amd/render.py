@@ -152,7 +152,9 @@ class RenderStep:
 
     # ------------------------------------------------------------------ forward + backward (training step)
     def parameters(self):
-        return list(self.geometry.parameters()) + list(self.radiance.parameters()) + list(self.density.parameters())
+        """trainable parameters (the empty checkpoint-compatibility entry of the SH encoding is not one)."""
+        ps = list(self.geometry.parameters()) + list(self.radiance.parameters()) + list(self.density.parameters())
+        return [p for p in ps if p.requires_grad]
 
     def forward_backward(self, rays: Tensor, target_rgb: Tensor, target_mask: Optional[Tensor] = None,
                          jitter: Optional[Tensor] = None, curv_u: Optional[Tensor] = None, lambda_curv: float = 0.0

@@ -10,7 +10,7 @@ with torch.no_grad():
 n = rays.shape[0]
 g = torch.Generator().manual_seed(0)
 target = torch.rand((n, 3), generator=g).cuda(); tmask = (torch.rand(n, generator=g) > 0.5).float().cuda()
-names = [k for k, _ in list(rs.geometry.named_parameters()) + list(rs.radiance.named_parameters()) + list(rs.density.named_parameters())]
+names = [k for k, p in list(rs.geometry.named_parameters()) + list(rs.radiance.named_parameters()) + list(rs.density.named_parameters()) if p.requires_grad]
 runs = []
 for it in range(4):
     for p in rs.parameters(): p.grad = None
