@@ -119,8 +119,10 @@ def main():
         dist.barrier()
     from intrinsicavatar_amd import synthetic as S, _lib as L, parallel
 
-    # one frame per rank (frame-/ray-batch sharding, replicated parameters)
-    rs, rays, export = S.build_frame(dev, args.hw, args.hw, pose_seed=rank, beta=0.01, num_samples_per_ray=128)
+    # one frame per rank (frame-/ray-batch sharding, replicated parameters).  Weak scaling = the SAME per-GPU workload at
+    # every N: each rank renders the configs[1] frame (pose 0) against its own target image, so the per-rank work at N=8
+    # is exactly the N=1 work and the gradients that meet in the all-reduce still differ per rank.
+    rs, rays, export = S.build_frame(dev, args.hw, args.hw, pose_seed=0, beta=0.01, num_samples_per_ray=128)
     n_rays = rays.shape[0]
 
     params = rs.parameters()
