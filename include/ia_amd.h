@@ -365,6 +365,25 @@ int ia_occgrid_binarize(int res_x, int res_y, int res_z, const float* occs, floa
                         uint8_t* binaries, float* thre_out, void* tmp, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
+/* Elementwise tail of SNARFDeformer.deform for the winning candidates (snarf_deformer.py:192-231) and the eikonal term
+ * (systems/intrinsic_avatar.py:195-203), one kernel per direction instead of ~20 torch launches over the samples.
+ *   c2w[i]      = fwd_J[cand_src[max(sel[i], 0)]]          (zeros when fwd_J == NULL)
+ *   feat[i]     = valid ? out13[i] : 0;   sdf[i] = valid ? out13[i,0] : 1e5;
+ *   sdf_grad[i] = valid ? c2w[i] . grad_c[i] : (0, 0, 1)
+ * _bwd: g_out13 = valid ? g_feat (+ g_sdf on column 0) : 0;  g_grad_c = valid ? c2w^T g_sdf_grad : 0  (NULL gradients = 0). */
+int ia_select_push(int64_t n, const float* out13, const float* grad_c, const uint8_t* valid, const float* fwd_J,
+                   const int32_t* cand_src, const int32_t* sel, float* feat, float* sdf, float* sdf_grad, float* c2w,
+                   ia_stream_t stream);
+int ia_select_push_bwd(int64_t n, const uint8_t* valid, const float* c2w, const float* g_feat, const float* g_sdf,
+                       const float* g_sdf_grad, float* g_out13, float* g_grad_c, ia_stream_t stream);
+/* partial[k] = (sum over the valid samples of workgroup k of (|sdf_grad| - 1)^2, number of valid samples);
+ * ia_eikonal_partials(n) pairs.  _bwd: g = weight[0] * 2 (|g| - 1) g / |g| on valid samples, 0 elsewhere. */
+int64_t ia_eikonal_partials(int64_t n);
+int ia_eikonal(int64_t n, const float* sdf_grad, const uint8_t* valid, float* partial, ia_stream_t stream);
+int ia_eikonal_bwd(int64_t n, const float* sdf_grad, const uint8_t* valid, const float* weight, float* g_sdf_grad,
+                   ia_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
 /* Optimiser step.  torch.optim.Adam exactly as the reference builds it (configs/config.yaml:110-136,
  * systems/utils.py:314-325: Adam, betas (0.9, 0.99), eps 1e-15, per-group lr and L2 weight_decay), for n_tensors
  * parameter tensors in ONE launch (40 per launch internally).  params/grads/exp_avg/exp_avg_sq/numel/step_size/

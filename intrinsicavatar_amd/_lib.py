@@ -28,7 +28,7 @@ class _Timed:
 
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
-        if not name.startswith("ia_") or name in ("ia_last_error", "ia_scan_tmp_bytes", "ia_version", "ia_hashgrid_n_entries", "ia_traverse_scratch_bytes", "ia_occgrid_tmp_bytes", "ia_hashgrid_bwd_scratch_bytes", "ia_traverse_fused_scratch_bytes", "ia_hashgrid_fwd_scratch_bytes"):
+        if not name.startswith("ia_") or name in ("ia_last_error", "ia_scan_tmp_bytes", "ia_version", "ia_hashgrid_n_entries", "ia_traverse_scratch_bytes", "ia_occgrid_tmp_bytes", "ia_hashgrid_bwd_scratch_bytes", "ia_traverse_fused_scratch_bytes", "ia_hashgrid_fwd_scratch_bytes", "ia_eikonal_partials"):
             return fn
 
         def call(*args):
@@ -71,6 +71,7 @@ def lib():
         cdll.ia_hashgrid_bwd_scratch_bytes.restype = C.c_int64
         cdll.ia_traverse_fused_scratch_bytes.restype = C.c_int64
         cdll.ia_hashgrid_fwd_scratch_bytes.restype = C.c_int64
+        cdll.ia_eikonal_partials.restype = C.c_int64
         _lib = _Timed(cdll)
     return _lib
 

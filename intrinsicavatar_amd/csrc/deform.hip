@@ -373,3 +373,161 @@ IA_EXPORT int ia_laplace_alpha_bwd(int64_t n, const float* sdf, const float* dis
     laplace_alpha_bwd_kernel<<<grid, THREADS, 0, (hipStream_t)stream>>>(n, sdf, dists, dist_const, beta, g_alpha, g_sdf, g_beta);
     return ia::check_launch("ia_laplace_alpha_bwd");
 }
+
+// ---- winners -> shading inputs, and the eikonal term: the elementwise glue of the differentiable shading pass --------
+// SNARFDeformer.deform's tail (snarf_deformer.py:192-231) as ONE kernel per direction instead of ~20 elementwise torch
+// launches over 4.4 M rows: features masked by `valid`, sdf default 1e5, normal push-forward c2w . grad_c with the
+// default (0, 0, 1) for points without a canonical correspondence; c2w = fwd_J of the winning candidate.
+namespace {
+
+__global__ __launch_bounds__(THREADS) void select_push_kernel(int64_t n, const float* __restrict__ out13,
+                                                               const float* __restrict__ grad_c,
+                                                               const uint8_t* __restrict__ valid,
+                                                               const float* __restrict__ fwd_J,
+                                                               const int32_t* __restrict__ cand_src,
+                                                               const int32_t* __restrict__ sel, float* __restrict__ feat,
+                                                               float* __restrict__ sdf, float* __restrict__ sdf_grad,
+                                                               float* __restrict__ c2w)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const bool v = valid[i] != 0;
+    float R[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = 0.0f;
+    if (fwd_J) {                                   // same gather as fwd_J[cand_src[clamp(sel, 0)]] (also for invalid points)
+        int s = sel[i];
+        if (s < 0) s = 0;
+        const float* src = fwd_J + (int64_t)cand_src[s] * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = src[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) c2w[i * 9 + k] = R[k];
+#pragma unroll
+    for (int k = 0; k < 13; k++) feat[i * 13 + k] = v ? out13[i * 13 + k] : 0.0f;
+    sdf[i] = v ? out13[i * 13] : 1e5f;
+    const float g0 = grad_c[i * 3 + 0], g1 = grad_c[i * 3 + 1], g2 = grad_c[i * 3 + 2];
+    sdf_grad[i * 3 + 0] = v ? R[0] * g0 + R[1] * g1 + R[2] * g2 : 0.0f;
+    sdf_grad[i * 3 + 1] = v ? R[3] * g0 + R[4] * g1 + R[5] * g2 : 0.0f;
+    sdf_grad[i * 3 + 2] = v ? R[6] * g0 + R[7] * g1 + R[8] * g2 : 1.0f;
+}
+
+__global__ __launch_bounds__(THREADS) void select_push_bwd_kernel(int64_t n, const uint8_t* __restrict__ valid,
+                                                                   const float* __restrict__ c2w,
+                                                                   const float* __restrict__ g_feat,
+                                                                   const float* __restrict__ g_sdf,
+                                                                   const float* __restrict__ g_sdf_grad,
+                                                                   float* __restrict__ g_out13, float* __restrict__ g_grad_c)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const bool v = valid[i] != 0;
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+        float g = (v && g_feat) ? g_feat[i * 13 + k] : 0.0f;
+        if (k == 0 && v && g_sdf) g += g_sdf[i];
+        g_out13[i * 13 + k] = g;
+    }
+    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+    if (v && g_sdf_grad) {
+        const float* R = c2w + i * 9;
+        const float a = g_sdf_grad[i * 3 + 0], b = g_sdf_grad[i * 3 + 1], c = g_sdf_grad[i * 3 + 2];
+        o0 = R[0] * a + R[3] * b + R[6] * c;
+        o1 = R[1] * a + R[4] * b + R[7] * c;
+        o2 = R[2] * a + R[5] * b + R[8] * c;
+    }
+    g_grad_c[i * 3 + 0] = o0; g_grad_c[i * 3 + 1] = o1; g_grad_c[i * 3 + 2] = o2;
+}
+
+// eikonal term over the valid samples: per-workgroup partial sums of (|g| - 1)^2 and of the valid count (the host-side
+// reduction over the few thousand partials is a deterministic torch sum: no float atomics)
+constexpr int EIK_PER_WG = 4 * THREADS;
+__global__ __launch_bounds__(THREADS) void eikonal_kernel(int64_t n, const float* __restrict__ g, const uint8_t* __restrict__ valid,
+                                                           float* __restrict__ partial /*[nwg,2]*/)
+{
+    __shared__ float s_sum[THREADS / 64], s_cnt[THREADS / 64];
+    float s = 0.0f, c = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int64_t i = (int64_t)blockIdx.x * EIK_PER_WG + r * THREADS + threadIdx.x;
+        if (i < n && valid[i]) {
+            const float x = g[i * 3 + 0], y = g[i * 3 + 1], z = g[i * 3 + 2];
+            const float d = sqrtf(x * x + y * y + z * z) - 1.0f;
+            s += d * d;
+            c += 1.0f;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); c += __shfl_xor(c, off, 64); }
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = s; s_cnt[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ts = 0.0f, tc = 0.0f;
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; w++) { ts += s_sum[w]; tc += s_cnt[w]; }
+        partial[blockIdx.x * 2 + 0] = ts;
+        partial[blockIdx.x * 2 + 1] = tc;
+    }
+}
+
+// d/dg of  w * sum_valid (|g| - 1)^2 :  w * 2 (|g| - 1) g / |g|   (0 where |g| = 0, like torch's norm backward)
+__global__ __launch_bounds__(THREADS) void eikonal_bwd_kernel(int64_t n, const float* __restrict__ g, const uint8_t* __restrict__ valid,
+                                                               const float* __restrict__ w, float* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+    if (valid[i]) {
+        const float x = g[i * 3 + 0], y = g[i * 3 + 1], z = g[i * 3 + 2];
+        const float nrm = sqrtf(x * x + y * y + z * z);
+        if (nrm > 0.0f) {
+            const float k = w[0] * 2.0f * (nrm - 1.0f) / nrm;
+            o0 = k * x; o1 = k * y; o2 = k * z;
+        }
+    }
+    out[i * 3 + 0] = o0; out[i * 3 + 1] = o1; out[i * 3 + 2] = o2;
+}
+
+}  // namespace
+
+IA_EXPORT int ia_select_push(int64_t n, const float* out13, const float* grad_c, const uint8_t* valid, const float* fwd_J,
+                             const int32_t* cand_src, const int32_t* sel, float* feat, float* sdf, float* sdf_grad,
+                             float* c2w, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    IA_REQUIRE(out13 && grad_c && valid && feat && sdf && sdf_grad && c2w, "null buffer");
+    IA_REQUIRE(fwd_J == nullptr || (cand_src && sel), "fwd_J needs cand_src and sel");
+    select_push_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, out13, grad_c, valid, fwd_J, cand_src, sel,
+                                                                                   feat, sdf, sdf_grad, c2w);
+    return ia::check_launch("ia_select_push");
+}
+
+IA_EXPORT int ia_select_push_bwd(int64_t n, const uint8_t* valid, const float* c2w, const float* g_feat, const float* g_sdf,
+                                 const float* g_sdf_grad, float* g_out13, float* g_grad_c, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    IA_REQUIRE(valid && c2w && g_out13 && g_grad_c, "null buffer");
+    select_push_bwd_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, valid, c2w, g_feat, g_sdf, g_sdf_grad,
+                                                                                       g_out13, g_grad_c);
+    return ia::check_launch("ia_select_push_bwd");
+}
+
+IA_EXPORT int64_t ia_eikonal_partials(int64_t n) { return n <= 0 ? 0 : (n + EIK_PER_WG - 1) / EIK_PER_WG; }
+
+IA_EXPORT int ia_eikonal(int64_t n, const float* sdf_grad, const uint8_t* valid, float* partial, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    IA_REQUIRE(sdf_grad && valid && partial, "null buffer");
+    eikonal_kernel<<<(int)ia_eikonal_partials(n), THREADS, 0, (hipStream_t)stream>>>(n, sdf_grad, valid, partial);
+    return ia::check_launch("ia_eikonal");
+}
+
+IA_EXPORT int ia_eikonal_bwd(int64_t n, const float* sdf_grad, const uint8_t* valid, const float* weight, float* g_sdf_grad,
+                             ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    IA_REQUIRE(sdf_grad && valid && weight && g_sdf_grad, "null buffer");
+    eikonal_bwd_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, sdf_grad, valid, weight, g_sdf_grad);
+    return ia::check_launch("ia_eikonal_bwd");
+}

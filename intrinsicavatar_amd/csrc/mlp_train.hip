@@ -378,6 +378,7 @@ struct SdfTrainArgs {
     float *dW1, *db1, *dWo, *dbo;      // [64,35] [64] [13,64] [13]  accumulated into
 };
 
+template <bool WANT_XYZ>
 __global__ __launch_bounds__(THREADS) void sdf_train_kernel(SdfTrainArgs a)
 {
     constexpr int IN = 35, IN_PAD = 36, OUT = 13;
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(THREADS) void sdf_train_kernel(SdfTrainArgs a)
         ACC2_FOREACH(nt, r, row, col, lane) {
             const int64_t p = p0 + row;
             if (col < 32 && p < a.n) a.gE[p * 32 + col] = acc[nt][r];
-            if (a.gXYZ && col >= 32 && col < 35 && p < a.n) a.gXYZ[p * 3 + (col - 32)] = acc[nt][r];
+            if (WANT_XYZ && col >= 32 && col < 35 && p < a.n) a.gXYZ[p * 3 + (col - 32)] = acc[nt][r];
         }
     }
     float* sRed = sTiles;
@@ -536,10 +537,15 @@ IA_EXPORT int ia_sdf_mlp_bwd_fused(int64_t n, int n_segs, const float* const* se
     constexpr size_t lds = sizeof(float) * (HID * 37 + 16 * 65 + 144 + TILES);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)sdf_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)sdf_train_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)sdf_train_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
     const int64_t n_tiles = (n + TM - 1) / TM;
     int grid = (int)((n_tiles + WAVES - 1) / WAVES);
     if (grid > 256) grid = 256;
-    sdf_train_kernel<<<grid, THREADS, lds, (hipStream_t)stream>>>(a);
+    if (g_xyz) sdf_train_kernel<true><<<grid, THREADS, lds, (hipStream_t)stream>>>(a);
+    else sdf_train_kernel<false><<<grid, THREADS, lds, (hipStream_t)stream>>>(a);
     return ia::check_launch("ia_sdf_mlp_bwd_fused");
 }

@@ -143,6 +143,59 @@ class _ShadePrep(Function):
         return out, None, None, None
 
 
+class _SelectPush(Function):
+    """(out[n,13], grad_c[n,3]) -> (feat, sdf, sdf_grad, c2w): masking by `valid`, defaults for points without a canonical
+    correspondence and the normal push-forward with the winning candidate's blended rotation, in one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, out, grad_c, valid, fwd_J, cand_src, sel):
+        n, dev = out.shape[0], out.device
+        out, grad_c = out.contiguous(), grad_c.contiguous()
+        feat, sdf = torch.empty((n, 13), device=dev), torch.empty(n, device=dev)
+        sdf_grad, c2w = torch.empty((n, 3), device=dev), torch.empty((n, 3, 3), device=dev)
+        L.check(L.lib().ia_select_push(L.i64(n), L.ptr(out), L.ptr(grad_c), L.ptr(valid), L.ptr(fwd_J), L.ptr(cand_src),
+                                       L.ptr(sel), L.ptr(feat), L.ptr(sdf), L.ptr(sdf_grad), L.ptr(c2w), L.stream()),
+                "ia_select_push")
+        ctx.save_for_backward(valid, c2w)
+        ctx.mark_non_differentiable(c2w)
+        return feat, sdf, sdf_grad, c2w
+
+    @staticmethod
+    def backward(ctx, g_feat, g_sdf, g_sdf_grad, _g_c2w):
+        valid, c2w = ctx.saved_tensors
+        n, dev = valid.shape[0], valid.device
+        cg = lambda t: t.contiguous() if t is not None else None      # noqa: E731
+        g_out, g_gc = torch.empty((n, 13), device=dev), torch.empty((n, 3), device=dev)
+        L.check(L.lib().ia_select_push_bwd(L.i64(n), L.ptr(valid), L.ptr(c2w), L.ptr(cg(g_feat)), L.ptr(cg(g_sdf)),
+                                           L.ptr(cg(g_sdf_grad)), L.ptr(g_out), L.ptr(g_gc), L.stream()), "ia_select_push_bwd")
+        return g_out, g_gc, None, None, None, None
+
+
+class _Eikonal(Function):
+    """sdf_grad[n,3], valid[n] -> (sum over valid of (|g| - 1)^2, number of valid samples)."""
+
+    @staticmethod
+    def forward(ctx, sdf_grad, valid):
+        n = sdf_grad.shape[0]
+        sdf_grad = sdf_grad.contiguous()
+        k = int(L.lib().ia_eikonal_partials(L.i64(n)))
+        part = torch.zeros((max(k, 1), 2), device=sdf_grad.device)
+        L.check(L.lib().ia_eikonal(L.i64(n), L.ptr(sdf_grad), L.ptr(valid), L.ptr(part), L.stream()), "ia_eikonal")
+        ctx.save_for_backward(sdf_grad, valid)
+        tot = part.sum(0)
+        ctx.mark_non_differentiable(tot[1])
+        return tot[0], tot[1]
+
+    @staticmethod
+    def backward(ctx, g_sum, _g_cnt):
+        sdf_grad, valid = ctx.saved_tensors
+        out = torch.empty_like(sdf_grad)
+        w = g_sum.reshape(1).float().contiguous()
+        L.check(L.lib().ia_eikonal_bwd(L.i64(sdf_grad.shape[0]), L.ptr(sdf_grad), L.ptr(valid), L.ptr(w), L.ptr(out), L.stream()),
+                "ia_eikonal_bwd")
+        return out, None
+
+
 class _Alpha(Function):
     @staticmethod
     def forward(ctx, sdf, dists, beta):
@@ -250,9 +303,12 @@ def shade_differentiable(rs, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor
     with torch.no_grad():
         d = dfm.deform(pts, geo, with_grad=False, with_feature=False, want_fwd=True, want_jinv=pose_grad)      # candidate search + winner selection (the gradient is evaluated once, on the winners, by _SDFField)
         valid = d["valid"]
-        sel = d["sel"].long().clamp(min=0)
-        win = d["cand_src"].long()[sel] if d["n_candidates"] > 0 else None
-        c2w = d["fwd_J"].reshape(-1, 3, 3)[win] if win is not None else torch.zeros((pts.shape[0], 3, 3), device=pts.device)
+        win = c2w = None         # win: flat (point, init) index of each sample's winning candidate (pose mode), or a flag
+        if d["n_candidates"] > 0:
+            win = True
+            if pose_grad:
+                win = d["cand_src"].long()[d["sel"].long().clamp(min=0)]
+                c2w = d["fwd_J"].reshape(-1, 3, 3)[win]
     pts_cano = d["pts_cano"]
     if pose_grad and win is not None:
         # pose_correction / SMPL parameters are being optimised (configs/config.yaml: pose_correction.enable_pose_correction):
@@ -263,12 +319,16 @@ def shade_differentiable(rs, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor
         c2w = c2w + (R - R.detach()) * valid[:, None, None].to(R.dtype)
     W1k, b1, W2, b2 = geo.effective_weights()
     out, grad_c = _SDFField.apply(pts_cano, geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale, geo.prog.level_bits())
-    vf = valid[:, None].float()
     # invalid points: sdf 1e5, feature 0, gradient [0,0,1] (snarf_deformer.py:192-231)
-    dflt_g = torch.tensor([0.0, 0.0, 1.0], device=pts.device)
-    feat = out * vf
-    sdf = torch.where(valid, out[:, 0], torch.full_like(out[:, 0], 1e5))
-    sdf_grad = torch.where(valid[:, None], (c2w * grad_c[:, None, :]).sum(-1), dflt_g[None])
+    if pose_grad and win is not None:          # c2w carries the pose graph: plain torch expressions
+        vf = valid[:, None].float()
+        dflt_g = torch.tensor([0.0, 0.0, 1.0], device=pts.device)
+        feat = out * vf
+        sdf = torch.where(valid, out[:, 0], torch.full_like(out[:, 0], 1e5))
+        sdf_grad = torch.where(valid[:, None], (c2w * grad_c[:, None, :]).sum(-1), dflt_g[None])
+    else:
+        feat, sdf, sdf_grad, c2w = _SelectPush.apply(out, grad_c, valid, d["fwd_J"] if win is not None else None,
+                                                     d["cand_src"], d["sel"])
     w2s_rot = dfm.w2s[:3, :3].contiguous()
     normal_smpl, normal_world, refl01 = _ShadePrep.apply(sdf_grad, rays_d, ray_indices, w2s_rot)
     alphas = _Alpha.apply(sdf, t_ends - t_starts, rs.density.get_beta())
@@ -292,9 +352,8 @@ def training_loss(out: Dict[str, Tensor], target_rgb: Tensor, target_mask: Optio
     loss = (out["comp_rgb"] - target_rgb).abs().mean()
     # eikonal term: mean over the valid samples, written as a masked sum (boolean-mask indexing costs a host sync forward
     # and a 1.3 ms index_put in backward for 4.4 M samples)
-    vf = out["valid"].float()
-    eik = ((torch.linalg.norm(out["sdf_grad"], dim=-1) - 1.0) ** 2 * vf).sum() / vf.sum().clamp_min(1.0)
-    loss = loss + lambda_eik * eik
+    eik_sum, n_valid = _Eikonal.apply(out["sdf_grad"], out["valid"])
+    loss = loss + lambda_eik * eik_sum / n_valid.clamp_min(1.0)
     if target_mask is not None:
         op = out["opacity"][:, 0].clamp(1e-3, 1 - 1e-3)
         loss = loss + lambda_mask * torch.nn.functional.binary_cross_entropy(op, target_mask)
