@@ -205,7 +205,7 @@ def main():
             roofline = dict(kernel=dname, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                             frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=pmc_traffic(dname),
                             traffic_source="profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per "
-                                           "launch, separate passes, tools/pmc_collect.sh)",
+                                           "launch, separate passes, tools/pmc_traffic.py)",
                             avg_launch_us=round(avg_us, 1), launches_per_step=launches_per_step,
                             algorithmic_bytes_per_launch=int(per_launch_bytes),
                             share_of_kernel_time=round(dms / max(total_ms, 1e-9), 3))

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""memory-side traffic per kernel launch of the bench step -> gpurun_out/r01_pmc_traffic.json (copied to profiles/).
+
+Two separate rocprofv3 --pmc passes (counters only next to --kernel-trace, as the pool requires) over
+`bench.py --steps 2 --warmup 1`:  FETCH_SIZE  and  WRITE_SIZE TCC_HIT_sum TCC_MISS_sum.  Units / corrections per
+/opt/skills/guides/MI355X_MICROARCH.md: both counters are in KB and FETCH_SIZE reports half of the bytes on gfx950."""
+import collections
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CMD = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+
+
+def run_pass(name, counters):
+    d = f"/tmp/pmc_{name}"
+    subprocess.run(["rm", "-rf", d])
+    env = dict(os.environ, TMPDIR="/tmp")
+    subprocess.run(["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + CMD,
+                   cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    seen, cnt = set(), collections.Counter()
+    for r in csv.DictReader(open(f[0])):
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "")[:60]
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        key = (k, r.get("Dispatch_Id"))
+        if key not in seen:
+            seen.add(key)
+            cnt[k] += 1
+    return acc, cnt
+
+
+def main():
+    fa, fc = run_pass("fetch", ["FETCH_SIZE"])
+    wa, wc = run_pass("write", ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"])
+    kernels = {}
+    for k in fa:
+        if k not in wa or fc[k] == 0:
+            continue
+        fetch = 2.0 * fa[k]["FETCH_SIZE"] * 1024.0 / fc[k]
+        write = wa[k]["WRITE_SIZE"] * 1024.0 / wc[k]
+        hit, miss = wa[k]["TCC_HIT_sum"], wa[k]["TCC_MISS_sum"]
+        kernels[k] = dict(launches=fc[k], fetch_bytes=fetch, write_bytes=write, hbm_side_bytes_per_launch=fetch + write,
+                          l2_hit_rate=round(hit / max(hit + miss, 1.0), 3))
+    top = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_side_bytes_per_launch"] * kv[1]["launches"])[:16])
+    out = dict(note="rocprofv3 --pmc passes on `bench.py --steps 2 --warmup 1` (tools/pmc_traffic.py): FETCH_SIZE / WRITE_SIZE are "
+                    "KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of the bytes of a streaming read); values "
+                    "are per launch, averaged over the launches of the run; Infinity-Cache hits are included (memory-side "
+                    "requests of the L2)", kernels=top)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r01_pmc_traffic.json"), "w"), indent=1)
+    for k, v in top.items():
+        print(f"{k:62s} x{v['launches']:3d}  fetch {v['fetch_bytes'] / 1e9:7.2f} GB  write {v['write_bytes'] / 1e9:6.2f} GB  L2 hit {v['l2_hit_rate']}")
+
+
+if __name__ == "__main__":
+    main()
