@@ -257,9 +257,12 @@ class _Accumulate(torch.autograd.Function):
         dim = 1 if values is None else values.shape[-1]
         if values is not None:
             values = values.contiguous().float()
-        out = torch.empty((n_rays, dim), dtype=torch.float32, device=weights.device)
-        L.check(L.lib().ia_accumulate_along_rays(L.i64(n_rays), L.ptr(packed_info), L.i32(dim), L.ptr(weights),
-                                                 L.ptr(values), L.ptr(out), L.stream()), "ia_accumulate_along_rays")
+        if weights.shape[0] == 0:       # no samples at all (an empty tensor has a NULL data pointer, which the C ABI reads
+            out = torch.zeros((n_rays, dim), dtype=torch.float32, device=weights.device)      # as "values omitted")
+        else:
+            out = torch.empty((n_rays, dim), dtype=torch.float32, device=weights.device)
+            L.check(L.lib().ia_accumulate_along_rays(L.i64(n_rays), L.ptr(packed_info), L.i32(dim), L.ptr(weights),
+                                                     L.ptr(values), L.ptr(out), L.stream()), "ia_accumulate_along_rays")
         ctx.save_for_backward(weights, values, ray_indices)
         ctx.dim = dim
         return out
@@ -271,6 +274,8 @@ class _Accumulate(torch.autograd.Function):
         need_w, need_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and values is not None
         gw = torch.empty_like(weights) if need_w else None
         gv = torch.empty_like(values) if need_v else None
+        if weights.shape[0] == 0:
+            return gw, gv, None, None
         L.check(L.lib().ia_accumulate_along_rays_bwd(
             L.i64(weights.shape[0]), L.i32(ctx.dim), L.ptr(ray_indices), L.ptr(weights), L.ptr(values), L.ptr(g),
             L.ptr(gw), L.ptr(gv), L.stream()), "ia_accumulate_along_rays_bwd")

@@ -346,3 +346,32 @@ def test_relight_global_illumination_adds_indirect_light(frame, env):
     assert float(d.min()) >= -1e-6 and float(d.max()) > 1e-4
     occluded = a["secondary_tr"][:, 0] < 0.5
     assert float(d[occluded].mean()) > float(d[~occluded].mean())
+
+
+def test_pbr_paths_with_rays_that_miss_everything():
+    """empty edge case of the PBR branch (relight and the physically based training step): rays that miss the occupancy
+    grid produce no samples, no volume interactions and no secondary rays; the images are the background colour."""
+    from intrinsicavatar_amd import build
+    build.build()
+    from intrinsicavatar_amd import synthetic as S, fields, pbr
+    rs, rays, _ = S.build_frame(DEV, 48, 48, pose_seed=0, beta=0.05, num_samples_per_ray=64, grid_D=16, grid_H=64, grid_W=64,
+                                smooth_iters=3, hash_amp=1e-2)
+    mat = fields.VolumeMaterial(seed=2).to(DEV)
+    env = pbr.EnvironmentLightTensor(torch.full((16, 32, 3), 0.7, device=DEV)); env.update_pdf()
+    away = rays[:1024].clone()
+    away[:, 3:6] = -away[:, 3:6]
+    n, spp = away.shape[0], 64
+    g = torch.Generator().manual_seed(0)
+    light_u = torch.rand((spp, 3), generator=g).to(DEV)
+    shuffle_u = torch.rand((n, spp), generator=g).to(DEV)
+    bg = torch.tensor([0.2, 0.3, 0.4], device=DEV)
+    out = rs.relight(away, mat, env, spp, light_u, shuffle_u, background_color=bg)
+    assert out["stats"]["n_samples"] == 0
+    assert torch.allclose(out["comp_rgb_phys"], bg.expand(n, 3))
+    target = torch.rand((n, 3), generator=g).to(DEV)
+    env_base = env.base.clone().requires_grad_(True)
+    for p in rs.parameters() + list(mat.parameters()):
+        p.grad = None
+    res = rs.forward_backward_phys(away, target, mat, env, spp, light_u, shuffle_u, render_mode="uniform_light",
+                                   env_base=env_base, background_color=bg)
+    assert torch.isfinite(res["loss"]) and torch.allclose(res["comp_rgb_phys"].detach(), bg.expand(n, 3))

@@ -356,3 +356,24 @@ def test_pose_parameters_receive_gradients_through_smpl_kinematics():
         assert int((per_joint > 1e-3 * per_joint.max()).sum()) >= 10
     finally:
         dfm.prepare(tfs0, w2s0)
+
+
+def test_training_step_with_rays_that_miss_everything(frame):
+    """a ray shard can be empty of samples (rays that miss the occupancy grid; multi-GPU ray-batch sharding makes that a
+    real case): every kernel on the path sees n = 0, the loss reduces to the background terms and backward still runs."""
+    rs, rays = frame
+    away = rays[:4096].clone()
+    away[:, 3:6] = -away[:, 3:6]                     # look away from the subject
+    g = torch.Generator().manual_seed(0)
+    target = torch.rand((away.shape[0], 3), generator=g).cuda()
+    tmask = torch.zeros(away.shape[0], device=DEV)
+    for p in rs.parameters():
+        p.grad = None
+    out = rs.forward_backward(away, target, tmask)
+    assert out["n_samples"] == 0
+    assert torch.isfinite(out["loss"]) and float(out["opacity"].abs().max()) == 0.0
+    for p in rs.parameters():
+        assert p.grad is None or bool(torch.isfinite(p.grad).all())
+    # inference form too
+    res = rs.forward(away)
+    assert float(res["opacity"].abs().max()) == 0.0 and res["stats"]["n_samples"] == 0
