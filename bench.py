@@ -22,6 +22,13 @@ import os
 import sys
 import time
 
+# one process per GPU: the host side of a rank is one launch thread.  Library thread pools default to the number of
+# visible CPUs (256 on the GPU boxes, 8 ranks per node) while a container's CPU quota is a fraction of that; an
+# oversubscribed pool burns the cgroup quota and the launch thread gets throttled with it.
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+for _v in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):      # also keeps cpu_baseline's "cores": 1 honest
+    os.environ.setdefault(_v, "1")
+
 import numpy as np
 import torch
 
@@ -80,6 +87,16 @@ def pmc_traffic(entry):
     return int(tot / max(calls, 1))
 
 
+def cgroup_throttle():
+    """(nr_throttled, throttled_usec) of this container's CPU controller, or None (diagnostic: a throttled launch thread
+    makes the step host-bound)."""
+    try:
+        kv = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat").read().strip().splitlines())
+        return int(kv.get("nr_throttled", 0)), int(kv.get("throttled_usec", 0))
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +129,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev))
 
+    from intrinsicavatar_amd import parallel as _par
+    numa_node = _par.pin_to_gpu_numa_node(local_rank)          # host side of the step next to its GPU (2-socket hosts)
     from intrinsicavatar_amd import build
     if rank == 0:
         build.build()
@@ -161,6 +180,7 @@ def main():
         dist.barrier()
     lib = L.lib()
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides, nothing else running
+    thr0 = cgroup_throttle()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -168,6 +188,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    thr1 = cgroup_throttle()
     # ---- the same K steps again with a HIP-event pair around every C-ABI launch (on the launch stream): per-kernel
     # durations for the roofline / breakdown.  Kept out of the throughput region because the ~600 event records per step
     # cost host time that the un-instrumented step does not pay (ms_per_step_instrumented is reported next to it).
@@ -231,7 +252,8 @@ def main():
             "config": {"workload": f"{args.hw}x{args.hw} frame ({n_rays} rays), 128 samples/ray, radiance + SDF geometry, "
                                    "fast-SNARF deformer (13 inits), 2x importance resampling, random-init hash-grid/MLP "
                                    "fields, synthetic 24-bone rig",
-                       "pass": args.mode, "optimizer_step_in_timed_region": bool(opt is not None), "frames_per_step_per_gpu": 1, "parallelism": f"frame/ray-batch sharding x{world}",
+                       "pass": args.mode, "host_numa_node": numa_node,
+                       "host_cpu_throttled_ms_in_timed_region": (None if not (thr0 and thr1) else round((thr1[1] - thr0[1]) / 1e3, 1)), "optimizer_step_in_timed_region": bool(opt is not None), "frames_per_step_per_gpu": 1, "parallelism": f"frame/ray-batch sharding x{world}",
                        "samples": stats},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_breakdown_ms_per_step": breakdown,
             "ms_per_step_instrumented": round(dt_instr / args.steps * 1e3, 3),

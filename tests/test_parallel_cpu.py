@@ -94,3 +94,13 @@ def test_shard_range_covers_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_numa_pinning_helper_degrades_gracefully():
+    from intrinsicavatar_amd import parallel
+    assert parallel._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert parallel._parse_cpulist("") == set()
+    import os
+    before = os.sched_getaffinity(0)
+    assert parallel.pin_to_gpu_numa_node(0) is None          # no GPU here: nothing changes
+    assert os.sched_getaffinity(0) == before
