@@ -11,6 +11,8 @@
 //     contiguous 128-byte row: fully coalesced stores;
 //   * per-level constants (scale, resolution, table offset/size) live in registers, computed once.
 // Tables are fp32 [entries, 2] (50.4 MB per grid): resident in the 256 MiB Infinity Cache.
+#include <stdlib.h>
+
 #include "ia_common.h"
 
 namespace {
@@ -348,6 +350,16 @@ __host__ void make_bins(BinCfg& b, const HashCfg& c)
     b.n_buckets = k;
 }
 
+// running maximum of a level's |record value| (scale of the fixed-point reduction).  Every wave used to fire one
+// device-scope atomicMax per level at the SAME address: ~400 k same-address atomics serialise at the memory side and
+// cost 1.7 - 3.5 ms per launch (measured by ablation).  The maximum converges after a few waves, so look first (a stale
+// value only means one redundant atomic) and touch the address only when this wave would raise it.
+__device__ __forceinline__ void level_max_update(unsigned* p, float lmax)
+{
+    const unsigned v = __float_as_uint(lmax);                 // non-negative floats order like their bit patterns
+    if (v > __atomic_load_n(p, __ATOMIC_RELAXED)) atomicMax(p, v);
+}
+
 template <bool SECOND, bool FILL>
 __global__ __launch_bounds__(THREADS) void hash_bin_kernel(int64_t n, const float* __restrict__ x, HashCfg cfg, BinCfg bins,
                                                             const float* __restrict__ gE, int gE_stride,
@@ -466,7 +478,7 @@ __global__ __launch_bounds__(THREADS) void hash_bin_kernel(int64_t n, const floa
             if (FILL) {                                           // per-level max |value| -> fixed-point scale of the reduction
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off, 64));
-                if (lane == 0 && lmax > 0.0f) atomicMax(level_max + l, __float_as_uint(lmax));
+                if (lane == 0 && lmax > 0.0f) level_max_update(level_max + l, lmax);
             }
         }
     }
@@ -474,6 +486,177 @@ __global__ __launch_bounds__(THREADS) void hash_bin_kernel(int64_t n, const floa
         __syncthreads();
         for (int b = threadIdx.x; b < bins.n_buckets; b += THREADS) counts[(int64_t)b * nwg + blockIdx.x] = hist[b];
     }
+}
+
+
+// ---- binned backward, STAGED variant: wave-private units and full-line record stores ---------------------------------
+// The fill above appends every record straight to its (bucket, workgroup) run: a wave's store instruction scatters 64
+// lanes over up to 64 runs (PMC: 6.7 GB written + 3-6 GB write-allocated for 4.2 GB of records).  Here the unit of the
+// count -> scan -> fill protocol is ONE WAVE (128 points): per level the wave sorts its <= 1024 records by slice in a
+// 10 KB LDS staging area (offsets come from the scanned counts, positions from integer LDS atomics), then copies the
+// sorted block out so that consecutive lanes write consecutive records of a run.  No workgroup barrier anywhere: waves
+// never share state (LDS operations of one wave execute in order).
+constexpr int U_ROUNDS = 2;
+constexpr int U_PTS = 64 * U_ROUNDS;                  // points per unit (wave)
+constexpr int U_REC = U_PTS * 8;                      // records per unit and level
+constexpr int U_WAVES = THREADS / 64;
+
+struct UnitLds {
+    unsigned long long cur[64];      // per slice: (global run start - staging offset) << 32 | next staging slot
+    float4 rec[U_REC];               // staged records, sorted by slice: (value.x, value.y, bits(destination), bits(local index))
+};
+
+template <bool SECOND, bool FILL>
+__global__ __launch_bounds__(THREADS) void hash_bin_unit_kernel(int64_t n, const float* __restrict__ x, HashCfg cfg, BinCfg bins,
+                                                                 const float* __restrict__ gE, int gE_stride,
+                                                                 const float* __restrict__ gG, int gG_stride,
+                                                                 const float* __restrict__ q, int nunits, int64_t m,
+                                                                 int32_t* __restrict__ counts, const int32_t* __restrict__ total,
+                                                                 uint16_t* __restrict__ rec_idx, float2* __restrict__ rec_val,
+                                                                 uint32_t level_mask, unsigned* __restrict__ level_max)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int unit = blockIdx.x * U_WAVES + wave;
+    int* hist = reinterpret_cast<int*>(smem_raw) + wave * MAX_BUCKETS;                 // COUNT: per-wave histogram
+    UnitLds& U = reinterpret_cast<UnitLds*>(smem_raw)[wave];                           // FILL : per-wave staging
+    if (!FILL)
+        for (int b = lane; b < bins.n_buckets; b += 64) hist[b] = 0;
+    float px[U_ROUNDS][3], pq[U_ROUNDS][3];
+    bool act[U_ROUNDS];
+    int64_t pi[U_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < U_ROUNDS; r++) {
+        const int64_t i = (int64_t)unit * U_PTS + r * 64 + lane;
+        act[r] = i < n;
+        pi[r] = act[r] ? i : n - 1;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            px[r][d] = x[pi[r] * 3 + d];
+            pq[r][d] = (SECOND && FILL) ? q[pi[r] * 3 + d] : 0.0f;
+        }
+    }
+    constexpr int LG = 4;
+    for (int l0 = 0; l0 < cfg.n_levels; l0 += LG) {
+        float2 ev[U_ROUNDS][LG], gv[U_ROUNDS][LG];
+#pragma unroll
+        for (int r = 0; r < U_ROUNDS; r++)
+#pragma unroll
+            for (int j = 0; j < LG; j++) {
+                ev[r][j] = make_float2(0.f, 0.f);
+                gv[r][j] = make_float2(0.f, 0.f);
+                if (FILL && act[r] && l0 + j < cfg.n_levels && ((level_mask >> (l0 + j)) & 1u)) {
+                    if (gE) ev[r][j] = *reinterpret_cast<const float2*>(gE + pi[r] * gE_stride + (l0 + j) * 2);
+                    if (SECOND) gv[r][j] = *reinterpret_cast<const float2*>(gG + pi[r] * gG_stride + (l0 + j) * 2);
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < LG; j++) {
+            const int l = l0 + j;
+            if (l >= cfg.n_levels) break;
+            if (!((level_mask >> l) & 1u)) continue;
+            float lmax = 0.0f;
+            const float sc = cfg.scale[l];
+            const uint32_t res = cfg.res[l], hsize = cfg.offsets[l + 1] - cfg.offsets[l];
+            const int b0 = bins.bstart[l], nb = bins.bstart[l + 1] - b0;
+            int tot = 0;
+            if (FILL) {
+                // this unit's run of every slice of the level: start and length from the scanned count matrix
+                int cnt = 0, start = 0;
+                if (lane < nb && unit < nunits) {
+                    const int64_t flat = (int64_t)(b0 + lane) * nunits + unit;
+                    start = counts[flat];
+                    cnt = ((flat + 1 < m) ? counts[flat + 1] : total[0]) - start;
+                }
+                int incl = cnt;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += t;
+                }
+                tot = __shfl(incl, 63, 64);
+                const int off = incl - cnt;
+                U.cur[lane] = ((unsigned long long)(unsigned)(start - off) << 32) | (unsigned)off;
+                __builtin_amdgcn_wave_barrier();
+            }
+#pragma unroll
+            for (int r = 0; r < U_ROUNDS; r++) {
+                const float2 e = ev[r][j], g = gv[r][j];
+                const bool active = act[r];
+                float pos[3];
+                uint32_t pg[3];
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const float p = fmaf(sc, px[r][d], 0.5f);
+                    const float fl = floorf(p);
+                    pg[d] = (uint32_t)(int)fl;
+                    pos[d] = p - fl;
+                }
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    uint32_t idx = grid_index(hsize, res, pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1));
+                    if (!active) idx = 0xFFFFFFFFu;
+                    const uint32_t prev = __shfl_up(idx, 1, 64);
+                    const bool head = (lane == 0) || (prev != idx);
+                    const unsigned long long heads = __ballot(head);
+                    const bool tail = (lane == 63) || ((heads >> (lane + 1)) & 1ull);
+                    float vx = 0.f, vy = 0.f;
+                    if (FILL) {
+                        const float wx = (c & 1) ? pos[0] : 1.0f - pos[0];
+                        const float wy = (c & 2) ? pos[1] : 1.0f - pos[1];
+                        const float wz = (c & 4) ? pos[2] : 1.0f - pos[2];
+                        const float w0 = wx * wy * wz;
+                        vx = e.x * w0; vy = e.y * w0;
+                        if (SECOND) {
+                            const float dw = ((c & 1) ? sc : -sc) * wy * wz * pq[r][0] + ((c & 2) ? sc : -sc) * wx * wz * pq[r][1] +
+                                             ((c & 4) ? sc : -sc) * wx * wy * pq[r][2];
+                            vx += g.x * dw;
+                            vy += g.y * dw;
+                        }
+                        if (!active) { vx = 0.f; vy = 0.f; }
+                        const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+                        const int hpos = 63 - __clzll(below);
+                        if (heads != ~0ull) {
+#pragma unroll
+                            for (int off = 1; off < 64; off <<= 1) {
+                                const float ax = __shfl_up(vx, off, 64), ay = __shfl_up(vy, off, 64);
+                                if (lane - off >= hpos) { vx += ax; vy += ay; }
+                            }
+                        }
+                    }
+                    if (tail && active) {
+                        const int bin = (int)(idx >> SLICE_LOG2);
+                        if (FILL) {
+                            lmax = fmaxf(lmax, fmaxf(fabsf(vx), fabsf(vy)));
+                            // one 64-bit LDS atomic hands out the staging slot AND the slice's destination delta
+                            const unsigned long long t = atomicAdd(&U.cur[bin], 1ull);
+                            const unsigned slot = (unsigned)t & (U_REC - 1);
+                            const unsigned d = (unsigned)(t >> 32) + (unsigned)t;
+                            U.rec[slot] = make_float4(vx, vy, __uint_as_float(d), __uint_as_float(idx & (SLICE - 1)));
+                        } else {
+                            atomicAdd(&hist[b0 + bin], 1);
+                        }
+                    }
+                }
+            }
+            if (FILL) {
+                __builtin_amdgcn_wave_barrier();
+                // copy-out: the staging block is sorted by slice, so consecutive lanes write consecutive records of a run
+                for (int k = lane; k < tot; k += 64) {
+                    const float4 rcd = U.rec[k];
+                    const unsigned d = __float_as_uint(rcd.z);
+                    rec_idx[d] = (uint16_t)__float_as_uint(rcd.w);
+                    rec_val[d] = make_float2(rcd.x, rcd.y);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off, 64));
+                if (lane == 0 && lmax > 0.0f) level_max_update(level_max + l, lmax);
+            }
+        }
+    }
+    if (!FILL && unit < nunits)
+        for (int b = lane; b < bins.n_buckets; b += 64) counts[(int64_t)b * nunits + unit] = hist[b];
 }
 
 // LDS accumulation in 64-bit FIXED POINT with integer atomics.  Measured on MI355X (tools/probes/lds_atomic_probe.hip):
@@ -844,10 +1027,20 @@ struct BinLayout {
     int nwg; int64_t m, records;
     int64_t off_counts, off_total, off_tmp, off_val, off_idx, bytes;
 };
+bool staged_fill()
+{
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("IA_HASHBWD_FILL");        // test hook: "direct" = per-workgroup runs, scattered appends
+        mode = (e && e[0] == 'd') ? 0 : 1;
+    }
+    return mode == 1;
+}
+
 BinLayout bin_layout(int64_t n, int n_levels, int n_buckets)
 {
     BinLayout L;
-    L.nwg = ia::cdiv(n, BIN_TILE);
+    L.nwg = staged_fill() ? ia::cdiv(n, U_PTS) : ia::cdiv(n, BIN_TILE);       // units of the count matrix
     L.m = (int64_t)n_buckets * L.nwg;
     L.records = n * n_levels * 8;
     auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
@@ -900,12 +1093,32 @@ IA_EXPORT int ia_hashgrid_bwd_binned(int64_t n, const float* x, int n_levels, in
     hipStream_t s = (hipStream_t)stream;
     unsigned* level_max = (unsigned*)(base + L.off_total + 256);
     if (hipMemsetAsync(level_max, 0, MAX_LEVELS * sizeof(unsigned), s) != hipSuccess) return ia::check_launch("ia_hashgrid_bwd_binned(memset)");
-    if (g_jac) hash_bin_kernel<true, false><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, g_jac, g_jac_stride, q, L.nwg, counts, rec_idx, rec_val, level_mask, level_max);
-    else hash_bin_kernel<false, false><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, nullptr, 0, nullptr, L.nwg, counts, rec_idx, rec_val, level_mask, level_max);
+    const bool staged = staged_fill();
+    const int ugrid = ia::cdiv(L.nwg, U_WAVES);
+    constexpr size_t lds_count = (size_t)U_WAVES * MAX_BUCKETS * sizeof(int), lds_fill = (size_t)U_WAVES * sizeof(UnitLds);
+    if (staged) {
+        if (g_jac) hash_bin_unit_kernel<true, false><<<ugrid, THREADS, lds_count, s>>>(n, x, c, b, g_enc, g_enc_stride, g_jac, g_jac_stride, q, L.nwg, L.m, counts, total, rec_idx, rec_val, level_mask, level_max);
+        else hash_bin_unit_kernel<false, false><<<ugrid, THREADS, lds_count, s>>>(n, x, c, b, g_enc, g_enc_stride, nullptr, 0, nullptr, L.nwg, L.m, counts, total, rec_idx, rec_val, level_mask, level_max);
+    } else {
+        if (g_jac) hash_bin_kernel<true, false><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, g_jac, g_jac_stride, q, L.nwg, counts, rec_idx, rec_val, level_mask, level_max);
+        else hash_bin_kernel<false, false><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, nullptr, 0, nullptr, L.nwg, counts, rec_idx, rec_val, level_mask, level_max);
+    }
     int r = ia_exclusive_scan_i32(counts, counts, total, L.m, tmp, stream);
     if (r != IA_OK) return r;
-    if (g_jac) hash_bin_kernel<true, true><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, g_jac, g_jac_stride, q, L.nwg, counts, rec_idx, rec_val, level_mask, level_max);
-    else hash_bin_kernel<false, true><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, nullptr, 0, nullptr, L.nwg, counts, rec_idx, rec_val, level_mask, level_max);
+    static bool attr_fill = false;
+    if (staged && !attr_fill) {
+        (void)hipFuncSetAttribute((const void*)hash_bin_unit_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fill);
+        (void)hipFuncSetAttribute((const void*)hash_bin_unit_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fill);
+        (void)hipGetLastError();
+        attr_fill = true;
+    }
+    if (staged) {
+        if (g_jac) hash_bin_unit_kernel<true, true><<<ugrid, THREADS, lds_fill, s>>>(n, x, c, b, g_enc, g_enc_stride, g_jac, g_jac_stride, q, L.nwg, L.m, counts, total, rec_idx, rec_val, level_mask, level_max);
+        else hash_bin_unit_kernel<false, true><<<ugrid, THREADS, lds_fill, s>>>(n, x, c, b, g_enc, g_enc_stride, nullptr, 0, nullptr, L.nwg, L.m, counts, total, rec_idx, rec_val, level_mask, level_max);
+    } else {
+        if (g_jac) hash_bin_kernel<true, true><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, g_jac, g_jac_stride, q, L.nwg, counts, rec_idx, rec_val, level_mask, level_max);
+        else hash_bin_kernel<false, true><<<L.nwg, THREADS, 0, s>>>(n, x, c, b, g_enc, g_enc_stride, nullptr, 0, nullptr, L.nwg, counts, rec_idx, rec_val, level_mask, level_max);
+    }
     static bool attr = false;
     constexpr size_t red_lds = (size_t)SLICE * 2 * sizeof(unsigned long long);      // 128 KB
     if (!attr) {
