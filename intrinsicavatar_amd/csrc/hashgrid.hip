@@ -663,8 +663,8 @@ __global__ __launch_bounds__(THREADS) void hash_bin_unit_kernel(int64_t n, const
 // ds_add_f32 retires 0.17 updates / clk / CU, ds_add_u64 5.6 -- the float LDS atomic is ~30x slower than the integer
 // one, and it alone made this kernel 6x slower than its HBM-read time.  Each level gets a power-of-two scale from the
 // largest |value| of its records (2^40 / 2^ceil(log2 max)): every record is converted with at most 2^-40 max relative
-// quantisation (exact for |v| >= 2^-16 max), the sums themselves are exact integer sums -- order independent, hence
-// bit-reproducible run to run, which the float atomics never were.
+// quantisation (exact for |v| >= 2^-16 max), the sums themselves are exact integer sums -- order independent: a bucket
+// reduced in one part is bit-reproducible run to run (buckets split in parts still meet in float atomics below).
 constexpr int RTHREADS = 512;
 __device__ __forceinline__ void fx_add(unsigned long long* a, uint32_t i, float vx, float vy, float scale)
 {
