@@ -133,6 +133,53 @@ struct XcdPlan {
     int part[8], nparts[8];             // this slot covers points [part, part+1) / nparts of the batch
 };
 
+// one (point, level) of the XCD-partitioned forward: 8 gathers, trilinear blend (+ Jacobian), level-major stores
+template <bool WITH_JAC>
+__device__ __forceinline__ void xcd_gather(const float2* __restrict__ tab, uint32_t hsize, uint32_t res, float sc,
+                                           const float xs[3], float2 v[8], float pos[3])
+{
+    uint32_t pg[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const float p = fmaf(sc, xs[d], 0.5f);
+        const float fl = floorf(p);
+        pg[d] = (uint32_t)(int)fl;
+        pos[d] = p - fl;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+        v[c] = tab[grid_index(hsize, res, pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1))];
+}
+
+template <bool WITH_JAC>
+__device__ __forceinline__ void xcd_blend_store(const float2 v[8], const float pos[3], float sc, int64_t slot,
+                                                float2* __restrict__ tmp, float* __restrict__ tmp_jac)
+{
+    float a0 = 0.f, a1 = 0.f;
+    float j0[3] = {0.f, 0.f, 0.f}, j1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const float wx = (c & 1) ? pos[0] : 1.0f - pos[0];
+        const float wy = (c & 2) ? pos[1] : 1.0f - pos[1];
+        const float wz = (c & 4) ? pos[2] : 1.0f - pos[2];
+        const float w = wx * wy * wz;
+        a0 += w * v[c].x;
+        a1 += w * v[c].y;
+        if (WITH_JAC) {
+            const float dx = ((c & 1) ? sc : -sc) * wy * wz;
+            const float dy = ((c & 2) ? sc : -sc) * wx * wz;
+            const float dz = ((c & 4) ? sc : -sc) * wx * wy;
+            j0[0] += dx * v[c].x; j0[1] += dy * v[c].x; j0[2] += dz * v[c].x;
+            j1[0] += dx * v[c].y; j1[1] += dy * v[c].y; j1[2] += dz * v[c].y;
+        }
+    }
+    tmp[slot] = make_float2(a0, a1);
+    if (WITH_JAC) {
+        float2* J = reinterpret_cast<float2*>(tmp_jac + slot * 6);
+        J[0] = make_float2(j0[0], j0[1]); J[1] = make_float2(j0[2], j1[0]); J[2] = make_float2(j1[1], j1[2]);
+    }
+}
+
 template <bool WITH_JAC>
 __global__ __launch_bounds__(THREADS) void hash_fwd_xcd_kernel(int64_t n, const float* __restrict__ x,
                                                                 const float2* __restrict__ params, HashCfg cfg, XcdPlan plan,
@@ -144,50 +191,25 @@ __global__ __launch_bounds__(THREADS) void hash_fwd_xcd_kernel(int64_t n, const 
     const int np = plan.nparts[slot];
     const int64_t per = (n + np - 1) / np;
     const int64_t lo = per * plan.part[slot], hi = (lo + per < n) ? lo + per : n;
-    for (int64_t i = lo + chunk * THREADS + threadIdx.x; i < hi; i += nchunks * THREADS) {
-        const float xs[3] = {x[i * 3 + 0], x[i * 3 + 1], x[i * 3 + 2]};
+    const int64_t stride = nchunks * THREADS;
+    // two points per lane and iteration: the gathers of both (16 independent 8-byte loads) are issued before either
+    // blend -- the kernel is bound by L2 gather latency x requests in flight, not by bandwidth (L2 hit 0.91)
+    for (int64_t i = lo + chunk * THREADS + threadIdx.x; i < hi; i += 2 * stride) {
+        const int64_t i2 = i + stride;
+        const bool two = i2 < hi;
+        const int64_t ib = two ? i2 : i;
+        const float xa[3] = {x[i * 3 + 0], x[i * 3 + 1], x[i * 3 + 2]};
+        const float xb[3] = {x[ib * 3 + 0], x[ib * 3 + 1], x[ib * 3 + 2]};
         for (int l = plan.first_level[slot]; l < plan.first_level[slot] + plan.n_level[slot]; l++) {
             const float sc = cfg.scale[l];
             const uint32_t res = cfg.res[l], hsize = cfg.offsets[l + 1] - cfg.offsets[l];
             const float2* tab = params + cfg.offsets[l];
-            float pos[3];
-            uint32_t pg[3];
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                const float p = fmaf(sc, xs[d], 0.5f);
-                const float fl = floorf(p);
-                pg[d] = (uint32_t)(int)fl;
-                pos[d] = p - fl;
-            }
-            float2 v[8];
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const uint32_t idx = grid_index(hsize, res, pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1));
-                v[c] = tab[idx];
-            }
-            float a0 = 0.f, a1 = 0.f;
-            float j0[3] = {0.f, 0.f, 0.f}, j1[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const float wx = (c & 1) ? pos[0] : 1.0f - pos[0];
-                const float wy = (c & 2) ? pos[1] : 1.0f - pos[1];
-                const float wz = (c & 4) ? pos[2] : 1.0f - pos[2];
-                const float w = wx * wy * wz;
-                a0 += w * v[c].x;
-                a1 += w * v[c].y;
-                if (WITH_JAC) {
-                    const float dx = ((c & 1) ? sc : -sc) * wy * wz;
-                    const float dy = ((c & 2) ? sc : -sc) * wx * wz;
-                    const float dz = ((c & 4) ? sc : -sc) * wx * wy;
-                    j0[0] += dx * v[c].x; j0[1] += dy * v[c].x; j0[2] += dz * v[c].x;
-                    j1[0] += dx * v[c].y; j1[1] += dy * v[c].y; j1[2] += dz * v[c].y;
-                }
-            }
-            tmp[(int64_t)l * n + i] = make_float2(a0, a1);
-            if (WITH_JAC) {
-                float2* J = reinterpret_cast<float2*>(tmp_jac + ((int64_t)l * n + i) * 6);
-                J[0] = make_float2(j0[0], j0[1]); J[1] = make_float2(j0[2], j1[0]); J[2] = make_float2(j1[1], j1[2]);
-            }
+            float2 va[8], vb[8];
+            float pa[3], pb[3];
+            xcd_gather<WITH_JAC>(tab, hsize, res, sc, xa, va, pa);
+            xcd_gather<WITH_JAC>(tab, hsize, res, sc, xb, vb, pb);
+            xcd_blend_store<WITH_JAC>(va, pa, sc, (int64_t)l * n + i, tmp, tmp_jac);
+            if (two) xcd_blend_store<WITH_JAC>(vb, pb, sc, (int64_t)l * n + i2, tmp, tmp_jac);
         }
     }
 }
