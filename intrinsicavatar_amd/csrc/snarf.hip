@@ -262,12 +262,12 @@ __global__ __launch_bounds__(THREADS) void broyden_persistent_kernel(
     int64_t total, int64_t N, int I, const float* __restrict__ xd_tgt, const float* __restrict__ voxel_J, int D, int H,
     int W, const float* __restrict__ tfs, const int32_t* __restrict__ bone_ids, const float* __restrict__ offset_g,
     const float* __restrict__ scale_g, float cvg_threshold, float dvg_threshold, float* __restrict__ x,
-    float* __restrict__ J_inv, uint8_t* __restrict__ is_valid, float* __restrict__ fwd_J)
+    float* __restrict__ J_inv, uint8_t* __restrict__ is_valid, float* __restrict__ fwd_J, int br_chunk)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave_id = ((int64_t)blockIdx.x * THREADS + threadIdx.x) >> 6;
-    int64_t cursor = wave_id * BR_CHUNK;                                  // wave-uniform
-    const int64_t chunk_end = (cursor + BR_CHUNK < total) ? cursor + BR_CHUNK : total;
+    int64_t cursor = wave_id * br_chunk;                                  // wave-uniform
+    const int64_t chunk_end = (cursor + br_chunk < total) ? cursor + br_chunk : total;
     if (cursor >= total) return;
     const int64_t vol = (int64_t)D * H * W;
     const float offset[3] = {offset_g[0], offset_g[1], offset_g[2]};
@@ -422,16 +422,18 @@ IA_EXPORT int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt, cons
     bool persistent = total >= (int64_t)32 << 20;
     if (const char* e = getenv("IA_BROYDEN_SCHEDULE")) persistent = (e[0] == 'p');     // test hook: "persistent" / "simple"
     if (persistent) {
-        const int64_t n_waves = (total + BR_CHUNK - 1) / BR_CHUNK;
+        int br_chunk = BR_CHUNK;
+        if (const char* e = getenv("IA_BR_CHUNK")) br_chunk = atoi(e);                   // tuning hook
+        const int64_t n_waves = (total + br_chunk - 1) / br_chunk;
         const int grid = ia::cdiv(n_waves * 64, THREADS);
         if (layout == IA_LAYOUT_NDHWC)
             broyden_persistent_kernel<IA_LAYOUT_NDHWC><<<grid, THREADS, 0, s>>>(total, N, I, xd_tgt, voxel_J, D, H, W, tfs,
                                                                                 bone_ids, offset, scale, cvg_threshold,
-                                                                                dvg_threshold, x, J_inv, is_valid, fwd_J);
+                                                                                dvg_threshold, x, J_inv, is_valid, fwd_J, br_chunk);
         else
             broyden_persistent_kernel<IA_LAYOUT_NCDHW><<<grid, THREADS, 0, s>>>(total, N, I, xd_tgt, voxel_J, D, H, W, tfs,
                                                                                 bone_ids, offset, scale, cvg_threshold,
-                                                                                dvg_threshold, x, J_inv, is_valid, fwd_J);
+                                                                                dvg_threshold, x, J_inv, is_valid, fwd_J, br_chunk);
     } else {
         const int grid = ia::cdiv(total, THREADS);
         if (layout == IA_LAYOUT_NDHWC)
