@@ -131,6 +131,14 @@ def main():
 
     from intrinsicavatar_amd import parallel as _par
     numa_node = _par.pin_to_gpu_numa_node(local_rank)          # host side of the step next to its GPU (2-socket hosts)
+    # Buffer sizes follow the sample counts, which move a little every step once the optimiser updates the geometry; with
+    # exact-size caching the allocator keeps growing (13 -> 34 GiB over 14 steps) and a 5 GiB hipMalloc on a freshly booted
+    # box costs ~100 ms -- inside the timed region that showed up as 75-110 ms "steps".  Size classes (1/8 power-of-two
+    # steps) make the blocks of one step reusable by the next, and one up-front reservation moves the remaining growth in
+    # front of the warm-up.  288 GB of HBM: the 24 GiB arena is 8 % of the device.
+    torch.cuda.memory._set_allocator_settings("roundup_power2_divisions:8")
+    _arena = torch.empty(24 << 30, dtype=torch.uint8, device=dev)
+    del _arena
     from intrinsicavatar_amd import build
     if rank == 0:
         build.build()
