@@ -42,8 +42,10 @@ def hashgrid_forward(x01: Tensor, params: Tensor, cfg=HASH, with_jac: bool = Fal
     if out is None:
         out = torch.empty((n, LF), dtype=torch.float32, device=x01.device)
     jac = torch.empty((n, LF, 3), dtype=torch.float32, device=x01.device) if with_jac else None
-    # measured (tools/hashfwd_probe.py, 4.4 M points): flat 3.43 / 3.78 ms (without / with Jacobian), XCD-partitioned
-    # 2.57 / 4.07 ms -- the fabric traffic drops 8x (L2 hit 0.93) but the Jacobian's transpose pass costs more than it saves
+    # measured (tools/hashfwd_probe.py, 4.4 M points): flat 3.44 / 3.78 ms (without / with Jacobian), XCD-partitioned
+    # 2.06 / 3.32 ms (fabric traffic 8x lower, L2 hit 0.91; x-neighbour corners fetched as 16-byte pairs)
+    # -- but on the training step's real sample distribution (clustered at the surface) the flat kernel does the Jacobian
+    # call in 2.72 ms against 3.29 ms, so the Jacobian call stays flat
     method = os.environ.get("IA_HASH_FWD") or ("xcd" if (n >= HASH_FWD_XCD_MIN and not with_jac) else "flat")
     if method == "xcd":
         nb = int(L.lib().ia_hashgrid_fwd_scratch_bytes(L.i64(n), L.i32(cfg["n_levels"]), L.i32(1 if with_jac else 0)))
