@@ -586,16 +586,28 @@ __global__ __launch_bounds__(THREADS) void hash_bin_unit_kernel(int64_t n, const
     }
     constexpr int LG = 4;
     for (int l0 = 0; l0 < cfg.n_levels; l0 += LG) {
+        // gradient rows: two levels (16 bytes) per load -- every lane reads its own row, so a load instruction costs 64
+        // line accesses however wide it is (tools/probes/tcp_mask_probe.hip); half as many of them
         float2 ev[U_ROUNDS][LG], gv[U_ROUNDS][LG];
 #pragma unroll
         for (int r = 0; r < U_ROUNDS; r++)
 #pragma unroll
-            for (int j = 0; j < LG; j++) {
-                ev[r][j] = make_float2(0.f, 0.f);
-                gv[r][j] = make_float2(0.f, 0.f);
-                if (FILL && act[r] && l0 + j < cfg.n_levels && ((level_mask >> (l0 + j)) & 1u)) {
-                    if (gE) ev[r][j] = *reinterpret_cast<const float2*>(gE + pi[r] * gE_stride + (l0 + j) * 2);
-                    if (SECOND) gv[r][j] = *reinterpret_cast<const float2*>(gG + pi[r] * gG_stride + (l0 + j) * 2);
+            for (int j = 0; j < LG; j += 2) {
+                ev[r][j] = ev[r][j + 1] = make_float2(0.f, 0.f);
+                gv[r][j] = gv[r][j + 1] = make_float2(0.f, 0.f);
+                const int l = l0 + j;
+                if (FILL && act[r] && l + 1 < cfg.n_levels && ((level_mask >> l) & 3u)) {
+                    if (gE) {
+                        const f4_a8 t = *reinterpret_cast<const f4_a8*>(gE + pi[r] * gE_stride + l * 2);
+                        ev[r][j] = make_float2(t.x, t.y); ev[r][j + 1] = make_float2(t.z, t.w);
+                    }
+                    if (SECOND) {
+                        const f4_a8 t = *reinterpret_cast<const f4_a8*>(gG + pi[r] * gG_stride + l * 2);
+                        gv[r][j] = make_float2(t.x, t.y); gv[r][j + 1] = make_float2(t.z, t.w);
+                    }
+                } else if (FILL && act[r] && l < cfg.n_levels && ((level_mask >> l) & 1u)) {      // odd level count: last level
+                    if (gE) ev[r][j] = *reinterpret_cast<const float2*>(gE + pi[r] * gE_stride + l * 2);
+                    if (SECOND) gv[r][j] = *reinterpret_cast<const float2*>(gG + pi[r] * gG_stride + l * 2);
                 }
             }
 #pragma unroll
