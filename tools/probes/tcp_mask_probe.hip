@@ -31,6 +31,34 @@ __global__ __launch_bounds__(256) void gather(const float4* __restrict__ tab, ui
     out[tid] = acc;
 }
 
+// cooperative variant: 8 lanes share one 96-byte run (lanes 0..5 of the group read its six 16-byte pieces), so a wave
+// instruction touches 8 runs (<= 16 lines) instead of 64 lines.  Same bytes per "fetch" (4 runs) as gather(): one wave
+// serves 64 fetches with 4 passes x 8 instructions.
+__global__ __launch_bounds__(256) void gather_coop(const float4* __restrict__ tab, uint32_t n_vox, int iters, float* out)
+{
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 3, piece = lane & 7;
+    uint32_t s = tid * 2654435761u + 12345u;
+    float acc = 0.f;
+    for (int it = 0; it < iters; it++) {
+        s = s * 1664525u + 1013904223u;
+        const uint32_t v_own = (s >> 4) % (n_vox - 200u);          // this lane's fetch (voxel index)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {                              // pass = run c of every fetch
+#pragma unroll
+            for (int k = 0; k < 8; k++) {                          // instruction k serves the fetches of lanes 8k .. 8k+7
+                const uint32_t v = __shfl(v_own, 8 * k + grp, 64);
+                if (piece < 6) {
+                    const float4 q = tab[(size_t)(v + c * 37u) * 3u + piece];
+                    acc += q.x + q.y + q.z + q.w;
+                }
+            }
+        }
+    }
+    out[tid] = acc;
+}
+
 int main()
 {
     const uint32_t n_vox = 32 * 128 * 128;
@@ -50,6 +78,17 @@ int main()
         float ms; hipEventElapsedTime(&ms, e0, e1);
         const double fetches = (double)grid * 256 * iters;
         printf("%-16s %7.3f ms   %.2f G lane-fetches/s issued (384 B each when active)\n", names[mode], ms, fetches / ms / 1e6);
+    }
+    {
+        gather_coop<<<grid, 256>>>(tab, n_vox, 10, out);
+        hipDeviceSynchronize();
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
+        gather_coop<<<grid, 256>>>(tab, n_vox, iters, out);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double fetches = (double)grid * 256 * iters;
+        printf("%-16s %7.3f ms   %.2f G lane-fetches/s (384 B each, 8 lanes per 96-byte run)\n", "cooperative", ms, fetches / ms / 1e6);
     }
     return 0;
 }
