@@ -62,7 +62,7 @@ def hashgrid_forward(x01: Tensor, params: Tensor, cfg=HASH, with_jac: bool = Fal
     return (out, jac) if with_jac else out
 
 
-HASH_FWD_XCD_MIN = 1 << 20          # XCD-partitioned forward from 1 M points (Jacobian-free calls only)
+HASH_FWD_XCD_MIN = 1 << 17          # XCD-partitioned forward from 128 k points (tools/hashfwd_sweep.py; Jacobian-free calls only)
 HASH_BWD_BINNED_MIN = 1 << 15        # below this the 4-kernel binned path is launch-bound; plain run-merged atomics
 HASH_BWD_CHUNK = 1 << 23             # points per binned call (scratch ~1.3 KB / point, 32-bit record offsets)
 
