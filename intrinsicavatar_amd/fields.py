@@ -223,6 +223,13 @@ class VolumeSDF(nn.Module):
     def prepare_bbox(self, bbox: Tensor):
         self.center = ((bbox[0] + bbox[1]) / 2).to(self.center)
         self.scale = (bbox[1] - bbox[0]).to(self.scale)
+        self._inv_scale_host = None
+
+    def inv_scale_host(self):
+        """1 / scale as python floats for the kernels' host-side arguments; read back once per bbox, not once per step."""
+        if getattr(self, "_inv_scale_host", None) is None:
+            self._inv_scale_host = (1.0 / self.scale).tolist()
+        return self._inv_scale_host
 
     def update_step(self, epoch, global_step):
         self.global_step = global_step
@@ -256,7 +263,7 @@ class VolumeSDF(nn.Module):
             enc, jac = hashgrid_forward(xp, self.grid_params), None
         W1k, b1, W2, b2 = self.effective_weights()
         res = mlp_forward(0, [(enc, 32, 1.0, 0.0), (xp, 3, 2.0, -1.0)], W1k, b1, None, None, W2, b2, 13, jac=jac,
-                          xyz_col=32, inv_scale=(1.0 / self.scale).tolist() if with_grad else None, want_grad=with_grad)
+                          xyz_col=32, inv_scale=self.inv_scale_host() if with_grad else None, want_grad=with_grad)
         y, grad = res if with_grad else (res, None)
         out = [y[:, 0]]
         if with_grad:

@@ -69,11 +69,11 @@ class _SDFField(Function):
     """(x_cano, table, W1k, b1, W2, b2) -> (out[n,13], grad[n,3]); grads w.r.t. table and weights (1st + 2nd order)."""
 
     @staticmethod
-    def forward(ctx, x, table, W1k, b1, W2, b2, center, scale, level_bits=0xFFFFFFFF):
+    def forward(ctx, x, table, W1k, b1, W2, b2, center, scale, level_bits=0xFFFFFFFF, inv_scale_host=None):
         ctx.level_bits = int(level_bits)
         xp = ((x - center) / scale + 0.5).contiguous()
         enc, jac = fields.hashgrid_forward(xp, table, with_jac=True)
-        inv = (1.0 / scale).tolist()
+        inv = inv_scale_host if inv_scale_host is not None else (1.0 / scale).tolist()      # the fallback is a host sync
         y, grad = fields.mlp_forward(0, [(enc, 32, 1.0, 0.0), (xp, 3, 2.0, -1.0)], W1k, b1, None, None, W2, b2, 13,
                                      jac=jac, xyz_col=32, inv_scale=inv, want_grad=True)
         ctx.save_for_backward(xp, enc, jac, table, W1k.contiguous(), b1.contiguous(), W2.contiguous(), b2.contiguous(), scale)
@@ -103,7 +103,7 @@ class _SDFField(Function):
                 # first-order d L / d x (pose gradients, SNARF's implicit differentiation): J_enc^T gE + 2 g_xyz, / scale.
                 # The dependence of the analytic normal on x (a Hessian term; tiny-cuda-nn returns zero for it too) is dropped.
                 g_x = (_jac_contract_T(jac, gE) + 2.0 * g_xyz) / scale
-            return g_x, g_table, dW1k, db1, dW2, db2, None, None, None
+            return g_x, g_table, dW1k, db1, dW2, db2, None, None, None, None
         if ctx.needs_input_grad[0]:
             raise NotImplementedError("pose gradients (d L / d x_cano) are only produced by the fused backward (FUSED_WGRAD)")
         Hh, U = torch.empty((n, 36), device=dev), torch.empty((n, 36), device=dev)
@@ -117,7 +117,7 @@ class _SDFField(Function):
         dW1k = dW1k + wgrad(GZ, 64, U, 35, want_bias=False)[0]
         dW2, db2 = wgrad(g_y, 13, A, 64)
         dW2[0] += wgrad(DGS, 64, DGS, 1)[1]          # column sums of DGS
-        return None, g_table, dW1k, db1, dW2, db2, None, None, None
+        return None, g_table, dW1k, db1, dW2, db2, None, None, None, None
 
 
 class _ShadePrep(Function):
@@ -287,7 +287,8 @@ def curvature_laplace(geo, pts_cano: Tensor, grad_c: Tensor, rand_u: Tensor, eps
     with torch.no_grad():
         tangent = torch.cross(nrm(grad_c, dim=-1, eps=1e-6), nrm(rand_u, dim=-1, eps=1e-6), dim=-1)
         x_d = (pts_cano + eps * tangent).contiguous()
-    _, grad_d = _SDFField.apply(x_d, geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale, geo.prog.level_bits())
+    _, grad_d = _SDFField.apply(x_d, geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale, geo.prog.level_bits(),
+                                geo.inv_scale_host())
     dot = (nrm(grad_c, dim=-1, eps=1e-6) * nrm(grad_d, dim=-1, eps=1e-6)).sum(-1)
     return torch.acos(dot.clamp(-1.0 + 1e-6, 1.0 - 1e-6)) / math.pi
 
@@ -318,7 +319,8 @@ def shade_differentiable(rs, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor
         pts_cano, R = dfm.implicit_pose_terms(pts_cano, J_inv_win, valid)
         c2w = c2w + (R - R.detach()) * valid[:, None, None].to(R.dtype)
     W1k, b1, W2, b2 = geo.effective_weights()
-    out, grad_c = _SDFField.apply(pts_cano, geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale, geo.prog.level_bits())
+    out, grad_c = _SDFField.apply(pts_cano, geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale, geo.prog.level_bits(),
+                                  geo.inv_scale_host())
     # invalid points: sdf 1e5, feature 0, gradient [0,0,1] (snarf_deformer.py:192-231)
     if pose_grad and win is not None:          # c2w carries the pose graph: plain torch expressions
         vf = valid[:, None].float()

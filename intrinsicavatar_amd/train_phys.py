@@ -94,7 +94,8 @@ def shade_differentiable_phys(rs, material, emitter, rays_o: Tensor, rays_d: Ten
         c2w = d["fwd_J"].reshape(-1, 3, 3)[d["cand_src"].long()[sel]] if d["n_candidates"] > 0 else \
             torch.zeros((pts.shape[0], 3, 3), device=dev)
     W1k, b1, W2, b2 = geo.effective_weights()
-    out, grad_c = train._SDFField.apply(d["pts_cano"], geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale)
+    out, grad_c = train._SDFField.apply(d["pts_cano"], geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale, 0xFFFFFFFF,
+                                            geo.inv_scale_host())
     vf = valid[:, None].float()
     feat = out * vf
     sdf = torch.where(valid, out[:, 0], torch.full_like(out[:, 0], 1e5))
@@ -121,7 +122,7 @@ def shade_differentiable_phys(rs, material, emitter, rays_o: Tensor, rays_d: Ten
         # material jitter pass: geometry feature + radiance embedding + material head at the jittered canonical points
         # (material_feature = hybrid); no deformer, no validity mask, exactly as the reference evaluates it
         x_j = (d["pts_cano"] + 0.01 * jitter_n[:pts.shape[0]]).detach().contiguous()
-        out_j, _ = train._SDFField.apply(x_j, geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale)
+        out_j, _ = train._SDFField.apply(x_j, geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale, 0xFFFFFFFF, geo.inv_scale_host())
         xp2_j = ((x_j - rad.center) / rad.scale + 0.5).contiguous()
         enc2_j = _HashEncode.apply(xp2_j, rad.grid_params)
         mraw_j = _MLP2.apply(2, 5, *material.effective_weights(mask), enc2_j, xp2_j, out_j)
