@@ -119,6 +119,18 @@ def main():
     share_gpu = os.environ.get("IA_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
+    # host threads spin while they wait for the GPU (HIP's default when CPUs outnumber GPUs): one rank burns ~1 CPU doing
+    # so, eight ranks plus their RCCL proxies can exhaust a container's CPU quota and throttle each other.  With more than
+    # one rank per host, waits block on an interrupt instead (costs ~10 us per size read-back, frees the CPUs).
+    blocking = os.environ.get("IA_BLOCKING_SYNC", "1" if world > 1 else "0") == "1"
+    if blocking:
+        import ctypes
+        try:
+            _hip = ctypes.CDLL("libamdhip64.so")
+            _rc = _hip.hipSetDeviceFlags(ctypes.c_uint(0x4))          # hipDeviceScheduleBlockingSync
+            blocking = (_rc == 0)
+        except OSError:
+            blocking = False
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
@@ -157,6 +169,16 @@ def main():
     target_rgb = torch.rand((n_rays, 3), generator=g).to(dev)
     target_mask = (torch.rand(n_rays, generator=g) > 0.5).float().to(dev)
 
+    # one-time initialisation (not a step, and BEFORE the all-reduce hooks exist): the first launches load the code
+    # objects and set kernel attributes; done on a 4096-ray slice so that the W warm-up steps see a warm library
+    if args.mode == "fwd":
+        rs.forward(rays[:4096].contiguous())
+    else:
+        rs.forward_backward(rays[:4096].contiguous(), target_rgb[:4096].contiguous(), target_mask[:4096].contiguous())
+        for p in params:
+            p.grad = None
+    torch.cuda.synchronize()
+
     # the one exchange step of the path: all-reduce(sum) of the gradients over RCCL/xGMI; the two 50 MB
     # hash-table gradients are launched from autograd hooks as soon as they are complete (overlap with the rest of backward)
     sync = parallel.OverlappedGradientAllReduce(params) if (world > 1 and args.mode != "fwd") else None
@@ -181,17 +203,6 @@ def main():
             sched.step()
         return out
 
-    # one-time initialisation (not a step): first launches load the code objects, set kernel attributes and create the
-    # optimiser state; done on a 4096-ray slice so that the W warm-up steps -- even W = 0 -- see a warm library
-    if args.mode == "fwd":
-        rs.forward(rays[:4096].contiguous())
-    else:
-        for p in params:
-            p.grad = None
-        rs.forward_backward(rays[:4096].contiguous(), target_rgb[:4096].contiguous(), target_mask[:4096].contiguous())
-        for p in params:
-            p.grad = None
-    torch.cuda.synchronize()
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
@@ -200,6 +211,7 @@ def main():
     lib = L.lib()
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides, nothing else running
     thr0 = cgroup_throttle()
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -207,6 +219,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    cpu_busy = (time.process_time() - cpu0) / max(dt, 1e-9)          # CPUs this rank kept busy during the timed region
     thr1 = cgroup_throttle()
     # ---- the same K steps again with a HIP-event pair around every C-ABI launch (on the launch stream): per-kernel
     # durations for the roofline / breakdown.  Kept out of the throughput region because the ~600 event records per step
@@ -271,7 +284,7 @@ def main():
             "config": {"workload": f"{args.hw}x{args.hw} frame ({n_rays} rays), 128 samples/ray, radiance + SDF geometry, "
                                    "fast-SNARF deformer (13 inits), 2x importance resampling, random-init hash-grid/MLP "
                                    "fields, synthetic 24-bone rig",
-                       "pass": args.mode, "host_numa_node": numa_node,
+                       "pass": args.mode, "host_numa_node": numa_node, "host_cpus_busy": round(cpu_busy, 2), "blocking_sync": bool(blocking),
                        "host_cpu_throttled_ms_in_timed_region": (None if not (thr0 and thr1) else round((thr1[1] - thr0[1]) / 1e3, 1)), "optimizer_step_in_timed_region": bool(opt is not None), "frames_per_step_per_gpu": 1, "parallelism": f"frame/ray-batch sharding x{world}",
                        "samples": stats},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_breakdown_ms_per_step": breakdown,
