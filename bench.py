@@ -1,20 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- render_step throughput on MI355X (BASELINE.json metric: rays/sec at 540x540).
+"""bench.py -- render_step throughput on MI355X (BASELINE.json metric: rays/sec (fwd+bwd) at 540x540, 1024 spp).
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
-A "step" is one pass of the render_step hot path over one 540x540 frame (291 600 primary rays) of
-synthetic input: BASELINE config 2 (128 samples/ray, radiance + SDF geometry, fast-SNARF deformer,
-random-init network of the reference's architecture, synthetic 24-bone rig; inputs resident in HBM).
-Multi-GPU: frames / ray batches shard across ranks with replicated parameters (weak scaling: one
-frame per rank per step).  Rank 0 prints ONE JSON line.
+Default workload (`--workload headline`) = the configuration the metric is quoted on: ONE training-form pass
+(forward + backward + optimiser step) of the render_step hot path over one 540x540 frame (291 600 primary rays) WITH the
+physically based branch at samples_per_pixel = 1024: primary march + 2x importance resampling, fast-SNARF deformer,
+SDF / radiance / material fields, volume-interaction re-sampling (1024 per ray), one light-importance-sampled secondary
+ray per foreground re-sample (render_mode=light, training form of pbr_light_forward: models/intrinsic_avatar.py:755-861),
+secondary march + zero-crossing resampling + shading of every secondary ray (compute_indirect_radiance, :396-545,
+global_illumination on), Monte-Carlo estimator, composite, L1/eikonal/mask losses, backward to the hash grids, MLPs,
+density, material head and the spherical-Gaussian environment light, fused Adam.  The frame is processed in ray chunks
+with gradient accumulation (the reference trains on 4096-ray batches and tests on 4096-ray chunks; 288 GB of HBM take
+65 536).  `--workload config2` times BASELINE configs[1] (128 samples/ray, radiance + SDF geometry, no PBR branch) --
+round 1's number, kept as a second key of the headline line (`config2_ms_per_step`).
+
+Synthetic data: random-init networks of the reference's architecture, synthetic 24-bone rig, procedural light; all
+inputs resident in HBM when the timed region starts; random numbers are drawn on the device inside the step (the
+reference draws them per step too).  Multi-GPU: frames shard across ranks with replicated parameters (weak scaling: one
+frame per rank per step), gradients all-reduced over RCCL.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     -- the dominant kernel of the step (by HIP-event time measured live in the timed region)
-                  priced against its roofline with SURVEY.md 8(d)'s algorithmic bytes;
-  cpu_baseline -- the CPU oracle (oracle/render_ref.py, a port) on a bounded ray sample of the same frame,
-                  rank 0 / N == 1 only.
+  roofline     -- the dominant C-ABI entry point of the step (by HIP-event time measured live on the launch stream)
+                  priced against HBM with algorithmic bytes computed from the COUNTED units of the step's launches;
+                  `traffic` = PMC bytes per launch from the committed rocprofv3 passes of the same command;
+  l1_roofline  -- (when the dominant kernel is the Broyden search) the bound that actually binds it: bytes through the
+                  vector-memory (TCP/L1) path from the counted trilinear fetches against 256 CUs x 64 B/clk;
+  cpu_baseline -- the CPU oracle (a port; forward only) on a bounded ray sample of the same frame, rank 0 / N == 1.
 """
 import argparse
 import json
@@ -37,54 +50,58 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3     # fp32-in MFMA dense peak
+L1_PEAK_GBPS = 256 * 64 * 2.4    # 256 CUs x 64 B/clk (vector L1 / TCP) x 2.4 GHz = 39.3 TB/s
+VOXEL_J_BYTES = 32 * 128 * 128 * 48
+PROFILE_TAG = "r02"
 
 
-def algorithmic_bytes(name, stats):
-    """SURVEY.md 8(d) per-unit algorithmic bytes x units of ONE step, per C-ABI entry point."""
-    n, E0, S0 = stats["n_rays"], stats["n_edges0"], stats["n_samples0"]
-    trav = 48 * n + 16 * S0 + 14 * E0
-    P = stats["deform_points"]          # total points pushed through the deformer in one step
-    Q = stats["sdf_points"]             # total candidates through the SDF network
-    return {
-        "ia_traverse_grids_count": trav, "ia_traverse_grids_fill": trav,
-        # Broyden: compulsory HBM traffic only -- 12 B point in, 13 inits x 49 B out (x 12, J_inv 36, valid 1) and the
-        # 25.2 MB voxel_J grid once per launch; the <= 11 x 8-corner x 48 B gathers per (point, init) of SURVEY 8(d) are
-        # served by L2 / Infinity Cache (the grid is resident), they are reported as gather traffic in DESIGN.md
-        "ia_fuse_broyden": P * (12 + 13 * 49) + 3 * 25_165_824,
-        # hash grid fwd: 12 B in + 16 levels x 8 corners x 8 B gathered + 128 B out (+384 B Jacobian when asked)
-        "ia_hashgrid_fwd": (Q + stats["n_samples"]) * (12 + 1024 + 128),
-        "ia_hashgrid_bwd": 2 * stats["n_samples"] * (12 + 128 + 1024 + 1024),     # read-modify-write atomics
-        "ia_hashgrid_bwd_binned": 2 * stats["n_samples"] * (12 + 128 + 1024 + 1024),
-        "ia_mlp_fwd": Q * (35 + 13) * 4 + stats["n_samples"] * (67 + 3) * 4,
-    }.get(name)
+def algorithmic_bytes(name, calls):
+    """SURVEY.md 8(d) per-unit algorithmic bytes x the COUNTED units of every launch of one entry point.
+    calls = [(ms, units, extras)].  Returns total bytes over the calls (None: no model for this entry point)."""
+    n = sum(u for _, u, _ in calls)
+    if name == "ia_fuse_broyden":
+        # compulsory HBM traffic per (point): 12 B target in; per init 12 B x + 1 B valid out (+36 B J_inv, +36 B fwd_J
+        # when requested) and the 25.2 MB voxel_J grid + tfs once per launch.  The <= 11 x 8-corner x 48 B gathers per
+        # (point, init) of SURVEY 8(d) are cache traffic (grid resident in L2 / Infinity Cache): see l1_roofline.
+        tot = 0
+        for _, u, ex in calls:
+            per_init = 13 + (36 if ex["J_inv"] else 0) + (36 if ex["fwd_J"] else 0)
+            tot += u * (12 + ex["I"] * per_init) + VOXEL_J_BYTES + 24 * 64
+        return tot
+    if name in ("ia_hashgrid_fwd", "ia_hashgrid_fwd_xcd"):
+        return n * (12 + 1024 + 128)             # 12 B in + 16 levels x 8 corners x 8 B gathered + 128 B out
+    if name in ("ia_hashgrid_bwd", "ia_hashgrid_bwd_binned"):
+        return n * (12 + 128 + 1024 + 1024)      # read-modify-write of the touched entries
+    if name == "ia_sdf_fused":
+        return n * (12 + 1024 + 4)               # encode + MLP fused: point in, gathers, one SDF out
+    if name == "ia_accumulate_along_rays":
+        return n * (4 + 8 + 12) + 0              # w, ray index, rgb per sample (ray outputs negligible)
+    return None
 
 
-# C-ABI entry point -> kernels it launches (substring match on the rocprofv3 kernel names); "alt": one of them runs per
-# call, "seq": all of them run once per call
-PMC_KERNELS = {
-    "ia_fuse_broyden": ("alt", ["broyden_persistent_kernel", "broyden_kernel"]),
-    "ia_hashgrid_fwd": ("alt", ["hash_fwd_kernel<false>", "hash_fwd_kernel<true>"]),
-    "ia_hashgrid_bwd_binned": ("seq", ["hash_bin_kernel", "hash_reduce_kernel"]),
-    "ia_mlp_fwd": ("alt", ["mlp_fwd_kernel"]),
-    "ia_mlp_bwd_fused": ("alt", ["mlp2_train_kernel"]),
-    "ia_sdf_mlp_bwd_fused": ("alt", ["sdf_train_kernel"]),
+PMC_KERNELS = {          # C-ABI entry point -> substrings of the kernels it launches (rocprofv3 kernel names)
+    "ia_fuse_broyden": ["broyden_persistent_kernel", "broyden_kernel", "broyden_slim"],
+    "ia_hashgrid_fwd": ["hash_fwd_kernel"],
+    "ia_hashgrid_fwd_xcd": ["hash_fwd_xcd_kernel", "hash_transpose_kernel"],
+    "ia_hashgrid_bwd_binned": ["hash_bin", "hash_reduce_kernel"],
+    "ia_mlp_fwd": ["mlp_fwd_kernel"],
+    "ia_sdf_fused": ["sdf_fused_kernel"],
 }
 
 
 def pmc_traffic(entry):
-    """HBM-side bytes per launch of `entry` from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
-    2 x FETCH_SIZE + WRITE_SIZE, per MI355X_MICROARCH.md), or None when the entry point has not been profiled."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    """(HBM-side bytes per launch, source) of `entry` from the committed rocprofv3 PMC passes of THIS command
+    (profiles/<tag>_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md), or (None, None)."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic.json")
     if entry not in PMC_KERNELS or not os.path.exists(path):
-        return None
-    mode, subs = PMC_KERNELS[entry]
+        return None, None
     ks = json.load(open(path))["kernels"]
-    hits = [v for k, v in ks.items() if any(sub in k for sub in subs)]
+    hits = [v for k, v in ks.items() if any(sub in k for sub in PMC_KERNELS[entry])]
     if not hits:
-        return None
+        return None, None
     tot = sum(v["hbm_side_bytes_per_launch"] * v["launches"] for v in hits)
-    calls = sum(v["launches"] for v in hits) if mode == "alt" else max(v["launches"] for v in hits)
-    return int(tot / max(calls, 1))
+    calls = max(v["launches"] for v in hits)
+    return int(tot / max(calls, 1)), f"profiles/{PROFILE_TAG}_pmc_traffic.json"
 
 
 def cgroup_throttle():
@@ -97,16 +114,30 @@ def cgroup_throttle():
         return None
 
 
+def build_headline(dev, hw, spp, rank):
+    """the synthetic frame + material head + training-time light of the headline workload."""
+    from intrinsicavatar_amd import synthetic as S, fields, pbr
+    rs, rays, export = S.build_frame(dev, hw, hw, pose_seed=0, beta=0.01, num_samples_per_ray=128)
+    mat = fields.VolumeMaterial(seed=2).to(dev)
+    sg = pbr.EnvironmentLightSG(num_SGs=64, base_res=256, seed=4).to(dev)       # configs/light/envlight_SG.yaml
+    return rs, rays, export, mat, sg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--hw", type=int, default=540)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--ray-chunk", type=int, default=int(os.environ.get("IA_RAY_CHUNK", "65536")))
+    ap.add_argument("--workload", choices=["headline", "config2"], default="headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config2", action="store_true", help="skip the secondary configs[1] measurement of the headline line")
+    ap.add_argument("--no-breakdown", action="store_true", help="skip the instrumented repeat (profiling runs)")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd only (no Adam step)")
     ap.add_argument("--pass", dest="mode", choices=["fwd+bwd", "fwd"], default="fwd+bwd",
-                    help="fwd+bwd = training-step form of render_step (BASELINE metric); fwd = inference form")
+                    help="fwd+bwd = training-step form of render_step (BASELINE metric); fwd = inference form (config2 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,58 +175,110 @@ def main():
     from intrinsicavatar_amd import parallel as _par
     numa_node = _par.pin_to_gpu_numa_node(local_rank)          # host side of the step next to its GPU (2-socket hosts)
     # Buffer sizes follow the sample counts, which move a little every step once the optimiser updates the geometry; with
-    # exact-size caching the allocator keeps growing (13 -> 34 GiB over 14 steps) and a 5 GiB hipMalloc on a freshly booted
-    # box costs ~100 ms -- inside the timed region that showed up as 75-110 ms "steps".  Size classes (1/8 power-of-two
-    # steps) make the blocks of one step reusable by the next, and one up-front reservation moves the remaining growth in
-    # front of the warm-up.  288 GB of HBM: the 24 GiB arena is 8 % of the device.
+    # exact-size caching the allocator keeps growing and a multi-GiB hipMalloc on a freshly booted box costs ~100 ms.
+    # Size classes (1/8 power-of-two steps) make the blocks of one step reusable by the next, and one up-front
+    # reservation moves the remaining growth in front of the warm-up.  288 GB of HBM: the arena is < 20 % of the device.
     torch.cuda.memory._set_allocator_settings("roundup_power2_divisions:8")
-    _arena = torch.empty(24 << 30, dtype=torch.uint8, device=dev)
-    del _arena
+    if not share_gpu:
+        _arena = torch.empty((48 if args.workload == "headline" else 24) << 30, dtype=torch.uint8, device=dev)
+        del _arena
     from intrinsicavatar_amd import build
     if rank == 0:
         build.build()
     if world > 1:
         dist.barrier()
-    from intrinsicavatar_amd import synthetic as S, _lib as L, parallel
+    from intrinsicavatar_amd import _lib as L, parallel, optim, pbr
 
-    # one frame per rank (frame-/ray-batch sharding, replicated parameters).  Weak scaling = the SAME per-GPU workload at
-    # every N: each rank renders the configs[1] frame (pose 0) against its own target image, so the per-rank work at N=8
-    # is exactly the N=1 work and the gradients that meet in the all-reduce still differ per rank.
-    rs, rays, export = S.build_frame(dev, args.hw, args.hw, pose_seed=0, beta=0.01, num_samples_per_ray=128)
+    headline = args.workload == "headline"
+    rs, rays, export, mat, sg = build_headline(dev, args.hw, args.spp, rank)
     n_rays = rays.shape[0]
-
-    params = rs.parameters()
+    # one frame per rank (frame-/ray-batch sharding, replicated parameters).  Weak scaling = the SAME per-GPU workload at
+    # every N: each rank renders the same frame (pose 0) against its own target image and draws its own random numbers,
+    # so the per-rank work at N=8 is the N=1 work and the gradients that meet in the all-reduce still differ per rank.
     g = torch.Generator().manual_seed(1234 + rank)
     target_rgb = torch.rand((n_rays, 3), generator=g).to(dev)
     target_mask = (torch.rand(n_rays, generator=g) > 0.5).float().to(dev)
+    torch.manual_seed(99 + rank)
+    bg = torch.ones(3, device=dev)
+    chunks = [(c0, min(c0 + args.ray_chunk, n_rays)) for c0 in range(0, n_rays, args.ray_chunk)]
+    chunk_views = [(rays[a:b].contiguous(), target_rgb[a:b].contiguous(), target_mask[a:b].contiguous(), (b - a) / n_rays)
+                   for a, b in chunks]
+
+    params2 = rs.parameters()
+    params = params2 + ([p for p in mat.parameters() if p.requires_grad] + list(sg.parameters()) if headline else [])
+
+    def zero_grads():
+        for p in params:
+            p.grad = None
+
+    def step_config2(sync=None):
+        if args.mode == "fwd":
+            return rs.forward(rays)
+        for p in params2:
+            p.grad = None
+        out = rs.forward_backward(rays, target_rgb, target_mask)
+        return out
+
+    totals = {}
+
+    def step_headline(sync=None):
+        """one 540x540 frame: fwd + bwd with the PBR branch at `spp`, chunked with gradient accumulation."""
+        zero_grads()
+        # training-time light: SG lobes -> equirect image (differentiable); the chunks share one image and its gradient
+        # is accumulated in a leaf and pushed through generate_image() once at the end
+        img = sg.generate_image()
+        leaf = img.detach().requires_grad_(True)
+        emitter = pbr.EnvironmentLightTensor(leaf.detach())
+        emitter.update_pdf()                                        # pbr_light_forward: `if self.training: update_pdf()`
+        tot = dict(n_samples=0, n_edges0=0, n_samples0=0, n_resampled=0, n_fg=0, n_secondary=0)
+        for ci, (r, t, m, frac) in enumerate(chunk_views):
+            last = ci == len(chunk_views) - 1
+            ctx = sync.no_sync() if (sync is not None and not last) else _null()
+            with ctx:
+                o = rs.forward_backward_phys(r, t, mat, emitter, args.spp, None, None, target_mask=m, render_mode="light",
+                                             env_base=leaf, background_color=bg, global_illumination=True,
+                                             light_sampling="per_point", loss_scale=frac)
+            for k in tot:
+                tot[k] += int(o["stats"].get(k, 0))
+            del o
+        if leaf.grad is not None:
+            img.backward(leaf.grad)
+        totals.update(tot)
+        return dict(stats=tot)
+
+    import contextlib
+    _null = contextlib.nullcontext
 
     # one-time initialisation (not a step, and BEFORE the all-reduce hooks exist): the first launches load the code
     # objects and set kernel attributes; done on a 4096-ray slice so that the W warm-up steps see a warm library
-    if args.mode == "fwd":
-        rs.forward(rays[:4096].contiguous())
+    r0, t0_, m0 = rays[:4096].contiguous(), target_rgb[:4096].contiguous(), target_mask[:4096].contiguous()
+    if headline:
+        img0 = sg.generate_image().detach()
+        e0 = pbr.EnvironmentLightTensor(img0)
+        e0.update_pdf()
+        rs.forward_backward_phys(r0, t0_, mat, e0, 64, None, None, target_mask=m0, render_mode="light",
+                                 background_color=bg, global_illumination=True, light_sampling="per_point")
+    elif args.mode == "fwd":
+        rs.forward(r0)
     else:
-        rs.forward_backward(rays[:4096].contiguous(), target_rgb[:4096].contiguous(), target_mask[:4096].contiguous())
-        for p in params:
-            p.grad = None
+        rs.forward_backward(r0, t0_, m0)
+    zero_grads()
     torch.cuda.synchronize()
 
     # the one exchange step of the path (SURVEY 8(e)): all-reduce(sum) of the gradients over RCCL/xGMI; the two 50 MB
     # hash-table gradients are launched from autograd hooks as soon as they are complete (overlap with the rest of backward)
-    sync = parallel.OverlappedGradientAllReduce(params) if (world > 1 and args.mode != "fwd") else None
+    train = headline or args.mode != "fwd"
+    sync = parallel.OverlappedGradientAllReduce(params) if (world > 1 and train) else None
     # the optimiser step of the iteration is inside the timed region: torch.optim.Adam semantics with the reference's
-    # parameter groups and linear warm-up (configs/config.yaml:110-148), one fused launch; the summed all-reduce becomes
-    # DDP's mean through grad_scale = 1/world
+    # parameter groups and scheduler (configs/config.yaml:110-155), one fused launch; the summed all-reduce becomes DDP's
+    # mean through grad_scale = 1/world
     opt = sched = None
-    if args.mode != "fwd" and not args.no_optimizer:
-        from intrinsicavatar_amd import optim
-        opt, sched = optim.reference_optimizer(rs, grad_scale=1.0 / world)
+    if train and not args.no_optimizer:
+        opt, sched = optim.reference_optimizer(rs, grad_scale=1.0 / world, material=mat if headline else None,
+                                               emitter=sg if headline else None)
 
     def step():
-        if args.mode == "fwd":
-            return rs.forward(rays)
-        for p in params:
-            p.grad = None
-        out = rs.forward_backward(rays, target_rgb, target_mask)
+        out = step_headline(sync) if headline else step_config2(sync)
         if sync is not None:
             sync.finish()
         if opt is not None:
@@ -221,16 +304,19 @@ def main():
     dt = time.perf_counter() - t0
     cpu_busy = (time.process_time() - cpu0) / max(dt, 1e-9)          # CPUs this rank kept busy during the timed region
     thr1 = cgroup_throttle()
-    # ---- the same K steps again with a HIP-event pair around every C-ABI launch (on the launch stream): per-kernel
-    # durations for the roofline / breakdown.  Kept out of the throughput region because the ~600 event records per step
-    # cost host time that the un-instrumented step does not pay (ms_per_step_instrumented is reported next to it).
-    lib.start()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    dt_instr = time.perf_counter() - t1
-    per_call = lib.report()
+    # ---- ONE more step with a HIP-event pair around every C-ABI launch (on the launch stream): per-kernel durations
+    # and counted units for the roofline / breakdown.  Kept out of the throughput region because the event records cost
+    # host time that the un-instrumented step does not pay (ms_per_step_instrumented is reported next to it).
+    detail, dt_instr, k_instr = {}, 0.0, 0
+    if not args.no_breakdown:
+        k_instr = 1 if headline else args.steps
+        lib.start()
+        t1 = time.perf_counter()
+        for _ in range(k_instr):
+            out = step()
+        torch.cuda.synchronize()
+        dt_instr = time.perf_counter() - t1
+        detail = lib.report(detail=True)
     if world > 1:
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -238,62 +324,141 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * n_rays * args.steps / dt
 
+    # ---- secondary key of the headline line: round 1's configs[1] step (radiance + SDF, no PBR branch), same frame
+    config2 = None
+    if headline and rank == 0 and world == 1 and not args.no_config2:
+        opt2, sched2 = optim.reference_optimizer(rs)
+
+        def s2():
+            for p in params2:
+                p.grad = None
+            o = rs.forward_backward(rays, target_rgb, target_mask)
+            opt2.step()
+            sched2.step()
+            return o
+        for _ in range(2):
+            s2()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(10):
+            s2()
+        torch.cuda.synchronize()
+        config2 = (time.perf_counter() - tc) / 10 * 1e3
+
     if rank == 0:
         stats = dict(out["stats"])
         stats["n_rays"] = n_rays
-        # points through the deformer per step: edges (it0) + intervals (it1) + final samples
-        calls_b, ms_b = per_call.get("ia_fuse_broyden", (0, 0.0))
-        stats["deform_points"] = stats["n_edges0"] + 2 * stats["n_samples"]       # ~ (it1 has fewer intervals; upper est.)
-        stats["sdf_points"] = stats["deform_points"]                               # ~1 surviving candidate / point
+        per_call = {k: (len(v), sum(c[0] for c in v)) for k, v in detail.items()}
         total_ms = sum(v[1] for v in per_call.values())
-        dom = max(per_call.items(), key=lambda kv: kv[1][1])
-        dname, (dcalls, dms) = dom
-        launches_per_step = dcalls / args.steps
-        ab = algorithmic_bytes(dname, stats)
-        roofline = None
-        if ab:
-            per_launch_bytes = ab / launches_per_step
-            avg_us = dms / dcalls * 1e3
-            achieved = per_launch_bytes / (avg_us * 1e-6) / 1e9
-            roofline = dict(kernel=dname, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                            frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=pmc_traffic(dname),
-                            traffic_source="profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per "
-                                           "launch, separate passes, tools/pmc_traffic.py)",
-                            avg_launch_us=round(avg_us, 1), launches_per_step=launches_per_step,
-                            algorithmic_bytes_per_launch=int(per_launch_bytes),
-                            share_of_kernel_time=round(dms / max(total_ms, 1e-9), 3))
-        breakdown = {k: dict(calls_per_step=v[0] / args.steps, ms_per_step=round(v[1] / args.steps, 3))
-                     for k, v in sorted(per_call.items(), key=lambda kv: -kv[1][1])[:10]}
+        roofline = l1 = None
+        breakdown = {}
+        if per_call:
+            dname, (dcalls, dms) = max(per_call.items(), key=lambda kv: kv[1][1])
+            ab = algorithmic_bytes(dname, detail[dname])
+            stats["deform_points"] = sum(u for _, u, _ in detail.get("ia_fuse_broyden", []))      # counted, not estimated
+            stats["hash_points"] = sum(u for k in ("ia_hashgrid_fwd", "ia_hashgrid_fwd_xcd", "ia_sdf_fused")
+                                       for _, u, _ in detail.get(k, []))
+            if ab:
+                avg_us = dms / dcalls * 1e3
+                achieved = ab / (dms * 1e-3) / 1e9
+                traffic, tsrc = pmc_traffic(dname)
+                roofline = dict(kernel=dname, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                                frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=tsrc,
+                                avg_launch_us=round(avg_us, 1), launches_per_step=dcalls / k_instr,
+                                units_per_step=sum(u for _, u, _ in detail[dname]) // k_instr,
+                                algorithmic_bytes_per_launch=int(ab / dcalls),
+                                share_of_kernel_time=round(dms / max(total_ms, 1e-9), 3))
+            if dname == "ia_fuse_broyden":
+                # the bound that binds the search: every trilinear fetch of voxel_J is 8 corners x 48 B through
+                # the CU's vector L1; fetches are COUNTED by the kernel itself (ia_broyden_fetch_count, debug counter pass)
+                cnt = getattr(lib, "ia_broyden_fetch_count", None)
+                fetches = None
+                if cnt is not None:
+                    try:
+                        fetches = _count_fetches(lib, step)
+                    except Exception:          # counter not available in this build
+                        fetches = None
+                if fetches:
+                    l1_bytes = fetches * 384.0
+                    l1 = dict(bound="l1 (TCP vector-memory path)", achieved=round(l1_bytes / (dms / k_instr * 1e-3) / 1e9, 1),
+                              peak=round(L1_PEAK_GBPS, 1), unit="GB/s", frac=round(l1_bytes / (dms / k_instr * 1e-3) / 1e9 / L1_PEAK_GBPS, 4),
+                              fetches_per_step=int(fetches), bytes_per_fetch=384)
+            breakdown = {k: dict(calls_per_step=v[0] / k_instr, ms_per_step=round(v[1] / k_instr, 3))
+                         for k, v in sorted(per_call.items(), key=lambda kv: -kv[1][1])[:12]}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import render_ref as R, oracle as O
-            O.build()
-            stride = max(1, n_rays // 24000)
-            sample = rays[::stride].cpu().numpy()
-            sc = R.Scene(**export)
-            tc = time.perf_counter()
-            R.render_step(sc, sample)
-            tcpu = time.perf_counter() - tc
-            cpu = dict(value=round(sample.shape[0] / tcpu, 1), unit="rays/s", cores=1, kind="port",
-                       sample=f"every {stride}th ray of the same 540x540 frame ({sample.shape[0]} rays), "
-                              f"oracle/render_ref.py render_step forward, {tcpu:.1f} s single-threaded")
+            cpu = cpu_baseline(rays, export, n_rays, headline, args.spp)
+        wl = (f"{args.hw}x{args.hw} frame ({n_rays} rays), fwd+bwd+Adam WITH the PBR branch: 128 samples/ray primary march, 2x importance "
+              f"resampling, fast-SNARF deformer (13 inits), SDF/radiance/material fields, samples_per_pixel={args.spp} volume-interaction "
+              f"re-samples per ray, render_mode=light (one light-importance-sampled secondary ray per foreground re-sample, training form), "
+              f"secondary march 64 steps + zero-crossing resampling + shading (global_illumination on), SG environment light; "
+              f"ray chunks of {args.ray_chunk} with gradient accumulation; random-init fields, synthetic 24-bone rig") if headline else \
+             (f"{args.hw}x{args.hw} frame ({n_rays} rays), 128 samples/ray, radiance + SDF geometry, fast-SNARF deformer (13 inits), "
+              "2x importance resampling, random-init hash-grid/MLP fields, synthetic 24-bone rig")
+        metric = (f"rays/sec (fwd+bwd) at {args.hw}x{args.hw}, {args.spp} spp" if headline else
+                  (f"rays/sec (fwd+bwd) at {args.hw}x{args.hw}, no PBR branch (configs[1])" if args.mode == "fwd+bwd" else f"rays/sec (fwd) at {args.hw}x{args.hw}"))
         line = {
-            "metric": "rays/sec (fwd+bwd) at 540x540" if args.mode == "fwd+bwd" else "rays/sec (fwd) at 540x540", "value": round(value, 1), "unit": "rays/s",
+            "metric": metric, "value": round(value, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.hw}x{args.hw} frame ({n_rays} rays), 128 samples/ray, radiance + SDF geometry, "
-                                   "fast-SNARF deformer (13 inits), 2x importance resampling, random-init hash-grid/MLP "
-                                   "fields, synthetic 24-bone rig",
-                       "pass": args.mode, "host_numa_node": numa_node, "host_cpus_busy": round(cpu_busy, 2), "blocking_sync": bool(blocking),
-                       "host_cpu_throttled_ms_in_timed_region": (None if not (thr0 and thr1) else round((thr1[1] - thr0[1]) / 1e3, 1)), "optimizer_step_in_timed_region": bool(opt is not None), "frames_per_step_per_gpu": 1, "parallelism": f"frame/ray-batch sharding x{world}",
-                       "samples": stats},
-            "roofline": roofline, "cpu_baseline": cpu, "kernel_breakdown_ms_per_step": breakdown,
-            "ms_per_step_instrumented": round(dt_instr / args.steps * 1e3, 3),
-            "abi_kernel_ms_per_step": round(total_ms / args.steps, 3),
+            "config": {"workload": wl, "pass": "fwd+bwd" if headline else args.mode, "spp": args.spp if headline else 0,
+                       "render_mode": "light" if headline else None, "global_illumination": bool(headline),
+                       "ray_chunk": args.ray_chunk if headline else n_rays,
+                       "host_numa_node": numa_node, "host_cpus_busy": round(cpu_busy, 2), "blocking_sync": bool(blocking),
+                       "host_cpu_throttled_ms_in_timed_region": (None if not (thr0 and thr1) else round((thr1[1] - thr0[1]) / 1e3, 1)),
+                       "optimizer_step_in_timed_region": bool(opt is not None), "frames_per_step_per_gpu": 1,
+                       "parallelism": f"frame/ray-batch sharding x{world}", "samples": stats},
+            "roofline": roofline, "l1_roofline": l1, "cpu_baseline": cpu, "kernel_breakdown_ms_per_step": breakdown,
+            "ms_per_step_instrumented": round(dt_instr / max(k_instr, 1) * 1e3, 3),
+            "abi_kernel_ms_per_step": round(total_ms / max(k_instr, 1), 3),
+            "secondary_rays_per_s": (round(world * stats.get("n_secondary", 0) * args.steps / dt, 1) if headline else None),
+            "config2_ms_per_step": (round(config2, 3) if config2 else None),
+            "config2_rays_per_s": (round(n_rays / (config2 * 1e-3), 1) if config2 else None),
         }
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _count_fetches(lib, step):
+    """one extra (untimed) step with the Broyden kernel's fetch counter on -> trilinear fetches of that step."""
+    lib.ia_broyden_fetch_count.restype = ctypes_i64()
+    lib.ia_broyden_fetch_count(1)            # reset + enable
+    step()
+    torch.cuda.synchronize()
+    n = int(lib.ia_broyden_fetch_count(0))   # read + disable
+    return n
+
+
+def ctypes_i64():
+    import ctypes
+    return ctypes.c_int64
+
+
+def cpu_baseline(rays, export, n_rays, headline, spp):
+    """the CPU oracle (oracle/: a port of the reference's algorithm, test infrastructure) timed on this box's host cores on
+    a bounded sample of the same frame.  Forward only: the oracle has no backward."""
+    from oracle import render_ref as R, oracle as O
+    O.build()
+    sc = R.Scene(**export)
+    if headline and hasattr(R, "relight_step"):
+        stride = max(1, n_rays // 96)
+        sample = rays[::stride].cpu().numpy()
+        tc = time.perf_counter()
+        R.relight_step(sc, sample, spp=spp, seed=0)
+        tcpu = time.perf_counter() - tc
+        what = (f"every {stride}th ray of the same 540x540 frame ({sample.shape[0]} rays) x {spp} spp, oracle/render_ref.py "
+                f"relight_step (render_step forward WITH the PBR branch, render_mode=light, secondary rays on), {tcpu:.1f} s")
+    else:
+        stride = max(1, n_rays // 24000)
+        sample = rays[::stride].cpu().numpy()
+        tc = time.perf_counter()
+        R.render_step(sc, sample)
+        tcpu = time.perf_counter() - tc
+        what = (f"every {stride}th ray of the same 540x540 frame ({sample.shape[0]} rays), oracle/render_ref.py render_step "
+                f"forward WITHOUT the PBR branch (configs[1] form), {tcpu:.1f} s")
+    return dict(value=round(sample.shape[0] / tcpu, 1), unit="rays/s", cores=1, kind="port", passes="forward only (the oracle has no backward)",
+                sample=what)
 
 
 if __name__ == "__main__":

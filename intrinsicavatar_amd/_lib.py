@@ -17,6 +17,10 @@ class IaError(RuntimeError):
     pass
 
 
+# optional outputs that change an entry point's compulsory traffic: ia_fuse_broyden(..., x, J_inv, is_valid, fwd_J, stream)
+_EXTRAS = {"ia_fuse_broyden": lambda a: dict(I=int(a[2].value), J_inv=bool(a[16].value), fwd_J=bool(a[18].value))}
+
+
 class _Timed:
     """optional per-entry-point HIP-event timing (bench.py): events are recorded on the stream the
     kernels are launched on (torch's current stream), nothing synchronises until report()."""
@@ -39,7 +43,11 @@ class _Timed:
             e0.record()
             rc = fn(*args)
             e1.record()
-            self.events.setdefault(name, []).append((e0, e1))
+            # units of the launch = its first int64 argument (every entry point leads with its element count);
+            # per-entry extras (which optional outputs were requested) for the algorithmic-bytes model of bench.py
+            units = next((int(a.value) for a in args if isinstance(a, C.c_int64)), 0)
+            ex = _EXTRAS.get(name)
+            self.events.setdefault(name, []).append((e0, e1, units, ex(args) if ex else None))
             return rc
         return call
 
@@ -47,11 +55,13 @@ class _Timed:
         self.events = {}
         self.enabled = True
 
-    def report(self):
-        """-> {entry point: (n_calls, total_ms)}; synchronises."""
+    def report(self, detail: bool = False):
+        """-> {entry point: (n_calls, total_ms)}; synchronises.  detail=True: {entry point: [(ms, units, extras), ...]}."""
         self.enabled = False
         torch.cuda.synchronize()
-        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.events.items()}
+        if detail:
+            return {k: [(a.elapsed_time(b), u, x) for a, b, u, x in v] for k, v in self.events.items()}
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b, _, _ in v)) for k, v in self.events.items()}
 
 
 def lib():

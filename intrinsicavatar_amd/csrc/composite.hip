@@ -94,7 +94,7 @@ __global__ __launch_bounds__(THREADS) void weight_from_alpha_bwd_kernel(
         for (int j = pi.y - 1; j >= 0; j--) {
             const int i = pi.x + j;
             const float gw = g_weights ? g_weights[i] : 0.0f, gT = g_trans ? g_trans[i] : 0.0f;
-            g_alphas[i] = gw * trans[i] - S / (1.0f - alphas[i]);
+            g_alphas[i] = gw * trans[i] - S / fmaxf(1.0f - alphas[i], 1e-10f);
             S = S + (gw * weights[i] + gT * trans[i]);
         }
         return;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(THREADS) void weight_from_alpha_bwd_kernel(
         while (pi.y > 0 && pos >= pi.x && pos >= c0) {
             const int k = pos - c0;
             const float gw = sGw[k], gT = sGt[k];
-            sO[k] = gw * sT[k] - S / (1.0f - sA[k]);
+            sO[k] = gw * sT[k] - S / fmaxf(1.0f - sA[k], 1e-10f);
             S = S + (gw * sW[k] + gT * sT[k]);
             pos--;
         }

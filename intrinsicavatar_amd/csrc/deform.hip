@@ -279,7 +279,7 @@ __global__ __launch_bounds__(THREADS) void laplace_alpha_bwd_kernel(int64_t n, c
         // d dens / d s = (1/beta) * 0.5 * sg * e * (-sg/beta) = -e / (2 beta^2)   (s != 0)
         g_sdf[i] = ga * (-(e) / (2.0f * beta * beta)) * (s == 0.f ? 0.f : 1.f);
         // d dens / d beta = -dens/beta + (1/beta) * 0.5 * sg * e * (as / beta^2)
-        gb = ga * (-dens / beta + 0.5f * sg * e * as / (beta * beta * beta));
+        gb += ga * (-dens / beta + 0.5f * sg * e * as / (beta * beta * beta));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) gb += __shfl_down(gb, off, 64);

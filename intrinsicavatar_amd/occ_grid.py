@@ -55,9 +55,23 @@ class TemporalOccGridEstimator(torch.nn.Module):
         self._bits = {}
 
     def _grid_bits(self, lvl: int):
-        if lvl not in self._bits:
-            self._bits[lvl] = nerfacc.pack_occupancy_bits(self.binaries[lvl])
-        return self._bits[lvl]
+        """bit-packed copy of level `lvl` for the traversal kernel, cached per (buffer identity, in-place version):
+        load_state_dict() copies into `binaries` in place (version bump), .to(device) / _apply replace the tensor."""
+        b = self.binaries
+        key = (b.data_ptr(), b._version, str(b.device))
+        hit = self._bits.get(lvl)
+        if hit is None or hit[0] != key:
+            hit = (key, nerfacc.pack_occupancy_bits(b[lvl]))
+            self._bits[lvl] = hit
+        return hit[1]
+
+    def _apply(self, fn, *a, **kw):
+        self._bits = {}
+        return super()._apply(fn, *a, **kw)
+
+    def _load_from_state_dict(self, *a, **kw):
+        self._bits = {}
+        return super()._load_from_state_dict(*a, **kw)
 
     @torch.no_grad()
     def sampling(self, rays_o, rays_d, sigma_fn=None, alpha_fn=None, near_plane=0.0, far_plane=1e10, t_min=None, t_max=None,

@@ -4,7 +4,7 @@ The reference builds `torch.optim.Adam(param_groups, lr=1e-3, betas=(0.9, 0.99),
 `weight_decay` (configs/config.yaml:110-136, systems/utils.py:314-325) and drives it with `torch.optim.lr_scheduler`
 objects (systems/utils.py:328-346).  `Adam` below is a `torch.optim.Optimizer` subclass with the same constructor
 arguments, `param_groups`, `state` layout (`step`, `exp_avg`, `exp_avg_sq` -> `state_dict()` is interchangeable with
-torch.optim.Adam's, so optimiser checkpoints load either way) and scheduler compatibility; `step()` updates every
+torch.optim.Adam's for the same parameter groups) and scheduler compatibility; `step()` updates every
 parameter tensor with ONE `ia_adam_step` launch instead of ~10 elementwise kernels per tensor.
 
 No CPU fallback: parameters must live on the GPU (`_lib.ptr` raises otherwise).
@@ -106,12 +106,27 @@ def reference_param_groups(rs, lr: float = 1e-3, color_grid_wd: float = 0.0, mat
 
 
 def reference_optimizer(rs, lr: float = 1e-3, color_grid_wd: float = 0.0, material=None, emitter=None,
-                        grad_scale: float = 1.0, warmup_steps: Optional[int] = 1000):
-    """Adam + the linear warm-up of configs/config.yaml:137-148 (LinearLR 0.01 -> 1 over `warmup_steps`).
-    returns (optimizer, scheduler or None)."""
+                        grad_scale: float = 1.0, warmup_steps: Optional[int] = 1000,
+                        milestones=(12500, 18750, 22500, 23750), gamma: float = 0.3):
+    """Adam + the scheduler of configs/config.yaml:137-155: SequentialLR(LinearLR 0.01 -> 1 over `warmup_steps`,
+    then MultiStepLR(milestones, gamma) -- milestones count from the END of the warm-up, as SequentialLR restarts the
+    second scheduler's step counter).  returns (optimizer, scheduler or None).
+
+    The parameter groups are the reference's for the modules a RenderStep owns (geometry, radiance.network,
+    radiance.xyz_encoding, density, material, emitter); the reference's pose_correction / pose_encoder / deformer groups
+    belong to modules outside the render_step path, so an optimiser checkpoint of the full reference model does NOT load
+    here -- only same-group torch.optim.Adam state does."""
     opt = Adam(reference_param_groups(rs, lr, color_grid_wd, material, emitter), lr=lr, betas=(0.9, 0.99), eps=1e-15,
                grad_scale=grad_scale)
     sched = None
     if warmup_steps:
-        sched = torch.optim.lr_scheduler.LinearLR(opt, start_factor=0.01, end_factor=1.0, total_iters=warmup_steps)
+        S = torch.optim.lr_scheduler
+        warm = S.LinearLR(opt, start_factor=0.01, end_factor=1.0, total_iters=warmup_steps)
+        if milestones:
+            decay = S.MultiStepLR(opt, milestones=list(milestones), gamma=gamma)
+            sched = S.SequentialLR(opt, schedulers=[warm, decay], milestones=[warmup_steps])
+        else:
+            sched = warm
+    elif milestones:
+        sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=list(milestones), gamma=gamma)
     return opt, sched

@@ -8,6 +8,8 @@ over all links) and the ~20 small tensors are flattened into a single bucket ins
 """
 from typing import Iterable, List, Tuple
 
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -111,6 +113,7 @@ class OverlappedGradientAllReduce:
         self._next = 0
         self._handles = []
         self._hooks = []
+        self._hold = False
         if self.active:
             for p in self.order:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_ready))
@@ -120,7 +123,19 @@ class OverlappedGradientAllReduce:
             self._handles.append(dist.all_reduce(self.order[self._next].grad, async_op=True))
             self._next += 1
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """gradient accumulation over ray chunks (DDP.no_sync analogue): backward passes inside this context only
+        accumulate into .grad; the hooks launch the all-reduces from the first backward pass OUTSIDE of it (the last chunk)."""
+        self._hold = True
+        try:
+            yield
+        finally:
+            self._hold = False
+
     def _on_ready(self, p):
+        if self._hold:
+            return
         if id(p) in self._ready:
             raise RuntimeError("OverlappedGradientAllReduce: a table received a second gradient in the same backward pass "
                                "(e.g. the curvature term evaluates the SDF grid twice); its all-reduce is already in "

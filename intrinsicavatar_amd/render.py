@@ -59,9 +59,18 @@ class RenderStep:
                  render_step_size: float, importance_sample: bool = True):
         self.geometry, self.radiance, self.density, self.deformer = geometry, radiance, density, deformer
         self.binaries, self.aabbs = occ_binaries, occ_aabb
-        self.grid_bits = nerfacc.pack_occupancy_bits(occ_binaries[0])
+        self._grid_bits = None
         self.render_step_size = float(render_step_size)
         self.importance_sample = importance_sample
+
+    @property
+    def grid_bits(self) -> Tensor:
+        """bit-packed occupancy grid for the traversal kernel; re-packed when `binaries` is replaced or written in place."""
+        b = self.binaries
+        key = (b.data_ptr(), b._version, str(b.device))
+        if self._grid_bits is None or self._grid_bits[0] != key:
+            self._grid_bits = (key, nerfacc.pack_occupancy_bits(b[0]))
+        return self._grid_bits[1]
 
     # ------------------------------------------------------------------ helpers
     def _beta(self) -> Tensor:
@@ -175,16 +184,22 @@ class RenderStep:
     def forward_backward_phys(self, rays: Tensor, target_rgb: Tensor, material, emitter, spp: int, light_u: Tensor,
                               shuffle_u: Tensor, target_mask: Optional[Tensor] = None, jitter: Optional[Tensor] = None,
                               render_mode: str = "uniform_light", env_base: Optional[Tensor] = None,
-                              background_color: Optional[Tensor] = None) -> Dict[str, Tensor]:
+                              background_color: Optional[Tensor] = None, global_illumination: bool = False,
+                              light_sampling: str = "shared", loss_scale: float = 1.0, retain_graph: bool = False
+                              ) -> Dict[str, Tensor]:
         """BASELINE config 4: training step with the PBR branch (material head, volume scattering, secondary rays,
-        light / uniform_light estimator) -- fwd + bwd to geometry, radiance, material and environment-light parameters."""
+        light / uniform_light estimator) -- fwd + bwd to geometry, radiance, material and environment-light parameters.
+        loss_scale: weight of this ray chunk when a frame is processed in several chunks with gradient accumulation
+        (n_chunk_rays / n_frame_rays makes the accumulated gradient that of the frame-mean loss); retain_graph: keep the
+        graph of `env_base` (one generated environment image shared by all chunks of a step)."""
         from . import train_phys
         rays_o, rays_d, far, t_starts, t_ends, ray_indices, packed_info, stats = self.sample(rays, jitter)
         out = train_phys.shade_differentiable_phys(self, material, emitter, rays_o, rays_d, ray_indices, t_starts, t_ends,
                                                    packed_info, spp, light_u, shuffle_u, render_mode=render_mode,
-                                                   env_base=env_base, background_color=background_color)
+                                                   env_base=env_base, background_color=background_color,
+                                                   global_illumination=global_illumination, light_sampling=light_sampling)
         loss = train_phys.training_loss_phys(out, target_rgb, target_mask)
-        loss.backward()
+        (loss * loss_scale if loss_scale != 1.0 else loss).backward(retain_graph=retain_graph)
         out["loss"] = loss.detach()
         out["stats"].update(stats)
         return out
@@ -324,6 +339,7 @@ class RenderStep:
                 else:
                     raise NotImplementedError(f"Render mode {render_mode} not supported.")
                 Lo = torch.zeros((rri.shape[0], 3), device=dev)
+                Lo[bg_idx] = background_color[None]          # Lo.scatter_(0, bg_indices, background_color), :1335-1342
                 Lo[fg_idx] = fg_Lo
                 rgb_phys = nerfacc.accumulate_along_rays(rw, Lo, rri, n_rays)
                 out["secondary_tr"], out["fg_Lo"], out["fg_extras"] = sec_tr, fg_Lo, ex

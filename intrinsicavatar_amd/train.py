@@ -349,13 +349,19 @@ def shade_differentiable(rs, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor
 
 
 def training_loss(out: Dict[str, Tensor], target_rgb: Tensor, target_mask: Optional[Tensor] = None,
-                  lambda_eik: float = 0.1, lambda_mask: float = 0.1, lambda_curv: float = 0.0) -> Tensor:
+                  lambda_eik: float = 0.1, lambda_mask: float = 0.1, lambda_curv: float = 0.0,
+                  eik_denominator: Optional[float] = None) -> Tensor:
     """the rgb / eikonal / mask terms of systems/intrinsic_avatar.py:167-251 (L1 rgb, (|grad|-1)^2, BCE opacity)."""
     loss = (out["comp_rgb"] - target_rgb).abs().mean()
-    # eikonal term: mean over the valid samples, written as a masked sum (boolean-mask indexing costs a host sync forward
-    # and a 1.3 ms index_put in backward for 4.4 M samples)
-    eik_sum, n_valid = _Eikonal.apply(out["sdf_grad"], out["valid"])
-    loss = loss + lambda_eik * eik_sum / n_valid.clamp_min(1.0)
+    # eikonal term: the reference takes .mean() over ALL samples of out["sdf_grad_samples"]
+    # (systems/intrinsic_avatar.py:235-237); samples without a valid root carry the default gradient [0,0,1]
+    # (snarf_deformer.py:233-235), i.e. they add 0 to the sum but count in the denominator.  Written as a masked sum over
+    # the valid samples (no boolean-mask indexing: that costs a host sync forward and a 1.3 ms index_put in backward for
+    # 4.4 M samples) divided by the TOTAL sample count -- `eik_denominator` overrides it with a global count under ray
+    # sharding (sum of shard gradients == full-batch gradient).
+    eik_sum, _n_valid = _Eikonal.apply(out["sdf_grad"], out["valid"])
+    denom = float(eik_denominator) if eik_denominator is not None else float(max(out["sdf_grad"].shape[0], 1))
+    loss = loss + lambda_eik * eik_sum / denom
     if target_mask is not None:
         op = out["opacity"][:, 0].clamp(1e-3, 1 - 1e-3)
         loss = loss + lambda_mask * torch.nn.functional.binary_cross_entropy(op, target_mask)

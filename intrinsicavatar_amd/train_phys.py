@@ -79,10 +79,14 @@ def shade_differentiable_phys(rs, material, emitter, rays_o: Tensor, rays_d: Ten
                               t_ends: Tensor, packed_info: Tensor, spp: int, light_u: Tensor, shuffle_u: Tensor,
                               render_mode: str = "uniform_light", env_base: Optional[Tensor] = None,
                               background_color: Optional[Tensor] = None, global_illumination: bool = False,
-                              jitter_n: Optional[Tensor] = None) -> Dict[str, Tensor]:
+                              jitter_n: Optional[Tensor] = None, light_sampling: str = "shared") -> Dict[str, Tensor]:
     """differentiable rgb_normal_mats_alpha_fn + rendering_with_normals_mats_sdf + volume scattering.
     jitter_n [n_samples,3]: standard-normal noise of the material jitter pass (torch.randn_like in the reference,
-    :1116-1140): materials are re-evaluated at x_cano + 0.01 * jitter_n for the relative smoothness maps (:1546-1597)."""
+    :1116-1140): materials are re-evaluated at x_cano + 0.01 * jitter_n for the relative smoothness maps (:1546-1597).
+    light_sampling (render_mode 'light' only): 'shared' = the eval form of pbr_light_forward (:777-786): ONE set of spp
+    light directions per frame (light_u [spp,3]) permuted per ray (shuffle_u [n_rays,spp]); 'per_point' = the training form
+    (:772-776, `self.training`): an independent emitter.sample() per foreground point -- light_u is then [>= n_fg, 3]
+    uniforms (or None: drawn on the device) and shuffle_u is not used."""
     dfm, geo, rad = rs.deformer, rs.geometry, rs.radiance
     n_rays = packed_info.shape[0]
     dev = rays_o.device
@@ -156,15 +160,20 @@ def shade_differentiable_phys(rs, material, emitter, rays_o: Tensor, rays_d: Ten
             F_ = fg_idx.shape[0]
             with torch.no_grad():
                 s2 = dfm.w2s[:3, :3].T
-                if render_mode == "light":
-                    dirs_smpl = torch.nn.functional.normalize(emitter.sample(spp, light_u) @ s2, dim=-1, eps=1e-6)
-                    inv_pdf_all = None
+                inv_pdf = None
+                if render_mode == "light" and light_sampling == "per_point":
+                    u = light_u[:F_] if light_u is not None else None
+                    out_dirs = torch.nn.functional.normalize(emitter.sample(F_, u) @ s2, dim=-1, eps=1e-6).contiguous()
                 else:
-                    assert spp == 512, "uniform_light asserts samples_per_pixel == 512 (:1392)"
-                    dirs_smpl, inv_pdf_all = pbr.uniform_sphere_stratified(16, 32, light_u[:, :2])
-                shuffled = pbr.light_shuffle(n_rays, spp, rpi, fg_idx, shuffle_u)
-                out_dirs = dirs_smpl[shuffled].contiguous()
-                inv_pdf = inv_pdf_all[shuffled] if inv_pdf_all is not None else None
+                    if render_mode == "light":
+                        dirs_smpl = torch.nn.functional.normalize(emitter.sample(spp, light_u) @ s2, dim=-1, eps=1e-6)
+                        inv_pdf_all = None
+                    else:
+                        assert spp == 512, "uniform_light asserts samples_per_pixel == 512 (:1392)"
+                        dirs_smpl, inv_pdf_all = pbr.uniform_sphere_stratified(16, 32, light_u[:, :2])
+                    shuffled = pbr.light_shuffle(n_rays, spp, rpi, fg_idx, shuffle_u)
+                    out_dirs = dirs_smpl[shuffled].contiguous()
+                    inv_pdf = inv_pdf_all[shuffled] if inv_pdf_all is not None else None
                 nrm = ex["normals"].detach()
                 cos_mask = (nrm * out_dirs).sum(-1) > 1e-6
                 sec_tr = torch.zeros((F_, 1), device=dev)
@@ -176,7 +185,10 @@ def shade_differentiable_phys(rs, material, emitter, rays_o: Tensor, rays_d: Ten
             fg_Lo, fg_Ld, fg_Ls = pbr.pbr_shade_differentiable(
                 render_mode, ex["normals"], ex["albedo"], ex["roughness"], ex["metallic"], ex["t_dirs"], out_dirs, sec_tr,
                 sec_rgb if global_illumination else None, emitter, w2s_rot, inv_pdf=inv_pdf, env_base=env_base)
-            Lo = torch.zeros((rri.shape[0], 3), device=dev).index_put((fg_idx,), fg_Lo)
+            # background re-samples carry the background colour (Lo.scatter_(0, bg_indices, background_color), :1335-1342),
+            # their weights sum to the ray's transmittance
+            Lo = torch.zeros((rri.shape[0], 3), device=dev).index_put((bg_idx,), background_color[None].expand(bg_idx.shape[0], 3))
+            Lo = Lo.index_put((fg_idx,), fg_Lo)
             rgb_phys = nerfacc.accumulate_along_rays(rw, Lo, rri, n_rays)
             no_samples = (rpi[:, 1] <= 0)[:, None]
             rgb_phys = torch.where(no_samples, background_color[None].expand(n_rays, 3), rgb_phys)

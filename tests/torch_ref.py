@@ -176,8 +176,9 @@ def shade_reference(P, fixed, target_rgb, target_mask, lambda_eik=0.1, lambda_ma
     comp = torch.zeros(n_rays, 3, dtype=x.dtype).index_add(0, ri, w[:, None] * rgbs)
     opac = torch.zeros(n_rays, 1, dtype=x.dtype).index_add(0, ri, w[:, None])
     loss = (comp - target_rgb).abs().mean()
+    # .mean() over ALL samples (systems/intrinsic_avatar.py:235-237); invalid samples carry [0,0,1] -> 0 in the sum
     if valid.any():
-        loss = loss + lambda_eik * ((sdf_grad[valid].norm(dim=-1) - 1.0) ** 2).mean()
+        loss = loss + lambda_eik * ((sdf_grad[valid].norm(dim=-1) - 1.0) ** 2).sum() / max(sdf_grad.shape[0], 1)
     if target_mask is not None:
         op = opac[:, 0].clamp(1e-3, 1 - 1e-3)
         loss = loss + lambda_mask * torch.nn.functional.binary_cross_entropy(op, target_mask)
