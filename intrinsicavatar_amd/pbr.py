@@ -282,7 +282,7 @@ def sample_volume_interaction(rays_o, rays_d, ray_indices, t_starts, t_ends, n_r
 def light_shuffle(n_rays: int, spp: int, resampled_packed_info: Tensor, fg_indices: Tensor, shuffle_u: Tensor) -> Tensor:
     """intrinsic_avatar.py:1356-1378: independent permutation of [0, spp) per ray (argsort of uniforms, here an explicit
     device tensor instead of the reference's CPU torch.rand), packed to the resampled points, restricted to fg points."""
-    col = torch.argsort(shuffle_u, dim=-1)                                  # [n_rays, spp]
+    col = torch.argsort(shuffle_u, dim=-1, stable=True)                     # [n_rays, spp]; ties by index (the reference leaves them unspecified)
     has = resampled_packed_info[:, 1] > 0                                   # rays that own spp resampled points
     packed = col[has].reshape(-1)                                           # every such ray owns exactly spp points, in order
     return packed[fg_indices]

@@ -343,6 +343,10 @@ class RenderStep:
                 Lo[fg_idx] = fg_Lo
                 rgb_phys = nerfacc.accumulate_along_rays(rw, Lo, rri, n_rays)
                 out["secondary_tr"], out["fg_Lo"], out["fg_extras"] = sec_tr, fg_Lo, ex
+                if render_mode in ("light", "uniform_light"):
+                    out["shuffled"] = shuffled
+            out.update(resampled_packed_info=rpi, resampled_ray_indices=rri, resampled_weights=rw, fg_indices=fg_idx,
+                       bg_indices=bg_idx)
             rgb_phys[rpi[:, 1] <= 0] = background_color[None]
         out.update(comp_rgb_phys=rgb_phys, stats=stats)
         return out

@@ -234,3 +234,18 @@ def build_frame(device="cuda:0", height=128, width=128, pose_seed=0, beta=0.01, 
         rad_mask=N(rad.prog.mask(rad.global_step, "cpu")), rad_sh_mask=N(rad.sh_mask[0]),
         rad_W=[N(rl[i].weight) for i in (0, 2, 4)], rad_b=[N(rl[i].bias) for i in (0, 2, 4)])
     return rs, rays, export
+
+
+def export_phys(material, env_base):
+    """numpy arrays of the PBR branch for the CPU oracle (oracle/render_ref.py relight_step): the material head's
+    Lipschitz-normalised weights in the REFERENCE's column order [xyz(3) | hash(32) | feat(13)] (network_utils.py:396-403)
+    and the environment image."""
+    import torch
+    N = lambda t: t.detach().cpu().numpy()      # noqa: E731
+    Ws, bs = [], []
+    for i in range(3):
+        w = material.network.weights_per_layer[i]
+        c = torch.nn.functional.softplus(material.network.lipshitz_bound_per_layer[i])
+        Ws.append(N(w * torch.clamp(c / w.abs().sum(dim=1), max=1.0)[:, None]))
+        bs.append(N(material.network.biases_per_layer[i]))
+    return dict(mat_W=Ws, mat_b=bs, env_base=N(env_base))

@@ -1,5 +1,7 @@
 """CPU ORACLE (test infrastructure, NOT the product): numpy/C restatement of the reference's render_step
-forward for BASELINE configs 1-2 (radiance + SDF geometry), composed from the oracle primitives.
+forward, composed from the oracle primitives: `render_step` = BASELINE configs 1-2 (radiance + SDF geometry),
+`relight_step` = the same with the physically based branch (steps 6-8 of forward_, BASELINE configs 3 / 5 and the
+forward half of config 4).
 
 Follows IntrinsicAvatarModel.forward_ (models/intrinsic_avatar.py:950-1287), SNARFDeformer.deform
 (models/deformers/snarf_deformer.py:187-261), VolumeSDF / VolumeRefDirRadiance forward
@@ -96,7 +98,7 @@ def radiance(sc, pts_cano, feat, view_world, normal_world):
     return O.mlp_fwd(inp, sc.rad_W, sc.rad_b, "relu", "sigmoid")
 
 
-def render_step(sc, rays_world, jitter=None, importance_sample=True):
+def render_step(sc, rays_world, jitter=None, importance_sample=True, _sampling_only=False):
     rays = transform_rays_w2s(rays_world, sc.w2s)
     n = rays.shape[0]
     ro, rd, far = rays[:, :3], rays[:, 3:6], rays[:, 7]
@@ -132,6 +134,8 @@ def render_step(sc, rays_world, jitter=None, importance_sample=True):
             pi = O.pack_info(ridx, n)
     ts, te, rix = vals[il], vals[ir], ridx[il]
     pinfo = O.pack_info(rix, n)
+    if _sampling_only:
+        return ro, rd, far, ts, te, rix, pinfo, stats
     pts = ro[rix] + rd[rix] * ((ts + te) / np.float32(2.0))[:, None]
     d = deform(sc, pts, with_grad=True, with_feature=True)
     R = sc.w2s[:3, :3]
@@ -148,3 +152,167 @@ def render_step(sc, rays_world, jitter=None, importance_sample=True):
     stats.update(n_samples=len(ts), n_candidates=d["n_candidates"])
     return dict(comp_rgb=col, comp_normal=nrm, opacity=opa, depth=dep, weights=w, alphas=alphas, rgbs=rgbs, sdf=d["sdf"],
                 sdf_grad=d["sdf_grad"], t_starts=ts, t_ends=te, ray_indices=rix, packed_info=pinfo, stats=stats)
+
+
+# =============================================================================================================
+# steps 6-8 of forward_ (enable_phys): materials, volume-interaction re-sampling, secondary rays, PBR estimator
+# =============================================================================================================
+MAT_SCALE = np.array([0.77, 0.77, 0.77, 0.9, 1.0], np.float32)       # models/pbr/material.py:24-29 defaults
+MAT_BIAS = np.array([0.03, 0.03, 0.03, 0.09, 0.0], np.float32)
+
+
+def material(sc, pts_cano, feat):
+    """VolumeMaterial.forward on material_feature = hybrid (models/intrinsic_avatar.py:1100-1113, models/pbr/material.py:31-51):
+    [radiance xyz embedding (35) | geometry feature (13)] -> LipshitzMLP -> sigmoid -> affine.  sc.mat_W / sc.mat_b are the
+    Lipschitz-normalised weights (network_utils.py:396-403) in the reference's column order."""
+    xp = ((pts_cano - sc.rad_center) / sc.rad_scale + 0.5).astype(np.float32)
+    enc = O.hashgrid_fwd(xp, sc.rad_params) * sc.rad_mask[None]
+    inp = np.concatenate([xp * 2 - 1, enc, feat], -1).astype(np.float32)
+    return O.mlp_fwd(inp, sc.mat_W, sc.mat_b, "relu", "sigmoid") * MAT_SCALE[None] + MAT_BIAS[None]
+
+
+def shade_points(sc, ro, rd, rix, ts, te, with_materials=False):
+    """rgb_normal[_mats]_alpha_fn (models/intrinsic_avatar.py:1032-1156, eval): deformer + SDF(grad, feature) -> normals,
+    alpha, radiance (, materials) at the interval mid-points."""
+    pts = ro[rix] + rd[rix] * ((ts + te) / np.float32(2.0))[:, None]
+    d = deform(sc, pts, with_grad=True, with_feature=True)
+    R = sc.w2s[:3, :3]
+    normal_smpl = _normalize(d["sdf_grad"]).astype(np.float32)                  # F.normalize(sdf_grad, eps=1e-6)
+    normal_world = _normalize(d["sdf_grad"] @ R).astype(np.float32)             # transform_dirs_s2w
+    view_world = _normalize(rd[rix] @ R).astype(np.float32)
+    alphas = O.laplace_alpha(d["sdf"], te - ts, sc.beta)
+    rgbs = radiance(sc, d["pts_cano"], d["feature"], view_world, normal_world)
+    out = dict(d, normal_smpl=normal_smpl, normal_world=normal_world, alphas=alphas, rgbs=rgbs)
+    if with_materials:
+        out["materials"] = material(sc, d["pts_cano"], d["feature"])
+    return out
+
+
+def compute_indirect_radiance(sc, ro, rd, near=0.0, far=1.5, n_secondary=64):
+    """models/intrinsic_avatar.py:396-545 (eval): march [near, far] through the occupancy grid with step (far-near)/63,
+    SDF at the interval STARTS (coarse_alpha_sdf_fn :399-428), zero-crossing re-sampling to 4 intervals (K4, :490-505), keep
+    the foreground intervals, shade them (rgb_alpha_fn :430-456) and composite with `rendering` (volrend.py:19-194).
+    returns (1 - acc [M,1], rgb [M,3], stats)."""
+    M = ro.shape[0]
+    step = np.float32((far - near) / (n_secondary - 1))
+    tr = O.traverse_grids(ro, rd, sc.binaries, sc.aabb, np.full(M, near, np.float32), np.full(M, far, np.float32), step)
+    iv = tr["intervals"]
+    ts, te, rix = iv["vals"][iv["is_left"]], iv["vals"][iv["is_right"]], tr["samples"]["ray_indices"]
+    stats = dict(n_secondary_samples=len(ts), n_secondary_fg=0)
+    acc = np.zeros((M, 1), np.float32)
+    rgb = np.zeros((M, 3), np.float32)
+    if len(ts) == 0:
+        return 1.0 - acc, rgb, stats
+    sdf = deform(sc, ro[rix] + rd[rix] * ts[:, None])["sdf"]
+    alphas = O.laplace_alpha(sdf, te - ts, sc.beta)
+    pinfo = O.pack_info(rix, M)
+    rpi, rs, re, is_fg = O.ray_resampling_sdf_fine(pinfo, ts[:, None], te[:, None], alphas, sdf, 4)
+    rri = O.unpack_info(rpi, rs.shape[0])
+    rix, ts, te = rri[is_fg], rs[is_fg, 0], re[is_fg, 0]
+    stats["n_secondary_fg"] = len(ts)
+    if len(ts) == 0:
+        return 1.0 - acc, rgb, stats
+    sh = shade_points(sc, ro, rd, rix, ts, te)
+    pinfo = O.pack_info(rix, M)
+    w, _ = O.render_weight_from_alpha(sh["alphas"], pinfo)
+    acc = O.accumulate_along_rays(w, None, rix, M)
+    rgb = O.accumulate_along_rays(w, sh["rgbs"], rix, M)
+    return 1.0 - acc, rgb, stats
+
+
+def sample_volume_interaction(ro, rd, rix, ts, te, n_rays, spp, transmittance_map, extras):
+    """models/pbr/utils.py:70-229: K1 re-sampling of the un-normalised weight CDF (+ background bin), fg / bg split by the
+    1e4 offset marker, re-sampled weights = w / count (fg) and (1 - acc) / count (bg), attribute gathers."""
+    weights, sdfs = extras["weights"], extras["sdf"]
+    pinfo = O.pack_info(rix, n_rays)
+    rpi, mid, offs, sidx, fg_cnt, bg_cnt, surf = O.ray_resampling(pinfo, ts[:, None], te[:, None], weights, sdfs, spp)
+    fg_idx = np.nonzero(offs[:, 0] < 1e4)[0]
+    bg_idx = np.nonzero(offs[:, 0] >= 1e4)[0]
+    rri = O.unpack_info(rpi, mid.shape[0])
+    fg_rri, bg_rri = rri[fg_idx], rri[bg_idx]
+    fg_s = sidx[fg_idx]
+    rw = np.zeros(mid.shape[0], np.float32)
+    ex = {}
+    if len(fg_s) > 0:
+        rw[fg_idx] = weights[fg_s] / fg_cnt[fg_s].astype(np.float32)
+        rw[bg_idx] = transmittance_map[bg_rri, 0] / bg_cnt[bg_rri].astype(np.float32)
+        t = mid[fg_idx]
+        ex = dict(sdf=sdfs[fg_s], alphas=extras["alphas"][fg_s], dists=(te - ts)[:, None][fg_s],
+                  positions=(ro[fg_rri] + rd[fg_rri] * t).astype(np.float32), normals=extras["normals"][fg_s],
+                  albedo=extras["albedo"][fg_s], roughness=extras["roughness"][fg_s], metallic=extras["metallic"][fg_s],
+                  t_dirs=rd[fg_rri])
+    return rpi, rri, rw, fg_idx, bg_idx, ex, dict(sampled_indices=sidx, fg_counts=fg_cnt, bg_counts=bg_cnt, midpoints=mid,
+                                                   offsets=offs, surface_idx=surf)
+
+
+def light_shuffle(n_rays, spp, rpi, fg_idx, shuffle_u):
+    """models/intrinsic_avatar.py:1356-1378: per-ray permutation of [0, spp) = argsort of uniforms (explicit here; ties --
+    which torch.argsort leaves unspecified -- by index), unpack_data mask -> pack_data -> restrict to fg re-samples."""
+    col = np.argsort(shuffle_u, axis=-1, kind="stable")
+    has = rpi[:, 1] > 0
+    return col[has].reshape(-1)[fg_idx]
+
+
+def relight_step(sc, rays_world, spp=16, seed=0, light_u=None, shuffle_u=None, jitter=None, global_illumination=False,
+                 background_color=(1.0, 1.0, 1.0), importance_sample=True):
+    """forward_ with enable_phys, render_mode = light, eval form (models/intrinsic_avatar.py:950-1651): steps 1-4 as
+    render_step, step 5 = rendering_with_normals_mats_sdf (volrend.py:810-1020), steps 6-8 = :1288-1470.
+    light_u [spp,3] (emitter.sample uniforms) and shuffle_u [n_rays,spp] are explicit (drawn from `seed` when None).
+    sc additionally carries mat_W, mat_b, env_base [H,W,3]."""
+    from . import pbr_ref as Pb
+    rng = np.random.default_rng(seed)
+    n = rays_world.shape[0]
+    if light_u is None:
+        light_u = rng.random((spp, 3), dtype=np.float32)
+    if shuffle_u is None:
+        shuffle_u = rng.random((n, spp), dtype=np.float32)
+    bgc = np.asarray(background_color, np.float32)
+    base = render_step(sc, rays_world, jitter=jitter, importance_sample=importance_sample, _sampling_only=True)
+    ro, rd, far, ts, te, rix, pinfo, stats = base
+    sh = shade_points(sc, ro, rd, rix, ts, te, with_materials=True)
+    w, trn = O.render_weight_from_alpha(sh["alphas"], pinfo)
+    acc = lambda v: O.accumulate_along_rays(w, v, rix, n)      # noqa: E731
+    mats = sh["materials"]
+    out = dict(comp_rgb=acc(sh["rgbs"]), comp_normal=acc(sh["normal_world"]), albedo=acc(np.ascontiguousarray(mats[:, :3])),
+               roughness=acc(np.ascontiguousarray(mats[:, 3:4])), metallic=acc(np.ascontiguousarray(mats[:, 4:5])),
+               opacity=acc(None), weights=w, alphas=sh["alphas"], sdf=sh["sdf"], t_starts=ts, t_ends=te, ray_indices=rix,
+               packed_info=pinfo)
+    out["depth"] = acc(((ts + te) / np.float32(2.0))[:, None]) + (1 - out["opacity"]) * far[:, None]
+    rgb_phys = np.tile(bgc[None], (n, 1)).astype(np.float32)
+    stats.update(n_samples=len(ts), n_resampled=0, n_fg=0, n_secondary=0)
+    if len(rix) > 0:
+        extras = dict(weights=w, sdf=sh["sdf"], alphas=sh["alphas"], normals=sh["normal_smpl"], albedo=mats[:, :3],
+                      roughness=mats[:, 3:4], metallic=mats[:, 4:5])
+        rpi, rri, rw, fg_idx, bg_idx, ex, k1 = sample_volume_interaction(ro, rd, rix, ts, te, n, spp, 1.0 - out["opacity"], extras)
+        stats.update(n_resampled=len(rri), n_fg=len(fg_idx))
+        out.update(resampled_packed_info=rpi, resampled_weights=rw, fg_indices=fg_idx, bg_indices=bg_idx, k1=k1)
+        if len(fg_idx) > 0:
+            F_ = len(fg_idx)
+            R = sc.w2s[:3, :3]
+            pmf = Pb.envlight_pmf(sc.env_base)
+            dirs_world = Pb.envlight_sample(pmf, spp, light_u[:, 0].astype(np.float64), light_u[:, 1].astype(np.float64),
+                                            light_u[:, 2].astype(np.float64))
+            dirs_smpl = _normalize(dirs_world @ R.T).astype(np.float32)                     # transform_dirs_w2s
+            shuffled = light_shuffle(n, spp, rpi, fg_idx, shuffle_u)
+            out_dirs = dirs_smpl[shuffled]
+            cos_mask = (ex["normals"] * out_dirs).sum(-1) > 1e-6
+            sec_tr = np.zeros((F_, 1), np.float32)
+            sec_rgb = np.zeros((F_, 3), np.float32)
+            stats["n_secondary"] = int(cos_mask.sum())
+            if stats["n_secondary"] > 0:
+                t_, c_, st2 = compute_indirect_radiance(sc, np.ascontiguousarray(ex["positions"][cos_mask]),
+                                                        np.ascontiguousarray(out_dirs[cos_mask]))
+                sec_tr[cos_mask], sec_rgb[cos_mask] = np.clip(t_, 0.0, 1.0), c_
+                stats.update(st2)
+            fg_Lo, fg_Ld, fg_Ls = Pb.pbr_light_shade(ex["normals"], ex["albedo"], ex["roughness"][:, 0], ex["metallic"][:, 0],
+                                                     ex["t_dirs"], out_dirs, sec_tr[:, 0],
+                                                     sec_rgb if global_illumination else None, sc.env_base, pmf, R)
+            Lo = np.zeros((len(rri), 3), np.float32)
+            Lo[bg_idx] = bgc[None]                                                           # :1335-1342
+            Lo[fg_idx] = fg_Lo
+            rgb_phys = O.accumulate_along_rays(rw, Lo, rri, n)
+            out.update(fg_Lo=fg_Lo, fg_Lo_diff=fg_Ld, fg_Lo_spec=fg_Ls, secondary_tr=sec_tr, secondary_rgb=sec_rgb,
+                       out_dirs=out_dirs, cos_mask=cos_mask, fg_extras=ex, shuffled=shuffled)
+        rgb_phys[rpi[:, 1] <= 0] = bgc[None]                                                 # :1452-1466
+    out.update(comp_rgb_phys=rgb_phys, stats=stats)
+    return out
