@@ -369,20 +369,18 @@ def main():
                                 algorithmic_bytes_per_launch=int(ab / dcalls),
                                 share_of_kernel_time=round(dms / max(total_ms, 1e-9), 3))
             if dname == "ia_fuse_broyden":
-                # the bound that binds the search: every trilinear fetch of voxel_J is 8 corners x 48 B through
-                # the CU's vector L1; fetches are COUNTED by the kernel itself (ia_broyden_fetch_count, debug counter pass)
-                cnt = getattr(lib, "ia_broyden_fetch_count", None)
-                fetches = None
-                if cnt is not None:
-                    try:
-                        fetches = _count_fetches(lib, step)
-                    except Exception:          # counter not available in this build
-                        fetches = None
-                if fetches:
-                    l1_bytes = fetches * 384.0
-                    l1 = dict(bound="l1 (TCP vector-memory path)", achieved=round(l1_bytes / (dms / k_instr * 1e-3) / 1e9, 1),
-                              peak=round(L1_PEAK_GBPS, 1), unit="GB/s", frac=round(l1_bytes / (dms / k_instr * 1e-3) / 1e9 / L1_PEAK_GBPS, 4),
-                              fetches_per_step=int(fetches), bytes_per_fetch=384)
+                # what actually binds the search: every trilinear fetch of voxel_J is up to 8 corners x 48 B through
+                # the CU's vector L1; fetches and in-range corner loads are COUNTED by re-running the step's searches
+                # (ia_broyden_stats) in one extra untimed step
+                c = count_broyden_fetches(step, dev)
+                sec = dms / k_instr * 1e-3
+                l1_bytes = c[1] * 48.0
+                l1 = dict(bound="l1 (vector-memory path, 256 CUs x 64 B/clk x 2.4 GHz)", achieved=round(l1_bytes / sec / 1e9, 1),
+                          peak=round(L1_PEAK_GBPS, 1), unit="GB/s", frac=round(l1_bytes / sec / 1e9 / L1_PEAK_GBPS, 4),
+                          fetches_per_step=int(c[0]), corner_loads_per_step=int(c[1]), bytes_per_corner=48,
+                          fetches_per_item=round(c[0] / max(c[2] + c[3] + c[4], 1), 3),
+                          items=dict(converged=int(c[2]), diverged=int(c[3]), exhausted=int(c[4])),
+                          note="latency-bound on the L1's outstanding misses, see profiles/r02_broyden_probe.json")
             breakdown = {k: dict(calls_per_step=v[0] / k_instr, ms_per_step=round(v[1] / k_instr, 3))
                          for k, v in sorted(per_call.items(), key=lambda kv: -kv[1][1])[:12]}
         cpu = None
@@ -420,19 +418,31 @@ def main():
         dist.destroy_process_group()
 
 
-def _count_fetches(lib, step):
-    """one extra (untimed) step with the Broyden kernel's fetch counter on -> trilinear fetches of that step."""
-    lib.ia_broyden_fetch_count.restype = ctypes_i64()
-    lib.ia_broyden_fetch_count(1)            # reset + enable
-    step()
-    torch.cuda.synchronize()
-    n = int(lib.ia_broyden_fetch_count(0))   # read + disable
-    return n
+def count_broyden_fetches(step, dev):
+    """one extra (untimed) step in which every ia_fuse_broyden call is followed by ia_broyden_stats on the same inputs:
+    -> accumulated counters [17] (fetches, in-range corner loads, outcomes, exit histogram) of that step."""
+    from intrinsicavatar_amd import fast_snarf, _lib as L
+    cnt = torch.zeros(17, dtype=torch.int64, device=dev)
+    orig = fast_snarf.fuse_broyden
 
-
-def ctypes_i64():
-    import ctypes
-    return ctypes.c_int64
+    def wrapped(x, xd_tgt, voxel, voxel_J, tfs, bone_ids, align_corners, J_inv, is_valid, offset, scale, cvg, dvg, fwd_J=None):
+        orig(x, xd_tgt, voxel, voxel_J, tfs, bone_ids, align_corners, J_inv, is_valid, offset, scale, cvg, dvg, fwd_J=fwd_J)
+        cl = isinstance(voxel_J, fast_snarf.ChannelLastVoxelJ)
+        vj = voxel_J.data if cl else voxel_J.contiguous()
+        D, H, W = (vj.shape[1:4] if cl else vj.shape[2:5])
+        B, N, _ = xd_tgt.shape
+        L.check(L.lib().ia_broyden_stats(L.i32(B), L.i64(N), L.i32(bone_ids.shape[0]), L.ptr(xd_tgt.contiguous().float()), L.ptr(vj),
+                                         L.i32(1 if cl else 0), L.i32(D), L.i32(H), L.i32(W), L.ptr(tfs.contiguous().float()),
+                                         L.ptr(bone_ids.contiguous().to(torch.int32)), L.ptr(offset.reshape(3).contiguous().float()),
+                                         L.ptr(scale.reshape(3).contiguous().float()), L.f32(cvg), L.f32(dvg), L.ptr(cnt), L.stream()),
+                "ia_broyden_stats")
+    fast_snarf.fuse_broyden = wrapped
+    try:
+        step()
+        torch.cuda.synchronize()
+    finally:
+        fast_snarf.fuse_broyden = orig
+    return cnt.cpu().tolist()
 
 
 def cpu_baseline(rays, export, n_rays, headline, spp):

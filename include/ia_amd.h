@@ -174,6 +174,13 @@ int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt /*[B,N,3]*/, co
                     float* fwd_J /*[B,N,I,3,3] or NULL: forward LBS Jacobian at each root (= fwd_tfs, deformer_torch.py:49-52)*/,
                     ia_stream_t stream);
 int ia_filter(int64_t N, int I, const float* x /*[1,N,I,3]*/, const uint8_t* mask, uint8_t* out, ia_stream_t stream);
+/* diagnostics (no reference counterpart): runs the searches of ia_fuse_broyden without outputs and ACCUMULATES into
+ * counters[17] (caller-zeroed): [0] trilinear fetches, [1] in-range corner loads, [2] converged & in-box items,
+ * [3] diverged, [4] out of iterations, [5+k] items that ended after k fetches (k = 2..11).  Used by bench.py to price the
+ * search against the vector-memory (L1) path. */
+int ia_broyden_stats(int B, int64_t N, int I, const float* xd_tgt, const float* voxel_J, int layout, int D, int H, int W,
+                     const float* tfs, const int32_t* bone_ids, const float* offset, const float* scale,
+                     float cvg_threshold, float dvg_threshold, uint64_t* counters, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* tinycudann.Encoding replacements (reference call sites models/network_utils.py:65,77,191;

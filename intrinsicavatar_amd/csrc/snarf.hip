@@ -371,6 +371,107 @@ __global__ __launch_bounds__(THREADS) void broyden_persistent_kernel(
     }
 }
 
+
+// ---- K8 diagnostics ---------------------------------------------------------------
+// Same search as broyden_kernel (identical arithmetic, no outputs): counts what the searches of a batch cost, for the
+// L1-path figures of bench.py / DESIGN.md.  counters[0] = trilinear fetches issued, [1] = corner loads actually performed
+// (in-range corners; an out-of-range corner costs no memory request), [2] = converged & in-box items, [3] = diverged items,
+// [4] = items that ran out of iterations, [5 + k] = items whose search ended after k fetches (k = 2..11).
+template <int LAYOUT>
+__global__ __launch_bounds__(THREADS) void broyden_stats_kernel(
+    int64_t total, int64_t N, int I, const float* __restrict__ xd_tgt, const float* __restrict__ voxel_J, int D, int H,
+    int W, const float* __restrict__ tfs, const int32_t* __restrict__ bone_ids, const float* __restrict__ offset_g,
+    const float* __restrict__ scale_g, float cvg_threshold, float dvg_threshold, unsigned long long* __restrict__ counters)
+{
+    const int64_t index = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    unsigned fetches = 0, corners = 0, outcome = 3;      // 0 converged, 1 diverged, 2 exhausted, 3 = no item
+    if (index < total) {
+        const int64_t vol = (int64_t)D * H * W;
+        const int i_batch = (int)(index / (N * I));
+        const int64_t i_point = (index % (N * I)) / I;
+        const int i_init = (int)((index % (N * I)) % I);
+        const float* vJ = (LAYOUT == IA_LAYOUT_NDHWC) ? voxel_J : voxel_J + (int64_t)i_batch * 12 * vol;
+        const int vox0 = (LAYOUT == IA_LAYOUT_NDHWC) ? (int)(i_batch * vol) : 0;
+        const float offset[3] = {offset_g[0], offset_g[1], offset_g[2]};
+        const float scale[3] = {scale_g[0], scale_g[1], scale_g[2]};
+        auto in_range_corners = [&](float gx, float gy, float gz) -> unsigned {
+            float ix = ((gx + 1.f) / 2) * (W - 1), iy = ((gy + 1.f) / 2) * (H - 1), iz = ((gz + 1.f) / 2) * (D - 1);
+            if (ix > 2147483646.0f || ix < -2147483648.0f || !isfinite(ix)) ix = -100.0f;
+            if (iy > 2147483646.0f || iy < -2147483648.0f || !isfinite(iy)) iy = -100.0f;
+            if (iz > 2147483646.0f || iz < -2147483648.0f || !isfinite(iz)) iz = -100.0f;
+            const int x0 = (int)floorf(ix), y0 = (int)floorf(iy), z0 = (int)floorf(iz);
+            const unsigned cx = (unsigned)(x0 >= 0 && x0 < W) + (unsigned)(x0 + 1 >= 0 && x0 + 1 < W);
+            const unsigned cy = (unsigned)(y0 >= 0 && y0 < H) + (unsigned)(y0 + 1 >= 0 && y0 + 1 < H);
+            const unsigned cz = (unsigned)(z0 >= 0 && z0 < D) + (unsigned)(z0 + 1 >= 0 && z0 + 1 < D);
+            return cx * cy * cz;
+        };
+        float gx[3], gx_new[3] = {0, 0, 0}, xt[3], x_l[3];
+        xt[0] = xd_tgt[((int64_t)i_batch * N + i_point) * 3 + 0];
+        xt[1] = xd_tgt[((int64_t)i_batch * N + i_point) * 3 + 1];
+        xt[2] = xd_tgt[((int64_t)i_batch * N + i_point) * 3 + 2];
+        const float* T = tfs + ((int64_t)i_batch * 24 + bone_ids[i_init]) * 16;
+        const float ixd = xt[0] - T[0 * 4 + 3], iyd = xt[1] - T[1 * 4 + 3], izd = xt[2] - T[2 * 4 + 3];
+        x_l[0] = ixd * T[0 * 4 + 0] + iyd * T[1 * 4 + 0] + izd * T[2 * 4 + 0];
+        x_l[1] = ixd * T[0 * 4 + 1] + iyd * T[1 * 4 + 1] + izd * T[2 * 4 + 1];
+        x_l[2] = ixd * T[0 * 4 + 2] + iyd * T[1 * 4 + 2] + izd * T[2 * 4 + 2];
+        float Jl[12];
+        {
+            const float a = scale[0] * (x_l[0] + offset[0]), b = scale[1] * (x_l[1] + offset[1]), c = scale[2] * (x_l[2] + offset[2]);
+            grid_sample_J<LAYOUT>(vJ, vox0, D, H, W, a, b, c, Jl);
+            fetches++; corners += in_range_corners(a, b, c);
+        }
+        float Ji[9];
+        Ji[0] = Jl[0]; Ji[3] = Jl[1]; Ji[6] = Jl[2];
+        Ji[1] = Jl[4]; Ji[4] = Jl[5]; Ji[7] = Jl[6];
+        Ji[2] = Jl[8]; Ji[5] = Jl[9]; Ji[8] = Jl[10];
+        outcome = 2;
+        for (int it = 0; it < 10; it++) {
+            if (it == 0) {
+                gx[0] = Jl[0] * x_l[0] + Jl[1] * x_l[1] + Jl[2] * x_l[2] + Jl[3];
+                gx[1] = Jl[4] * x_l[0] + Jl[5] * x_l[1] + Jl[6] * x_l[2] + Jl[7];
+                gx[2] = Jl[8] * x_l[0] + Jl[9] * x_l[1] + Jl[10] * x_l[2] + Jl[11];
+                gx[0] = gx[0] - xt[0]; gx[1] = gx[1] - xt[1]; gx[2] = gx[2] - xt[2];
+            } else {
+                gx[0] = gx_new[0]; gx[1] = gx_new[1]; gx[2] = gx_new[2];
+            }
+            const float u0 = -Ji[0] * gx[0] + -Ji[1] * gx[1] + -Ji[2] * gx[2];
+            const float u1 = -Ji[3] * gx[0] + -Ji[4] * gx[1] + -Ji[5] * gx[2];
+            const float u2 = -Ji[6] * gx[0] + -Ji[7] * gx[1] + -Ji[8] * gx[2];
+            x_l[0] += u0; x_l[1] += u1; x_l[2] += u2;
+            const float ix = scale[0] * (x_l[0] + offset[0]);
+            const float iy = scale[1] * (x_l[1] + offset[1]);
+            const float iz = scale[2] * (x_l[2] + offset[2]);
+            grid_sample_J<LAYOUT>(vJ, vox0, D, H, W, ix, iy, iz, Jl);
+            fetches++; corners += in_range_corners(ix, iy, iz);
+            gx_new[0] = Jl[0] * x_l[0] + Jl[1] * x_l[1] + Jl[2] * x_l[2] + Jl[3] - xt[0];
+            gx_new[1] = Jl[4] * x_l[0] + Jl[5] * x_l[1] + Jl[6] * x_l[2] + Jl[7] - xt[1];
+            gx_new[2] = Jl[8] * x_l[0] + Jl[9] * x_l[1] + Jl[10] * x_l[2] + Jl[11] - xt[2];
+            const float norm_gx = gx_new[0] * gx_new[0] + gx_new[1] * gx_new[1] + gx_new[2] * gx_new[2];
+            if (norm_gx < cvg_threshold * cvg_threshold) {
+                outcome = (ix >= -1 && ix <= 1 && iy >= -1 && iy <= 1 && iz >= -1 && iz <= 1) ? 0 : 1;
+                break;
+            } else if (norm_gx > dvg_threshold * dvg_threshold) {
+                outcome = 1;
+                break;
+            }
+            J_inv_update(Ji, u0, u1, u2, gx_new[0] - gx[0], gx_new[1] - gx[1], gx_new[2] - gx[2]);
+        }
+    }
+    // wave-level reduction, one atomic per counter and wave
+    unsigned f = fetches, c = corners;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { f += __shfl_down(f, off, 64); c += __shfl_down(c, off, 64); }
+    const unsigned long long m0 = __ballot(outcome == 0), m1 = __ballot(outcome == 1), m2 = __ballot(outcome == 2);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&counters[0], (unsigned long long)f);
+        atomicAdd(&counters[1], (unsigned long long)c);
+        if (m0) atomicAdd(&counters[2], (unsigned long long)__popcll(m0));
+        if (m1) atomicAdd(&counters[3], (unsigned long long)__popcll(m1));
+        if (m2) atomicAdd(&counters[4], (unsigned long long)__popcll(m2));
+    }
+    if (outcome != 3 && fetches <= 11) atomicAdd(&counters[5 + fetches], 1ull);
+}
+
 // ---- K9 -------------------------------------------------------------------------
 __global__ __launch_bounds__(THREADS) void filter_kernel(int64_t N, int I, const float* __restrict__ x,
                                                           const uint8_t* __restrict__ mask, uint8_t* __restrict__ out)
@@ -414,7 +515,7 @@ IA_EXPORT int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt, cons
     const int64_t total = (int64_t)B * N * I;
     if (total == 0) return IA_OK;
     IA_REQUIRE(layout == IA_LAYOUT_NCDHW || layout == IA_LAYOUT_NDHWC, "unknown voxel_J layout");
-    IA_REQUIRE((int64_t)B * D * H * W < ((int64_t)1 << 28), "voxel grid too large for 32-bit voxel indices");
+    IA_REQUIRE((int64_t)B * D * H * W < ((int64_t)1 << 26), "voxel grid too large for 32-bit byte offsets (48 B per voxel)");
     hipStream_t s = (hipStream_t)stream;
     // Two bit-identical schedules.  Measured on MI355X (profiles/r01_*): primary-ray batches (most searches converge,
     // uniform length) are ~20 % faster with one item per lane; the huge secondary-ray batches (most searches diverge
@@ -453,4 +554,24 @@ IA_EXPORT int ia_filter(int64_t N, int I, const float* x, const uint8_t* mask, u
     if (N == 0) return IA_OK;
     filter_kernel<<<ia::cdiv(N, THREADS), THREADS, 0, (hipStream_t)stream>>>(N, I, x, mask, out);
     return ia::check_launch("ia_filter");
+}
+
+IA_EXPORT int ia_broyden_stats(int B, int64_t N, int I, const float* xd_tgt, const float* voxel_J, int layout, int D, int H,
+                               int W, const float* tfs, const int32_t* bone_ids, const float* offset, const float* scale,
+                               float cvg_threshold, float dvg_threshold, uint64_t* counters /*[17], caller-zeroed, accumulated*/,
+                               ia_stream_t stream)
+{
+    const int64_t total = (int64_t)B * N * I;
+    if (total == 0) return IA_OK;
+    IA_REQUIRE(layout == IA_LAYOUT_NCDHW || layout == IA_LAYOUT_NDHWC, "unknown voxel_J layout");
+    IA_REQUIRE((int64_t)B * D * H * W < ((int64_t)1 << 26), "voxel grid too large for 32-bit byte offsets");
+    const int grid = ia::cdiv(total, THREADS);
+    unsigned long long* c = reinterpret_cast<unsigned long long*>(counters);
+    if (layout == IA_LAYOUT_NDHWC)
+        broyden_stats_kernel<IA_LAYOUT_NDHWC><<<grid, THREADS, 0, (hipStream_t)stream>>>(
+            total, N, I, xd_tgt, voxel_J, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, c);
+    else
+        broyden_stats_kernel<IA_LAYOUT_NCDHW><<<grid, THREADS, 0, (hipStream_t)stream>>>(
+            total, N, I, xd_tgt, voxel_J, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, c);
+    return ia::check_launch("ia_broyden_stats");
 }
