@@ -403,6 +403,59 @@ int ia_adam_step(int n_tensors, float* const* params, const float* const* grads,
                  float* const* exp_avg_sq, const int64_t* numel, const float* step_size, const float* weight_decay,
                  float beta1, float beta2, float eps, float bias_correction2_sqrt, float grad_scale, ia_stream_t stream);
 
+/* ------------------------------------------------------------------------- */
+/* Host logic between K1 and the PBR estimator (models/pbr/utils.py:130-229 sample_volume_interaction;
+ * models/intrinsic_avatar.py:1356-1378 light shuffle, :1335-1342,:1420-1466 Lo scatter + accumulate, :788-803 secondary-ray
+ * mask; lib.torch_pbr emitter.sample).  K1's output is structured: a ray with samples owns spp consecutive re-samples, its
+ * foreground ones first (j < spp - bg_counts[ray]) in non-decreasing order of the sampled interval.  The foreground list
+ * [F] is ray-major; fg_start = exclusive scan of fg_ray_cnt; the re-samples of interval s are the range
+ * [fg_off[s], fg_off[s] + fg_counts[s]) of it (fg_off = exclusive scan of fg_counts). */
+int ia_vi_layout(int64_t n_rays, int spp, const int32_t* resampled_packed_info, const int32_t* bg_counts, int32_t* fg_ray_cnt,
+                 ia_stream_t stream);
+/* gathers of the per-interval attributes + positions o + d t, view dirs, re-sampled fg weights w[s] / fg_counts[s] */
+int ia_vi_gather(int64_t n_rays, const int32_t* resampled_packed_info, const int32_t* fg_ray_cnt, const int32_t* fg_start,
+                 const float* ts /*[R]*/, const int64_t* sampled_idx /*[R]*/, const int32_t* fg_counts /*[S]*/,
+                 const float* weights /*[S]*/, const float* rays_o, const float* rays_d, const float* normals /*[S,3]*/,
+                 const float* albedo /*[S,3]*/, const float* roughness /*[S]*/, const float* metallic /*[S]*/,
+                 int32_t* fg_src /*[F]*/, int32_t* fg_ray /*[F]*/, float* positions /*[F,3]*/, float* view_dirs /*[F,3]*/,
+                 float* o_normals, float* o_albedo, float* o_roughness, float* o_metallic, float* o_weights /*[F]*/,
+                 ia_stream_t stream);
+/* backward of the gathers: segmented sums over each interval's contiguous fg range (no atomics, deterministic) */
+int ia_vi_gather_bwd(int64_t S, const int32_t* fg_counts, const int32_t* fg_off, const float* g_normals_fg,
+                     const float* g_albedo_fg, const float* g_roughness_fg, const float* g_metallic_fg,
+                     const float* g_weights_fg, float* g_normals, float* g_albedo, float* g_roughness, float* g_metallic,
+                     float* g_weights, ia_stream_t stream);
+/* rgb[r] = sum_fg w Lo + [bg_counts > 0] transmittance[r] * background (rays without samples: background);
+ * background_rays [n,3] (optional) overrides the constant colour per ray (add_emitter) */
+int ia_vi_composite(int64_t n_rays, const int32_t* resampled_packed_info, const int32_t* fg_ray_cnt, const int32_t* fg_start,
+                    const int32_t* bg_counts, const float* weights_fg, const float* Lo /*[F,3]*/, const float* transmittance /*[n]*/,
+                    const float* background /*[3]*/, const float* background_rays, float* rgb /*[n,3]*/, ia_stream_t stream);
+int ia_vi_composite_bwd(int64_t n_rays, int64_t F, const int32_t* resampled_packed_info, const int32_t* bg_counts,
+                        const int32_t* fg_ray, const float* weights_fg, const float* Lo, const float* background,
+                        const float* g_rgb, float* g_weights_fg, float* g_Lo, float* g_transmittance, ia_stream_t stream);
+/* the reference's index lists: fg_indices [F], bg_indices [R-F], resampled_ray_indices [R], resampled_weights [R] (each optional) */
+int ia_vi_indices(int64_t n_rays, int spp, const int32_t* resampled_packed_info, const int32_t* fg_ray_cnt,
+                  const int32_t* fg_start, const int32_t* bg_counts, const int64_t* sampled_idx, const int32_t* fg_counts,
+                  const float* weights, const float* transmittance, int64_t* fg_indices, int64_t* bg_indices,
+                  int64_t* ray_indices, float* resampled_weights, ia_stream_t stream);
+/* per-ray permutation of [0, spp) = stable argsort of u[r, :] (explicit uniforms in [0,1)), first fg_ray_cnt[r] entries
+ * written at fg_start[r] (models/intrinsic_avatar.py:1356-1378) */
+int ia_light_shuffle(int64_t n_rays, int spp, const int32_t* fg_ray_cnt, const int32_t* fg_start, const float* u /*[n,spp]*/,
+                     int32_t* shuffled /*[F]*/, ia_stream_t stream);
+/* emitter.sample: k directions ~ luminance x sin(theta): inverse CDF of the flattened pmf (u[:,0]), jitter in the texel
+ * (u[:,1:3]); rot [9] (optional) = world -> SMPL rotation applied + normalised (transform_dirs_w2s) */
+int ia_envlight_sample(int64_t k, const float* u /*[k,3]*/, const double* cdf /*[H*W]*/, int env_h, int env_w, const float* rot,
+                       float* dirs /*[k,3]*/, ia_stream_t stream);
+/* secondary rays of the light estimators (:788-803): flag = n . d > 1e-6 (d = dirs[dir_index[k]] when dir_index is given),
+ * compaction into ray lists (slot = exclusive scan of flag), scatter of the traced results back (transmittance clamped) */
+int ia_secondary_mask(int64_t F, const float* normals, const float* dirs, const int32_t* dir_index, int32_t* flag,
+                      ia_stream_t stream);
+int ia_secondary_compact(int64_t F, const int32_t* flag, const int32_t* slot, const float* positions, const float* dirs,
+                         const int32_t* dir_index, float* rays_o, float* rays_d, int32_t* src, float* dense_dirs /*[F,3] or NULL*/,
+                         ia_stream_t stream);
+int ia_secondary_scatter(int64_t M, const int32_t* src, const float* transmittance, const float* rgb, float* dense_transmittance,
+                         float* dense_rgb, ia_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,7 @@
 There is deliberately no CPU / PyTorch fallback: if the HIP library is missing or a
 tensor is not on a GPU, the call fails loudly.
 """
+import collections
 import ctypes as C
 import os
 
@@ -92,10 +93,17 @@ def check(rc: int, what: str = ""):
         raise IaError(f"{what} failed (code {rc}): {msg}")
 
 
+# tensors whose pointers were handed out most recently: a temporary passed as `ptr(x.contiguous())` must stay alive until the
+# ctypes call that consumes the pointer has ENQUEUED its kernel -- otherwise the caching allocator may hand its block to the
+# next temporary of the same argument list (after the enqueue, stream order makes reuse safe).  64 > arguments per call.
+_KEEPALIVE = collections.deque(maxlen=64)
+
+
 def ptr(t):
     """device pointer of a contiguous CUDA(HIP) tensor, or NULL for None."""
     if t is None:
         return C.c_void_p(0)
+    _KEEPALIVE.append(t)
     if not t.is_cuda:
         raise IaError("intrinsicavatar_amd operators need GPU tensors (no CPU fallback)")
     if not t.is_contiguous():

@@ -28,6 +28,7 @@ SOURCES = {
     "mlp_train.hip": ["-munsafe-fp-atomics"],
     "deform.hip": ["-ffp-contract=off"],
     "pbr.hip": ["-munsafe-fp-atomics"],
+    "volint.hip": ["-ffp-contract=off"],
     "occgrid.hip": [],
     "optim.hip": ["-ffp-contract=off"],
 }

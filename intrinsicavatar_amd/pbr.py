@@ -37,17 +37,20 @@ class EnvironmentLightTensor:
         self._cdf = torch.cumsum(self.pmf.reshape(-1).double(), 0)
 
     @torch.no_grad()
-    def sample(self, k: int, u: Optional[Tensor] = None) -> Tensor:
-        """k world-space directions proportional to luminance x sin(theta); u [k,3] uniforms (explicit RNG)."""
+    def sample(self, k: int, u: Optional[Tensor] = None, w2s_rot: Optional[Tensor] = None) -> Tensor:
+        """k world-space directions proportional to luminance x sin(theta); u [k,3] uniforms (explicit RNG; drawn on the
+        device when None).  w2s_rot [3,3]: also apply transform_dirs_w2s (rotate into SMPL space + normalise) in the same
+        kernel (ia_envlight_sample)."""
         H, W, _ = self.base.shape
+        dev = self.base.device
         if u is None:
-            u = torch.rand((k, 3), device=self.base.device)
-        u = u.to(self.base.device).double()
-        idx = torch.searchsorted(self._cdf, u[:, 0] * self._cdf[-1], right=True).clamp(max=H * W - 1)
-        y, x = idx // W, idx % W
-        uu, vv = (x + u[:, 1]) / W, (y + u[:, 2]) / H
-        phi, th = (uu - 0.5) * 2 * math.pi, vv * math.pi
-        return torch.stack([torch.sin(th) * torch.sin(phi), torch.cos(th), -torch.sin(th) * torch.cos(phi)], -1).float()
+            u = torch.rand((k, 3), device=dev)
+        u = u.to(dev).float().contiguous()
+        out = torch.empty((k, 3), device=dev)
+        rot = None if w2s_rot is None else w2s_rot.detach().float().contiguous()
+        L.check(L.lib().ia_envlight_sample(L.i64(k), L.ptr(u), L.ptr(self._cdf), L.i32(H), L.i32(W), L.ptr(rot), L.ptr(out),
+                                           L.stream()), "ia_envlight_sample")
+        return out
 
     def _eval(self, d: Tensor, want_rgb: bool, want_pdf: bool):
         d = d.contiguous().float()
@@ -248,41 +251,205 @@ def pbr_light_shade(normal, albedo, roughness, metallic, view_dirs, light_dirs, 
     return Lo, Ld, Ls
 
 
+class VolumeInteraction:
+    """K1 (ray_resampling, cdf.cu:10-215) + the layout of its output (csrc/volint.hip): which re-samples are foreground,
+    where each ray's / each source interval's foreground re-samples sit in the ray-major foreground list [F].
+    Everything sample_volume_interaction (models/pbr/utils.py:70-229) derives with nonzero / gathers / scatters comes
+    out of scans and streaming kernels; the only host read-back is F."""
+
+    @torch.no_grad()
+    def __init__(self, ray_indices: Tensor, t_starts: Tensor, t_ends: Tensor, n_rays: int, spp: int, weights: Tensor, sdfs: Tensor):
+        dev = ray_indices.device
+        self.n_rays, self.spp = n_rays, spp
+        self.packed_info = lib_nerfacc.pack_info(ray_indices, n_rays)
+        (self.resampled_packed_info, self.ts, self.offsets, self.sampled_idx, self.fg_counts, self.bg_counts,
+         self.surface_idx) = lib_nerfacc.ray_resampling(self.packed_info, t_starts[:, None], t_ends[:, None], weights.detach(),
+                                                        sdfs.detach(), spp)
+        self.R = int(self.ts.shape[0])
+        self.S = int(weights.shape[0])
+        lib, st = L.lib(), L.stream()
+        self.fg_ray_cnt = torch.empty(n_rays, dtype=torch.int32, device=dev)
+        L.check(lib.ia_vi_layout(L.i64(n_rays), L.i32(spp), L.ptr(self.resampled_packed_info), L.ptr(self.bg_counts),
+                                 L.ptr(self.fg_ray_cnt), st), "ia_vi_layout")
+        self.fg_start = torch.empty(n_rays, dtype=torch.int32, device=dev)
+        total = torch.zeros(1, dtype=torch.int32, device=dev)
+        tmp = L.scan_tmp(max(n_rays, self.S), dev)
+        L.check(lib.ia_exclusive_scan_i32(L.ptr(self.fg_ray_cnt), L.ptr(self.fg_start), L.ptr(total), L.i64(n_rays), L.ptr(tmp), st),
+                "scan")
+        self.fg_off = torch.empty(self.S, dtype=torch.int32, device=dev)          # per source interval (gather backward)
+        tot2 = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.check(lib.ia_exclusive_scan_i32(L.ptr(self.fg_counts), L.ptr(self.fg_off), L.ptr(tot2), L.i64(self.S), L.ptr(tmp), st), "scan")
+        self.F = int(total.item())
+        self.fg_src = self.fg_ray = self.positions = self.view_dirs = None
+
+    def gather(self, rays_o, rays_d, weights, normals, albedo, roughness, metallic):
+        """-> (w_fg [F], normals [F,3], albedo [F,3], roughness [F,1], metallic [F,1]) differentiable w.r.t. the five
+        per-interval inputs; sets .positions / .view_dirs / .fg_src / .fg_ray (constants)."""
+        return _VIGather.apply(self, rays_o, rays_d, weights, normals, albedo, roughness, metallic)
+
+    def composite(self, w_fg, Lo, transmittance, background):
+        """rgb_phys [n,3] = sum_fg w Lo + transmittance x background (models/intrinsic_avatar.py:1335-1342,1420-1466)."""
+        return _VIComposite.apply(self, w_fg, Lo, transmittance, background)
+
+    @torch.no_grad()
+    def index_lists(self, weights: Tensor, transmittance: Tensor, want_weights: bool = True):
+        """the reference's (fg_indices [F], bg_indices [R-F], resampled_ray_indices [R], resampled_weights [R])."""
+        dev = self.ts.device
+        fg = torch.empty(self.F, dtype=torch.int64, device=dev)
+        bg = torch.empty(self.R - self.F, dtype=torch.int64, device=dev)
+        rri = torch.empty(self.R, dtype=torch.int64, device=dev)
+        rw = torch.zeros(self.R, device=dev) if want_weights else None
+        L.check(L.lib().ia_vi_indices(L.i64(self.n_rays), L.i32(self.spp), L.ptr(self.resampled_packed_info), L.ptr(self.fg_ray_cnt),
+                                      L.ptr(self.fg_start), L.ptr(self.bg_counts), L.ptr(self.sampled_idx), L.ptr(self.fg_counts),
+                                      L.ptr(weights.detach().float().contiguous()),
+                                      L.ptr(transmittance.detach().reshape(-1).float().contiguous()), L.ptr(fg), L.ptr(bg), L.ptr(rri),
+                                      L.ptr(rw), L.stream()), "ia_vi_indices")
+        return fg, bg, rri, rw
+
+    @torch.no_grad()
+    def shuffle(self, shuffle_u: Tensor) -> Tensor:
+        """models/intrinsic_avatar.py:1356-1378: per-ray permutation of [0, spp) (stable argsort of the explicit uniforms
+        shuffle_u [n_rays, spp]) restricted to the foreground re-samples -> int32 [F]."""
+        out = torch.empty(self.F, dtype=torch.int32, device=self.ts.device)
+        u = shuffle_u.float().contiguous()
+        assert u.shape == (self.n_rays, self.spp)
+        L.check(L.lib().ia_light_shuffle(L.i64(self.n_rays), L.i32(self.spp), L.ptr(self.fg_ray_cnt), L.ptr(self.fg_start), L.ptr(u),
+                                         L.ptr(out), L.stream()), "ia_light_shuffle")
+        return out
+
+
+class _VIGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vi, rays_o, rays_d, weights, normals, albedo, roughness, metallic):
+        dev = weights.device
+        F_ = vi.F
+        c = lambda t: t.detach().float().contiguous()      # noqa: E731
+        vi.fg_src = torch.empty(F_, dtype=torch.int32, device=dev)
+        vi.fg_ray = torch.empty(F_, dtype=torch.int32, device=dev)
+        vi.positions, vi.view_dirs = torch.empty((F_, 3), device=dev), torch.empty((F_, 3), device=dev)
+        o_n, o_a = torch.empty((F_, 3), device=dev), torch.empty((F_, 3), device=dev)
+        o_r, o_m, o_w = torch.empty((F_, 1), device=dev), torch.empty((F_, 1), device=dev), torch.empty(F_, device=dev)
+        L.check(L.lib().ia_vi_gather(
+            L.i64(vi.n_rays), L.ptr(vi.resampled_packed_info), L.ptr(vi.fg_ray_cnt), L.ptr(vi.fg_start), L.ptr(vi.ts),
+            L.ptr(vi.sampled_idx), L.ptr(vi.fg_counts), L.ptr(c(weights)), L.ptr(c(rays_o)), L.ptr(c(rays_d)), L.ptr(c(normals)),
+            L.ptr(c(albedo)), L.ptr(c(roughness.reshape(-1))), L.ptr(c(metallic.reshape(-1))), L.ptr(vi.fg_src), L.ptr(vi.fg_ray),
+            L.ptr(vi.positions), L.ptr(vi.view_dirs), L.ptr(o_n), L.ptr(o_a), L.ptr(o_r), L.ptr(o_m), L.ptr(o_w), L.stream()),
+            "ia_vi_gather")
+        ctx.vi = vi
+        ctx.shapes = (roughness.shape, metallic.shape)
+        return o_w, o_n, o_a, o_r, o_m
+
+    @staticmethod
+    def backward(ctx, g_w, g_n, g_a, g_r, g_m):
+        vi = ctx.vi
+        S, dev = vi.S, vi.ts.device
+        c = lambda t: None if t is None else t.float().contiguous()      # noqa: E731
+        G_n, G_a = torch.empty((S, 3), device=dev), torch.empty((S, 3), device=dev)
+        G_r, G_m, G_w = torch.empty(S, device=dev), torch.empty(S, device=dev), torch.empty(S, device=dev)
+        L.check(L.lib().ia_vi_gather_bwd(L.i64(S), L.ptr(vi.fg_counts), L.ptr(vi.fg_off), L.ptr(c(g_n)), L.ptr(c(g_a)),
+                                         L.ptr(c(g_r.reshape(-1)) if g_r is not None else None),
+                                         L.ptr(c(g_m.reshape(-1)) if g_m is not None else None), L.ptr(c(g_w)), L.ptr(G_n), L.ptr(G_a),
+                                         L.ptr(G_r), L.ptr(G_m), L.ptr(G_w), L.stream()), "ia_vi_gather_bwd")
+        return None, None, None, G_w, G_n, G_a, G_r.reshape(ctx.shapes[0]), G_m.reshape(ctx.shapes[1])
+
+
+class _VIComposite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vi, w_fg, Lo, transmittance, background):
+        dev = Lo.device
+        w_fg, Lo = w_fg.detach().float().contiguous(), Lo.detach().float().contiguous()
+        T = transmittance.detach().reshape(-1).float().contiguous()
+        bg = background.detach().float().contiguous()
+        rgb = torch.empty((vi.n_rays, 3), device=dev)
+        L.check(L.lib().ia_vi_composite(L.i64(vi.n_rays), L.ptr(vi.resampled_packed_info), L.ptr(vi.fg_ray_cnt), L.ptr(vi.fg_start),
+                                        L.ptr(vi.bg_counts), L.ptr(w_fg), L.ptr(Lo), L.ptr(T), L.ptr(bg), L.ptr(None), L.ptr(rgb),
+                                        L.stream()), "ia_vi_composite")
+        ctx.vi = vi
+        ctx.t_shape = transmittance.shape
+        ctx.save_for_backward(w_fg, Lo, bg)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, g_rgb):
+        vi = ctx.vi
+        w_fg, Lo, bg = ctx.saved_tensors
+        dev = Lo.device
+        g_rgb = g_rgb.float().contiguous()
+        g_w = torch.empty(vi.F, device=dev) if ctx.needs_input_grad[1] else None
+        g_Lo = torch.empty((vi.F, 3), device=dev) if ctx.needs_input_grad[2] else None
+        g_T = torch.empty(vi.n_rays, device=dev) if ctx.needs_input_grad[3] else None
+        L.check(L.lib().ia_vi_composite_bwd(L.i64(vi.n_rays), L.i64(vi.F), L.ptr(vi.resampled_packed_info), L.ptr(vi.bg_counts),
+                                            L.ptr(vi.fg_ray), L.ptr(w_fg), L.ptr(Lo), L.ptr(bg), L.ptr(g_rgb), L.ptr(g_w), L.ptr(g_Lo),
+                                            L.ptr(g_T), L.stream()), "ia_vi_composite_bwd")
+        return None, g_w, g_Lo, (g_T.reshape(ctx.t_shape) if g_T is not None else None), None
+
+
+@torch.no_grad()
+def secondary_rays(normals: Tensor, positions: Tensor, dirs: Tensor, dir_index: Optional[Tensor] = None):
+    """the secondary rays of the light estimators (models/intrinsic_avatar.py:788-803): cosine mask n . d > 1e-6, compacted
+    ray list.  dirs [F,3], or a direction table + dir_index int32 [F] (shuffled shared light directions).
+    returns (rays_o [M,3], rays_d [M,3], src int32 [M] -> index into the F points, out_dirs [F,3])."""
+    F_ = normals.shape[0]
+    dev = normals.device
+    lib, st = L.lib(), L.stream()
+    normals, positions, dirs = normals.detach().float().contiguous(), positions.float().contiguous(), dirs.float().contiguous()
+    flag = torch.empty(F_, dtype=torch.int32, device=dev)
+    L.check(lib.ia_secondary_mask(L.i64(F_), L.ptr(normals), L.ptr(dirs), L.ptr(dir_index), L.ptr(flag), st), "ia_secondary_mask")
+    slot = torch.empty(F_, dtype=torch.int32, device=dev)
+    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    tmp = L.scan_tmp(F_, dev)
+    L.check(lib.ia_exclusive_scan_i32(L.ptr(flag), L.ptr(slot), L.ptr(total), L.i64(F_), L.ptr(tmp), st), "scan")
+    M = int(total.item())
+    ro, rd = torch.empty((M, 3), device=dev), torch.empty((M, 3), device=dev)
+    src = torch.empty(M, dtype=torch.int32, device=dev)
+    dense = torch.empty((F_, 3), device=dev) if dir_index is not None else None
+    L.check(lib.ia_secondary_compact(L.i64(F_), L.ptr(flag), L.ptr(slot), L.ptr(positions), L.ptr(dirs), L.ptr(dir_index), L.ptr(ro),
+                                     L.ptr(rd), L.ptr(src), L.ptr(dense), st), "ia_secondary_compact")
+    return ro, rd, src, (dense if dir_index is not None else dirs)
+
+
+@torch.no_grad()
+def scatter_secondary(F_: int, src: Tensor, tr: Tensor, rgb: Tensor):
+    """traced (transmittance [M,1], rgb [M,3]) back into dense [F,1] / [F,3] (zeros for masked points), transmittance
+    clamped to [0, 1] (:796-803)."""
+    dev = src.device
+    d_tr, d_rgb = torch.zeros((F_, 1), device=dev), torch.zeros((F_, 3), device=dev)
+    L.check(L.lib().ia_secondary_scatter(L.i64(src.shape[0]), L.ptr(src), L.ptr(tr.reshape(-1).float().contiguous()),
+                                         L.ptr(rgb.float().contiguous()), L.ptr(d_tr), L.ptr(d_rgb), L.stream()), "ia_secondary_scatter")
+    return d_tr, d_rgb
+
+
 def sample_volume_interaction(rays_o, rays_d, ray_indices, t_starts, t_ends, n_rays: int, spp: int, transmittance_map,
                               extras: Dict[str, Tensor]):
-    """models/pbr/utils.py:70-229: spp stratified samples of the un-normalised weight CDF per ray (+ background bin),
-    zero-crossing clamp, per-interval counts, gathers of the per-sample attributes.  The re-sampling itself is not
-    differentiated (no_grad in the reference too); the gathers and the re-sampled weights are plain torch ops, so under
-    autograd the gradients flow back to weights / normals / albedo / roughness / metallic (training, train_phys.py)."""
+    """models/pbr/utils.py:70-229, same signature and return tuple: (resampled_packed_info, resampled_ray_indices,
+    resampled_weights, fg_indices, bg_indices, resampled_extras).  K1 + csrc/volint.hip kernels; differentiable w.r.t.
+    extras' weights / normals / albedo / roughness / metallic through the gather kernels (resampled_weights is returned
+    detached -- the training path composites with VolumeInteraction.composite instead of the dense [R] weights)."""
     weights, sdfs = extras["weights"], extras["sdf"]
-    packed_info = lib_nerfacc.pack_info(ray_indices, n_rays)
-    rpi, mid, offs, sampled_idx, fg_cnt, bg_cnt, surface_idx = lib_nerfacc.ray_resampling(
-        packed_info, t_starts[:, None], t_ends[:, None], weights, sdfs, spp)
-    fg_indices = torch.nonzero(offs[:, 0] < 1e4)[:, 0]
-    bg_indices = torch.nonzero(offs[:, 0] >= 1e4)[:, 0]
-    rri = lib_nerfacc.unpack_info(rpi, mid.shape[0])
-    fg_rri, bg_rri = rri[fg_indices], rri[bg_indices]
-    fg_sidx = sampled_idx[fg_indices]
+    vi = VolumeInteraction(ray_indices, t_starts, t_ends, n_rays, spp, weights, sdfs)
+    fg_idx, bg_idx, rri, rw = vi.index_lists(weights, transmittance_map)
     ex = {}
-    if fg_sidx.numel() > 0:
-        rw = torch.zeros_like(mid[:, 0])
-        rw[fg_indices] = weights[fg_sidx] / fg_cnt[fg_sidx].float()
-        rw[bg_indices] = transmittance_map[bg_rri][:, 0] / bg_cnt[bg_rri].float()
-        t = mid[fg_indices]
-        ex = dict(sdf=sdfs[fg_sidx], alphas=extras["alphas"][fg_sidx], dists=(t_ends - t_starts)[:, None][fg_sidx],
-                  positions=rays_o[fg_rri] + rays_d[fg_rri] * t, normals=extras["normals"][fg_sidx],
-                  albedo=extras["albedo"][fg_sidx], roughness=extras["roughness"][fg_sidx],
-                  metallic=extras["metallic"][fg_sidx], t_dirs=rays_d[fg_rri])
+    if vi.F > 0:
+        w_fg, nrm, alb, rough, metal = vi.gather(rays_o, rays_d, weights, extras["normals"], extras["albedo"], extras["roughness"],
+                                                 extras["metallic"])
+        src = vi.fg_src.long()
+        ex = dict(sdf=sdfs[src], alphas=extras["alphas"][src], dists=(t_ends - t_starts)[:, None][src], positions=vi.positions,
+                  normals=nrm, albedo=alb, roughness=rough, metallic=metal, t_dirs=vi.view_dirs)
     else:
         rw = torch.zeros((0,), device=rays_o.device)
-    return rpi, rri, rw, fg_indices, bg_indices, ex
+    return vi.resampled_packed_info, rri, rw, fg_idx, bg_idx, ex
 
 
 @torch.no_grad()
 def light_shuffle(n_rays: int, spp: int, resampled_packed_info: Tensor, fg_indices: Tensor, shuffle_u: Tensor) -> Tensor:
-    """intrinsic_avatar.py:1356-1378: independent permutation of [0, spp) per ray (argsort of uniforms, here an explicit
-    device tensor instead of the reference's CPU torch.rand), packed to the resampled points, restricted to fg points."""
-    col = torch.argsort(shuffle_u, dim=-1, stable=True)                     # [n_rays, spp]; ties by index (the reference leaves them unspecified)
-    has = resampled_packed_info[:, 1] > 0                                   # rays that own spp resampled points
-    packed = col[has].reshape(-1)                                           # every such ray owns exactly spp points, in order
-    return packed[fg_indices]
+    """intrinsic_avatar.py:1356-1378 with the reference's arguments: independent permutation of [0, spp) per ray (stable
+    argsort of explicit uniforms instead of the reference's CPU torch.rand), packed over the rays that own re-samples,
+    restricted to the re-samples listed in fg_indices.  The permutations come from ia_light_shuffle (LDS bitonic sort)."""
+    dev = shuffle_u.device
+    rpi = resampled_packed_info.to(torch.int32).contiguous()
+    cnt = torch.where(rpi[:, 1] > 0, torch.full_like(rpi[:, 1], spp), torch.zeros_like(rpi[:, 1])).contiguous()
+    start = (torch.cumsum(cnt, 0) - cnt).to(torch.int32).contiguous()
+    full = torch.empty(int(cnt.sum()), dtype=torch.int32, device=dev)
+    L.check(L.lib().ia_light_shuffle(L.i64(n_rays), L.i32(spp), L.ptr(cnt), L.ptr(start), L.ptr(shuffle_u.float().contiguous()),
+                                     L.ptr(full), L.stream()), "ia_light_shuffle")
+    return full[fg_indices].long()

@@ -254,8 +254,8 @@ class RenderStep:
     @torch.no_grad()
     def relight(self, rays: Tensor, material, emitter, spp: int, light_u: Tensor, shuffle_u: Tensor,
                 background_color: Optional[Tensor] = None, global_illumination: bool = False,
-                jitter: Optional[Tensor] = None, render_mode: str = "light", scatter_u: Optional[Tensor] = None
-                ) -> Dict[str, Tensor]:
+                jitter: Optional[Tensor] = None, render_mode: str = "light", scatter_u: Optional[Tensor] = None,
+                return_index_lists: bool = False) -> Dict[str, Tensor]:
         """forward_ with enable_phys and render_mode='light' (BASELINE configs 3 / 5):
         rendering_with_normals_mats_sdf (volrend.py:810-1020) -> sample_volume_interaction (pbr/utils.py:70-229)
         -> per-ray shuffled light directions (:1356-1378) -> secondary rays (:396-545) -> pbr_light_forward (:755-861)
@@ -286,67 +286,62 @@ class RenderStep:
         rgb_phys = background_color[None].expand(n_rays, 3).clone()
         stats.update(n_resampled=0, n_fg=0, n_secondary=0)
         if ray_indices.numel() > 0:
-            rpi, rri, rw, fg_idx, bg_idx, ex = pbr.sample_volume_interaction(
-                rays_o, rays_d, ray_indices, t_starts, t_ends, n_rays, spp, 1.0 - out["opacity"], extras)
-            stats["n_resampled"], stats["n_fg"] = int(rri.shape[0]), int(fg_idx.shape[0])
-            if fg_idx.numel() > 0:
-                F_ = fg_idx.shape[0]
+            # -- volume-interaction re-sampling (sample_volume_interaction, models/pbr/utils.py:70-229): K1 + layout scans
+            vi = pbr.VolumeInteraction(ray_indices, t_starts, t_ends, n_rays, spp, weights, d["sdf"])
+            stats["n_resampled"], stats["n_fg"] = vi.R, vi.F
+            transmittance = 1.0 - out["opacity"]
+            if vi.F > 0:
+                F_ = vi.F
+                w_fg, nrm, alb, rough, metal = vi.gather(rays_o, rays_d, weights, normal_smpl, mats[:, :3], mats[:, 3:4], mats[:, 4:5])
+                pos, view = vi.positions, vi.view_dirs
                 ind = lambda c: c if global_illumination else None      # noqa: E731
-                s2 = dfm.w2s[:3, :3].T
                 if render_mode in ("light", "uniform_light"):
                     if render_mode == "light":
-                        # light directions: sampled once per frame (prepare, :292-305), permuted per ray (:1356-1378)
-                        dirs_world = emitter.sample(spp, light_u)
-                        dirs_smpl = torch.nn.functional.normalize(dirs_world @ s2, dim=-1, eps=1e-6)      # transform_dirs_w2s
-                        inv_pdf = None
+                        # light directions: sampled once per frame (prepare, :292-305), rotated to SMPL space
+                        # (transform_dirs_w2s), permuted per ray (:1356-1378)
+                        dirs_smpl = emitter.sample(spp, light_u, w2s_rot=w2s_rot)
+                        inv_pdf_all = None
                     else:
                         # stratified uniform sphere (:680-689); directions are used as-is in SMPL space
                         assert spp == 512, "uniform_light asserts samples_per_pixel == 512 (:1392)"
                         dirs_smpl, inv_pdf_all = pbr.uniform_sphere_stratified(16, 32, light_u[:, :2])
-                    shuffled = pbr.light_shuffle(n_rays, spp, rpi, fg_idx, shuffle_u)
-                    out_dirs = dirs_smpl[shuffled].contiguous()
-                    inv_pdf = inv_pdf_all[shuffled] if render_mode == "uniform_light" else None
-                    cos_mask = (ex["normals"] * out_dirs).sum(-1) > 1e-6
-                    sec_tr = torch.zeros((F_, 1), device=dev)
-                    sec_rgb = torch.zeros((F_, 3), device=dev)
-                    stats["n_secondary"] = int(cos_mask.sum())
-                    if stats["n_secondary"] > 0:
-                        t_, c_ = self.compute_indirect_radiance(ex["positions"][cos_mask], out_dirs[cos_mask])
-                        sec_tr[cos_mask], sec_rgb[cos_mask] = t_.clamp(0.0, 1.0), c_
-                    res = pbr.pbr_shade(render_mode, ex["normals"], ex["albedo"], ex["roughness"], ex["metallic"], ex["t_dirs"],
-                                        out_dirs, sec_tr, ind(sec_rgb), emitter, w2s_rot, inv_pdf=inv_pdf)
+                    shuffled = vi.shuffle(shuffle_u)
+                    ro, rd, src, out_dirs = pbr.secondary_rays(nrm, pos, dirs_smpl, dir_index=shuffled)
+                    inv_pdf = inv_pdf_all[shuffled.long()] if render_mode == "uniform_light" else None
+                    stats["n_secondary"] = int(ro.shape[0])
+                    t_, c_ = self.compute_indirect_radiance(ro, rd)
+                    sec_tr, sec_rgb = pbr.scatter_secondary(F_, src, t_, c_)
+                    res = pbr.pbr_shade(render_mode, nrm, alb, rough, metal, view, out_dirs, sec_tr, ind(sec_rgb), emitter, w2s_rot,
+                                        inv_pdf=inv_pdf)
                     fg_Lo = res[0]
+                    out["shuffled"] = shuffled
                     if render_mode == "uniform_light":
-                        vis = torch.zeros((rri.shape[0], 3), device=dev)
-                        vis[fg_idx] = res[3]
-                        out["visibility"] = nerfacc.accumulate_along_rays(rw, vis, rri, n_rays).mean(-1, keepdim=True)
+                        zero3 = torch.zeros(3, device=dev)
+                        out["visibility"] = vi.composite(w_fg, res[3], torch.zeros_like(transmittance), zero3).mean(-1, keepdim=True)
                 elif render_mode in ("mats", "mis"):
                     # scatterer.sample (+ emitter.sample per point for mis), :547-652 / :863-948; explicit uniforms scatter_u
                     assert scatter_u is not None and scatter_u.shape[0] >= F_, "mats / mis need scatter_u [n_fg, 6]"
-                    sc_dirs = pbr.brdf_sample(ex["normals"], ex["t_dirs"], ex["roughness"], scatter_u[:F_, :3])
+                    sc_dirs = pbr.brdf_sample(nrm, view, rough, scatter_u[:F_, :3])
                     if render_mode == "mis":
-                        li_dirs = torch.nn.functional.normalize(emitter.sample(F_, scatter_u[:F_, 3:6]) @ s2, dim=-1, eps=1e-6)
+                        li_dirs = emitter.sample(F_, scatter_u[:F_, 3:6].contiguous(), w2s_rot=w2s_rot)
                         out_dirs = torch.cat([sc_dirs, li_dirs], 0)
                         rep = lambda t: t.repeat(2, 1)      # noqa: E731
                     else:
                         out_dirs, rep = sc_dirs, (lambda t: t)
                     stats["n_secondary"] = int(out_dirs.shape[0])
-                    sec_tr, sec_rgb = self.compute_indirect_radiance(rep(ex["positions"]).contiguous(), out_dirs.contiguous())
-                    Lo2, _, _ = pbr.pbr_shade(render_mode, rep(ex["normals"]), rep(ex["albedo"]), rep(ex["roughness"]),
-                                              rep(ex["metallic"]), rep(ex["t_dirs"]), out_dirs, sec_tr, ind(sec_rgb), emitter,
-                                              w2s_rot)
+                    sec_tr, sec_rgb = self.compute_indirect_radiance(rep(pos).contiguous(), out_dirs.contiguous())
+                    Lo2, _, _ = pbr.pbr_shade(render_mode, rep(nrm), rep(alb), rep(rough), rep(metal), rep(view), out_dirs, sec_tr,
+                                              ind(sec_rgb), emitter, w2s_rot)
                     fg_Lo = Lo2.reshape(2, F_, 3).sum(0) if render_mode == "mis" else Lo2
                 else:
                     raise NotImplementedError(f"Render mode {render_mode} not supported.")
-                Lo = torch.zeros((rri.shape[0], 3), device=dev)
-                Lo[bg_idx] = background_color[None]          # Lo.scatter_(0, bg_indices, background_color), :1335-1342
-                Lo[fg_idx] = fg_Lo
-                rgb_phys = nerfacc.accumulate_along_rays(rw, Lo, rri, n_rays)
-                out["secondary_tr"], out["fg_Lo"], out["fg_extras"] = sec_tr, fg_Lo, ex
-                if render_mode in ("light", "uniform_light"):
-                    out["shuffled"] = shuffled
-            out.update(resampled_packed_info=rpi, resampled_ray_indices=rri, resampled_weights=rw, fg_indices=fg_idx,
-                       bg_indices=bg_idx)
-            rgb_phys[rpi[:, 1] <= 0] = background_color[None]
+                # Lo.scatter_(bg_indices, background) + accumulate_along_rays(resampled_weights, Lo) (:1335-1342,:1420-1466)
+                rgb_phys = vi.composite(w_fg, fg_Lo, transmittance, background_color)
+                out["secondary_tr"], out["fg_Lo"] = sec_tr, fg_Lo
+                out["fg_extras"] = dict(positions=pos, normals=nrm, albedo=alb, roughness=rough, metallic=metal, t_dirs=view)
+            out["resampled_packed_info"] = vi.resampled_packed_info
+            if return_index_lists:
+                fg_idx, bg_idx, rri, rw = vi.index_lists(weights, transmittance)
+                out.update(resampled_ray_indices=rri, resampled_weights=rw, fg_indices=fg_idx, bg_indices=bg_idx)
         out.update(comp_rgb_phys=rgb_phys, stats=stats)
         return out

@@ -151,47 +151,37 @@ def shade_differentiable_phys(rs, material, emitter, rays_o: Tensor, rays_d: Ten
     rgb_phys = background_color[None].expand(n_rays, 3)
     stats = dict(n_resampled=0, n_fg=0, n_secondary=0)
     if ray_indices.numel() > 0:
-        extras = dict(weights=weights, sdf=sdf.detach(), alphas=alphas, normals=normal_smpl, albedo=albedo, roughness=rough,
-                      metallic=metal)
-        rpi, rri, rw, fg_idx, bg_idx, ex = pbr.sample_volume_interaction(
-            rays_o, rays_d, ray_indices, t_starts, t_ends, n_rays, spp, (1.0 - res["opacity"]), extras)
-        stats["n_resampled"], stats["n_fg"] = int(rri.shape[0]), int(fg_idx.shape[0])
-        if fg_idx.numel() > 0:
-            F_ = fg_idx.shape[0]
+        vi = pbr.VolumeInteraction(ray_indices, t_starts, t_ends, n_rays, spp, weights, sdf)
+        stats["n_resampled"], stats["n_fg"] = vi.R, vi.F
+        if vi.F > 0:
+            F_ = vi.F
+            # differentiable gathers of the per-interval attributes + re-sampled weights w[s] / count[s] (ia_vi_gather / _bwd)
+            w_fg, nrm, alb, rgh, mtl = vi.gather(rays_o, rays_d, weights, normal_smpl, albedo, rough, metal)
             with torch.no_grad():
-                s2 = dfm.w2s[:3, :3].T
                 inv_pdf = None
                 if render_mode == "light" and light_sampling == "per_point":
-                    u = light_u[:F_] if light_u is not None else None
-                    out_dirs = torch.nn.functional.normalize(emitter.sample(F_, u) @ s2, dim=-1, eps=1e-6).contiguous()
+                    u = light_u[:F_].contiguous() if light_u is not None else None
+                    dirs = emitter.sample(F_, u, w2s_rot=w2s_rot)                      # emitter.sample + transform_dirs_w2s
+                    ro, rd, src, out_dirs = pbr.secondary_rays(nrm, vi.positions, dirs)
                 else:
                     if render_mode == "light":
-                        dirs_smpl = torch.nn.functional.normalize(emitter.sample(spp, light_u) @ s2, dim=-1, eps=1e-6)
+                        dirs_smpl = emitter.sample(spp, light_u, w2s_rot=w2s_rot)
                         inv_pdf_all = None
                     else:
                         assert spp == 512, "uniform_light asserts samples_per_pixel == 512 (:1392)"
                         dirs_smpl, inv_pdf_all = pbr.uniform_sphere_stratified(16, 32, light_u[:, :2])
-                    shuffled = pbr.light_shuffle(n_rays, spp, rpi, fg_idx, shuffle_u)
-                    out_dirs = dirs_smpl[shuffled].contiguous()
-                    inv_pdf = inv_pdf_all[shuffled] if inv_pdf_all is not None else None
-                nrm = ex["normals"].detach()
-                cos_mask = (nrm * out_dirs).sum(-1) > 1e-6
-                sec_tr = torch.zeros((F_, 1), device=dev)
-                sec_rgb = torch.zeros((F_, 3), device=dev)
-                stats["n_secondary"] = int(cos_mask.sum())
-                if stats["n_secondary"] > 0:
-                    t_, c_ = rs.compute_indirect_radiance(ex["positions"].detach()[cos_mask], out_dirs[cos_mask])
-                    sec_tr[cos_mask], sec_rgb[cos_mask] = t_.clamp(0.0, 1.0), c_
+                    shuffled = vi.shuffle(shuffle_u)
+                    ro, rd, src, out_dirs = pbr.secondary_rays(nrm, vi.positions, dirs_smpl, dir_index=shuffled)
+                    inv_pdf = inv_pdf_all[shuffled.long()] if inv_pdf_all is not None else None
+                stats["n_secondary"] = int(ro.shape[0])
+                t_, c_ = rs.compute_indirect_radiance(ro, rd)
+                sec_tr, sec_rgb = pbr.scatter_secondary(F_, src, t_, c_)
             fg_Lo, fg_Ld, fg_Ls = pbr.pbr_shade_differentiable(
-                render_mode, ex["normals"], ex["albedo"], ex["roughness"], ex["metallic"], ex["t_dirs"], out_dirs, sec_tr,
-                sec_rgb if global_illumination else None, emitter, w2s_rot, inv_pdf=inv_pdf, env_base=env_base)
+                render_mode, nrm, alb, rgh, mtl, vi.view_dirs, out_dirs, sec_tr, sec_rgb if global_illumination else None, emitter,
+                w2s_rot, inv_pdf=inv_pdf, env_base=env_base)
             # background re-samples carry the background colour (Lo.scatter_(0, bg_indices, background_color), :1335-1342),
-            # their weights sum to the ray's transmittance
-            Lo = torch.zeros((rri.shape[0], 3), device=dev).index_put((bg_idx,), background_color[None].expand(bg_idx.shape[0], 3))
-            Lo = Lo.index_put((fg_idx,), fg_Lo)
-            rgb_phys = nerfacc.accumulate_along_rays(rw, Lo, rri, n_rays)
-            no_samples = (rpi[:, 1] <= 0)[:, None]
-            rgb_phys = torch.where(no_samples, background_color[None].expand(n_rays, 3), rgb_phys)
+            # their weights sum to the ray's transmittance; rays without samples show the background (:1452-1466)
+            rgb_phys = vi.composite(w_fg, fg_Lo, 1.0 - res["opacity"], background_color)
             res.update(fg_Lo=fg_Lo, secondary_tr=sec_tr)
     res.update(comp_rgb_phys=rgb_phys, stats=stats)
     return res

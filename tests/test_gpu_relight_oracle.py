@@ -60,13 +60,17 @@ def test_relight_light_mode_vs_oracle(setup, hw, spp, gi):
     shuffle_u = rng.random((n, spp), dtype=np.float32)
     bg = np.array([0.2, 0.4, 0.6], np.float32)
     ref = R.relight_step(sc, N(rays), spp=spp, light_u=light_u, shuffle_u=shuffle_u, global_illumination=gi, background_color=bg)
-    out = rs.relight(rays, mat, env, spp, T(light_u), T(shuffle_u), background_color=T(bg), global_illumination=gi)
+    out = rs.relight(rays, mat, env, spp, T(light_u), T(shuffle_u), background_color=T(bg), global_illumination=gi,
+                     return_index_lists=True)
     st, rst = out["stats"], ref["stats"]
     assert st["n_samples"] == rst["n_samples"] and rst["n_fg"] > 500
-    # ---- step 5: materials composite (rendering_with_normals_mats_sdf); 2e-3 abs like the radiance-only parity test
-    for k in ("comp_rgb", "comp_normal", "albedo", "roughness", "metallic", "opacity"):
-        err = np.abs(N(out[k]) - ref[k])
-        assert (err.max(-1) <= 2e-3).mean() >= 0.995 and err.mean() < 2e-4, (k, err.max(), err.mean())
+    # ---- step 5: materials composite (rendering_with_normals_mats_sdf); the bars of the radiance-only parity test
+    # (tests/test_gpu_render.py): 2e-3 abs (normals 4e-3) on >= 98.5 % of the pixels, mean < 2e-4
+    for k, tol in (("comp_rgb", 2e-3), ("comp_normal", 4e-3), ("albedo", 2e-3), ("roughness", 2e-3), ("metallic", 2e-3),
+                   ("opacity", 2e-3)):
+        err = np.abs(N(out[k]) - ref[k]).max(-1)
+        assert (err < tol).mean() >= 0.985 and err.max() < 0.15 and err.mean() < (5e-4 if k == "comp_normal" else 2e-4), \
+            (k, err.max(), err.mean())
     # ---- step 6: volume-interaction re-sampling.  K1 is bit-exact given identical weights / sdfs; the weights here come from
     # fp32 field kernels (tolerance), so a CDF threshold can fall on the other side for a few re-samples: layout (packed
     # info = which rays own spp re-samples) exact, sampled interval index equal for >= 99.5 % of the re-samples
@@ -77,10 +81,13 @@ def test_relight_light_mode_vs_oracle(setup, hw, spp, gi):
     assert (fg_ref == fg_gpu).mean() >= 0.998
     assert abs(st["n_fg"] - rst["n_fg"]) <= 0.002 * rst["n_fg"] + 2
     np.testing.assert_allclose(N(out["resampled_weights"]).sum(), ref["resampled_weights"].sum(), rtol=1e-3)
-    # re-sampled weights of a ray sum to 1 (fg weights sum to the opacity, bg weights to the transmittance)
+    # re-sampled weights of a ray sum to AT MOST 1: bg weights sum to the transmittance, fg weights to the opacity minus
+    # the weight of the intervals that received no re-sample (the reference drops those, models/pbr/utils.py:137-152)
     rw_sum = np.zeros(n); np.add.at(rw_sum, N(out["resampled_ray_indices"]), N(out["resampled_weights"]))
     has = ref["resampled_packed_info"][:, 1] > 0
-    np.testing.assert_allclose(rw_sum[has], 1.0, atol=2e-4)
+    rw_ref = np.zeros(n); np.add.at(rw_ref, ref["k1"]["midpoints"][:, 0].shape[0] and np.repeat(np.nonzero(has)[0], spp), ref["resampled_weights"])
+    assert rw_sum[has].max() <= 1.0 + 2e-4
+    np.testing.assert_allclose(rw_sum, rw_ref, atol=2e-3)
     # ---- step 7: secondary rays.  Same re-sample <-> light-direction pairing (shuffle), visibility agreement per sample
     same = fg_ref & fg_gpu
     pos_g = np.cumsum(fg_gpu) - 1
@@ -128,3 +135,86 @@ def test_light_shuffle_is_a_per_ray_permutation_matching_the_oracle(setup):
     if cnt[9] > 0:
         row = int((cnt[:9] > 0).sum())
         assert np.array_equal(full[row], np.arange(spp))
+
+
+def _sample_volume_interaction_torch(rays_o, rays_d, ray_indices, t_starts, t_ends, n_rays, spp, transmittance_map, extras):
+    """the reference's op sequence (models/pbr/utils.py:113-229: nonzero x 2, unpack_info, scatter_ x 2, nine gathers) in
+    plain torch on top of the same K1 output -- what the volint.hip kernels replace."""
+    from intrinsicavatar_amd import lib_nerfacc
+    weights, sdfs = extras["weights"], extras["sdf"]
+    packed_info = lib_nerfacc.pack_info(ray_indices, n_rays)
+    rpi, mid, offs, sampled_idx, fg_cnt, bg_cnt, _ = lib_nerfacc.ray_resampling(packed_info, t_starts[:, None], t_ends[:, None],
+                                                                                weights, sdfs, spp)
+    fg_indices = torch.nonzero(offs[:, 0] < 1e4)[:, 0]
+    bg_indices = torch.nonzero(offs[:, 0] >= 1e4)[:, 0]
+    rri = lib_nerfacc.unpack_info(rpi, mid.shape[0])
+    fg_rri, bg_rri = rri[fg_indices], rri[bg_indices]
+    fg_sidx = sampled_idx[fg_indices]
+    rw = torch.zeros_like(mid[:, 0])
+    rw = rw.scatter(0, fg_indices, weights[fg_sidx] / fg_cnt[fg_sidx].float())
+    rw = rw.scatter(0, bg_indices, transmittance_map[bg_rri][:, 0] / bg_cnt[bg_rri].float())
+    ex = dict(positions=rays_o[fg_rri] + rays_d[fg_rri] * mid[fg_indices], normals=extras["normals"][fg_sidx],
+              albedo=extras["albedo"][fg_sidx], roughness=extras["roughness"][fg_sidx], metallic=extras["metallic"][fg_sidx],
+              t_dirs=rays_d[fg_rri], sdf=sdfs[fg_sidx], alphas=extras["alphas"][fg_sidx],
+              dists=(t_ends - t_starts)[:, None][fg_sidx])
+    return rpi, rri, rw, fg_indices, bg_indices, ex
+
+
+@pytest.mark.parametrize("spp", [8, 64, 1024])
+def test_volume_interaction_kernels_vs_reference_op_sequence(setup, spp):
+    """sample_volume_interaction through the volint.hip kernels == the reference's torch op sequence on the same K1 output:
+    index lists and gathered values bit-exact, gradients (segmented sums vs index_add atomics) to 1e-5; the fused composite ==
+    Lo.scatter_ + accumulate_along_rays."""
+    from intrinsicavatar_amd import pbr, nerfacc, lib_nerfacc
+    g = torch.Generator().manual_seed(spp)
+    n_rays = 700
+    cnt = torch.randint(0, 24, (n_rays,), generator=g)
+    cnt[torch.rand(n_rays, generator=g) < 0.3] = 0
+    S_ = int(cnt.sum())
+    ray_indices = torch.repeat_interleave(torch.arange(n_rays), cnt).to(DEV)
+    t0 = torch.rand(S_, generator=g).to(DEV)
+    t_starts, t_ends = t0, t0 + 0.01 + 0.05 * torch.rand(S_, generator=g).to(DEV)
+    alphas = (torch.rand(S_, generator=g) ** 3).to(DEV)
+    packed = lib_nerfacc.pack_info(ray_indices, n_rays)
+    w, _ = nerfacc.render_weight_from_alpha(alphas, packed_info=packed)
+    opacity = nerfacc.accumulate_along_rays(w, None, ray_indices, n_rays)
+    rays_o, rays_d = torch.randn((n_rays, 3), generator=g).to(DEV), torch.randn((n_rays, 3), generator=g).to(DEV)
+
+    def leafs():
+        gg = torch.Generator().manual_seed(7)
+        mk = lambda *sh: torch.rand(sh, generator=gg).to(DEV).requires_grad_(True)      # noqa: E731
+        mats = mk(S_, 5)            # the model hands over column views of one [S,5] material tensor (non-contiguous)
+        return dict(weights=w.clone().requires_grad_(True), sdf=(torch.rand(S_, generator=gg) - 0.3).to(DEV), alphas=alphas,
+                    normals=mk(S_, 3), mats=mats, albedo=mats[:, :3], roughness=mats[:, 3:4], metallic=mats[:, 4:5])
+    ex_a, ex_b = leafs(), leafs()
+    T_a = (1.0 - opacity).clone().requires_grad_(True)
+    T_b = (1.0 - opacity).clone().requires_grad_(True)
+    a = pbr.sample_volume_interaction(rays_o, rays_d, ray_indices, t_starts, t_ends, n_rays, spp, T_a, ex_a)
+    b = _sample_volume_interaction_torch(rays_o, rays_d, ray_indices, t_starts, t_ends, n_rays, spp, T_b, ex_b)
+    for x, y, what in zip(a[:5], b[:5], ("rpi", "rri", "rw", "fg_indices", "bg_indices")):
+        assert torch.equal(x, y.to(x.dtype)), what
+    for k in ("positions", "normals", "albedo", "roughness", "metallic", "t_dirs", "sdf", "alphas", "dists"):
+        assert torch.equal(a[5][k], b[5][k]), k
+    F_ = a[3].shape[0]
+    assert F_ > 0
+    gg = torch.Generator().manual_seed(11)
+    Lo_coef = torch.rand((F_, 3), generator=gg).to(DEV)
+    bg = torch.tensor([0.3, 0.6, 0.9], device=DEV)
+    g_img = torch.randn((n_rays, 3), generator=gg).to(DEV)
+    # (a) kernels: differentiable gathers + fused composite
+    vi = pbr.VolumeInteraction(ray_indices, t_starts, t_ends, n_rays, spp, ex_a["weights"], ex_a["sdf"])
+    w_fg, nrm, alb, rgh, mtl = vi.gather(rays_o, rays_d, ex_a["weights"], ex_a["normals"], ex_a["albedo"], ex_a["roughness"], ex_a["metallic"])
+    Lo_a = Lo_coef * (nrm * alb).sum(-1, keepdim=True) * (rgh + mtl)
+    img_a = vi.composite(w_fg, Lo_a, T_a, bg)
+    (img_a * g_img).sum().backward()
+    # (b) the reference's sequence: dense Lo with background at the bg re-samples, accumulate over all R re-samples
+    rpi, rri, rw, fg_idx, bg_idx, ex = b
+    Lo_b = Lo_coef * (ex["normals"] * ex["albedo"]).sum(-1, keepdim=True) * (ex["roughness"] + ex["metallic"])
+    Lo = torch.zeros((rri.shape[0], 3), device=DEV).index_put((bg_idx,), bg[None].expand(bg_idx.shape[0], 3)).index_put((fg_idx,), Lo_b)
+    img_b = nerfacc.accumulate_along_rays(rw, Lo, rri, n_rays)
+    img_b = torch.where((rpi[:, 1] <= 0)[:, None], bg[None].expand(n_rays, 3), img_b)
+    (img_b * g_img).sum().backward()
+    torch.testing.assert_close(img_a, img_b, rtol=2e-5, atol=2e-6)
+    for k in ("weights", "normals", "mats"):
+        torch.testing.assert_close(ex_a[k].grad, ex_b[k].grad, rtol=2e-4, atol=2e-6, msg=k)
+    torch.testing.assert_close(T_a.grad, T_b.grad, rtol=2e-5, atol=1e-7)
