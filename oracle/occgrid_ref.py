@@ -5,6 +5,17 @@ import numpy as np
 from scipy.ndimage import maximum_filter
 
 
+def connected_component_labels(binaries):
+    """max_connected_component (models/utils.py:152-163): every occupied cell ends up with the largest 1-based linear index
+    of its 26-connected component, after exactly res[-1] * 3 sweeps."""
+    res = binaries.shape
+    comp = np.arange(1, binaries.size + 1, dtype=np.int64).reshape(res)
+    comp[~binaries] = 0
+    for _ in range(res[-1] * 3):
+        comp = maximum_filter(comp, size=3, mode="constant", cval=0) * binaries
+    return comp
+
+
 def binarize(occs, res, thre_max, keep_largest_component=True):
     occs = occs.reshape(res).astype(np.float32)
     pooled = maximum_filter(occs, size=3, mode="constant", cval=-np.inf)
@@ -12,10 +23,7 @@ def binarize(occs, res, thre_max, keep_largest_component=True):
     thre = np.float32(min(mean, np.float32(thre_max))) if not np.isnan(mean) else mean
     binaries = pooled > thre
     if keep_largest_component:
-        comp = np.arange(1, occs.size + 1, dtype=np.int64).reshape(res)
-        comp[~binaries] = 0
-        for _ in range(res[-1] * 3):
-            comp = maximum_filter(comp, size=3, mode="constant", cval=0) * binaries
+        comp = connected_component_labels(binaries)
         labels = comp[binaries]
         if labels.size:
             vals, counts = np.unique(labels, return_counts=True)

@@ -88,11 +88,15 @@ def _normalize(v, eps=1e-6):
     return v / np.maximum(n, eps)
 
 
+def reflect(x, n):
+    """models/utils.py:115-116."""
+    return 2 * (x * n).sum(-1, keepdims=True) * n - x
+
+
 def radiance(sc, pts_cano, feat, view_world, normal_world):
     xp = ((pts_cano - sc.rad_center) / sc.rad_scale + 0.5).astype(np.float32)
     enc = O.hashgrid_fwd(xp, sc.rad_params) * sc.rad_mask[None]
-    x = -view_world
-    dirs = 2 * (x * normal_world).sum(-1, keepdims=True) * normal_world - x       # reflect, models/utils.py:115
+    dirs = reflect(-view_world, normal_world)
     sh = O.sh4(((dirs + 1) / 2).astype(np.float32)) * sc.rad_sh_mask[None]
     inp = np.concatenate([xp * 2 - 1, enc, feat, sh, normal_world], -1).astype(np.float32)
     return O.mlp_fwd(inp, sc.rad_W, sc.rad_b, "relu", "sigmoid")

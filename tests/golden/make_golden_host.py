@@ -1,0 +1,330 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE's own host-side Python (L2) in the build container.
+
+  python tests/golden/make_golden_host.py          (needs /root/reference; CPU only; ~1 min)
+
+What runs is the reference's unmodified code, imported from /root/reference by file path (never copied):
+    models/volrend.py                     rendering, rendering_with_normals_sdf, rendering_with_normals_mats_sdf
+    models/pbr/utils.py                   sample_volume_interaction
+    models/occ_grid/temporal_occ_grid.py  TemporalOccGridEstimator.sampling / _update
+    models/utils.py                       max_connected_component, reflect, GaussianHistogram, chunk_batch
+    models/rf/density.py                  LearnedLaplaceDensity.density_func (the formula; its setup() calls .cuda())
+    lib/nerfacc/{__init__,cdf,pack}.py    the Python wrappers of K1..K7
+underneath them, for what has no CPU implementation in the reference tree:
+    lib.nerfacc.cuda._backend._C  <- the reference's own cdf.cu / pack.cu kernel bodies compiled for the host by
+                                     tests/golden/make_golden.py (serial launch shim);
+    pip `nerfacc` 0.5.3 (absent)  <- the CPU oracle (oracle/oracle.py) exposed on CPU tensors under the nerfacc names
+                                     (tests-side shim below; never part of the package).
+Every random tensor is explicit (torch.rand_like is patched while the occupancy grid updates).
+
+Only DATA is written: inputs and outputs as arrays in tests/golden/golden_host.npz.  GPU tests hold
+intrinsicavatar_amd/{volrend,pbr,occ_grid}.py to them; CPU tests hold oracle/{render_ref,occgrid_ref}.py to them.
+"""
+import importlib.util
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+REF = "/root/reference"
+
+
+# ----------------------------------------------------------------------------- pip-nerfacc names on CPU tensors (oracle)
+def make_nerfacc_cpu_shim():
+    from dataclasses import dataclass
+    from typing import Optional
+    from oracle import oracle as O
+    O.build()
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))      # noqa: E731
+    N = lambda t: t.detach().cpu().numpy()                         # noqa: E731
+
+    @dataclass
+    class RayIntervals:
+        vals: torch.Tensor
+        packed_info: Optional[torch.Tensor] = None
+        ray_indices: Optional[torch.Tensor] = None
+        is_left: Optional[torch.Tensor] = None
+        is_right: Optional[torch.Tensor] = None
+
+    @dataclass
+    class RaySamples:
+        vals: torch.Tensor
+        packed_info: Optional[torch.Tensor] = None
+        ray_indices: Optional[torch.Tensor] = None
+        is_valid: Optional[torch.Tensor] = None
+
+    def _pinfo(packed_info, ray_indices, n_rays, n):
+        if packed_info is not None:
+            return N(packed_info).astype(np.int32)
+        return O.pack_info(N(ray_indices).astype(np.int64), int(n_rays))
+
+    def render_weight_from_alpha(alphas, packed_info=None, ray_indices=None, n_rays=None, prefix_trans=None):
+        pi = _pinfo(packed_info, ray_indices, n_rays, alphas.shape[0])
+        w, tr = O.render_weight_from_alpha(N(alphas).astype(np.float32), pi)
+        return T(w), T(tr)
+
+    def render_weight_from_density(t_starts, t_ends, sigmas, packed_info=None, ray_indices=None, n_rays=None, prefix_trans=None):
+        alphas = 1.0 - torch.exp(-sigmas * (t_ends - t_starts))
+        w, tr = render_weight_from_alpha(alphas, packed_info, ray_indices, n_rays)
+        return w, tr, alphas
+
+    def accumulate_along_rays(weights, values=None, ray_indices=None, n_rays=None):
+        v = None if values is None else N(values).astype(np.float32)
+        return T(O.accumulate_along_rays(N(weights).astype(np.float32), v, N(ray_indices).astype(np.int64), int(n_rays)))
+
+    def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes=None, far_planes=None, step_size=1e-3, cone_angle=0.0):
+        n = rays_o.shape[0]
+        near = np.zeros(n, np.float32) if near_planes is None else N(near_planes).astype(np.float32)
+        far = np.full(n, 1e10, np.float32) if far_planes is None else N(far_planes).astype(np.float32)
+        r = O.traverse_grids(N(rays_o).astype(np.float32), N(rays_d).astype(np.float32), N(binaries[0]), N(aabbs[0]).astype(np.float32),
+                             near, far, float(step_size), float(cone_angle))
+        iv, sm = r["intervals"], r["samples"]
+        return (RayIntervals(vals=T(iv["vals"]), packed_info=T(iv["packed_info"]), ray_indices=T(iv["ray_indices"]),
+                             is_left=T(iv["is_left"]), is_right=T(iv["is_right"])),
+                RaySamples(vals=T(sm["vals"]), packed_info=T(sm["packed_info"]), ray_indices=T(sm["ray_indices"])), None)
+
+    def _unused(*a, **k):
+        raise NotImplementedError("not reached on the render_step path")
+
+    m = types.ModuleType("nerfacc")
+    m.__version__ = "0.5.3"
+    for k, v in dict(RayIntervals=RayIntervals, RaySamples=RaySamples, render_weight_from_alpha=render_weight_from_alpha,
+                     render_weight_from_density=render_weight_from_density, accumulate_along_rays=accumulate_along_rays,
+                     traverse_grids=traverse_grids, render_visibility_from_alpha=_unused, render_visibility_from_density=_unused,
+                     OccGridEstimator=object).items():
+        setattr(m, k, v)
+    vr = types.ModuleType("nerfacc.volrend")
+    vr.render_weight_from_alpha, vr.render_weight_from_density, vr.accumulate_along_rays = (
+        render_weight_from_alpha, render_weight_from_density, accumulate_along_rays)
+    m.volrend = vr
+    sys.modules["nerfacc"], sys.modules["nerfacc.volrend"] = m, vr
+    return m
+
+
+def load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def pkg(name, path):
+    m = types.ModuleType(name)
+    m.__path__ = [path]
+    sys.modules[name] = m
+    return m
+
+
+def import_reference_host_code():
+    """-> dict of the reference's own modules, importable on CPU once the boundary names resolve."""
+    import make_golden as MG
+    make_nerfacc_cpu_shim()
+    ref_C, _ = MG.build_reference_host_modules()          # the reference's cdf.cu / pack.cu bodies, host-compiled
+    for name in ("tinycudann", "cv2", "pytorch_lightning", "pytorch_lightning.utilities", "pytorch_lightning.utilities.rank_zero",
+                 "omegaconf", "systems", "systems.utils", "utils", "utils.misc"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["pytorch_lightning.utilities.rank_zero"].rank_zero_debug = lambda *a, **k: None
+    sys.modules["pytorch_lightning.utilities.rank_zero"].rank_zero_info = lambda *a, **k: None
+    sys.modules["systems.utils"].update_module_step = lambda *a, **k: None
+    sys.modules["utils.misc"].config_to_primitive = lambda c: c
+    sys.modules["utils.misc"].get_rank = lambda: 0
+    sys.modules["omegaconf"].OmegaConf = object
+    # lib.nerfacc: the reference's Python wrappers over its own (host-compiled) kernels
+    pkg("lib", f"{REF}/lib")
+    pkg("lib.nerfacc", f"{REF}/lib/nerfacc")
+    back = types.ModuleType("lib.nerfacc.cuda._backend")
+    back._C = ref_C
+    sys.modules["lib.nerfacc.cuda._backend"] = back
+    load("lib.nerfacc.cuda", f"{REF}/lib/nerfacc/cuda/__init__.py")
+    load("lib.nerfacc.cdf", f"{REF}/lib/nerfacc/cdf.py")
+    pack = load("lib.nerfacc.pack", f"{REF}/lib/nerfacc/pack.py")
+    ln = sys.modules["lib.nerfacc"]
+    for k in ("ray_resampling", "ray_resampling_merge", "ray_resampling_fine", "ray_resampling_sdf_fine"):
+        setattr(ln, k, getattr(sys.modules["lib.nerfacc.cdf"], k))
+
+    class _AsCuda(torch.Tensor):          # pack.py only runs its (pure torch) body `if tensor.is_cuda`
+        is_cuda = property(lambda self: True)
+
+    def _cpu_ok(fn):
+        def call(t, *a, **k):
+            out = fn(t.as_subclass(_AsCuda), *a, **k)
+            return out.as_subclass(torch.Tensor) if isinstance(out, torch.Tensor) else out
+        return call
+    ln.pack_info, ln.unpack_info = _cpu_ok(pack.pack_info), _cpu_ok(pack.unpack_info)
+    ln.pack_data, ln.unpack_data = pack.pack_data, pack.unpack_data
+    pkg("models", f"{REF}/models")
+    pkg("models.pbr", f"{REF}/models/pbr")
+    pkg("models.occ_grid", f"{REF}/models/occ_grid")
+    pkg("models.rf", f"{REF}/models/rf")
+    mods = dict(utils=load("models.utils", f"{REF}/models/utils.py"))
+    mods["volrend"] = load("models.volrend", f"{REF}/models/volrend.py")
+    mods["pbr_utils"] = load("models.pbr.utils", f"{REF}/models/pbr/utils.py")
+    load("models.occ_grid.base", f"{REF}/models/occ_grid/base.py")
+    mods["occ"] = load("models.occ_grid.temporal_occ_grid", f"{REF}/models/occ_grid/temporal_occ_grid.py")
+    return mods
+
+
+# ----------------------------------------------------------------------------- inputs
+def random_samples(g, n_rays, max_cnt, p_empty=0.25):
+    cnt = torch.randint(1, max_cnt, (n_rays,), generator=g)
+    cnt[torch.rand(n_rays, generator=g) < p_empty] = 0
+    S = int(cnt.sum())
+    ray_indices = torch.repeat_interleave(torch.arange(n_rays), cnt)
+    t_starts = torch.empty(S)
+    t_ends = torch.empty(S)
+    o = 0
+    for c in cnt.tolist():
+        if c:
+            edges = torch.sort(torch.rand(c + 1, generator=g) * 2.0 + 0.5)[0]
+            t_starts[o:o + c], t_ends[o:o + c] = edges[:-1], edges[1:]
+            o += c
+    return ray_indices, t_starts, t_ends, S
+
+
+def main():
+    assert os.path.isdir(REF), "needs /root/reference (build container only)"
+    torch.manual_seed(0)
+    M = import_reference_host_code()
+    VR, PU, OCC, U = M["volrend"], M["pbr_utils"], M["occ"], M["utils"]
+    g = torch.Generator().manual_seed(20260928)
+    out = {}
+    N = lambda t: t.detach().cpu().numpy()      # noqa: E731
+
+    # ---- a13: the three rendering functions of models/volrend.py, per-sample quantities given by fixed closures ----------
+    n_rays = 257
+    ri, ts, te, S = random_samples(g, n_rays, 20)
+    r3 = lambda: torch.rand((S, 3), generator=g)      # noqa: E731
+    unit = lambda v: torch.nn.functional.normalize(v * 2 - 1, dim=-1)      # noqa: E731
+    per = dict(positions=r3() * 2 - 1, valid=torch.rand(S, generator=g) > 0.1, rgbs=r3(), normals_smpl=unit(r3()),
+               normals_world=unit(r3()), materials=torch.rand((S, 5), generator=g), materials_jitter=torch.rand((S, 5), generator=g),
+               alphas=torch.rand(S, generator=g) ** 2, sdf=torch.rand(S, generator=g) - 0.5, sdf_grad=r3() * 2 - 1,
+               laplace=torch.rand(S, generator=g) - 0.5)
+    out.update({"vr_ray_indices": N(ri), "vr_t_starts": N(ts), "vr_t_ends": N(te), "vr_n_rays": np.int64(n_rays)})
+    out.update({"vr_in_" + k: N(v) for k, v in per.items()})
+    bk = torch.tensor([0.25, 0.5, 0.75])
+    out["vr_render_bkgd"] = N(bk)
+
+    def fn_sdf(t0, t1, r):
+        return (per["positions"], per["valid"], per["rgbs"], per["normals_smpl"], per["normals_world"], per["alphas"], per["sdf"],
+                per["sdf_grad"], per["laplace"])
+
+    def fn_mats(t0, t1, r):
+        return (per["positions"], per["valid"], per["rgbs"], per["normals_smpl"], per["normals_world"], per["materials"],
+                per["materials_jitter"], per["alphas"], per["sdf"], per["sdf_grad"], per["laplace"])
+
+    def fn_plain(t0, t1, r):
+        return per["sdf"], per["rgbs"], per["alphas"]
+    for tag, bkgd in (("", None), ("_bk", bk)):
+        c, nrm, op, dep, ex = VR.rendering_with_normals_sdf(ts, te, ray_indices=ri, n_rays=n_rays, rgb_alpha_fn=fn_sdf, render_bkgd=bkgd)
+        out.update({f"vr_sdf{tag}_colors": N(c), f"vr_sdf{tag}_normals": N(nrm), f"vr_sdf{tag}_opacities": N(op), f"vr_sdf{tag}_depths": N(dep)})
+        if not tag:
+            out["vr_sdf_extras_keys"] = np.array(sorted(ex.keys()))
+            out.update({"vr_sdf_extras_" + k: N(v) for k, v in ex.items()})
+        r = VR.rendering_with_normals_mats_sdf(ts, te, ray_indices=ri, n_rays=n_rays, rgb_alpha_fn=fn_mats, render_bkgd=bkgd)
+        names = ("colors", "normals", "albedo", "roughness", "metallic", "opacities", "depths")
+        out.update({f"vr_mats{tag}_{k}": N(v) for k, v in zip(names, r[:7])})
+        if not tag:
+            out["vr_mats_extras_keys"] = np.array(sorted(r[7].keys()))
+            out.update({"vr_mats_extras_" + k: N(v) for k, v in r[7].items()})
+        c, op, dep, ex = VR.rendering(ts, te, ray_indices=ri, n_rays=n_rays, rgb_alpha_fn=fn_plain, render_bkgd=bkgd)
+        out.update({f"vr_plain{tag}_colors": N(c), f"vr_plain{tag}_opacities": N(op), f"vr_plain{tag}_depths": N(dep)})
+        if not tag:
+            out["vr_plain_extras_keys"] = np.array(sorted(ex.keys()))
+
+    # ---- a14: sample_volume_interaction (models/pbr/utils.py:70-229) over the reference's own K1 ----------------------
+    for spp in (8, 64):
+        n2 = 193
+        ri2, ts2, te2, S2 = random_samples(g, n2, 24)
+        alphas = torch.rand(S2, generator=g) ** 3
+        pk = sys.modules["lib.nerfacc"].pack_info(ri2, n2)
+        w, _ = sys.modules["nerfacc"].render_weight_from_alpha(alphas, packed_info=pk)
+        acc = sys.modules["nerfacc"].accumulate_along_rays(w, None, ri2, n2)
+        sdf = torch.rand(S2, generator=g) - 0.3
+        extras = dict(weights=w, sdf=sdf, alphas=alphas, normals=unit(torch.rand((S2, 3), generator=g)),
+                      albedo=torch.rand((S2, 3), generator=g), roughness=torch.rand((S2, 1), generator=g),
+                      metallic=torch.rand((S2, 1), generator=g))
+        ro, rd = torch.randn((n2, 3), generator=g), unit(torch.rand((n2, 3), generator=g))
+        rpi, rri, rw, fg, bgi, rex = PU.sample_volume_interaction(ro, rd, ri2, ts2, te2, n2, spp, 1.0 - acc, extras)
+        p = f"svi{spp}_"
+        out.update({p + "rays_o": N(ro), p + "rays_d": N(rd), p + "ray_indices": N(ri2), p + "t_starts": N(ts2), p + "t_ends": N(te2),
+                    p + "n_rays": np.int64(n2), p + "transmittance": N(1.0 - acc)})
+        out.update({p + "in_" + k: N(v) for k, v in extras.items()})
+        out.update({p + "resampled_packed_info": N(rpi), p + "resampled_ray_indices": N(rri), p + "resampled_weights": N(rw),
+                    p + "fg_indices": N(fg), p + "bg_indices": N(bgi)})
+        out[p + "extras_keys"] = np.array(sorted(rex.keys()))
+        out.update({p + "out_" + k: N(v) for k, v in rex.items()})
+
+    # ---- a18 / a1: TemporalOccGridEstimator._update and .sampling ----------------------------------------------------------
+    res = 32
+    aabb = torch.tensor([[-1.0, -1.2, -0.8, 1.0, 0.8, 0.9]])
+    est = OCC.TemporalOccGridEstimator(roi_aabb=aabb.repeat(2, 1), resolution=res, levels=2)
+    rand = torch.rand((res ** 3, 3), generator=g)
+    orig_rand_like = torch.rand_like
+
+    def occ_eval_fn(x):        # two blobs (one much larger) + a speck: exercises the largest-component filter
+        d1 = (x - torch.tensor([0.1, -0.2, 0.0])).norm(dim=-1)
+        d2 = (x - torch.tensor([-0.7, 0.5, 0.6])).norm(dim=-1)
+        return (torch.exp(-(d1 / 0.35) ** 4) + 0.8 * torch.exp(-(d2 / 0.12) ** 4))[:, None] * 0.05
+    torch.rand_like = lambda t, **k: rand.to(k.get("dtype", t.dtype)) if t.shape == rand.shape else orig_rand_like(t, **k)
+    try:
+        est._update(step=0, t_idx=1, occ_eval_fn=occ_eval_fn, occ_thre=0.001, ema_decay=0.8)
+        occs1, bin1 = est.occs.clone(), est.binaries.clone()
+        est._update(step=20, t_idx=1, occ_eval_fn=lambda x: occ_eval_fn(x) * 0.5, occ_thre=0.001, ema_decay=0.8)
+    finally:
+        torch.rand_like = orig_rand_like
+    x_eval = (est.grid_coords.float() + rand) / est.resolution
+    x_eval = est.aabbs[1, :3] + x_eval * (est.aabbs[1, 3:] - est.aabbs[1, :3])
+    out.update(occ_res=np.int64(res), occ_aabbs=N(est.aabbs), occ_rand=N(rand), occ_eval1=N(occ_eval_fn(x_eval)[:, 0]),
+               occ_occs_after1=N(occs1), occ_binaries_after1=N(bin1), occ_occs_after2=N(est.occs), occ_binaries_after2=N(est.binaries))
+    # max_connected_component on its own
+    gridb = torch.rand((1, 16, 16, 16), generator=g) > 0.72
+    out.update(mcc_in=N(gridb), mcc_out=N(U.max_connected_component(gridb)))
+    # sampling through the estimator (level picked by t_idx, near/far planes, stratified jitter) -- traversal by the oracle
+    n3 = 300
+    o3 = torch.randn((n3, 3), generator=g) * 0.2 + torch.tensor([0.0, 0.0, -3.0])
+    d3 = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, 1.0]) + 0.25 * torch.randn((n3, 3), generator=g), dim=-1)
+    jit = torch.rand(n3, generator=g)
+    torch.rand_like = lambda t, **k: jit.to(k.get("dtype", t.dtype)) if t.shape == jit.shape else orig_rand_like(t, **k)
+    try:
+        est.eval()
+        iv, ri3, ts3, te3 = est.sampling(o3, d3, near_plane=0.1, far_plane=5.0, t_idx=0.75, render_step_size=0.03, stratified=True)
+        _, ri4, ts4, te4 = est.sampling(o3, d3, t_min=torch.full((n3,), 2.9), t_max=torch.full((n3,), 3.6), t_idx=0.5,
+                                        render_step_size=0.05)
+    finally:
+        torch.rand_like = orig_rand_like
+    out.update(smp_rays_o=N(o3), smp_rays_d=N(d3), smp_jitter=N(jit), smp_ray_indices=N(ri3), smp_t_starts=N(ts3), smp_t_ends=N(te3),
+               smp_iv_vals=N(iv.vals), smp_iv_is_left=N(iv.is_left), smp_iv_is_right=N(iv.is_right), smp_iv_packed_info=N(iv.packed_info),
+               smp2_ray_indices=N(ri4), smp2_t_starts=N(ts4), smp2_t_ends=N(te4))
+
+    # ---- leaf helpers of models/utils.py and the density formula --------------------------------------------------------
+    a, b = torch.randn((200, 3), generator=g), unit(torch.rand((200, 3), generator=g))
+    out.update(reflect_x=N(a), reflect_n=N(b), reflect_out=N(U.reflect(a, b)))
+    h = U.GaussianHistogram(15, 0.0, 1.0, sigma=torch.tensor(0.07))
+    xs = torch.rand(500, generator=g)
+    out.update(hist_x=N(xs), hist_out=N(h(xs)), hist_sigma=np.float64(0.07))
+    sys.modules["models"].register = lambda name: (lambda cls: cls)
+    load("models.base", f"{REF}/models/base.py")
+    dens = load("models.rf.density", f"{REF}/models/rf/density.py")
+    cls = dens.LearnedLaplaceDensity
+    obj = cls.__new__(cls)
+    torch.nn.Module.__init__(obj)
+    obj.beta = torch.nn.Parameter(torch.tensor(0.013))
+    obj.beta_min = torch.tensor(1e-4)
+    sd = (torch.rand(400, generator=g) - 0.5) * 0.2
+    out.update(dens_sdf=N(sd), dens_beta=np.float64(float(obj.beta)), dens_beta_min=np.float64(1e-4), dens_out=N(obj.density_func(sd)))
+
+    out = {k: v for k, v in out.items() if v is not None}
+    np.savez_compressed(f"{HERE}/golden_host.npz", **out)
+    print("golden_host.npz", os.path.getsize(f"{HERE}/golden_host.npz") // 1024, "KiB,", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

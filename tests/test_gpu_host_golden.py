@@ -1,0 +1,146 @@
+"""GPU (MI355X): the package's mirrors of the reference's HOST-side operators against vectors produced by running the
+reference's own Python in the build container (tests/golden/golden_host.npz <- tests/golden/make_golden_host.py):
+
+    intrinsicavatar_amd.volrend.{rendering, rendering_with_normals_sdf, rendering_with_normals_mats_sdf}   models/volrend.py
+    intrinsicavatar_amd.pbr.sample_volume_interaction                                                      models/pbr/utils.py:70-229
+    intrinsicavatar_amd.occ_grid.TemporalOccGridEstimator._update / .sampling                              models/occ_grid/temporal_occ_grid.py
+    render.laplace_alpha (get_alpha o LearnedLaplaceDensity.density_func)                                  models/rf/density.py:25-30
+
+Integer / bool / index outputs bit-exact; float outputs to the tolerance written at each assert (the fixture's weights and
+per-ray sums were computed serially on the CPU; the kernels keep that order for short rays)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    from intrinsicavatar_amd import build
+    build.build()
+    return np.load(f"{golden_dir}/golden_host.npz")
+
+
+def test_volrend_functions_vs_reference(G):
+    from intrinsicavatar_amd import volrend as VR
+    ri, ts, te, n = T(G["vr_ray_indices"]), T(G["vr_t_starts"]), T(G["vr_t_ends"]), int(G["vr_n_rays"])
+    per = {k[6:]: T(G[k]) for k in G.files if k.startswith("vr_in_")}
+    order_sdf = ("positions", "valid", "rgbs", "normals_smpl", "normals_world", "alphas", "sdf", "sdf_grad", "laplace")
+    order_mats = order_sdf[:5] + ("materials", "materials_jitter") + order_sdf[5:]
+    close = lambda a, b, what: np.testing.assert_allclose(N(a), b, rtol=2e-6, atol=2e-7, err_msg=what)      # noqa: E731
+    for tag, bk in (("", None), ("_bk", T(G["vr_render_bkgd"]))):
+        c, nrm, op, dep, ex = VR.rendering_with_normals_sdf(ts, te, ray_indices=ri, n_rays=n, render_bkgd=bk,
+                                                            rgb_alpha_fn=lambda a, b, r: tuple(per[k] for k in order_sdf))
+        for name, v in zip(("colors", "normals", "opacities", "depths"), (c, nrm, op, dep)):
+            close(v, G[f"vr_sdf{tag}_{name}"], f"sdf{tag} {name}")
+        if not tag:
+            assert sorted(ex.keys()) == list(G["vr_sdf_extras_keys"])              # the extras contract, volrend.py:766-777
+            for k, v in ex.items():
+                close(v.float(), G["vr_sdf_extras_" + k].astype(np.float32), "extras " + k)
+        r = VR.rendering_with_normals_mats_sdf(ts, te, ray_indices=ri, n_rays=n, render_bkgd=bk,
+                                               rgb_alpha_fn=lambda a, b, r: tuple(per[k] for k in order_mats))
+        for name, v in zip(("colors", "normals", "albedo", "roughness", "metallic", "opacities", "depths"), r[:7]):
+            close(v, G[f"vr_mats{tag}_{name}"], f"mats{tag} {name}")
+        if not tag:
+            assert sorted(r[7].keys()) == list(G["vr_mats_extras_keys"])            # volrend.py:967-984
+            for k, v in r[7].items():
+                close(v.float(), G["vr_mats_extras_" + k].astype(np.float32), "extras " + k)
+        c, op, dep, ex = VR.rendering(ts, te, ray_indices=ri, n_rays=n, render_bkgd=bk,
+                                      rgb_alpha_fn=lambda a, b, r: (per["sdf"], per["rgbs"], per["alphas"]))
+        for name, v in zip(("colors", "opacities", "depths"), (c, op, dep)):
+            close(v, G[f"vr_plain{tag}_{name}"], f"plain{tag} {name}")
+        if not tag:
+            assert sorted(ex.keys()) == list(G["vr_plain_extras_keys"])
+    # chunked closure evaluation (chunk_batch, models/utils.py:16-61) gives the same image
+    off = [0]
+
+    def chunked(a, b, r):
+        s = slice(off[0], off[0] + a.shape[0])
+        off[0] += a.shape[0]
+        return per["sdf"][s], per["rgbs"][s], per["alphas"][s]
+    c2, op2, dep2, _ = VR.rendering(ts, te, ray_indices=ri, n_rays=n, rgb_alpha_fn=chunked, chunk_size=97)
+    close(c2, G["vr_plain_colors"], "chunked colors")
+    # error behaviour of the reference
+    with pytest.raises(ValueError):
+        VR.rendering(ts, te, ray_indices=ri, n_rays=n)
+    with pytest.raises(NotImplementedError):
+        VR.rendering_with_normals_sdf(ts, te, ray_indices=ri, n_rays=n, rgb_sigma_fn=lambda *a: None)
+    with pytest.raises(AssertionError, match="alphas must have shape"):
+        VR.rendering(ts, te, ray_indices=ri, n_rays=n, rgb_alpha_fn=lambda a, b, r: (per["sdf"], per["rgbs"], per["alphas"][:-1]))
+
+
+@pytest.mark.parametrize("spp", [8, 64])
+def test_sample_volume_interaction_vs_reference(G, spp):
+    from intrinsicavatar_amd import pbr
+    p = f"svi{spp}_"
+    extras = {k: T(G[p + "in_" + k]) for k in ("weights", "sdf", "alphas", "normals", "albedo", "roughness", "metallic")}
+    rpi, rri, rw, fg, bg, ex = pbr.sample_volume_interaction(T(G[p + "rays_o"]), T(G[p + "rays_d"]), T(G[p + "ray_indices"]),
+                                                             T(G[p + "t_starts"]), T(G[p + "t_ends"]), int(G[p + "n_rays"]), spp,
+                                                             T(G[p + "transmittance"]), extras)
+    for got, key in ((rpi, "resampled_packed_info"), (rri, "resampled_ray_indices"), (fg, "fg_indices"), (bg, "bg_indices")):
+        np.testing.assert_array_equal(N(got), G[p + key], err_msg=key)
+    np.testing.assert_array_equal(N(rw), G[p + "resampled_weights"])
+    assert sorted(ex.keys()) == list(G[p + "extras_keys"])                       # models/pbr/utils.py:190-206
+    for k, v in ex.items():
+        np.testing.assert_array_equal(N(v), G[p + "out_" + k], err_msg=k)
+
+
+def test_temporal_occ_grid_update_and_sampling_vs_reference(G):
+    from intrinsicavatar_amd.occ_grid import TemporalOccGridEstimator
+    res = int(G["occ_res"])
+    est = TemporalOccGridEstimator(torch.from_numpy(G["occ_aabbs"]), resolution=res, levels=2).to(DEV)
+    rand = T(G["occ_rand"])
+    e1 = T(G["occ_eval1"])
+    est._update(step=0, t_idx=1, occ_eval_fn=lambda x: e1[:, None], occ_thre=0.001, ema_decay=0.8, rand=rand)
+    np.testing.assert_array_equal(N(est.occs), G["occ_occs_after1"])
+    np.testing.assert_array_equal(N(est.binaries), G["occ_binaries_after1"])
+    est._update(step=20, t_idx=1, occ_eval_fn=lambda x: e1[:, None] * 0.5, occ_thre=0.001, ema_decay=0.8, rand=rand)
+    np.testing.assert_array_equal(N(est.occs), G["occ_occs_after2"])
+    np.testing.assert_array_equal(N(est.binaries), G["occ_binaries_after2"])
+    # the sample positions handed to occ_eval_fn are the reference's (grid_coords + rand) / resolution mapped into the level's aabb
+    seen = {}
+    est._update(step=40, t_idx=0, occ_eval_fn=lambda x: (seen.setdefault("x", x), torch.zeros(x.shape[0], 1, device=DEV))[1],
+                occ_thre=0.001, ema_decay=0.8, rand=rand)
+    gc = torch.stack(torch.meshgrid([torch.arange(res)] * 3, indexing="ij"), -1).reshape(-1, 3).float()
+    a = torch.from_numpy(G["occ_aabbs"])[0]
+    want = a[:3] + (gc + torch.from_numpy(G["occ_rand"])) / res * (a[3:] - a[:3])
+    np.testing.assert_allclose(N(seen["x"]), want.numpy(), rtol=1e-6, atol=1e-6)
+    # sampling: level from t_idx, near / far planes, stratified jitter, t_min / t_max clamps (temporal_occ_grid.py:152-178)
+    est.eval()
+    est.binaries.copy_(T(G["occ_binaries_after2"]))
+    o, d = T(G["smp_rays_o"]), T(G["smp_rays_d"])
+    iv, ri, ts, te = est.sampling(o, d, near_plane=0.1, far_plane=5.0, t_idx=0.75, render_step_size=0.03, stratified=True,
+                                  jitter=T(G["smp_jitter"]))
+    np.testing.assert_array_equal(N(ri), G["smp_ray_indices"])
+    np.testing.assert_array_equal(N(ts), G["smp_t_starts"])
+    np.testing.assert_array_equal(N(te), G["smp_t_ends"])
+    np.testing.assert_array_equal(N(iv.vals), G["smp_iv_vals"])
+    np.testing.assert_array_equal(N(iv.is_left), G["smp_iv_is_left"])
+    np.testing.assert_array_equal(N(iv.is_right), G["smp_iv_is_right"])
+    np.testing.assert_array_equal(N(iv.packed_info), G["smp_iv_packed_info"])
+    assert ts.numel() > 200
+    n3 = o.shape[0]
+    _, ri, ts, te = est.sampling(o, d, t_min=torch.full((n3,), 2.9, device=DEV), t_max=torch.full((n3,), 3.6, device=DEV), t_idx=0.5,
+                                 render_step_size=0.05)
+    np.testing.assert_array_equal(N(ri), G["smp2_ray_indices"])
+    np.testing.assert_array_equal(N(ts), G["smp2_t_starts"])
+    np.testing.assert_array_equal(N(te), G["smp2_t_ends"])
+
+
+def test_density_formula_vs_reference(G):
+    from intrinsicavatar_amd import render
+    beta = torch.tensor([float(G["dens_beta"]) + float(G["dens_beta_min"])], device=DEV)       # get_beta(): |beta| + beta_min
+    a = render.laplace_alpha(T(G["dens_sdf"]), 0.02, beta)
+    want = 1.0 - np.exp(-G["dens_out"].astype(np.float64) * 0.02)
+    np.testing.assert_allclose(N(a), want, rtol=3e-6, atol=1e-7)
