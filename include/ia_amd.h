@@ -456,6 +456,16 @@ int ia_secondary_compact(int64_t F, const int32_t* flag, const int32_t* slot, co
 int ia_secondary_scatter(int64_t M, const int32_t* src, const float* transmittance, const float* rgb, float* dense_transmittance,
                          float* dense_rgb, ia_stream_t stream);
 
+/* lib.torch_pbr scatterer classes (registered at models/__init__.py:44-50; call sites models/intrinsic_avatar.py:566-574,
+ * 591-614, 714-723, 816-825, 882-923): sample / pdf / eval of the lobe set `lobes` = 1 Lambertian, 2 GGX, 3 MultiLobe,
+ * 4 Mirror.  wi points away from the surface; eval returns (diff [F], spec [F,3]) including the cosine term. */
+int ia_scatterer_sample(int64_t F, int lobes, const float* normal, const float* wi, const float* alpha, const float* u /*[F,3]*/,
+                        float* wo, ia_stream_t stream);
+int ia_scatterer_pdf(int64_t F, int lobes, const float* normal, const float* wi, const float* wo, const float* alpha, float* pdf,
+                     ia_stream_t stream);
+int ia_scatterer_eval(int64_t F, int lobes, const float* normal, const float* wi, const float* wo, const float* alpha,
+                      const float* albedo, const float* metallic, float* diff, float* spec, ia_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

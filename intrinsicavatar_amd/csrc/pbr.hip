@@ -178,6 +178,95 @@ __global__ __launch_bounds__(THREADS) void brdf_pdf_kernel(int64_t F, const floa
     pdf[i] = brdf_pdf(n, wi, w, roughness[i]);
 }
 
+// ---- lib.torch_pbr scatterer classes: sample / pdf / eval per lobe set -------------------------------------------------
+// lobes: 1 = Lambertian (cosine lobe), 2 = GGX (specular lobe), 3 = MultiLobe (both, 1/2 : 1/2 sampling), 4 = Mirror
+// (perfect reflection: sample = reflect(wi, n), pdf = 1 -- a discrete direction --, eval = Schlick Fresnel for wo on the
+// reflection direction).  wi points AWAY from the surface (the call sites pass -ray direction, intrinsic_avatar.py:559).
+__device__ __forceinline__ void lobes_sample(int lobes, const float n[3], const float wi[3], float alpha, const float u[3], float wo[3])
+{
+    if (lobes == 4) {
+        const float c = n[0] * wi[0] + n[1] * wi[1] + n[2] * wi[2];
+#pragma unroll
+        for (int k = 0; k < 3; k++) wo[k] = 2.0f * c * n[k] - wi[k];
+        return;
+    }
+    float uu[3] = {u[0], u[1], u[2]};
+    if (lobes == 1) uu[0] = 0.0f;          // always the cosine lobe
+    if (lobes == 2) uu[0] = 1.0f;          // always the GGX lobe
+    brdf_sample(n, wi, alpha, uu, wo);
+}
+
+__device__ __forceinline__ float lobes_pdf(int lobes, const float n[3], const float wi[3], const float wo[3], float alpha)
+{
+    if (lobes == 4) return 1.0f;
+    const float NoL = n[0] * wo[0] + n[1] * wo[1] + n[2] * wo[2];
+    if (NoL <= 0.0f) return 0.0f;
+    const float pd = NoL * (1.0f / PI_F);
+    if (lobes == 1) return pd;
+    const float both = brdf_pdf(n, wi, wo, alpha);                    // 1/2 pd + 1/2 ps
+    return lobes == 3 ? both : 2.0f * (both - 0.5f * pd);
+}
+
+__global__ __launch_bounds__(THREADS) void scatterer_sample_kernel(int64_t F, int lobes, const float* __restrict__ normal,
+                                                                    const float* __restrict__ wi_in, const float* __restrict__ alpha,
+                                                                    const float* __restrict__ u, float* __restrict__ wo_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= F) return;
+    const float n[3] = {normal[i * 3], normal[i * 3 + 1], normal[i * 3 + 2]};
+    const float wi[3] = {wi_in[i * 3], wi_in[i * 3 + 1], wi_in[i * 3 + 2]};
+    const float uu[3] = {u[i * 3], u[i * 3 + 1], u[i * 3 + 2]};
+    float wo[3];
+    lobes_sample(lobes, n, wi, alpha[i], uu, wo);
+    wo_out[i * 3] = wo[0]; wo_out[i * 3 + 1] = wo[1]; wo_out[i * 3 + 2] = wo[2];
+}
+
+__global__ __launch_bounds__(THREADS) void scatterer_pdf_kernel(int64_t F, int lobes, const float* __restrict__ normal,
+                                                                 const float* __restrict__ wi_in, const float* __restrict__ wo_in,
+                                                                 const float* __restrict__ alpha, float* __restrict__ pdf)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= F) return;
+    const float n[3] = {normal[i * 3], normal[i * 3 + 1], normal[i * 3 + 2]};
+    const float wi[3] = {wi_in[i * 3], wi_in[i * 3 + 1], wi_in[i * 3 + 2]};
+    const float wo[3] = {wo_in[i * 3], wo_in[i * 3 + 1], wo_in[i * 3 + 2]};
+    pdf[i] = lobes_pdf(lobes, n, wi, wo, alpha[i]);
+}
+
+__global__ __launch_bounds__(THREADS) void scatterer_eval_kernel(int64_t F, int lobes, const float* __restrict__ normal,
+                                                                  const float* __restrict__ wi_in, const float* __restrict__ wo_in,
+                                                                  const float* __restrict__ alpha, const float* __restrict__ albedo,
+                                                                  const float* __restrict__ metallic, float* __restrict__ diff_out,
+                                                                  float* __restrict__ spec_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= F) return;
+    const float n[3] = {normal[i * 3], normal[i * 3 + 1], normal[i * 3 + 2]};
+    const float wi[3] = {wi_in[i * 3], wi_in[i * 3 + 1], wi_in[i * 3 + 2]};
+    const float wo[3] = {wo_in[i * 3], wo_in[i * 3 + 1], wo_in[i * 3 + 2]};
+    const float alb[3] = {albedo[i * 3], albedo[i * 3 + 1], albedo[i * 3 + 2]};
+    float diff = 0.0f, spec[3] = {0, 0, 0};
+    if (lobes == 4) {
+        const float c = n[0] * wi[0] + n[1] * wi[1] + n[2] * wi[2];
+        const float r[3] = {2.0f * c * n[0] - wi[0], 2.0f * c * n[1] - wi[1], 2.0f * c * n[2] - wi[2]};
+        const float d2 = (r[0] - wo[0]) * (r[0] - wo[0]) + (r[1] - wo[1]) * (r[1] - wo[1]) + (r[2] - wo[2]) * (r[2] - wo[2]);
+        if (c > 0.0f && d2 < 1e-6f) {
+            const float om = 1.0f - c, f5 = om * om * om * om * om;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float F0 = 0.04f * (1.0f - metallic[i]) + alb[k] * metallic[i];
+                spec[k] = F0 + (1.0f - F0) * f5;
+            }
+        }
+    } else {
+        brdf_eval(n, wi, wo, alpha[i], alb, metallic[i], diff, spec);
+        if (lobes == 1) spec[0] = spec[1] = spec[2] = 0.0f;
+        if (lobes == 2) diff = 0.0f;
+    }
+    diff_out[i] = diff;
+    spec_out[i * 3] = spec[0]; spec_out[i * 3 + 1] = spec[1]; spec_out[i * 3 + 2] = spec[2];
+}
+
 // Monte-Carlo estimators (one lane per shading sample).  MODE:
 //   0 light          pbr_light_forward         :755-861  weight 1/pdf_light (pdf<=0 -> 1), cosine + tr masks
 //   1 uniform_light  pbr_uniform_light_forward :654-753  weight inv_pdf[i] (stratified sphere), cosine + tr masks, vis
@@ -472,4 +561,32 @@ IA_EXPORT int ia_envlight_eval(int64_t n, const float* dirs_world, const float* 
     EnvMap e{env_base, env_pmf, env_h, env_w};
     env_eval_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, dirs_world, e, rgb, pdf);
     return ia::check_launch("ia_envlight_eval");
+}
+
+IA_EXPORT int ia_scatterer_sample(int64_t F, int lobes, const float* normal, const float* wi, const float* alpha, const float* u,
+                                  float* wo, ia_stream_t stream)
+{
+    if (F == 0) return IA_OK;
+    IA_REQUIRE(lobes >= 1 && lobes <= 4, "lobes: 1 Lambertian, 2 GGX, 3 MultiLobe, 4 Mirror");
+    scatterer_sample_kernel<<<ia::cdiv(F, THREADS), THREADS, 0, (hipStream_t)stream>>>(F, lobes, normal, wi, alpha, u, wo);
+    return ia::check_launch("ia_scatterer_sample");
+}
+
+IA_EXPORT int ia_scatterer_pdf(int64_t F, int lobes, const float* normal, const float* wi, const float* wo, const float* alpha,
+                               float* pdf, ia_stream_t stream)
+{
+    if (F == 0) return IA_OK;
+    IA_REQUIRE(lobes >= 1 && lobes <= 4, "lobes: 1 Lambertian, 2 GGX, 3 MultiLobe, 4 Mirror");
+    scatterer_pdf_kernel<<<ia::cdiv(F, THREADS), THREADS, 0, (hipStream_t)stream>>>(F, lobes, normal, wi, wo, alpha, pdf);
+    return ia::check_launch("ia_scatterer_pdf");
+}
+
+IA_EXPORT int ia_scatterer_eval(int64_t F, int lobes, const float* normal, const float* wi, const float* wo, const float* alpha,
+                                const float* albedo, const float* metallic, float* diff, float* spec, ia_stream_t stream)
+{
+    if (F == 0) return IA_OK;
+    IA_REQUIRE(lobes >= 1 && lobes <= 4, "lobes: 1 Lambertian, 2 GGX, 3 MultiLobe, 4 Mirror");
+    scatterer_eval_kernel<<<ia::cdiv(F, THREADS), THREADS, 0, (hipStream_t)stream>>>(F, lobes, normal, wi, wo, alpha, albedo, metallic,
+                                                                                    diff, spec);
+    return ia::check_launch("ia_scatterer_eval");
 }

@@ -18,20 +18,74 @@ from . import _lib as L
 from . import lib_nerfacc
 
 
-class EnvironmentLightTensor:
-    """`emitter` with attributes .base [H,W,3], .pdf_scale and methods update_pdf / sample / eval / pdf."""
+def _cfg(config, key, default=None):
+    """read `key` from an OmegaConf / dict / attribute-style config (the reference builds every module as cls(config))."""
+    if config is None:
+        return default
+    if isinstance(config, dict):
+        return config.get(key, default)
+    if hasattr(config, "get"):
+        try:
+            return config.get(key, default)
+        except TypeError:
+            pass
+    return getattr(config, key, default)
 
-    def __init__(self, base: Tensor):
-        self.base = base.contiguous().float()
-        self.pdf_scale = self.base.shape[0] * self.base.shape[1] / (2 * math.pi * math.pi)
+
+class EnvironmentLightTensor(torch.nn.Module):
+    """`envlight-tensor` emitter (models/__init__.py:39; configs/light/envlight_tensor.yaml): equirectangular radiance image
+    `base` [H,W,3] (a Parameter; the test path replaces it with the HDRI, models/intrinsic_avatar.py:297-301), `.pdf_scale`,
+    methods update_pdf / sample / eval / pdf / generate_image / sample_uniform_sphere_stratified.
+    Construct from a config (`cls(config)`: envlight_config.{base_res, scale, bias}; random init = scale * U[0,1) + bias, the
+    nvdiffrecmc convention -- lib/torch_pbr is absent from the reference tree) or directly from an image tensor."""
+
+    def __init__(self, config=None):
+        super().__init__()
+        if isinstance(config, Tensor):
+            base = config.detach().contiguous().float()
+            self.config = None
+        else:
+            self.config = config
+            ec = _cfg(config, "envlight_config", None)
+            res = int(_cfg(ec, "base_res", 256))
+            scale, bias = float(_cfg(ec, "scale", 0.5)), float(_cfg(ec, "bias", 0.25))
+            g = torch.Generator().manual_seed(int(_cfg(ec, "seed", 0)))
+            base = torch.rand((res, 2 * res, 3), generator=g) * scale + bias
+        self.base = torch.nn.Parameter(base)
         self.pmf = None
         self._cdf = None
+
+    def __setattr__(self, name, value):
+        if name == "base" and isinstance(value, Tensor) and not isinstance(value, torch.nn.Parameter):
+            value = torch.nn.Parameter(value.detach().contiguous().float())
+        super().__setattr__(name, value)
+
+    @property
+    def pdf_scale(self) -> float:
+        return self.base.shape[0] * self.base.shape[1] / (2 * math.pi * math.pi)
+
+    @pdf_scale.setter
+    def pdf_scale(self, value):          # assigned by the reference's prepare() (:298-300); derived from the image here
+        pass
+
+    def generate_image(self) -> Tensor:
+        return self.base
+
+    @torch.no_grad()
+    def sample_uniform_sphere_stratified(self, n_rays: int, n_theta: int = 16, n_phi: int = 32, device=None, u: Optional[Tensor] = None):
+        """(dirs [n_theta*n_phi, 3], inv_pdf [n_theta*n_phi, 1]): one jittered direction per equal-area stratum -- the set
+        the reference indexes with shuffled indices in [0, n_theta*n_phi) (:680-689, :1393-1401).  u [K,2]: explicit jitter."""
+        dev = device if device is not None else self.base.device
+        if u is None:
+            u = torch.rand((n_theta * n_phi, 2), device=dev)
+        return uniform_sphere_stratified(n_theta, n_phi, u.to(dev))
 
     @torch.no_grad()
     def update_pdf(self):
         H, W, _ = self.base.shape
-        sin_t = torch.sin((torch.arange(H, device=self.base.device) + 0.5) * math.pi / H)[:, None]
-        lum = (0.2126 * self.base[..., 0] + 0.7152 * self.base[..., 1] + 0.0722 * self.base[..., 2]).clamp_min(0).double()
+        base = self.base.detach()
+        sin_t = torch.sin((torch.arange(H, device=base.device) + 0.5) * math.pi / H)[:, None]
+        lum = (0.2126 * base[..., 0] + 0.7152 * base[..., 1] + 0.0722 * base[..., 2]).clamp_min(0).double()
         w = lum * sin_t
         self.pmf = (w / w.sum()).float().contiguous()
         self._cdf = torch.cumsum(self.pmf.reshape(-1).double(), 0)
@@ -58,7 +112,7 @@ class EnvironmentLightTensor:
         rgb = torch.empty((n, 3), device=d.device) if want_rgb else None
         pdf = torch.empty((n,), device=d.device) if want_pdf else None
         H, W, _ = self.base.shape
-        L.check(L.lib().ia_envlight_eval(L.i64(n), L.ptr(d), L.ptr(self.base), L.ptr(self.pmf), L.i32(H), L.i32(W), L.ptr(rgb),
+        L.check(L.lib().ia_envlight_eval(L.i64(n), L.ptr(d), L.ptr(self.base.detach()), L.ptr(self.pmf), L.i32(H), L.i32(W), L.ptr(rgb),
                                          L.ptr(pdf), L.stream()), "ia_envlight_eval")
         return rgb, pdf
 
@@ -76,8 +130,12 @@ class EnvironmentLightSG(torch.nn.Module):
     rendered into an equirectangular [base_res, 2 base_res, 3] image (`generate_image`, differentiable) that the kernels
     evaluate like any EnvironmentLightTensor (`as_tensor_light()`, `env_base=` of pbr_shade_differentiable)."""
 
-    def __init__(self, num_SGs: int = 64, base_res: int = 256, seed: int = 0):
+    def __init__(self, num_SGs=64, base_res: int = 256, seed: int = 0):
         super().__init__()
+        if not isinstance(num_SGs, int):            # cls(config): configs/light/envlight_SG.yaml
+            ec = _cfg(num_SGs, "envlight_config", None)
+            self.config = num_SGs
+            num_SGs, base_res, seed = int(_cfg(ec, "num_SGs", 64)), int(_cfg(ec, "base_res", 256)), int(_cfg(ec, "seed", 0))
         g = torch.Generator().manual_seed(seed)
         i = torch.arange(num_SGs, dtype=torch.float32) + 0.5                    # Fibonacci sphere: even lobe coverage
         phi = math.pi * (1 + 5 ** 0.5) * i
@@ -106,6 +164,40 @@ class EnvironmentLightSG(torch.nn.Module):
         e = EnvironmentLightTensor(self.generate_image().detach())
         e.update_pdf()
         return e
+
+    # -- the emitter surface the model calls (update_pdf / sample / pdf / eval / base / pdf_scale): sampling and pdf go
+    # through the equirect image of the current lobes (regenerated by update_pdf, as the training path calls it every step,
+    # :777-781); eval is the closed-form lobe sum, differentiable w.r.t. the lobe parameters
+    @torch.no_grad()
+    def update_pdf(self):
+        self.__dict__["_tl"] = self.as_tensor_light()
+
+    def _light(self) -> "EnvironmentLightTensor":
+        if "_tl" not in self.__dict__:
+            self.update_pdf()
+        return self.__dict__["_tl"]
+
+    @property
+    def base(self) -> Tensor:
+        return self._light().base
+
+    @property
+    def pdf_scale(self) -> float:
+        return self._light().pdf_scale
+
+    def sample(self, k: int, u: Optional[Tensor] = None, w2s_rot: Optional[Tensor] = None) -> Tensor:
+        return self._light().sample(k, u, w2s_rot=w2s_rot)
+
+    def pdf(self, d_world: Tensor) -> Tensor:
+        return self._light().pdf(d_world)
+
+    def eval(self, d_world: Tensor) -> Tensor:
+        xi = torch.nn.functional.normalize(self.axis, dim=-1)
+        w = torch.exp(torch.exp(self.log_lambda) * (d_world @ xi.T - 1.0))
+        return w @ torch.nn.functional.softplus(self.mu)
+
+    def sample_uniform_sphere_stratified(self, n_rays: int, n_theta: int = 16, n_phi: int = 32, device=None, u: Optional[Tensor] = None):
+        return self._light().sample_uniform_sphere_stratified(n_rays, n_theta, n_phi, device=device, u=u)
 
 
 # ----------------------------------------------------------------------------- colour helpers of lib.torch_pbr
@@ -453,3 +545,150 @@ def light_shuffle(n_rays: int, spp: int, resampled_packed_info: Tensor, fg_indic
     L.check(L.lib().ia_light_shuffle(L.i64(n_rays), L.i32(spp), L.ptr(cnt), L.ptr(start), L.ptr(shuffle_u.float().contiguous()),
                                      L.ptr(full), L.stream()), "ia_light_shuffle")
     return full[fg_indices].long()
+
+
+# ----------------------------------------------------------------------------- scatterer classes of lib.torch_pbr
+class _ScattererEval(torch.autograd.Function):
+    """(diff [P,1], spec [P,3]) = BRDF x cosine for the lobe set; differentiable w.r.t. normal, albedo, roughness, metallic.
+    Backward = the estimator's backward kernel (ia_pbr_shade_bwd, uniform_light form) with unit incident radiance and unit
+    weight, so the derivative code exists once."""
+
+    @staticmethod
+    def forward(ctx, lobes, n, wi, wo, alpha, albedo, metallic):
+        P = n.shape[0]
+        dev = n.device
+        keep = [t.detach().float().contiguous() for t in (n, wi, wo, alpha.reshape(-1), albedo, metallic.reshape(-1))]
+        diff, spec = torch.empty((P, 1), device=dev), torch.empty((P, 3), device=dev)
+        L.check(L.lib().ia_scatterer_eval(L.i64(P), L.i32(lobes), *[L.ptr(t) for t in keep], L.ptr(diff), L.ptr(spec), L.stream()),
+                "ia_scatterer_eval")
+        ctx.lobes = lobes
+        ctx.shapes = (alpha.shape, metallic.shape)
+        ctx.save_for_backward(*keep)
+        return diff, spec
+
+    @staticmethod
+    def backward(ctx, g_diff, g_spec):
+        n, wi, wo, alpha, albedo, metallic = ctx.saved_tensors
+        if ctx.lobes == 4:
+            return (None,) * 7
+        P, dev = n.shape[0], n.device
+        g_Ld = torch.zeros((P, 3), device=dev)
+        if ctx.lobes != 2:
+            g_Ld[:, 0] = g_diff.reshape(-1)
+        g_Ls = g_spec.float().contiguous() if ctx.lobes != 1 else torch.zeros((P, 3), device=dev)
+        ones3, zeros, ones = torch.ones((P, 3), device=dev), torch.zeros(P, device=dev), torch.ones(P, device=dev)
+        env, pmf, eye = torch.zeros((1, 1, 3), device=dev), torch.ones((1, 1), device=dev), torch.eye(3, device=dev)
+        g_n, g_a, g_r, g_m = (torch.empty((P, 3), device=dev), torch.empty((P, 3), device=dev), torch.empty(P, device=dev),
+                              torch.empty(P, device=dev))
+        g_env = torch.zeros((1, 1, 3), device=dev)
+        view = (-wi).contiguous()
+        # Li = 0 * em + ind_rgb = 1, weight = inv_pdf = 1  ->  Lo_diff = diff, Lo_spec = spec
+        L.check(L.lib().ia_pbr_shade_bwd(L.i32(1), L.i64(P), L.ptr(n), L.ptr(albedo), L.ptr(alpha), L.ptr(metallic), L.ptr(view),
+                                         L.ptr(wo), L.ptr(zeros), L.ptr(ones3), L.ptr(ones), L.ptr(env), L.ptr(pmf), L.i32(1), L.i32(1),
+                                         L.ptr(eye), L.ptr(None), L.ptr(g_Ld), L.ptr(g_Ls), L.ptr(g_n), L.ptr(g_a), L.ptr(g_r),
+                                         L.ptr(g_m), L.ptr(g_env), L.stream()), "ia_pbr_shade_bwd")
+        if ctx.lobes == 1:       # the cosine lobe does not depend on the material
+            g_a, g_r, g_m = torch.zeros_like(g_a), torch.zeros_like(g_r), torch.zeros_like(g_m)
+        return None, g_n, None, None, g_r.reshape(ctx.shapes[0]), g_a, g_m.reshape(ctx.shapes[1])
+
+
+class _Scatterer(torch.nn.Module):
+    """common surface of the lib.torch_pbr scatterers as the reference calls them (keyword arguments, per-point tensors):
+        sample(n=, wi=, alpha_x=, alpha_y=, albedo=, metallic=, attenuation=) -> wo [P,3]     (:566-574, :882-890)
+        pdf(n=, wi=, wo=, ...)                                                -> [P,1]         (:591-600, :899-908)
+        eval(wi=, n=, wo=, ...)                                               -> (diff [P,1], spec [P,3]) incl. cosine (:605-614)
+    wi points away from the surface.  Isotropic: alpha_y is accepted and must equal alpha_x (every call site passes the same
+    tensor twice); `attenuation` is accepted and ignored ("no attenuation for now", :560-562).  `u` [P,3]: explicit uniforms
+    for sample() (drawn on the device when None)."""
+    LOBES = 3
+
+    def __init__(self, config=None):
+        super().__init__()
+        self.config = config
+
+    @staticmethod
+    def _alpha(alpha_x, alpha_y):
+        if alpha_y is not None and alpha_y is not alpha_x and alpha_y.data_ptr() != alpha_x.data_ptr():
+            if not torch.equal(alpha_x, alpha_y):
+                raise NotImplementedError("anisotropic roughness (alpha_x != alpha_y) is not used by the reference")
+        return alpha_x.reshape(-1)
+
+    @torch.no_grad()
+    def sample(self, n, wi, alpha_x, alpha_y=None, albedo=None, metallic=None, attenuation=None, u: Optional[Tensor] = None):
+        P, dev = n.shape[0], n.device
+        if u is None:
+            u = torch.rand((P, 3), device=dev)
+        keep = [t.detach().float().contiguous() for t in (n, wi, self._alpha(alpha_x, alpha_y), u)]
+        out = torch.empty((P, 3), device=dev)
+        L.check(L.lib().ia_scatterer_sample(L.i64(P), L.i32(self.LOBES), *[L.ptr(t) for t in keep], L.ptr(out), L.stream()),
+                "ia_scatterer_sample")
+        return out
+
+    @torch.no_grad()
+    def pdf(self, n, wi, wo, alpha_x, alpha_y=None, albedo=None, metallic=None, attenuation=None):
+        P, dev = n.shape[0], n.device
+        keep = [t.detach().float().contiguous() for t in (n, wi, wo, self._alpha(alpha_x, alpha_y))]
+        out = torch.empty((P, 1), device=dev)
+        L.check(L.lib().ia_scatterer_pdf(L.i64(P), L.i32(self.LOBES), *[L.ptr(t) for t in keep], L.ptr(out), L.stream()),
+                "ia_scatterer_pdf")
+        return out
+
+    def eval(self, wi, n, wo, alpha_x, alpha_y=None, albedo=None, metallic=None, attenuation=None):
+        if metallic is not None and metallic.dim() == 2 and metallic.shape[-1] != 1:
+            raise NotImplementedError("3-channel specular albedo (volume scattering, phase-* scatterers) is not built")
+        if albedo is None:
+            albedo = torch.ones_like(n)
+        if metallic is None:
+            metallic = torch.zeros((n.shape[0], 1), device=n.device)
+        return _ScattererEval.apply(self.LOBES, n, wi, wo, self._alpha(alpha_x, alpha_y), albedo, metallic)
+
+
+class MultiLobe(_Scatterer):
+    """`brdf-multi-lobe` (configs/scatterer/brdf-multi-lobe.yaml): Lambert + GGX, lobes sampled 1/2 : 1/2."""
+    LOBES = 3
+
+
+class Lambertian(_Scatterer):
+    """`brdf-lambertian`: the cosine lobe alone."""
+    LOBES = 1
+
+
+class GGX(_Scatterer):
+    """`brdf-ggx`: the GGX specular lobe alone (Smith G, Schlick F)."""
+    LOBES = 2
+
+
+class Mirror(_Scatterer):
+    """`brdf-mirror`: perfect reflection (discrete direction: pdf = 1)."""
+    LOBES = 4
+
+
+class _NotBuilt(torch.nn.Module):
+    """a lib.torch_pbr class the render_step path never instantiates with the shipped configs (configs/light/*.yaml,
+    configs/scatterer/brdf-multi-lobe.yaml): the NAME resolves so that models/__init__.py:39-51 registers it; constructing
+    it raises, like an unsupported option of the reference would."""
+
+    def __init__(self, config=None):
+        super().__init__()
+        raise NotImplementedError(f"lib.torch_pbr.{type(self).__name__} is not built (IA_ERR_UNSUPPORTED): the MI355X path covers "
+                                  "envlight-tensor / envlight-SG and brdf-{multi-lobe, lambertian, ggx, mirror}")
+
+
+class EnvironmentLightMLP(_NotBuilt):
+    pass
+
+
+class EnvironmentLightNGP(_NotBuilt):
+    pass
+
+
+class DiffuseSGGX(_NotBuilt):
+    pass
+
+
+class SpecularSGGX(_NotBuilt):
+    pass
+
+
+class MultiLobeSGGX(_NotBuilt):
+    pass
