@@ -385,7 +385,8 @@ def main():
                          for k, v in sorted(per_call.items(), key=lambda kv: -kv[1][1])[:12]}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(rays, export, n_rays, headline, args.spp)
+            from intrinsicavatar_amd import synthetic as _S
+            cpu = cpu_baseline(rays, export, n_rays, headline, args.spp, _S.export_phys(mat, sg.generate_image().detach()) if headline else None)
         wl = (f"{args.hw}x{args.hw} frame ({n_rays} rays), fwd+bwd+Adam WITH the PBR branch: 128 samples/ray primary march, 2x importance "
               f"resampling, fast-SNARF deformer (13 inits), SDF/radiance/material fields, samples_per_pixel={args.spp} volume-interaction "
               f"re-samples per ray, render_mode=light (one light-importance-sampled secondary ray per foreground re-sample, training form), "
@@ -445,20 +446,21 @@ def count_broyden_fetches(step, dev):
     return cnt.cpu().tolist()
 
 
-def cpu_baseline(rays, export, n_rays, headline, spp):
+def cpu_baseline(rays, export, n_rays, headline, spp, phys=None):
     """the CPU oracle (oracle/: a port of the reference's algorithm, test infrastructure) timed on this box's host cores on
     a bounded sample of the same frame.  Forward only: the oracle has no backward."""
     from oracle import render_ref as R, oracle as O
     O.build()
-    sc = R.Scene(**export)
+    sc = R.Scene(**export, **(phys or {}))
     if headline and hasattr(R, "relight_step"):
-        stride = max(1, n_rays // 96)
+        stride = max(1, n_rays // 640)
         sample = rays[::stride].cpu().numpy()
         tc = time.perf_counter()
         R.relight_step(sc, sample, spp=spp, seed=0)
         tcpu = time.perf_counter() - tc
         what = (f"every {stride}th ray of the same 540x540 frame ({sample.shape[0]} rays) x {spp} spp, oracle/render_ref.py "
-                f"relight_step (render_step forward WITH the PBR branch, render_mode=light, secondary rays on), {tcpu:.1f} s")
+                f"relight_step (render_step FORWARD with the PBR branch: render_mode=light in its eval form -- {spp} shared light "
+                f"directions shuffled per ray --, secondary rays + indirect shading on), {tcpu:.1f} s")
     else:
         stride = max(1, n_rays // 24000)
         sample = rays[::stride].cpu().numpy()

@@ -466,6 +466,13 @@ int ia_scatterer_pdf(int64_t F, int lobes, const float* normal, const float* wi,
 int ia_scatterer_eval(int64_t F, int lobes, const float* normal, const float* wi, const float* wo, const float* alpha,
                       const float* albedo, const float* metallic, float* diff, float* spec, ia_stream_t stream);
 
+/* spatial ordering of large query batches (no reference counterpart: a scheduling aid, results are order-independent):
+ * 30-bit Morton code of each point's cell for a key-value sort, and the gather / scatter that apply the permutation */
+int ia_morton_keys(int64_t n, const float* pts /*[n,3]*/, const float* origin_host3 /*HOST pointer to 3 floats*/, float inv_cell,
+                   int32_t* keys, ia_stream_t stream);
+int ia_gather_rows3(int64_t n, const float* src, const int64_t* order, float* dst, ia_stream_t stream);
+int ia_scatter_f32(int64_t n, const float* src, const int64_t* order, float* dst, ia_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

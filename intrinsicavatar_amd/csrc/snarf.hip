@@ -372,6 +372,129 @@ __global__ __launch_bounds__(THREADS) void broyden_persistent_kernel(
 }
 
 
+
+// ---- K8, lane-persistent form, v2 (B == 1, channel-last grid) -----------------------------------------------------------
+// Same state machine and per-item arithmetic as broyden_persistent_kernel.  What changed is the cost of everything AROUND a
+// fetch: ~15 of 64 lanes finish per iteration, so the refill path runs (for the whole wave) on practically every
+// iteration.  It used to be two 64-bit divisions + fifteen global loads (target point, the bone's 4x4) per refill; now an
+// item is (chunk-local 32-bit counter) -> (point, init) by one multiply-high with a host-computed magic, and the bones'
+// rows (the 12 floats x0 = R^T (xd - t) needs) sit in LDS.  Results are bit-identical (the golden test runs all schedules).
+__global__ __launch_bounds__(THREADS) void broyden_persistent2_kernel(
+    int64_t total, int I, uint32_t magic_I, const float* __restrict__ xd_tgt, const float* __restrict__ voxel_J, int D, int H, int W,
+    const float* __restrict__ tfs, const int32_t* __restrict__ bone_ids, const float* __restrict__ offset_g,
+    const float* __restrict__ scale_g, float cvg_threshold, float dvg_threshold, float* __restrict__ x,
+    float* __restrict__ J_inv, uint8_t* __restrict__ is_valid, float* __restrict__ fwd_J, int br_chunk)
+{
+    __shared__ float s_T[16 * 12];                     // per init: rows 0..2 of its bone's 4x4 (R | t)
+    for (int t = threadIdx.x; t < I * 12; t += THREADS) s_T[t] = tfs[(int64_t)bone_ids[t / 12] * 16 + (t % 12)];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = ((int64_t)blockIdx.x * THREADS + threadIdx.x) >> 6;
+    const int64_t chunk_begin = wave_id * br_chunk;
+    if (chunk_begin >= total) return;
+    const int n_items = (int)((chunk_begin + br_chunk < total) ? br_chunk : total - chunk_begin);
+    const int64_t p0 = chunk_begin / I;                // wave-uniform 64-bit division, once
+    const int i0 = (int)(chunk_begin - p0 * I);
+    int cur = 0;                                       // items of the chunk handed out so far (wave-uniform)
+    const float offset[3] = {offset_g[0], offset_g[1], offset_g[2]};
+    const float scale[3] = {scale_g[0], scale_g[1], scale_g[2]};
+    const float cvg2 = cvg_threshold * cvg_threshold, dvg2 = dvg_threshold * dvg_threshold;
+
+    bool have = false;
+    int64_t index = 0;
+    int it = -1;                  // -1: waiting for the initial fetch
+    float xt[3] = {0, 0, 0}, x_l[3] = {0, 0, 0}, gx[3] = {0, 0, 0}, u[3] = {0, 0, 0};
+    float Ji[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (;;) {
+        // ---- refill idle lanes from the wave's chunk ----
+        const unsigned long long need = __ballot(!have);
+        if (need) {
+            if (!have) {
+                const int rank = __popcll(need & ((1ull << lane) - 1ull));
+                const int c = cur + rank;
+                if (c < n_items) {
+                    have = true;
+                    it = -1;
+                    const uint32_t t = (uint32_t)(i0 + c);               // < br_chunk + I <= 4096 + 16
+                    const uint32_t q = __umulhi(t, magic_I);             // t / I (magic = ceil(2^32 / I), exact for t < 2^28)
+                    const int i_init = (int)(t - q * (uint32_t)I);
+                    const int64_t i_point = p0 + q;
+                    index = chunk_begin + c;
+                    xt[0] = xd_tgt[i_point * 3 + 0];
+                    xt[1] = xd_tgt[i_point * 3 + 1];
+                    xt[2] = xd_tgt[i_point * 3 + 2];
+                    const float* T = s_T + i_init * 12;                  // T[r*4 + c], r < 3
+                    const float ixd = xt[0] - T[0 * 4 + 3], iyd = xt[1] - T[1 * 4 + 3], izd = xt[2] - T[2 * 4 + 3];
+                    x_l[0] = ixd * T[0 * 4 + 0] + iyd * T[1 * 4 + 0] + izd * T[2 * 4 + 0];
+                    x_l[1] = ixd * T[0 * 4 + 1] + iyd * T[1 * 4 + 1] + izd * T[2 * 4 + 1];
+                    x_l[2] = ixd * T[0 * 4 + 2] + iyd * T[1 * 4 + 2] + izd * T[2 * 4 + 2];
+                }
+            }
+            cur += __popcll(need);
+            if (cur > n_items) cur = n_items;
+        }
+        if (!__any(have)) break;
+        if (!have) continue;
+        // ---- one fetch at the current x_l ----
+        const float ix = scale[0] * (x_l[0] + offset[0]);
+        const float iy = scale[1] * (x_l[1] + offset[1]);
+        const float iz = scale[2] * (x_l[2] + offset[2]);
+        float Jl[12];
+        grid_sample_J<IA_LAYOUT_NDHWC>(voxel_J, 0, D, H, W, ix, iy, iz, Jl);
+        if (it < 0) {
+            // initial fetch: J_inv guess and g(x0)   (fuse_cuda_kernel_fast.cu:295-331)
+            Ji[0] = Jl[0]; Ji[3] = Jl[1]; Ji[6] = Jl[2];
+            Ji[1] = Jl[4]; Ji[4] = Jl[5]; Ji[7] = Jl[6];
+            Ji[2] = Jl[8]; Ji[5] = Jl[9]; Ji[8] = Jl[10];
+            gx[0] = Jl[0] * x_l[0] + Jl[1] * x_l[1] + Jl[2] * x_l[2] + Jl[3];
+            gx[1] = Jl[4] * x_l[0] + Jl[5] * x_l[1] + Jl[6] * x_l[2] + Jl[7];
+            gx[2] = Jl[8] * x_l[0] + Jl[9] * x_l[1] + Jl[10] * x_l[2] + Jl[11];
+            gx[0] = gx[0] - xt[0]; gx[1] = gx[1] - xt[1]; gx[2] = gx[2] - xt[2];
+            it = 0;
+        } else {
+            // fetch of iteration `it` (x_l already updated): residual, tests, Broyden update (:352-411)
+            float gn[3];
+            gn[0] = Jl[0] * x_l[0] + Jl[1] * x_l[1] + Jl[2] * x_l[2] + Jl[3] - xt[0];
+            gn[1] = Jl[4] * x_l[0] + Jl[5] * x_l[1] + Jl[6] * x_l[2] + Jl[7] - xt[1];
+            gn[2] = Jl[8] * x_l[0] + Jl[9] * x_l[1] + Jl[10] * x_l[2] + Jl[11] - xt[2];
+            const float norm_gx = gn[0] * gn[0] + gn[1] * gn[1] + gn[2] * gn[2];
+            if (norm_gx < cvg2) {
+                const bool ok = ix >= -1 && ix <= 1 && iy >= -1 && iy <= 1 && iz >= -1 && iz <= 1;
+                is_valid[index] = ok ? 1 : 0;
+                if (ok) {
+                    x[index * 3 + 0] = x_l[0]; x[index * 3 + 1] = x_l[1]; x[index * 3 + 2] = x_l[2];
+                    if (J_inv) {
+                        float* Jo = J_inv + index * 9;
+#pragma unroll
+                        for (int k = 0; k < 9; k++) Jo[k] = Ji[k];
+                    }
+                    if (fwd_J) {
+                        float* Fo = fwd_J + index * 9;
+                        Fo[0] = Jl[0]; Fo[1] = Jl[1]; Fo[2] = Jl[2]; Fo[3] = Jl[4]; Fo[4] = Jl[5]; Fo[5] = Jl[6];
+                        Fo[6] = Jl[8]; Fo[7] = Jl[9]; Fo[8] = Jl[10];
+                    }
+                }
+                have = false;
+                continue;
+            } else if (norm_gx > dvg2) {
+                is_valid[index] = 0;
+                have = false;
+                continue;
+            }
+            J_inv_update(Ji, u[0], u[1], u[2], gn[0] - gx[0], gn[1] - gx[1], gn[2] - gx[2]);
+            gx[0] = gn[0]; gx[1] = gn[1]; gx[2] = gn[2];
+            it++;
+            if (it >= 10) { is_valid[index] = 0; have = false; continue; }       // not converged
+        }
+        // step: update = -J_inv g, x += update
+        u[0] = -Ji[0] * gx[0] + -Ji[1] * gx[1] + -Ji[2] * gx[2];
+        u[1] = -Ji[3] * gx[0] + -Ji[4] * gx[1] + -Ji[5] * gx[2];
+        u[2] = -Ji[6] * gx[0] + -Ji[7] * gx[1] + -Ji[8] * gx[2];
+        x_l[0] += u[0]; x_l[1] += u[1]; x_l[2] += u[2];
+    }
+}
+
 // ---- K8 diagnostics ---------------------------------------------------------------
 // Same search as broyden_kernel (identical arithmetic, no outputs): counts what the searches of a batch cost, for the
 // L1-path figures of bench.py / DESIGN.md.  counters[0] = trilinear fetches issued, [1] = corner loads actually performed
@@ -527,6 +650,14 @@ IA_EXPORT int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt, cons
         if (const char* e = getenv("IA_BR_CHUNK")) br_chunk = atoi(e);                   // tuning hook
         const int64_t n_waves = (total + br_chunk - 1) / br_chunk;
         const int grid = ia::cdiv(n_waves * 64, THREADS);
+        const char* v = getenv("IA_BROYDEN_V2");
+        if (B == 1 && layout == IA_LAYOUT_NDHWC && I >= 2 && I <= 16 && br_chunk < (1 << 24) && !(v && v[0] == '0')) {
+            // umulhi(t, ceil(2^32 / I)) == t / I while t * (magic * I - 2^32) < 2^32, i.e. for every t < 2^28
+            const uint32_t magic = (uint32_t)((((uint64_t)1 << 32) + (uint64_t)I - 1) / (uint64_t)I);
+            broyden_persistent2_kernel<<<grid, THREADS, 0, s>>>(total, I, magic, xd_tgt, voxel_J, D, H, W, tfs, bone_ids, offset, scale,
+                                                                cvg_threshold, dvg_threshold, x, J_inv, is_valid, fwd_J, br_chunk);
+            return ia::check_launch("ia_fuse_broyden");
+        }
         if (layout == IA_LAYOUT_NDHWC)
             broyden_persistent_kernel<IA_LAYOUT_NDHWC><<<grid, THREADS, 0, s>>>(total, N, I, xd_tgt, voxel_J, D, H, W, tfs,
                                                                                 bone_ids, offset, scale, cvg_threshold,

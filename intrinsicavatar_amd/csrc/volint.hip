@@ -313,7 +313,66 @@ __global__ __launch_bounds__(THREADS) void scatter_secondary_kernel(int64_t M, c
     dense_rgb[3 * k] = rgb[3 * m]; dense_rgb[3 * k + 1] = rgb[3 * m + 1]; dense_rgb[3 * k + 2] = rgb[3 * m + 2];
 }
 
+// ---- spatial ordering of query points: 30-bit Morton code of the cell (origin, 1 / cell size), for a key-value sort ----
+__device__ __forceinline__ uint32_t spread10(uint32_t v)
+{
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    return (v | (v << 2)) & 0x09249249u;
+}
+
+__global__ __launch_bounds__(THREADS) void morton_keys_kernel(int64_t n, const float* __restrict__ pts, float ox, float oy, float oz,
+                                                               float inv_cell, int32_t* __restrict__ keys)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float fx = (pts[3 * i] - ox) * inv_cell, fy = (pts[3 * i + 1] - oy) * inv_cell, fz = (pts[3 * i + 2] - oz) * inv_cell;
+    const uint32_t x = (uint32_t)fminf(fmaxf(fx, 0.0f), 1023.0f), y = (uint32_t)fminf(fmaxf(fy, 0.0f), 1023.0f),
+                   z = (uint32_t)fminf(fmaxf(fz, 0.0f), 1023.0f);
+    keys[i] = (int32_t)(spread10(x) | (spread10(y) << 1) | (spread10(z) << 2));
+}
+
+__global__ __launch_bounds__(THREADS) void gather_rows3_kernel(int64_t n, const float* __restrict__ src, const int64_t* __restrict__ order,
+                                                                float* __restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const int64_t j = order[i];
+    dst[3 * i] = src[3 * j]; dst[3 * i + 1] = src[3 * j + 1]; dst[3 * i + 2] = src[3 * j + 2];
+}
+
+__global__ __launch_bounds__(THREADS) void scatter_f32_kernel(int64_t n, const float* __restrict__ src, const int64_t* __restrict__ order,
+                                                               float* __restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    dst[order[i]] = src[i];
+}
+
 }  // namespace
+
+IA_EXPORT int ia_morton_keys(int64_t n, const float* pts, const float* origin_host3, float inv_cell, int32_t* keys, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    morton_keys_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, pts, origin_host3[0], origin_host3[1],
+                                                                                 origin_host3[2], inv_cell, keys);
+    return ia::check_launch("ia_morton_keys");
+}
+
+IA_EXPORT int ia_gather_rows3(int64_t n, const float* src, const int64_t* order, float* dst, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    gather_rows3_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, src, order, dst);
+    return ia::check_launch("ia_gather_rows3");
+}
+
+IA_EXPORT int ia_scatter_f32(int64_t n, const float* src, const int64_t* order, float* dst, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    scatter_f32_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, src, order, dst);
+    return ia::check_launch("ia_scatter_f32");
+}
 
 IA_EXPORT int ia_vi_layout(int64_t n_rays, int spp, const int32_t* rpi, const int32_t* bg_cnt, int32_t* fg_ray_cnt,
                            ia_stream_t stream)

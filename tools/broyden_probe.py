@@ -36,14 +36,50 @@ def run():
                             dfm.scale_kernel, 1e-5, 1e-1)
 res = dict(points=P, samples_per_ray=P / n_sec)
 _, _, D, H, W = dfm.lbs_voxel_final.shape
-for sched in ("persistent", "simple"):
-    os.environ["IA_BROYDEN_SCHEDULE"] = sched
+ref_out = None
+for sched, v2 in (("persistent", "0"), ("persistent", "1"), ("simple", "1")):
+    os.environ["IA_BROYDEN_SCHEDULE"], os.environ["IA_BROYDEN_V2"] = sched, v2
+    x.fill_(0); valid.fill_(False)
     run(); torch.cuda.synchronize()
+    cur = (valid.clone(), torch.where(valid[..., None], x, torch.zeros_like(x)))
+    if ref_out is None:
+        ref_out = cur
+    else:
+        assert torch.equal(cur[0], ref_out[0]) and torch.equal(cur[1], ref_out[1]), "schedules differ"
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(3): run()
     e1.record(); torch.cuda.synchronize()
-    res[sched + "_ms"] = e0.elapsed_time(e1) / 3
+    res[sched + ("_v2" if (v2 == "1" and sched == "persistent") else "") + "_ms"] = e0.elapsed_time(e1) / 3
+os.environ["IA_BROYDEN_V2"] = os.environ.get("IA_PROBE_V2", "1")
+def stats_for(points):
+    c = torch.zeros(17, dtype=torch.int64, device=dev)
+    L.check(L.lib().ia_broyden_stats(L.i32(1), L.i64(points.shape[0]), L.i32(I), L.ptr(points), L.ptr(dfm.voxel_J_cl), L.i32(1), L.i32(D), L.i32(H),
+                                     L.i32(W), L.ptr(dfm.tfs), L.ptr(dfm.init_bones), L.ptr(dfm.offset_kernel), L.ptr(dfm.scale_kernel),
+                                     L.f32(1e-5), L.f32(1e-1), L.ptr(c), L.stream()), "ia_broyden_stats")
+    return c.cpu().tolist()
+if os.environ.get("IA_ORDER_EXPERIMENT", "1") == "1":
+    # how much does the ORDER / locality of the items matter?  same multiset of points: ray order (above), random order,
+    # spatially sorted (Morton code of the 1 cm cell), and the degenerate all-items-identical case (pure L1-hit rate)
+    os.environ["IA_BROYDEN_SCHEDULE"] = "persistent"
+    base_pts = pts
+    q = ((base_pts - base_pts.min(0)[0]) / 0.01).long().clamp(0, 1023)
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F; v = (v | (v << 4)) & 0x030C30C3; return (v | (v << 2)) & 0x09249249
+    morton = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    variants = dict(random=base_pts[torch.randperm(P, device=dev)].contiguous(), morton=base_pts[torch.argsort(morton)].contiguous(),
+                    identical=base_pts[P // 2:P // 2 + 1].expand(P, 3).contiguous())
+    for name, v in variants.items():
+        pts = v
+        run(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3): run()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        c = stats_for(v)
+        res["order_" + name] = dict(ms=ms, fetches=c[0], ns_per_fetch_lane=ms * 1e6 / max(c[0], 1), Gfetch_per_s=c[0] / ms / 1e6)
+    pts = base_pts
 cnt = torch.zeros(17, dtype=torch.int64, device=dev)
 L.check(L.lib().ia_broyden_stats(L.i32(1), L.i64(P), L.i32(I), L.ptr(pts), L.ptr(dfm.voxel_J_cl), L.i32(1), L.i32(D), L.i32(H), L.i32(W),
                                  L.ptr(dfm.tfs), L.ptr(dfm.init_bones), L.ptr(dfm.offset_kernel), L.ptr(dfm.scale_kernel),

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""memory-side traffic per kernel launch of the bench step -> gpurun_out/r01_pmc_traffic.json (copied to profiles/).
+"""memory-side traffic per kernel launch of the bench step (default: the headline workload) -> gpurun_out/<tag>_pmc_traffic.json
+(copied to profiles/).
 
 Two separate rocprofv3 --pmc passes (counters only next to --kernel-trace, as the pool requires) over
-`bench.py --steps 2 --warmup 1`:  FETCH_SIZE  and  WRITE_SIZE TCC_HIT_sum TCC_MISS_sum.  Units / corrections per
+`bench.py --steps 1 --warmup 1`:  FETCH_SIZE  and  WRITE_SIZE TCC_HIT_sum TCC_MISS_sum.  Units / corrections per
 /opt/skills/guides/MI355X_MICROARCH.md: both counters are in KB and FETCH_SIZE reports half of the bytes on gfx950."""
 import collections
 import csv
@@ -13,7 +14,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CMD = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+TAG = os.environ.get("IA_PROFILE_TAG", "r02")
+CMD = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-config2",
+       "--no-breakdown"] + sys.argv[1:]
 
 
 def run_pass(name, counters):
@@ -47,13 +50,13 @@ def main():
         hit, miss = wa[k]["TCC_HIT_sum"], wa[k]["TCC_MISS_sum"]
         kernels[k] = dict(launches=fc[k], fetch_bytes=fetch, write_bytes=write, hbm_side_bytes_per_launch=fetch + write,
                           l2_hit_rate=round(hit / max(hit + miss, 1.0), 3))
-    top = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_side_bytes_per_launch"] * kv[1]["launches"])[:16])
-    out = dict(note="rocprofv3 --pmc passes on `bench.py --steps 2 --warmup 1` (tools/pmc_traffic.py): FETCH_SIZE / WRITE_SIZE are "
+    top = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_side_bytes_per_launch"] * kv[1]["launches"])[:20])
+    out = dict(note="rocprofv3 --pmc passes on `bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-config2 --no-breakdown` " + " ".join(sys.argv[1:]) + " (tools/pmc_traffic.py): FETCH_SIZE / WRITE_SIZE are "
                     "KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of the bytes of a streaming read); values "
                     "are per launch, averaged over the launches of the run; Infinity-Cache hits are included (memory-side "
                     "requests of the L2)", kernels=top)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r01_pmc_traffic.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"{TAG}_pmc_traffic.json"), "w"), indent=1)
     for k, v in top.items():
         print(f"{k:62s} x{v['launches']:3d}  fetch {v['fetch_bytes'] / 1e9:7.2f} GB  write {v['write_bytes'] / 1e9:6.2f} GB  L2 hit {v['l2_hit_rate']}")
 
