@@ -189,8 +189,8 @@ class RenderStep:
         return [p for p in ps if p.requires_grad]
 
     def forward_backward(self, rays: Tensor, target_rgb: Tensor, target_mask: Optional[Tensor] = None,
-                         jitter: Optional[Tensor] = None, curv_u: Optional[Tensor] = None, lambda_curv: float = 0.0
-                         ) -> Dict[str, Tensor]:
+                         jitter: Optional[Tensor] = None, curv_u: Optional[Tensor] = None, lambda_curv: float = 0.0,
+                         loss_scale: float = 1.0, **loss_kw) -> Dict[str, Tensor]:
         """one optimisation step's fwd+bwd (training_step, systems/intrinsic_avatar.py:160-251, rgb/eikonal/mask
         terms): no-grad sampling, differentiable shading + compositing, loss, backward to every parameter."""
         from . import train
@@ -198,8 +198,8 @@ class RenderStep:
         if curv_u is not None:
             curv_u = curv_u[:t_starts.shape[0]]
         out = train.shade_differentiable(self, rays_o, rays_d, ray_indices, t_starts, t_ends, packed_info, curv_u=curv_u)
-        loss = train.training_loss(out, target_rgb, target_mask, lambda_curv=lambda_curv)
-        loss.backward()
+        loss = train.training_loss(out, target_rgb, target_mask, lambda_curv=lambda_curv, **loss_kw)
+        (loss * loss_scale if loss_scale != 1.0 else loss).backward()
         out["loss"] = loss.detach()
         out["stats"] = stats
         return out

@@ -1,17 +1,47 @@
 #!/usr/bin/env python3
-"""BASELINE config 3 / 5 shape: relight one 540x540 frame, render_mode=light, spp light samples per pixel,
-secondary rays on.  Prints JSON (primary rays/s, secondary rays/s, per-entry-point breakdown)."""
-import json, os, sys, time
+"""BASELINE config 3 / 5 shape: relight 540x540 frames, render_mode=light, spp light samples per pixel, secondary rays on.
+Frame-parallel over GPUs (each rank its own pose -> own voxel_J and occupancy grid; no collective on the data
+path, only the final gather of the timings):
+
+    python tools/relight_bench.py                                   one GPU, one frame
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/relight_bench.py --gpus N --frames F
+
+Every rank renders frames rank, rank + N, ... of F animation poses (pose seed = frame index).  Prints JSON on rank 0
+(frames/s of the whole job, primary / secondary rays per second, per-entry-point breakdown of rank 0)."""
+import argparse, json, os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from intrinsicavatar_amd import build; build.build()
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--gpus", type=int, default=1)
+ap.add_argument("--frames", type=int, default=0, help="frames of the whole job (default: one per rank)")
+ap.add_argument("--hw", type=int, default=int(os.environ.get("IA_HW", "540")))
+ap.add_argument("--spp", type=int, default=int(os.environ.get("IA_SPP", "256")))
+ap.add_argument("--gi", action="store_true", default=os.environ.get("IA_GI", "0") == "1")
+ap.add_argument("--ray-chunk", type=int, default=int(os.environ.get("IA_RAY_CHUNK", "65536")))
+args = ap.parse_args()
+world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+share = os.environ.get("IA_BENCH_SHARE_GPU") == "1"          # test hook: all ranks on cuda:0 over gloo
+if share:
+    local = 0
+torch.cuda.set_device(local)
+dev = f"cuda:{local}"
+if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo" if share else "nccl", **({} if share else dict(device_id=torch.device(dev))))
+from intrinsicavatar_amd import build
+if rank == 0:
+    build.build()
+if world > 1:
+    dist.barrier()
 from intrinsicavatar_amd import synthetic as S, fields, pbr, _lib as L
 
-hw = int(os.environ.get("IA_HW", "540")); spp = int(os.environ.get("IA_SPP", "256")); gi = os.environ.get("IA_GI", "0") == "1"
-chunk = int(os.environ.get("IA_RAY_CHUNK", "65536"))
-dev = "cuda:0"
-rs, rays, _ = S.build_frame(dev, hw, hw, pose_seed=0, beta=0.01)
+hw, spp, gi, chunk = args.hw, args.spp, args.gi, args.ray_chunk
+n_frames = args.frames or world
+my_frames = list(range(rank, n_frames, world))
 mat = fields.VolumeMaterial(seed=2).to(dev)
 H, W = 1024, 2048
 v, u = np.meshgrid((np.arange(H) + 0.5) / H, (np.arange(W) + 0.5) / W, indexing="ij")
@@ -20,20 +50,42 @@ img = img + (5e4 * np.exp(-(((u - 0.3) * 2) ** 2 + ((v - 0.25) * 2) ** 2) / (2 *
 env = pbr.EnvironmentLightTensor(torch.from_numpy(img.astype(np.float32)).to(dev)); env.update_pdf()
 g = torch.Generator().manual_seed(0)
 light_u = torch.rand((spp, 3), generator=g).to(dev)
-n = rays.shape[0]
-def frame():
-    tot = dict(n_secondary=0, n_fg=0)
+
+
+def frame(pose_seed):
+    """one frame: per-frame deformer grids + occupancy grid (prepare), then the ray chunks of the image."""
+    rs, rays, _ = S.build_frame(dev, hw, hw, pose_seed=pose_seed, beta=0.01)
+    n = rays.shape[0]
+    tot = dict(n_secondary=0, n_fg=0, n_rays=n)
     for c0 in range(0, n, chunk):                 # ray chunks as the reference does at eval (ray_chunk), but 16x larger
         r = rays[c0:c0 + chunk]
         su = torch.rand((r.shape[0], spp), device=dev)
         o = rs.relight(r, mat, env, spp, light_u, su, global_illumination=gi)
         tot["n_secondary"] += o["stats"]["n_secondary"]; tot["n_fg"] += o["stats"]["n_fg"]
     return tot
-frame(); torch.cuda.synchronize()
+
+
+frame(0); torch.cuda.synchronize()
+if world > 1:
+    dist.barrier()
 lib = L.lib(); lib.start(); t0 = time.perf_counter()
-tot = frame(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+tots = [frame(f) for f in my_frames]
+torch.cuda.synchronize()
+if world > 1:
+    dist.barrier()
+dt = time.perf_counter() - t0
 pc = lib.report()
-print(json.dumps(dict(hw=hw, spp=spp, gi=gi, ray_chunk=chunk, s_per_frame=round(dt, 3), primary_rays_per_s=round(n / dt, 1),
-                      secondary_rays=tot["n_secondary"], secondary_rays_per_s=round(tot["n_secondary"] / dt, 1), fg_points=tot["n_fg"],
-                      breakdown_ms={k: round(v[1], 1) for k, v in sorted(pc.items(), key=lambda kv: -kv[1][1])[:8]},
-                      kernel_ms=round(sum(v[1] for v in pc.values()), 1))))
+sec = sum(t["n_secondary"] for t in tots); fg = sum(t["n_fg"] for t in tots); nr = sum(t["n_rays"] for t in tots)
+if world > 1:
+    t = torch.tensor([dt, float(sec), float(fg), float(nr)], dtype=torch.float64, device=dev)
+    tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX); dist.all_reduce(t)
+    dt, sec, fg, nr = float(tm[0]), int(t[1]), int(t[2]), int(t[3])
+if rank == 0:
+    print(json.dumps(dict(hw=hw, spp=spp, gi=gi, ray_chunk=chunk, n_gpus=world, frames=n_frames, s_total=round(dt, 3),
+                          frames_per_s=round(n_frames / dt, 4), s_per_frame_per_gpu=round(dt / max(len(my_frames), 1), 3),
+                          primary_rays_per_s=round(nr / dt, 1), secondary_rays=sec, secondary_rays_per_s=round(sec / dt, 1), fg_points=fg,
+                          includes="per-frame prepare (precompute + occupancy grid) inside the timed region",
+                          breakdown_ms_rank0={k: round(v[1], 1) for k, v in sorted(pc.items(), key=lambda kv: -kv[1][1])[:8]},
+                          kernel_ms_rank0=round(sum(v[1] for v in pc.values()), 1))))
+if world > 1:
+    dist.destroy_process_group()
