@@ -473,6 +473,14 @@ int ia_morton_keys(int64_t n, const float* pts /*[n,3]*/, const float* origin_ho
 int ia_gather_rows3(int64_t n, const float* src, const int64_t* order, float* dst, ia_stream_t stream);
 int ia_scatter_f32(int64_t n, const float* src, const int64_t* order, float* dst, ia_stream_t stream);
 
+/* GaussianHistogram (models/utils.py:133-149) of the albedo-entropy regulariser (models/pbr/material.py:59-70):
+ * out[b] (caller-zeroed, accumulated) = sum_n exp(-0.5 ((x_n - c_b) / sigma)^2) / (sigma sqrt(2 pi)) * delta; sigma is a
+ * DEVICE scalar (the reference passes torch.var(channel)); backward w.r.t. x [n] and sigma (caller-zeroed scalar). */
+int ia_gaussian_histogram(int64_t n, const float* x, const float* sigma, int bins, float vmin, float vmax, float* out,
+                          ia_stream_t stream);
+int ia_gaussian_histogram_bwd(int64_t n, const float* x, const float* sigma, int bins, float vmin, float vmax, const float* g_out,
+                              float* g_x, float* g_sigma, ia_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

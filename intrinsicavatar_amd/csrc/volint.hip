@@ -350,7 +350,97 @@ __global__ __launch_bounds__(THREADS) void scatter_f32_kernel(int64_t n, const f
     dst[order[i]] = src[i];
 }
 
+// ---- GaussianHistogram (models/utils.py:133-149), the soft histogram of the albedo-entropy regulariser --------------------
+//   h_b = sum_n exp(-0.5 ((x_n - c_b) / sigma)^2) / (sigma sqrt(2 pi)) * delta ,  c_b = min + delta (b + 0.5)
+constexpr int GH_MAX_BINS = 32;
+
+__global__ __launch_bounds__(THREADS) void gauss_hist_kernel(int64_t n, const float* __restrict__ x, const float* __restrict__ sigma_p,
+                                                              int bins, float vmin, float delta, float* __restrict__ out)
+{
+    __shared__ float s_acc[GH_MAX_BINS];
+    if (threadIdx.x < GH_MAX_BINS) s_acc[threadIdx.x] = 0.0f;
+    __syncthreads();
+    const float sigma = *sigma_p;
+    const float norm = delta / (sigma * 2.5066282746310002f);
+    float acc[GH_MAX_BINS];
+#pragma unroll
+    for (int b = 0; b < GH_MAX_BINS; b++) acc[b] = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) {
+        const float xi = x[i];
+#pragma unroll
+        for (int b = 0; b < GH_MAX_BINS; b++) {
+            if (b < bins) {
+                const float z = (xi - (vmin + delta * ((float)b + 0.5f))) / sigma;
+                acc[b] += expf(-0.5f * z * z) * norm;
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < GH_MAX_BINS; b++) {
+        if (b < bins) {
+            const float t = wave_sum(acc[b]);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&s_acc[b], t);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < bins) atomicAdd(&out[threadIdx.x], s_acc[threadIdx.x]);
+}
+
+// g_x[n] = sum_b g_b dh_nb/dx ;  g_sigma += sum_n sum_b g_b dh_nb/dsigma
+__global__ __launch_bounds__(THREADS) void gauss_hist_bwd_kernel(int64_t n, const float* __restrict__ x, const float* __restrict__ sigma_p,
+                                                                  int bins, float vmin, float delta, const float* __restrict__ g_out,
+                                                                  float* __restrict__ g_x, float* __restrict__ g_sigma)
+{
+    __shared__ float s_gs[THREADS / 64];
+    const float sigma = *sigma_p;
+    const float norm = delta / (sigma * 2.5066282746310002f);
+    float gs = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) {
+        const float xi = x[i];
+        float gx = 0.0f;
+        for (int b = 0; b < bins; b++) {
+            const float d = xi - (vmin + delta * ((float)b + 0.5f));
+            const float z = d / sigma;
+            const float h = expf(-0.5f * z * z) * norm * g_out[b];
+            gx += h * (-d / (sigma * sigma));
+            gs += h * (z * z - 1.0f) / sigma;
+        }
+        g_x[i] = gx;
+    }
+    gs = wave_sum(gs);
+    if ((threadIdx.x & 63) == 0) s_gs[threadIdx.x >> 6] = gs;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int w = 0; w < THREADS / 64; w++) t += s_gs[w];
+        atomicAdd(g_sigma, t);
+    }
+}
+
 }  // namespace
+
+IA_EXPORT int ia_gaussian_histogram(int64_t n, const float* x, const float* sigma, int bins, float vmin, float vmax, float* out,
+                                    ia_stream_t stream)
+{
+    IA_REQUIRE(bins >= 1 && bins <= GH_MAX_BINS, "ia_gaussian_histogram: 1 <= bins <= 32");
+    if (n == 0) return IA_OK;
+    int grid = ia::cdiv(n, THREADS);
+    if (grid > 1024) grid = 1024;
+    gauss_hist_kernel<<<grid, THREADS, 0, (hipStream_t)stream>>>(n, x, sigma, bins, vmin, (vmax - vmin) / (float)bins, out);
+    return ia::check_launch("ia_gaussian_histogram");
+}
+
+IA_EXPORT int ia_gaussian_histogram_bwd(int64_t n, const float* x, const float* sigma, int bins, float vmin, float vmax,
+                                        const float* g_out, float* g_x, float* g_sigma, ia_stream_t stream)
+{
+    IA_REQUIRE(bins >= 1 && bins <= GH_MAX_BINS, "ia_gaussian_histogram_bwd: 1 <= bins <= 32");
+    if (n == 0) return IA_OK;
+    int grid = ia::cdiv(n, THREADS);
+    if (grid > 1024) grid = 1024;
+    gauss_hist_bwd_kernel<<<grid, THREADS, 0, (hipStream_t)stream>>>(n, x, sigma, bins, vmin, (vmax - vmin) / (float)bins, g_out, g_x,
+                                                                     g_sigma);
+    return ia::check_launch("ia_gaussian_histogram_bwd");
+}
 
 IA_EXPORT int ia_morton_keys(int64_t n, const float* pts, const float* origin_host3, float inv_cell, int32_t* keys, ia_stream_t stream)
 {

@@ -405,6 +405,30 @@ class VolumeMaterial(nn.Module):
             out += [w, self.network.biases_per_layer[i]]
         return out
 
+    def lipshitz_bound_full(self) -> Tensor:
+        """LipshitzMLP.lipshitz_bound_full (network_utils.py:405-412): product of the softplus'ed per-layer bounds -- the
+        `lipshitz_bound` regulariser of the trainer (configs/config.yaml lambda_lipshitz_bound, from step 12500)."""
+        out = 1.0
+        for c in self.network.lipshitz_bound_per_layer:
+            out = out * torch.nn.functional.softplus(c)
+        return out
+
+    def regularizations(self, out=None):
+        """VolumeMaterial.regularizations (models/pbr/material.py:53-87) + LipshitzMLP.regularizations (:430-431) for the maps
+        a training step produces (train_phys.shade_differentiable_phys): means of the smoothness / orientation maps, the
+        Gaussian-histogram entropy of log-albedo over the valid rays, and the Lipschitz bound."""
+        ret = {"lipshitz_bound": self.lipshitz_bound_full().mean()}
+        if out is None:
+            return ret
+        for key, name in (("normals_orientation_loss_map", "normal_orientation"), ("albedo_smoothness_loss_map", "albedo_smoothness"),
+                          ("roughness_smoothness_loss_map", "roughness_smoothness"), ("metallic_smoothness_loss_map", "metallic_smoothness")):
+            if key in out:
+                ret[name] = out[key].mean()
+        if "comp_albedo_full" in out:
+            valid = out["rays_valid_phys_full"][..., 0]
+            ret["albedo_entropy"] = albedo_entropy(out["comp_albedo_full"][valid])
+        return ret
+
     @torch.no_grad()
     def forward(self, enc2: Tensor, xp2: Tensor, feat: Tensor, hash_mask: Tensor) -> Tensor:
         """-> [n,5] = albedo(3), roughness(1), metallic(1)"""
@@ -415,3 +439,46 @@ class VolumeMaterial(nn.Module):
         scale = m.new_tensor([self.albedo_scale] * 3 + [self.roughness_scale, self.metallic_scale])
         bias = m.new_tensor([self.albedo_bias] * 3 + [self.roughness_bias, self.metallic_bias])
         return m * scale + bias
+
+
+class _GaussianHistogram(torch.autograd.Function):
+    """GaussianHistogram(bins, min, max, sigma).forward (models/utils.py:133-149) on ia_gaussian_histogram; differentiable
+    w.r.t. the samples and sigma (the reference builds sigma = torch.var(channel) inside the graph)."""
+
+    @staticmethod
+    def forward(ctx, x, sigma, bins, vmin, vmax):
+        x = x.detach().reshape(-1).float().contiguous()
+        sg = sigma.detach().reshape(1).float().contiguous()
+        out = torch.zeros(bins, device=x.device)
+        L.check(L.lib().ia_gaussian_histogram(L.i64(x.shape[0]), L.ptr(x), L.ptr(sg), L.i32(bins), L.f32(vmin), L.f32(vmax), L.ptr(out),
+                                              L.stream()), "ia_gaussian_histogram")
+        ctx.cfg = (bins, vmin, vmax)
+        ctx.save_for_backward(x, sg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, sg = ctx.saved_tensors
+        bins, vmin, vmax = ctx.cfg
+        gx, gs = torch.empty_like(x), torch.zeros(1, device=x.device)
+        L.check(L.lib().ia_gaussian_histogram_bwd(L.i64(x.shape[0]), L.ptr(x), L.ptr(sg), L.i32(bins), L.f32(vmin), L.f32(vmax),
+                                                  L.ptr(g.float().contiguous()), L.ptr(gx), L.ptr(gs), L.stream()),
+                "ia_gaussian_histogram_bwd")
+        return gx, gs.reshape(()), None, None, None
+
+
+def gaussian_histogram(x: Tensor, sigma: Tensor, bins: int = 15, vmin: float = 0.0, vmax: float = 1.0) -> Tensor:
+    return _GaussianHistogram.apply(x, sigma if isinstance(sigma, Tensor) else torch.tensor(float(sigma), device=x.device), bins, vmin, vmax)
+
+
+def albedo_entropy(albedo: Tensor) -> Tensor:
+    """models/pbr/material.py:58-70: per channel, soft histogram (15 bins on [0,1], sigma = var) of log(albedo + 1e-6),
+    normalised (+1e-6), entropy summed over the channels."""
+    pred = torch.log(albedo + 1e-6)
+    total = 0
+    for i in range(pred.shape[-1]):
+        ch = pred[..., i].contiguous()
+        h = gaussian_histogram(ch, torch.var(ch), 15, 0.0, 1.0)
+        h = h.div(h.sum()) + 1e-6 if float(h.sum()) > 1e-6 else torch.ones_like(h)
+        total = total + torch.sum(-h * torch.log(h))
+    return total

@@ -144,3 +144,51 @@ def test_density_formula_vs_reference(G):
     a = render.laplace_alpha(T(G["dens_sdf"]), 0.02, beta)
     want = 1.0 - np.exp(-G["dens_out"].astype(np.float64) * 0.02)
     np.testing.assert_allclose(N(a), want, rtol=3e-6, atol=1e-7)
+
+
+def test_gaussian_histogram_and_material_regularisers_vs_reference(G):
+    """GaussianHistogram (models/utils.py:133-149) against the reference's own module (fixture), its backward against fp64
+    autograd, and the albedo-entropy / Lipschitz-bound regularisers (models/pbr/material.py:53-87, network_utils.py:405-431)
+    against a plain restatement."""
+    from intrinsicavatar_amd import fields
+    x = T(G["hist_x"])
+    h = fields.gaussian_histogram(x, float(G["hist_sigma"]), 15, 0.0, 1.0)
+    np.testing.assert_allclose(N(h), G["hist_out"], rtol=2e-5, atol=1e-6)
+    # backward w.r.t. samples and sigma
+    xs = x.clone().requires_grad_(True)
+    sg = torch.tensor(0.07, device=DEV, requires_grad=True)
+    g = torch.linspace(-1, 1, 15, device=DEV)
+    (fields.gaussian_histogram(xs, sg, 15, 0.0, 1.0) * g).sum().backward()
+    x64 = torch.from_numpy(G["hist_x"]).double().requires_grad_(True)
+    s64 = torch.tensor(0.07, dtype=torch.float64, requires_grad=True)
+    c = (torch.arange(15, dtype=torch.float64) + 0.5) / 15
+    h64 = (torch.exp(-0.5 * ((x64[None] - c[:, None]) / s64) ** 2) / (s64 * np.sqrt(2 * np.pi)) / 15).sum(1)
+    (h64 * g.cpu().double()).sum().backward()
+    np.testing.assert_allclose(N(xs.grad), x64.grad.numpy(), rtol=1e-4, atol=1e-6)
+    assert abs(float(sg.grad) - float(s64.grad)) < 1e-3 * abs(float(s64.grad))
+    # albedo entropy (material.py:58-70) on a batch of composited albedos
+    gen = torch.Generator().manual_seed(1)
+    alb = (torch.rand((3000, 3), generator=gen) * 0.77 + 0.03).to(DEV).requires_grad_(True)
+    ent = fields.albedo_entropy(alb)
+    a64 = alb.detach().cpu().double().requires_grad_(True)
+    pred = torch.log(a64 + 1e-6)
+    ref = 0
+    for i in range(3):
+        ch = pred[:, i]
+        s_ = torch.var(ch)
+        hh = (torch.exp(-0.5 * ((ch[None] - c[:, None]) / s_) ** 2) / (s_ * np.sqrt(2 * np.pi)) / 15).sum(1)
+        hh = hh / hh.sum() + 1e-6 if float(hh.sum()) > 1e-6 else torch.ones_like(hh)
+        ref = ref + torch.sum(-hh * torch.log(hh))
+    assert abs(float(ent) - float(ref)) < 1e-4 * max(abs(float(ref)), 1.0)
+    ent.backward(); ref.backward()
+    np.testing.assert_allclose(N(alb.grad), a64.grad.numpy(), rtol=5e-3, atol=1e-7)
+    mat = fields.VolumeMaterial(seed=2).to(DEV)
+    reg = mat.regularizations(dict(comp_albedo_full=alb.detach(), rays_valid_phys_full=torch.ones((3000, 1), dtype=torch.bool, device=DEV),
+                                   albedo_smoothness_loss_map=torch.rand((10, 1), device=DEV)))
+    want = 1.0
+    for cc in mat.network.lipshitz_bound_per_layer:
+        want = want * float(torch.nn.functional.softplus(cc))
+    assert abs(float(reg["lipshitz_bound"]) - want) < 1e-5 * want
+    assert set(reg) >= {"lipshitz_bound", "albedo_entropy", "albedo_smoothness"}
+    reg["lipshitz_bound"].backward()
+    assert all(cc.grad is not None for cc in mat.network.lipshitz_bound_per_layer)
