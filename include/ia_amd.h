@@ -481,6 +481,15 @@ int ia_gaussian_histogram(int64_t n, const float* x, const float* sigma, int bin
 int ia_gaussian_histogram_bwd(int64_t n, const float* x, const float* sigma, int bins, float vmin, float vmax, const float* g_out,
                               float* g_x, float* g_sigma, ia_stream_t stream);
 
+/* SDF-only query path of the no-grad coarse passes (coarse_alpha_fn / alpha_fn / coarse_alpha_sdf_fn, models/intrinsic_avatar.py
+ * :399-428, :955-1030): ia_hashgrid_fwd_xcd with out == NULL leaves its level-major result (float2 [L][n]) in `scratch`;
+ * ia_sdf_levels_fwd runs the SDF head on it and writes the SDF alone; ia_deform_select_min = min over a point's candidates
+ * (1e5 when it has none, snarf_deformer.py:192). */
+int ia_sdf_levels_fwd(int64_t n, const void* levels, const float* xp /*[n,3] in [0,1]*/, const float* W1 /*[64,35] hash|xyz*/,
+                      const float* b1, const float* Wo /*[>=1,64], row 0 used*/, const float* bo, float* sdf /*[n]*/,
+                      ia_stream_t stream);
+int ia_deform_select_min(int64_t P, const int32_t* start, const int32_t* cnt, const float* cand_sdf, float* sdf, ia_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,21 @@ __global__ __launch_bounds__(THREADS) void compact_fill_kernel(int64_t P, int I,
     }
 }
 
+// ---- 4'. min over a point's candidates, SDF only (no-grad coarse queries) ----------
+__global__ __launch_bounds__(THREADS) void select_min_kernel(int64_t P, const int32_t* __restrict__ start, const int32_t* __restrict__ cnt,
+                                                              const float* __restrict__ cand_sdf, float* __restrict__ sdf_out)
+{
+    const int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (p >= P) return;
+    const int s = start[p], c = cnt[p];
+    float best = 1e5f;      // snarf_deformer.py:192
+    for (int j = 0; j < c; j++) {
+        const float v = cand_sdf[s + j];
+        if (v < best) best = v;
+    }
+    sdf_out[p] = best;
+}
+
 // ---- 4. select ------------------------------------------------------------------
 __global__ __launch_bounds__(THREADS) void select_kernel(
     int64_t P, const int32_t* __restrict__ start, const int32_t* __restrict__ cnt, const float* __restrict__ cand_x,
@@ -325,6 +340,14 @@ IA_EXPORT int ia_deform_select(int64_t P, const int32_t* start, const int32_t* c
         P, start, cnt, cand_x, cand_src, cand_sdf, sdf_stride, cand_grad, cand_feat, feat_stride, feat_dim, c2w,
         pts_cano, sdf, valid, sel, grad_posed, grad_cano, feat);
     return ia::check_launch("ia_deform_select");
+}
+
+IA_EXPORT int ia_deform_select_min(int64_t P, const int32_t* start, const int32_t* cnt, const float* cand_sdf, float* sdf,
+                                   ia_stream_t stream)
+{
+    if (P == 0) return IA_OK;
+    select_min_kernel<<<ia::cdiv(P, THREADS), THREADS, 0, (hipStream_t)stream>>>(P, start, cnt, cand_sdf, sdf);
+    return ia::check_launch("ia_deform_select_min");
 }
 
 IA_EXPORT int ia_ray_points(int64_t n, const float* rays_o, const float* rays_d, const int64_t* ray_indices,

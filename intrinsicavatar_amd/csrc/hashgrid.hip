@@ -1050,6 +1050,7 @@ IA_EXPORT int ia_hashgrid_fwd_xcd(int64_t n, const float* x, const float* params
         if (dy_dx) hash_fwd_xcd_kernel<true><<<8 * chunks, THREADS, 0, s>>>(n, x, (const float2*)params, c, plan, tmp, tmp_jac);
         else hash_fwd_xcd_kernel<false><<<8 * chunks, THREADS, 0, s>>>(n, x, (const float2*)params, c, plan, tmp, nullptr);
     }
+    if (out == nullptr) return ia::check_launch("ia_hashgrid_fwd_xcd");      // level-major result stays in `scratch` (float2 [L][n])
     const size_t lds = sizeof(float) * THREADS * (dy_dx ? 6 * n_levels + 1 : 2 * n_levels + 1);
     static bool attr = false;
     if (!attr) {

@@ -362,3 +362,23 @@ IA_EXPORT int ia_mlp_fwd(int kind, int64_t n, int n_segs, const float* const* se
     if (kind == 1) return launch_fwd<1, 67, 2, 3, 0, 1, false>(a, s);
     return launch_fwd<2, 48, 2, 5, 0, 1, false>(a, s);
 }
+
+// SDF value only, from the level-major hash features (no-grad coarse queries: importance resampling passes, the secondary
+// march): levels = float2 [16][n] as left in the scratch of ia_hashgrid_fwd_xcd(out = NULL), xp [n,3] in [0,1].
+// Same first layer / Softplus as kind 0; only row 0 of the output layer (the SDF, rf/geometry.py:152-160) is evaluated
+// and 4 bytes per point are written instead of the 13-wide feature row.
+IA_EXPORT int ia_sdf_levels_fwd(int64_t n, const void* levels, const float* xp, const float* W1, const float* b1, const float* Wo,
+                                const float* bo, float* sdf, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    IA_REQUIRE(n < ((int64_t)1 << 31), "ia_sdf_levels_fwd: at most 2^31 points per call");
+    MlpArgs a = {};
+    a.n = n;
+    a.n_segs = 2;
+    for (int s = 0; s < MAX_SEGS; s++) { a.segs[s].p = nullptr; a.segs[s].stride = 0; a.segs[s].width = 0; a.segs[s].mul = 1.f; a.segs[s].add = 0.f; }
+    a.segs[0].p = (const float*)levels; a.segs[0].stride = (int)n; a.segs[0].width = 32;
+    a.segs[1].p = xp; a.segs[1].stride = 3; a.segs[1].width = 3; a.segs[1].mul = 2.0f; a.segs[1].add = -1.0f;
+    a.W1 = W1; a.b1 = b1; a.W2 = nullptr; a.b2 = nullptr; a.Wo = Wo; a.bo = bo;
+    a.y = sdf; a.y_stride = 1;
+    return launch_fwd<3, 35, 1, 1, 1, 0, false>(a, (hipStream_t)stream);
+}

@@ -19,6 +19,9 @@ template <int KIND> struct SegWidths;
 template <> struct SegWidths<0> { static constexpr int n = 2; static constexpr int w[MAX_SEGS] = {32, 3, 0, 0, 0}; };
 template <> struct SegWidths<1> { static constexpr int n = 5; static constexpr int w[MAX_SEGS] = {32, 3, 13, 16, 3}; };
 template <> struct SegWidths<2> { static constexpr int n = 3; static constexpr int w[MAX_SEGS] = {32, 3, 13, 0, 0}; };
+// kind 3: the SDF head fed straight from the level-major result of ia_hashgrid_fwd_xcd (segment 0 = float2 [16][n],
+// segs[0].stride = n), no [n,32] row in HBM
+template <> struct SegWidths<3> { static constexpr int n = 2; static constexpr int w[MAX_SEGS] = {32, 3, 0, 0, 0}; };
 
 // Two-phase segment transfer: all global loads of a tile are issued into registers first (SegRegs), the LDS stores
 // follow -- one exposed global-load latency per tile instead of one per segment.
@@ -96,6 +99,29 @@ __device__ __forceinline__ void assemble(float* sT, int ldx, const Seg* segs, in
 {
     using SW = SegWidths<KIND>;
     constexpr int IN_PAD = (IN + 1) / 2 * 2;
+    if constexpr (KIND == 3) {
+        // 16 levels x ROWS points of float2, level-major: lane -> (level, row) so that a half-wave reads 32 consecutive
+        // float2 (256 contiguous bytes) of ONE level; all loads in flight before the LDS stores
+        static_assert(ROWS == 32, "level-major assembly is written for 32-point tiles");
+        const float2* lv = reinterpret_cast<const float2*>(segs[0].p);
+        const int64_t ls = segs[0].stride;                  // points per level (= n)
+        float2 q[8];
+        SegRegs<3, ROWS> r1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int i = j * 64 + lane, lvl = i >> 5, row = i & 31;
+            q[j] = (p0 + row < n) ? lv[(int64_t)lvl * ls + p0 + row] : make_float2(0.f, 0.f);
+        }
+        seg_load(r1, segs[1], p0, n, lane);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int i = j * 64 + lane, lvl = i >> 5, row = i & 31;
+            sT[row * ldx + 2 * lvl] = q[j].x; sT[row * ldx + 2 * lvl + 1] = q[j].y;
+        }
+        seg_store(r1, sT, ldx, 32, segs[1], p0, n, lane);
+        if (IN_PAD > IN && lane < ROWS) sT[lane * ldx + IN] = 0.0f;
+        return;
+    }
     SegRegs<SW::w[0], ROWS> r0; SegRegs<SW::w[1], ROWS> r1; SegRegs<SW::w[2], ROWS> r2;
     SegRegs<SW::w[3], ROWS> r3; SegRegs<SW::w[4], ROWS> r4;
     seg_load(r0, segs[0], p0, n, lane); seg_load(r1, segs[1], p0, n, lane); seg_load(r2, segs[2], p0, n, lane);

@@ -102,6 +102,34 @@ class SNARFDeformer:
         return xc + corr, R
 
     @torch.no_grad()
+    def deform_sdf(self, pts: Tensor, geometry) -> Tensor:
+        """SDF at posed points, nothing else: SNARFDeformer.deform with with_grad = with_feature = False as the no-grad coarse
+        passes call it (coarse_alpha_fn / alpha_fn / coarse_alpha_sdf_fn).  Same search, filter and min-select as deform();
+        the candidates go through geometry.sdf_only and only sdf [P] is produced (1e5 where no candidate survives)."""
+        pts = pts.contiguous().float()
+        P, I = pts.shape[0], self.init_bones.shape[0]
+        dev = self.device
+        lib, st = L.lib(), L.stream()
+        x, valid, _ = self.search(pts)
+        mask = torch.empty((P, I), dtype=torch.bool, device=dev)
+        cnt = torch.empty(P, dtype=torch.int32, device=dev)
+        start = torch.empty(P, dtype=torch.int32, device=dev)
+        total = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.check(lib.ia_deform_filter_count(L.i64(P), L.i32(I), L.ptr(x), L.ptr(valid), L.ptr(mask), L.ptr(cnt), st),
+                "ia_deform_filter_count")
+        tmp = L.scan_tmp(P, dev)
+        L.check(lib.ia_exclusive_scan_i32(L.ptr(cnt), L.ptr(start), L.ptr(total), L.i64(P), L.ptr(tmp), st), "scan")
+        Q = int(total.item())
+        cand_x = torch.empty((Q, 3), device=dev)
+        cand_src = torch.empty(Q, dtype=torch.int32, device=dev)
+        L.check(lib.ia_deform_compact(L.i64(P), L.i32(I), L.ptr(x), L.ptr(mask), L.ptr(start), L.ptr(cand_x),
+                                      L.ptr(cand_src), st), "ia_deform_compact")
+        csdf = geometry.sdf_only(cand_x)
+        sdf = torch.empty(P, device=dev)
+        L.check(lib.ia_deform_select_min(L.i64(P), L.ptr(start), L.ptr(cnt), L.ptr(csdf), L.ptr(sdf), st), "ia_deform_select_min")
+        return sdf
+
+    @torch.no_grad()
     def deform(self, pts: Tensor, geometry, with_grad: bool = False, with_feature: bool = False, want_fwd: bool = False,
                want_jinv: bool = False):
         """SNARFDeformer.deform (snarf_deformer.py:187-261).

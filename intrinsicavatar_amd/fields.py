@@ -246,6 +246,28 @@ class VolumeSDF(nn.Module):
         return W1k, self.network.layers[0].bias, self.network.layers[2].effective(), self.network.layers[2].bias
 
     @torch.no_grad()
+    def sdf_only(self, points: Tensor) -> Tensor:
+        """SDF value alone (feature[:, 0] of VolumeSDF.forward, rf/geometry.py:152-160) for the no-grad coarse queries.  Large
+        batches: XCD-partitioned hash gather whose level-major result feeds the MLP kernel directly (no [n,32] feature rows,
+        no transpose pass, 4 instead of 52 output bytes per point); values equal forward()'s (same kernels' arithmetic)."""
+        n = points.shape[0]
+        if n < HASH_FWD_XCD_MIN or os.environ.get("IA_SDF_ONLY_FUSED", "1") != "1":
+            return self.forward(points, with_grad=False, with_feature=False).contiguous()
+        cfg = HASH
+        xp = ((points - self.center) / self.scale + 0.5).contiguous()
+        nb = int(L.lib().ia_hashgrid_fwd_scratch_bytes(L.i64(n), L.i32(cfg["n_levels"]), L.i32(0)))
+        scratch = torch.empty(nb, dtype=torch.uint8, device=xp.device)
+        L.check(L.lib().ia_hashgrid_fwd_xcd(L.i64(n), L.ptr(xp), L.ptr(self.grid_params), L.i32(cfg["n_levels"]),
+                                            L.i32(cfg["n_features_per_level"]), L.i32(cfg["log2_hashmap_size"]),
+                                            L.i32(cfg["base_resolution"]), L.f32(cfg["per_level_scale"]), L.ptr(None), L.i32(0),
+                                            L.ptr(None), L.ptr(scratch), L.stream()), "ia_hashgrid_fwd_xcd")
+        W1k, b1, W2, b2 = self.effective_weights()
+        sdf = torch.empty(n, device=xp.device)
+        L.check(L.lib().ia_sdf_levels_fwd(L.i64(n), L.ptr(scratch), L.ptr(xp), L.ptr(W1k.contiguous()), L.ptr(b1.contiguous()),
+                                          L.ptr(W2.contiguous()), L.ptr(b2.contiguous()), L.ptr(sdf), L.stream()), "ia_sdf_levels_fwd")
+        return sdf
+
+    @torch.no_grad()
     def forward(self, points: Tensor, with_grad=True, with_feature=True):
         """returns [sdf, (grad), (feature)] like VolumeSDF.forward (eval / no-grad path)."""
         n = points.shape[0]

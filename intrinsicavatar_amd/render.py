@@ -88,7 +88,7 @@ class RenderStep:
         unsorted evaluation, only the schedule changes."""
         n = pts.shape[0]
         if n < self.SORT_MIN_POINTS or os.environ.get("IA_SORT_POINTS", "1") != "1":
-            return self.deformer.deform(pts, self.geometry)["sdf"]
+            return self.deformer.deform_sdf(pts, self.geometry)
         import ctypes as C
         lo = self.aabbs[0, :3].tolist() if not hasattr(self, "_aabb_lo") else self._aabb_lo
         self._aabb_lo = lo
@@ -98,7 +98,7 @@ class RenderStep:
         order = torch.sort(keys)[1]
         ps = torch.empty_like(pts)
         L.check(L.lib().ia_gather_rows3(L.i64(n), L.ptr(pts), L.ptr(order), L.ptr(ps), L.stream()), "ia_gather_rows3")
-        sdf_s = self.deformer.deform(ps, self.geometry)["sdf"]
+        sdf_s = self.deformer.deform_sdf(ps, self.geometry)
         sdf = torch.empty_like(sdf_s)
         L.check(L.lib().ia_scatter_f32(L.i64(n), L.ptr(sdf_s), L.ptr(order), L.ptr(sdf), L.stream()), "ia_scatter_f32")
         return sdf

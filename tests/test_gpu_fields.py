@@ -257,3 +257,33 @@ def test_tcnn_encoding_dropin_first_and_second_order(fields):
     (TR.sh4(d64) * torch.arange(16).double()).sum().backward()
     np.testing.assert_allclose(N(d.grad), d64.grad.numpy(), rtol=1e-4, atol=1e-4)
     assert tcnn.free_temporary_memory() is None
+
+
+def test_sdf_only_query_path_equals_the_general_one(fields):
+    """geometry.sdf_only (level-major hash result -> SDF head, one output) and deformer.deform_sdf == the general forward /
+    deform on the same points, bit for bit (same kernels' arithmetic; only what is written differs)."""
+    from intrinsicavatar_amd import synthetic as S
+    rs, rays, _ = S.build_frame(DEV, 96, 96, pose_seed=0, beta=0.01, num_samples_per_ray=64, grid_D=16, grid_H=64, grid_W=64,
+                                smooth_iters=5, hash_amp=1e-2)
+    geo = rs.geometry
+    g = torch.Generator().manual_seed(0)
+    for n in (fields.HASH_FWD_XCD_MIN + 37, 5):                    # fused path / small-batch fallback
+        x = (geo.center + (torch.rand((n, 3), generator=g).to(DEV) - 0.5) * geo.scale).contiguous()
+        a = geo.sdf_only(x)
+        b = geo.forward(x, with_grad=False, with_feature=False)
+        assert torch.equal(a, b), float((a - b).abs().max())
+    r = rs.deformer.transform_rays_w2s(rays.float())
+    t = torch.rand((rays.shape[0], 40), generator=g).to(DEV) * 2.0 + 4.0
+    pts = (r[:, None, :3] + r[:, None, 3:6] * t[..., None]).reshape(-1, 3).contiguous()
+    assert pts.shape[0] > fields.HASH_FWD_XCD_MIN
+    d = rs.deformer.deform(pts, geo)
+    s = rs.deformer.deform_sdf(pts, geo)
+    assert torch.equal(s, d["sdf"]) and int((s < 1e5).sum()) > 1000
+    # spatial ordering of big batches does not change the values either
+    old = rs.SORT_MIN_POINTS
+    try:
+        rs.SORT_MIN_POINTS = 1000
+        s2 = rs._sdf_at(pts)
+    finally:
+        rs.SORT_MIN_POINTS = old
+    assert torch.equal(s2, s)
