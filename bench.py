@@ -55,19 +55,18 @@ VOXEL_J_BYTES = 32 * 128 * 128 * 48
 PROFILE_TAG = "r02"
 
 
-def algorithmic_bytes(name, calls):
+def algorithmic_bytes(name, calls, extra=None):
     """SURVEY.md 8(d) per-unit algorithmic bytes x the COUNTED units of every launch of one entry point.
     calls = [(ms, units, extras)].  Returns total bytes over the calls (None: no model for this entry point)."""
     n = sum(u for _, u, _ in calls)
     if name == "ia_fuse_broyden":
-        # compulsory HBM traffic per (point): 12 B target in; per init 12 B x + 1 B valid out (+36 B J_inv, +36 B fwd_J
-        # when requested) and the 25.2 MB voxel_J grid + tfs once per launch.  The <= 11 x 8-corner x 48 B gathers per
-        # (point, init) of SURVEY 8(d) are cache traffic (grid resident in L2 / Infinity Cache): see l1_roofline.
+        # SURVEY 8(d) row "Broyden (a7/K8)": per (point, init) 12 B target + 64 B bone row in, (1 + iters) x 8 corners x 48 B
+        # gathered (SURVEY gives the <= 11-fetch upper bound; here the fetches are COUNTED by ia_broyden_stats: `extra`
+        # = in-range corner loads of the step), 13 B out (x + valid; +36 B each for J_inv / fwd_J when requested).
         tot = 0
         for _, u, ex in calls:
-            per_init = 13 + (36 if ex["J_inv"] else 0) + (36 if ex["fwd_J"] else 0)
-            tot += u * (12 + ex["I"] * per_init) + VOXEL_J_BYTES + 24 * 64
-        return tot
+            tot += u * ex["I"] * (12 + 64 + 13 + (36 if ex["J_inv"] else 0) + (36 if ex["fwd_J"] else 0))
+        return tot + (extra or 0) * 48
     if name in ("ia_hashgrid_fwd", "ia_hashgrid_fwd_xcd"):
         return n * (12 + 1024 + 128)             # 12 B in + 16 levels x 8 corners x 8 B gathered + 128 B out
     if name in ("ia_hashgrid_bwd", "ia_hashgrid_bwd_binned"):
@@ -79,28 +78,31 @@ def algorithmic_bytes(name, calls):
     return None
 
 
-PMC_KERNELS = {          # C-ABI entry point -> substrings of the kernels it launches (rocprofv3 kernel names)
-    "ia_fuse_broyden": ["broyden_persistent_kernel", "broyden_kernel", "broyden_slim"],
-    "ia_hashgrid_fwd": ["hash_fwd_kernel"],
-    "ia_hashgrid_fwd_xcd": ["hash_fwd_xcd_kernel", "hash_transpose_kernel"],
-    "ia_hashgrid_bwd_binned": ["hash_bin", "hash_reduce_kernel"],
-    "ia_mlp_fwd": ["mlp_fwd_kernel"],
-    "ia_sdf_fused": ["sdf_fused_kernel"],
+# C-ABI entry point -> (mode, substrings of the kernels it launches in the rocprofv3 kernel names).  "alt": ONE of the kernels runs
+# per call (per-launch traffic = launch-weighted mean); "seq": all of them run per call (sum of their per-call traffic)
+PMC_KERNELS = {
+    "ia_fuse_broyden": ("alt", ["broyden_persistent2_kernel", "broyden_persistent_kernel", "broyden_kernel"]),
+    "ia_hashgrid_fwd": ("alt", ["hash_fwd_kernel"]),
+    "ia_hashgrid_fwd_xcd": ("seq", ["hash_fwd_xcd_kernel", "hash_transpose_kernel"]),
+    "ia_hashgrid_bwd_binned": ("seq", ["hash_bin", "hash_reduce_kernel"]),
+    "ia_mlp_fwd": ("alt", ["mlp_fwd_kernel<0", "mlp_fwd_kernel<1", "mlp_fwd_kernel<2"]),
+    "ia_sdf_levels_fwd": ("alt", ["mlp_fwd_kernel<3"]),
 }
 
 
-def pmc_traffic(entry):
-    """(HBM-side bytes per launch, source) of `entry` from the committed rocprofv3 PMC passes of THIS command
+def pmc_traffic(entry, calls_per_step=None):
+    """(HBM-side bytes per launch of the entry point, source) from the committed rocprofv3 PMC passes of THIS command
     (profiles/<tag>_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md), or (None, None)."""
     path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic.json")
     if entry not in PMC_KERNELS or not os.path.exists(path):
         return None, None
+    mode, subs = PMC_KERNELS[entry]
     ks = json.load(open(path))["kernels"]
-    hits = [v for k, v in ks.items() if any(sub in k for sub in PMC_KERNELS[entry])]
+    hits = [v for k, v in ks.items() if any(sub in k for sub in subs)]
     if not hits:
         return None, None
     tot = sum(v["hbm_side_bytes_per_launch"] * v["launches"] for v in hits)
-    calls = max(v["launches"] for v in hits)
+    calls = sum(v["launches"] for v in hits) if mode == "alt" else max(v["launches"] for v in hits)
     return int(tot / max(calls, 1)), f"profiles/{PROFILE_TAG}_pmc_traffic.json"
 
 
@@ -354,10 +356,10 @@ def main():
         breakdown = {}
         if per_call:
             dname, (dcalls, dms) = max(per_call.items(), key=lambda kv: kv[1][1])
-            ab = algorithmic_bytes(dname, detail[dname])
-            stats["deform_points"] = sum(u for _, u, _ in detail.get("ia_fuse_broyden", []))      # counted, not estimated
-            stats["hash_points"] = sum(u for k in ("ia_hashgrid_fwd", "ia_hashgrid_fwd_xcd", "ia_sdf_fused")
-                                       for _, u, _ in detail.get(k, []))
+            bro = count_broyden_fetches(step, dev) if (dname == "ia_fuse_broyden" and world == 1) else None   # one extra untimed step (a step has collectives: single rank only)
+            ab = algorithmic_bytes(dname, detail[dname], extra=(bro[1] * k_instr if bro else None))
+            stats["deform_points"] = sum(u for _, u, _ in detail.get("ia_fuse_broyden", [])) // k_instr      # counted, not estimated
+            stats["hash_points"] = sum(u for k in ("ia_hashgrid_fwd", "ia_hashgrid_fwd_xcd") for _, u, _ in detail.get(k, [])) // k_instr
             if ab:
                 avg_us = dms / dcalls * 1e3
                 achieved = ab / (dms * 1e-3) / 1e9
@@ -368,19 +370,26 @@ def main():
                                 units_per_step=sum(u for _, u, _ in detail[dname]) // k_instr,
                                 algorithmic_bytes_per_launch=int(ab / dcalls),
                                 share_of_kernel_time=round(dms / max(total_ms, 1e-9), 3))
-            if dname == "ia_fuse_broyden":
-                # what actually binds the search: every trilinear fetch of voxel_J is up to 8 corners x 48 B through
-                # the CU's vector L1; fetches and in-range corner loads are COUNTED by re-running the step's searches
-                # (ia_broyden_stats) in one extra untimed step
-                c = count_broyden_fetches(step, dev)
+            if bro:
+                # SURVEY 8(d) classes this stage "cache-gather latency": the gathers are served by L1 / L2 / Infinity Cache
+                # (voxel_J is 25 MB), so the algorithmic rate can exceed the HBM peak (frac > 1 = "not an HBM-bound kernel");
+                # what binds it is the CU's vector-memory path and VALU issue.  Next to it: the bytes that MUST
+                # cross HBM (targets in, x / valid out, the grid once per launch) and the L1-path rate.
+                c = bro
                 sec = dms / k_instr * 1e-3
+                items = max(c[2] + c[3] + c[4], 1)
+                comp = sum(u * (12 + ex["I"] * (13 + (36 if ex["J_inv"] else 0) + (36 if ex["fwd_J"] else 0))) + VOXEL_J_BYTES
+                           for _, u, ex in detail[dname]) / k_instr
+                roofline.update(algorithmic_model="SURVEY 8(d) Broyden row with COUNTED fetches: per (point, init) 76 B in + 13 B out + "
+                                                  "fetches x in-range corners x 48 B gathered",
+                                compulsory_hbm_GBps=round(comp / sec / 1e9, 1), compulsory_hbm_frac=round(comp / sec / 1e9 / HBM_PEAK_GBPS, 4))
                 l1_bytes = c[1] * 48.0
                 l1 = dict(bound="l1 (vector-memory path, 256 CUs x 64 B/clk x 2.4 GHz)", achieved=round(l1_bytes / sec / 1e9, 1),
                           peak=round(L1_PEAK_GBPS, 1), unit="GB/s", frac=round(l1_bytes / sec / 1e9 / L1_PEAK_GBPS, 4),
                           fetches_per_step=int(c[0]), corner_loads_per_step=int(c[1]), bytes_per_corner=48,
-                          fetches_per_item=round(c[0] / max(c[2] + c[3] + c[4], 1), 3),
+                          fetches_per_item=round(c[0] / items, 3), Gfetch_per_s=round(c[0] / sec / 1e9, 2),
                           items=dict(converged=int(c[2]), diverged=int(c[3]), exhausted=int(c[4])),
-                          note="latency-bound on the L1's outstanding misses, see profiles/r02_broyden_probe.json")
+                          note="VALU-issue / L1-latency bound: 49 Gfetch/s even with every item on one voxel (profiles/r02_broyden_probe.json)")
             breakdown = {k: dict(calls_per_step=v[0] / k_instr, ms_per_step=round(v[1] / k_instr, 3))
                          for k, v in sorted(per_call.items(), key=lambda kv: -kv[1][1])[:12]}
         cpu = None

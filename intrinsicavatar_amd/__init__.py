@@ -5,7 +5,9 @@ render_step hot path, exposed through the operator surface the reference imports
     intrinsicavatar_amd.lib_nerfacc   <- `lib.nerfacc` (ray_resampling*, pack/unpack)
     intrinsicavatar_amd.fast_snarf    <- fast-SNARF JIT modules (fuse_broyden, filter, precompute)
     intrinsicavatar_amd.tinycudann    <- `tinycudann` (Encoding: HashGrid / SphericalHarmonics, incl. double backward)
-    intrinsicavatar_amd.pbr           <- `lib.torch_pbr` call chains (estimators, BRDF sample / pdf, environment lights)
+    intrinsicavatar_amd.pbr           <- `lib.torch_pbr` (emitter / scatterer classes, colour helpers) + the fused estimators and the
+                                         kernels behind models/pbr/utils.py sample_volume_interaction
+    intrinsicavatar_amd.volrend       <- `models/volrend.py` (rendering, rendering_with_normals_sdf, rendering_with_normals_mats_sdf)
 
 All compute runs in hand-written HIP kernels behind the C ABI of include/ia_amd.h
 (libia_amd.so); PyTorch is used for device memory, streams and torch.distributed only.
@@ -26,6 +28,6 @@ def install_aliases() -> None:
     lib.nerfacc = lib_nerfacc
     sys.modules["lib"] = lib
     sys.modules["lib.nerfacc"] = lib_nerfacc
-    lib.torch_pbr = pbr                     # rgb_to_srgb, luminance, luma, max_value (+ the estimator kernels)
+    lib.torch_pbr = pbr                     # the eleven classes of models/__init__.py:39-51 + rgb_to_srgb, luminance, luma, max_value
     sys.modules["lib.torch_pbr"] = pbr
     sys.modules["tinycudann"] = tinycudann
