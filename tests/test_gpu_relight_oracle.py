@@ -218,3 +218,54 @@ def test_volume_interaction_kernels_vs_reference_op_sequence(setup, spp):
     for k in ("weights", "normals", "mats"):
         torch.testing.assert_close(ex_a[k].grad, ex_b[k].grad, rtol=2e-4, atol=2e-6, msg=k)
     torch.testing.assert_close(T_a.grad, T_b.grad, rtol=2e-5, atol=1e-7)
+
+
+def test_relight_full_size_properties():
+    """BASELINE config 3 at FULL size (540x540, render_mode=light, spp 256, GI off) through size-independent properties:
+    one K1 re-sample block of spp entries per ray with samples, fg / bg split consistent with the counts, per-ray re-sampled
+    weights <= 1, rays without samples show the background, finite non-negative radiance, transmittances in [0, 1], bit
+    reproducibility, and invariance (to float round-off) to how the frame is cut into ray chunks."""
+    from intrinsicavatar_amd import build
+    build.build()
+    from intrinsicavatar_amd import synthetic as S, fields, pbr
+    rs, rays, _ = S.build_frame(DEV, 540, 540, pose_seed=0, beta=0.01)
+    mat = fields.VolumeMaterial(seed=2).to(DEV)
+    env = pbr.EnvironmentLightTensor(T(hdri(256, 512)))
+    env.update_pdf()
+    spp, n = 256, rays.shape[0]
+    g = torch.Generator().manual_seed(0)
+    light_u = torch.rand((spp, 3), generator=g).to(DEV)
+    bg = torch.tensor([0.2, 0.4, 0.6], device=DEV)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    shuffle_u = torch.rand((n, spp), generator=gen, device=DEV)
+
+    def run(chunk):
+        img, tot = torch.empty((n, 3), device=DEV), dict(n_resampled=0, n_fg=0, n_secondary=0, hit=0)
+        for c0 in range(0, n, chunk):
+            o = rs.relight(rays[c0:c0 + chunk], mat, env, spp, light_u, shuffle_u[c0:c0 + chunk], background_color=bg,
+                           return_index_lists=(chunk == n))
+            img[c0:c0 + chunk] = o["comp_rgb_phys"]
+            for k in ("n_resampled", "n_fg", "n_secondary"):
+                tot[k] += o["stats"][k]
+            tot["hit"] += int((o["resampled_packed_info"][:, 1] > 0).sum())
+        return img, tot, o
+    img, tot, o = run(n)
+    assert tot["n_resampled"] == spp * tot["hit"] and 0 < tot["n_secondary"] <= tot["n_fg"] <= tot["n_resampled"]
+    assert tot["hit"] > 50000
+    rpi = o["resampled_packed_info"]
+    has = rpi[:, 1] > 0
+    assert torch.equal(rpi[has, 1], torch.full_like(rpi[has, 1], spp))
+    assert o["fg_indices"].numel() + o["bg_indices"].numel() == tot["n_resampled"]
+    rw_sum = torch.zeros(n, device=DEV).index_add_(0, o["resampled_ray_indices"], o["resampled_weights"])
+    assert float(rw_sum.max()) <= 1.0 + 5e-4 and float(o["resampled_weights"].min()) >= 0.0
+    assert torch.equal(img[~has], bg[None].expand(int((~has).sum()), 3))
+    assert torch.isfinite(img).all() and float(img.min()) >= 0.0
+    assert 0.0 <= float(o["secondary_tr"].min()) and float(o["secondary_tr"].max()) <= 1.0
+    img2, tot2, _ = run(n)
+    assert tot == tot2 and torch.equal(img, img2), float((img - img2).abs().max())     # bit reproducible
+    img3, tot3, _ = run(65536)                                                  # ray-chunk invariance (the secondary march of a
+    assert tot3 == tot                                                          # chunk is sorted per chunk: values are unchanged)
+    # values: batch-size dependent kernel choices (flat vs XCD-partitioned hash gather, two-pass vs fused traversal) differ
+    # in the last float bits, which moves a zero-crossing decision on a handful of secondary rays
+    diff = (img3 - img).abs().max(-1)[0]
+    assert float((diff > 1e-5).float().mean()) < 2e-3 and float(diff.max()) < 2e-2, (float(diff.max()), int((diff > 1e-5).sum()))

@@ -184,7 +184,8 @@ def shade_reference(P, fixed, target_rgb, target_mask, lambda_eik=0.1, lambda_ma
         loss = loss + lambda_mask * torch.nn.functional.binary_cross_entropy(op, target_mask)
     if laplace is not None:
         loss = loss + lambda_curv * laplace.abs().mean()
-    return loss, dict(comp_rgb=comp, opacity=opac, sdf_grad=sdf_grad, rgbs=rgbs, alphas=alphas)
+    return loss, dict(comp_rgb=comp, opacity=opac, sdf_grad=sdf_grad, rgbs=rgbs, alphas=alphas, weights=w, feat=feat, xp2=xp2,
+                      enc2=enc2)
 
 
 # ----------------------------------------------------------------------------- PBR (fp64, differentiable)
@@ -236,3 +237,37 @@ def pbr_uniform_light_t(n, albedo, rough, metal, view_dirs, wo, tr, base, R, inv
     w = (inv_pdf * cosm)[:, None]
     Ld, Ls = Li * diff[:, None] * w, Li * spec * w
     return ((1 - metal[:, None]) * albedo) * Ld + Ls, Ld, Ls
+
+
+def shade_reference_phys(P, fixed, target_rgb, target_mask, background, lambda_phys=1.0, **kw):
+    """shade_reference + the physically based branch of the training step (BASELINE config 4), float64 autograd:
+    material head on [radiance embedding | geometry feature] (models/intrinsic_avatar.py:1100-1113, pbr/material.py:31-51,
+    LipshitzMLP network_utils.py:396-428), re-sampled weights w / count and attribute gathers (models/pbr/utils.py:137-206),
+    uniform_light estimator on the GIVEN secondary rays (pbr_uniform_light_forward :654-753; directions, transmittance and
+    inverse pdf are no_grad constants there too), Lo.scatter_ + accumulate (:1335-1342,:1420-1466), L1 on the image.
+    fixed additionally carries: fg_src, fg_ray (int64 [F]), fg_counts [S], has_samples / has_bg (bool [n]), out_dirs, sec_tr,
+    inv_pdf, env_R."""
+    loss, r = shade_reference(P, fixed, target_rgb, target_mask, **kw)
+    nrm = lambda v: v / v.norm(dim=-1, keepdim=True).clamp_min(1e-6)     # noqa: E731
+    normal_smpl = nrm(r["sdf_grad"])
+    inp = torch.cat([r["xp2"] * 2 - 1, r["enc2"], r["feat"]], -1)
+    h = inp
+    for i in range(3):
+        Wm = P[f"mat_W{i}"]
+        c = torch.nn.functional.softplus(P[f"mat_c{i}"])
+        Wn = Wm * torch.clamp(c / Wm.abs().sum(dim=1), max=1.0)[:, None]
+        h = h @ Wn.T + P[f"mat_b{i}"]
+        h = torch.relu(h) if i < 2 else torch.sigmoid(h)
+    albedo, rough, metal = h[:, :3] * 0.77 + 0.03, h[:, 3] * 0.9 + 0.09, h[:, 4]
+    src, ray = fixed["fg_src"], fixed["fg_ray"]
+    w_fg = r["weights"][src] / fixed["fg_counts"][src].double()
+    Lo, _, _ = pbr_uniform_light_t(normal_smpl[src], albedo[src], rough[src], metal[src], fixed["rays_d"][ray], fixed["out_dirs"],
+                                   fixed["sec_tr"], P["env_base"], fixed["env_R"], fixed["inv_pdf"])
+    n_rays = fixed["n_rays"]
+    img = torch.zeros(n_rays, 3, dtype=Lo.dtype).index_add(0, ray, w_fg[:, None] * Lo)
+    T = (1.0 - r["opacity"][:, 0]) * fixed["has_bg"].double()
+    img = img + T[:, None] * background[None]
+    img = torch.where(fixed["has_samples"][:, None], img, background[None].expand(n_rays, 3))
+    loss = loss + lambda_phys * (img - target_rgb).abs().mean()
+    r.update(comp_rgb_phys=img, albedo=albedo, roughness=rough, metallic=metal)
+    return loss, r
