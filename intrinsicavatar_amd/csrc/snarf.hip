@@ -379,7 +379,10 @@ __global__ __launch_bounds__(THREADS) void broyden_persistent_kernel(
 // iteration.  It used to be two 64-bit divisions + fifteen global loads (target point, the bone's 4x4) per refill; now an
 // item is (chunk-local 32-bit counter) -> (point, init) by one multiply-high with a host-computed magic, and the bones'
 // rows (the 12 floats x0 = R^T (xd - t) needs) sit in LDS.  Results are bit-identical (the golden test runs all schedules).
-__global__ __launch_bounds__(THREADS) void broyden_persistent2_kernel(
+#ifndef IA_BR2_WAVES
+#define IA_BR2_WAVES 5
+#endif
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES, IA_BR2_WAVES))) void broyden_persistent2_kernel(
     int64_t total, int I, uint32_t magic_I, const float* __restrict__ xd_tgt, const float* __restrict__ voxel_J, int D, int H, int W,
     const float* __restrict__ tfs, const int32_t* __restrict__ bone_ids, const float* __restrict__ offset_g,
     const float* __restrict__ scale_g, float cvg_threshold, float dvg_threshold, float* __restrict__ x,

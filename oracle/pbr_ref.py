@@ -141,3 +141,32 @@ def brdf_sample(n, wi, alpha, u):
     h = (st * np.cos(phi))[:, None] * t + (st * np.sin(phi))[:, None] * b + ct[:, None] * n
     wo_s = 2 * (wi * h).sum(-1, keepdims=True) * h - wi
     return np.where((u[:, 0] < 0.5)[:, None], wo_d, wo_s).astype(np.float32)
+
+
+def uniform_sphere_stratified(n_theta, n_phi, u):
+    """emitter.sample_uniform_sphere_stratified restricted to the n_theta x n_phi strata the reference indexes
+    (models/intrinsic_avatar.py:680-689): equal-area strata in (cos theta, phi), one jittered direction each; pdf = 1/(4 pi)."""
+    i = np.repeat(np.arange(n_theta), n_phi).astype(np.float32)
+    j = np.tile(np.arange(n_phi), n_theta).astype(np.float32)
+    z = np.float32(1.0) - np.float32(2.0) * (i + u[:, 0]) / np.float32(n_theta)
+    phi = np.float32(2.0 * np.pi) * (j + u[:, 1]) / np.float32(n_phi)
+    r = np.sqrt(np.maximum(np.float32(1.0) - z * z, 0.0))
+    dirs = np.stack([r * np.cos(phi), r * np.sin(phi), z], -1).astype(np.float32)
+    return dirs, np.full((n_theta * n_phi, 1), 4.0 * np.pi, np.float32)
+
+
+def pbr_uniform_light_shade(normal, albedo, roughness, metallic, view_dirs, light_dirs, tr, ind_rgb, base, w2s_rot, inv_pdf):
+    """pbr_uniform_light_forward (models/intrinsic_avatar.py:654-753) after the secondary rays have been traced:
+    weight = inv_pdf (no light pdf), vis = 2 * transmittance."""
+    cos_mask = (normal * light_dirs).sum(-1) > 1e-6
+    diff, spec = brdf_eval(normal, -view_dirs, light_dirs, roughness, albedo, metallic)
+    t = np.where(cos_mask, np.clip(tr, 0, 1), 0.0)
+    dw = light_dirs @ w2s_rot
+    dw = dw / np.maximum(np.linalg.norm(dw, axis=-1, keepdims=True), 1e-6)
+    em = np.where((cos_mask & (t > 0))[:, None], envlight_eval(base, dw), 0.0)
+    Li = em * t[:, None] + (np.where(cos_mask[:, None], ind_rgb, 0.0) if ind_rgb is not None else 0.0)
+    Ld = np.where(cos_mask[:, None], Li * diff * inv_pdf[:, None], 0.0)
+    Ls = np.where(cos_mask[:, None], Li * spec * inv_pdf[:, None], 0.0)
+    Lo = (1 - metallic[:, None]) * albedo * Ld + Ls
+    vis = np.repeat((2.0 * t)[:, None], 3, 1)
+    return Lo.astype(np.float32), Ld.astype(np.float32), Ls.astype(np.float32), vis.astype(np.float32)

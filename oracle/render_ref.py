@@ -258,7 +258,7 @@ def light_shuffle(n_rays, spp, rpi, fg_idx, shuffle_u):
 
 
 def relight_step(sc, rays_world, spp=16, seed=0, light_u=None, shuffle_u=None, jitter=None, global_illumination=False,
-                 background_color=(1.0, 1.0, 1.0), importance_sample=True):
+                 background_color=(1.0, 1.0, 1.0), importance_sample=True, render_mode="light"):
     """forward_ with enable_phys, render_mode = light, eval form (models/intrinsic_avatar.py:950-1651): steps 1-4 as
     render_step, step 5 = rendering_with_normals_mats_sdf (volrend.py:810-1020), steps 6-8 = :1288-1470.
     light_u [spp,3] (emitter.sample uniforms) and shuffle_u [n_rays,spp] are explicit (drawn from `seed` when None).
@@ -294,9 +294,14 @@ def relight_step(sc, rays_world, spp=16, seed=0, light_u=None, shuffle_u=None, j
             F_ = len(fg_idx)
             R = sc.w2s[:3, :3]
             pmf = Pb.envlight_pmf(sc.env_base)
-            dirs_world = Pb.envlight_sample(pmf, spp, light_u[:, 0].astype(np.float64), light_u[:, 1].astype(np.float64),
-                                            light_u[:, 2].astype(np.float64))
-            dirs_smpl = _normalize(dirs_world @ R.T).astype(np.float32)                     # transform_dirs_w2s
+            if render_mode == "light":
+                dirs_world = Pb.envlight_sample(pmf, spp, light_u[:, 0].astype(np.float64), light_u[:, 1].astype(np.float64),
+                                                light_u[:, 2].astype(np.float64))
+                dirs_smpl = _normalize(dirs_world @ R.T).astype(np.float32)                 # transform_dirs_w2s
+                inv_pdf_all = None
+            else:                                                                            # uniform_light (:654-753, :1390-1401)
+                assert render_mode == "uniform_light" and spp == 512
+                dirs_smpl, inv_pdf_all = Pb.uniform_sphere_stratified(16, 32, light_u[:, :2])
             shuffled = light_shuffle(n, spp, rpi, fg_idx, shuffle_u)
             out_dirs = dirs_smpl[shuffled]
             cos_mask = (ex["normals"] * out_dirs).sum(-1) > 1e-6
@@ -308,9 +313,17 @@ def relight_step(sc, rays_world, spp=16, seed=0, light_u=None, shuffle_u=None, j
                                                         np.ascontiguousarray(out_dirs[cos_mask]))
                 sec_tr[cos_mask], sec_rgb[cos_mask] = np.clip(t_, 0.0, 1.0), c_
                 stats.update(st2)
-            fg_Lo, fg_Ld, fg_Ls = Pb.pbr_light_shade(ex["normals"], ex["albedo"], ex["roughness"][:, 0], ex["metallic"][:, 0],
-                                                     ex["t_dirs"], out_dirs, sec_tr[:, 0],
-                                                     sec_rgb if global_illumination else None, sc.env_base, pmf, R)
+            if render_mode == "light":
+                fg_Lo, fg_Ld, fg_Ls = Pb.pbr_light_shade(ex["normals"], ex["albedo"], ex["roughness"][:, 0], ex["metallic"][:, 0],
+                                                         ex["t_dirs"], out_dirs, sec_tr[:, 0],
+                                                         sec_rgb if global_illumination else None, sc.env_base, pmf, R)
+            else:
+                fg_Lo, fg_Ld, fg_Ls, fg_vis = Pb.pbr_uniform_light_shade(
+                    ex["normals"], ex["albedo"], ex["roughness"][:, 0], ex["metallic"][:, 0], ex["t_dirs"], out_dirs, sec_tr[:, 0],
+                    sec_rgb if global_illumination else None, sc.env_base, R, inv_pdf_all[shuffled][:, 0])
+                vis = np.zeros((len(rri), 3), np.float32)
+                vis[fg_idx] = fg_vis
+                out["visibility"] = O.accumulate_along_rays(rw, vis, rri, n).mean(-1, keepdims=True)      # :1414-1419
             Lo = np.zeros((len(rri), 3), np.float32)
             Lo[bg_idx] = bgc[None]                                                           # :1335-1342
             Lo[fg_idx] = fg_Lo

@@ -269,3 +269,37 @@ def test_relight_full_size_properties():
     # in the last float bits, which moves a zero-crossing decision on a handful of secondary rays
     diff = (img3 - img).abs().max(-1)[0]
     assert float((diff > 1e-5).float().mean()) < 2e-3 and float(diff.max()) < 2e-2, (float(diff.max()), int((diff > 1e-5).sum()))
+
+
+def test_relight_uniform_light_mode_vs_oracle(setup):
+    """render_mode = uniform_light (the training default, configs/config.yaml: spp 512 on the 16 x 32 stratified sphere;
+    the estimator of config 4 in its eval form) vs the oracle: per-sample radiance, image and the visibility map."""
+    from oracle import render_ref as R
+    rs, rays, mat, env, sc = setup(32)
+    n, spp = rays.shape[0], 512
+    rng = np.random.default_rng(7)
+    light_u = rng.random((spp, 3), dtype=np.float32)
+    shuffle_u = rng.random((n, spp), dtype=np.float32)
+    bg = np.array([0.0, 0.0, 0.0], np.float32)
+    ref = R.relight_step(sc, N(rays), spp=spp, light_u=light_u, shuffle_u=shuffle_u, global_illumination=True, background_color=bg,
+                         render_mode="uniform_light")
+    out = rs.relight(rays, mat, env, spp, T(light_u), T(shuffle_u), background_color=T(bg), global_illumination=True,
+                     render_mode="uniform_light", return_index_lists=True)
+    assert out["stats"]["n_resampled"] == ref["stats"]["n_resampled"] and ref["stats"]["n_fg"] > 500
+    fg_ref = np.zeros(ref["stats"]["n_resampled"], bool); fg_ref[ref["fg_indices"]] = True
+    fg_gpu = np.zeros(out["stats"]["n_resampled"], bool); fg_gpu[N(out["fg_indices"])] = True
+    same = fg_ref & fg_gpu
+    assert same.sum() >= 0.998 * fg_ref.sum()
+    ig, ir = (np.cumsum(fg_gpu) - 1)[same], (np.cumsum(fg_ref) - 1)[same]
+    assert np.array_equal(N(out["shuffled"])[ig], ref["shuffled"][ir])
+    tr_g, tr_r = N(out["secondary_tr"])[ig, 0], ref["secondary_tr"][ir, 0]
+    ok = np.abs(tr_g - tr_r) <= 2e-3
+    assert ok.mean() >= 0.99
+    Lo_g, Lo_r = N(out["fg_Lo"])[ig][ok], ref["fg_Lo"][ir][ok]
+    assert (np.abs(Lo_g - Lo_r).max(-1) <= 5e-3 * (np.abs(Lo_r).mean() + 1e-6) + 5e-3 * np.abs(Lo_r).max(-1)).mean() >= 0.99
+    has = ref["resampled_packed_info"][:, 1] > 0
+    for k, tol in (("comp_rgb_phys", 2e-2), ("visibility", 2e-2)):
+        a, b = N(out[k]), ref[k]
+        err = np.abs(a - b).max(-1)
+        assert (err <= tol * np.abs(b).max(-1) + tol).mean() >= 0.98, (k, float(err.max()))
+    assert float(N(out["visibility"])[has].max()) <= 2.0 + 1e-4 and float(N(out["visibility"])[~has].max(initial=0.0)) == 0.0
