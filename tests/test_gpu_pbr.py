@@ -369,7 +369,7 @@ def test_pbr_paths_with_rays_that_miss_everything():
     assert out["stats"]["n_samples"] == 0
     assert torch.allclose(out["comp_rgb_phys"], bg.expand(n, 3))
     target = torch.rand((n, 3), generator=g).to(DEV)
-    env_base = env.base.clone().requires_grad_(True)
+    env_base = env.base.detach().clone().requires_grad_(True)
     for p in rs.parameters() + list(mat.parameters()):
         p.grad = None
     res = rs.forward_backward_phys(away, target, mat, env, spp, light_u, shuffle_u, render_mode="uniform_light",

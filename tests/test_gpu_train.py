@@ -234,7 +234,7 @@ def test_phys_training_step_gradients():
     spp = 512
     light_u = torch.rand((spp, 3), generator=g).to(DEV)
     shuffle_u = torch.rand((n, spp), generator=g).to(DEV)
-    env_base = env.base.clone().requires_grad_(True)
+    env_base = env.base.detach().clone().requires_grad_(True)
     params = rs.parameters() + list(mat.parameters())
     jitter_n = torch.randn((400000, 3), generator=g).to(DEV)          # material jitter pass noise (explicit)
 

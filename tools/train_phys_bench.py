@@ -15,7 +15,7 @@ mat = fields.VolumeMaterial(seed=2).to(dev)
 yy, xx = np.meshgrid(np.linspace(0, np.pi, 256), np.linspace(-np.pi, np.pi, 512), indexing="ij")
 sky = (0.6 + 0.35 * np.cos(yy)[..., None] * np.array([1.0, 0.8, 0.6]) + 0.05 * np.sin(2 * xx)[..., None]).astype(np.float32)
 env = pbr.EnvironmentLightTensor(torch.from_numpy(sky).to(dev)); env.update_pdf()
-env_base = env.base.clone().requires_grad_(True)
+env_base = env.base.detach().clone().requires_grad_(True)
 g = torch.Generator().manual_seed(0)
 hit = torch.nonzero(rs.forward(rays)["opacity"][:, 0] > 0.5)[:, 0]          # sample pixels on the subject, like the trainer's fg sampler
 sel = hit[torch.randint(0, hit.shape[0], (n_batch,), generator=g).to(dev)]
