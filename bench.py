@@ -12,8 +12,8 @@ ray per foreground re-sample (render_mode=light, training form of pbr_light_forw
 secondary march + zero-crossing resampling + shading of every secondary ray (compute_indirect_radiance, :396-545,
 global_illumination on), Monte-Carlo estimator, composite, L1/eikonal/mask losses, backward to the hash grids, MLPs,
 density, material head and the spherical-Gaussian environment light, fused Adam.  The frame is processed in ray chunks
-with gradient accumulation (the reference trains on 4096-ray batches and tests on 4096-ray chunks; 288 GB of HBM take
-65 536).  `--workload config2` times BASELINE configs[1] (128 samples/ray, radiance + SDF geometry, no PBR branch) --
+of --ray-chunk rays with gradient accumulation (the reference trains on 4096-ray batches and tests on 4096-ray chunks;
+288 GB of HBM take the whole 291 600-ray frame and 16 Mi secondary rays at a time: the default is one chunk).  `--workload config2` times BASELINE configs[1] (128 samples/ray, radiance + SDF geometry, no PBR branch) --
 round 1's number, kept as a second key of the headline line (`config2_ms_per_step`).
 
 Synthetic data: random-init networks of the reference's architecture, synthetic 24-bone rig, procedural light; all
@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--hw", type=int, default=540)
     ap.add_argument("--spp", type=int, default=1024)
-    ap.add_argument("--ray-chunk", type=int, default=int(os.environ.get("IA_RAY_CHUNK", "65536")))
+    ap.add_argument("--ray-chunk", type=int, default=int(os.environ.get("IA_RAY_CHUNK", str(1 << 19))))
     ap.add_argument("--workload", choices=["headline", "config2"], default="headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config2", action="store_true", help="skip the secondary configs[1] measurement of the headline line")
@@ -179,10 +179,10 @@ def main():
     # Buffer sizes follow the sample counts, which move a little every step once the optimiser updates the geometry; with
     # exact-size caching the allocator keeps growing and a multi-GiB hipMalloc on a freshly booted box costs ~100 ms.
     # Size classes (1/8 power-of-two steps) make the blocks of one step reusable by the next, and one up-front
-    # reservation moves the remaining growth in front of the warm-up.  288 GB of HBM: the arena is < 20 % of the device.
+    # reservation moves the remaining growth in front of the warm-up.  288 GB of HBM: the arena is under half of the device.
     torch.cuda.memory._set_allocator_settings("roundup_power2_divisions:8")
     if not share_gpu:
-        _arena = torch.empty((48 if args.workload == "headline" else 24) << 30, dtype=torch.uint8, device=dev)
+        _arena = torch.empty((136 if args.workload == "headline" else 24) << 30, dtype=torch.uint8, device=dev)
         del _arena
     from intrinsicavatar_amd import build
     if rank == 0:
@@ -400,7 +400,8 @@ def main():
               f"resampling, fast-SNARF deformer (13 inits), SDF/radiance/material fields, samples_per_pixel={args.spp} volume-interaction "
               f"re-samples per ray, render_mode=light (one light-importance-sampled secondary ray per foreground re-sample, training form), "
               f"secondary march 64 steps + zero-crossing resampling + shading (global_illumination on), SG environment light; "
-              f"ray chunks of {args.ray_chunk} with gradient accumulation; random-init fields, synthetic 24-bone rig") if headline else \
+              f"{len(chunks)} ray chunk(s) of <= {args.ray_chunk} rays (gradient accumulation across chunks), secondary rays in chunks of 16 Mi; "
+              f"random-init fields, synthetic 24-bone rig") if headline else \
              (f"{args.hw}x{args.hw} frame ({n_rays} rays), 128 samples/ray, radiance + SDF geometry, fast-SNARF deformer (13 inits), "
               "2x importance resampling, random-init hash-grid/MLP fields, synthetic 24-bone rig")
         metric = (f"rays/sec (fwd+bwd) at {args.hw}x{args.hw}, {args.spp} spp" if headline else
@@ -415,6 +416,7 @@ def main():
                        "host_numa_node": numa_node, "host_cpus_busy": round(cpu_busy, 2), "blocking_sync": bool(blocking),
                        "host_cpu_throttled_ms_in_timed_region": (None if not (thr0 and thr1) else round((thr1[1] - thr0[1]) / 1e3, 1)),
                        "optimizer_step_in_timed_region": bool(opt is not None), "frames_per_step_per_gpu": 1,
+                       "peak_device_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                        "parallelism": f"frame/ray-batch sharding x{world}", "samples": stats},
             "roofline": roofline, "l1_roofline": l1, "cpu_baseline": cpu, "kernel_breakdown_ms_per_step": breakdown,
             "ms_per_step_instrumented": round(dt_instr / max(k_instr, 1) * 1e3, 3),

@@ -230,10 +230,11 @@ class RenderStep:
     # ------------------------------------------------------------------ secondary rays (compute_indirect_radiance)
     @torch.no_grad()
     def compute_indirect_radiance(self, rays_o: Tensor, rays_d: Tensor, near: float = 0.0, far: float = 1.5,
-                                  n_secondary: int = 64, chunk: int = 1 << 21):
+                                  n_secondary: int = 64, chunk: int = int(os.environ.get("IA_SECONDARY_CHUNK", str(1 << 24)))):
         """models/intrinsic_avatar.py:396-545 (eval): march each secondary ray over [near, far] (step (far-near)/63),
         SDF at the sample starts, zero-crossing resampling to 4 intervals (K4), shade them, composite.
-        returns (transmittance [M,1], indirect rgb [M,3]).  Rays are processed in chunks of `chunk` rays."""
+        returns (transmittance [M,1], indirect rgb [M,3]).  Rays are processed in chunks of `chunk` rays (16 Mi: ~145 M sample points
+        and ~25 GB of search outputs per chunk -- sized for 288 GB of HBM; measured 1067 -> 1008 ms per headline step against 2 Mi)."""
         M = rays_o.shape[0]
         dev = rays_o.device
         tr = torch.ones((M, 1), device=dev)

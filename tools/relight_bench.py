@@ -19,7 +19,7 @@ ap.add_argument("--frames", type=int, default=0, help="frames of the whole job (
 ap.add_argument("--hw", type=int, default=int(os.environ.get("IA_HW", "540")))
 ap.add_argument("--spp", type=int, default=int(os.environ.get("IA_SPP", "256")))
 ap.add_argument("--gi", action="store_true", default=os.environ.get("IA_GI", "0") == "1")
-ap.add_argument("--ray-chunk", type=int, default=int(os.environ.get("IA_RAY_CHUNK", "65536")))
+ap.add_argument("--ray-chunk", type=int, default=int(os.environ.get("IA_RAY_CHUNK", str(1 << 19))))
 args = ap.parse_args()
 world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
