@@ -88,6 +88,7 @@ def lib():
 
 
 def check(rc: int, what: str = ""):
+    _KEEPALIVE.clear()          # the call that consumed the pointers has enqueued its kernels: stream order protects them now
     if rc != 0:
         msg = lib().ia_last_error().decode(errors="replace")
         raise IaError(f"{what} failed (code {rc}): {msg}")
@@ -96,7 +97,7 @@ def check(rc: int, what: str = ""):
 # tensors whose pointers were handed out most recently: a temporary passed as `ptr(x.contiguous())` must stay alive until the
 # ctypes call that consumes the pointer has ENQUEUED its kernel -- otherwise the caching allocator may hand its block to the
 # next temporary of the same argument list (after the enqueue, stream order makes reuse safe).  64 > arguments per call.
-_KEEPALIVE = collections.deque(maxlen=64)
+_KEEPALIVE = collections.deque(maxlen=64)        # cleared by check() after every entry-point call
 
 
 def ptr(t):
