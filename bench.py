@@ -457,31 +457,55 @@ def count_broyden_fetches(step, dev):
     return cnt.cpu().tolist()
 
 
+def usable_cores():
+    """host cores this process may actually use: the affinity mask, capped by the cgroup's CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(rays, export, n_rays, headline, spp, phys=None):
-    """the CPU oracle (oracle/: a port of the reference's algorithm, test infrastructure) timed on this box's host cores on
-    a bounded sample of the same frame.  Forward only: the oracle has no backward."""
-    from oracle import render_ref as R, oracle as O
+    """the CPU oracle (oracle/: a port of the reference's algorithm, test infrastructure) timed on this box's host cores on a
+    bounded sample of the same frame: one single-threaded worker process per core (oracle/cpu_worker.py), each on its share
+    of the sample; rate = sample rays / slowest worker's compute time.  Forward only: the oracle has no backward."""
+    import subprocess
+    import tempfile
+    from oracle import oracle as O, cpu_worker as CW
     O.build()
-    sc = R.Scene(**export, **(phys or {}))
-    if headline and hasattr(R, "relight_step"):
-        stride = max(1, n_rays // 640)
-        sample = rays[::stride].cpu().numpy()
+    cores = min(usable_cores(), int(os.environ.get("IA_CPU_BASELINE_CORES", "32")))
+    per = 150 if headline else 6000                       # rays per worker: ~4 s of work each
+    n_sample = min(per * cores, n_rays)
+    stride = max(1, n_rays // n_sample)
+    sample = rays[::stride][:n_sample].cpu().numpy()
+    with tempfile.TemporaryDirectory() as td:
+        CW.save_scene(f"{td}/scene.npz", dict(export, **(phys or {})))
+        np.save(f"{td}/rays.npy", sample)
+        edges = [len(sample) * k // cores for k in range(cores + 1)]
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
         tc = time.perf_counter()
-        R.relight_step(sc, sample, spp=spp, seed=0)
-        tcpu = time.perf_counter() - tc
-        what = (f"every {stride}th ray of the same 540x540 frame ({sample.shape[0]} rays) x {spp} spp, oracle/render_ref.py "
-                f"relight_step (render_step FORWARD with the PBR branch: render_mode=light in its eval form -- {spp} shared light "
-                f"directions shuffled per ray --, secondary rays + indirect shading on), {tcpu:.1f} s")
-    else:
-        stride = max(1, n_rays // 24000)
-        sample = rays[::stride].cpu().numpy()
-        tc = time.perf_counter()
-        R.render_step(sc, sample)
-        tcpu = time.perf_counter() - tc
-        what = (f"every {stride}th ray of the same 540x540 frame ({sample.shape[0]} rays), oracle/render_ref.py render_step "
-                f"forward WITHOUT the PBR branch (configs[1] form), {tcpu:.1f} s")
-    return dict(value=round(sample.shape[0] / tcpu, 1), unit="rays/s", cores=1, kind="port", passes="forward only (the oracle has no backward)",
-                sample=what)
+        procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", f"{td}/scene.npz", f"{td}/rays.npy", str(edges[k]),
+                                   str(edges[k + 1]), str(spp if headline else 0)], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                                  stderr=subprocess.DEVNULL) for k in range(cores)]
+        times = []
+        for p_ in procs:
+            out, _ = p_.communicate(timeout=600)
+            if p_.returncode != 0:
+                return dict(value=None, unit="rays/s", cores=cores, kind="port", sample="worker failed")
+            times.append(float(out.decode().strip().splitlines()[-1]))
+        wall = time.perf_counter() - tc
+    tcpu = max(times)
+    form = (f"relight_step (render_step FORWARD with the PBR branch at {spp} spp: render_mode=light in its eval form -- shared light "
+            f"directions shuffled per ray --, secondary rays + indirect shading on)") if headline else \
+           "render_step forward WITHOUT the PBR branch (configs[1] form)"
+    return dict(value=round(len(sample) / tcpu, 1), unit="rays/s", cores=cores, kind="port", passes="forward only (the oracle has no backward)",
+                sample=f"every {stride}th ray of the same 540x540 frame ({len(sample)} rays), oracle/render_ref.py {form}; {cores} "
+                       f"single-threaded worker processes, slowest {tcpu:.1f} s, mean {sum(times) / len(times):.1f} s, {wall:.1f} s incl. start-up",
+                single_core_rays_per_s=round(len(sample) / sum(times), 2))
 
 
 if __name__ == "__main__":
