@@ -404,7 +404,14 @@ def main():
               f"random-init fields, synthetic 24-bone rig") if headline else \
              (f"{args.hw}x{args.hw} frame ({n_rays} rays), 128 samples/ray, radiance + SDF geometry, fast-SNARF deformer (13 inits), "
               "2x importance resampling, random-init hash-grid/MLP fields, synthetic 24-bone rig")
-        metric = (f"rays/sec (fwd+bwd) at {args.hw}x{args.hw}, {args.spp} spp" if headline else
+        base_metric = None
+        try:
+            base_metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+        except (OSError, KeyError, ValueError):
+            pass
+        # BASELINE.json's own metric string when the run IS that configuration (540x540, 1024 spp, fwd+bwd with the PBR branch)
+        metric = ((base_metric if (base_metric and args.hw == 540 and args.spp == 1024) else
+                   f"rays/sec (fwd+bwd) at {args.hw}x{args.hw}, {args.spp} spp") if headline else
                   (f"rays/sec (fwd+bwd) at {args.hw}x{args.hw}, no PBR branch (configs[1])" if args.mode == "fwd+bwd" else f"rays/sec (fwd) at {args.hw}x{args.hw}"))
         line = {
             "metric": metric, "value": round(value, 1), "unit": "rays/s",
