@@ -251,6 +251,15 @@ int ia_deform_filter_count(int64_t P, int I, const float* x /*[P,I,3]*/, const u
 /* packed candidate list in (point, init) order; start = exclusive scan of cnt */
 int ia_deform_compact(int64_t P, int I, const float* x, const uint8_t* mask, const int32_t* start,
                       float* cand_x /*[Q,3]*/, int32_t* cand_src /*[Q] = p*I+i*/, ia_stream_t stream);
+/* the three steps above (filter + count, exclusive scan, packed list) in one pass over x: a tile of points is filtered in
+ * LDS and written to its final place, the tile offsets come from a chained (look-back) scan.  cnt / start [P] as above,
+ * *total = Q.  cand_x must hold the packed list; it MAY BE x ITSELF (in-place compaction: the packed list is a prefix of
+ * x's storage, x is consumed).  cand_src and mask are optional (NULL).  tmp: ia_deform_filter_compact_tmp_bytes(P) bytes,
+ * 8-byte aligned.  Deterministic: identical outputs to the three separate calls. */
+size_t ia_deform_filter_compact_tmp_bytes(int64_t P);
+int ia_deform_filter_compact(int64_t P, int I, const float* x, const uint8_t* valid, int32_t* cnt /*[P]*/, int32_t* start /*[P]*/,
+                             float* cand_x /*[Q,3], or x*/, int32_t* cand_src /*[Q] or NULL*/, uint8_t* mask /*[P,I] or NULL*/,
+                             int32_t* total /*[1]*/, void* tmp, size_t tmp_bytes, ia_stream_t stream);
 /* first-minimum SDF over each point's candidates (1e5 / zeros / [0,0,1] defaults when none),
  * gradient pushed to posed space with c2w[cand_src] (3x3, row-major) */
 int ia_deform_select(int64_t P, const int32_t* start, const int32_t* cnt, const float* cand_x,

@@ -92,6 +92,215 @@ __global__ __launch_bounds__(THREADS) void compact_fill_kernel(int64_t P, int I,
     }
 }
 
+// ---- 1 + 2 in ONE pass: filter, count, chained scan, compaction ---------------------
+// filter_count -> exclusive scan -> compact_fill read x twice and the mask once more (338 B per point over three kernels).
+// Here a tile of FCC_ROWS points is staged into LDS once, filtered, counted, and its candidates are written straight to their
+// final positions: the tile's global offset comes from a decoupled look-back over the tile descriptors (status | value in
+// one 64-bit word).
+//  * cand_x MAY ALIAS x (in-place compaction): a tile only learns its offset after every earlier tile has published its
+//    count, i.e. after those tiles finished reading their rows, and its own output ends at or before the end of its own rows.
+//  * The descriptor accesses are RELAXED device-scope atomics on purpose: an acquire / release at device scope invalidates /
+//    writes back the XCD's whole L2 on this part (8 non-coherent L2s), once per tile -- measured 9x slower than the three
+//    kernels.  No fence is needed: a tile's count depends on the rows it loaded (so those loads are complete when the count
+//    is published), nothing written by this kernel is read back by it, and tiles are whole 128-byte lines.
+//  * tile = workgroup index: workgroups are dispatched in index order (per XCD as well), so the lowest unfinished tile is
+//    always resident and every wait ends.  A ticket counter instead costs one same-address device-scope atomic per tile, 30 ns
+//    each, serialised = 52 ms per step.  One poll covers FCC_LOOK x 64 predecessors (a 64-tile window ran at 18 ns per tile).
+//  * Measured alternatives that were slower (tools/filter_probe.py, 49 M points): 128-row tiles with a 512-tile window (5.4 ms
+//    against 4.6 ms: the look-back cost is per tile), persistent workgroups that load the next tile's rows into registers
+//    before the look-back of the current one (6.1 ms: 40 more live registers spill in the pair tests).  Loads alone: 2.2 ms.
+constexpr int FCC_ROWS = 256, FCC_LOOK = 4;
+constexpr uint64_t FCC_AGGREGATE = 1ull << 32, FCC_PREFIX = 2ull << 32;
+
+template <int IT>
+__global__ __launch_bounds__(FCC_ROWS) void filter_compact_kernel(int64_t P, int I_rt, uint32_t magic_I, int n_tiles, const float* x,
+                                                                  const uint8_t* __restrict__ valid, uint64_t* desc,
+                                                                  int32_t* __restrict__ cnt, int32_t* __restrict__ start, float* cand_x,
+                                                                  int32_t* __restrict__ cand_src, uint8_t* __restrict__ mask,
+                                                                  int32_t* __restrict__ total)
+{
+    const int I = IT > 0 ? IT : I_rt;
+    constexpr int U = IT > 0 ? (IT * 3 + 3) / 4 : (FC_MAX_I * 3) / 4;   // float4 per thread and tile
+    constexpr int UV = 4;                                              // valid words per thread and tile (I <= 16)
+    extern __shared__ __attribute__((aligned(16))) float s_x[];         // [ROWS][I*3]
+    uint8_t* s_v = reinterpret_cast<uint8_t*>(s_x + FCC_ROWS * I * 3);  // [ROWS][I]   (4-byte aligned)
+    __shared__ int s_lo[FCC_ROWS];
+    __shared__ unsigned short s_kb[FCC_ROWS];
+    __shared__ int s_wsum[FCC_ROWS / 64];
+    __shared__ int s_prefix;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    // tile strides are multiples of 16 bytes (x) and 4 bytes (valid): alignment is a property of the launch
+    const bool wide = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(valid) & 3) == 0;
+    float4 r[U];
+    uint32_t vw[UV];
+    auto tile_rows = [&](int tile) { const int64_t left = P - (int64_t)tile * FCC_ROWS; return (int)(left < FCC_ROWS ? left : FCC_ROWS); };
+    auto issue_loads = [&](int tile) {          // clamped, unconditional: the registers stay registers
+        const int rows = tile_rows(tile);
+        const int n4 = rows * I * 3 / 4, nw = rows * I / 4;
+        const float4* g4 = reinterpret_cast<const float4*>(x + (int64_t)tile * FCC_ROWS * I * 3);
+        const uint32_t* gw = reinterpret_cast<const uint32_t*>(valid + (int64_t)tile * FCC_ROWS * I);
+#pragma unroll
+        for (int u = 0; u < U; u++) r[u] = n4 > 0 ? g4[min(t + u * FCC_ROWS, n4 - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < UV; u++) vw[u] = nw > 0 ? gw[min(t + u * FCC_ROWS, nw - 1)] : 0u;
+    };
+    auto stage = [&](int tile) {                // registers (or, unaligned, global memory) -> LDS
+        const int rows = tile_rows(tile);
+        const int nf = rows * I * 3, nb = rows * I;
+        const float* gx = x + (int64_t)tile * FCC_ROWS * I * 3;
+        const uint8_t* gv = valid + (int64_t)tile * FCC_ROWS * I;
+        const int n4 = wide ? nf / 4 : 0, nw = wide ? nb / 4 : 0;
+        float4* s4 = reinterpret_cast<float4*>(s_x);
+        uint32_t* sw = reinterpret_cast<uint32_t*>(s_v);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (t + u * FCC_ROWS < n4) s4[t + u * FCC_ROWS] = r[u];
+#pragma unroll
+        for (int u = 0; u < UV; u++)
+            if (t + u * FCC_ROWS < nw) sw[t + u * FCC_ROWS] = vw[u];
+        for (int i = n4 * 4 + t; i < nf; i += FCC_ROWS) s_x[i] = gx[i];
+        for (int i = nw * 4 + t; i < nb; i += FCC_ROWS) s_v[i] = gv[i];
+    };
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {      // the host launches one workgroup per tile
+        if (wide) issue_loads(tile);
+        stage(tile);
+        __syncthreads();
+        const int64_t p0 = (int64_t)tile * FCC_ROWS;
+        const int rows = tile_rows(tile);
+        const int nb = rows * I;
+        // K9 (filter.cu:10-77): a valid candidate is dropped when a LATER valid one lies within 1e-4; same arithmetic as filter_kernel
+        unsigned keep_bits = 0;
+        if (t < rows) {
+            const float* xr = s_x + t * I * 3;
+            unsigned vbits = 0;
+            for (int i = 0; i < I; i++) vbits |= (s_v[t * I + i] ? 1u : 0u) << i;
+            if constexpr (IT > 0) {
+                // straight line: the row goes to registers with its LDS reads in flight together, then all IT (IT - 1) / 2 pair
+                // tests without a branch (the data-dependent loop below is a chain of ~15 dependent LDS round trips per point).
+                // (double)dist < 0.0001 * 0.0001 for a float dist <=> dist < the smallest float above that double (0x322bcc78).
+                const float thr = __uint_as_float(0x322bcc78u);
+                float xv[IT * 3];
+#pragma unroll
+                for (int k = 0; k < IT * 3; k++) xv[k] = xr[k];
+                unsigned kill = 0;                           // bit i: a LATER valid candidate lies within the threshold
+#pragma unroll
+                for (int i = 0; i < IT; i++) {
+#pragma unroll
+                    for (int j = i + 1; j < IT; j++) {
+                        const float d0 = xv[i * 3 + 0] - xv[j * 3 + 0];
+                        const float d1 = xv[i * 3 + 1] - xv[j * 3 + 1];
+                        const float d2 = xv[i * 3 + 2] - xv[j * 3 + 2];
+                        const float dist = d0 * d0 + d1 * d1 + d2 * d2;
+                        kill |= ((dist < thr) && ((vbits >> j) & 1u)) ? (1u << i) : 0u;
+                    }
+                }
+                keep_bits = vbits & ~kill;
+            } else {
+                for (int i = 0; i < I; i++) {
+                    if (!((vbits >> i) & 1u)) continue;
+                    const float xi0 = xr[i * 3 + 0], xi1 = xr[i * 3 + 1], xi2 = xr[i * 3 + 2];
+                    bool keep = true;
+                    for (unsigned rest = vbits >> (i + 1), j = i + 1; rest; rest >>= 1, j++) {
+                        if (!(rest & 1u)) continue;
+                        const float d0 = xi0 - xr[j * 3 + 0];
+                        const float d1 = xi1 - xr[j * 3 + 1];
+                        const float d2 = xi2 - xr[j * 3 + 2];
+                        const float dist = d0 * d0 + d1 * d1 + d2 * d2;
+                        if ((double)dist < 0.0001 * 0.0001) { keep = false; break; }
+                    }
+                    keep_bits |= (keep ? 1u : 0u) << i;
+                }
+            }
+        }
+        const int c = __popc(keep_bits);
+        // exclusive scan of the counts inside the tile
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) s_wsum[w] = incl;
+        __syncthreads();
+        int woff = 0, tile_total = 0;
+#pragma unroll
+        for (int k = 0; k < FCC_ROWS / 64; k++) {
+            if (k < w) woff += s_wsum[k];
+            tile_total += s_wsum[k];
+        }
+        const int lo = woff + incl - c;
+        s_lo[t] = lo;
+        s_kb[t] = (unsigned short)keep_bits;
+        // decoupled look-back (wave 0): exclusive prefix of the tile over all earlier tiles
+        if (w == 0) {
+            int excl = 0;
+            if (tile == 0) {
+                if (lane == 0) __hip_atomic_store(&desc[0], FCC_PREFIX | (uint32_t)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (lane == 0)
+                    __hip_atomic_store(&desc[tile], FCC_AGGREGATE | (uint32_t)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // one poll covers FCC_LOOK x 64 predecessors
+                int base = tile - 1, part = 0;
+                for (;;) {
+                    uint64_t d[FCC_LOOK];
+#pragma unroll
+                    for (int k = 0; k < FCC_LOOK; k++) {
+                        const int idx = base - (k * 64 + lane);
+                        d[k] = idx >= 0 ? __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FCC_PREFIX;
+                    }
+                    bool retry = false, done = false;
+                    int add = 0;
+#pragma unroll
+                    for (int k = 0; k < FCC_LOOK; k++) {
+                        if (retry || done) continue;                    // wave-uniform
+                        const uint32_t status = (uint32_t)(d[k] >> 32);
+                        const uint64_t full = __ballot(status == 2u), missing = __ballot(status == 0u);
+                        const int first_full = full ? __builtin_ctzll(full) : 64;
+                        const uint64_t window = first_full < 63 ? ((1ull << (first_full + 1)) - 1ull) : ~0ull;
+                        if (missing & window) { retry = true; continue; }     // a predecessor has not published yet
+                        add += ((window >> lane) & 1ull) ? (int)(uint32_t)d[k] : 0;
+                        done = first_full < 64;
+                    }
+                    if (retry) { __builtin_amdgcn_s_sleep(1); continue; }
+                    part += add;
+                    if (done) break;
+                    base -= 64 * FCC_LOOK;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+                excl = part;
+                if (lane == 0)
+                    __hip_atomic_store(&desc[tile], FCC_PREFIX | (uint32_t)(excl + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0) s_prefix = excl;
+        }
+        __syncthreads();
+        const int bp = s_prefix;
+        if (t < rows) {
+            cnt[p0 + t] = c;
+            start[p0 + t] = bp + lo;
+        }
+        if (tile == n_tiles - 1 && t == 0) *total = bp + tile_total;
+        // item-parallel write-out: consecutive lanes hold consecutive (point, init) items, so the kept ones land on consecutive
+        // 12-byte slots of the packed list
+        for (int e = t; e < nb; e += FCC_ROWS) {
+            const int rr = (int)__umulhi((uint32_t)e, magic_I);
+            const int i = e - rr * I;
+            const unsigned kb = s_kb[rr];
+            const bool kept = (kb >> i) & 1u;
+            if (mask) mask[p0 * I + e] = kept ? 1 : 0;
+            if (kept) {
+                const int64_t dst = (int64_t)bp + s_lo[rr] + __popc(kb & ((1u << i) - 1u));
+                cand_x[dst * 3 + 0] = s_x[e * 3 + 0];
+                cand_x[dst * 3 + 1] = s_x[e * 3 + 1];
+                cand_x[dst * 3 + 2] = s_x[e * 3 + 2];
+                if (cand_src) cand_src[dst] = (int32_t)(p0 * I + e);
+            }
+        }
+        __syncthreads();                         // everyone is done with this tile's LDS
+    }
+}
+
 // ---- 4'. min over a point's candidates, SDF only (no-grad coarse queries) ----------
 __global__ __launch_bounds__(THREADS) void select_min_kernel(int64_t P, const int32_t* __restrict__ start, const int32_t* __restrict__ cnt,
                                                               const float* __restrict__ cand_sdf, float* __restrict__ sdf_out)
@@ -326,6 +535,41 @@ IA_EXPORT int ia_deform_compact(int64_t P, int I, const float* x, const uint8_t*
     if (P == 0) return IA_OK;
     compact_fill_kernel<<<ia::cdiv(P, THREADS), THREADS, 0, (hipStream_t)stream>>>(P, I, x, mask, start, cand_x, cand_src);
     return ia::check_launch("ia_deform_compact");
+}
+
+IA_EXPORT size_t ia_deform_filter_compact_tmp_bytes(int64_t P)
+{
+    return (size_t)(ia::cdiv(P > 0 ? P : 1, FCC_ROWS)) * sizeof(uint64_t) + 16;
+}
+
+IA_EXPORT int ia_deform_filter_compact(int64_t P, int I, const float* x, const uint8_t* valid, int32_t* cnt, int32_t* start,
+                                       float* cand_x, int32_t* cand_src, uint8_t* mask, int32_t* total, void* tmp, size_t tmp_bytes,
+                                       ia_stream_t stream)
+{
+    IA_REQUIRE(total != nullptr, "ia_deform_filter_compact: total is required");
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 0) {
+        if (hipMemsetAsync(total, 0, sizeof(int32_t), s) != hipSuccess) return ia::check_launch("ia_deform_filter_compact(memset)");
+        return IA_OK;
+    }
+    IA_REQUIRE(I >= 1 && I <= FC_MAX_I, "ia_deform_filter_compact: at most 16 initialisations per point");
+    IA_REQUIRE(P * I < ((int64_t)1 << 31), "ia_deform_filter_compact: P * I must stay below 2^31");
+    const int64_t n_tiles = ia::cdiv(P, FCC_ROWS);
+    const size_t need = ia_deform_filter_compact_tmp_bytes(P);
+    IA_REQUIRE(tmp != nullptr && tmp_bytes >= need, "ia_deform_filter_compact: tmp too small (ia_deform_filter_compact_tmp_bytes)");
+    IA_REQUIRE((reinterpret_cast<uintptr_t>(tmp) & 7) == 0, "ia_deform_filter_compact: tmp must be 8-byte aligned");
+    if (hipMemsetAsync(tmp, 0, need, s) != hipSuccess) return ia::check_launch("ia_deform_filter_compact(memset)");
+    uint64_t* desc = reinterpret_cast<uint64_t*>(tmp);
+    const uint32_t magic = (uint32_t)((((uint64_t)1 << 32) + (uint64_t)I - 1) / (uint64_t)I);   // e / I for e < 2^16 (checked for I <= 16)
+    const size_t lds = (size_t)FCC_ROWS * I * 3 * sizeof(float) + (size_t)FCC_ROWS * I + 16;
+    const unsigned grid = (unsigned)n_tiles;
+    if (I == 13)      // the reference's 13 initialisations (snarf_deformer.py:98): straight-line filter
+        filter_compact_kernel<13><<<grid, FCC_ROWS, lds, s>>>(P, I, magic, (int)n_tiles, x, valid, desc, cnt, start, cand_x, cand_src, mask,
+                                                               total);
+    else
+        filter_compact_kernel<0><<<grid, FCC_ROWS, lds, s>>>(P, I, magic, (int)n_tiles, x, valid, desc, cnt, start, cand_x, cand_src, mask,
+                                                              total);
+    return ia::check_launch("ia_deform_filter_compact");
 }
 
 IA_EXPORT int ia_deform_select(int64_t P, const int32_t* start, const int32_t* cnt, const float* cand_x,

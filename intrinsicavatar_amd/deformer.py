@@ -11,6 +11,8 @@ boolean-mask index).
 """
 from typing import Optional
 
+import ctypes as C
+
 import torch
 from torch import Tensor
 
@@ -102,6 +104,26 @@ class SNARFDeformer:
         return xc + corr, R
 
     @torch.no_grad()
+    def _pack_candidates(self, x: Tensor, valid: Tensor, with_src: bool):
+        """K9 filter + per-point count + exclusive scan + packed candidate list (snarf_deformer.py:187-196's mask indexing) in
+        one pass, IN PLACE: the packed list [Q,3] is a prefix of x's storage (x [P,I,3] is consumed).
+        -> cand_x [Q,3], cand_src [Q] int32 (= p*I+i; None unless with_src), cnt [P], start [P], Q."""
+        P, I = valid.shape
+        dev = x.device
+        lib, st = L.lib(), L.stream()
+        cnt = torch.empty(P, dtype=torch.int32, device=dev)
+        start = torch.empty(P, dtype=torch.int32, device=dev)
+        total = torch.empty(1, dtype=torch.int32, device=dev)
+        src = torch.empty(P * I, dtype=torch.int32, device=dev) if with_src else None
+        nbytes = int(lib.ia_deform_filter_compact_tmp_bytes(L.i64(P)))
+        tmp = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
+        L.check(lib.ia_deform_filter_compact(L.i64(P), L.i32(I), L.ptr(x), L.ptr(valid), L.ptr(cnt), L.ptr(start), L.ptr(x),
+                                             L.ptr(src), L.ptr(None), L.ptr(total), L.ptr(tmp), C.c_size_t(tmp.numel() * 8), st),
+                "ia_deform_filter_compact")
+        Q = int(total.item())
+        return x.reshape(-1, 3)[:Q], (src[:Q] if with_src else None), cnt, start, Q
+
+    @torch.no_grad()
     def deform_sdf(self, pts: Tensor, geometry) -> Tensor:
         """SDF at posed points, nothing else: SNARFDeformer.deform with with_grad = with_feature = False as the no-grad coarse
         passes call it (coarse_alpha_fn / alpha_fn / coarse_alpha_sdf_fn).  Same search, filter and min-select as deform();
@@ -111,19 +133,7 @@ class SNARFDeformer:
         dev = self.device
         lib, st = L.lib(), L.stream()
         x, valid, _ = self.search(pts)
-        mask = torch.empty((P, I), dtype=torch.bool, device=dev)
-        cnt = torch.empty(P, dtype=torch.int32, device=dev)
-        start = torch.empty(P, dtype=torch.int32, device=dev)
-        total = torch.zeros(1, dtype=torch.int32, device=dev)
-        L.check(lib.ia_deform_filter_count(L.i64(P), L.i32(I), L.ptr(x), L.ptr(valid), L.ptr(mask), L.ptr(cnt), st),
-                "ia_deform_filter_count")
-        tmp = L.scan_tmp(P, dev)
-        L.check(lib.ia_exclusive_scan_i32(L.ptr(cnt), L.ptr(start), L.ptr(total), L.i64(P), L.ptr(tmp), st), "scan")
-        Q = int(total.item())
-        cand_x = torch.empty((Q, 3), device=dev)
-        cand_src = torch.empty(Q, dtype=torch.int32, device=dev)
-        L.check(lib.ia_deform_compact(L.i64(P), L.i32(I), L.ptr(x), L.ptr(mask), L.ptr(start), L.ptr(cand_x),
-                                      L.ptr(cand_src), st), "ia_deform_compact")
+        cand_x, _, cnt, start, Q = self._pack_candidates(x, valid, with_src=False)
         csdf = geometry.sdf_only(cand_x)
         sdf = torch.empty(P, device=dev)
         L.check(lib.ia_deform_select_min(L.i64(P), L.ptr(start), L.ptr(cnt), L.ptr(csdf), L.ptr(sdf), st), "ia_deform_select_min")
@@ -143,19 +153,7 @@ class SNARFDeformer:
             x, valid, fwd, J_inv = self.search(pts, want_fwd=with_grad or want_fwd, want_jinv=True)
         else:
             x, valid, fwd = self.search(pts, want_fwd=with_grad or want_fwd)
-        mask = torch.empty((P, I), dtype=torch.bool, device=dev)
-        cnt = torch.empty(P, dtype=torch.int32, device=dev)
-        start = torch.empty(P, dtype=torch.int32, device=dev)
-        total = torch.zeros(1, dtype=torch.int32, device=dev)
-        L.check(lib.ia_deform_filter_count(L.i64(P), L.i32(I), L.ptr(x), L.ptr(valid), L.ptr(mask), L.ptr(cnt), st),
-                "ia_deform_filter_count")
-        tmp = L.scan_tmp(P, dev)
-        L.check(lib.ia_exclusive_scan_i32(L.ptr(cnt), L.ptr(start), L.ptr(total), L.i64(P), L.ptr(tmp), st), "scan")
-        Q = int(total.item())
-        cand_x = torch.empty((Q, 3), device=dev)
-        cand_src = torch.empty(Q, dtype=torch.int32, device=dev)
-        L.check(lib.ia_deform_compact(L.i64(P), L.i32(I), L.ptr(x), L.ptr(mask), L.ptr(start), L.ptr(cand_x),
-                                      L.ptr(cand_src), st), "ia_deform_compact")
+        cand_x, cand_src, cnt, start, Q = self._pack_candidates(x, valid, with_src=True)
         # SDF network on the packed candidates
         cg = None
         r = geometry(cand_x, with_grad=with_grad, with_feature=True)      # feature[:, 0] is the SDF

@@ -388,3 +388,54 @@ def test_density_and_visibility_wrappers(ops):
     ref_vis = (t64 >= 1e-2) & (a64 >= 0.05)
     safe = (np.abs(t64 - 1e-2) > 1e-5) & (np.abs(a64 - 0.05) > 1e-5)
     assert np.array_equal(N(vis_a)[safe], ref_vis[safe]) and torch.equal(vis_a, vis_d)
+
+
+# ----------------------------------------------------------------------------- deformer candidate packing
+@pytest.mark.parametrize("P,I", [(1, 13), (127, 13), (128, 13), (129, 13), (255, 13), (256, 13), (257, 13), (100_003, 13), (6_000_001, 13), (50_000, 5), (70_001, 16)])
+@pytest.mark.parametrize("in_place", [False, True])
+def test_filter_compact_single_pass_equals_the_three_step_path(P, I, in_place):
+    """ia_deform_filter_compact (filter + count + chained scan + packed list in one pass, optionally in place over x)
+    == ia_deform_filter_count -> ia_exclusive_scan_i32 -> ia_deform_compact, bit for bit, and == fast_snarf.filter (K9)."""
+    import ctypes as C
+    from intrinsicavatar_amd import _lib as L, fast_snarf
+    lib, st = L.lib(), L.stream()
+    g = torch.Generator(device="cpu").manual_seed(P * 31 + I)
+    x = torch.rand(P, I, 3, generator=g)
+    # clusters of near-identical candidates (|dx| around the 1e-4 threshold), as converged searches produce
+    dup = torch.rand(P, I, generator=g) < 0.5
+    x = torch.where(dup[..., None], x[:, :1] + (torch.rand(P, I, 3, generator=g) - 0.5) * 1.6e-4, x)
+    valid = torch.rand(P, I, generator=g) < 0.6
+    x, valid = x.to(DEV), valid.to(DEV)
+    # three-step path
+    mask0 = torch.empty((P, I), dtype=torch.bool, device=DEV)
+    cnt0 = torch.empty(P, dtype=torch.int32, device=DEV)
+    start0 = torch.empty(P, dtype=torch.int32, device=DEV)
+    tot0 = torch.zeros(1, dtype=torch.int32, device=DEV)
+    L.check(lib.ia_deform_filter_count(L.i64(P), L.i32(I), L.ptr(x), L.ptr(valid), L.ptr(mask0), L.ptr(cnt0), st), "fc")
+    tmp = L.scan_tmp(P, DEV)
+    L.check(lib.ia_exclusive_scan_i32(L.ptr(cnt0), L.ptr(start0), L.ptr(tot0), L.i64(P), L.ptr(tmp), st), "scan")
+    Q = int(tot0.item())
+    cx0 = torch.empty((Q, 3), device=DEV)
+    cs0 = torch.empty(Q, dtype=torch.int32, device=DEV)
+    L.check(lib.ia_deform_compact(L.i64(P), L.i32(I), L.ptr(x), L.ptr(mask0), L.ptr(start0), L.ptr(cx0), L.ptr(cs0), st), "compact")
+    assert torch.equal(mask0, fast_snarf.filter(x[None], valid[None])[0])
+    # single pass
+    xin = x.clone()
+    cnt = torch.full((P,), -1, dtype=torch.int32, device=DEV)
+    start = torch.full((P,), -1, dtype=torch.int32, device=DEV)
+    tot = torch.full((1,), -1, dtype=torch.int32, device=DEV)
+    mask = torch.zeros((P, I), dtype=torch.bool, device=DEV)
+    src = torch.full((P * I,), -1, dtype=torch.int32, device=DEV)
+    out = xin if in_place else torch.full((P * I, 3), -1.0, device=DEV)
+    nb = int(lib.ia_deform_filter_compact_tmp_bytes(L.i64(P)))
+    tmp2 = torch.full(((nb + 7) // 8,), -1, dtype=torch.int64, device=DEV)        # the entry point clears its own scratch
+    for _ in range(2):                                                             # twice on the same scratch
+        if in_place:
+            xin.copy_(x)
+        L.check(lib.ia_deform_filter_compact(L.i64(P), L.i32(I), L.ptr(xin), L.ptr(valid), L.ptr(cnt), L.ptr(start), L.ptr(out),
+                                             L.ptr(src), L.ptr(mask), L.ptr(tot), L.ptr(tmp2), C.c_size_t(tmp2.numel() * 8), st), "fcc")
+    assert int(tot.item()) == Q and 0 < Q < int(valid.sum())
+    assert torch.equal(cnt, cnt0) and torch.equal(start, start0) and torch.equal(mask, mask0)
+    assert torch.equal(out.reshape(-1, 3)[:Q], cx0) and torch.equal(src[:Q], cs0)
+    if not in_place:
+        assert torch.equal(xin, x) and bool((out.reshape(-1, 3)[Q:] == -1).all())
