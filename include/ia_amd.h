@@ -357,7 +357,10 @@ int ia_pbr_shade_bwd(int mode, int64_t F, const float* normal, const float* albe
                      const float* indirect_rgb, const float* inv_pdf, const float* env_base, const float* env_pmf,
                      int env_h, int env_w, const float* w2s_rot, const float* g_Lo, const float* g_Lo_diff,
                      const float* g_Lo_spec, float* g_normal, float* g_albedo, float* g_roughness, float* g_metallic,
-                     float* g_env_base, ia_stream_t stream);
+                     float* g_env_base, void* scratch /*or NULL*/, size_t scratch_bytes, ia_stream_t stream);
+/* bytes of scratch (16-byte aligned) with which ia_pbr_shade_bwd accumulates g_env_base through per-sample records and LDS
+ * instead of 12 device-scope atomics per sample; 0 = the batch is too small to benefit (pass NULL). */
+size_t ia_pbr_shade_bwd_scratch_bytes(int64_t F);
 /* scatterer.sample / scatterer.pdf of the multi-lobe BRDF (1/2 cosine hemisphere + 1/2 GGX half-vector sampling);
  * u [F,3] uniforms = (lobe selector, u1, u2): explicit RNG */
 int ia_brdf_sample(int64_t F, const float* normal, const float* view_dirs, const float* roughness, const float* u,

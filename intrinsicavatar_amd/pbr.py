@@ -11,6 +11,8 @@ Random numbers are explicit inputs."""
 import math
 from typing import Dict, Optional
 
+import ctypes as C
+
 import torch
 from torch import Tensor
 
@@ -276,11 +278,13 @@ class _PbrShade(torch.autograd.Function):
         g_r, g_m = torch.empty(F_, device=dev), torch.empty(F_, device=dev)
         g_base = torch.zeros_like(env_base) if ctx.needs_input_grad[5] else None
         H, W, _ = env_base.shape
+        nb = int(L.lib().ia_pbr_shade_bwd_scratch_bytes(L.i64(F_))) if g_base is not None else 0
+        scratch = torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None
         L.check(L.lib().ia_pbr_shade_bwd(
             L.i32(ctx.mode), L.i64(F_), L.ptr(normal), L.ptr(albedo), L.ptr(roughness), L.ptr(metallic), L.ptr(view_dirs),
             L.ptr(out_dirs), L.ptr(tr), L.ptr(ind), L.ptr(inv_pdf), L.ptr(env_base), L.ptr(env_pmf), L.i32(H), L.i32(W),
             L.ptr(w2s_rot), L.ptr(c(g_Lo)), L.ptr(c(g_Ld)), L.ptr(c(g_Ls)), L.ptr(g_n), L.ptr(g_a), L.ptr(g_r), L.ptr(g_m),
-            L.ptr(g_base), L.stream()), "ia_pbr_shade_bwd")
+            L.ptr(g_base), L.ptr(scratch), C.c_size_t(nb), L.stream()), "ia_pbr_shade_bwd")
         return (None, g_n, g_a, g_r[:, None], g_m[:, None], g_base, None, None, None, None, None, None, None)
 
 
@@ -586,7 +590,7 @@ class _ScattererEval(torch.autograd.Function):
         L.check(L.lib().ia_pbr_shade_bwd(L.i32(1), L.i64(P), L.ptr(n), L.ptr(albedo), L.ptr(alpha), L.ptr(metallic), L.ptr(view),
                                          L.ptr(wo), L.ptr(zeros), L.ptr(ones3), L.ptr(ones), L.ptr(env), L.ptr(pmf), L.i32(1), L.i32(1),
                                          L.ptr(eye), L.ptr(None), L.ptr(g_Ld), L.ptr(g_Ls), L.ptr(g_n), L.ptr(g_a), L.ptr(g_r),
-                                         L.ptr(g_m), L.ptr(g_env), L.stream()), "ia_pbr_shade_bwd")
+                                         L.ptr(g_m), L.ptr(g_env), L.ptr(None), C.c_size_t(0), L.stream()), "ia_pbr_shade_bwd")
         if ctx.lobes == 1:       # the cosine lobe does not depend on the material
             g_a, g_r, g_m = torch.zeros_like(g_a), torch.zeros_like(g_r), torch.zeros_like(g_m)
         return None, g_n, None, None, g_r.reshape(ctx.shapes[0]), g_a, g_m.reshape(ctx.shapes[1])

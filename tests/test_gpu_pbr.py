@@ -290,6 +290,49 @@ def test_pbr_shade_backward_vs_autograd(env):
 
 
 
+@pytest.mark.parametrize("mode,hw", [("light", (256, 512)), ("uniform_light", (64, 128)), ("light", (40, 96))])
+def test_env_texel_gradient_banded_accumulation_equals_the_atomic_scatter(mode, hw, monkeypatch):
+    """large batches: ia_pbr_shade_bwd accumulates d L / d env texels through per-sample records and banded LDS sums; the
+    result is the direct atomic scatter's (IA_ENV_GRAD_ATOMIC=1) up to fp32 summation order, every other gradient is identical.
+    (256, 512) needs 13 bands, the others one; the sizes cover wrap-around in x and the clamped first / last rows."""
+    from intrinsicavatar_amd import pbr
+    F = (1 << 21) + 12345
+    g = torch.Generator(device=DEV).manual_seed(F + hw[0])
+    unit = lambda: torch.nn.functional.normalize(torch.randn(F, 3, device=DEV, generator=g), dim=-1)      # noqa: E731
+    n, wo = unit(), unit()
+    wo[: F // 50, 0] = 0.0                                   # directions on the u = 0 / 1 seam and at the poles
+    wo[F // 50: F // 25] = torch.tensor([0.0, 1.0, 0.0], device=DEV)
+    wo[F // 25: F // 16] = torch.tensor([0.0, -1.0, 0.0], device=DEV)
+    wo = torch.nn.functional.normalize(wo + 1e-7, dim=-1)
+    v = -torch.nn.functional.normalize(n + 0.5 * unit(), dim=-1)
+    alb = torch.rand(F, 3, device=DEV, generator=g) * 0.8 + 0.1
+    rough = torch.rand(F, 1, device=DEV, generator=g) * 0.7 + 0.2
+    met = torch.rand(F, 1, device=DEV, generator=g)
+    tr = (torch.rand(F, device=DEV, generator=g) * 1.4 - 0.4).clamp(0, 1)          # ~30 % fully occluded samples
+    inv_pdf = torch.full((F,), 4 * math.pi, device=DEV)
+    Rm = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(1)))[0].to(DEV)
+    base = torch.rand(*hw, 3, device=DEV, generator=g) + 0.2
+    e = pbr.EnvironmentLightTensor(base.clone()); e.update_pdf()
+    gl = torch.randn(F, 3, device=DEV, generator=g)
+    res = []
+    for atomic in ("1", None):
+        if atomic:
+            monkeypatch.setenv("IA_ENV_GRAD_ATOMIC", atomic)
+        else:
+            monkeypatch.delenv("IA_ENV_GRAD_ATOMIC")
+        leaves = [t.clone().requires_grad_(True) for t in (n, alb, rough, met, base)]
+        Lo, _, _ = pbr.pbr_shade_differentiable(mode, leaves[0], leaves[1], leaves[2], leaves[3], v, wo, tr, None, e, Rm,
+                                                inv_pdf=inv_pdf if mode == "uniform_light" else None, env_base=leaves[4])
+        (Lo * gl).sum().backward()
+        res.append([t.grad.clone() for t in leaves])
+    for a, b in zip(res[0][:4], res[1][:4]):
+        assert torch.equal(a, b)
+    ga, gb = res[0][4].double(), res[1][4].double()
+    assert float(ga.abs().max()) > 0
+    assert float((ga - gb).abs().max()) <= 2e-4 * float(ga.abs().max())
+    assert torch.equal(ga == 0, gb == 0)
+
+
 def test_sg_environment_light_trains_through_the_estimator():
     """envlight-SG: the lobe parameters receive gradients through generate_image -> ia_pbr_shade_bwd's texel gradient,
     and a few Adam steps on the lobes reduce an image-space loss (the light is learnable end to end)."""
