@@ -373,13 +373,14 @@ __device__ __forceinline__ void env_scatter(const EnvMap& e, float* __restrict__
 // execute at the memory side of the fabric (~21 G/s wherever they land): 31 ms for the 98.6 M samples of the headline step,
 // against 3 ms for everything else the backward kernel does.  Instead the backward kernel leaves one 24-byte record per sample
 // (texel x0 | y0 << 16 | (y1 == y0) << 31, the two bilinear fractions, the three channel gradients) and this kernel adds the
-// records up in LDS: the map is cut into horizontal bands of TH rows (+1 row for the y1 neighbours: <= 128 KB of LDS), the
+// records up in LDS: the map is cut into horizontal bands of TH rows (+1 row for the y1 neighbours: <= 112 KB of LDS), the
 // samples into n_ranges contiguous ranges, one workgroup per (range, band) streams the range's records, keeps those whose y0
 // lies in its band, and finally adds its band to g_base with one atomic per touched texel channel.  The bands of one range
 // run on one XCD (workgroup index modulo 8), so that a range's records come out of that XCD's L2 after the first reader.
 constexpr uint32_t ENV_REC_NONE = 0xFFFFFFFFu;
 constexpr int ENV_ACC_THREADS = 1024;
-constexpr int ENV_ACC_LDS = 128 * 1024;
+constexpr int ENV_ACC_LDS = 112 * 1024;             // band accumulator; + 32 KB of wave queues: 144 of the CU's 160 KB
+constexpr int ENV_Q = 512;                           // queue entries per wave (a stretch of 4 records per lane adds <= 256)
 
 __global__ __launch_bounds__(ENV_ACC_THREADS) void env_band_accumulate_kernel(int64_t F, const uint32_t* __restrict__ rec_idx,
                                                                               const float2* __restrict__ rec_w,
@@ -397,38 +398,67 @@ __global__ __launch_bounds__(ENV_ACC_THREADS) void env_band_accumulate_kernel(in
     __syncthreads();
     const int64_t per = ((F + n_ranges - 1) / n_ranges + 3) & ~(int64_t)3;         // multiple of 4: 16-byte index loads
     const int64_t i0 = (int64_t)range * per, i1 = min(F, i0 + per);
-    auto one = [&](int64_t i, uint32_t k) {
-        if (k == ENV_REC_NONE) return;
-        const int y0 = (int)((k >> 16) & 0x7FFFu) - y_lo;
-        if (y0 < 0 || y0 >= TH) return;
-        const int x0 = (int)(k & 0xFFFFu);
-        const int x1 = x0 + 1 == W ? 0 : x0 + 1;
-        const int y1 = (k >> 31) ? y0 : y0 + 1;
-        const float2 a = rec_w[i];
-        const float w00 = (1 - a.x) * (1 - a.y), w10 = a.x * (1 - a.y), w01 = (1 - a.x) * a.y, w11 = a.x * a.y;
+    // Only ~1 record in 2 n_bands belongs to this band: a wave first collects the matching records of a stretch in its own LDS
+    // queue (ballot + prefix append, no barrier: a wave's LDS operations execute in order) and then works the queue off with
+    // all lanes busy -- 64 records' weight / gradient loads in flight together and full-width LDS atomics.  (Handling a match
+    // where it is found costs every wave the whole matched path, two dependent global loads included, for one or two lanes:
+    // 9.3 ms per step instead of ~2.)
+    __shared__ uint32_t s_q[ENV_ACC_THREADS / 64][ENV_Q];        // offsets from i0 of the queued records
+    uint32_t* wq = s_q[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    int nq = 0;                                                    // wave-uniform
+    auto drain = [&]() {
+        for (int e = lane; e < nq; e += 64) {
+            const int64_t i = i0 + wq[e];
+            const uint32_t k = rec_idx[i];
+            const int y0 = (int)((k >> 16) & 0x7FFFu) - y_lo;
+            const int x0 = (int)(k & 0xFFFFu);
+            const int x1 = x0 + 1 == W ? 0 : x0 + 1;
+            const int y1 = (k >> 31) ? y0 : y0 + 1;
+            const float2 a = rec_w[i];
+            const float w00 = (1 - a.x) * (1 - a.y), w10 = a.x * (1 - a.y), w01 = (1 - a.x) * a.y, w11 = a.x * a.y;
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float g = rec_g[i * 3 + c];
-            if (g == 0.0f) continue;
-            atomicAdd(&s_acc[(y0 * W + x0) * 3 + c], w00 * g);
-            atomicAdd(&s_acc[(y0 * W + x1) * 3 + c], w10 * g);
-            atomicAdd(&s_acc[(y1 * W + x0) * 3 + c], w01 * g);
-            atomicAdd(&s_acc[(y1 * W + x1) * 3 + c], w11 * g);
+            for (int c = 0; c < 3; c++) {
+                const float g = rec_g[i * 3 + c];
+                if (g == 0.0f) continue;
+                atomicAdd(&s_acc[(y0 * W + x0) * 3 + c], w00 * g);
+                atomicAdd(&s_acc[(y0 * W + x1) * 3 + c], w10 * g);
+                atomicAdd(&s_acc[(y1 * W + x0) * 3 + c], w01 * g);
+                atomicAdd(&s_acc[(y1 * W + x1) * 3 + c], w11 * g);
+            }
         }
+        nq = 0;
     };
+    auto push = [&](int64_t i, uint32_t k) {
+        const int y0 = (int)((k >> 16) & 0x7FFFu) - y_lo;
+        const bool m = k != ENV_REC_NONE && y0 >= 0 && y0 < TH;
+        const uint64_t bal = __ballot(m);
+        if (m) wq[nq + __popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)(i - i0);
+        nq += __popcll(bal);
+    };
+    // trip counts are wave-uniform (push() ballots): whole strides of 8 records per thread first, then guarded strides of 4
     const bool a16 = (reinterpret_cast<uintptr_t>(rec_idx) & 15) == 0;
+    const int64_t n = i1 > i0 ? i1 - i0 : 0;
+    const int64_t n8 = a16 ? n / (8 * ENV_ACC_THREADS) : 0;
     int64_t i = i0 + (int64_t)threadIdx.x * 4;
-    if (a16) {
-        for (; i + 4 * ENV_ACC_THREADS + 3 < i1; i += 8 * ENV_ACC_THREADS) {          // two 16-byte index loads in flight per thread
-            const uint4 k0 = *reinterpret_cast<const uint4*>(rec_idx + i);
-            const uint4 k1 = *reinterpret_cast<const uint4*>(rec_idx + i + 4 * ENV_ACC_THREADS);
-            one(i, k0.x); one(i + 1, k0.y); one(i + 2, k0.z); one(i + 3, k0.w);
-            const int64_t j = i + 4 * ENV_ACC_THREADS;
-            one(j, k1.x); one(j + 1, k1.y); one(j + 2, k1.z); one(j + 3, k1.w);
-        }
+    for (int64_t it = 0; it < n8; it++, i += 8 * ENV_ACC_THREADS) {
+        const uint4 k0 = *reinterpret_cast<const uint4*>(rec_idx + i);
+        const uint4 k1 = *reinterpret_cast<const uint4*>(rec_idx + i + 4 * ENV_ACC_THREADS);
+        push(i, k0.x); push(i + 1, k0.y); push(i + 2, k0.z); push(i + 3, k0.w);
+        if (nq > ENV_Q - 4 * 64) drain();
+        const int64_t j = i + 4 * ENV_ACC_THREADS;
+        push(j, k1.x); push(j + 1, k1.y); push(j + 2, k1.z); push(j + 3, k1.w);
+        if (nq > ENV_Q - 4 * 64) drain();
     }
-    for (; i < i1; i += 4 * ENV_ACC_THREADS)
-        for (int u = 0; u < 4 && i + u < i1; u++) one(i + u, rec_idx[i + u]);
+    const int64_t rest0 = i0 + n8 * 8 * ENV_ACC_THREADS;
+    const int64_t n4 = (i1 - rest0 + 4 * ENV_ACC_THREADS - 1) / (4 * ENV_ACC_THREADS);
+    i = rest0 + (int64_t)threadIdx.x * 4;
+    for (int64_t it = 0; it < n4; it++, i += 4 * ENV_ACC_THREADS) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) push(i + u, i + u < i1 ? rec_idx[i + u] : ENV_REC_NONE);
+        if (nq > ENV_Q - 4 * 64) drain();
+    }
+    drain();
     __syncthreads();
     float* gb = g_base + (int64_t)y_lo * W * 3;
     for (int e = threadIdx.x; e < rows * W * 3; e += ENV_ACC_THREADS) {
