@@ -84,7 +84,9 @@ int ia_traverse_grids_fill(
 /* Single-launch variant for callers that can bound the output size (count + look-back scan + coalesced fill in one
  * kernel; identical outputs).  cap_edges / cap_samples = element capacity of the output arrays (< 2^31); totals[3]
  * (device) receives {n_edges, n_samples, overflow}: when overflow != 0 the outputs are incomplete and the caller must
- * fall back to the two-phase protocol above.  The flag arrays need NOT be zeroed.  scratch:
+ * fall back to the two-phase protocol above.  The flag arrays need NOT be zeroed.  sm_t_starts / sm_t_ends (both or
+ * neither): the interval ends per SAMPLE, i.e. iv_vals[iv_is_left] / iv_vals[iv_is_right] as every caller of traverse_grids
+ * forms them next (occ_grid sampling, models/intrinsic_avatar.py:396-428), without the two boolean-mask gathers.  scratch:
  * ia_traverse_fused_scratch_bytes(n_rays) bytes. */
 int64_t ia_traverse_fused_scratch_bytes(int64_t n_rays);
 int ia_traverse_grids_fused(int64_t n_rays, const float* rays_o, const float* rays_d, const uint32_t* grid_bits,
@@ -93,7 +95,8 @@ int ia_traverse_grids_fused(int64_t n_rays, const float* rays_o, const float* ra
                             int64_t cap_edges, int64_t cap_samples, int64_t* totals, int64_t* iv_packed_info,
                             int64_t* sm_packed_info, float* iv_vals, uint8_t* iv_is_left, uint8_t* iv_is_right,
                             int64_t* iv_ray_indices, float* sm_vals, int64_t* sm_ray_indices,
-                            float* termination_planes, ia_stream_t stream);
+                            float* termination_planes, float* sm_t_starts /*[cap_samples] or NULL*/,
+                            float* sm_t_ends /*[cap_samples] or NULL*/, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* nerfacc.render_weight_from_alpha / accumulate_along_rays

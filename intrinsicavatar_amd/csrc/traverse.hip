@@ -312,6 +312,7 @@ struct LdsRunSink {
 struct DirectWriteSink {       // in-order writes of one ray (rays with more than TR_RUNS runs); writes every flag
     float* iv_vals; uint8_t* iv_is_left; uint8_t* iv_is_right; int64_t* iv_ray; float* sm_vals; int64_t* sm_ray;
     int64_t iv_base, sm_base, tid;
+    float* sm_ts = nullptr; float* sm_te = nullptr;        // optional: interval ends per sample (= vals[is_left] / vals[is_right])
     int64_t n_samples = 0, n_intervals = 0;
     __device__ __forceinline__ void emit(float t_last, float t_next, bool continuous)
     {
@@ -327,6 +328,7 @@ struct DirectWriteSink {       // in-order writes of one ray (rays with more tha
         }
         const int64_t si = sm_base + n_samples;
         sm_vals[si] = (t_next + t_last) * 0.5f; sm_ray[si] = tid;
+        if (sm_ts) { sm_ts[si] = t_last; sm_te[si] = t_next; }
         n_samples++;
     }
 };
@@ -516,7 +518,8 @@ __global__ __launch_bounds__(TR_THREADS) void traverse_fused_kernel(
     int64_t cap_edges, int64_t cap_samples, int64_t* __restrict__ totals /*[3]: edges, samples, overflow*/,
     int64_t* __restrict__ iv_pinfo, int64_t* __restrict__ sm_pinfo, float* __restrict__ iv_vals,
     uint8_t* __restrict__ iv_is_left, uint8_t* __restrict__ iv_is_right, int64_t* __restrict__ iv_ray,
-    float* __restrict__ sm_vals, int64_t* __restrict__ sm_ray, float* __restrict__ term_planes)
+    float* __restrict__ sm_vals, int64_t* __restrict__ sm_ray, float* __restrict__ term_planes,
+    float* __restrict__ sm_ts /*or NULL*/, float* __restrict__ sm_te /*or NULL*/)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
     __shared__ float s_tfirst[TR_RUNS * TR_THREADS];
@@ -658,11 +661,12 @@ __global__ __launch_bounds__(TR_THREADS) void traverse_fused_kernel(
             const float t_next = t + calc_dt(t, cone_angle, step_size, 1e10f);
             const int64_t gs = baseS + sidx + k;
             sm_vals[gs] = (t_next + t) * 0.5f; sm_ray[gs] = ray;
+            if (sm_ts) { sm_ts[gs] = t; sm_te[gs] = t_next; }      // t_next IS the next edge's value (ia_advance is the exact recurrence)
         }
     }
     if (active && sink.n_runs > TR_RUNS) {
         DirectWriteSink w{iv_vals, iv_is_left, iv_is_right, iv_ray, sm_vals, sm_ray, baseE + s_offE[lane_wg],
-                          baseS + s_offS[lane_wg], tid};
+                          baseS + s_offS[lane_wg], tid, sm_ts, sm_te};
         (void)dda_walk(o, d, aabb, rx, ry, rz, near_plane, far_plane, step_size, cone_angle, s_bits, w);
     }
   }
@@ -755,9 +759,11 @@ IA_EXPORT int ia_traverse_grids_fused(int64_t n_rays, const float* rays_o, const
                                       float cone_angle, void* scratch, int64_t cap_edges, int64_t cap_samples,
                                       int64_t* totals, int64_t* iv_packed_info, int64_t* sm_packed_info, float* iv_vals,
                                       uint8_t* iv_is_left, uint8_t* iv_is_right, int64_t* iv_ray_indices, float* sm_vals,
-                                      int64_t* sm_ray_indices, float* termination_planes, ia_stream_t stream)
+                                      int64_t* sm_ray_indices, float* termination_planes, float* sm_t_starts,
+                                      float* sm_t_ends, ia_stream_t stream)
 {
     hipStream_t s = (hipStream_t)stream;
+    IA_REQUIRE((sm_t_starts == nullptr) == (sm_t_ends == nullptr), "sm_t_starts and sm_t_ends come together");
     if (hipMemsetAsync(totals, 0, 3 * sizeof(int64_t), s) != hipSuccess) return ia::check_launch("ia_traverse_grids_fused(memset)");
     if (n_rays == 0) return IA_OK;
     size_t lds;
@@ -780,6 +786,6 @@ IA_EXPORT int ia_traverse_grids_fused(int64_t n_rays, const float* rays_o, const
     traverse_fused_kernel<<<grid, TR_THREADS, lds, s>>>(
         n_rays, rays_o, rays_d, grid_bits, rx, ry, rz, aabb, near_planes, far_planes, step_size, cone_angle, state, ticket,
         tiles, cap_edges, cap_samples, totals, iv_packed_info, sm_packed_info, iv_vals, iv_is_left, iv_is_right,
-        iv_ray_indices, sm_vals, sm_ray_indices, termination_planes);
+        iv_ray_indices, sm_vals, sm_ray_indices, termination_planes, sm_t_starts, sm_t_ends);
     return ia::check_launch("ia_traverse_grids_fused");
 }

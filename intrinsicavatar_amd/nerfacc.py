@@ -40,10 +40,20 @@ class RaySamples:
     packed_info: Optional[Tensor] = None
     ray_indices: Optional[Tensor] = None
     is_valid: Optional[Tensor] = None
+    # extension (None when not produced): the interval ends per sample = intervals.vals[is_left] / intervals.vals[is_right]
+    t_starts: Optional[Tensor] = None
+    t_ends: Optional[Tensor] = None
 
     @property
     def device(self):
         return self.vals.device
+
+    def interval_ends(self, intervals: "RayIntervals"):
+        """(t_starts, t_ends) of the samples: the traversal's own arrays when it wrote them, else the boolean-mask gathers on
+        the edge list that the reference does (models/occ_grid/temporal_occ_grid.py sampling, intrinsic_avatar.py:396-428)."""
+        if self.t_starts is not None:
+            return self.t_starts, self.t_ends
+        return intervals.vals[intervals.is_left], intervals.vals[intervals.is_right]
 
 
 def pack_occupancy_bits(binaries: Tensor) -> Tensor:
@@ -156,18 +166,20 @@ def _traverse_fused(args, n_rays, aabb, step_size, max_extent, dev):
     iv_ray = torch.empty(cap_e, dtype=torch.int64, device=dev)
     sm_vals = torch.empty(cap_s, dtype=torch.float32, device=dev)
     sm_ray = torch.empty(cap_s, dtype=torch.int64, device=dev)
+    sm_ends = torch.empty((2, cap_s), dtype=torch.float32, device=dev)
     term = torch.empty(n_rays, dtype=torch.float32, device=dev)
     pinfo = torch.empty((2, n_rays, 2), dtype=torch.int64, device=dev)
     L.check(lib.ia_traverse_grids_fused(*args, L.ptr(scratch), L.i64(cap_e), L.i64(cap_s), L.ptr(totals), L.ptr(pinfo[0]),
                                         L.ptr(pinfo[1]), L.ptr(iv_vals), L.ptr(iv_flags[0]), L.ptr(iv_flags[1]), L.ptr(iv_ray),
-                                        L.ptr(sm_vals), L.ptr(sm_ray), L.ptr(term), st), "ia_traverse_grids_fused")
+                                        L.ptr(sm_vals), L.ptr(sm_ray), L.ptr(term), L.ptr(sm_ends[0]), L.ptr(sm_ends[1]), st),
+            "ia_traverse_grids_fused")
     E, S, ovf = (int(v) for v in totals.tolist())          # the one host sync (output sizes are data dependent)
     if ovf:
         return None
     intervals = RayIntervals(vals=iv_vals[:E], packed_info=pinfo[0], ray_indices=iv_ray[:E],
                              is_left=iv_flags[0, :E], is_right=iv_flags[1, :E])
     samples = RaySamples(vals=sm_vals[:S], packed_info=pinfo[1], ray_indices=sm_ray[:S],
-                         is_valid=torch.ones(S, dtype=torch.bool, device=dev))
+                         is_valid=torch.ones(S, dtype=torch.bool, device=dev), t_starts=sm_ends[0, :S], t_ends=sm_ends[1, :S])
     return intervals, samples, term
 
 
@@ -337,6 +349,5 @@ class OccGridEstimator(torch.nn.Module):
         intervals, samples, _ = traverse_grids(rays_o, rays_d, self.binaries, self.aabbs, near_planes=near_planes,
                                                far_planes=far_planes, step_size=render_step_size,
                                                cone_angle=cone_angle)
-        t_starts = intervals.vals[intervals.is_left]
-        t_ends = intervals.vals[intervals.is_right]
+        t_starts, t_ends = samples.interval_ends(intervals)
         return intervals, samples.ray_indices, t_starts, t_ends

@@ -93,7 +93,7 @@ class TemporalOccGridEstimator(torch.nn.Module):
                                                        near_planes=near_planes, far_planes=far_planes,
                                                        step_size=render_step_size, cone_angle=cone_angle,
                                                        grid_bits=self._grid_bits(lvl))
-        return intervals, samples.ray_indices, intervals.vals[intervals.is_left], intervals.vals[intervals.is_right]
+        return (intervals, samples.ray_indices) + samples.interval_ends(intervals)
 
     @torch.no_grad()
     def update_every_n_steps(self, step: int, t_idx: float, occ_eval_fn: Callable, occ_thre: float = 1e-2,

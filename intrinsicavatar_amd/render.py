@@ -248,7 +248,7 @@ class RenderStep:
             intervals, samples, _ = nerfacc.traverse_grids(
                 ro, rd, self.binaries, self.aabbs, torch.full((m,), near, device=dev), torch.full((m,), far, device=dev),
                 step, 0.0, grid_bits=self.grid_bits, max_extent=far - near)
-            t_starts, t_ends = intervals.vals[intervals.is_left], intervals.vals[intervals.is_right]
+            t_starts, t_ends = samples.interval_ends(intervals)
             ray_indices = samples.ray_indices
             if t_starts.numel() == 0:
                 continue

@@ -113,6 +113,11 @@ def test_traverse_fused_equals_two_pass(ops, oracle):
         for k in ("vals", "packed_info", "ray_indices"):
             assert torch.equal(getattr(a[1], k), getattr(b[1], k)), (name, "samples", k)
         assert torch.equal(a[2], b[2]), name
+        # the per-sample interval ends the fused traversal writes == the boolean-mask gathers on the edge list
+        assert a[1].t_starts is None and b[1].t_starts is not None
+        assert torch.equal(b[1].t_starts, a[0].vals[a[0].is_left]) and torch.equal(b[1].t_ends, a[0].vals[a[0].is_right]), name
+        ts, te = b[1].interval_ends(b[0])
+        assert ts is b[1].t_starts and torch.equal(a[1].interval_ends(a[0])[1], te)
         if name == "checker":
             assert int((a[0].packed_info[:, 1] - a[1].packed_info[:, 1]).max()) > 8      # rays with more than 8 runs
     # capacity overflow (a deliberately wrong extent hint) -> transparent fallback to the two-phase protocol
