@@ -487,6 +487,14 @@ int ia_morton_keys(int64_t n, const float* pts /*[n,3]*/, const float* origin_ho
                    int32_t* keys, ia_stream_t stream);
 int ia_gather_rows3(int64_t n, const float* src, const int64_t* order, float* dst, ia_stream_t stream);
 int ia_scatter_f32(int64_t n, const float* src, const int64_t* order, float* dst, ia_stream_t stream);
+/* the same ordering in one call: order [n] int32 = stable argsort of the Morton codes restricted to their bits [drop_bits, 30)
+ * (device radix sort of (key, index) pairs; 32-bit indices and 3 instead of 4 digit passes for drop_bits = 6), with the int32
+ * forms of the gather / scatter.  tmp: ia_morton_order_tmp_bytes(n) bytes, 256-byte aligned. */
+size_t ia_morton_order_tmp_bytes(int64_t n);
+int ia_morton_order(int64_t n, const float* pts /*[n,3]*/, const float* origin_host3, float inv_cell, int drop_bits,
+                    int32_t* order /*[n]*/, void* tmp, size_t tmp_bytes, ia_stream_t stream);
+int ia_gather_rows3_i32(int64_t n, const float* src, const int32_t* order, float* dst, ia_stream_t stream);
+int ia_scatter_f32_i32(int64_t n, const float* src, const int32_t* order, float* dst, ia_stream_t stream);
 
 /* GaussianHistogram (models/utils.py:133-149) of the albedo-entropy regulariser (models/pbr/material.py:59-70):
  * out[b] (caller-zeroed, accumulated) = sum_n exp(-0.5 ((x_n - c_b) / sigma)^2) / (sigma sqrt(2 pi)) * delta; sigma is a

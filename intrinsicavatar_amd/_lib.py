@@ -85,6 +85,8 @@ def lib():
         cdll.ia_eikonal_partials.restype = C.c_int64
         cdll.ia_deform_filter_compact_tmp_bytes.restype = C.c_size_t
         cdll.ia_pbr_shade_bwd_scratch_bytes.restype = C.c_size_t
+        cdll.ia_morton_order_tmp_bytes.restype = C.c_size_t
+        cdll.ia_morton_order_tmp_bytes.argtypes = [C.c_int64]
         cdll.ia_pbr_shade_bwd_scratch_bytes.argtypes = [C.c_int64]
         cdll.ia_deform_filter_compact_tmp_bytes.argtypes = [C.c_int64]
         _lib = _Timed(cdll)

@@ -29,6 +29,7 @@ SOURCES = {
     "deform.hip": ["-ffp-contract=off"],
     "pbr.hip": ["-munsafe-fp-atomics"],
     "volint.hip": ["-ffp-contract=off"],
+    "sort.hip": ["-ffp-contract=off"],
     "occgrid.hip": [],
     "optim.hip": ["-ffp-contract=off"],
 }

@@ -284,6 +284,38 @@ def test_sdf_only_query_path_equals_the_general_one(fields):
     try:
         rs.SORT_MIN_POINTS = 1000
         s2 = rs._sdf_at(pts)
+        rs.SORT_DROP_BITS = 6
+        s3 = rs._sdf_at(pts)
     finally:
         rs.SORT_MIN_POINTS = old
-    assert torch.equal(s2, s)
+        rs.SORT_DROP_BITS = 0
+    assert torch.equal(s2, s) and torch.equal(s3, s)
+
+
+@pytest.mark.parametrize("drop_bits", [0, 3, 6])
+def test_morton_order_is_a_stable_key_sort(drop_bits):
+    """ia_morton_order: a permutation that sorts the bits [drop_bits, 30) of the Morton keys, stable (equal keys keep their
+    input order) -- checked against torch.sort(stable=True) of ia_morton_keys' codes; int32 gather / scatter round trip."""
+    import ctypes as C
+    from intrinsicavatar_amd import _lib as L
+    lib, st = L.lib(), L.stream()
+    n = 3_000_017
+    g = torch.Generator(device=DEV).manual_seed(drop_bits)
+    pts = (torch.rand(n, 3, device=DEV, generator=g) * 3.0 - 1.5).contiguous()
+    pts[::5] = pts[1::5][: pts[::5].shape[0]]                             # many equal keys
+    origin = (C.c_float * 3)(-2.0, -2.0, -2.0)
+    keys = torch.empty(n, dtype=torch.int32, device=DEV)
+    L.check(lib.ia_morton_keys(L.i64(n), L.ptr(pts), origin, L.f32(100.0), L.ptr(keys), st), "keys")
+    want = torch.sort(keys >> drop_bits, stable=True)[1]
+    order = torch.empty(n, dtype=torch.int32, device=DEV)
+    nb = int(lib.ia_morton_order_tmp_bytes(L.i64(n)))
+    tmp = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    L.check(lib.ia_morton_order(L.i64(n), L.ptr(pts), origin, L.f32(100.0), L.i32(drop_bits), L.ptr(order), L.ptr(tmp), C.c_size_t(nb), st),
+            "ia_morton_order")
+    assert torch.equal(order.long(), want)
+    ps = torch.empty_like(pts)
+    L.check(lib.ia_gather_rows3_i32(L.i64(n), L.ptr(pts), L.ptr(order), L.ptr(ps), st), "gather")
+    assert torch.equal(ps, pts[want])
+    back = torch.empty(n, device=DEV)
+    L.check(lib.ia_scatter_f32_i32(L.i64(n), L.ptr(ps[:, 0].contiguous()), L.ptr(order), L.ptr(back), st), "scatter")
+    assert torch.equal(back, pts[:, 0])
