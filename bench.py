@@ -319,6 +319,9 @@ def main():
         torch.cuda.synchronize()
         dt_instr = time.perf_counter() - t1
         detail = lib.report(detail=True)
+        if os.environ.get("IA_BENCH_DETAIL"):       # per-launch (ms, units) of the instrumented step(s), for tuning
+            for name_, calls_ in sorted(detail.items(), key=lambda kv: -sum(c[0] for c in kv[1]))[:10]:
+                print(name_, [(round(c[0], 2), c[1]) for c in calls_], file=sys.stderr)
     if world > 1:
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -495,6 +495,8 @@ int ia_morton_order(int64_t n, const float* pts /*[n,3]*/, const float* origin_h
                     int32_t* order /*[n]*/, void* tmp, size_t tmp_bytes, ia_stream_t stream);
 int ia_gather_rows3_i32(int64_t n, const float* src, const int32_t* order, float* dst, ia_stream_t stream);
 int ia_scatter_f32_i32(int64_t n, const float* src, const int32_t* order, float* dst, ia_stream_t stream);
+int ia_scatter_rows3_i32(int64_t n, const float* src /*[n,3]*/, const int32_t* order, float* dst /*[n,3]: dst[order[i]] = src[i]*/,
+                         ia_stream_t stream);
 
 /* GaussianHistogram (models/utils.py:133-149) of the albedo-entropy regulariser (models/pbr/material.py:59-70):
  * out[b] (caller-zeroed, accumulated) = sum_n exp(-0.5 ((x_n - c_b) / sigma)^2) / (sigma sqrt(2 pi)) * delta; sigma is a

@@ -52,6 +52,15 @@ __global__ __launch_bounds__(THREADS) void scatter_f32_i32_kernel(int64_t n, con
     dst[order[i]] = src[i];
 }
 
+__global__ __launch_bounds__(THREADS) void scatter_rows3_i32_kernel(int64_t n, const float* __restrict__ src, const int32_t* __restrict__ order,
+                                                                     float* __restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const int64_t j = order[i];
+    dst[3 * j] = src[3 * i]; dst[3 * j + 1] = src[3 * i + 1]; dst[3 * j + 2] = src[3 * i + 2];
+}
+
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 size_t sort_storage_bytes(int64_t n, int drop_bits)
@@ -111,4 +120,11 @@ IA_EXPORT int ia_scatter_f32_i32(int64_t n, const float* src, const int32_t* ord
     if (n == 0) return IA_OK;
     scatter_f32_i32_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, src, order, dst);
     return ia::check_launch("ia_scatter_f32_i32");
+}
+
+IA_EXPORT int ia_scatter_rows3_i32(int64_t n, const float* src, const int32_t* order, float* dst, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    scatter_rows3_i32_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, src, order, dst);
+    return ia::check_launch("ia_scatter_rows3_i32");
 }

@@ -134,6 +134,30 @@ def test_compute_indirect_radiance_visibility(frame):
     assert float(rgb_in.max()) <= 1 + 1e-5 and float(rgb_in.min()) >= 0
 
 
+def test_secondary_march_in_spatial_order_is_the_unsorted_march(frame, monkeypatch):
+    """compute_indirect_radiance evaluates big batches (march samples and the K4 shading points) in Morton order of the points;
+    that only reschedules per-point work: transmittance and indirect radiance are bit-identical to the ray-order evaluation."""
+    rs, rays, _ = frame
+    out = rs.forward(rays)
+    hit = out["opacity"][:, 0] > 0.9
+    r = rs.deformer.transform_rays_w2s(rays.float())
+    p = r[hit, :3] + r[hit, 3:6] * out["depth"][hit]
+    g = torch.Generator(device=DEV).manual_seed(0)
+    k = 200                                                                     # directions per surface point
+    o = (p[:, None, :] - 0.03 * r[hit, None, 3:6]).expand(-1, k, -1).reshape(-1, 3).contiguous()
+    d = torch.nn.functional.normalize(torch.randn(o.shape[0], 3, device=DEV, generator=g), dim=-1).contiguous()
+    old = rs.SORT_MIN_POINTS
+    try:
+        rs.SORT_MIN_POINTS = 1000
+        tr_s, rgb_s = rs.compute_indirect_radiance(o, d)
+        monkeypatch.setenv("IA_SORT_POINTS", "0")
+        tr_u, rgb_u = rs.compute_indirect_radiance(o, d)
+    finally:
+        rs.SORT_MIN_POINTS = old
+    assert torch.equal(tr_s, tr_u) and torch.equal(rgb_s, rgb_u)
+    assert 0.05 < float((tr_u < 0.5).float().mean()) < 0.95 and float(rgb_u.max()) > 0          # both outcomes occur
+
+
 def test_relight_pipeline_invariants(frame, env):
     rs, rays, mat = frame
     n = rays.shape[0]
