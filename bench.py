@@ -392,7 +392,7 @@ def main():
                           fetches_per_step=int(c[0]), corner_loads_per_step=int(c[1]), bytes_per_corner=48,
                           fetches_per_item=round(c[0] / items, 3), Gfetch_per_s=round(c[0] / sec / 1e9, 2),
                           items=dict(converged=int(c[2]), diverged=int(c[3]), exhausted=int(c[4])),
-                          note="VALU-issue / L1-latency bound: 49 Gfetch/s even with every item on one voxel (profiles/r02_broyden_probe.json)")
+                          note="texture-addresser bound: a 16-byte gather instruction takes ~32 clk whatever it hits -- 49 Gfetch/s with EVERY item on one voxel (profiles/r02_broyden_probe.json), 50-51 on the step's spatially sorted batches")
             breakdown = {k: dict(calls_per_step=v[0] / k_instr, ms_per_step=round(v[1] / k_instr, 3))
                          for k, v in sorted(per_call.items(), key=lambda kv: -kv[1][1])[:12]}
         cpu = None
