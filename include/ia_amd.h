@@ -263,6 +263,17 @@ size_t ia_deform_filter_compact_tmp_bytes(int64_t P);
 int ia_deform_filter_compact(int64_t P, int I, const float* x, const uint8_t* valid, int32_t* cnt /*[P]*/, int32_t* start /*[P]*/,
                              float* cand_x /*[Q,3], or x*/, int32_t* cand_src /*[Q] or NULL*/, uint8_t* mask /*[P,I] or NULL*/,
                              int32_t* total /*[1]*/, void* tmp, size_t tmp_bytes, ia_stream_t stream);
+/* the same packing in two steps with no dependence between tiles (faster: the look-back above runs at half the rate of its
+ * loads).  ia_deform_filter_tiles: filter + count, every 256-point tile's candidates packed IN PLACE at the start of the tile's
+ * own rows of x (x is consumed; (point, init) indices likewise into src_local [P*I], optional), cnt [P], tile-local start [P],
+ * *total = Q.  The host reads Q and allocates cand_x [Q,3]; ia_deform_pack_tiles copies the tile blocks there (cand_x must not
+ * alias x; cand_src [Q] iff src_local) and makes start global.  tmp (ia_deform_filter_tiles_tmp_bytes(P) bytes, 8-byte aligned)
+ * carries the tile offsets from the first call to the second. */
+size_t ia_deform_filter_tiles_tmp_bytes(int64_t P);
+int ia_deform_filter_tiles(int64_t P, int I, float* x, const uint8_t* valid, int32_t* cnt, int32_t* start, int32_t* src_local /*or NULL*/,
+                           uint8_t* mask /*or NULL*/, int32_t* total, void* tmp, size_t tmp_bytes, ia_stream_t stream);
+int ia_deform_pack_tiles(int64_t P, int I, const float* x, const int32_t* src_local /*or NULL*/, int32_t* start, float* cand_x,
+                         int32_t* cand_src /*or NULL*/, const void* tmp, ia_stream_t stream);
 /* first-minimum SDF over each point's candidates (1e5 / zeros / [0,0,1] defaults when none),
  * gradient pushed to posed space with c2w[cand_src] (3x3, row-major) */
 int ia_deform_select(int64_t P, const int32_t* start, const int32_t* cnt, const float* cand_x,

@@ -84,6 +84,8 @@ def lib():
         cdll.ia_hashgrid_fwd_scratch_bytes.restype = C.c_int64
         cdll.ia_eikonal_partials.restype = C.c_int64
         cdll.ia_deform_filter_compact_tmp_bytes.restype = C.c_size_t
+        cdll.ia_deform_filter_tiles_tmp_bytes.restype = C.c_size_t
+        cdll.ia_deform_filter_tiles_tmp_bytes.argtypes = [C.c_int64]
         cdll.ia_pbr_shade_bwd_scratch_bytes.restype = C.c_size_t
         cdll.ia_morton_order_tmp_bytes.restype = C.c_size_t
         cdll.ia_morton_order_tmp_bytes.argtypes = [C.c_int64]

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(THREADS) void compact_fill_kernel(int64_t P, int I,
 constexpr int FCC_ROWS = 256, FCC_LOOK = 4;
 constexpr uint64_t FCC_AGGREGATE = 1ull << 32, FCC_PREFIX = 2ull << 32;
 
-template <int IT>
+template <int IT, bool LOCAL>
 __global__ __launch_bounds__(FCC_ROWS) void filter_compact_kernel(int64_t P, int I_rt, uint32_t magic_I, int n_tiles, const float* x,
                                                                   const uint8_t* __restrict__ valid, uint64_t* desc,
                                                                   int32_t* __restrict__ cnt, int32_t* __restrict__ start, float* cand_x,
@@ -231,6 +231,11 @@ __global__ __launch_bounds__(FCC_ROWS) void filter_compact_kernel(int64_t P, int
         const int lo = woff + incl - c;
         s_lo[t] = lo;
         s_kb[t] = (unsigned short)keep_bits;
+        // LOCAL: no dependence between tiles -- the tile's candidates are packed at the start of its OWN rows (in place), its total
+        // goes to desc[tile] (as int32) for a scan, and ia_deform_pack_tiles moves the blocks to their final place
+        if (LOCAL) {
+            if (t == 0) { reinterpret_cast<int32_t*>(desc)[tile] = tile_total; s_prefix = (int)(p0 * I); }
+        } else
         // decoupled look-back (wave 0): exclusive prefix of the tile over all earlier tiles
         if (w == 0) {
             int excl = 0;
@@ -278,9 +283,9 @@ __global__ __launch_bounds__(FCC_ROWS) void filter_compact_kernel(int64_t P, int
         const int bp = s_prefix;
         if (t < rows) {
             cnt[p0 + t] = c;
-            start[p0 + t] = bp + lo;
+            start[p0 + t] = LOCAL ? lo : bp + lo;
         }
-        if (tile == n_tiles - 1 && t == 0) *total = bp + tile_total;
+        if (!LOCAL && tile == n_tiles - 1 && t == 0) *total = bp + tile_total;
         // item-parallel write-out: consecutive lanes hold consecutive (point, init) items, so the kept ones land on consecutive
         // 12-byte slots of the packed list
         for (int e = t; e < nb; e += FCC_ROWS) {
@@ -299,6 +304,25 @@ __global__ __launch_bounds__(FCC_ROWS) void filter_compact_kernel(int64_t P, int
         }
         __syncthreads();                         // everyone is done with this tile's LDS
     }
+}
+
+// second half of the tile-local variant: tile_off = exclusive scan of the tile totals; one workgroup per tile copies the tile's
+// packed block from the start of its rows in x to cand_x[tile_off ...] (coalesced on both sides) and turns the tile-local
+// starts into global ones.
+__global__ __launch_bounds__(FCC_ROWS) void pack_tiles_kernel(int64_t P, int I, const float* __restrict__ x, const int32_t* __restrict__ src_local,
+                                                              const int32_t* __restrict__ tile_off, const int32_t* __restrict__ tile_tot,
+                                                              int32_t* __restrict__ start, float* __restrict__ cand_x,
+                                                              int32_t* __restrict__ cand_src)
+{
+    const int tile = blockIdx.x, t = threadIdx.x;
+    const int64_t p0 = (int64_t)tile * FCC_ROWS;
+    const int off = tile_off[tile], n = tile_tot[tile];
+    if (p0 + t < P) start[p0 + t] += off;
+    const float* in = x + p0 * I * 3;
+    float* out = cand_x + (int64_t)off * 3;
+    for (int e = t; e < n * 3; e += FCC_ROWS) out[e] = in[e];
+    if (cand_src)
+        for (int e = t; e < n; e += FCC_ROWS) cand_src[off + e] = src_local[p0 * I + e];
 }
 
 // ---- 4'. min over a point's candidates, SDF only (no-grad coarse queries) ----------
@@ -564,12 +588,70 @@ IA_EXPORT int ia_deform_filter_compact(int64_t P, int I, const float* x, const u
     const size_t lds = (size_t)FCC_ROWS * I * 3 * sizeof(float) + (size_t)FCC_ROWS * I + 16;
     const unsigned grid = (unsigned)n_tiles;
     if (I == 13)      // the reference's 13 initialisations (snarf_deformer.py:98): straight-line filter
-        filter_compact_kernel<13><<<grid, FCC_ROWS, lds, s>>>(P, I, magic, (int)n_tiles, x, valid, desc, cnt, start, cand_x, cand_src, mask,
-                                                               total);
+        filter_compact_kernel<13, false><<<grid, FCC_ROWS, lds, s>>>(P, I, magic, (int)n_tiles, x, valid, desc, cnt, start, cand_x, cand_src,
+                                                                      mask, total);
     else
-        filter_compact_kernel<0><<<grid, FCC_ROWS, lds, s>>>(P, I, magic, (int)n_tiles, x, valid, desc, cnt, start, cand_x, cand_src, mask,
-                                                              total);
+        filter_compact_kernel<0, false><<<grid, FCC_ROWS, lds, s>>>(P, I, magic, (int)n_tiles, x, valid, desc, cnt, start, cand_x, cand_src,
+                                                                     mask, total);
     return ia::check_launch("ia_deform_filter_compact");
+}
+
+// The same result in two steps without any dependence between tiles (the look-back above runs at half the rate of its loads):
+//   ia_deform_filter_tiles : filter + count; every tile's candidates packed IN PLACE at the start of the tile's own rows of x
+//                            (x is consumed), cand_src likewise into src_local [P*I] (optional); cnt [P], tile-local start [P];
+//                            tile totals -> exclusive scan -> tile_off [n_tiles], *total = Q
+//   (host reads Q, allocates cand_x [Q,3])
+//   ia_deform_pack_tiles   : segmented copy of the tile blocks to cand_x (must NOT alias x), start += tile_off
+// tmp: ia_deform_filter_tiles_tmp_bytes(P) bytes, 8-byte aligned, kept between the two calls.
+IA_EXPORT size_t ia_deform_filter_tiles_tmp_bytes(int64_t P)
+{
+    const int64_t n_tiles = ia::cdiv(P > 0 ? P : 1, FCC_ROWS);
+    return (size_t)n_tiles * 8 + (size_t)ia_scan_tmp_bytes(n_tiles) + 64;
+}
+
+IA_EXPORT int ia_deform_filter_tiles(int64_t P, int I, float* x, const uint8_t* valid, int32_t* cnt, int32_t* start, int32_t* src_local,
+                                     uint8_t* mask, int32_t* total, void* tmp, size_t tmp_bytes, ia_stream_t stream)
+{
+    IA_REQUIRE(total != nullptr, "ia_deform_filter_tiles: total is required");
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 0) {
+        if (hipMemsetAsync(total, 0, sizeof(int32_t), s) != hipSuccess) return ia::check_launch("ia_deform_filter_tiles(memset)");
+        return IA_OK;
+    }
+    IA_REQUIRE(I >= 1 && I <= FC_MAX_I, "ia_deform_filter_tiles: at most 16 initialisations per point");
+    IA_REQUIRE(P * I < ((int64_t)1 << 31), "ia_deform_filter_tiles: P * I must stay below 2^31");
+    const int64_t n_tiles = ia::cdiv(P, FCC_ROWS);
+    IA_REQUIRE(tmp != nullptr && tmp_bytes >= ia_deform_filter_tiles_tmp_bytes(P), "ia_deform_filter_tiles: tmp too small");
+    IA_REQUIRE((reinterpret_cast<uintptr_t>(tmp) & 7) == 0, "ia_deform_filter_tiles: tmp must be 8-byte aligned");
+    int32_t* tile_tot = reinterpret_cast<int32_t*>(tmp);
+    int32_t* tile_off = tile_tot + n_tiles;
+    void* scan_tmp = reinterpret_cast<char*>(tmp) + (size_t)n_tiles * 8;
+    const uint32_t magic = (uint32_t)((((uint64_t)1 << 32) + (uint64_t)I - 1) / (uint64_t)I);
+    const size_t lds = (size_t)FCC_ROWS * I * 3 * sizeof(float) + (size_t)FCC_ROWS * I + 16;
+    const unsigned grid = (unsigned)n_tiles;
+    if (I == 13)
+        filter_compact_kernel<13, true><<<grid, FCC_ROWS, lds, s>>>(P, I, magic, (int)n_tiles, x, valid, reinterpret_cast<uint64_t*>(tile_tot),
+                                                                     cnt, start, x, src_local, mask, total);
+    else
+        filter_compact_kernel<0, true><<<grid, FCC_ROWS, lds, s>>>(P, I, magic, (int)n_tiles, x, valid, reinterpret_cast<uint64_t*>(tile_tot),
+                                                                    cnt, start, x, src_local, mask, total);
+    int r = ia::check_launch("ia_deform_filter_tiles");
+    if (r != IA_OK) return r;
+    return ia_exclusive_scan_i32(tile_tot, tile_off, total, n_tiles, scan_tmp, stream);
+}
+
+IA_EXPORT int ia_deform_pack_tiles(int64_t P, int I, const float* x, const int32_t* src_local, int32_t* start, float* cand_x,
+                                   int32_t* cand_src, const void* tmp, ia_stream_t stream)
+{
+    if (P == 0) return IA_OK;
+    IA_REQUIRE(cand_x != x, "ia_deform_pack_tiles: cand_x must not alias x");
+    IA_REQUIRE((cand_src == nullptr) == (src_local == nullptr), "ia_deform_pack_tiles: cand_src and src_local come together");
+    const int64_t n_tiles = ia::cdiv(P, FCC_ROWS);
+    const int32_t* tile_tot = reinterpret_cast<const int32_t*>(tmp);
+    const int32_t* tile_off = tile_tot + n_tiles;
+    pack_tiles_kernel<<<(unsigned)n_tiles, FCC_ROWS, 0, (hipStream_t)stream>>>(P, I, x, src_local, tile_off, tile_tot, start, cand_x,
+                                                                                cand_src);
+    return ia::check_launch("ia_deform_pack_tiles");
 }
 
 IA_EXPORT int ia_deform_select(int64_t P, const int32_t* start, const int32_t* cnt, const float* cand_x,

@@ -12,6 +12,7 @@ boolean-mask index).
 from typing import Optional
 
 import ctypes as C
+import os
 
 import torch
 from torch import Tensor
@@ -105,9 +106,10 @@ class SNARFDeformer:
 
     @torch.no_grad()
     def _pack_candidates(self, x: Tensor, valid: Tensor, with_src: bool):
-        """K9 filter + per-point count + exclusive scan + packed candidate list (snarf_deformer.py:187-196's mask indexing) in
-        one pass, IN PLACE: the packed list [Q,3] is a prefix of x's storage (x [P,I,3] is consumed).
-        -> cand_x [Q,3], cand_src [Q] int32 (= p*I+i; None unless with_src), cnt [P], start [P], Q."""
+        """K9 filter + per-point count + exclusive scan + packed candidate list (snarf_deformer.py:187-196's mask indexing).
+        x [P,I,3] is consumed.  -> cand_x [Q,3], cand_src [Q] int32 (= p*I+i; None unless with_src), cnt [P], start [P], Q.
+        Default: tile-local packing in place + segmented copy (ia_deform_filter_tiles / ia_deform_pack_tiles);
+        IA_PACK=lookback: one pass with a chained scan, the packed list a prefix of x's storage (ia_deform_filter_compact)."""
         P, I = valid.shape
         dev = x.device
         lib, st = L.lib(), L.stream()
@@ -115,13 +117,24 @@ class SNARFDeformer:
         start = torch.empty(P, dtype=torch.int32, device=dev)
         total = torch.empty(1, dtype=torch.int32, device=dev)
         src = torch.empty(P * I, dtype=torch.int32, device=dev) if with_src else None
-        nbytes = int(lib.ia_deform_filter_compact_tmp_bytes(L.i64(P)))
+        if os.environ.get("IA_PACK", "tiles") == "lookback":
+            nbytes = int(lib.ia_deform_filter_compact_tmp_bytes(L.i64(P)))
+            tmp = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
+            L.check(lib.ia_deform_filter_compact(L.i64(P), L.i32(I), L.ptr(x), L.ptr(valid), L.ptr(cnt), L.ptr(start), L.ptr(x),
+                                                 L.ptr(src), L.ptr(None), L.ptr(total), L.ptr(tmp), C.c_size_t(tmp.numel() * 8), st),
+                    "ia_deform_filter_compact")
+            Q = int(total.item())
+            return x.reshape(-1, 3)[:Q], (src[:Q] if with_src else None), cnt, start, Q
+        nbytes = int(lib.ia_deform_filter_tiles_tmp_bytes(L.i64(P)))
         tmp = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
-        L.check(lib.ia_deform_filter_compact(L.i64(P), L.i32(I), L.ptr(x), L.ptr(valid), L.ptr(cnt), L.ptr(start), L.ptr(x),
-                                             L.ptr(src), L.ptr(None), L.ptr(total), L.ptr(tmp), C.c_size_t(tmp.numel() * 8), st),
-                "ia_deform_filter_compact")
+        L.check(lib.ia_deform_filter_tiles(L.i64(P), L.i32(I), L.ptr(x), L.ptr(valid), L.ptr(cnt), L.ptr(start), L.ptr(src), L.ptr(None),
+                                           L.ptr(total), L.ptr(tmp), C.c_size_t(tmp.numel() * 8), st), "ia_deform_filter_tiles")
         Q = int(total.item())
-        return x.reshape(-1, 3)[:Q], (src[:Q] if with_src else None), cnt, start, Q
+        cand_x = torch.empty((Q, 3), device=dev)
+        cand_src = torch.empty(Q, dtype=torch.int32, device=dev) if with_src else None
+        L.check(lib.ia_deform_pack_tiles(L.i64(P), L.i32(I), L.ptr(x), L.ptr(src), L.ptr(start), L.ptr(cand_x), L.ptr(cand_src),
+                                         L.ptr(tmp), st), "ia_deform_pack_tiles")
+        return cand_x, cand_src, cnt, start, Q
 
     @torch.no_grad()
     def deform_sdf(self, pts: Tensor, geometry) -> Tensor:

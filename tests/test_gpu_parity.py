@@ -444,3 +444,17 @@ def test_filter_compact_single_pass_equals_the_three_step_path(P, I, in_place):
     assert torch.equal(out.reshape(-1, 3)[:Q], cx0) and torch.equal(src[:Q], cs0)
     if not in_place:
         assert torch.equal(xin, x) and bool((out.reshape(-1, 3)[Q:] == -1).all())
+    # the two-step form: tile-local packing in place, then the segmented copy
+    xin = x.clone()
+    cnt.fill_(-1); start.fill_(-1); tot.fill_(-1); mask.zero_()
+    src_local = torch.full((P * I,), -1, dtype=torch.int32, device=DEV) if in_place else None       # with / without cand_src
+    nb = int(lib.ia_deform_filter_tiles_tmp_bytes(L.i64(P)))
+    tmp3 = torch.full(((nb + 7) // 8,), -1, dtype=torch.int64, device=DEV)
+    L.check(lib.ia_deform_filter_tiles(L.i64(P), L.i32(I), L.ptr(xin), L.ptr(valid), L.ptr(cnt), L.ptr(start), L.ptr(src_local),
+                                       L.ptr(mask), L.ptr(tot), L.ptr(tmp3), C.c_size_t(tmp3.numel() * 8), st), "tiles")
+    assert int(tot.item()) == Q and torch.equal(cnt, cnt0) and torch.equal(mask, mask0)
+    cx = torch.full((Q, 3), -1.0, device=DEV)
+    cs = torch.full((Q,), -1, dtype=torch.int32, device=DEV) if in_place else None
+    L.check(lib.ia_deform_pack_tiles(L.i64(P), L.i32(I), L.ptr(xin), L.ptr(src_local), L.ptr(start), L.ptr(cx), L.ptr(cs), L.ptr(tmp3), st),
+            "pack")
+    assert torch.equal(start, start0) and torch.equal(cx, cx0) and (cs is None or torch.equal(cs, cs0))

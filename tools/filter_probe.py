@@ -19,10 +19,18 @@ cnt = torch.empty(P, dtype=torch.int32, device=dev); start = torch.empty_like(cn
 out = torch.empty(P * I, 3, device=dev)
 nb = int(lib.ia_deform_filter_compact_tmp_bytes(L.i64(P))); tmp = torch.empty((nb + 7) // 8, dtype=torch.int64, device=dev)
 res = {}
-for dbg in ("single_pass",):
+nb2 = int(lib.ia_deform_filter_tiles_tmp_bytes(L.i64(P))); tmp2 = torch.empty((nb2 + 7) // 8, dtype=torch.int64, device=dev)
+xw = x.clone()
+for dbg in ("single_pass", "tiles"):
     def run():
-        L.check(lib.ia_deform_filter_compact(L.i64(P), L.i32(I), L.ptr(x), L.ptr(valid), L.ptr(cnt), L.ptr(start), L.ptr(out), L.ptr(None),
-                                             L.ptr(None), L.ptr(tot), L.ptr(tmp), C.c_size_t(tmp.numel() * 8), st), "fcc")
+        if dbg == "single_pass":
+            L.check(lib.ia_deform_filter_compact(L.i64(P), L.i32(I), L.ptr(x), L.ptr(valid), L.ptr(cnt), L.ptr(start), L.ptr(out), L.ptr(None),
+                                                 L.ptr(None), L.ptr(tot), L.ptr(tmp), C.c_size_t(tmp.numel() * 8), st), "fcc")
+        else:        # (x is consumed: later repetitions filter the packed leftovers -- same traffic, the timing is what is measured)
+            L.check(lib.ia_deform_filter_tiles(L.i64(P), L.i32(I), L.ptr(xw), L.ptr(valid), L.ptr(cnt), L.ptr(start), L.ptr(None), L.ptr(None),
+                                               L.ptr(tot), L.ptr(tmp2), C.c_size_t(tmp2.numel() * 8), st), "tiles")
+            L.check(lib.ia_deform_pack_tiles(L.i64(P), L.i32(I), L.ptr(xw), L.ptr(None), L.ptr(start), L.ptr(out), L.ptr(None), L.ptr(tmp2), st),
+                    "pack")
     for _ in range(2): run()
     torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
