@@ -184,6 +184,11 @@ int ia_filter(int64_t N, int I, const float* x /*[1,N,I,3]*/, const uint8_t* mas
 int ia_broyden_stats(int B, int64_t N, int I, const float* xd_tgt, const float* voxel_J, int layout, int D, int H, int W,
                      const float* tfs, const int32_t* bone_ids, const float* offset, const float* scale,
                      float cvg_threshold, float dvg_threshold, uint64_t* counters, ia_stream_t stream);
+/* diagnostics: how many distinct voxels the 64 lanes of a wave touch in the first two fetches of every search, with the items in
+ * point-major (init_major = 0) or init-major order; counters [16] caller-zeroed (layout: broyden_voxel_stats_kernel, snarf.hip) */
+int ia_broyden_voxel_stats(int64_t N, int I, int init_major, const float* xd_tgt, const float* voxel_J /*channel-last*/, int D, int H,
+                           int W, const float* tfs, const int32_t* bone_ids, const float* offset, const float* scale,
+                           uint64_t* counters, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* tinycudann.Encoding replacements (reference call sites models/network_utils.py:65,77,191;

@@ -598,6 +598,89 @@ __global__ __launch_bounds__(THREADS) void broyden_stats_kernel(
     if (outcome != 3 && fetches <= 11) atomicAdd(&counters[5 + fetches], 1ull);
 }
 
+// ---- K8 diagnostics 2: how many DISTINCT voxels do the 64 lanes of a wave fetch from? ------------------------------------
+// The first two trilinear fetches of every search (47 % of all fetches; every item makes them), one item per lane, in
+// point-major item order (lane l -> point l / I, init l % I: what the search kernels do) or init-major (64 consecutive points
+// x one init per wave).  counters[f * 8 + k], f = fetch 0 / 1: k = 0 waves, 1 sum of distinct voxels, 2..7 histogram of the
+// distinct count (1, 2, 3-4, 5-8, 9-16, 17+).  Decides whether a wave-broadcast path for the corner data can replace
+// the per-lane gathers.
+__global__ __launch_bounds__(THREADS) void broyden_voxel_stats_kernel(
+    int64_t N, int I, int init_major, const float* __restrict__ xd_tgt, const float* __restrict__ voxel_J, int D, int H, int W,
+    const float* __restrict__ tfs, const int32_t* __restrict__ bone_ids, const float* __restrict__ offset_g,
+    const float* __restrict__ scale_g, unsigned long long* __restrict__ counters)
+{
+    const int64_t index = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    const int64_t total = N * I;
+    int64_t i_point;
+    int i_init;
+    if (init_major) {
+        const int64_t blk = index / (64 * (int64_t)I);
+        const int r = (int)(index - blk * 64 * I);
+        i_init = r >> 6;
+        i_point = blk * 64 + (r & 63);
+    } else {
+        i_point = index / I;
+        i_init = (int)(index - i_point * I);
+    }
+    const bool live = index < total && i_point < N;
+    const float offset[3] = {offset_g[0], offset_g[1], offset_g[2]};
+    const float scale[3] = {scale_g[0], scale_g[1], scale_g[2]};
+    auto voxel_of = [&](float gx, float gy, float gz) -> int {
+        float ix = ((gx + 1.f) / 2) * (W - 1), iy = ((gy + 1.f) / 2) * (H - 1), iz = ((gz + 1.f) / 2) * (D - 1);
+        if (ix > 2147483646.0f || ix < -2147483648.0f || !isfinite(ix)) ix = -100.0f;
+        if (iy > 2147483646.0f || iy < -2147483648.0f || !isfinite(iy)) iy = -100.0f;
+        if (iz > 2147483646.0f || iz < -2147483648.0f || !isfinite(iz)) iz = -100.0f;
+        const int x0 = (int)floorf(ix), y0 = (int)floorf(iy), z0 = (int)floorf(iz);
+        return (z0 * H + y0) * W + x0;
+    };
+    auto tally = [&](int fetch, int vox) {
+        unsigned long long m = __ballot(live);
+        const unsigned long long all = m;
+        int U = 0;
+        while (m) {
+            const int first = __builtin_ctzll(m);
+            const int v = __shfl(vox, first, 64);
+            m &= ~__ballot(live && vox == v);
+            U++;
+        }
+        if ((threadIdx.x & 63) == 0 && all) {
+            const int b = U <= 1 ? 2 : U == 2 ? 3 : U <= 4 ? 4 : U <= 8 ? 5 : U <= 16 ? 6 : 7;
+            atomicAdd(&counters[fetch * 8 + 0], 1ull);
+            atomicAdd(&counters[fetch * 8 + 1], (unsigned long long)U);
+            atomicAdd(&counters[fetch * 8 + b], 1ull);
+        }
+    };
+    float xt[3] = {0, 0, 0}, x_l[3] = {0, 0, 0};
+    float Jl[12];
+    int v0 = 0, v1 = 0;
+    if (live) {
+        xt[0] = xd_tgt[i_point * 3 + 0]; xt[1] = xd_tgt[i_point * 3 + 1]; xt[2] = xd_tgt[i_point * 3 + 2];
+        const float* T = tfs + (int64_t)bone_ids[i_init] * 16;
+        const float ixd = xt[0] - T[0 * 4 + 3], iyd = xt[1] - T[1 * 4 + 3], izd = xt[2] - T[2 * 4 + 3];
+        x_l[0] = ixd * T[0 * 4 + 0] + iyd * T[1 * 4 + 0] + izd * T[2 * 4 + 0];
+        x_l[1] = ixd * T[0 * 4 + 1] + iyd * T[1 * 4 + 1] + izd * T[2 * 4 + 1];
+        x_l[2] = ixd * T[0 * 4 + 2] + iyd * T[1 * 4 + 2] + izd * T[2 * 4 + 2];
+        const float a = scale[0] * (x_l[0] + offset[0]), b = scale[1] * (x_l[1] + offset[1]), c = scale[2] * (x_l[2] + offset[2]);
+        v0 = voxel_of(a, b, c);
+        grid_sample_J<IA_LAYOUT_NDHWC>(voxel_J, 0, D, H, W, a, b, c, Jl);
+        // J_inv starts as the transpose of the blended 3x3 block, as in the search kernels
+        float Ji[9];
+        Ji[0] = Jl[0]; Ji[3] = Jl[1]; Ji[6] = Jl[2];
+        Ji[1] = Jl[4]; Ji[4] = Jl[5]; Ji[7] = Jl[6];
+        Ji[2] = Jl[8]; Ji[5] = Jl[9]; Ji[8] = Jl[10];
+        float gx[3];
+        gx[0] = Jl[0] * x_l[0] + Jl[1] * x_l[1] + Jl[2] * x_l[2] + Jl[3] - xt[0];
+        gx[1] = Jl[4] * x_l[0] + Jl[5] * x_l[1] + Jl[6] * x_l[2] + Jl[7] - xt[1];
+        gx[2] = Jl[8] * x_l[0] + Jl[9] * x_l[1] + Jl[10] * x_l[2] + Jl[11] - xt[2];
+        x_l[0] += -Ji[0] * gx[0] + -Ji[1] * gx[1] + -Ji[2] * gx[2];
+        x_l[1] += -Ji[3] * gx[0] + -Ji[4] * gx[1] + -Ji[5] * gx[2];
+        x_l[2] += -Ji[6] * gx[0] + -Ji[7] * gx[1] + -Ji[8] * gx[2];
+        v1 = voxel_of(scale[0] * (x_l[0] + offset[0]), scale[1] * (x_l[1] + offset[1]), scale[2] * (x_l[2] + offset[2]));
+    }
+    tally(0, v0);
+    tally(1, v1);
+}
+
 // ---- K9 -------------------------------------------------------------------------
 __global__ __launch_bounds__(THREADS) void filter_kernel(int64_t N, int I, const float* __restrict__ x,
                                                           const uint8_t* __restrict__ mask, uint8_t* __restrict__ out)
@@ -708,4 +791,17 @@ IA_EXPORT int ia_broyden_stats(int B, int64_t N, int I, const float* xd_tgt, con
         broyden_stats_kernel<IA_LAYOUT_NCDHW><<<grid, THREADS, 0, (hipStream_t)stream>>>(
             total, N, I, xd_tgt, voxel_J, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, c);
     return ia::check_launch("ia_broyden_stats");
+}
+
+// diagnostics: distinct voxels per wave for the first two fetches of every search (see broyden_voxel_stats_kernel);
+// counters [16], caller-zeroed.  B = 1, channel-last grid.
+IA_EXPORT int ia_broyden_voxel_stats(int64_t N, int I, int init_major, const float* xd_tgt, const float* voxel_J, int D, int H, int W,
+                                     const float* tfs, const int32_t* bone_ids, const float* offset, const float* scale,
+                                     uint64_t* counters, ia_stream_t stream)
+{
+    if (N == 0) return IA_OK;
+    const int64_t total = ((N + 63) / 64) * 64 * I;
+    broyden_voxel_stats_kernel<<<ia::cdiv(total, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+        N, I, init_major, xd_tgt, voxel_J, D, H, W, tfs, bone_ids, offset, scale, reinterpret_cast<unsigned long long*>(counters));
+    return ia::check_launch("ia_broyden_voxel_stats");
 }
