@@ -185,6 +185,7 @@ def main():
         _arena = torch.empty((136 if args.workload == "headline" else 24) << 30, dtype=torch.uint8, device=dev)
         del _arena
     from intrinsicavatar_amd import build
+    _build = build
     if rank == 0:
         build.build()
     if world > 1:
@@ -427,7 +428,8 @@ def main():
                        "host_cpu_throttled_ms_in_timed_region": (None if not (thr0 and thr1) else round((thr1[1] - thr0[1]) / 1e3, 1)),
                        "optimizer_step_in_timed_region": bool(opt is not None), "frames_per_step_per_gpu": 1,
                        "peak_device_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-                       "parallelism": f"frame/ray-batch sharding x{world}", "samples": stats},
+                       "parallelism": f"frame/ray-batch sharding x{world}", "samples": stats,
+                       "library_sources_sha256_16": _build.source_fingerprint(), "library_built_from": _build.built_fingerprint()},
             "roofline": roofline, "l1_roofline": l1, "cpu_baseline": cpu, "kernel_breakdown_ms_per_step": breakdown,
             "ms_per_step_instrumented": round(dt_instr / max(k_instr, 1) * 1e3, 3),
             "abi_kernel_ms_per_step": round(total_ms / max(k_instr, 1), 3),

@@ -35,6 +35,33 @@ SOURCES = {
 }
 
 
+def source_fingerprint() -> str:
+    """sha256 (first 16 hex digits) over every kernel source, header and compiler flag that goes into libia_amd.so: the library is
+    rebuilt whenever this differs from the fingerprint recorded next to it (mtimes do not survive a copy of the tree), and
+    bench.py reports it so that a measured library can be tied to the sources that are tracked."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(repr(COMMON).encode())
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    files.append(os.path.join(os.path.dirname(HERE), "include", "ia_amd.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(repr(SOURCES.get(os.path.basename(f), "")).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+FINGERPRINT = SO + ".src"        # sidecar of the built library (git-ignored like the library, travels with it)
+
+
+def built_fingerprint():
+    try:
+        return open(FINGERPRINT).read().strip()
+    except OSError:
+        return None
+
+
 def _stale(dst, srcs):
     if not os.path.exists(dst):
         return True
@@ -45,6 +72,9 @@ def _stale(dst, srcs):
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
+    fp = source_fingerprint()
+    if os.path.exists(SO) and built_fingerprint() not in (None, fp):
+        force = True                     # the library next to these sources was built from other sources
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "ia_amd.h"))
     objs, procs = [], []
@@ -72,6 +102,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if force or procs or _stale(SO, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
         subprocess.check_call(cmd)
+    if built_fingerprint() != fp:
+        with open(FINGERPRINT, "w") as fh:
+            fh.write(fp + "\n")
     return SO
 
 
