@@ -154,11 +154,18 @@ inline int fill_segs(Seg* segs, int kind, int n_segs, const float* const* seg_pt
 }
 
 // Softplus(beta=100, threshold=20) and its derivative with the hardware exp/log units
+// Straight-line: the raw v_exp_f32 / v_log_f32 (base 2) with the scale factors applied here, and both log1p forms computed and
+// selected.  (__expf / __logf wrap the same instructions in range fix-ups for denormal results / arguments -- compare, ldexp,
+// select -- and the conditional around the logarithm compiled to a divergent branch per activation: 60 branch regions and
+// ~190 of the ~1180 VALU instructions of a 32-point tile of the SDF head.  1 + e is in (1, 2], and an e below the normal range
+// contributes nothing to max(bx, 0) + l at the precision of the result.)
 __device__ __forceinline__ float softplus100(float z, float& sig)
 {
     const float bx = 100.0f * z;
-    const float e = __expf(-fabsf(bx));                 // in (0, 1]
-    const float l = (e < 1e-4f) ? e * (1.0f - 0.5f * e) : __logf(1.0f + e);     // log1p(e)
+    const float e = __builtin_amdgcn_exp2f(-fabsf(bx) * 1.44269504088896340736f);      // exp(-|bx|) in [0, 1]
+    const float lg = __builtin_amdgcn_logf(1.0f + e) * 0.69314718055994530942f;       // log(1 + e)
+    const float sm = e * (1.0f - 0.5f * e);
+    const float l = (e < 1e-4f) ? sm : lg;                                              // log1p(e)
     sig = bx >= 0.0f ? 1.0f / (1.0f + e) : e / (1.0f + e);
     return bx > 20.0f ? z : (fmaxf(bx, 0.0f) + l) * 0.01f;
 }
