@@ -1016,7 +1016,28 @@ IA_EXPORT int ia_hashgrid_fwd_xcd(int64_t n, const float* x, const float* params
     int n_small = 0;
     while (n_small < n_levels && c.offsets[n_small + 1] - c.offsets[n_small] < cap) n_small++;
     hipStream_t s = (hipStream_t)stream;
-    const int chunks = 256;                                     // workgroups per XCD slot
+    // workgroups per XCD slot = what is RESIDENT at once (the kernels are grid-stride loops over equal shares): with 70 VGPRs the
+    // gather kernel fits 7 workgroups of 256 threads per CU, and the 8th per CU of a 256-per-slot grid ran as a second round at
+    // an eighth of the occupancy -- a tail as long as the first round
+    static int chunks_jac = 0, chunks_plain = 0;
+    if (!chunks_plain) {
+        int dev = 0, n_cu = 256, b0 = 0, b1 = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, hash_fwd_xcd_kernel<false>, THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, hash_fwd_xcd_kernel<true>, THREADS, 0);
+        (void)hipGetLastError();
+        const int per_xcd = n_cu >= 8 ? n_cu / 8 : 1;
+        // ... and FEWER resident workgroups are faster still: the resident workgroups of a slot sweep a window of
+        // chunks x 512 consecutive (spatially sorted) points, and the smaller that window the more of its gathers hit L1 / L2
+        // (100 M sorted points, ms per forward: 256 -> 37.7, 224 -> 33.4, 192 -> 31.4, 160 -> 30.6, 128 -> 30.5, 96 -> 33.7, 64 -> 46.4)
+        // headline step (ms per step in this kernel, whole workgroups per CU only -- 144 / 176 leave CUs unevenly loaded: 157 / 162):
+        // 4 per CU 149.6, 5 per CU 144.2, 6 per CU 152.6, 8 per CU (7 resident) 186.4
+        chunks_plain = (b0 > 5 ? 5 : (b0 > 0 ? b0 : 4)) * per_xcd;
+        chunks_jac = (b1 > 5 ? 5 : (b1 > 0 ? b1 : 4)) * per_xcd;
+        if (const char* e = getenv("IA_HASH_XCD_CHUNKS")) chunks_plain = chunks_jac = atoi(e);
+    }
+    const int chunks = dy_dx ? chunks_jac : chunks_plain;
     int l = n_small;
     bool small_done = (n_small == 0);
     while (l < n_levels || !small_done) {
