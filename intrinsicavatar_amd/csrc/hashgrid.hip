@@ -85,7 +85,7 @@ __device__ __forceinline__ void load_x_pair(const float2* __restrict__ tab, uint
 
 // forward (+ optional analytic d enc / d x)
 template <bool WITH_JAC>
-__global__ __launch_bounds__(THREADS) void hash_fwd_kernel(int64_t n, const float* __restrict__ x,
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void hash_fwd_kernel(int64_t n, const float* __restrict__ x,
                                                             const float2* __restrict__ params, HashCfg cfg,
                                                             float* __restrict__ out, int out_stride,
                                                             float* __restrict__ dy_dx)
