@@ -530,6 +530,9 @@ int ia_sdf_levels_fwd(int64_t n, const void* levels, const float* xp /*[n,3] in 
                       const float* b1, const float* Wo /*[>=1,64], row 0 used*/, const float* bo, float* sdf /*[n]*/,
                       ia_stream_t stream);
 int ia_deform_select_min(int64_t P, const int32_t* start, const int32_t* cnt, const float* cand_sdf, float* sdf, ia_stream_t stream);
+/* ... for points evaluated as a permutation of the caller's list: sdf[order[p]] = the minimum of point p */
+int ia_deform_select_min_scatter(int64_t P, const int32_t* start, const int32_t* cnt, const float* cand_sdf, const int32_t* order,
+                                 float* sdf, ia_stream_t stream);
 
 #ifdef __cplusplus
 }

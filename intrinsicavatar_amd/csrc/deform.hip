@@ -327,7 +327,8 @@ __global__ __launch_bounds__(FCC_ROWS) void pack_tiles_kernel(int64_t P, int I, 
 
 // ---- 4'. min over a point's candidates, SDF only (no-grad coarse queries) ----------
 __global__ __launch_bounds__(THREADS) void select_min_kernel(int64_t P, const int32_t* __restrict__ start, const int32_t* __restrict__ cnt,
-                                                              const float* __restrict__ cand_sdf, float* __restrict__ sdf_out)
+                                                              const float* __restrict__ cand_sdf, const int32_t* __restrict__ order,
+                                                              float* __restrict__ sdf_out)
 {
     const int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     if (p >= P) return;
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(THREADS) void select_min_kernel(int64_t P, const in
         const float v = cand_sdf[s + j];
         if (v < best) best = v;
     }
-    sdf_out[p] = best;
+    sdf_out[order ? (int64_t)order[p] : p] = best;       // order: the points were evaluated as a permutation of the caller's list
 }
 
 // ---- 4. select ------------------------------------------------------------------
@@ -672,8 +673,18 @@ IA_EXPORT int ia_deform_select_min(int64_t P, const int32_t* start, const int32_
                                    ia_stream_t stream)
 {
     if (P == 0) return IA_OK;
-    select_min_kernel<<<ia::cdiv(P, THREADS), THREADS, 0, (hipStream_t)stream>>>(P, start, cnt, cand_sdf, sdf);
+    select_min_kernel<<<ia::cdiv(P, THREADS), THREADS, 0, (hipStream_t)stream>>>(P, start, cnt, cand_sdf, nullptr, sdf);
     return ia::check_launch("ia_deform_select_min");
+}
+
+// the same, for points that were evaluated in another order than the caller's: sdf[order[p]] = min over the candidates of p
+IA_EXPORT int ia_deform_select_min_scatter(int64_t P, const int32_t* start, const int32_t* cnt, const float* cand_sdf,
+                                           const int32_t* order, float* sdf, ia_stream_t stream)
+{
+    if (P == 0) return IA_OK;
+    IA_REQUIRE(order != nullptr, "ia_deform_select_min_scatter: order is required");
+    select_min_kernel<<<ia::cdiv(P, THREADS), THREADS, 0, (hipStream_t)stream>>>(P, start, cnt, cand_sdf, order, sdf);
+    return ia::check_launch("ia_deform_select_min_scatter");
 }
 
 IA_EXPORT int ia_ray_points(int64_t n, const float* rays_o, const float* rays_d, const int64_t* ray_indices,

@@ -137,7 +137,7 @@ class SNARFDeformer:
         return cand_x, cand_src, cnt, start, Q
 
     @torch.no_grad()
-    def deform_sdf(self, pts: Tensor, geometry) -> Tensor:
+    def deform_sdf(self, pts: Tensor, geometry, order: Optional[Tensor] = None) -> Tensor:
         """SDF at posed points, nothing else: SNARFDeformer.deform with with_grad = with_feature = False as the no-grad coarse
         passes call it (coarse_alpha_fn / alpha_fn / coarse_alpha_sdf_fn).  Same search, filter and min-select as deform();
         the candidates go through geometry.sdf_only and only sdf [P] is produced (1e5 where no candidate survives)."""
@@ -149,7 +149,11 @@ class SNARFDeformer:
         cand_x, _, cnt, start, Q = self._pack_candidates(x, valid, with_src=False)
         csdf = geometry.sdf_only(cand_x)
         sdf = torch.empty(P, device=dev)
-        L.check(lib.ia_deform_select_min(L.i64(P), L.ptr(start), L.ptr(cnt), L.ptr(csdf), L.ptr(sdf), st), "ia_deform_select_min")
+        if order is not None:         # pts = caller's points[order]: the result goes back to the caller's order on the way out
+            L.check(lib.ia_deform_select_min_scatter(L.i64(P), L.ptr(start), L.ptr(cnt), L.ptr(csdf), L.ptr(order), L.ptr(sdf), st),
+                    "ia_deform_select_min_scatter")
+        else:
+            L.check(lib.ia_deform_select_min(L.i64(P), L.ptr(start), L.ptr(cnt), L.ptr(csdf), L.ptr(sdf), st), "ia_deform_select_min")
         return sdf
 
     @torch.no_grad()

@@ -117,10 +117,7 @@ class RenderStep:
         order = self._spatial_order(pts)
         ps = torch.empty_like(pts)
         L.check(lib.ia_gather_rows3_i32(L.i64(n), L.ptr(pts), L.ptr(order), L.ptr(ps), st), "ia_gather_rows3_i32")
-        sdf_s = self.deformer.deform_sdf(ps, self.geometry)
-        sdf = torch.empty_like(sdf_s)
-        L.check(lib.ia_scatter_f32_i32(L.i64(n), L.ptr(sdf_s), L.ptr(order), L.ptr(sdf), st), "ia_scatter_f32_i32")
-        return sdf
+        return self.deformer.deform_sdf(ps, self.geometry, order=order)      # the min-select writes through `order`
 
     # ------------------------------------------------------------------ sampling (no grad)
     @torch.no_grad()
