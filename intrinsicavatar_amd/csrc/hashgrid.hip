@@ -1047,15 +1047,20 @@ IA_EXPORT int ia_hashgrid_fwd_xcd(int64_t n, const float* x, const float* params
             for (int k = 0; k < 8; k++) { plan.first_level[k] = l + k; plan.n_level[k] = 1; plan.part[k] = 0; plan.nparts[k] = 1; }
             l += 8;
         } else {                                                // pass B: remaining big levels + the small set
-            // XCD slots in proportion to the work of each unit (a big level = 1, the small set = its level count),
-            // every unit at least one slot; a unit with several slots splits the points between them
+            // XCD slots by COST of each unit, every unit at least one slot; a unit with several slots splits the points between
+            // them.  Cost of one hashed level = 1 (every gather of a fine level misses L1); the dense levels hit L1 / L2 on spatially
+            // sorted points, so the whole small set costs about as much as ONE hashed level -- weighing it by its level count (5)
+            // left three XCDs with a full hashed level each while five XCDs idled through a fifth of the small set.
             const int units = big_left + (small_done ? 0 : 1);
-            int w[9], share[9], wsum = 0;
-            for (int u = 0; u < units; u++) { w[u] = (!small_done && u == units - 1) ? n_small : 1; wsum += w[u]; }
-            int used = 0;
-            for (int u = 0; u < units; u++) { share[u] = (8 * w[u]) / wsum; if (share[u] < 1) share[u] = 1; used += share[u]; }
-            for (int u = units - 1; used > 8; u = (u + units - 1) % units) if (share[u] > 1) { share[u]--; used--; }
-            for (int u = units - 1; used < 8; u = (u + units - 1) % units) { share[u]++; used++; }
+            static const float small_cost = getenv("IA_HASH_SMALL_COST") ? (float)atof(getenv("IA_HASH_SMALL_COST")) : 1.0f;
+            float w[9];
+            int share[9], used = 0;
+            for (int u = 0; u < units; u++) { w[u] = (!small_done && u == units - 1) ? small_cost : 1.0f; share[u] = 1; used++; }
+            for (; used < 8; used++) {                          // next slot to the unit with the most work per slot
+                int best = 0;
+                for (int u = 1; u < units; u++) if (w[u] / share[u] > w[best] / share[best]) best = u;
+                share[best]++;
+            }
             int k = 0;
             for (int u = 0; u < units; u++) {
                 const bool is_small = (!small_done && u == units - 1);
