@@ -1040,6 +1040,26 @@ IA_EXPORT int ia_hashgrid_fwd_xcd(int64_t n, const float* x, const float* params
     const int chunks = dy_dx ? chunks_jac : chunks_plain;
     int l = n_small;
     bool small_done = (n_small == 0);
+    // Default schedule: ONE table at a time.  A launch gathers one hashed level (or the whole dense set) for all points, the
+    // eight XCD slots taking an eighth of the points each: every XCD's L2 holds just that 4 MB table, and the launches are
+    // balanced by construction.  Giving each XCD its own level (passes A / B below, IA_HASH_XCD_PLAN=passes) is bound by the
+    // slowest level of a pass: per-level cost for 100 M sorted points on the whole device is 1.18 ms (level 5) ... 1.83
+    // (level 12) ... 2.42 ms (level 15), 3.47 ms for the five dense levels together = 21.8 ms against 26.9 ms for the passes.
+    static const bool by_level = !(getenv("IA_HASH_XCD_PLAN") && getenv("IA_HASH_XCD_PLAN")[0] == 'p');
+    if (by_level) {
+        for (int u = (n_small > 0 ? -1 : 0); u < n_levels - n_small; u++) {
+            XcdPlan plan;
+            for (int k = 0; k < 8; k++) {
+                plan.first_level[k] = u < 0 ? 0 : n_small + u;
+                plan.n_level[k] = u < 0 ? n_small : 1;
+                plan.part[k] = k; plan.nparts[k] = 8;
+            }
+            if (dy_dx) hash_fwd_xcd_kernel<true><<<8 * chunks, THREADS, 0, s>>>(n, x, (const float2*)params, c, plan, tmp, tmp_jac);
+            else hash_fwd_xcd_kernel<false><<<8 * chunks, THREADS, 0, s>>>(n, x, (const float2*)params, c, plan, tmp, nullptr);
+        }
+        l = n_levels;
+        small_done = true;
+    }
     while (l < n_levels || !small_done) {
         XcdPlan plan;
         const int big_left = n_levels - l;
