@@ -1033,8 +1033,10 @@ IA_EXPORT int ia_hashgrid_fwd_xcd(int64_t n, const float* x, const float* params
         // (100 M sorted points, ms per forward: 256 -> 37.7, 224 -> 33.4, 192 -> 31.4, 160 -> 30.6, 128 -> 30.5, 96 -> 33.7, 64 -> 46.4)
         // headline step (ms per step in this kernel, whole workgroups per CU only -- 144 / 176 leave CUs unevenly loaded: 157 / 162):
         // 4 per CU 149.6, 5 per CU 144.2, 6 per CU 152.6, 8 per CU (7 resident) 186.4
-        chunks_plain = (b0 > 5 ? 5 : (b0 > 0 ? b0 : 4)) * per_xcd;
-        chunks_jac = (b1 > 5 ? 5 : (b1 > 0 ? b1 : 4)) * per_xcd;
+        // (those figures are for the per-XCD-level passes; with one table at a time: 4 per CU 22.9 ms per 100 M points, 5 -> 21.6,
+        //  6 -> 21.0, 7 -> 20.9; headline step 116.3 / 113.5 / 113.9 ms for 5 / 6 / 7)
+        chunks_plain = (b0 > 6 ? 6 : (b0 > 0 ? b0 : 4)) * per_xcd;
+        chunks_jac = (b1 > 6 ? 6 : (b1 > 0 ? b1 : 4)) * per_xcd;
         if (const char* e = getenv("IA_HASH_XCD_CHUNKS")) chunks_plain = chunks_jac = atoi(e);
     }
     const int chunks = dy_dx ? chunks_jac : chunks_plain;
