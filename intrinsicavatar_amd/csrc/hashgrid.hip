@@ -143,7 +143,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// forward, XCD-PARTITIONED (large batches).  The level-major kernel above pulls ~4 KB per point through the fabric
+// forward, XCD-PARTITIONED (large batches; since round 2 the default schedule is ONE table per launch with the eight XCD slots
+// sharing the points -- see ia_hashgrid_fwd_xcd -- and the per-XCD level plans described here are IA_HASH_XCD_PLAN=passes).
+// The level-major kernel above pulls ~4 KB per point through the fabric
 // (every 8-byte gather of a fine level drags a 64-byte sector out of the Infinity Cache: measured 18 GB per 4.4 M
 // points at 6.2 TB/s, L2 hit rate 0.6), because each XCD's 4 MiB L2 sees all sixteen 4 MB level tables.  Here a
 // workgroup's levels are chosen by the XCD it runs on (block b -> XCD b % 8, observed dispatch order; used for speed
