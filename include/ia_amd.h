@@ -529,6 +529,16 @@ int ia_gaussian_histogram_bwd(int64_t n, const float* x, const float* sigma, int
 int ia_sdf_levels_fwd(int64_t n, const void* levels, const float* xp /*[n,3] in [0,1]*/, const float* W1 /*[64,35] hash|xyz*/,
                       const float* b1, const float* Wo /*[>=1,64], row 0 used*/, const float* bo, float* sdf /*[n]*/,
                       ia_stream_t stream);
+/* the general SDF head on level-major gather results (no [n,32] rows, no [n,32,3] Jacobian): ia_hashgrid_fwd_levels = the
+ * XCD-partitioned gather without its transpose (scratch: ia_hashgrid_fwd_scratch_bytes(n, L, with_jac) bytes; features float2
+ * [L][n] at its start, Jacobian float [L][n][6] at ia_hashgrid_fwd_levels_jac_offset(n, L)); ia_sdf_levels_fwd_grad = kind 0 of
+ * ia_mlp_fwd with the analytic gradient (y [n,13], grad [n,3]) reading both. */
+int64_t ia_hashgrid_fwd_levels_jac_offset(int64_t n, int n_levels);
+int ia_hashgrid_fwd_levels(int64_t n, const float* x, const float* params, int n_levels, int n_features, int log2_hashmap_size,
+                           int base_resolution, float per_level_scale, int with_jac, void* scratch, ia_stream_t stream);
+int ia_sdf_levels_fwd_grad(int64_t n, const void* levels, const float* levels_jac, const float* xp, const float* W1, const float* b1,
+                           const float* Wo /*[13,64]*/, const float* bo, float* y, int y_stride, const float* inv_scale_host,
+                           float* grad, ia_stream_t stream);
 int ia_deform_select_min(int64_t P, const int32_t* start, const int32_t* cnt, const float* cand_sdf, float* sdf, ia_stream_t stream);
 /* ... for points evaluated as a permutation of the caller's list: sdf[order[p]] = the minimum of point p */
 int ia_deform_select_min_scatter(int64_t P, const int32_t* start, const int32_t* cnt, const float* cand_sdf, const int32_t* order,

@@ -82,6 +82,7 @@ def lib():
         cdll.ia_hashgrid_bwd_scratch_bytes.restype = C.c_int64
         cdll.ia_traverse_fused_scratch_bytes.restype = C.c_int64
         cdll.ia_hashgrid_fwd_scratch_bytes.restype = C.c_int64
+        cdll.ia_hashgrid_fwd_levels_jac_offset.restype = C.c_int64
         cdll.ia_eikonal_partials.restype = C.c_int64
         cdll.ia_deform_filter_compact_tmp_bytes.restype = C.c_size_t
         cdll.ia_deform_filter_tiles_tmp_bytes.restype = C.c_size_t

@@ -1113,6 +1113,20 @@ IA_EXPORT int ia_hashgrid_fwd_xcd(int64_t n, const float* x, const float* params
     return ia::check_launch("ia_hashgrid_fwd_xcd");
 }
 
+// level-major results only: float2 [L][n] at scratch, and (with_jac) float [L][n][6] at scratch + ia_hashgrid_fwd_levels_jac_offset
+IA_EXPORT int64_t ia_hashgrid_fwd_levels_jac_offset(int64_t n, int n_levels)
+{
+    return ((n * n_levels * 8 + 255) / 256) * 256;
+}
+
+IA_EXPORT int ia_hashgrid_fwd_levels(int64_t n, const float* x, const float* params, int n_levels, int n_features, int log2_hashmap_size,
+                                     int base_resolution, float per_level_scale, int with_jac, void* scratch, ia_stream_t stream)
+{
+    // out == NULL: no transpose; a non-NULL dy_dx only selects the Jacobian variant of the gather (nothing is written through it)
+    return ia_hashgrid_fwd_xcd(n, x, params, n_levels, n_features, log2_hashmap_size, base_resolution, per_level_scale, nullptr, 0,
+                               with_jac ? reinterpret_cast<float*>(scratch) : nullptr, scratch, stream);
+}
+
 IA_EXPORT int ia_hashgrid_bwd(int64_t n, const float* x, int n_levels, int n_features, int log2_hashmap_size,
                               int base_resolution, float per_level_scale, const float* g_enc, int g_enc_stride,
                               const float* g_jac, int g_jac_stride, const float* q, float* grad_params,

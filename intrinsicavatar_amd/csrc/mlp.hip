@@ -288,14 +288,29 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fwd_kernel(MlpArgs a)
             const int64_t p = p0 + lane;
             if (lane < TM && p < a.n) {
                 const float* gh = sG + lane * LDX;
-                const float* J = a.jac + p * 96;
                 float g0 = 2.0f * gh[a.xyz_col + 0], g1 = 2.0f * gh[a.xyz_col + 1], g2 = 2.0f * gh[a.xyz_col + 2];
+                if constexpr (KIND == 3) {
+                    // level-major Jacobian [16][n][6] (as the XCD-partitioned gather leaves it): consecutive lanes = consecutive
+                    // points read consecutive 24-byte records of a level -- coalesced, where the [n,32,3] rows are 384 bytes apart
+                    const float* J = a.jac + p * 6;
+                    const int64_t ls = a.n * 6;
+#pragma unroll 4
+                    for (int l = 0; l < 16; l++) {
+                        const float2 ja = *reinterpret_cast<const float2*>(J + l * ls), jb = *reinterpret_cast<const float2*>(J + l * ls + 2),
+                                     jc = *reinterpret_cast<const float2*>(J + l * ls + 4);
+                        const float ga = gh[2 * l], gb = gh[2 * l + 1];      // same order of operations as the row-major loop
+                        g0 = fmaf(ga, ja.x, g0); g1 = fmaf(ga, ja.y, g1); g2 = fmaf(ga, jb.x, g2);
+                        g0 = fmaf(gb, jb.y, g0); g1 = fmaf(gb, jc.x, g1); g2 = fmaf(gb, jc.y, g2);
+                    }
+                } else {
+                const float* J = a.jac + p * 96;
 #pragma unroll 8
                 for (int k = 0; k < 32; k++) {
                     const float g = gh[k];      // hash features occupy columns 0..31
                     g0 = fmaf(g, J[k * 3 + 0], g0);
                     g1 = fmaf(g, J[k * 3 + 1], g1);
                     g2 = fmaf(g, J[k * 3 + 2], g2);
+                }
                 }
                 a.grad[p * 3 + 0] = g0 * a.inv_scale[0];
                 a.grad[p * 3 + 1] = g1 * a.inv_scale[1];
@@ -381,4 +396,28 @@ IA_EXPORT int ia_sdf_levels_fwd(int64_t n, const void* levels, const float* xp, 
     a.W1 = W1; a.b1 = b1; a.W2 = nullptr; a.b2 = nullptr; a.Wo = Wo; a.bo = bo;
     a.y = sdf; a.y_stride = 1;
     return launch_fwd<3, 35, 1, 1, 1, 0, false>(a, (hipStream_t)stream);
+}
+
+// The full SDF head (13 outputs + analytic gradient, kind 0 of ia_mlp_fwd with grad) on the level-major results of the
+// XCD-partitioned gather: levels = float2 [16][n], levels_jac = float [16][n][6] (d feature / d x', features 2l and 2l+1),
+// both as ia_hashgrid_fwd_levels leaves them in its scratch.  No [n,32] rows, no [n,32,3] Jacobian.
+IA_EXPORT int ia_sdf_levels_fwd_grad(int64_t n, const void* levels, const float* levels_jac, const float* xp, const float* W1,
+                                     const float* b1, const float* Wo, const float* bo, float* y, int y_stride,
+                                     const float* inv_scale_host, float* grad, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    IA_REQUIRE(n < ((int64_t)1 << 31), "ia_sdf_levels_fwd_grad: at most 2^31 points per call");
+    IA_REQUIRE(levels_jac != nullptr && inv_scale_host != nullptr && grad != nullptr, "ia_sdf_levels_fwd_grad: Jacobian, 1/scale and grad are required");
+    IA_REQUIRE(y_stride >= 13, "ia_sdf_levels_fwd_grad: y_stride must be >= 13");
+    MlpArgs a = {};
+    a.n = n;
+    a.n_segs = 2;
+    for (int s = 0; s < MAX_SEGS; s++) { a.segs[s].p = nullptr; a.segs[s].stride = 0; a.segs[s].width = 0; a.segs[s].mul = 1.f; a.segs[s].add = 0.f; }
+    a.segs[0].p = (const float*)levels; a.segs[0].stride = (int)n; a.segs[0].width = 32;
+    a.segs[1].p = xp; a.segs[1].stride = 3; a.segs[1].width = 3; a.segs[1].mul = 2.0f; a.segs[1].add = -1.0f;
+    a.W1 = W1; a.b1 = b1; a.W2 = nullptr; a.b2 = nullptr; a.Wo = Wo; a.bo = bo;
+    a.y = y; a.y_stride = y_stride;
+    a.jac = levels_jac; a.xyz_col = 32; a.grad = grad;
+    for (int k = 0; k < 3; k++) a.inv_scale[k] = inv_scale_host[k];
+    return launch_fwd<3, 35, 1, 13, 1, 0, true>(a, (hipStream_t)stream);
 }

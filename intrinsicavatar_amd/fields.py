@@ -279,6 +279,29 @@ class VolumeSDF(nn.Module):
                 out.append(points.new_empty(0, 13))
             return out[0] if len(out) == 1 else out
         xp = ((points - self.center) / self.scale + 0.5).contiguous()
+        if with_grad and n >= HASH_FWD_XCD_MIN and os.environ.get("IA_SDF_GRAD_LEVELS", "1") == "1":
+            # big batches: one-table-at-a-time gather with Jacobian, level-major results straight into the head (no [n,32] rows, no
+            # [n,32,3] Jacobian tensor, coalesced Jacobian reads in the gradient epilogue)
+            cfg = HASH
+            lib, st = L.lib(), L.stream()
+            nb = int(lib.ia_hashgrid_fwd_scratch_bytes(L.i64(n), L.i32(cfg["n_levels"]), L.i32(1)))
+            scratch = torch.empty(nb, dtype=torch.uint8, device=xp.device)
+            L.check(lib.ia_hashgrid_fwd_levels(L.i64(n), L.ptr(xp), L.ptr(self.grid_params), L.i32(cfg["n_levels"]),
+                                               L.i32(cfg["n_features_per_level"]), L.i32(cfg["log2_hashmap_size"]),
+                                               L.i32(cfg["base_resolution"]), L.f32(cfg["per_level_scale"]), L.i32(1), L.ptr(scratch), st),
+                    "ia_hashgrid_fwd_levels")
+            joff = int(lib.ia_hashgrid_fwd_levels_jac_offset(L.i64(n), L.i32(cfg["n_levels"])))
+            W1k, b1, W2, b2 = self.effective_weights()
+            y = torch.empty((n, 13), device=xp.device)
+            grad = torch.empty((n, 3), device=xp.device)
+            inv = (C.c_float * 3)(*[float(v) for v in self.inv_scale_host()])
+            L.check(lib.ia_sdf_levels_fwd_grad(L.i64(n), L.ptr(scratch), C.c_void_p(scratch.data_ptr() + joff), L.ptr(xp),
+                                               L.ptr(W1k.contiguous()), L.ptr(b1.contiguous()), L.ptr(W2.contiguous()), L.ptr(b2.contiguous()),
+                                               L.ptr(y), L.i32(13), inv, L.ptr(grad), st), "ia_sdf_levels_fwd_grad")
+            out = [y[:, 0], grad]
+            if with_feature:
+                out.append(y)
+            return out
         if with_grad:
             enc, jac = hashgrid_forward(xp, self.grid_params, with_jac=True)
         else:

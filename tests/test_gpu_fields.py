@@ -292,6 +292,26 @@ def test_sdf_only_query_path_equals_the_general_one(fields):
     assert torch.equal(s2, s) and torch.equal(s3, s)
 
 
+def test_sdf_head_with_gradient_on_level_major_results_equals_the_row_major_path(fields, monkeypatch):
+    """big batches evaluate VolumeSDF.forward(with_grad=True) from the level-major gather results (ia_hashgrid_fwd_levels +
+    ia_sdf_levels_fwd_grad: no [n,32] rows, no [n,32,3] Jacobian): sdf, 13 features and the analytic gradient equal the flat gather
+    + row-major head (same arithmetic in the same order; ragged last tile)."""
+    from intrinsicavatar_amd import synthetic as S
+    rs, rays, _ = S.build_frame(DEV, 96, 96, pose_seed=0, beta=0.01, num_samples_per_ray=64, grid_D=16, grid_H=64, grid_W=64,
+                                smooth_iters=5, hash_amp=1e-2)
+    geo = rs.geometry
+    g = torch.Generator().manual_seed(3)
+    n = fields.HASH_FWD_XCD_MIN + 1237
+    x = (geo.center + (torch.rand((n, 3), generator=g).to(DEV) - 0.5) * geo.scale).contiguous()
+    a = geo.forward(x, with_grad=True, with_feature=True)
+    monkeypatch.setenv("IA_SDF_GRAD_LEVELS", "0")
+    b = geo.forward(x, with_grad=True, with_feature=True)
+    for u, v, name in zip(a, b, ("sdf", "grad", "feature")):
+        assert u.shape == v.shape
+        assert torch.allclose(u, v, rtol=1e-6, atol=1e-7), (name, float((u - v).abs().max()))
+    assert float(a[1].abs().max()) > 0.1
+
+
 @pytest.mark.parametrize("drop_bits", [0, 3, 6])
 def test_morton_order_is_a_stable_key_sort(drop_bits):
     """ia_morton_order: a permutation that sorts the bits [drop_bits, 30) of the Morton keys, stable (equal keys keep their
