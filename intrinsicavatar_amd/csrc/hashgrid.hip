@@ -201,10 +201,14 @@ __device__ __forceinline__ void xcd_blend_store(const float2 v[8], const float p
             j1[0] += dx * v[c].y; j1[1] += dy * v[c].y; j1[2] += dz * v[c].y;
         }
     }
-    tmp[slot] = make_float2(a0, a1);
+    // streaming outputs bypass the caches' retention (non-temporal): the L2 should hold the level's 4 MB table, nothing else
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store((v2f){a0, a1}, reinterpret_cast<v2f*>(tmp + slot));
     if (WITH_JAC) {
-        float2* J = reinterpret_cast<float2*>(tmp_jac + slot * 6);
-        J[0] = make_float2(j0[0], j0[1]); J[1] = make_float2(j0[2], j1[0]); J[2] = make_float2(j1[1], j1[2]);
+        v2f* J = reinterpret_cast<v2f*>(tmp_jac + slot * 6);
+        __builtin_nontemporal_store((v2f){j0[0], j0[1]}, J);
+        __builtin_nontemporal_store((v2f){j0[2], j1[0]}, J + 1);
+        __builtin_nontemporal_store((v2f){j1[1], j1[2]}, J + 2);
     }
 }
 
@@ -226,8 +230,10 @@ __global__ __launch_bounds__(THREADS) void hash_fwd_xcd_kernel(int64_t n, const 
         const int64_t i2 = i + stride;
         const bool two = i2 < hi;
         const int64_t ib = two ? i2 : i;
-        const float xa[3] = {x[i * 3 + 0], x[i * 3 + 1], x[i * 3 + 2]};
-        const float xb[3] = {x[ib * 3 + 0], x[ib * 3 + 1], x[ib * 3 + 2]};
+        const float xa[3] = {__builtin_nontemporal_load(x + i * 3 + 0), __builtin_nontemporal_load(x + i * 3 + 1),
+                             __builtin_nontemporal_load(x + i * 3 + 2)};
+        const float xb[3] = {__builtin_nontemporal_load(x + ib * 3 + 0), __builtin_nontemporal_load(x + ib * 3 + 1),
+                             __builtin_nontemporal_load(x + ib * 3 + 2)};
         for (int l = plan.first_level[slot]; l < plan.first_level[slot] + plan.n_level[slot]; l++) {
             const float sc = cfg.scale[l];
             const uint32_t res = cfg.res[l], hsize = cfg.offsets[l + 1] - cfg.offsets[l];
