@@ -2,7 +2,8 @@
 """bench.py -- render_step throughput on MI355X (BASELINE.json metric: rays/sec (fwd+bwd) at 540x540, 1024 spp).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  (N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, or started
+   plainly -- WORLD_SIZE unset -- in which case bench.py re-executes itself under torch.distributed.run, one rank per GPU)
 
 Default workload (`--workload headline`) = the configuration the metric is quoted on: ONE training-form pass
 (forward + backward + optimiser step) of the render_step hot path over one 540x540 frame (291 600 primary rays) WITH the
@@ -22,11 +23,12 @@ reference draws them per step too).  Multi-GPU: frames shard across ranks with r
 frame per rank per step), gradients all-reduced over RCCL.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     -- the dominant C-ABI entry point of the step (by HIP-event time measured live on the launch stream)
-                  priced against HBM with algorithmic bytes computed from the COUNTED units of the step's launches;
-                  `traffic` = PMC bytes per launch from the committed rocprofv3 passes of the same command;
-  l1_roofline  -- (when the dominant kernel is the Broyden search) the bound that actually binds it: bytes through the
-                  vector-memory (TCP/L1) path from the counted trilinear fetches against 256 CUs x 64 B/clk;
+  roofline     -- the dominant C-ABI entry point of the step (by HIP-event time measured live on the launch stream).  For the
+                  Broyden search ("cache-gather latency") it is priced against the bound that binds it: bytes
+                  through the vector-memory (TCP/L1) path from the COUNTED trilinear fetches against 256 CUs x 64 B/clk;
+                  `traffic` = PMC bytes per launch from the committed rocprofv3 passes of the same command, `hbm_side` what
+                  that is against the HBM peak.  Any other dominant kernel is priced against HBM with SURVEY 8(d)'s bytes;
+  mfma         -- the SDF head of the no-grad queries in-step: useful FLOP / live time against the fp32 MFMA peak;
   cpu_baseline -- the CPU oracle (a port; forward only) on a bounded ray sample of the same frame, rank 0 / N == 1.
 """
 import argparse
@@ -142,6 +144,7 @@ def main():
                     help="fwd+bwd = training-step form of render_step (BASELINE metric); fwd = inference form (config2 only)")
     args = ap.parse_args()
 
+    self_launch_ranks(args.gpus)                 # plain `python bench.py --gpus N`: start the N ranks ourselves
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -356,7 +359,7 @@ def main():
         stats["n_rays"] = n_rays
         per_call = {k: (len(v), sum(c[0] for c in v)) for k, v in detail.items()}
         total_ms = sum(v[1] for v in per_call.values())
-        roofline = l1 = None
+        roofline = l1 = mfma = None
         breakdown = {}
         if per_call:
             dname, (dcalls, dms) = max(per_call.items(), key=lambda kv: kv[1][1])
@@ -375,25 +378,47 @@ def main():
                                 algorithmic_bytes_per_launch=int(ab / dcalls),
                                 share_of_kernel_time=round(dms / max(total_ms, 1e-9), 3))
             if bro:
-                # SURVEY 8(d) classes this stage "cache-gather latency": the gathers are served by L1 / L2 / Infinity Cache
-                # (voxel_J is 25 MB), so the algorithmic rate can exceed the HBM peak (frac > 1 = "not an HBM-bound kernel");
-                # what binds it is the CU's vector-memory path and VALU issue.  Next to it: the bytes that MUST
-                # cross HBM (targets in, x / valid out, the grid once per launch) and the L1-path rate.
+                # SURVEY 8(d) classes this stage "cache-gather latency": voxel_J is 25 MB, the gathers are served by L1 / L2 /
+                # Infinity Cache, so the counted gather bytes can exceed what HBM could ever deliver -- an HBM ratio of them is
+                # not a fraction of anything.  The bound that binds is the CU's vector-memory (L1 / texture-addresser) path:
+                # `frac` = counted corner loads x 48 B / time against 256 CUs x 64 B/clk.  What HBM itself sees sits next to it:
+                # `hbm_side` (PMC bytes of the committed rocprofv3 passes / the live launch time) and the compulsory bytes
+                # (targets in, x / valid out, the grid once per launch).
                 c = bro
                 sec = dms / k_instr * 1e-3
                 items = max(c[2] + c[3] + c[4], 1)
                 comp = sum(u * (12 + ex["I"] * (13 + (36 if ex["J_inv"] else 0) + (36 if ex["fwd_J"] else 0))) + VOXEL_J_BYTES
                            for _, u, ex in detail[dname]) / k_instr
-                roofline.update(algorithmic_model="SURVEY 8(d) Broyden row with COUNTED fetches: per (point, init) 76 B in + 13 B out + "
-                                                  "fetches x in-range corners x 48 B gathered",
-                                compulsory_hbm_GBps=round(comp / sec / 1e9, 1), compulsory_hbm_frac=round(comp / sec / 1e9 / HBM_PEAK_GBPS, 4))
                 l1_bytes = c[1] * 48.0
-                l1 = dict(bound="l1 (vector-memory path, 256 CUs x 64 B/clk x 2.4 GHz)", achieved=round(l1_bytes / sec / 1e9, 1),
-                          peak=round(L1_PEAK_GBPS, 1), unit="GB/s", frac=round(l1_bytes / sec / 1e9 / L1_PEAK_GBPS, 4),
-                          fetches_per_step=int(c[0]), corner_loads_per_step=int(c[1]), bytes_per_corner=48,
-                          fetches_per_item=round(c[0] / items, 3), Gfetch_per_s=round(c[0] / sec / 1e9, 2),
-                          items=dict(converged=int(c[2]), diverged=int(c[3]), exhausted=int(c[4])),
-                          note="texture-addresser bound: a 16-byte gather instruction takes ~32 clk whatever it hits -- 49 Gfetch/s with EVERY item on one voxel (profiles/r02_broyden_probe.json), 50-51 on the step's spatially sorted batches")
+                l1_rate = l1_bytes / sec / 1e9
+                hbm_side = None
+                if roofline["traffic"]:
+                    hs = roofline["traffic"] * (dcalls / k_instr) / sec / 1e9
+                    hbm_side = dict(GBps=round(hs, 1), frac_of_hbm_peak=round(hs / HBM_PEAK_GBPS, 4), source=roofline["traffic_source"])
+                roofline.update(
+                    bound="l1 (cache-gather, SURVEY 8(d)): vector-memory path, 256 CUs x 64 B/clk x 2.4 GHz",
+                    achieved=round(l1_rate, 1), peak=round(L1_PEAK_GBPS, 1), frac=round(l1_rate / L1_PEAK_GBPS, 4),
+                    algorithmic_model="COUNTED trilinear fetches (ia_broyden_stats, one extra untimed step) x in-range corners x 48 B "
+                                      "through the L1 path / live HIP-event time of the entry point",
+                    fetches_per_step=int(c[0]), corner_loads_per_step=int(c[1]), bytes_per_corner=48,
+                    fetches_per_item=round(c[0] / items, 3), Gfetch_per_s=round(c[0] / sec / 1e9, 2),
+                    items=dict(converged=int(c[2]), diverged=int(c[3]), exhausted=int(c[4])),
+                    hbm_side=hbm_side,
+                    survey_8d_gather_bytes_GBps=round(achieved, 1),
+                    compulsory_hbm_GBps=round(comp / sec / 1e9, 1), compulsory_hbm_frac=round(comp / sec / 1e9 / HBM_PEAK_GBPS, 4),
+                    note="texture-addresser bound: a 16-byte gather instruction takes ~32 clk whatever it hits -- 49 Gfetch/s with EVERY "
+                         "item on one voxel (profiles/r02_broyden_probe.json)")
+                l1 = None
+            # north star's second target (MFMA utilisation of the batched MLP evaluation), in-step: the SDF head of the no-grad
+            # queries (35 -> 64 -> 1: 2 x (35 x 64 + 64) useful FLOP per point) over its live HIP-event time
+            for hname, flop_pt in (("ia_sdf_levels_fwd", 2.0 * (35 * 64 + 64)),):
+                if hname in detail:
+                    hms = sum(c_[0] for c_ in detail[hname])
+                    hpts = sum(c_[1] for c_ in detail[hname])
+                    tf = hpts * flop_pt / (hms * 1e-3) / 1e12
+                    mfma = dict(kernel=hname, bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                                frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4), points_per_step=hpts // k_instr, ms_per_step=round(hms / k_instr, 3),
+                                useful_flop_per_point=flop_pt, note="fp32 MFMA (v_mfma_f32_32x32x2_f32) dense peak; in-step, live HIP events")
             breakdown = {k: dict(calls_per_step=v[0] / k_instr, ms_per_step=round(v[1] / k_instr, 3))
                          for k, v in sorted(per_call.items(), key=lambda kv: -kv[1][1])[:12]}
         cpu = None
@@ -430,7 +455,7 @@ def main():
                        "peak_device_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                        "parallelism": f"frame/ray-batch sharding x{world}", "samples": stats,
                        "library_sources_sha256_16": _build.source_fingerprint(), "library_built_from": _build.built_fingerprint()},
-            "roofline": roofline, "l1_roofline": l1, "cpu_baseline": cpu, "kernel_breakdown_ms_per_step": breakdown,
+            "roofline": roofline, "mfma": mfma, "cpu_baseline": cpu, "kernel_breakdown_ms_per_step": breakdown,
             "ms_per_step_instrumented": round(dt_instr / max(k_instr, 1) * 1e3, 3),
             "abi_kernel_ms_per_step": round(total_ms / max(k_instr, 1), 3),
             "secondary_rays_per_s": (round(world * stats.get("n_secondary", 0) * args.steps / dt, 1) if headline else None),
@@ -440,6 +465,27 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def self_launch_ranks(n_gpus, script=None):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset, N > 1): re-exec the same command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on 127.0.0.1 (one rank per GPU, RCCL) and exit with its
+    status.  Refuses only when fewer than N devices are visible (IA_BENCH_SHARE_GPU=1, the 1-GPU test hook, lifts that).
+    The reference's analogue is launch.py:83-98 (one process, Lightning spawns the DDP ranks)."""
+    if n_gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n_gpus and os.environ.get("IA_BENCH_SHARE_GPU") != "1":
+        sys.exit(f"--gpus {n_gpus}: only {have} GPU(s) visible")
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script or os.path.abspath(sys.argv[0])] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def count_broyden_fetches(step, dev):

@@ -463,7 +463,8 @@ int ia_vi_composite(int64_t n_rays, const int32_t* resampled_packed_info, const 
                     const float* background /*[3]*/, const float* background_rays, float* rgb /*[n,3]*/, ia_stream_t stream);
 int ia_vi_composite_bwd(int64_t n_rays, int64_t F, const int32_t* resampled_packed_info, const int32_t* bg_counts,
                         const int32_t* fg_ray, const float* weights_fg, const float* Lo, const float* background,
-                        const float* g_rgb, float* g_weights_fg, float* g_Lo, float* g_transmittance, ia_stream_t stream);
+                        const float* background_rays /* as passed to the forward */, const float* g_rgb, float* g_weights_fg,
+                        float* g_Lo, float* g_transmittance, ia_stream_t stream);
 /* the reference's index lists: fg_indices [F], bg_indices [R-F], resampled_ray_indices [R], resampled_weights [R] (each optional) */
 int ia_vi_indices(int64_t n_rays, int spp, const int32_t* resampled_packed_info, const int32_t* fg_ray_cnt,
                   const int32_t* fg_start, const int32_t* bg_counts, const int64_t* sampled_idx, const int32_t* fg_counts,

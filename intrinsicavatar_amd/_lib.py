@@ -3,7 +3,6 @@
 There is deliberately no CPU / PyTorch fallback: if the HIP library is missing or a
 tensor is not on a GPU, the call fails loudly.
 """
-import collections
 import ctypes as C
 import os
 
@@ -65,6 +64,40 @@ class _Timed:
         return {k: (len(v), sum(a.elapsed_time(b) for a, b, _, _ in v)) for k, v in self.events.items()}
 
 
+_HEADER = os.path.join(os.path.dirname(_HERE), "include", "ia_amd.h")
+_CTYPE = {"int": C.c_int, "int32_t": C.c_int32, "uint32_t": C.c_uint32, "int64_t": C.c_int64, "uint64_t": C.c_uint64,
+          "size_t": C.c_size_t, "float": C.c_float, "double": C.c_double, "ia_stream_t": C.c_void_p, "void": None}
+
+
+def header_prototypes(path: str = _HEADER):
+    """{name: (restype, [argtypes])} of every `ia_*` prototype in include/ia_amd.h -- the header is the single source of the
+    ABI: the loader declares argtypes / restype for EVERY entry point from it, so a call with a missing, extra or mistyped
+    argument raises in Python instead of reading garbage off the stack.  Pointers (device or host) are void*."""
+    import re
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", " ", txt)
+    txt = re.sub(r"^\s*#[^\n]*", " ", txt, flags=re.M)                # preprocessor lines
+    protos = {}
+    for ret, name, args in re.findall(r"([A-Za-z_][\w\s\*]*?)\b(ia_\w+)\s*\(([^()]*)\)\s*;", txt):
+        def ctype(decl, is_ret=False):
+            decl = decl.replace("const", " ").strip()
+            if "*" in decl:
+                return C.c_char_p if (is_ret and "char" in decl) else C.c_void_p
+            base = decl.split()[0] if is_ret else decl.split()[0]
+            if base not in _CTYPE:
+                raise IaError(f"include/ia_amd.h: unknown type in prototype of {name}: {decl!r}")
+            return _CTYPE[base]
+        ret = ret.strip()
+        if ret.startswith("typedef") or not ret:
+            continue
+        arglist = [a_.strip() for a_ in args.split(",") if a_.strip()]
+        if arglist == ["void"]:
+            arglist = []
+        protos[name] = (ctype(ret, True), [ctype(a_) for a_ in arglist])
+    return protos
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -72,53 +105,41 @@ def lib():
             raise IaError(
                 f"{_SO} not found: build it with `python -m intrinsicavatar_amd.build` "
                 "(there is no CPU fallback for the MI355X hot path)")
+        if not os.path.exists(_HEADER):
+            raise IaError(f"{_HEADER} not found: the C-ABI header declares the argument types of libia_amd.so")
         cdll = C.CDLL(_SO)
-        cdll.ia_last_error.restype = C.c_char_p
-        cdll.ia_scan_tmp_bytes.restype = C.c_int64
-        cdll.ia_scan_tmp_bytes.argtypes = [C.c_int64]
-        cdll.ia_hashgrid_n_entries.restype = C.c_int64
-        cdll.ia_traverse_scratch_bytes.restype = C.c_int64
-        cdll.ia_occgrid_tmp_bytes.restype = C.c_int64
-        cdll.ia_hashgrid_bwd_scratch_bytes.restype = C.c_int64
-        cdll.ia_traverse_fused_scratch_bytes.restype = C.c_int64
-        cdll.ia_hashgrid_fwd_scratch_bytes.restype = C.c_int64
-        cdll.ia_hashgrid_fwd_levels_jac_offset.restype = C.c_int64
-        cdll.ia_eikonal_partials.restype = C.c_int64
-        cdll.ia_deform_filter_compact_tmp_bytes.restype = C.c_size_t
-        cdll.ia_deform_filter_tiles_tmp_bytes.restype = C.c_size_t
-        cdll.ia_deform_filter_tiles_tmp_bytes.argtypes = [C.c_int64]
-        cdll.ia_pbr_shade_bwd_scratch_bytes.restype = C.c_size_t
-        cdll.ia_morton_order_tmp_bytes.restype = C.c_size_t
-        cdll.ia_morton_order_tmp_bytes.argtypes = [C.c_int64]
-        cdll.ia_pbr_shade_bwd_scratch_bytes.argtypes = [C.c_int64]
-        cdll.ia_deform_filter_compact_tmp_bytes.argtypes = [C.c_int64]
+        for name, (restype, argtypes) in header_prototypes().items():
+            fn = getattr(cdll, name)              # AttributeError: the header declares a symbol the library does not export
+            fn.restype, fn.argtypes = restype, argtypes
         _lib = _Timed(cdll)
     return _lib
 
 
 def check(rc: int, what: str = ""):
-    _KEEPALIVE.clear()          # the call that consumed the pointers has enqueued its kernels: stream order protects them now
     if rc != 0:
         msg = lib().ia_last_error().decode(errors="replace")
         raise IaError(f"{what} failed (code {rc}): {msg}")
 
 
-# tensors whose pointers were handed out most recently: a temporary passed as `ptr(x.contiguous())` must stay alive until the
-# ctypes call that consumes the pointer has ENQUEUED its kernel -- otherwise the caching allocator may hand its block to the
-# next temporary of the same argument list (after the enqueue, stream order makes reuse safe).  64 > arguments per call.
-_KEEPALIVE = collections.deque(maxlen=64)        # cleared by check() after every entry-point call
+class _TensorPtr(C.c_void_p):
+    """device pointer that OWNS a reference to its tensor.  A temporary passed as `ptr(x.contiguous())` must stay alive
+    until the ctypes call that consumes the pointer has ENQUEUED its kernel -- otherwise the caching allocator may hand its
+    block to the next temporary of the same argument list (after the enqueue, stream order makes reuse safe).  The pointer
+    objects live in the argument tuple of the call, so the tensors live exactly as long as the call: no global state, no
+    limit on the number of arguments, nested entry-point calls inside an argument expression cannot release anything."""
 
 
 def ptr(t):
     """device pointer of a contiguous CUDA(HIP) tensor, or NULL for None."""
     if t is None:
         return C.c_void_p(0)
-    _KEEPALIVE.append(t)
     if not t.is_cuda:
         raise IaError("intrinsicavatar_amd operators need GPU tensors (no CPU fallback)")
     if not t.is_contiguous():
         raise IaError("tensor must be contiguous")
-    return C.c_void_p(t.data_ptr())
+    p = _TensorPtr(t.data_ptr())
+    p._keep = t
+    return p
 
 
 def stream():

@@ -73,8 +73,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
     fp = source_fingerprint()
-    if os.path.exists(SO) and built_fingerprint() not in (None, fp):
-        force = True                     # the library next to these sources was built from other sources
+    if os.path.exists(SO) and built_fingerprint() != fp:
+        force = True                     # the library next to these sources was built from other sources (or nobody knows from which)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "ia_amd.h"))
     objs, procs = [], []

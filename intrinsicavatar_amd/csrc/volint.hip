@@ -192,13 +192,16 @@ __global__ __launch_bounds__(THREADS) void vi_composite_bwd_kernel(
 
 __global__ __launch_bounds__(THREADS) void vi_composite_bwd_T_kernel(int64_t n_rays, const int32_t* __restrict__ rpi,
                                                                       const int32_t* __restrict__ bg_cnt,
-                                                                      const float* __restrict__ bg, const float* __restrict__ g_rgb,
-                                                                      float* __restrict__ g_T)
+                                                                      const float* __restrict__ bg,
+                                                                      const float* __restrict__ bg_rays /*[n,3] or NULL*/,
+                                                                      const float* __restrict__ g_rgb, float* __restrict__ g_T)
 {
     const int64_t r = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     if (r >= n_rays) return;
     const bool has = rpi[2 * r + 1] > 0 && bg_cnt[r] > 0;
-    g_T[r] = has ? bg[0] * g_rgb[3 * r] + bg[1] * g_rgb[3 * r + 1] + bg[2] * g_rgb[3 * r + 2] : 0.0f;
+    const float b0 = bg_rays ? bg_rays[3 * r] : bg[0], b1 = bg_rays ? bg_rays[3 * r + 1] : bg[1],
+                b2 = bg_rays ? bg_rays[3 * r + 2] : bg[2];                  // the colour the forward multiplied T with
+    g_T[r] = has ? b0 * g_rgb[3 * r] + b1 * g_rgb[3 * r + 1] + b2 * g_rgb[3 * r + 2] : 0.0f;
 }
 
 // ---- per-ray permutation of [0, spp): argsort of uniforms, ties by index (stable) -----------------------------------
@@ -506,19 +509,21 @@ IA_EXPORT int ia_vi_composite(int64_t n_rays, const int32_t* rpi, const int32_t*
                               const float* background, const float* background_rays, float* rgb, ia_stream_t stream)
 {
     if (n_rays == 0) return IA_OK;
+    IA_REQUIRE(n_rays < ((int64_t)1 << 25), "ia_vi_composite: n_rays must stay below 2^25 (one wave per ray, 32-bit grid)");
     vi_composite_kernel<<<ia::cdiv(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
         n_rays, rpi, fg_ray_cnt, fg_start, bg_cnt, weights_fg, Lo, transmittance, background, background_rays, rgb);
     return ia::check_launch("ia_vi_composite");
 }
 
 IA_EXPORT int ia_vi_composite_bwd(int64_t n_rays, int64_t F, const int32_t* rpi, const int32_t* bg_cnt, const int32_t* fg_ray,
-                                  const float* weights_fg, const float* Lo, const float* background, const float* g_rgb,
-                                  float* g_weights_fg, float* g_Lo, float* g_transmittance, ia_stream_t stream)
+                                  const float* weights_fg, const float* Lo, const float* background, const float* background_rays,
+                                  const float* g_rgb, float* g_weights_fg, float* g_Lo, float* g_transmittance, ia_stream_t stream)
 {
     hipStream_t s = (hipStream_t)stream;
     if (F > 0) vi_composite_bwd_kernel<<<ia::cdiv(F, THREADS), THREADS, 0, s>>>(F, fg_ray, weights_fg, Lo, g_rgb, g_weights_fg, g_Lo);
     if (n_rays > 0 && g_transmittance)
-        vi_composite_bwd_T_kernel<<<ia::cdiv(n_rays, THREADS), THREADS, 0, s>>>(n_rays, rpi, bg_cnt, background, g_rgb, g_transmittance);
+        vi_composite_bwd_T_kernel<<<ia::cdiv(n_rays, THREADS), THREADS, 0, s>>>(n_rays, rpi, bg_cnt, background, background_rays, g_rgb,
+                                                                                g_transmittance);
     return ia::check_launch("ia_vi_composite_bwd");
 }
 
@@ -527,6 +532,7 @@ IA_EXPORT int ia_light_shuffle(int64_t n_rays, int spp, const int32_t* fg_ray_cn
 {
     if (n_rays == 0) return IA_OK;
     IA_REQUIRE(spp >= 1 && spp <= 4096, "ia_light_shuffle: 1 <= samples_per_pixel <= 4096");
+    IA_REQUIRE(n_rays < ((int64_t)1 << 31), "ia_light_shuffle: n_rays must stay below 2^31 (one workgroup per ray)");
     int np = 1;
     while (np < spp) np <<= 1;
     if (np < 2) np = 2;
@@ -577,6 +583,7 @@ IA_EXPORT int ia_vi_indices(int64_t n_rays, int spp, const int32_t* rpi, const i
                             float* resampled_weights, ia_stream_t stream)
 {
     if (n_rays == 0) return IA_OK;
+    IA_REQUIRE(n_rays < ((int64_t)1 << 31), "ia_vi_indices: n_rays must stay below 2^31 (one workgroup per ray)");
     vi_indices_kernel<<<(int)n_rays, THREADS, 0, (hipStream_t)stream>>>(n_rays, spp, rpi, fg_ray_cnt, fg_start, bg_cnt, sampled_idx,
                                                                        fg_cnt, weights, transmittance, fg_indices, bg_indices,
                                                                        ray_indices, resampled_weights);

@@ -56,11 +56,22 @@ class EnvironmentLightTensor(torch.nn.Module):
         self.base = torch.nn.Parameter(base)
         self.pmf = None
         self._cdf = None
+        self._pdf_key = None
 
     def __setattr__(self, name, value):
         if name == "base" and isinstance(value, Tensor) and not isinstance(value, torch.nn.Parameter):
             value = torch.nn.Parameter(value.detach().contiguous().float())
         super().__setattr__(name, value)
+
+    def _pdf_tables(self):
+        """(pmf, cdf) of the CURRENT `base`: built on first use and rebuilt whenever `base` was replaced, moved to another
+        device or written in place (load_state_dict, .to(), the test path's HDRI swap, an optimiser step) -- the kernels never
+        see a NULL or stale table.  update_pdf() forces a rebuild (the training path calls it every step)."""
+        b = self.base
+        key = (b.data_ptr(), b._version, str(b.device), tuple(b.shape))
+        if self.pmf is None or self._pdf_key != key:
+            self.update_pdf()
+        return self.pmf, self._cdf
 
     @property
     def pdf_scale(self) -> float:
@@ -91,6 +102,7 @@ class EnvironmentLightTensor(torch.nn.Module):
         w = lum * sin_t
         self.pmf = (w / w.sum()).float().contiguous()
         self._cdf = torch.cumsum(self.pmf.reshape(-1).double(), 0)
+        self._pdf_key = (self.base.data_ptr(), self.base._version, str(self.base.device), tuple(self.base.shape))
 
     @torch.no_grad()
     def sample(self, k: int, u: Optional[Tensor] = None, w2s_rot: Optional[Tensor] = None) -> Tensor:
@@ -104,7 +116,8 @@ class EnvironmentLightTensor(torch.nn.Module):
         u = u.to(dev).float().contiguous()
         out = torch.empty((k, 3), device=dev)
         rot = None if w2s_rot is None else w2s_rot.detach().float().contiguous()
-        L.check(L.lib().ia_envlight_sample(L.i64(k), L.ptr(u), L.ptr(self._cdf), L.i32(H), L.i32(W), L.ptr(rot), L.ptr(out),
+        _, cdf = self._pdf_tables()
+        L.check(L.lib().ia_envlight_sample(L.i64(k), L.ptr(u), L.ptr(cdf), L.i32(H), L.i32(W), L.ptr(rot), L.ptr(out),
                                            L.stream()), "ia_envlight_sample")
         return out
 
@@ -114,7 +127,8 @@ class EnvironmentLightTensor(torch.nn.Module):
         rgb = torch.empty((n, 3), device=d.device) if want_rgb else None
         pdf = torch.empty((n,), device=d.device) if want_pdf else None
         H, W, _ = self.base.shape
-        L.check(L.lib().ia_envlight_eval(L.i64(n), L.ptr(d), L.ptr(self.base.detach()), L.ptr(self.pmf), L.i32(H), L.i32(W), L.ptr(rgb),
+        pmf = self._pdf_tables()[0] if want_pdf else None
+        L.check(L.lib().ia_envlight_eval(L.i64(n), L.ptr(d), L.ptr(self.base.detach()), L.ptr(pmf), L.i32(H), L.i32(W), L.ptr(rgb),
                                          L.ptr(pdf), L.stream()), "ia_envlight_eval")
         return rgb, pdf
 
@@ -227,6 +241,12 @@ def max_value(x: Tensor) -> Tensor:
 MODES = {"light": 0, "uniform_light": 1, "mis": 2, "mats": 3}
 
 
+def _pmf_of(emitter) -> Tensor:
+    """sampling pmf [H,W] of an emitter's current image (never NULL, never stale: EnvironmentLightTensor._pdf_tables)."""
+    tl = emitter._light() if isinstance(emitter, EnvironmentLightSG) else emitter
+    return tl._pdf_tables()[0]
+
+
 def pbr_shade(mode: str, normal, albedo, roughness, metallic, view_dirs, out_dirs, transmittance, indirect_rgb,
               emitter: "EnvironmentLightTensor", w2s_rot, inv_pdf=None):
     """one of the four Monte-Carlo estimators (pbr_{light,uniform_light,mis,mats}_forward) for F shading samples and
@@ -241,7 +261,7 @@ def pbr_shade(mode: str, normal, albedo, roughness, metallic, view_dirs, out_dir
         L.i32(MODES[mode]), L.i64(F_), L.ptr(c(normal)), L.ptr(c(albedo)), L.ptr(c(roughness.reshape(-1))),
         L.ptr(c(metallic.reshape(-1))), L.ptr(c(view_dirs)), L.ptr(c(out_dirs)), L.ptr(c(transmittance.reshape(-1))),
         L.ptr(c(indirect_rgb)), L.ptr(c(inv_pdf.reshape(-1)) if inv_pdf is not None else None), L.ptr(emitter.base),
-        L.ptr(emitter.pmf), L.i32(H), L.i32(W), L.ptr(c(w2s_rot)), L.ptr(Lo), L.ptr(Ld), L.ptr(Ls), L.ptr(vis), L.stream()),
+        L.ptr(_pmf_of(emitter)), L.i32(H), L.i32(W), L.ptr(c(w2s_rot)), L.ptr(Lo), L.ptr(Ld), L.ptr(Ls), L.ptr(vis), L.stream()),
         "ia_pbr_shade")
     return (Lo, Ld, Ls, vis) if mode == "uniform_light" else (Lo, Ld, Ls)
 
@@ -295,7 +315,7 @@ def pbr_shade_differentiable(mode: str, normal, albedo, roughness, metallic, vie
     assert mode in ("light", "uniform_light")
     base = emitter.base if env_base is None else env_base
     return _PbrShade.apply(MODES[mode], normal, albedo, roughness, metallic, base, view_dirs, out_dirs, transmittance,
-                           indirect_rgb, inv_pdf, emitter.pmf, w2s_rot)
+                           indirect_rgb, inv_pdf, _pmf_of(emitter), w2s_rot)
 
 
 def brdf_sample(normal, view_dirs, roughness, u):
@@ -342,7 +362,7 @@ def pbr_light_shade(normal, albedo, roughness, metallic, view_dirs, light_dirs, 
     L.check(L.lib().ia_pbr_light_shade(
         L.i64(F_), L.ptr(c(normal)), L.ptr(c(albedo)), L.ptr(c(roughness.reshape(-1))), L.ptr(c(metallic.reshape(-1))),
         L.ptr(c(view_dirs)), L.ptr(c(light_dirs)), L.ptr(c(transmittance.reshape(-1))), L.ptr(c(indirect_rgb)),
-        L.ptr(emitter.base), L.ptr(emitter.pmf), L.i32(H), L.i32(W), L.ptr(c(w2s_rot)), L.ptr(Lo), L.ptr(Ld), L.ptr(Ls),
+        L.ptr(emitter.base), L.ptr(_pmf_of(emitter)), L.i32(H), L.i32(W), L.ptr(c(w2s_rot)), L.ptr(Lo), L.ptr(Ld), L.ptr(Ls),
         L.stream()), "ia_pbr_light_shade")
     return Lo, Ld, Ls
 
@@ -475,7 +495,7 @@ class _VIComposite(torch.autograd.Function):
         g_Lo = torch.empty((vi.F, 3), device=dev) if ctx.needs_input_grad[2] else None
         g_T = torch.empty(vi.n_rays, device=dev) if ctx.needs_input_grad[3] else None
         L.check(L.lib().ia_vi_composite_bwd(L.i64(vi.n_rays), L.i64(vi.F), L.ptr(vi.resampled_packed_info), L.ptr(vi.bg_counts),
-                                            L.ptr(vi.fg_ray), L.ptr(w_fg), L.ptr(Lo), L.ptr(bg), L.ptr(g_rgb), L.ptr(g_w), L.ptr(g_Lo),
+                                            L.ptr(vi.fg_ray), L.ptr(w_fg), L.ptr(Lo), L.ptr(bg), L.ptr(None), L.ptr(g_rgb), L.ptr(g_w), L.ptr(g_Lo),
                                             L.ptr(g_T), L.stream()), "ia_vi_composite_bwd")
         return None, g_w, g_Lo, (g_T.reshape(ctx.t_shape) if g_T is not None else None), None
 
@@ -519,8 +539,10 @@ def sample_volume_interaction(rays_o, rays_d, ray_indices, t_starts, t_ends, n_r
                               extras: Dict[str, Tensor]):
     """models/pbr/utils.py:70-229, same signature and return tuple: (resampled_packed_info, resampled_ray_indices,
     resampled_weights, fg_indices, bg_indices, resampled_extras).  K1 + csrc/volint.hip kernels; differentiable w.r.t.
-    extras' weights / normals / albedo / roughness / metallic through the gather kernels (resampled_weights is returned
-    detached -- the training path composites with VolumeInteraction.composite instead of the dense [R] weights)."""
+    extras' weights / normals / albedo / roughness / metallic through the gather kernels.
+    DEVIATION (also in INTEGRATION.md): `resampled_weights` is returned DETACHED -- the reference's carries the weight gradient;
+    the training path of this package composites with VolumeInteraction.composite (differentiable in the fg weights and the
+    transmittance) instead of the dense [R] weights.  A caller that composites with resampled_weights gets no weight gradient."""
     weights, sdfs = extras["weights"], extras["sdf"]
     vi = VolumeInteraction(ray_indices, t_starts, t_ends, n_rays, spp, weights, sdfs)
     fg_idx, bg_idx, rri, rw = vi.index_lists(weights, transmittance_map)
@@ -532,7 +554,12 @@ def sample_volume_interaction(rays_o, rays_d, ray_indices, t_starts, t_ends, n_r
         ex = dict(sdf=sdfs[src], alphas=extras["alphas"][src], dists=(t_ends - t_starts)[:, None][src], positions=vi.positions,
                   normals=nrm, albedo=alb, roughness=rough, metallic=metal, t_dirs=vi.view_dirs)
     else:
-        rw = torch.zeros((0,), device=rays_o.device)
+        # no foreground re-sample: zero-size tensors under every key, as models/pbr/utils.py:208-219 returns them
+        dev, z = rays_o.device, (lambda *s_: torch.zeros(s_, device=rays_o.device))     # noqa: E731
+        rw = z(0)
+        md = extras["metallic"].shape[-1] if extras["metallic"].dim() > 1 else 1
+        ex = dict(sdf=z(0), alphas=z(0), dists=z(0, 1), positions=z(0, 3), normals=z(0, 3), albedo=z(0, 3), roughness=z(0, 1),
+                  metallic=z(0, md), t_dirs=z(0, 3))
     return vi.resampled_packed_info, rri, rw, fg_idx, bg_idx, ex
 
 

@@ -78,6 +78,9 @@ class RenderStep:
         return self.density.get_beta().detach().reshape(1).float().contiguous()
 
     SORT_MIN_POINTS = 1 << 20
+    # points per deformer search: P * 13 (point, init) items must stay below 2^31 (165.2 M points) and x / valid take 169 B per
+    # point (25 GB at 150 M); the headline step's 16 Mi-ray secondary chunks average 145 M sample points
+    MAX_SEARCH_POINTS = int(os.environ.get("IA_MAX_SEARCH_POINTS", str(150_000_000)))
     SORT_DROP_BITS = int(os.environ.get("IA_SORT_DROP_BITS", "0"))     # low Morton bits left unsorted (0, 3 or 6)
 
     @torch.no_grad()
@@ -111,6 +114,10 @@ class RenderStep:
         out of the vector L1 instead of L2 (profiles/r02_broyden_probe.json); the values are those of the
         unsorted evaluation, only the schedule changes."""
         n = pts.shape[0]
+        if n > self.MAX_SEARCH_POINTS:
+            # the search keeps x [P,13,3] + valid [P,13] (169 B / point) and its packing needs P * 13 < 2^31: bound the batch in
+            # POINTS, whatever the caller's ray chunk produced (a dense occupancy grid gives 64 samples per secondary ray)
+            return torch.cat([self._sdf_at(pts[a:a + self.MAX_SEARCH_POINTS]) for a in range(0, n, self.MAX_SEARCH_POINTS)])
         if n < self.SORT_MIN_POINTS or os.environ.get("IA_SORT_POINTS", "1") != "1":
             return self.deformer.deform_sdf(pts, self.geometry)
         lib, st = L.lib(), L.stream()
@@ -249,8 +256,9 @@ class RenderStep:
                                   n_secondary: int = 64, chunk: int = int(os.environ.get("IA_SECONDARY_CHUNK", str(1 << 24)))):
         """models/intrinsic_avatar.py:396-545 (eval): march each secondary ray over [near, far] (step (far-near)/63),
         SDF at the sample starts, zero-crossing resampling to 4 intervals (K4), shade them, composite.
-        returns (transmittance [M,1], indirect rgb [M,3]).  Rays are processed in chunks of `chunk` rays (16 Mi: ~145 M sample points
-        and ~25 GB of search outputs per chunk -- sized for 288 GB of HBM; measured 1067 -> 1008 ms per headline step against 2 Mi)."""
+        returns (transmittance [M,1], indirect rgb [M,3]).  Rays are processed in chunks of at most `chunk` rays (16 Mi: ~145 M sample
+        points and ~25 GB of search outputs per chunk on the headline scene -- sized for 288 GB of HBM; measured 1067 -> 1008 ms per
+        headline step against 2 Mi); the sample points of a chunk go through the search in batches of <= MAX_SEARCH_POINTS."""
         M = rays_o.shape[0]
         dev = rays_o.device
         tr = torch.ones((M, 1), device=dev)
@@ -258,12 +266,20 @@ class RenderStep:
         step = (far - near) / (n_secondary - 1)
         beta = self._beta()
         w2s_rot = self.deformer.w2s[:3, :3].contiguous()
-        for c0 in range(0, M, chunk):
-            ro, rd = rays_o[c0:c0 + chunk].contiguous(), rays_d[c0:c0 + chunk].contiguous()
+        # ray chunks of at most `chunk` rays; a chunk whose march produced more sample points than four search batches is split
+        # in two and marched again (the march costs ~1 ms): the working set is bounded in SAMPLES, not only in rays
+        work = [(c0, min(c0 + chunk, M)) for c0 in range(0, M, chunk)][::-1]
+        while work:
+            c0, c1 = work.pop()
+            ro, rd = rays_o[c0:c1].contiguous(), rays_d[c0:c1].contiguous()
             m = ro.shape[0]
             intervals, samples, _ = nerfacc.traverse_grids(
                 ro, rd, self.binaries, self.aabbs, torch.full((m,), near, device=dev), torch.full((m,), far, device=dev),
                 step, 0.0, grid_bits=self.grid_bits, max_extent=far - near)
+            if samples.vals.shape[0] > 4 * self.MAX_SEARCH_POINTS and m > 1:
+                del intervals, samples
+                work += [(c0 + m // 2, c1), (c0, c0 + m // 2)]
+                continue
             t_starts, t_ends = samples.interval_ends(intervals)
             ray_indices = samples.ray_indices
             if t_starts.numel() == 0:

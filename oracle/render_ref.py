@@ -258,17 +258,21 @@ def light_shuffle(n_rays, spp, rpi, fg_idx, shuffle_u):
 
 
 def relight_step(sc, rays_world, spp=16, seed=0, light_u=None, shuffle_u=None, jitter=None, global_illumination=False,
-                 background_color=(1.0, 1.0, 1.0), importance_sample=True, render_mode="light"):
+                 background_color=(1.0, 1.0, 1.0), importance_sample=True, render_mode="light", light_sampling="shared"):
     """forward_ with enable_phys, render_mode = light, eval form (models/intrinsic_avatar.py:950-1651): steps 1-4 as
     render_step, step 5 = rendering_with_normals_mats_sdf (volrend.py:810-1020), steps 6-8 = :1288-1470.
     light_u [spp,3] (emitter.sample uniforms) and shuffle_u [n_rays,spp] are explicit (drawn from `seed` when None).
+    light_sampling (render_mode 'light'): 'shared' = the eval branch of pbr_light_forward (:782-789: one set of spp directions
+    per frame, permuted per ray); 'per_point' = its `self.training` branch (:777-781): emitter.sample(F) -- an independent
+    direction per foreground re-sample, light_u [>= F, 3], no shuffle.
     sc additionally carries mat_W, mat_b, env_base [H,W,3]."""
     from . import pbr_ref as Pb
     rng = np.random.default_rng(seed)
     n = rays_world.shape[0]
+    per_point = render_mode == "light" and light_sampling == "per_point"
     if light_u is None:
-        light_u = rng.random((spp, 3), dtype=np.float32)
-    if shuffle_u is None:
+        light_u = rng.random(((n * spp) if per_point else spp, 3), dtype=np.float32)
+    if shuffle_u is None and not per_point:
         shuffle_u = rng.random((n, spp), dtype=np.float32)
     bgc = np.asarray(background_color, np.float32)
     base = render_step(sc, rays_world, jitter=jitter, importance_sample=importance_sample, _sampling_only=True)
@@ -294,16 +298,22 @@ def relight_step(sc, rays_world, spp=16, seed=0, light_u=None, shuffle_u=None, j
             F_ = len(fg_idx)
             R = sc.w2s[:3, :3]
             pmf = Pb.envlight_pmf(sc.env_base)
-            if render_mode == "light":
-                dirs_world = Pb.envlight_sample(pmf, spp, light_u[:, 0].astype(np.float64), light_u[:, 1].astype(np.float64),
-                                                light_u[:, 2].astype(np.float64))
-                dirs_smpl = _normalize(dirs_world @ R.T).astype(np.float32)                 # transform_dirs_w2s
-                inv_pdf_all = None
-            else:                                                                            # uniform_light (:654-753, :1390-1401)
-                assert render_mode == "uniform_light" and spp == 512
-                dirs_smpl, inv_pdf_all = Pb.uniform_sphere_stratified(16, 32, light_u[:, :2])
-            shuffled = light_shuffle(n, spp, rpi, fg_idx, shuffle_u)
-            out_dirs = dirs_smpl[shuffled]
+            shuffled = None
+            if per_point:                                                                    # training branch (:777-781)
+                u = light_u[:F_]
+                dirs_world = Pb.envlight_sample(pmf, F_, u[:, 0].astype(np.float64), u[:, 1].astype(np.float64), u[:, 2].astype(np.float64))
+                out_dirs = _normalize(dirs_world @ R.T).astype(np.float32)                   # transform_dirs_w2s
+            else:
+                if render_mode == "light":
+                    dirs_world = Pb.envlight_sample(pmf, spp, light_u[:, 0].astype(np.float64), light_u[:, 1].astype(np.float64),
+                                                    light_u[:, 2].astype(np.float64))
+                    dirs_smpl = _normalize(dirs_world @ R.T).astype(np.float32)             # transform_dirs_w2s
+                    inv_pdf_all = None
+                else:                                                                        # uniform_light (:654-753, :1390-1401)
+                    assert render_mode == "uniform_light" and spp == 512
+                    dirs_smpl, inv_pdf_all = Pb.uniform_sphere_stratified(16, 32, light_u[:, :2])
+                shuffled = light_shuffle(n, spp, rpi, fg_idx, shuffle_u)
+                out_dirs = dirs_smpl[shuffled]
             cos_mask = (ex["normals"] * out_dirs).sum(-1) > 1e-6
             sec_tr = np.zeros((F_, 1), np.float32)
             sec_rgb = np.zeros((F_, 3), np.float32)

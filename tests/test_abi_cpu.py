@@ -72,3 +72,66 @@ def test_install_aliases_resolves_the_reference_imports():
             "assert nerfacc.__name__ == 'intrinsicavatar_amd.nerfacc'; print('ok')")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:]
+
+
+def _call_sites():
+    """(file, line, entry point, [arg kind or None], has_star) of every `<lib>.ia_*(...)` call in the package, bench and tools.
+    arg kind = the ctypes class the argument expression evidently has (L.i64 / L.i32 / L.f32 / L.ptr / L.stream / C.c_*)."""
+    import ast
+    import ctypes as C
+    kinds = {"i64": C.c_int64, "i32": C.c_int, "f32": C.c_float, "ptr": C.c_void_p, "stream": C.c_void_p,
+             "c_size_t": C.c_size_t, "c_int64": C.c_int64, "c_int": C.c_int, "c_float": C.c_float, "c_void_p": C.c_void_p,
+             "c_uint32": C.c_uint32, "c_uint64": C.c_uint64}
+    files = [os.path.join(ROOT, "bench.py")]
+    for d in ("intrinsicavatar_amd", "tools"):
+        files += [os.path.join(ROOT, d, f) for f in sorted(os.listdir(os.path.join(ROOT, d))) if f.endswith(".py")]
+    out = []
+    for path in files:
+        tree = ast.parse(open(path).read())
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr.startswith("ia_"):
+                args, star = [], False
+                for a in node.args:
+                    if isinstance(a, ast.Starred):
+                        star = True
+                        continue
+                    k = None
+                    if isinstance(a, ast.Call) and isinstance(a.func, ast.Attribute):
+                        k = kinds.get(a.func.attr)
+                    args.append(k)
+                out.append((os.path.relpath(path, ROOT), node.lineno, node.func.attr, args, star))
+    return out
+
+
+def test_every_call_site_matches_the_header():
+    """host logic: the loader takes argtypes / restype of all entry points from include/ia_amd.h; every call site in the package
+    must pass the declared NUMBER of arguments and, where the expression shows its ctypes class, the declared TYPE."""
+    from intrinsicavatar_amd import _lib
+    protos = _lib.header_prototypes()
+    assert len(protos) == len(_declared_symbols())
+    sites = _call_sites()
+    assert len(sites) > 100
+    bad = []
+    for f, line, name, args, star in sites:
+        if name not in protos:
+            bad.append((f, line, name, "not declared in include/ia_amd.h"))
+            continue
+        want = protos[name][1]
+        if (not star and len(args) != len(want)) or (star and len(args) > len(want)):
+            bad.append((f, line, name, f"{len(args)} arguments, header declares {len(want)}"))
+            continue
+        if not star:
+            for i, (k, w) in enumerate(zip(args, want)):
+                if k is not None and k is not w:
+                    bad.append((f, line, name, f"argument {i}: {k.__name__} passed, header declares {w.__name__}"))
+    assert not bad, "\n".join(map(str, bad))
+
+
+def test_loader_declares_argtypes_for_every_entry_point(so_path):
+    from intrinsicavatar_amd import _lib
+    l = _lib.lib()
+    for name, (restype, argtypes) in _lib.header_prototypes().items():
+        fn = getattr(l._cdll, name)
+        assert fn.argtypes is not None and list(fn.argtypes) == argtypes and fn.restype is restype, name
+    with pytest.raises((TypeError, ctypes.ArgumentError)):
+        l.ia_scan_tmp_bytes()                            # wrong arity is an error in Python, not a garbage read

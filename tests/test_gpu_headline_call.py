@@ -1,0 +1,193 @@
+"""GPU (MI355X): the EXACT call bench.py times (bench.py step_headline): RenderStep.forward_backward_phys with
+render_mode="light", light_sampling="per_point" (the `self.training` branch of pbr_light_forward,
+models/intrinsic_avatar.py:772-781: an independent emitter.sample() per foreground re-sample), global_illumination=True,
+an SG-generated environment image shared by >= 2 ray chunks through a leaf, loss_scale = chunk fraction, explicit light_u.
+
+  * backward half: loss, physically based image and EVERY parameter group (both hash tables, SDF / radiance MLPs, beta,
+    material head + Lipschitz bounds, SG lobe axes / sharpness / amplitudes) against float64 torch autograd of the same
+    computation on the sample set / secondary rays the GPU found (tests/torch_ref.py);
+  * forward half: against the CPU oracle's relight_step(light_sampling="per_point") on the same rays and uniforms.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def _frame(hw=40):
+    from intrinsicavatar_amd import build
+    build.build()
+    from intrinsicavatar_amd import synthetic as S, fields, pbr
+    rs, rays, export = S.build_frame(DEV, hw, hw, pose_seed=0, beta=0.05, num_samples_per_ray=64, grid_D=16, grid_H=64, grid_W=64,
+                                     smooth_iters=5, hash_amp=1e-2)
+    mat = fields.VolumeMaterial(seed=2).to(DEV)
+    sg = pbr.EnvironmentLightSG(num_SGs=12, base_res=16, seed=4).to(DEV)
+    return rs, rays, export, mat, sg
+
+
+def test_headline_training_call_vs_fp64_autograd():
+    from intrinsicavatar_amd import pbr, render
+    from tests import torch_ref as TR
+    rs, rays, _, mat, sg = _frame(40)
+    with torch.no_grad():
+        for c in mat.network.lipshitz_bound_per_layer:
+            c.mul_(0.35)                                              # make the Lipschitz clamp ACTIVE (else its gradient is 0)
+    n = rays.shape[0]
+    g = torch.Generator().manual_seed(11)
+    target = torch.rand((n, 3), generator=g).to(DEV)
+    tmask = (torch.rand(n, generator=g) > 0.5).float().to(DEV)
+    spp = 64
+    bg = torch.tensor([0.1, 0.2, 0.3], device=DEV)
+    edges = [0, n // 2 + 37, n]                                       # two unequal ray chunks
+    light_us = [torch.rand(((b - a) * spp, 3), generator=g).to(DEV) for a, b in zip(edges[:-1], edges[1:])]
+    params = rs.parameters() + [p for p in mat.parameters() if p.requires_grad] + list(sg.parameters())
+    for p in params:
+        p.grad = None
+    # ---- exactly bench.py's step_headline (with explicit light_u)
+    img = sg.generate_image()
+    leaf = img.detach().requires_grad_(True)
+    emitter = pbr.EnvironmentLightTensor(leaf.detach())
+    emitter.update_pdf()
+    outs, loss_gpu = [], 0.0
+    for (a, b), lu in zip(zip(edges[:-1], edges[1:]), light_us):
+        frac = (b - a) / n
+        o = rs.forward_backward_phys(rays[a:b].contiguous(), target[a:b].contiguous(), mat, emitter, spp, lu, None,
+                                     target_mask=tmask[a:b].contiguous(), render_mode="light", env_base=leaf, background_color=bg,
+                                     global_illumination=True, light_sampling="per_point", loss_scale=frac)
+        outs.append(o)
+        loss_gpu += frac * float(o["loss"])
+    assert leaf.grad is not None
+    img.backward(leaf.grad)
+    # ---- float64 autograd of the same computation on the sample sets / secondary rays the GPU found
+    geo, rad, dens = rs.geometry, rs.radiance, rs.density
+    D = lambda t: t.detach().cpu().double()      # noqa: E731
+    l0, l2 = geo.network.layers[0], geo.network.layers[2]
+    rl = rad.network.layers
+    P = dict(geo_center=D(geo.center), geo_scale=D(geo.scale), geo_table=D(geo.grid_params), geo_mask=D(geo.prog.mask(geo.global_step, "cpu")),
+             geo_g0=D(l0.weight_g), geo_v0=D(l0.weight_v), geo_b0=D(l0.bias), geo_g2=D(l2.weight_g), geo_v2=D(l2.weight_v),
+             geo_b2=D(l2.bias), beta=D(dens.beta), rad_center=D(rad.center), rad_scale=D(rad.scale), rad_table=D(rad.grid_params),
+             rad_mask=D(rad.prog.mask(rad.global_step, "cpu")), rad_sh_mask=D(rad.sh_mask[0]),
+             rad_W0=D(rl[0].weight), rad_b0=D(rl[0].bias), rad_W2=D(rl[2].weight), rad_b2=D(rl[2].bias),
+             rad_W4=D(rl[4].weight), rad_b4=D(rl[4].bias), sg_axis=D(sg.axis), sg_log_lambda=D(sg.log_lambda), sg_mu=D(sg.mu))
+    for i in range(3):
+        P[f"mat_W{i}"], P[f"mat_b{i}"] = D(mat.network.weights_per_layer[i]), D(mat.network.biases_per_layer[i])
+        P[f"mat_c{i}"] = D(mat.network.lipshitz_bound_per_layer[i])
+    leaves = ["geo_table", "geo_v0", "geo_b0", "geo_v2", "beta", "rad_table", "rad_W0", "rad_W4", "sg_axis", "sg_log_lambda", "sg_mu"] + \
+             [f"mat_{k}{i}" for i in range(3) for k in "Wbc"]
+    for k in leaves:
+        P[k].requires_grad_(True)
+    P["env_base"] = TR.sg_image_t(P["sg_axis"], P["sg_log_lambda"], P["sg_mu"], sg.base_res)
+    assert float((P["env_base"].detach() - D(img)).abs().max()) < 1e-5
+    w2s_rot = rs.deformer.w2s[:3, :3].contiguous()
+    loss_ref, imgs_ref = 0.0, []
+    for (a, b), o in zip(zip(edges[:-1], edges[1:]), outs):
+        r = rays[a:b].contiguous()
+        rays_o, rays_d, far, ts, te, ri, pi, _ = rs.sample(r, None)
+        assert ts.shape[0] == o["n_samples"]
+        vi = o["volume_interaction"]
+        assert vi.F > 3000 and o["stats"]["n_secondary"] > 1000
+        pts = render.ray_points(rays_o, rays_d, ri, ts, te)
+        d = rs.deformer.deform(pts, geo, with_grad=False, with_feature=False, want_fwd=True)
+        sel = d["sel"].long().clamp(min=0)
+        c2w = d["fwd_J"].reshape(-1, 3, 3)[d["cand_src"].long()[sel]]
+        dirs_world = torch.nn.functional.normalize(o["out_dirs"] @ w2s_rot, dim=-1)
+        fixed = dict(pts_cano=D(d["pts_cano"]), valid=d["valid"].cpu(), c2w=D(c2w), w2s_rot=D(w2s_rot), rays_d=D(rays_d),
+                     ray_indices=ri.cpu(), t_starts=D(ts), t_ends=D(te), n_rays=b - a, packed_info=pi.cpu(),
+                     fg_src=vi.fg_src.long().cpu(), fg_ray=vi.fg_ray.long().cpu(), fg_counts=vi.fg_counts.cpu(),
+                     has_samples=(vi.resampled_packed_info[:, 1] > 0).cpu(), has_bg=(vi.bg_counts > 0).cpu(),
+                     out_dirs=D(o["out_dirs"]), sec_tr=D(o["secondary_tr"][:, 0]), sec_rgb=D(o["secondary_rgb"]),
+                     light_pdf=D(emitter.pdf(dirs_world)[:, 0]), env_R=D(w2s_rot))
+        assert float(fixed["sec_rgb"].abs().max()) > 0, "global illumination term is identically zero -- test is vacuous"
+        lc, ref = TR.shade_reference_phys(P, fixed, D(target[a:b]), D(tmask[a:b]), D(bg), mode="light")
+        loss_ref = loss_ref + (b - a) / n * lc
+        imgs_ref.append(ref["comp_rgb_phys"].detach())
+    loss_ref.backward()
+    assert abs(loss_gpu - float(loss_ref)) < 5e-4 * max(1.0, abs(float(loss_ref))), (loss_gpu, float(loss_ref))
+    err = np.abs(np.concatenate([N(o["comp_rgb_phys"]) for o in outs]) - torch.cat(imgs_ref).numpy())
+    assert (err > 1e-3).mean() < 1e-2 and err.max() < 0.1, (float((err > 1e-3).mean()), float(err.max()))
+    got = dict(geo_table=geo.grid_params.grad, geo_v0=l0.weight_v.grad, geo_b0=l0.bias.grad, geo_v2=l2.weight_v.grad, beta=dens.beta.grad,
+               rad_table=rad.grid_params.grad, rad_W0=rl[0].weight.grad, rad_W4=rl[4].weight.grad,
+               sg_axis=sg.axis.grad, sg_log_lambda=sg.log_lambda.grad, sg_mu=sg.mu.grad)
+    for i in range(3):
+        got[f"mat_W{i}"], got[f"mat_b{i}"] = mat.network.weights_per_layer[i].grad, mat.network.biases_per_layer[i].grad
+        got[f"mat_c{i}"] = mat.network.lipshitz_bound_per_layer[i].grad
+    worst = {}
+    for k in leaves:
+        assert got[k] is not None, f"no gradient reached {k}"
+        a_, b_ = got[k].detach().cpu().double().reshape(-1), P[k].grad.reshape(-1)
+        assert float(b_.abs().max()) > 0, f"reference gradient of {k} is identically zero -- test is vacuous"
+        worst[k] = float((a_ - b_).norm() / b_.norm()) if k.endswith("_table") else float((a_ - b_).abs().max() / b_.abs().max())
+    print(worst)
+    bad = {k: v for k, v in worst.items() if v > (5e-2 if k.endswith("_table") else 1e-2)}
+    assert not bad, worst
+
+
+def test_headline_forward_vs_oracle_per_point(oracle):
+    """forward half of the timed call against oracle/render_ref.py relight_step(light_sampling='per_point').  The k-th
+    foreground re-sample draws its light direction from light_u[k], so a single fg / bg flip (the K1 weights come from fp32
+    field kernels) re-pairs every later sample: per-sample quantities are compared on the rays BEFORE the first ray whose
+    foreground count differs (and that prefix must be most of the frame)."""
+    from intrinsicavatar_amd import synthetic as S, pbr, train_phys
+    from oracle import render_ref as R, pbr_ref as Pb
+    rs, rays, export, mat, sg = _frame(32)
+    n = rays.shape[0]
+    spp = 32
+    img = sg.generate_image().detach()
+    emitter = pbr.EnvironmentLightTensor(img)
+    emitter.update_pdf()
+    sc = R.Scene(**export, **S.export_phys(mat, img))
+    rng = np.random.default_rng(3)
+    light_u = rng.random((n * spp, 3), dtype=np.float32)
+    bg = np.array([0.2, 0.4, 0.6], np.float32)
+    ref = R.relight_step(sc, N(rays), spp=spp, light_u=light_u, global_illumination=True, background_color=bg, light_sampling="per_point")
+    with torch.no_grad():
+        rays_o, rays_d, far, ts, te, ri, pi, st = rs.sample(rays, None)
+    out = train_phys.shade_differentiable_phys(rs, mat, emitter, rays_o, rays_d, ri, ts, te, pi, spp, T(light_u), None, render_mode="light",
+                                               background_color=T(bg), global_illumination=True, light_sampling="per_point")
+    rst = ref["stats"]
+    assert ts.shape[0] == rst["n_samples"] and rst["n_fg"] > 2000
+    vi = out["volume_interaction"]
+    assert np.array_equal(N(vi.resampled_packed_info), ref["resampled_packed_info"])
+    assert abs(vi.F - rst["n_fg"]) <= 0.002 * rst["n_fg"] + 2
+    # per-ray foreground counts -> the common prefix
+    cnt_g = N(vi.fg_ray_cnt).astype(np.int64)
+    rri = np.repeat(np.nonzero(ref["resampled_packed_info"][:, 1] > 0)[0], spp)
+    cnt_r = np.bincount(rri[ref["fg_indices"]], minlength=n)
+    diff = np.nonzero(cnt_g != cnt_r)[0]
+    r0 = int(diff[0]) if diff.size else n
+    F0 = int(cnt_r[:r0].sum())
+    assert F0 >= 0.5 * rst["n_fg"], (r0, F0, rst["n_fg"])
+    # light directions: same uniforms through the same CDF (fp64 both sides); a CDF threshold can fall on the other texel
+    dg, dr = N(out["out_dirs"])[:F0], ref["out_dirs"][:F0]
+    assert (np.abs(dg - dr).max(-1) < 1e-4).mean() >= 0.999
+    same_dir = np.abs(dg - dr).max(-1) < 1e-4
+    tr_g, tr_r = N(out["secondary_tr"])[:F0, 0], ref["secondary_tr"][:F0, 0]
+    agree = np.abs(tr_g - tr_r) <= 2e-3
+    assert agree[same_dir].mean() >= 0.99, float(agree[same_dir].mean())
+    ok = agree & same_dir
+    Lo_g, Lo_r = N(out["fg_Lo"])[:F0][ok], ref["fg_Lo"][:F0][ok]
+    scale = np.abs(Lo_r).mean() + 1e-6
+    assert (np.abs(Lo_g - Lo_r).max(-1) <= 5e-3 * scale + 5e-3 * np.abs(Lo_r).max(-1)).mean() >= 0.99
+    # the light pdf the estimator divides by, against the oracle's on the same directions
+    dw = dr @ sc.w2s[:3, :3]
+    dw = dw / np.maximum(np.linalg.norm(dw, axis=-1, keepdims=True), 1e-6)
+    pdf_r = Pb.envlight_pdf(Pb.envlight_pmf(sc.env_base), dw.astype(np.float32))
+    pdf_g = N(emitter.pdf(T(dw.astype(np.float32))))[:, 0]
+    assert (np.abs(pdf_g - pdf_r) <= 1e-4 * np.abs(pdf_r) + 1e-7).mean() >= 0.999
+    # image on the prefix rays
+    img_g, img_r = N(out["comp_rgb_phys"])[:r0], ref["comp_rgb_phys"][:r0]
+    err = np.abs(img_g - img_r).max(-1)
+    tol = 2e-2 * np.abs(img_r).max(-1) + 2e-2
+    assert (err <= tol).mean() >= 0.98, ((err > tol).mean(), err.max())
+    has = ref["resampled_packed_info"][:r0, 1] > 0
+    assert abs(img_g[has].mean() - img_r[has].mean()) <= 1e-2 * abs(img_r[has].mean())

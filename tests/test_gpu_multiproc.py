@@ -94,3 +94,32 @@ def test_two_rank_training_step_equals_single_process(tmp_path):
             moved += 1
             assert (p0 - ps).abs().max().item() <= 0.02 * step + 1e-7, (i, (p0 - ps).abs().max().item(), step)
     assert moved >= 4
+
+
+def _run_line(cmd, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IA_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable] + cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks():
+    """the driver's command form is plain `python3 bench.py --gpus N --steps K --warmup W` (no launcher, WORLD_SIZE unset):
+    bench.py must re-execute itself under torch.distributed.run.  Two ranks share the box's one GPU over gloo
+    (IA_BENCH_SHARE_GPU=1) -- the control flow of N > 1, not a measurement."""
+    line = _run_line(["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--hw", "64", "--spp", "16"])
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["config"]["samples"]["n_fg"] > 0 and line["config"]["samples"]["n_secondary"] > 0
+
+
+def test_relight_bench_starts_its_own_ranks():
+    line = _run_line(["tools/relight_bench.py", "--gpus", "2", "--frames", "2", "--hw", "48", "--spp", "16"])
+    assert line["n_gpus"] == 2 and line["frames"] == 2 and line["secondary_rays"] > 0

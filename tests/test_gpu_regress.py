@@ -101,3 +101,73 @@ def test_occupancy_bit_caches_follow_the_grid():
     _, ri, ts2, _ = est.sampling(o, d, render_step_size=0.05)
     assert 0 < ts2.numel() < ts.numel()
     assert torch.equal(est._grid_bits(0), nerfacc.pack_occupancy_bits(est.binaries[0]))
+
+
+# ----------------------------------------------------------------------------- round-2 review
+def _small_frame():
+    from intrinsicavatar_amd import synthetic as S
+    return S.build_frame(DEV, 40, 40, pose_seed=0, beta=0.01, num_samples_per_ray=64, grid_D=16, grid_H=64, grid_W=64,
+                         smooth_iters=5, hash_amp=1e-2)
+
+
+def test_secondary_work_is_bounded_in_sample_points_not_only_in_rays():
+    """compute_indirect_radiance: a ray chunk whose march yields more sample points than the search can take (P * 13 < 2^31,
+    169 B / point) is split / evaluated in point batches; the result is that of the unbounded evaluation."""
+    rs, rays, _ = _small_frame()
+    g = torch.Generator().manual_seed(1)
+    M = 30000
+    o = (torch.rand((M, 3), generator=g) * 0.6 - 0.3).to(DEV)
+    o[:, 1] -= 0.2
+    d = torch.nn.functional.normalize(torch.randn((M, 3), generator=g), dim=-1).to(DEV)
+    tr0, rgb0 = rs.compute_indirect_radiance(o, d)
+    assert float((tr0 < 0.5).float().mean()) > 0.02, "no secondary ray hits the body -- test is vacuous"
+    old = rs.MAX_SEARCH_POINTS
+    try:
+        rs.MAX_SEARCH_POINTS = 20000                  # << the ~10^5..10^6 sample points of this batch: forces ray splits AND point batches
+        tr1, rgb1 = rs.compute_indirect_radiance(o, d)
+    finally:
+        rs.MAX_SEARCH_POINTS = old
+    assert torch.equal(tr0, tr1) and torch.equal(rgb0, rgb1)
+
+
+def test_envlight_sampling_tables_follow_the_image():
+    """EnvironmentLightTensor: sample / pdf without an explicit update_pdf() build the tables (no NULL dereference on the
+    device), and a replaced / overwritten `base` is never sampled with the old tables."""
+    from intrinsicavatar_amd import pbr
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand((16, 32, 3), generator=g).to(DEV)
+    e = pbr.EnvironmentLightTensor(a)
+    u = torch.rand((4000, 3), generator=g).to(DEV)
+    d0 = e.sample(4000, u)                                       # no update_pdf() before
+    p0 = e.pdf(d0)
+    e2 = pbr.EnvironmentLightTensor(a)
+    e2.update_pdf()
+    assert torch.equal(d0, e2.sample(4000, u)) and torch.equal(p0, e2.pdf(d0))
+    b = a.clone()
+    b[:8] *= 50.0                                                # bright upper half
+    e.base = b                                                   # the test path's HDRI swap (models/intrinsic_avatar.py:297-301)
+    d1 = e.sample(4000, u)
+    assert float((d1[:, 1] > 0).float().mean()) > 0.9           # y up = upper rows
+    with torch.no_grad():
+        e.base.copy_(a)                                          # in-place write (load_state_dict)
+    assert torch.equal(e.sample(4000, u), d0)
+
+
+def test_sample_volume_interaction_without_foreground_has_every_key():
+    """models/pbr/utils.py:208-219: with no foreground re-sample the extras hold zero-size tensors under every key."""
+    from intrinsicavatar_amd import pbr, lib_nerfacc
+    n, S_ = 6, 12
+    ri = torch.arange(n, device=DEV).repeat_interleave(2)
+    ts = torch.linspace(0.1, 0.5, S_, device=DEV)
+    te = ts + 0.01
+    w = torch.zeros(S_, device=DEV)                              # zero weights: every re-sample falls into the background bin
+    ex_in = dict(weights=w, sdf=torch.ones(S_, device=DEV), alphas=w.clone(), normals=torch.zeros((S_, 3), device=DEV),
+                 albedo=torch.zeros((S_, 3), device=DEV), roughness=torch.zeros((S_, 1), device=DEV),
+                 metallic=torch.zeros((S_, 1), device=DEV))
+    ro = torch.zeros((n, 3), device=DEV)
+    rd = torch.tensor([[0.0, 0.0, 1.0]], device=DEV).repeat(n, 1)
+    rpi, rri, rw, fg, bg, ex = pbr.sample_volume_interaction(ro, rd, ri, ts, te, n, 8, torch.ones((n, 1), device=DEV), ex_in)
+    assert fg.numel() == 0 and bg.numel() == n * 8
+    assert set(ex) == {"sdf", "alphas", "dists", "positions", "normals", "albedo", "roughness", "metallic", "t_dirs"}
+    assert all(v.shape[0] == 0 for v in ex.values())
+    assert ex["positions"].shape == (0, 3) and ex["roughness"].shape == (0, 1)

@@ -239,14 +239,44 @@ def pbr_uniform_light_t(n, albedo, rough, metal, view_dirs, wo, tr, base, R, inv
     return ((1 - metal[:, None]) * albedo) * Ld + Ls, Ld, Ls
 
 
-def shade_reference_phys(P, fixed, target_rgb, target_mask, background, lambda_phys=1.0, **kw):
+def pbr_light_t(n, albedo, rough, metal, view_dirs, wo, tr, ind_rgb, base, R, pdf):
+    """pbr_light_forward (intrinsic_avatar.py:755-861) on given directions / transmittance / indirect radiance / light pdf
+    (all no_grad constants there), fp64; differentiable in the materials, the normal and the environment image."""
+    cosm = (n * wo).sum(-1) > 1e-6
+    t = tr.clamp(0, 1)
+    live = cosm & (t > 0)
+    diff, spec = brdf_eval_t(n, -view_dirs, wo, rough, albedo, metal)
+    dw = torch.nn.functional.normalize(wo @ R, dim=-1)
+    em = torch.where(live[:, None], env_eval_t(base, dw), torch.zeros_like(dw))
+    p = torch.where(live & (pdf > 0), pdf, torch.ones_like(pdf))
+    Li = em * t[:, None] + (ind_rgb if ind_rgb is not None else 0.0)
+    z = torch.zeros_like(Li)
+    Ld = torch.where(cosm[:, None], Li * diff[:, None] / p[:, None], z)
+    Ls = torch.where(cosm[:, None], Li * spec / p[:, None], z)
+    return ((1 - metal[:, None]) * albedo) * Ld + Ls, Ld, Ls
+
+
+def sg_image_t(axis, log_lambda, mu, base_res):
+    """EnvironmentLightSG.generate_image in fp64: sum_k softplus(mu_k) exp(lambda_k (d . xi_k - 1)) on the equirect grid."""
+    H, W = base_res, 2 * base_res
+    v = (torch.arange(H, dtype=axis.dtype) + 0.5) / H
+    u = (torch.arange(W, dtype=axis.dtype) + 0.5) / W
+    th, ph = (v * math.pi)[:, None], ((u - 0.5) * 2 * math.pi)[None, :]
+    d = torch.stack([torch.sin(th) * torch.sin(ph), torch.cos(th).expand(H, W), -torch.sin(th) * torch.cos(ph)], -1)
+    xi = torch.nn.functional.normalize(axis, dim=-1)
+    w = torch.exp(torch.exp(log_lambda) * (d.reshape(-1, 3) @ xi.T - 1.0))
+    return (w @ torch.nn.functional.softplus(mu)).reshape(H, W, 3)
+
+
+def shade_reference_phys(P, fixed, target_rgb, target_mask, background, lambda_phys=1.0, mode="uniform_light", **kw):
     """shade_reference + the physically based branch of the training step (BASELINE config 4), float64 autograd:
     material head on [radiance embedding | geometry feature] (models/intrinsic_avatar.py:1100-1113, pbr/material.py:31-51,
     LipshitzMLP network_utils.py:396-428), re-sampled weights w / count and attribute gathers (models/pbr/utils.py:137-206),
     uniform_light estimator on the GIVEN secondary rays (pbr_uniform_light_forward :654-753; directions, transmittance and
     inverse pdf are no_grad constants there too), Lo.scatter_ + accumulate (:1335-1342,:1420-1466), L1 on the image.
+    mode 'light': pbr_light_forward (:755-861) instead, with fixed['light_pdf'] and (global illumination) fixed['sec_rgb'].
     fixed additionally carries: fg_src, fg_ray (int64 [F]), fg_counts [S], has_samples / has_bg (bool [n]), out_dirs, sec_tr,
-    inv_pdf, env_R."""
+    inv_pdf | light_pdf (, sec_rgb), env_R."""
     loss, r = shade_reference(P, fixed, target_rgb, target_mask, **kw)
     nrm = lambda v: v / v.norm(dim=-1, keepdim=True).clamp_min(1e-6)     # noqa: E731
     normal_smpl = nrm(r["sdf_grad"])
@@ -261,8 +291,12 @@ def shade_reference_phys(P, fixed, target_rgb, target_mask, background, lambda_p
     albedo, rough, metal = h[:, :3] * 0.77 + 0.03, h[:, 3] * 0.9 + 0.09, h[:, 4]
     src, ray = fixed["fg_src"], fixed["fg_ray"]
     w_fg = r["weights"][src] / fixed["fg_counts"][src].double()
-    Lo, _, _ = pbr_uniform_light_t(normal_smpl[src], albedo[src], rough[src], metal[src], fixed["rays_d"][ray], fixed["out_dirs"],
-                                   fixed["sec_tr"], P["env_base"], fixed["env_R"], fixed["inv_pdf"])
+    if mode == "light":
+        Lo, _, _ = pbr_light_t(normal_smpl[src], albedo[src], rough[src], metal[src], fixed["rays_d"][ray], fixed["out_dirs"],
+                               fixed["sec_tr"], fixed.get("sec_rgb"), P["env_base"], fixed["env_R"], fixed["light_pdf"])
+    else:
+        Lo, _, _ = pbr_uniform_light_t(normal_smpl[src], albedo[src], rough[src], metal[src], fixed["rays_d"][ray], fixed["out_dirs"],
+                                       fixed["sec_tr"], P["env_base"], fixed["env_R"], fixed["inv_pdf"])
     n_rays = fixed["n_rays"]
     img = torch.zeros(n_rays, 3, dtype=Lo.dtype).index_add(0, ray, w_fg[:, None] * Lo)
     T = (1.0 - r["opacity"][:, 0]) * fixed["has_bg"].double()

@@ -4,6 +4,7 @@ Frame-parallel over GPUs (each rank its own pose -> own voxel_J and
 path, only the final gather of the timings):
 
     python tools/relight_bench.py                                   one GPU, one frame
+    python tools/relight_bench.py --gpus N --frames F               N ranks (re-executes itself under torch.distributed.run), or
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/relight_bench.py --gpus N --frames F
 
 Every rank renders frames rank, rank + N, ... of F animation poses (pose seed = frame index).  Prints JSON on rank 0
@@ -21,6 +22,8 @@ ap.add_argument("--spp", type=int, default=int(os.environ.get("IA_SPP", "256")))
 ap.add_argument("--gi", action="store_true", default=os.environ.get("IA_GI", "0") == "1")
 ap.add_argument("--ray-chunk", type=int, default=int(os.environ.get("IA_RAY_CHUNK", str(1 << 19))))
 args = ap.parse_args()
+import bench as _bench
+_bench.self_launch_ranks(args.gpus, script=os.path.abspath(__file__))        # plain `python tools/relight_bench.py --gpus N` starts its own ranks
 world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 share = os.environ.get("IA_BENCH_SHARE_GPU") == "1"          # test hook: all ranks on cuda:0 over gloo
