@@ -556,7 +556,7 @@ def sample_volume_interaction(rays_o, rays_d, ray_indices, t_starts, t_ends, n_r
     else:
         # no foreground re-sample: zero-size tensors under every key, as models/pbr/utils.py:208-219 returns them
         dev, z = rays_o.device, (lambda *s_: torch.zeros(s_, device=rays_o.device))     # noqa: E731
-        rw = z(0)
+        rw = z(0, 1)
         md = extras["metallic"].shape[-1] if extras["metallic"].dim() > 1 else 1
         ex = dict(sdf=z(0), alphas=z(0), dists=z(0, 1), positions=z(0, 3), normals=z(0, 3), albedo=z(0, 3), roughness=z(0, 1),
                   metallic=z(0, md), t_dirs=z(0, 3))
