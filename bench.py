@@ -61,7 +61,7 @@ def algorithmic_bytes(name, calls, extra=None):
     """SURVEY.md 8(d) per-unit algorithmic bytes x the COUNTED units of every launch of one entry point.
     calls = [(ms, units, extras)].  Returns total bytes over the calls (None: no model for this entry point)."""
     n = sum(u for _, u, _ in calls)
-    if name == "ia_fuse_broyden":
+    if name in ("ia_fuse_broyden", "ia_fuse_broyden_spec"):
         # SURVEY 8(d) row "Broyden (a7/K8)": per (point, init) 12 B target + 64 B bone row in, (1 + iters) x 8 corners x 48 B
         # gathered (SURVEY gives the <= 11-fetch upper bound; here the fetches are COUNTED by ia_broyden_stats: `extra`
         # = in-range corner loads of the step), 13 B out (x + valid; +36 B each for J_inv / fwd_J when requested).
@@ -84,6 +84,7 @@ def algorithmic_bytes(name, calls, extra=None):
 # per call (per-launch traffic = launch-weighted mean); "seq": all of them run per call (sum of their per-call traffic)
 PMC_KERNELS = {
     "ia_fuse_broyden": ("alt", ["broyden_persistent2_kernel", "broyden_persistent_kernel", "broyden_kernel"]),
+    "ia_fuse_broyden_spec": ("alt", ["broyden_spec_kernel"]),
     "ia_hashgrid_fwd": ("alt", ["hash_fwd_kernel"]),
     "ia_hashgrid_fwd_xcd": ("seq", ["hash_fwd_xcd_kernel", "hash_transpose_kernel"]),
     "ia_hashgrid_bwd_binned": ("seq", ["hash_bin", "hash_reduce_kernel"]),
@@ -363,7 +364,9 @@ def main():
         breakdown = {}
         if per_call:
             dname, (dcalls, dms) = max(per_call.items(), key=lambda kv: kv[1][1])
-            bro = count_broyden_fetches(step, dev) if (dname == "ia_fuse_broyden" and world == 1) else None   # one extra untimed step (a step has collectives: single rank only)
+            bro = None
+            if dname in ("ia_fuse_broyden", "ia_fuse_broyden_spec") and world == 1:      # one extra untimed step (a step has collectives: single rank only)
+                bro = count_broyden_fetches(step, dev, rs.deformer)[dname]
             ab = algorithmic_bytes(dname, detail[dname], extra=(bro[1] * k_instr if bro else None))
             stats["deform_points"] = sum(u for _, u, _ in detail.get("ia_fuse_broyden", [])) // k_instr      # counted, not estimated
             stats["hash_points"] = sum(u for k in ("ia_hashgrid_fwd", "ia_hashgrid_fwd_xcd") for _, u, _ in detail.get(k, [])) // k_instr
@@ -386,7 +389,7 @@ def main():
                 # (targets in, x / valid out, the grid once per launch).
                 c = bro
                 sec = dms / k_instr * 1e-3
-                items = max(c[2] + c[3] + c[4], 1)
+                items = max(c[2] + c[3] + c[4] + c[5] + c[6], 1)
                 comp = sum(u * (12 + ex["I"] * (13 + (36 if ex["J_inv"] else 0) + (36 if ex["fwd_J"] else 0))) + VOXEL_J_BYTES
                            for _, u, ex in detail[dname]) / k_instr
                 l1_bytes = c[1] * 48.0
@@ -402,7 +405,11 @@ def main():
                                       "through the L1 path / live HIP-event time of the entry point",
                     fetches_per_step=int(c[0]), corner_loads_per_step=int(c[1]), bytes_per_corner=48,
                     fetches_per_item=round(c[0] / items, 3), Gfetch_per_s=round(c[0] / sec / 1e9, 2),
-                    items=dict(converged=int(c[2]), diverged=int(c[3]), exhausted=int(c[4])),
+                    items=(dict(converged=int(c[2]), diverged=int(c[3]), exhausted=int(c[4])) if dname == "ia_fuse_broyden" else
+                           dict(retired_by_the_early_filter=int(c[5]), completed_valid=int(c[6]), other=int(c[4]))),
+                    speculative_early_filter=(None if dname == "ia_fuse_broyden" else dict(
+                        eps=rs.deformer.spec_eps, exact_search_fetches_per_step=int(c[7]),
+                        fetches_removed=round(1.0 - c[0] / max(c[7], 1), 4))),
                     hbm_side=hbm_side,
                     survey_8d_gather_bytes_GBps=round(achieved, 1),
                     compulsory_hbm_GBps=round(comp / sec / 1e9, 1), compulsory_hbm_frac=round(comp / sec / 1e9 / HBM_PEAK_GBPS, 4),
@@ -488,15 +495,19 @@ def self_launch_ranks(n_gpus, script=None):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def count_broyden_fetches(step, dev):
-    """one extra (untimed) step in which every ia_fuse_broyden call is followed by ia_broyden_stats on the same inputs:
-    -> accumulated counters [17] (fetches, in-range corner loads, outcomes, exit histogram) of that step."""
+def count_broyden_fetches(step, dev, dfm):
+    """one extra (untimed) step that counts what the searches cost.  Exact searches (ia_fuse_broyden): every call is followed
+    by ia_broyden_stats on the same inputs.  Speculative searches (ia_fuse_broyden_spec): the kernel's own counters, plus
+    ia_broyden_stats on the same inputs for what the exact search WOULD have fetched.
+    -> {entry point: [fetches, in-range corner loads, converged, diverged, exhausted | other, retired, completed valid, exact fetches]}"""
     from intrinsicavatar_amd import fast_snarf, _lib as L
-    cnt = torch.zeros(17, dtype=torch.int64, device=dev)
-    orig = fast_snarf.fuse_broyden
+    cnt = torch.zeros(17, dtype=torch.int64, device=dev)        # exact entry point
+    cnt_x = torch.zeros(17, dtype=torch.int64, device=dev)      # what the exact search would cost on the speculative calls' inputs
+    spec = torch.zeros(5, dtype=torch.int64, device=dev)
+    n_spec_items = [0]
+    orig, orig_spec = fast_snarf.fuse_broyden, fast_snarf.fuse_broyden_spec
 
-    def wrapped(x, xd_tgt, voxel, voxel_J, tfs, bone_ids, align_corners, J_inv, is_valid, offset, scale, cvg, dvg, fwd_J=None):
-        orig(x, xd_tgt, voxel, voxel_J, tfs, bone_ids, align_corners, J_inv, is_valid, offset, scale, cvg, dvg, fwd_J=fwd_J)
+    def stats(xd_tgt, voxel_J, tfs, bone_ids, offset, scale, cvg, dvg, out):
         cl = isinstance(voxel_J, fast_snarf.ChannelLastVoxelJ)
         vj = voxel_J.data if cl else voxel_J.contiguous()
         D, H, W = (vj.shape[1:4] if cl else vj.shape[2:5])
@@ -504,15 +515,27 @@ def count_broyden_fetches(step, dev):
         L.check(L.lib().ia_broyden_stats(L.i32(B), L.i64(N), L.i32(bone_ids.shape[0]), L.ptr(xd_tgt.contiguous().float()), L.ptr(vj),
                                          L.i32(1 if cl else 0), L.i32(D), L.i32(H), L.i32(W), L.ptr(tfs.contiguous().float()),
                                          L.ptr(bone_ids.contiguous().to(torch.int32)), L.ptr(offset.reshape(3).contiguous().float()),
-                                         L.ptr(scale.reshape(3).contiguous().float()), L.f32(cvg), L.f32(dvg), L.ptr(cnt), L.stream()),
+                                         L.ptr(scale.reshape(3).contiguous().float()), L.f32(cvg), L.f32(dvg), L.ptr(out), L.stream()),
                 "ia_broyden_stats")
-    fast_snarf.fuse_broyden = wrapped
+
+    def wrapped(x, xd_tgt, voxel, voxel_J, tfs, bone_ids, align_corners, J_inv, is_valid, offset, scale, cvg, dvg, fwd_J=None):
+        orig(x, xd_tgt, voxel, voxel_J, tfs, bone_ids, align_corners, J_inv, is_valid, offset, scale, cvg, dvg, fwd_J=fwd_J)
+        stats(xd_tgt, voxel_J, tfs, bone_ids, offset, scale, cvg, dvg, cnt)
+
+    def wrapped_spec(x, xd_tgt, voxel_J, tfs, bone_ids, J_inv, is_valid, offset, scale, cvg, dvg, eps, fwd_J=None, counters=None):
+        orig_spec(x, xd_tgt, voxel_J, tfs, bone_ids, J_inv, is_valid, offset, scale, cvg, dvg, eps, fwd_J=fwd_J, counters=spec)
+        stats(xd_tgt, voxel_J, tfs, bone_ids, offset, scale, cvg, dvg, cnt_x)
+        n_spec_items[0] += xd_tgt.shape[1] * bone_ids.shape[0]
+    fast_snarf.fuse_broyden, fast_snarf.fuse_broyden_spec = wrapped, wrapped_spec
     try:
         step()
         torch.cuda.synchronize()
     finally:
-        fast_snarf.fuse_broyden = orig
-    return cnt.cpu().tolist()
+        fast_snarf.fuse_broyden, fast_snarf.fuse_broyden_spec = orig, orig_spec
+    c, cx, sp = cnt.cpu().tolist(), cnt_x.cpu().tolist(), spec.cpu().tolist()
+    other = max(n_spec_items[0] - sp[1] - sp[2], 0)            # searches that ended by themselves without a valid root
+    return {"ia_fuse_broyden": c[:5] + [0, 0, c[0]],
+            "ia_fuse_broyden_spec": [sp[0], sp[4], 0, 0, other, sp[1], sp[2], cx[0]]}
 
 
 def usable_cores():

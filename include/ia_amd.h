@@ -177,6 +177,19 @@ int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt /*[B,N,3]*/, co
                     float* fwd_J /*[B,N,I,3,3] or NULL: forward LBS Jacobian at each root (= fwd_tfs, deformer_torch.py:49-52)*/,
                     ia_stream_t stream);
 int ia_filter(int64_t N, int I, const float* x /*[1,N,I,3]*/, const uint8_t* mask, uint8_t* out, ia_stream_t stream);
+/* ia_fuse_broyden with a SPECULATIVE EARLY FILTER (product path of the big no-grad query batches; B = 1, channel-last grid;
+ * no reference counterpart -- the reference runs every search to its end and lets filter.cu:10-54 drop the duplicates).
+ * One lane owns one point and searches its inits in REVERSE order; a search whose next position comes within `eps`
+ * (inf-norm, canonical metres) of a root that a LATER init of the same point converged to is retired (is_valid = 0): it
+ * would end on that root, where K9 keeps the later init.  Items that are not retired are computed with the operation
+ * sequence of ia_fuse_broyden (bit-identical x / J_inv / fwd_J / is_valid); eps = 0 retires nothing.  Mis-prediction rates
+ * on the headline distribution: DESIGN.md 4.5, tests/test_gpu_spec_search.py.
+ * counters: NULL or uint64[5], caller-zeroed, accumulated: fetches issued, retired items, completed valid items, roots
+ * that found the per-point root list (3) full, in-range corner loads of the fetches. */
+int ia_fuse_broyden_spec(int64_t N, int I, const float* xd_tgt /*[N,3]*/, const float* voxel_J_cl /*[D,H,W,12]*/, int D, int H, int W,
+                         const float* tfs /*[24,4,4]*/, const int32_t* bone_ids, const float* offset, const float* scale,
+                         float cvg_threshold, float dvg_threshold, float eps, float* x /*[N,I,3]*/, float* J_inv /*[N,I,3,3] or NULL*/,
+                         uint8_t* is_valid /*[N,I]*/, float* fwd_J /*[N,I,3,3] or NULL*/, uint64_t* counters, ia_stream_t stream);
 /* diagnostics (no reference counterpart): runs the searches of ia_fuse_broyden without outputs and ACCUMULATES into
  * counters[17] (caller-zeroed): [0] trilinear fetches, [1] in-range corner loads, [2] converged & in-box items,
  * [3] diverged, [4] out of iterations, [5+k] items that ended after k fetches (k = 2..11).  Used by bench.py to price the

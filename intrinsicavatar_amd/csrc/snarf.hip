@@ -498,6 +498,195 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
     }
 }
 
+// ---- K8 + speculative early filter (product path; B == 1, channel-last grid) ------------------------------------------------
+// 13 searches per point yield ~1.3 surviving roots: ~58 % of the searches converge, most of them onto a root that a LATER
+// init also finds -- and K9 (filter.cu:10-54) keeps only the LAST member of such a cluster.  Here one lane owns one POINT and
+// walks its inits in REVERSE order (I-1 .. 0), so when init i runs every later init has already finished and the roots they
+// converged to are known exactly.  After every Broyden step (x_k known, k >= 1, BEFORE the fetch at x_k) the lane tests
+// |x_k - r|_inf < eps against the recorded roots r of its point: a search that has come within eps of a root found by a
+// later init is going to end on that root (or fail) -- either way K9 would drop it -- so it is retired (is_valid = 0) and
+// its remaining fetches are never issued.  Everything that is NOT retired runs the operation sequence of broyden_kernel:
+// surviving candidates are bit-identical to the exact search.  What speculation can change (measured): a point
+// loses a candidate only if two DISTINCT roots lie within eps of each other (or a search within eps of a root would have
+// moved on to another one), and duplicates that the exact search leaves 1e-4 .. eps apart (K9 keeps both) collapse to the
+// later one.  eps = 0 never retires (the test is strict).  Scheduling as broyden_persistent2_kernel: every loop iteration
+// is exactly one trilinear fetch per busy lane; a lane that finishes a search starts its point's next init at once, a lane
+// that finishes a point pulls the wave's next point (ballot + popcount, wave-private cursor).
+__device__ __forceinline__ unsigned in_range_corner_count(float gx, float gy, float gz, int D, int H, int W)
+{
+    float ix = ((gx + 1.f) / 2) * (W - 1), iy = ((gy + 1.f) / 2) * (H - 1), iz = ((gz + 1.f) / 2) * (D - 1);
+    if (ix > 2147483646.0f || ix < -2147483648.0f || !isfinite(ix)) ix = -100.0f;
+    if (iy > 2147483646.0f || iy < -2147483648.0f || !isfinite(iy)) iy = -100.0f;
+    if (iz > 2147483646.0f || iz < -2147483648.0f || !isfinite(iz)) iz = -100.0f;
+    const int x0 = (int)floorf(ix), y0 = (int)floorf(iy), z0 = (int)floorf(iz);
+    const unsigned cx = (unsigned)(x0 >= 0 && x0 < W) + (unsigned)(x0 + 1 >= 0 && x0 + 1 < W);
+    const unsigned cy = (unsigned)(y0 >= 0 && y0 < H) + (unsigned)(y0 + 1 >= 0 && y0 + 1 < H);
+    const unsigned cz = (unsigned)(z0 >= 0 && z0 < D) + (unsigned)(z0 + 1 >= 0 && z0 + 1 < D);
+    return cx * cy * cz;
+}
+
+constexpr int SPEC_ROOTS = 3;      // recorded roots per point (survivors per point average 1.3; a 4th root is simply not recorded)
+
+template <bool COUNT>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES, IA_BR2_WAVES))) void broyden_spec_kernel(
+    int64_t N, int I, const float* __restrict__ xd_tgt, const float* __restrict__ voxel_J, int D, int H, int W,
+    const float* __restrict__ tfs, const int32_t* __restrict__ bone_ids, const float* __restrict__ offset_g,
+    const float* __restrict__ scale_g, float cvg_threshold, float dvg_threshold, float eps, float* __restrict__ x,
+    float* __restrict__ J_inv, uint8_t* __restrict__ is_valid, float* __restrict__ fwd_J, int pts_per_wave,
+    unsigned long long* __restrict__ counters /* NULL or [5]: fetches, retired items, completed valid items, unrecorded roots, in-range corner loads */)
+{
+    __shared__ float s_T[16 * 12];                     // per init: rows 0..2 of its bone's 4x4 (R | t)
+    for (int t = threadIdx.x; t < I * 12; t += THREADS) s_T[t] = tfs[(int64_t)bone_ids[t / 12] * 16 + (t % 12)];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = ((int64_t)blockIdx.x * THREADS + threadIdx.x) >> 6;
+    const int64_t p_begin = wave_id * pts_per_wave;
+    if (p_begin >= N) return;
+    const int n_pts = (int)((p_begin + pts_per_wave < N) ? pts_per_wave : N - p_begin);
+    int cur = 0;                                       // points of the chunk handed out so far (wave-uniform)
+    const float offset[3] = {offset_g[0], offset_g[1], offset_g[2]};
+    const float scale[3] = {scale_g[0], scale_g[1], scale_g[2]};
+    const float cvg2 = cvg_threshold * cvg_threshold, dvg2 = dvg_threshold * dvg_threshold;
+
+    bool have = false;            // lane owns a point
+    bool next = false;            // current search ended: move to the point's next init (or give the point up)
+    int pt = 0;                   // the lane's point, relative to the wave's chunk
+    int init = 0;
+    int it = -1;                  // -1: waiting for the initial fetch
+    int n_roots = 0;
+    float xt[3] = {0, 0, 0}, x_l[3] = {0, 0, 0}, gx[3] = {0, 0, 0}, u[3] = {0, 0, 0};
+    float Ji[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float root[SPEC_ROOTS][3];
+#pragma unroll
+    for (int r = 0; r < SPEC_ROOTS; r++) root[r][0] = root[r][1] = root[r][2] = 0.f;
+    unsigned c_fetch = 0, c_retired = 0, c_valid = 0, c_unrec = 0, c_corner = 0;
+
+    for (;;) {
+        // ---- transitions: next init of the lane's point, or the wave's next point ----
+        if (have && next) {
+            next = false;
+            if (init > 0) { init--; it = -1; } else have = false;
+        }
+        const unsigned long long need = __ballot(!have);
+        if (need) {
+            if (!have) {
+                const int rank = __popcll(need & ((1ull << lane) - 1ull));
+                const int c = cur + rank;
+                if (c < n_pts) {
+                    have = true;
+                    pt = c;
+                    init = I - 1;
+                    it = -1;
+                    n_roots = 0;
+                    xt[0] = xd_tgt[(p_begin + c) * 3 + 0];
+                    xt[1] = xd_tgt[(p_begin + c) * 3 + 1];
+                    xt[2] = xd_tgt[(p_begin + c) * 3 + 2];
+                }
+            }
+            cur += __popcll(need);
+            if (cur > n_pts) cur = n_pts;
+        }
+        if (!__any(have)) break;
+        if (!have) continue;
+        if (it < 0) {                                                    // a new search: x0 = R^T (xd - t) of its bone
+            const float* T = s_T + init * 12;                            // T[r*4 + c], r < 3
+            const float ixd = xt[0] - T[0 * 4 + 3], iyd = xt[1] - T[1 * 4 + 3], izd = xt[2] - T[2 * 4 + 3];
+            x_l[0] = ixd * T[0 * 4 + 0] + iyd * T[1 * 4 + 0] + izd * T[2 * 4 + 0];
+            x_l[1] = ixd * T[0 * 4 + 1] + iyd * T[1 * 4 + 1] + izd * T[2 * 4 + 1];
+            x_l[2] = ixd * T[0 * 4 + 2] + iyd * T[1 * 4 + 2] + izd * T[2 * 4 + 2];
+        }
+        const int64_t index = (p_begin + pt) * I + init;
+        // ---- one fetch at the current x_l ----
+        const float ix = scale[0] * (x_l[0] + offset[0]);
+        const float iy = scale[1] * (x_l[1] + offset[1]);
+        const float iz = scale[2] * (x_l[2] + offset[2]);
+        float Jl[12];
+        grid_sample_J<IA_LAYOUT_NDHWC>(voxel_J, 0, D, H, W, ix, iy, iz, Jl);
+        if (COUNT) { c_fetch++; c_corner += in_range_corner_count(ix, iy, iz, D, H, W); }
+        if (it < 0) {
+            // initial fetch: J_inv guess and g(x0)   (fuse_cuda_kernel_fast.cu:295-331)
+            Ji[0] = Jl[0]; Ji[3] = Jl[1]; Ji[6] = Jl[2];
+            Ji[1] = Jl[4]; Ji[4] = Jl[5]; Ji[7] = Jl[6];
+            Ji[2] = Jl[8]; Ji[5] = Jl[9]; Ji[8] = Jl[10];
+            gx[0] = Jl[0] * x_l[0] + Jl[1] * x_l[1] + Jl[2] * x_l[2] + Jl[3];
+            gx[1] = Jl[4] * x_l[0] + Jl[5] * x_l[1] + Jl[6] * x_l[2] + Jl[7];
+            gx[2] = Jl[8] * x_l[0] + Jl[9] * x_l[1] + Jl[10] * x_l[2] + Jl[11];
+            gx[0] = gx[0] - xt[0]; gx[1] = gx[1] - xt[1]; gx[2] = gx[2] - xt[2];
+            it = 0;
+        } else {
+            // fetch of iteration `it` (x_l already updated): residual, tests, Broyden update (:352-411)
+            float gn[3];
+            gn[0] = Jl[0] * x_l[0] + Jl[1] * x_l[1] + Jl[2] * x_l[2] + Jl[3] - xt[0];
+            gn[1] = Jl[4] * x_l[0] + Jl[5] * x_l[1] + Jl[6] * x_l[2] + Jl[7] - xt[1];
+            gn[2] = Jl[8] * x_l[0] + Jl[9] * x_l[1] + Jl[10] * x_l[2] + Jl[11] - xt[2];
+            const float norm_gx = gn[0] * gn[0] + gn[1] * gn[1] + gn[2] * gn[2];
+            if (norm_gx < cvg2) {
+                const bool ok = ix >= -1 && ix <= 1 && iy >= -1 && iy <= 1 && iz >= -1 && iz <= 1;
+                is_valid[index] = ok ? 1 : 0;
+                if (ok) {
+                    x[index * 3 + 0] = x_l[0]; x[index * 3 + 1] = x_l[1]; x[index * 3 + 2] = x_l[2];
+                    if (J_inv) {
+                        float* Jo = J_inv + index * 9;
+#pragma unroll
+                        for (int k = 0; k < 9; k++) Jo[k] = Ji[k];
+                    }
+                    if (fwd_J) {
+                        float* Fo = fwd_J + index * 9;
+                        Fo[0] = Jl[0]; Fo[1] = Jl[1]; Fo[2] = Jl[2]; Fo[3] = Jl[4]; Fo[4] = Jl[5]; Fo[5] = Jl[6];
+                        Fo[6] = Jl[8]; Fo[7] = Jl[9]; Fo[8] = Jl[10];
+                    }
+                    // a root of this point: searches of EARLIER inits that come within eps of it are duplicates-to-be
+                    if (COUNT) c_valid++;
+                    if (n_roots < SPEC_ROOTS) {
+#pragma unroll
+                        for (int r = 0; r < SPEC_ROOTS; r++)
+                            if (r == n_roots) { root[r][0] = x_l[0]; root[r][1] = x_l[1]; root[r][2] = x_l[2]; }
+                        n_roots++;
+                    } else if (COUNT) c_unrec++;
+                }
+                next = true;
+                continue;
+            } else if (norm_gx > dvg2) {
+                is_valid[index] = 0;
+                next = true;
+                continue;
+            }
+            J_inv_update(Ji, u[0], u[1], u[2], gn[0] - gx[0], gn[1] - gx[1], gn[2] - gx[2]);
+            gx[0] = gn[0]; gx[1] = gn[1]; gx[2] = gn[2];
+            it++;
+            if (it >= 10) { is_valid[index] = 0; next = true; continue; }       // not converged
+        }
+        // step: update = -J_inv g, x += update
+        u[0] = -Ji[0] * gx[0] + -Ji[1] * gx[1] + -Ji[2] * gx[2];
+        u[1] = -Ji[3] * gx[0] + -Ji[4] * gx[1] + -Ji[5] * gx[2];
+        u[2] = -Ji[6] * gx[0] + -Ji[7] * gx[1] + -Ji[8] * gx[2];
+        x_l[0] += u[0]; x_l[1] += u[1]; x_l[2] += u[2];
+        // ---- speculative early filter: the next fetch position against the roots later inits converged to ----
+        bool near = false;
+#pragma unroll
+        for (int r = 0; r < SPEC_ROOTS; r++) {
+            const float d = fmaxf(fmaxf(fabsf(x_l[0] - root[r][0]), fabsf(x_l[1] - root[r][1])), fabsf(x_l[2] - root[r][2]));
+            near = near || (r < n_roots && d < eps);
+        }
+        if (near) { is_valid[index] = 0; if (COUNT) c_retired++; next = true; }
+    }
+    if (COUNT) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            c_fetch += __shfl_down(c_fetch, off, 64); c_retired += __shfl_down(c_retired, off, 64);
+            c_valid += __shfl_down(c_valid, off, 64); c_unrec += __shfl_down(c_unrec, off, 64);
+            c_corner += __shfl_down(c_corner, off, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[0], (unsigned long long)c_fetch);
+            atomicAdd(&counters[1], (unsigned long long)c_retired);
+            atomicAdd(&counters[2], (unsigned long long)c_valid);
+            atomicAdd(&counters[3], (unsigned long long)c_unrec);
+            atomicAdd(&counters[4], (unsigned long long)c_corner);
+        }
+    }
+}
+
 // ---- K8 diagnostics ---------------------------------------------------------------
 // Same search as broyden_kernel (identical arithmetic, no outputs): counts what the searches of a batch cost, for the
 // L1-path figures of bench.py / DESIGN.md.  counters[0] = trilinear fetches issued, [1] = corner loads actually performed
@@ -764,6 +953,30 @@ IA_EXPORT int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt, cons
                                                                      is_valid, fwd_J);
     }
     return ia::check_launch("ia_fuse_broyden");
+}
+
+IA_EXPORT int ia_fuse_broyden_spec(int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
+                                   const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold,
+                                   float dvg_threshold, float eps, float* x, float* J_inv, uint8_t* is_valid, float* fwd_J,
+                                   uint64_t* counters, ia_stream_t stream)
+{
+    if (N == 0) return IA_OK;
+    IA_REQUIRE(I >= 1 && I <= 16, "ia_fuse_broyden_spec: 1 <= I <= 16 inits");
+    IA_REQUIRE(eps >= 0.0f, "ia_fuse_broyden_spec: eps must be >= 0");
+    IA_REQUIRE((int64_t)D * H * W < ((int64_t)1 << 26), "voxel grid too large for 32-bit byte offsets (48 B per voxel)");
+    int pts = 80;                                                        // points per wave (as many items as the exact schedule's chunk)
+    if (const char* e = getenv("IA_BR_SPEC_PTS")) pts = atoi(e) > 0 ? atoi(e) : pts;
+    const int64_t n_waves = (N + pts - 1) / pts;
+    const int grid = ia::cdiv(n_waves * 64, THREADS);
+    if (counters)
+        broyden_spec_kernel<true><<<grid, THREADS, 0, (hipStream_t)stream>>>(
+            N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J,
+            pts, reinterpret_cast<unsigned long long*>(counters));
+    else
+        broyden_spec_kernel<false><<<grid, THREADS, 0, (hipStream_t)stream>>>(
+            N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J,
+            pts, nullptr);
+    return ia::check_launch("ia_fuse_broyden_spec");
 }
 
 IA_EXPORT int ia_filter(int64_t N, int I, const float* x, const uint8_t* mask, uint8_t* out, ia_stream_t stream)

@@ -23,6 +23,12 @@ from . import fast_snarf
 
 class SNARFDeformer:
     INIT_BONES = [0, 1, 2, 4, 5, 10, 11, 12, 15, 16, 17, 18, 19]    # deformer_torch.py:27
+    # Speculative early filter of the search (fast_snarf.fuse_broyden_spec): batches of at least SPEC_MIN_POINTS
+    # points retire a search once it comes within SPEC_EPS metres of a root that a later init of the same point has found
+    # (K9 would drop it).  IA_BROYDEN_SPEC_EPS=0 (or spec_eps = 0) = the exact search everywhere.  Small batches -- every
+    # parity test against the oracle -- always run the exact search.
+    SPEC_EPS = float(os.environ.get("IA_BROYDEN_SPEC_EPS", "1e-3"))
+    SPEC_MIN_POINTS = int(os.environ.get("IA_BROYDEN_SPEC_MIN_POINTS", str(1 << 20)))
 
     def __init__(self, lbs_voxel_final: Tensor, offset_kernel: Tensor, scale_kernel: Tensor, bbox: Tensor):
         self.lbs_voxel_final = lbs_voxel_final.contiguous().float()          # [1,24,D,H,W]
@@ -31,6 +37,8 @@ class SNARFDeformer:
         self.bbox = bbox                                                     # [2,3] canonical bbox (deformer_torch.py:157)
         self.device = self.lbs_voxel_final.device
         self.init_bones = torch.tensor(self.INIT_BONES, dtype=torch.int32, device=self.device)
+        self.spec_eps = self.SPEC_EPS
+        self.spec_counters = None            # optional int64 [5] device tensor: accumulated by the speculative search (bench.py)
         self.tfs = None
         self.voxel_J_cl = None
         self.voxel_d = None
@@ -73,9 +81,14 @@ class SNARFDeformer:
         Jinv = torch.empty((1, P, I, 3, 3), device=self.device) if want_jinv else None
         valid = torch.empty((1, P, I), dtype=torch.bool, device=self.device)
         fwd = torch.empty((1, P, I, 3, 3), device=self.device) if want_fwd else None
-        fast_snarf.fuse_broyden(x, pts.reshape(1, P, 3), None, fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs,
-                                self.init_bones, True, Jinv, valid, self.offset_kernel, self.scale_kernel, 1e-5, 1e-1,
-                                fwd_J=fwd)
+        if self.spec_eps > 0.0 and P >= self.SPEC_MIN_POINTS and self.tfs.shape[0] == 1:
+            fast_snarf.fuse_broyden_spec(x, pts.reshape(1, P, 3), fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs,
+                                         self.init_bones, Jinv, valid, self.offset_kernel, self.scale_kernel, 1e-5, 1e-1,
+                                         self.spec_eps, fwd_J=fwd, counters=self.spec_counters)
+        else:
+            fast_snarf.fuse_broyden(x, pts.reshape(1, P, 3), None, fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs,
+                                    self.init_bones, True, Jinv, valid, self.offset_kernel, self.scale_kernel, 1e-5, 1e-1,
+                                    fwd_J=fwd)
         if want_jinv:
             return x[0], valid[0], (fwd[0] if want_fwd else None), Jinv[0]
         return x[0], valid[0], (fwd[0] if want_fwd else None)

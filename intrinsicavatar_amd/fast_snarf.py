@@ -69,6 +69,29 @@ def fuse_broyden(x: Tensor, xd_tgt: Tensor, voxel: Tensor, voxel_J, tfs: Tensor,
                                     L.ptr(is_valid), L.ptr(fwd_J), L.stream()), "ia_fuse_broyden")
 
 
+def fuse_broyden_spec(x: Tensor, xd_tgt: Tensor, voxel_J: ChannelLastVoxelJ, tfs: Tensor, bone_ids: Tensor, J_inv: Tensor,
+                      is_valid: Tensor, offset: Tensor, scale: Tensor, cvg_threshold: float, dvg_threshold: float, eps: float,
+                      fwd_J: Tensor = None, counters: Tensor = None) -> None:
+    """fuse_broyden with the speculative early filter (ia_fuse_broyden_spec; B = 1, channel-last grid): a search that comes within
+    `eps` of a root found by a LATER init of its point is retired -- K9 (filter.cu:10-54) would drop it.  Everything that is not
+    retired is bit-identical to fuse_broyden.  No counterpart in the reference; used by SNARFDeformer.search for large batches.
+    counters: optional int64 [5] (accumulated): fetches, retired items, completed valid items, unrecorded roots, corner loads."""
+    B, N, _ = xd_tgt.shape
+    I = bone_ids.shape[0]
+    assert B == 1 and isinstance(voxel_J, ChannelLastVoxelJ) and voxel_J.data.shape[0] == 1
+    _, D, H, W, _ = voxel_J.data.shape
+    if x.shape != (B, N, I, 3) or (J_inv is not None and J_inv.shape != (B, N, I, 3, 3)) or is_valid.shape != (B, N, I):
+        raise RuntimeError("output shapes must be x[B,N,I,3], J_inv[B,N,I,3,3], is_valid[B,N,I]")
+    for t in (x, J_inv, is_valid, fwd_J):
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("outputs must be contiguous")
+    L.check(L.lib().ia_fuse_broyden_spec(
+        L.i64(N), L.i32(I), L.ptr(xd_tgt.contiguous().float()), L.ptr(voxel_J.data), L.i32(D), L.i32(H), L.i32(W),
+        L.ptr(tfs.contiguous().float()), L.ptr(bone_ids.contiguous().to(torch.int32)), L.ptr(offset.reshape(3).contiguous().float()),
+        L.ptr(scale.reshape(3).contiguous().float()), L.f32(cvg_threshold), L.f32(dvg_threshold), L.f32(eps), L.ptr(x), L.ptr(J_inv),
+        L.ptr(is_valid), L.ptr(fwd_J), L.ptr(counters), L.stream()), "ia_fuse_broyden_spec")
+
+
 def filter(x: Tensor, mask: Tensor) -> Tensor:
     """filter_cuda.filter (deformer_torch.py:122, filter.cpp:12-18): drop candidate i if a later valid
     candidate j lies within 1e-4 (keeps the last of a cluster). B must be 1 (filter.cu:21-22)."""
