@@ -502,7 +502,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
 // 13 searches per point yield ~1.3 surviving roots: ~58 % of the searches converge, most of them onto a root that a LATER
 // init also finds -- and K9 (filter.cu:10-54) keeps only the LAST member of such a cluster.  Here one lane owns one POINT and
 // walks its inits in REVERSE order (I-1 .. 0), so when init i runs every later init has already finished and the roots they
-// converged to are known exactly.  After every Broyden step (x_k known, k >= 1, BEFORE the fetch at x_k) the lane tests
+// converged to are known exactly.  Before every fetch (at x_k, k >= 0: the start x_0 included) the lane tests
 // |x_k - r|_inf < eps against the recorded roots r of its point: a search that has come within eps of a root found by a
 // later init is going to end on that root (or fail) -- either way K9 would drop it -- so it is retired (is_valid = 0) and
 // its remaining fetches are never issued.  Everything that is NOT retired runs the operation sequence of broyden_kernel:
@@ -596,6 +596,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
             x_l[2] = ixd * T[0 * 4 + 2] + iyd * T[1 * 4 + 2] + izd * T[2 * 4 + 2];
         }
         const int64_t index = (p_begin + pt) * I + init;
+        if (it < 0) {
+            // the rigid inverse of a bone that owns the point IS the root (up to rounding): a search that STARTS within eps of a
+            // root a later init has found is retired before its first fetch
+            bool at_root = false;
+#pragma unroll
+            for (int r = 0; r < SPEC_ROOTS; r++) {
+                const float d = fmaxf(fmaxf(fabsf(x_l[0] - root[r][0]), fabsf(x_l[1] - root[r][1])), fabsf(x_l[2] - root[r][2]));
+                at_root = at_root || (r < n_roots && d < eps);
+            }
+            if (at_root) { is_valid[index] = 0; if (COUNT) c_retired++; next = true; }
+        }
+        // a lane retired here sits this fetch out (it starts its next search in the next iteration)
+        if (next) continue;
         // ---- one fetch at the current x_l ----
         const float ix = scale[0] * (x_l[0] + offset[0]);
         const float iy = scale[1] * (x_l[1] + offset[1]);

@@ -249,3 +249,16 @@ def export_phys(material, env_base):
         Ws.append(N(w * torch.clamp(c / w.abs().sum(dim=1), max=1.0)[:, None]))
         bs.append(N(material.network.biases_per_layer[i]))
     return dict(mat_W=Ws, mat_b=bs, env_base=N(env_base))
+
+
+def hash_table_values(n, seed, amp):
+    """n pseudo-random fp32 values in [-amp, amp) as a closed-form function of the entry index (64-bit integer mixing, 24
+    mantissa bits): the 50 MB hash tables of a golden scene are regenerated bit-identically anywhere instead of being stored."""
+    i = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        v = i * np.uint64(6364136223846793005) + np.uint64(seed) * np.uint64(1442695040888963407) + np.uint64(0x9E3779B97F4A7C15)
+        v ^= v >> np.uint64(29)
+        v *= np.uint64(0xBF58476D1CE4E5B9)
+        v ^= v >> np.uint64(32)
+    u = (v >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+    return ((u * 2.0 - 1.0) * amp).astype(np.float32)

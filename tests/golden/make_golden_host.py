@@ -153,12 +153,16 @@ def import_reference_host_code():
     class _AsCuda(torch.Tensor):          # pack.py only runs its (pure torch) body `if tensor.is_cuda`
         is_cuda = property(lambda self: True)
 
-    def _cpu_ok(fn):
-        def call(t, *a, **k):
-            out = fn(t.as_subclass(_AsCuda), *a, **k)
+    def _cpu_ok(fn, first):
+        def call(*a, **k):
+            if a:
+                a = (a[0].as_subclass(_AsCuda),) + a[1:]
+            else:
+                k[first] = k[first].as_subclass(_AsCuda)
+            out = fn(*a, **k)
             return out.as_subclass(torch.Tensor) if isinstance(out, torch.Tensor) else out
         return call
-    ln.pack_info, ln.unpack_info = _cpu_ok(pack.pack_info), _cpu_ok(pack.unpack_info)
+    ln.pack_info, ln.unpack_info = _cpu_ok(pack.pack_info, "ray_indices"), _cpu_ok(pack.unpack_info, "packed_info")
     ln.pack_data, ln.unpack_data = pack.pack_data, pack.unpack_data
     pkg("models", f"{REF}/models")
     pkg("models.pbr", f"{REF}/models/pbr")
