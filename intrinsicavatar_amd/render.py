@@ -357,6 +357,9 @@ class RenderStep:
         extras = dict(weights=weights, sdf=d["sdf"], alphas=alphas, normals=normal_smpl, albedo=mats[:, :3],
                       roughness=mats[:, 3:4], metallic=mats[:, 4:5])
         rgb_phys = background_color[None].expand(n_rays, 3).clone()
+        demod_phys = rgb_phys.clone()
+        if render_mode == "uniform_light":
+            out["visibility"] = torch.zeros((n_rays, 1), device=dev)                      # :1266-1267
         stats.update(n_resampled=0, n_fg=0, n_secondary=0)
         if ray_indices.numel() > 0:
             # -- volume-interaction re-sampling (sample_volume_interaction, models/pbr/utils.py:70-229): K1 + layout scans
@@ -386,7 +389,7 @@ class RenderStep:
                     sec_tr, sec_rgb = pbr.scatter_secondary(F_, src, t_, c_)
                     res = pbr.pbr_shade(render_mode, nrm, alb, rough, metal, view, out_dirs, sec_tr, ind(sec_rgb), emitter, w2s_rot,
                                         inv_pdf=inv_pdf)
-                    fg_Lo = res[0]
+                    fg_Lo, fg_demod = res[0], res[1] + res[2]
                     out["shuffled"] = shuffled
                     if render_mode == "uniform_light":
                         zero3 = torch.zeros(3, device=dev)
@@ -403,18 +406,99 @@ class RenderStep:
                         out_dirs, rep = sc_dirs, (lambda t: t)
                     stats["n_secondary"] = int(out_dirs.shape[0])
                     sec_tr, sec_rgb = self.compute_indirect_radiance(rep(pos).contiguous(), out_dirs.contiguous())
-                    Lo2, _, _ = pbr.pbr_shade(render_mode, rep(nrm), rep(alb), rep(rough), rep(metal), rep(view), out_dirs, sec_tr,
-                                              ind(sec_rgb), emitter, w2s_rot)
+                    Lo2, Ld2, Ls2 = pbr.pbr_shade(render_mode, rep(nrm), rep(alb), rep(rough), rep(metal), rep(view), out_dirs, sec_tr,
+                                                  ind(sec_rgb), emitter, w2s_rot)
                     fg_Lo = Lo2.reshape(2, F_, 3).sum(0) if render_mode == "mis" else Lo2
+                    fg_demod = (Ld2 + Ls2).reshape(2, F_, 3).sum(0) if render_mode == "mis" else Ld2 + Ls2
                 else:
                     raise NotImplementedError(f"Render mode {render_mode} not supported.")
                 # Lo.scatter_(bg_indices, background) + accumulate_along_rays(resampled_weights, Lo) (:1335-1342,:1420-1466)
                 rgb_phys = vi.composite(w_fg, fg_Lo, transmittance, background_color)
+                demod_phys = vi.composite(w_fg, fg_demod.contiguous(), transmittance, background_color)     # Lo_demod = Lo_diff + Lo_spec (:1421-1436)
                 out["secondary_tr"], out["fg_Lo"] = sec_tr, fg_Lo
                 out["fg_extras"] = dict(positions=pos, normals=nrm, albedo=alb, roughness=rough, metallic=metal, t_dirs=view)
             out["resampled_packed_info"] = vi.resampled_packed_info
             if return_index_lists:
                 fg_idx, bg_idx, rri, rw = vi.index_lists(weights, transmittance)
                 out.update(resampled_ray_indices=rri, resampled_weights=rw, fg_indices=fg_idx, bg_indices=bg_idx)
-        out.update(comp_rgb_phys=rgb_phys, stats=stats)
+        out.update(comp_rgb_phys=rgb_phys, comp_demod_phys=demod_phys, stats=stats)
         return out
+
+    # ------------------------------------------------------------------ the reference's output dict
+    @staticmethod
+    def output_dict(o: Dict[str, Tensor], background_color: Tensor, render_mode: str, n_samples: int) -> Dict[str, Tensor]:
+        """the dict IntrinsicAvatarModel.forward_ returns with enable_phys (models/intrinsic_avatar.py:1492-1651): the linear
+        maps, the constant-background dict (`*_bg`) and the composited sRGB dict (`*_full`), same keys / shapes / dtypes."""
+        from . import pbr
+        acc = o["opacity"]
+        n, dev = acc.shape[0], acc.device
+        bgc = background_color.to(dev).float()
+        out = dict(comp_rgb=o["comp_rgb"], comp_normal=o["comp_normal"], opacity=acc, depth=o["depth"], rays_valid=acc > 0,
+                   rays_valid_phys=acc > 0, num_samples=torch.as_tensor([n_samples], dtype=torch.int32, device=dev),
+                   comp_rgb_phys=o["comp_rgb_phys"], comp_demod_phys=o["comp_demod_phys"], comp_albedo=o["albedo"],
+                   comp_metallic=o["metallic"], comp_roughness=o["roughness"])
+        if render_mode == "uniform_light":
+            out["visibility"] = o["visibility"]
+        for k in ("sdf_samples", "sdf_grad_samples", "sdf_laplace_samples", "weights", "points", "intervals", "ray_indices",
+                  "normals_orientation_loss_map", "albedo_smoothness_loss_map", "roughness_smoothness_loss_map", "metallic_smoothness_loss_map"):
+            if k in o:
+                out[k] = o[k]                                                              # training form (:1519-1597)
+        bgm = bgc.mean().reshape(1, 1).expand(n, 1)
+        out_bg = dict(comp_rgb=bgc[None].expand(n, 3), num_samples=torch.zeros_like(out["num_samples"]),
+                      rays_valid=torch.zeros_like(out["rays_valid"]), rays_valid_phys=torch.zeros_like(out["rays_valid_phys"]),
+                      comp_albedo=torch.zeros((n, 3), device=dev), comp_metallic=bgm, comp_roughness=bgm)
+        T = 1.0 - acc
+        out_full = dict(comp_rgb=pbr.rgb_to_srgb(out["comp_rgb"] + out_bg["comp_rgb"] * T).clamp(0, 1),
+                        num_samples=out["num_samples"] + out_bg["num_samples"], rays_valid=out["rays_valid"] | out_bg["rays_valid"],
+                        rays_valid_phys=out["rays_valid_phys"] | out_bg["rays_valid_phys"],
+                        comp_rgb_phys=pbr.rgb_to_srgb(out["comp_rgb_phys"]).clamp(0, 1),
+                        comp_demod_phys=pbr.rgb_to_srgb(out["comp_demod_phys"]).clamp(0, 1),
+                        comp_albedo=out["comp_albedo"] + out_bg["comp_albedo"] * T,
+                        comp_metallic=out["comp_metallic"] + out_bg["comp_metallic"] * T,
+                        comp_roughness=out["comp_roughness"] + out_bg["comp_roughness"] * T)
+        return {**out, **{k + "_bg": v for k, v in out_bg.items()}, **{k + "_full": v for k, v in out_full.items()}}
+
+    @torch.no_grad()
+    def forward_(self, rays: Tensor, material, emitter, spp: int, light_u: Tensor, shuffle_u: Optional[Tensor] = None,
+                 background_color: Optional[Tensor] = None, global_illumination: bool = False, render_mode: str = "light",
+                 scatter_u: Optional[Tensor] = None, jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        """IntrinsicAvatarModel.forward_ in eval mode with enable_phys (models/intrinsic_avatar.py:950-1651): relight() + the
+        reference's output dict.  Random tensors are explicit."""
+        if background_color is None:
+            background_color = torch.ones(3, device=rays.device)
+        o = self.relight(rays, material, emitter, spp, light_u, shuffle_u, background_color=background_color,
+                         global_illumination=global_illumination, jitter=jitter, render_mode=render_mode, scatter_u=scatter_u)
+        return self.output_dict(o, background_color, render_mode, o["stats"]["n_samples"])
+
+    def forward_train_(self, rays: Tensor, material, emitter, spp: int, light_u: Optional[Tensor], jitter: Optional[Tensor] = None,
+                       material_jitter: Optional[Tensor] = None, background_color: Optional[Tensor] = None,
+                       global_illumination: bool = False, render_mode: str = "light", shuffle_u: Optional[Tensor] = None,
+                       env_base: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        """forward_ in train() mode (differentiable; the caller takes losses of the returned maps): stratified near plane
+        (`jitter`), material jitter pass (`material_jitter` ~ N(0,1), :1116-1140), per-point light directions for render_mode
+        'light' (:772-781), and the training keys of the output dict (:1519-1597)."""
+        from . import train_phys
+        if background_color is None:
+            background_color = torch.ones(3, device=rays.device)
+        rays_o, rays_d, far, t_starts, t_ends, ray_indices, packed_info, stats = self.sample(rays, jitter)
+        res = train_phys.shade_differentiable_phys(
+            self, material, emitter, rays_o, rays_d, ray_indices, t_starts, t_ends, packed_info, spp, light_u, shuffle_u,
+            render_mode=render_mode, env_base=env_base, background_color=background_color, global_illumination=global_illumination,
+            jitter_n=material_jitter, light_sampling="per_point" if render_mode == "light" else "shared")
+        mid = (t_starts + t_ends) / 2.0
+        depth = nerfacc._Accumulate.apply(res["weights"].detach(), mid[:, None].contiguous(), ray_indices, packed_info)
+        T = 1.0 - res["opacity"]
+        o = dict(res, depth=depth + T.detach() * far[:, None], comp_demod_phys=res["comp_rgb_phys"])
+        if "volume_interaction" in res:
+            o["comp_demod_phys"] = res["volume_interaction"].composite(res["fg_weights"], (res["fg_Lo_diff"] + res["fg_Lo_spec"]).contiguous(),
+                                                                       T, background_color)
+        z1 = torch.zeros((rays.shape[0], 1), device=rays.device)
+        o.update(sdf_samples=res["sdf"], sdf_grad_samples=res["sdf_grad"], sdf_laplace_samples=torch.zeros_like(res["sdf"]),
+                 points=mid, intervals=t_ends - t_starts, ray_indices=ray_indices)
+        for k in ("normals_orientation_loss_map", "albedo_smoothness_loss_map", "roughness_smoothness_loss_map", "metallic_smoothness_loss_map"):
+            o.setdefault(k, z1)
+        if render_mode == "uniform_light":
+            o.setdefault("visibility", z1)
+        d = self.output_dict(o, background_color, render_mode, int(t_starts.shape[0]))
+        d["stats"] = dict(res["stats"], **stats)
+        return d

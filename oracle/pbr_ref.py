@@ -170,3 +170,42 @@ def pbr_uniform_light_shade(normal, albedo, roughness, metallic, view_dirs, ligh
     Lo = (1 - metallic[:, None]) * albedo * Ld + Ls
     vis = np.repeat((2.0 * t)[:, None], 3, 1)
     return Lo.astype(np.float32), Ld.astype(np.float32), Ls.astype(np.float32), vis.astype(np.float32)
+
+
+def pbr_mats_shade(normal, albedo, roughness, metallic, view_dirs, out_dirs, tr, ind_rgb, base, w2s_rot):
+    """pbr_mats_forward (models/intrinsic_avatar.py:863-948) after the secondary rays have been traced: BRDF-sampled
+    directions, weight 1 / scatterer.pdf (pdf <= 0 -> 1); no cosine mask, no clamp of the transmittance."""
+    wi = -view_dirs
+    diff, spec = brdf_eval(normal, wi, out_dirs, roughness, albedo, metallic)
+    pdf = brdf_pdf(normal, wi, out_dirs, roughness)
+    pdf = np.where(pdf > 0, pdf, 1.0).astype(np.float32)
+    dw = out_dirs @ w2s_rot
+    dw = dw / np.maximum(np.linalg.norm(dw, axis=-1, keepdims=True), 1e-6)
+    Li = envlight_eval(base, dw) * tr[:, None] + (ind_rgb if ind_rgb is not None else 0.0)
+    Ld = Li * diff / pdf[:, None]
+    Ls = Li * spec / pdf[:, None]
+    Lo = (1 - metallic[:, None]) * albedo * Ld + Ls
+    return Lo.astype(np.float32), Ld.astype(np.float32), Ls.astype(np.float32)
+
+
+def pbr_mis_shade(normal, albedo, roughness, metallic, view_dirs, scatter_dirs, light_dirs, tr2, ind_rgb2, base, pmf, w2s_rot):
+    """pbr_mis_forward (models/intrinsic_avatar.py:547-652): both strategies' samples ([scatter | light], 2F rays, tr2 /
+    ind_rgb2 in that order) weighted by 1 / (pdf_scatter + pdf_light) (the balance heuristic with the Monte-Carlo pdf
+    cancelled; <= 1e-6 -> 0), summed over the two strategies."""
+    F_ = normal.shape[0]
+    rep = lambda a: np.concatenate([a, a], 0)      # noqa: E731
+    wo = np.concatenate([scatter_dirs, light_dirs], 0)
+    n2, wi2, a2, r2, m2 = rep(normal), rep(-view_dirs), rep(albedo), rep(roughness), rep(metallic)
+    pdf_s = brdf_pdf(n2, wi2, wo, r2)
+    dw = wo @ w2s_rot
+    dw = dw / np.maximum(np.linalg.norm(dw, axis=-1, keepdims=True), 1e-6)
+    pdf_l = envlight_pdf(pmf, dw)
+    diff, spec = brdf_eval(n2, wi2, wo, r2, a2, m2)
+    Li = envlight_eval(base, dw) * tr2[:, None] + (ind_rgb2 if ind_rgb2 is not None else 0.0)
+    tot = pdf_s + pdf_l
+    w = np.where(tot > 1e-6, 1.0 / np.where(tot > 1e-6, tot, 1.0), 0.0).astype(np.float32)
+    Ld = Li * diff * w[:, None]
+    Ls = Li * spec * w[:, None]
+    Lo = (1 - m2[:, None]) * a2 * Ld + Ls
+    s2 = lambda a: a.reshape(2, F_, 3).sum(0).astype(np.float32)      # noqa: E731
+    return s2(Lo), s2(Ld), s2(Ls)

@@ -257,14 +257,60 @@ def light_shuffle(n_rays, spp, rpi, fg_idx, shuffle_u):
     return col[has].reshape(-1)[fg_idx]
 
 
+def _light_estimators(sc, Pb, ex, pmf, R, F_, n, spp, rpi, rri, rw, fg_idx, light_u, shuffle_u, per_point, render_mode,
+                      global_illumination, stats):
+    """render_mode light / uniform_light of relight_step: directions, cosine mask, secondary rays, estimator."""
+    vis_map = None
+    shuffled = None
+    if per_point:                                                                    # training branch (:777-781)
+        u = light_u[:F_]
+        dirs_world = Pb.envlight_sample(pmf, F_, u[:, 0].astype(np.float64), u[:, 1].astype(np.float64), u[:, 2].astype(np.float64))
+        out_dirs = _normalize(dirs_world @ R.T).astype(np.float32)                   # transform_dirs_w2s
+    else:
+        if render_mode == "light":
+            dirs_world = Pb.envlight_sample(pmf, spp, light_u[:, 0].astype(np.float64), light_u[:, 1].astype(np.float64),
+                                            light_u[:, 2].astype(np.float64))
+            dirs_smpl = _normalize(dirs_world @ R.T).astype(np.float32)             # transform_dirs_w2s
+            inv_pdf_all = None
+        else:                                                                        # uniform_light (:654-753, :1390-1401)
+            assert render_mode == "uniform_light" and spp == 512
+            dirs_smpl, inv_pdf_all = Pb.uniform_sphere_stratified(16, 32, light_u[:, :2])
+        shuffled = light_shuffle(n, spp, rpi, fg_idx, shuffle_u)
+        out_dirs = dirs_smpl[shuffled]
+    cos_mask = (ex["normals"] * out_dirs).sum(-1) > 1e-6
+    sec_tr = np.zeros((F_, 1), np.float32)
+    sec_rgb = np.zeros((F_, 3), np.float32)
+    stats["n_secondary"] = int(cos_mask.sum())
+    if stats["n_secondary"] > 0:
+        t_, c_, st2 = compute_indirect_radiance(sc, np.ascontiguousarray(ex["positions"][cos_mask]),
+                                                np.ascontiguousarray(out_dirs[cos_mask]))
+        sec_tr[cos_mask], sec_rgb[cos_mask] = np.clip(t_, 0.0, 1.0), c_
+        stats.update(st2)
+    if render_mode == "light":
+        fg_Lo, fg_Ld, fg_Ls = Pb.pbr_light_shade(ex["normals"], ex["albedo"], ex["roughness"][:, 0], ex["metallic"][:, 0],
+                                                 ex["t_dirs"], out_dirs, sec_tr[:, 0],
+                                                 sec_rgb if global_illumination else None, sc.env_base, pmf, R)
+    else:
+        fg_Lo, fg_Ld, fg_Ls, fg_vis = Pb.pbr_uniform_light_shade(
+            ex["normals"], ex["albedo"], ex["roughness"][:, 0], ex["metallic"][:, 0], ex["t_dirs"], out_dirs, sec_tr[:, 0],
+            sec_rgb if global_illumination else None, sc.env_base, R, inv_pdf_all[shuffled][:, 0])
+        vis = np.zeros((len(rri), 3), np.float32)
+        vis[fg_idx] = fg_vis
+        vis_map = O.accumulate_along_rays(rw, vis, rri, n).mean(-1, keepdims=True)      # :1414-1419
+    return fg_Lo, cos_mask, sec_tr, sec_rgb, out_dirs, shuffled, fg_Ld, fg_Ls, vis_map
+
+
 def relight_step(sc, rays_world, spp=16, seed=0, light_u=None, shuffle_u=None, jitter=None, global_illumination=False,
-                 background_color=(1.0, 1.0, 1.0), importance_sample=True, render_mode="light", light_sampling="shared"):
+                 background_color=(1.0, 1.0, 1.0), importance_sample=True, render_mode="light", light_sampling="shared",
+                 scatter_u=None):
     """forward_ with enable_phys, render_mode = light, eval form (models/intrinsic_avatar.py:950-1651): steps 1-4 as
     render_step, step 5 = rendering_with_normals_mats_sdf (volrend.py:810-1020), steps 6-8 = :1288-1470.
     light_u [spp,3] (emitter.sample uniforms) and shuffle_u [n_rays,spp] are explicit (drawn from `seed` when None).
     light_sampling (render_mode 'light'): 'shared' = the eval branch of pbr_light_forward (:782-789: one set of spp directions
     per frame, permuted per ray); 'per_point' = its `self.training` branch (:777-781): emitter.sample(F) -- an independent
     direction per foreground re-sample, light_u [>= F, 3], no shuffle.
+    render_mode 'mats' / 'mis' (pbr_mats_forward :863-948, pbr_mis_forward :547-652): scatter_u [>= F, 6] = the uniforms of
+    scatterer.sample (columns 0..2) and, for mis, of emitter.sample(F) (columns 3..5); every fg re-sample traces its rays.
     sc additionally carries mat_W, mat_b, env_base [H,W,3]."""
     from . import pbr_ref as Pb
     rng = np.random.default_rng(seed)
@@ -287,6 +333,9 @@ def relight_step(sc, rays_world, spp=16, seed=0, light_u=None, shuffle_u=None, j
                packed_info=pinfo)
     out["depth"] = acc(((ts + te) / np.float32(2.0))[:, None]) + (1 - out["opacity"]) * far[:, None]
     rgb_phys = np.tile(bgc[None], (n, 1)).astype(np.float32)
+    demod_phys = rgb_phys.copy()
+    if render_mode == "uniform_light":
+        out["visibility"] = np.zeros((n, 1), np.float32)                                      # :1266-1267
     stats.update(n_samples=len(ts), n_resampled=0, n_fg=0, n_secondary=0)
     if len(rix) > 0:
         extras = dict(weights=w, sdf=sh["sdf"], alphas=sh["alphas"], normals=sh["normal_smpl"], albedo=mats[:, :3],
@@ -299,47 +348,72 @@ def relight_step(sc, rays_world, spp=16, seed=0, light_u=None, shuffle_u=None, j
             R = sc.w2s[:3, :3]
             pmf = Pb.envlight_pmf(sc.env_base)
             shuffled = None
-            if per_point:                                                                    # training branch (:777-781)
-                u = light_u[:F_]
-                dirs_world = Pb.envlight_sample(pmf, F_, u[:, 0].astype(np.float64), u[:, 1].astype(np.float64), u[:, 2].astype(np.float64))
-                out_dirs = _normalize(dirs_world @ R.T).astype(np.float32)                   # transform_dirs_w2s
-            else:
-                if render_mode == "light":
-                    dirs_world = Pb.envlight_sample(pmf, spp, light_u[:, 0].astype(np.float64), light_u[:, 1].astype(np.float64),
-                                                    light_u[:, 2].astype(np.float64))
-                    dirs_smpl = _normalize(dirs_world @ R.T).astype(np.float32)             # transform_dirs_w2s
-                    inv_pdf_all = None
-                else:                                                                        # uniform_light (:654-753, :1390-1401)
-                    assert render_mode == "uniform_light" and spp == 512
-                    dirs_smpl, inv_pdf_all = Pb.uniform_sphere_stratified(16, 32, light_u[:, :2])
-                shuffled = light_shuffle(n, spp, rpi, fg_idx, shuffle_u)
-                out_dirs = dirs_smpl[shuffled]
-            cos_mask = (ex["normals"] * out_dirs).sum(-1) > 1e-6
-            sec_tr = np.zeros((F_, 1), np.float32)
-            sec_rgb = np.zeros((F_, 3), np.float32)
-            stats["n_secondary"] = int(cos_mask.sum())
-            if stats["n_secondary"] > 0:
-                t_, c_, st2 = compute_indirect_radiance(sc, np.ascontiguousarray(ex["positions"][cos_mask]),
-                                                        np.ascontiguousarray(out_dirs[cos_mask]))
-                sec_tr[cos_mask], sec_rgb[cos_mask] = np.clip(t_, 0.0, 1.0), c_
+            if render_mode in ("mats", "mis"):
+                assert scatter_u is not None and scatter_u.shape[0] >= F_
+                rough, metal = ex["roughness"][:, 0], ex["metallic"][:, 0]
+                sc_dirs = Pb.brdf_sample(ex["normals"], -ex["t_dirs"], rough, scatter_u[:F_, :3].astype(np.float64))
+                if render_mode == "mis":
+                    u = scatter_u[:F_, 3:6].astype(np.float64)
+                    li_dirs = _normalize(Pb.envlight_sample(pmf, F_, u[:, 0], u[:, 1], u[:, 2]) @ R.T).astype(np.float32)
+                    out_dirs = np.concatenate([sc_dirs, li_dirs], 0)
+                    pos2 = np.concatenate([ex["positions"], ex["positions"]], 0)
+                else:
+                    out_dirs, pos2 = sc_dirs, ex["positions"]
+                stats["n_secondary"] = int(out_dirs.shape[0])
+                t_, c_, st2 = compute_indirect_radiance(sc, np.ascontiguousarray(pos2), np.ascontiguousarray(out_dirs))
                 stats.update(st2)
-            if render_mode == "light":
-                fg_Lo, fg_Ld, fg_Ls = Pb.pbr_light_shade(ex["normals"], ex["albedo"], ex["roughness"][:, 0], ex["metallic"][:, 0],
-                                                         ex["t_dirs"], out_dirs, sec_tr[:, 0],
-                                                         sec_rgb if global_illumination else None, sc.env_base, pmf, R)
+                sec_tr, sec_rgb = t_, c_
+                ind = sec_rgb if global_illumination else None
+                if render_mode == "mis":
+                    fg_Lo, fg_Ld, fg_Ls = Pb.pbr_mis_shade(ex["normals"], ex["albedo"], rough, metal, ex["t_dirs"], sc_dirs, li_dirs,
+                                                           sec_tr[:, 0], ind, sc.env_base, pmf, R)
+                else:
+                    fg_Lo, fg_Ld, fg_Ls = Pb.pbr_mats_shade(ex["normals"], ex["albedo"], rough, metal, ex["t_dirs"], sc_dirs, sec_tr[:, 0],
+                                                            ind, sc.env_base, R)
+                cos_mask = np.ones(out_dirs.shape[0], bool)
             else:
-                fg_Lo, fg_Ld, fg_Ls, fg_vis = Pb.pbr_uniform_light_shade(
-                    ex["normals"], ex["albedo"], ex["roughness"][:, 0], ex["metallic"][:, 0], ex["t_dirs"], out_dirs, sec_tr[:, 0],
-                    sec_rgb if global_illumination else None, sc.env_base, R, inv_pdf_all[shuffled][:, 0])
-                vis = np.zeros((len(rri), 3), np.float32)
-                vis[fg_idx] = fg_vis
-                out["visibility"] = O.accumulate_along_rays(rw, vis, rri, n).mean(-1, keepdims=True)      # :1414-1419
+                fg_Lo, cos_mask, sec_tr, sec_rgb, out_dirs, shuffled, fg_Ld, fg_Ls, vis_map = _light_estimators(
+                    sc, Pb, ex, pmf, R, F_, n, spp, rpi, rri, rw, fg_idx, light_u, shuffle_u, per_point, render_mode, global_illumination, stats)
+                if vis_map is not None:
+                    out["visibility"] = vis_map
             Lo = np.zeros((len(rri), 3), np.float32)
             Lo[bg_idx] = bgc[None]                                                           # :1335-1342
             Lo[fg_idx] = fg_Lo
             rgb_phys = O.accumulate_along_rays(rw, Lo, rri, n)
+            Lo_demod = Lo.copy()                                                             # :1336,1421-1423
+            Lo_demod[fg_idx] = fg_Ld + fg_Ls
+            demod_phys = O.accumulate_along_rays(rw, Lo_demod, rri, n)
             out.update(fg_Lo=fg_Lo, fg_Lo_diff=fg_Ld, fg_Lo_spec=fg_Ls, secondary_tr=sec_tr, secondary_rgb=sec_rgb,
                        out_dirs=out_dirs, cos_mask=cos_mask, fg_extras=ex, shuffled=shuffled)
         rgb_phys[rpi[:, 1] <= 0] = bgc[None]                                                 # :1452-1466
-    out.update(comp_rgb_phys=rgb_phys, stats=stats)
+        demod_phys[rpi[:, 1] <= 0] = bgc[None]
+    out.update(comp_rgb_phys=rgb_phys, comp_demod_phys=demod_phys, stats=stats)
     return out
+
+
+def rgb_to_srgb(f):
+    f = np.clip(f, 0.0, 1.0)
+    return np.where(f <= 0.0031308, f * 12.92, np.power(np.maximum(f, 0.0031308), 1.0 / 2.4) * 1.055 - 0.055).astype(np.float32)
+
+
+def forward_output_dict(o, background_color, render_mode="light"):
+    """the dict IntrinsicAvatarModel.forward_ returns in eval mode with enable_phys (models/intrinsic_avatar.py:1492-1651),
+    from a relight_step result: linear maps, the constant-background dict (`*_bg`) and the composited sRGB dict (`*_full`)."""
+    bgc = np.asarray(background_color, np.float32)
+    acc = o["opacity"]
+    n = acc.shape[0]
+    out = dict(comp_rgb=o["comp_rgb"], comp_normal=o["comp_normal"], opacity=acc, depth=o["depth"], rays_valid=acc > 0,
+               rays_valid_phys=acc > 0, num_samples=np.array([len(o["t_starts"])], np.int32), comp_rgb_phys=o["comp_rgb_phys"],
+               comp_demod_phys=o["comp_demod_phys"], comp_albedo=o["albedo"], comp_metallic=o["metallic"], comp_roughness=o["roughness"])
+    if render_mode == "uniform_light":
+        out["visibility"] = o["visibility"]
+    bgm = np.full((n, 1), bgc.mean(), np.float32)
+    out_bg = dict(comp_rgb=np.tile(bgc[None], (n, 1)), num_samples=np.zeros(1, np.int32), rays_valid=np.zeros((n, 1), bool),
+                  rays_valid_phys=np.zeros((n, 1), bool), comp_albedo=np.zeros((n, 3), np.float32), comp_metallic=bgm, comp_roughness=bgm)
+    T = 1.0 - acc
+    out_full = dict(comp_rgb=np.clip(rgb_to_srgb(out["comp_rgb"] + out_bg["comp_rgb"] * T), 0, 1), num_samples=out["num_samples"],
+                    rays_valid=out["rays_valid"], rays_valid_phys=out["rays_valid_phys"],
+                    comp_rgb_phys=np.clip(rgb_to_srgb(out["comp_rgb_phys"]), 0, 1), comp_demod_phys=np.clip(rgb_to_srgb(out["comp_demod_phys"]), 0, 1),
+                    comp_albedo=out["comp_albedo"] + out_bg["comp_albedo"] * T, comp_metallic=out["comp_metallic"] + out_bg["comp_metallic"] * T,
+                    comp_roughness=out["comp_roughness"] + out_bg["comp_roughness"] * T)
+    return {**out, **{k + "_bg": v for k, v in out_bg.items()}, **{k + "_full": v for k, v in out_full.items()}}

@@ -66,8 +66,13 @@ class RngLog:
         self.orig = (torch.rand, torch.rand_like, torch.randn_like)
 
     def rand(self, *size, **kw):
-        size = size[0] if (len(size) == 1 and not isinstance(size[0], int)) else size
-        t = self.orig[0](tuple(size), generator=self.g)
+        size = tuple(size[0] if (len(size) == 1 and not isinstance(size[0], int)) else size)
+        if int(np.prod(size)) >= FORMULA_MIN:                          # the [n_rays, 512] shuffle uniforms of uniform_light
+            seed = 7000 + len(self.log)
+            t = torch.from_numpy((S.hash_table_values(int(np.prod(size)), seed, 1.0).astype(np.float64) + 1.0) / 2.0).float().reshape(size)
+            self.log.append(("rand_formula", torch.tensor([seed, int(np.prod(size))], dtype=torch.int64)))
+            return t
+        t = self.orig[0](size, generator=self.g)
         self.log.append(("rand", t.clone()))
         return t
 
@@ -405,8 +410,9 @@ def main():
             log = RNG.log
         if not state_saved:
             sd = model.state_dict()
-            out["state_keys"] = np.array(sorted(k for k in sd if not k.endswith("encoding.encoding.params")))
-            out.update({"state_" + k: N(v) for k, v in sd.items() if not k.endswith("encoding.encoding.params") and v.numel() > 0})
+            keep = [k for k in sd if not k.endswith("encoding.encoding.params") and not k.startswith("occupancy_grid") and sd[k].numel() > 0]
+            out["state_keys"] = np.array(sorted(keep))
+            out.update({"state_" + k: N(sd[k]) for k in keep})
             out["render_step_size"] = np.float64(model.render_step_size)
             state_saved = True
         out[tag + "_occ_binaries"], out[tag + "_occ_aabb"] = N(binaries), N(aabb)
