@@ -119,10 +119,10 @@ def cgroup_throttle():
         return None
 
 
-def build_headline(dev, hw, spp, rank):
+def build_headline(dev, hw, spp, rank, pose):
     """the synthetic frame + material head + training-time light of the headline workload."""
     from intrinsicavatar_amd import synthetic as S, fields, pbr
-    rs, rays, export = S.build_frame(dev, hw, hw, pose_seed=0, beta=0.01, num_samples_per_ray=128)
+    rs, rays, export = S.build_frame(dev, hw, hw, pose=pose, beta=0.01, num_samples_per_ray=128)
     mat = fields.VolumeMaterial(seed=2).to(dev)
     sg = pbr.EnvironmentLightSG(num_SGs=64, base_res=256, seed=4).to(dev)       # configs/light/envlight_SG.yaml
     return rs, rays, export, mat, sg
@@ -137,6 +137,9 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--ray-chunk", type=int, default=int(os.environ.get("IA_RAY_CHUNK", str(1 << 19))))
     ap.add_argument("--workload", choices=["headline", "config2"], default="headline")
+    ap.add_argument("--pose", default=os.environ.get("IA_BENCH_POSE", "male-3-casual:0"),
+                    help="frame of the reference's pose files through plain FK: male-3-casual:{0,40,80,113} (peoplesnapshot training frames), "
+                         "aist:{0,100,200,319} (animation, out of distribution), or synthetic:K (N(0, 0.25) joint angles, rounds 1-2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config2", action="store_true", help="skip the secondary configs[1] measurement of the headline line")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the instrumented repeat (profiling runs)")
@@ -197,7 +200,7 @@ def main():
     from intrinsicavatar_amd import _lib as L, parallel, optim, pbr
 
     headline = args.workload == "headline"
-    rs, rays, export, mat, sg = build_headline(dev, args.hw, args.spp, rank)
+    rs, rays, export, mat, sg = build_headline(dev, args.hw, args.spp, rank, args.pose)
     n_rays = rays.shape[0]
     # one frame per rank (frame-/ray-batch sharding, replicated parameters).  Weak scaling = the SAME per-GPU workload at
     # every N: each rank renders the same frame (pose 0) against its own target image and draws its own random numbers,
@@ -437,9 +440,9 @@ def main():
               f"re-samples per ray, render_mode=light (one light-importance-sampled secondary ray per foreground re-sample, training form), "
               f"secondary march 64 steps + zero-crossing resampling + shading (global_illumination on), SG environment light; "
               f"{len(chunks)} ray chunk(s) of <= {args.ray_chunk} rays (gradient accumulation across chunks), secondary rays in chunks of 16 Mi; "
-              f"random-init fields, synthetic 24-bone rig") if headline else \
+              f"random-init fields, synthetic 24-bone rig posed by frame '{args.pose}' of the reference's pose files (plain FK)") if headline else \
              (f"{args.hw}x{args.hw} frame ({n_rays} rays), 128 samples/ray, radiance + SDF geometry, fast-SNARF deformer (13 inits), "
-              "2x importance resampling, random-init hash-grid/MLP fields, synthetic 24-bone rig")
+              f"2x importance resampling, random-init hash-grid/MLP fields, synthetic 24-bone rig posed by frame '{args.pose}' (plain FK)")
         base_metric = None
         try:
             base_metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
@@ -454,7 +457,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "pass": "fwd+bwd" if headline else args.mode, "spp": args.spp if headline else 0,
-                       "render_mode": "light" if headline else None, "global_illumination": bool(headline),
+                       "render_mode": "light" if headline else None, "global_illumination": bool(headline), "pose": args.pose,
                        "ray_chunk": args.ray_chunk if headline else n_rays,
                        "host_numa_node": numa_node, "host_cpus_busy": round(cpu_busy, 2), "blocking_sync": bool(blocking),
                        "host_cpu_throttled_ms_in_timed_region": (None if not (thr0 and thr1) else round((thr1[1] - thr0[1]) / 1e3, 1)),

@@ -61,6 +61,33 @@ def make_pose(seed=0, amplitude=0.25):
     return pose.astype(np.float64)
 
 
+def reference_pose(name="male-3-casual", frame=0):
+    """(pose72 [72] axis-angle = global_orient | body_pose, transl [3]) of one frame of the reference's own pose files:
+    'male-3-casual' (load/peoplesnapshot/male-3-casual/poses/anim_nerf_train.npz: training frames 0 / 40 / 80 / 113) or 'aist'
+    (load/animation/aist/poses.npz: out-of-distribution frames 0 / 100 / 200 / 319, translation re-based as
+    datasets/animation.py:129-130).  The arrays travel as data in tests/golden/reference_poses.npz
+    (tests/golden/make_reference_poses.py)."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "reference_poses.npz")
+    z = np.load(path)
+    frames = z[name + "_frames"].tolist()
+    if frame not in frames:
+        raise KeyError(f"{name}: frame {frame} is not in the committed set {frames}")
+    i = frames.index(frame)
+    pose = np.concatenate([z[name + "_global_orient"][i], z[name + "_body_pose"][i]]).astype(np.float64)
+    return pose, z[name + "_transl"][i].astype(np.float64)
+
+
+def parse_pose(spec):
+    """'male-3-casual:0' / 'aist:100' -> reference_pose(...); 'synthetic:K' -> (make_pose(K), (0, 0.15, 5)); 'neutral' -> rest pose."""
+    if spec in (None, "neutral"):
+        return None, (0.0, 0.15, 5.0)
+    name, _, k = spec.partition(":")
+    if name == "synthetic":
+        return make_pose(int(k or 0)), (0.0, 0.15, 5.0)
+    return reference_pose(name, int(k or 0))
+
+
 def make_rig(pose72=None, transl=(0.0, 0.15, 5.0)):
     """returns dict(tfs [1,24,4,4] (w2s @ A, root = identity), w2s [4,4], joints_posed [24,3] in SMPL space)."""
     if pose72 is None:
@@ -175,15 +202,20 @@ def make_scene(height=128, width=128, pose_seed=0, res=64):
 
 # ----------------------------------------------------------------------------- full synthetic frame (torch / GPU side)
 def build_frame(device="cuda:0", height=128, width=128, pose_seed=0, beta=0.01, hash_amp=1e-4, num_samples_per_ray=128,
-                grid_D=32, grid_H=128, grid_W=128, smooth_iters=30, occ_res=64, seed=0):
+                grid_D=32, grid_H=128, grid_W=128, smooth_iters=30, occ_res=64, seed=0, pose=None):
     """Random-init model of the reference's architecture + synthetic rig + per-frame occupancy grid.
+    pose: None -> make_pose(pose_seed) (N(0, 0.25) joint angles; pose_seed None = neutral); or a spec for parse_pose():
+    'male-3-casual:0', 'aist:100' ... = a frame of the reference's own pose files through plain forward kinematics.
     Returns (RenderStep, rays_world [H*W, 8] tensor, export dict of numpy arrays for the CPU oracle)."""
     import torch
     from . import fields, render
     from .deformer import SNARFDeformer
 
     w, offk, sck, bbox = skinning_weight_grid(grid_D, grid_H, grid_W, smooth_iters=smooth_iters)
-    rig = make_rig(None if pose_seed is None else make_pose(pose_seed))      # None: static neutral pose (tfs == identity)
+    if pose is not None:
+        rig = make_rig(*parse_pose(pose))
+    else:
+        rig = make_rig(None if pose_seed is None else make_pose(pose_seed))      # None: static neutral pose (tfs == identity)
     dev = torch.device(device)
     dfm = SNARFDeformer(torch.from_numpy(w).to(dev), torch.from_numpy(offk).to(dev), torch.from_numpy(sck).to(dev),
                         torch.from_numpy(bbox).to(dev))

@@ -7,7 +7,8 @@ path, only the final gather of the timings):
     python tools/relight_bench.py --gpus N --frames F               N ranks (re-executes itself under torch.distributed.run), or
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/relight_bench.py --gpus N --frames F
 
-Every rank renders frames rank, rank + N, ... of F animation poses (pose seed = frame index).  Prints JSON on rank 0
+Every rank renders frames rank, rank + N, ... of F animation poses: the committed frames 0 / 100 / 200 / 319 of the reference's
+load/animation/aist/poses.npz, cycled (plain FK; --poses synthetic = the N(0, 0.25) poses of rounds 1-2).  Prints JSON on rank 0
 (frames/s of the whole job, primary / secondary rays per second, per-entry-point breakdown of rank 0)."""
 import argparse, json, os, sys, time
 import numpy as np
@@ -21,6 +22,7 @@ ap.add_argument("--hw", type=int, default=int(os.environ.get("IA_HW", "540")))
 ap.add_argument("--spp", type=int, default=int(os.environ.get("IA_SPP", "256")))
 ap.add_argument("--gi", action="store_true", default=os.environ.get("IA_GI", "0") == "1")
 ap.add_argument("--ray-chunk", type=int, default=int(os.environ.get("IA_RAY_CHUNK", str(1 << 19))))
+ap.add_argument("--poses", choices=["aist", "synthetic"], default="aist")
 args = ap.parse_args()
 import bench as _bench
 _bench.self_launch_ranks(args.gpus, script=os.path.abspath(__file__))        # plain `python tools/relight_bench.py --gpus N` starts its own ranks
@@ -55,9 +57,13 @@ g = torch.Generator().manual_seed(0)
 light_u = torch.rand((spp, 3), generator=g).to(dev)
 
 
-def frame(pose_seed):
+AIST = (0, 100, 200, 319)
+
+
+def frame(k):
     """one frame: per-frame deformer grids + occupancy grid (prepare), then the ray chunks of the image."""
-    rs, rays, _ = S.build_frame(dev, hw, hw, pose_seed=pose_seed, beta=0.01)
+    pose = f"aist:{AIST[k % len(AIST)]}" if args.poses == "aist" else f"synthetic:{k}"
+    rs, rays, _ = S.build_frame(dev, hw, hw, pose=pose, beta=0.01)
     n = rays.shape[0]
     tot = dict(n_secondary=0, n_fg=0, n_rays=n)
     for c0 in range(0, n, chunk):                 # ray chunks as the reference does at eval (ray_chunk), but 16x larger
@@ -84,7 +90,7 @@ if world > 1:
     tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX); dist.all_reduce(t)
     dt, sec, fg, nr = float(tm[0]), int(t[1]), int(t[2]), int(t[3])
 if rank == 0:
-    print(json.dumps(dict(hw=hw, spp=spp, gi=gi, ray_chunk=chunk, n_gpus=world, frames=n_frames, s_total=round(dt, 3),
+    print(json.dumps(dict(hw=hw, spp=spp, gi=gi, poses=args.poses, ray_chunk=chunk, n_gpus=world, frames=n_frames, s_total=round(dt, 3),
                           frames_per_s=round(n_frames / dt, 4), s_per_frame_per_gpu=round(dt / max(len(my_frames), 1), 3),
                           primary_rays_per_s=round(nr / dt, 1), secondary_rays=sec, secondary_rays_per_s=round(sec / dt, 1), fg_points=fg,
                           includes="per-frame prepare (precompute + occupancy grid) inside the timed region",
