@@ -371,7 +371,7 @@ def main():
             if dname in ("ia_fuse_broyden", "ia_fuse_broyden_spec") and world == 1:      # one extra untimed step (a step has collectives: single rank only)
                 bro = count_broyden_fetches(step, dev, rs.deformer)[dname]
             ab = algorithmic_bytes(dname, detail[dname], extra=(bro[1] * k_instr if bro else None))
-            stats["deform_points"] = sum(u for _, u, _ in detail.get("ia_fuse_broyden", [])) // k_instr      # counted, not estimated
+            stats["deform_points"] = sum(u for k in ("ia_fuse_broyden", "ia_fuse_broyden_spec") for _, u, _ in detail.get(k, [])) // k_instr      # counted, not estimated
             stats["hash_points"] = sum(u for k in ("ia_hashgrid_fwd", "ia_hashgrid_fwd_xcd") for _, u, _ in detail.get(k, [])) // k_instr
             if ab:
                 avg_us = dms / dcalls * 1e3

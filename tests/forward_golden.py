@@ -17,7 +17,7 @@ def load():
 def hash_tables():
     """the two tables of the golden scene: closed-form in the entry index (make_golden_forward.py init_params)."""
     from intrinsicavatar_amd import synthetic as S
-    n = 12599920 * 2
+    n = 12599920                  # floats: 6 299 960 entries x 2 features (tiny-cuda-nn's flat `params`)
     return S.hash_table_values(n, 11, 1e-2), S.hash_table_values(n, 12, 1e-2)
 
 
