@@ -61,7 +61,7 @@ def algorithmic_bytes(name, calls, extra=None):
     """SURVEY.md 8(d) per-unit algorithmic bytes x the COUNTED units of every launch of one entry point.
     calls = [(ms, units, extras)].  Returns total bytes over the calls (None: no model for this entry point)."""
     n = sum(u for _, u, _ in calls)
-    if name in ("ia_fuse_broyden", "ia_fuse_broyden_spec"):
+    if name in ("ia_fuse_broyden", "ia_fuse_broyden_spec", "ia_fuse_broyden_spec_rows"):
         # SURVEY 8(d) row "Broyden (a7/K8)": per (point, init) 12 B target + 64 B bone row in, (1 + iters) x 8 corners x 48 B
         # gathered (SURVEY gives the <= 11-fetch upper bound; here the fetches are COUNTED by ia_broyden_stats: `extra`
         # = in-range corner loads of the step), 13 B out (x + valid; +36 B each for J_inv / fwd_J when requested).
@@ -85,6 +85,7 @@ def algorithmic_bytes(name, calls, extra=None):
 PMC_KERNELS = {
     "ia_fuse_broyden": ("alt", ["broyden_persistent2_kernel", "broyden_persistent_kernel", "broyden_kernel"]),
     "ia_fuse_broyden_spec": ("alt", ["broyden_spec_kernel"]),
+    "ia_fuse_broyden_spec_rows": ("alt", ["broyden_spec_kernel"]),
     "ia_hashgrid_fwd": ("alt", ["hash_fwd_kernel"]),
     "ia_hashgrid_fwd_xcd": ("seq", ["hash_fwd_xcd_kernel", "hash_transpose_kernel"]),
     "ia_hashgrid_bwd_binned": ("seq", ["hash_bin", "hash_reduce_kernel"]),
@@ -368,10 +369,10 @@ def main():
         if per_call:
             dname, (dcalls, dms) = max(per_call.items(), key=lambda kv: kv[1][1])
             bro = None
-            if dname in ("ia_fuse_broyden", "ia_fuse_broyden_spec") and world == 1:      # one extra untimed step (a step has collectives: single rank only)
+            if dname in ("ia_fuse_broyden", "ia_fuse_broyden_spec", "ia_fuse_broyden_spec_rows") and world == 1:      # one extra untimed step (a step has collectives: single rank only)
                 bro = count_broyden_fetches(step, dev, rs.deformer)[dname]
             ab = algorithmic_bytes(dname, detail[dname], extra=(bro[1] * k_instr if bro else None))
-            stats["deform_points"] = sum(u for k in ("ia_fuse_broyden", "ia_fuse_broyden_spec") for _, u, _ in detail.get(k, [])) // k_instr      # counted, not estimated
+            stats["deform_points"] = sum(u for k in ("ia_fuse_broyden", "ia_fuse_broyden_spec", "ia_fuse_broyden_spec_rows") for _, u, _ in detail.get(k, [])) // k_instr      # counted, not estimated
             stats["hash_points"] = sum(u for k in ("ia_hashgrid_fwd", "ia_hashgrid_fwd_xcd") for _, u, _ in detail.get(k, [])) // k_instr
             if ab:
                 avg_us = dms / dcalls * 1e3
@@ -508,7 +509,7 @@ def count_broyden_fetches(step, dev, dfm):
     cnt_x = torch.zeros(17, dtype=torch.int64, device=dev)      # what the exact search would cost on the speculative calls' inputs
     spec = torch.zeros(5, dtype=torch.int64, device=dev)
     n_spec_items = [0]
-    orig, orig_spec = fast_snarf.fuse_broyden, fast_snarf.fuse_broyden_spec
+    orig, orig_spec, orig_rows = fast_snarf.fuse_broyden, fast_snarf.fuse_broyden_spec, fast_snarf.fuse_broyden_spec_rows
 
     def stats(xd_tgt, voxel_J, tfs, bone_ids, offset, scale, cvg, dvg, out):
         cl = isinstance(voxel_J, fast_snarf.ChannelLastVoxelJ)
@@ -529,16 +530,20 @@ def count_broyden_fetches(step, dev, dfm):
         orig_spec(x, xd_tgt, voxel_J, tfs, bone_ids, J_inv, is_valid, offset, scale, cvg, dvg, eps, fwd_J=fwd_J, counters=spec)
         stats(xd_tgt, voxel_J, tfs, bone_ids, offset, scale, cvg, dvg, cnt_x)
         n_spec_items[0] += xd_tgt.shape[1] * bone_ids.shape[0]
-    fast_snarf.fuse_broyden, fast_snarf.fuse_broyden_spec = wrapped, wrapped_spec
+    def wrapped_rows(x, xd_tgt, voxel_J, tfs, bone_ids, J_inv, cnt_, slot_init, offset, scale, cvg, dvg, eps, fwd_J=None, counters=None):
+        orig_rows(x, xd_tgt, voxel_J, tfs, bone_ids, J_inv, cnt_, slot_init, offset, scale, cvg, dvg, eps, fwd_J=fwd_J, counters=spec)
+        stats(xd_tgt, voxel_J, tfs, bone_ids, offset, scale, cvg, dvg, cnt_x)
+        n_spec_items[0] += xd_tgt.shape[1] * bone_ids.shape[0]
+    fast_snarf.fuse_broyden, fast_snarf.fuse_broyden_spec, fast_snarf.fuse_broyden_spec_rows = wrapped, wrapped_spec, wrapped_rows
     try:
         step()
         torch.cuda.synchronize()
     finally:
-        fast_snarf.fuse_broyden, fast_snarf.fuse_broyden_spec = orig, orig_spec
+        fast_snarf.fuse_broyden, fast_snarf.fuse_broyden_spec, fast_snarf.fuse_broyden_spec_rows = orig, orig_spec, orig_rows
     c, cx, sp = cnt.cpu().tolist(), cnt_x.cpu().tolist(), spec.cpu().tolist()
     other = max(n_spec_items[0] - sp[1] - sp[2], 0)            # searches that ended by themselves without a valid root
-    return {"ia_fuse_broyden": c[:5] + [0, 0, c[0]],
-            "ia_fuse_broyden_spec": [sp[0], sp[4], 0, 0, other, sp[1], sp[2], cx[0]]}
+    spec_row = [sp[0], sp[4], 0, 0, other, sp[1], sp[2], cx[0]]
+    return {"ia_fuse_broyden": c[:5] + [0, 0, c[0]], "ia_fuse_broyden_spec": spec_row, "ia_fuse_broyden_spec_rows": spec_row}
 
 
 def usable_cores():

@@ -19,7 +19,8 @@ class IaError(RuntimeError):
 
 # optional outputs that change an entry point's compulsory traffic: ia_fuse_broyden(..., x, J_inv, is_valid, fwd_J, stream)
 _EXTRAS = {"ia_fuse_broyden": lambda a: dict(I=int(a[2].value), J_inv=bool(a[16].value), fwd_J=bool(a[18].value)),
-           "ia_fuse_broyden_spec": lambda a: dict(I=int(a[1].value), J_inv=bool(a[15].value), fwd_J=bool(a[17].value))}
+           "ia_fuse_broyden_spec": lambda a: dict(I=int(a[1].value), J_inv=bool(a[15].value), fwd_J=bool(a[17].value)),
+           "ia_fuse_broyden_spec_rows": lambda a: dict(I=int(a[1].value), J_inv=bool(a[15].value), fwd_J=bool(a[16].value))}
 
 
 class _Timed:

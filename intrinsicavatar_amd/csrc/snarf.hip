@@ -527,13 +527,21 @@ __device__ __forceinline__ unsigned in_range_corner_count(float gx, float gy, fl
 
 constexpr int SPEC_ROOTS = 3;      // recorded roots per point (survivors per point average 1.3; a 4th root is simply not recorded)
 
-template <bool COUNT>
+// PACK: the candidate bookkeeping of the caller done here.  With eps >= 1e-4 every search that COMPLETES valid is farther than
+// eps (inf-norm, so farther than K9's 1e-4 in L2) from every root recorded before it -- the completed items ARE K9's
+// survivors as long as a point has at most SPEC_ROOTS of them.  So instead of is_valid [N,I] for a filter pass, the k-th completed
+// search of a point (k = 0 is its highest init) stores its root in slot I-1-k of the point's row of x and its init in
+// slot_init, and the lane leaves cnt[point]: the row's last cnt slots hold the candidates in ascending init order
+// (ia_deform_rows_count / ia_deform_rows_pack turn that into the packed list; rows with more than SPEC_ROOTS candidates --
+// none in 18 M points of the headline distribution -- go through K9 there).
+template <bool COUNT, bool PACK>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES, IA_BR2_WAVES))) void broyden_spec_kernel(
     int64_t N, int I, const float* __restrict__ xd_tgt, const float* __restrict__ voxel_J, int D, int H, int W,
     const float* __restrict__ tfs, const int32_t* __restrict__ bone_ids, const float* __restrict__ offset_g,
     const float* __restrict__ scale_g, float cvg_threshold, float dvg_threshold, float eps, float* __restrict__ x,
     float* __restrict__ J_inv, uint8_t* __restrict__ is_valid, float* __restrict__ fwd_J, int pts_per_wave,
-    unsigned long long* __restrict__ counters /* NULL or [5]: fetches, retired items, completed valid items, unrecorded roots, in-range corner loads */)
+    unsigned long long* __restrict__ counters /* NULL or [5]: fetches, retired items, completed valid items, unrecorded roots, in-range corner loads */,
+    int32_t* __restrict__ cnt /* PACK: [N] */, uint8_t* __restrict__ slot_init /* PACK: [N,I] */)
 {
     __shared__ float s_T[16 * 12];                     // per init: rows 0..2 of its bone's 4x4 (R | t)
     for (int t = threadIdx.x; t < I * 12; t += THREADS) s_T[t] = tfs[(int64_t)bone_ids[t / 12] * 16 + (t % 12)];
@@ -554,6 +562,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
     int init = 0;
     int it = -1;                  // -1: waiting for the initial fetch
     int n_roots = 0;
+    int n_done = 0;               // PACK: searches of the lane's point that completed valid
     float xt[3] = {0, 0, 0}, x_l[3] = {0, 0, 0}, gx[3] = {0, 0, 0}, u[3] = {0, 0, 0};
     float Ji[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     float root[SPEC_ROOTS][3];
@@ -565,7 +574,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
         // ---- transitions: next init of the lane's point, or the wave's next point ----
         if (have && next) {
             next = false;
-            if (init > 0) { init--; it = -1; } else have = false;
+            if (init > 0) { init--; it = -1; }
+            else {
+                have = false;
+                if (PACK) cnt[p_begin + pt] = n_done;
+            }
         }
         const unsigned long long need = __ballot(!have);
         if (need) {
@@ -578,6 +591,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
                     init = I - 1;
                     it = -1;
                     n_roots = 0;
+                    n_done = 0;
                     xt[0] = xd_tgt[(p_begin + c) * 3 + 0];
                     xt[1] = xd_tgt[(p_begin + c) * 3 + 1];
                     xt[2] = xd_tgt[(p_begin + c) * 3 + 2];
@@ -605,7 +619,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
                 const float d = fmaxf(fmaxf(fabsf(x_l[0] - root[r][0]), fabsf(x_l[1] - root[r][1])), fabsf(x_l[2] - root[r][2]));
                 at_root = at_root || (r < n_roots && d < eps);
             }
-            if (at_root) { is_valid[index] = 0; if (COUNT) c_retired++; next = true; }
+            if (at_root) { if (!PACK) is_valid[index] = 0; if (COUNT) c_retired++; next = true; }
         }
         // a lane retired here sits this fetch out (it starts its next search in the next iteration)
         if (next) continue;
@@ -635,9 +649,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
             const float norm_gx = gn[0] * gn[0] + gn[1] * gn[1] + gn[2] * gn[2];
             if (norm_gx < cvg2) {
                 const bool ok = ix >= -1 && ix <= 1 && iy >= -1 && iy <= 1 && iz >= -1 && iz <= 1;
-                is_valid[index] = ok ? 1 : 0;
+                if (!PACK) is_valid[index] = ok ? 1 : 0;
                 if (ok) {
-                    x[index * 3 + 0] = x_l[0]; x[index * 3 + 1] = x_l[1]; x[index * 3 + 2] = x_l[2];
+                    if (PACK) {
+                        const int64_t slot = (p_begin + pt) * I + (I - 1 - n_done);
+                        x[slot * 3 + 0] = x_l[0]; x[slot * 3 + 1] = x_l[1]; x[slot * 3 + 2] = x_l[2];
+                        slot_init[slot] = (uint8_t)init;
+                        n_done++;
+                    } else {
+                        x[index * 3 + 0] = x_l[0]; x[index * 3 + 1] = x_l[1]; x[index * 3 + 2] = x_l[2];
+                    }
                     if (J_inv) {
                         float* Jo = J_inv + index * 9;
 #pragma unroll
@@ -660,14 +681,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
                 next = true;
                 continue;
             } else if (norm_gx > dvg2) {
-                is_valid[index] = 0;
+                if (!PACK) is_valid[index] = 0;
                 next = true;
                 continue;
             }
             J_inv_update(Ji, u[0], u[1], u[2], gn[0] - gx[0], gn[1] - gx[1], gn[2] - gx[2]);
             gx[0] = gn[0]; gx[1] = gn[1]; gx[2] = gn[2];
             it++;
-            if (it >= 10) { is_valid[index] = 0; next = true; continue; }       // not converged
+            if (it >= 10) { if (!PACK) is_valid[index] = 0; next = true; continue; }       // not converged
         }
         // step: update = -J_inv g, x += update
         u[0] = -Ji[0] * gx[0] + -Ji[1] * gx[1] + -Ji[2] * gx[2];
@@ -681,7 +702,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
             const float d = fmaxf(fmaxf(fabsf(x_l[0] - root[r][0]), fabsf(x_l[1] - root[r][1])), fabsf(x_l[2] - root[r][2]));
             near = near || (r < n_roots && d < eps);
         }
-        if (near) { is_valid[index] = 0; if (COUNT) c_retired++; next = true; }
+        if (near) { if (!PACK) is_valid[index] = 0; if (COUNT) c_retired++; next = true; }
     }
     if (COUNT) {
 #pragma unroll
@@ -697,6 +718,60 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
             atomicAdd(&counters[3], (unsigned long long)c_unrec);
             atomicAdd(&counters[4], (unsigned long long)c_corner);
         }
+    }
+}
+
+// ---- candidate rows of the PACK search -> packed candidate list ------------------------------------------------------------
+// rows_fix: a row with more than SPEC_ROOTS candidates was searched with some roots unrecorded, so its later searches were only
+// tested against the first SPEC_ROOTS: run K9 (filter.cu:10-54: drop a candidate when a LATER one lies within 1e-4) on the row,
+// keep the survivors packed at the row's end in ascending init order.  One lane per point; practically never taken.
+__global__ __launch_bounds__(THREADS) void rows_fix_kernel(int64_t N, int I, float* __restrict__ x, int32_t* __restrict__ cnt,
+                                                            uint8_t* __restrict__ slot_init)
+{
+    const int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (p >= N) return;
+    const int c = cnt[p];
+    if (c <= SPEC_ROOTS) return;
+    float* row = x + p * I * 3;
+    uint8_t* ini = slot_init + p * I;
+    float cx[16][3];                                        // the row's candidates, ascending init (slots I-c .. I-1); I <= 16
+    uint8_t ci[16];
+    for (int m = 0; m < c; m++) {
+        const int sl = I - c + m;
+        cx[m][0] = row[sl * 3]; cx[m][1] = row[sl * 3 + 1]; cx[m][2] = row[sl * 3 + 2]; ci[m] = ini[sl];
+    }
+    int kept = 0;
+    bool keep[16];
+    for (int m = 0; m < c; m++) {
+        bool k = true;
+        for (int j = m + 1; j < c && k; j++) {               // K9 tests against the UNFILTERED later candidates
+            const float d0 = cx[m][0] - cx[j][0], d1 = cx[m][1] - cx[j][1], d2 = cx[m][2] - cx[j][2];
+            const float dist = d0 * d0 + d1 * d1 + d2 * d2;
+            if ((double)dist < 0.0001 * 0.0001) k = false;
+        }
+        keep[m] = k;
+        kept += k ? 1 : 0;
+    }
+    int w = I - kept;
+    for (int m = 0; m < c; m++)
+        if (keep[m]) { row[w * 3] = cx[m][0]; row[w * 3 + 1] = cx[m][1]; row[w * 3 + 2] = cx[m][2]; ini[w] = ci[m]; w++; }
+    cnt[p] = kept;
+}
+
+__global__ __launch_bounds__(THREADS) void rows_pack_kernel(int64_t N, int I, const float* __restrict__ x, const int32_t* __restrict__ cnt,
+                                                             const uint8_t* __restrict__ slot_init, const int32_t* __restrict__ start,
+                                                             float* __restrict__ cand_x, int32_t* __restrict__ cand_src)
+{
+    const int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (p >= N) return;
+    const int c = cnt[p];
+    const int64_t q0 = start[p];
+    for (int k = 0; k < c; k++) {
+        const int64_t slot = p * I + (I - c + k);
+        cand_x[(q0 + k) * 3 + 0] = x[slot * 3 + 0];
+        cand_x[(q0 + k) * 3 + 1] = x[slot * 3 + 1];
+        cand_x[(q0 + k) * 3 + 2] = x[slot * 3 + 2];
+        if (cand_src) cand_src[q0 + k] = (int32_t)(p * I + slot_init[slot]);
     }
 }
 
@@ -968,28 +1043,71 @@ IA_EXPORT int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt, cons
     return ia::check_launch("ia_fuse_broyden");
 }
 
-IA_EXPORT int ia_fuse_broyden_spec(int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
-                                   const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold,
-                                   float dvg_threshold, float eps, float* x, float* J_inv, uint8_t* is_valid, float* fwd_J,
-                                   uint64_t* counters, ia_stream_t stream)
+static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
+                       const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold, float dvg_threshold, float eps,
+                       float* x, float* J_inv, uint8_t* is_valid, float* fwd_J, uint64_t* counters, int32_t* cnt, uint8_t* slot_init,
+                       ia_stream_t stream, const char* what)
 {
     if (N == 0) return IA_OK;
-    IA_REQUIRE(I >= 1 && I <= 16, "ia_fuse_broyden_spec: 1 <= I <= 16 inits");
-    IA_REQUIRE(eps >= 0.0f, "ia_fuse_broyden_spec: eps must be >= 0");
+    IA_REQUIRE(I >= 1 && I <= 16, "speculative search: 1 <= I <= 16 inits");
+    IA_REQUIRE(eps >= 0.0f, "speculative search: eps must be >= 0");
     IA_REQUIRE((int64_t)D * H * W < ((int64_t)1 << 26), "voxel grid too large for 32-bit byte offsets (48 B per voxel)");
     int pts = 80;                                                        // points per wave (as many items as the exact schedule's chunk)
     if (const char* e = getenv("IA_BR_SPEC_PTS")) pts = atoi(e) > 0 ? atoi(e) : pts;
     const int64_t n_waves = (N + pts - 1) / pts;
     const int grid = ia::cdiv(n_waves * 64, THREADS);
-    if (counters)
-        broyden_spec_kernel<true><<<grid, THREADS, 0, (hipStream_t)stream>>>(
-            N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J,
-            pts, reinterpret_cast<unsigned long long*>(counters));
-    else
-        broyden_spec_kernel<false><<<grid, THREADS, 0, (hipStream_t)stream>>>(
-            N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J,
-            pts, nullptr);
-    return ia::check_launch("ia_fuse_broyden_spec");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* c = reinterpret_cast<unsigned long long*>(counters);
+#define IA_SPEC_LAUNCH(COUNT, PACK)                                                                                                    \
+    broyden_spec_kernel<COUNT, PACK><<<grid, THREADS, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,         \
+                                                               cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J, pts, c, cnt, \
+                                                               slot_init)
+    if (pack) { if (counters) IA_SPEC_LAUNCH(true, true); else IA_SPEC_LAUNCH(false, true); }
+    else { if (counters) IA_SPEC_LAUNCH(true, false); else IA_SPEC_LAUNCH(false, false); }
+#undef IA_SPEC_LAUNCH
+    return ia::check_launch(what);
+}
+
+IA_EXPORT int ia_fuse_broyden_spec(int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
+                                   const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold,
+                                   float dvg_threshold, float eps, float* x, float* J_inv, uint8_t* is_valid, float* fwd_J,
+                                   uint64_t* counters, ia_stream_t stream)
+{
+    return launch_spec(false, N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x, J_inv,
+                       is_valid, fwd_J, counters, nullptr, nullptr, stream, "ia_fuse_broyden_spec");
+}
+
+IA_EXPORT int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
+                                        const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold,
+                                        float dvg_threshold, float eps, float* x, float* J_inv, float* fwd_J, int32_t* cnt,
+                                        uint8_t* slot_init, uint64_t* counters, ia_stream_t stream)
+{
+    IA_REQUIRE(eps >= 1e-4f, "ia_fuse_broyden_spec_rows: eps must be >= 1e-4 (the completed searches are K9's survivors only then)");
+    return launch_spec(true, N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x, J_inv,
+                       nullptr, fwd_J, counters, cnt, slot_init, stream, "ia_fuse_broyden_spec_rows");
+}
+
+extern "C" int ia_exclusive_scan_i32(const int32_t* in, int32_t* out, int32_t* total, int64_t n, void* tmp, ia_stream_t stream);
+
+IA_EXPORT int ia_deform_rows_count(int64_t N, int I, float* x, int32_t* cnt, uint8_t* slot_init, int32_t* start, int32_t* total,
+                                   void* scan_tmp, ia_stream_t stream)
+{
+    if (N == 0) return IA_OK;
+    IA_REQUIRE(N * I < ((int64_t)1 << 31), "ia_deform_rows_count: N * I must stay below 2^31");
+    IA_REQUIRE(I >= 1 && I <= 16, "ia_deform_rows_count: 1 <= I <= 16");
+    rows_fix_kernel<<<ia::cdiv(N, THREADS), THREADS, 0, (hipStream_t)stream>>>(N, I, x, cnt, slot_init);
+    int r = ia::check_launch("ia_deform_rows_count");
+    if (r != IA_OK) return r;
+    return ia_exclusive_scan_i32(cnt, start, total, N, scan_tmp, stream);
+}
+
+IA_EXPORT int ia_deform_rows_pack(int64_t N, int I, const float* x, const int32_t* cnt, const uint8_t* slot_init, const int32_t* start,
+                                  float* cand_x, int32_t* cand_src, ia_stream_t stream)
+{
+    if (N == 0) return IA_OK;
+    IA_REQUIRE(cand_x != x, "ia_deform_rows_pack: cand_x must not alias x");
+    rows_pack_kernel<<<ia::cdiv(N, THREADS), THREADS, 0, (hipStream_t)stream>>>(N, I, x, cnt, slot_init, start, cand_x, cand_src);
+    return ia::check_launch("ia_deform_rows_pack");
 }
 
 IA_EXPORT int ia_filter(int64_t N, int I, const float* x, const uint8_t* mask, uint8_t* out, ia_stream_t stream)

@@ -149,6 +149,41 @@ class SNARFDeformer:
                                          L.ptr(tmp), st), "ia_deform_pack_tiles")
         return cand_x, cand_src, cnt, start, Q
 
+    SPEC_ROWS = os.environ.get("IA_BROYDEN_SPEC_ROWS", "1") == "1"
+
+    @torch.no_grad()
+    def _candidates(self, pts: Tensor, with_src: bool, want_fwd: bool = False, want_jinv: bool = False):
+        """search + candidate bookkeeping for P posed points -> (cand_x [Q,3], cand_src [Q] | None, cnt [P], start [P], Q, fwd_J, J_inv).
+        Large batches (speculative search, eps >= 1e-4): the search kernel itself leaves each point's surviving candidates in its
+        row of x plus their count (fast_snarf.fuse_broyden_spec_rows) -- no is_valid, no K9 pass; a scan and one segmented copy make
+        the packed list.  Otherwise: search() + _pack_candidates() (K9 + count + pack)."""
+        P, I = pts.shape[0], self.init_bones.shape[0]
+        dev = self.device
+        if not (self.SPEC_ROWS and self.spec_eps >= 1e-4 and P >= self.SPEC_MIN_POINTS and self.tfs.shape[0] == 1):
+            r = self.search(pts, want_fwd=want_fwd, want_jinv=want_jinv)
+            x, valid, fwd = r[0], r[1], r[2]
+            J_inv = r[3] if want_jinv else None
+            return (*self._pack_candidates(x, valid, with_src=with_src), fwd, J_inv)
+        lib, st = L.lib(), L.stream()
+        x = torch.empty((1, P, I, 3), device=dev)
+        Jinv = torch.empty((1, P, I, 3, 3), device=dev) if want_jinv else None
+        fwd = torch.empty((1, P, I, 3, 3), device=dev) if want_fwd else None
+        cnt = torch.empty(P, dtype=torch.int32, device=dev)
+        slot_init = torch.empty((P, I), dtype=torch.uint8, device=dev)
+        fast_snarf.fuse_broyden_spec_rows(x, pts.reshape(1, P, 3), fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs, self.init_bones,
+                                          Jinv, cnt, slot_init, self.offset_kernel, self.scale_kernel, 1e-5, 1e-1, self.spec_eps, fwd_J=fwd,
+                                          counters=self.spec_counters)
+        start = torch.empty(P, dtype=torch.int32, device=dev)
+        total = torch.empty(1, dtype=torch.int32, device=dev)
+        L.check(lib.ia_deform_rows_count(L.i64(P), L.i32(I), L.ptr(x), L.ptr(cnt), L.ptr(slot_init), L.ptr(start), L.ptr(total),
+                                         L.ptr(L.scan_tmp(P, dev)), st), "ia_deform_rows_count")
+        Q = int(total.item())
+        cand_x = torch.empty((Q, 3), device=dev)
+        cand_src = torch.empty(Q, dtype=torch.int32, device=dev) if with_src else None
+        L.check(lib.ia_deform_rows_pack(L.i64(P), L.i32(I), L.ptr(x), L.ptr(cnt), L.ptr(slot_init), L.ptr(start), L.ptr(cand_x),
+                                        L.ptr(cand_src), st), "ia_deform_rows_pack")
+        return cand_x, cand_src, cnt, start, Q, (fwd[0] if want_fwd else None), (Jinv[0] if want_jinv else None)
+
     @torch.no_grad()
     def deform_sdf(self, pts: Tensor, geometry, order: Optional[Tensor] = None) -> Tensor:
         """SDF at posed points, nothing else: SNARFDeformer.deform with with_grad = with_feature = False as the no-grad coarse
@@ -158,8 +193,7 @@ class SNARFDeformer:
         P, I = pts.shape[0], self.init_bones.shape[0]
         dev = self.device
         lib, st = L.lib(), L.stream()
-        x, valid, _ = self.search(pts)
-        cand_x, _, cnt, start, Q = self._pack_candidates(x, valid, with_src=False)
+        cand_x, _, cnt, start, Q, _, _ = self._candidates(pts, with_src=False)
         csdf = geometry.sdf_only(cand_x)
         sdf = torch.empty(P, device=dev)
         if order is not None:         # pts = caller's points[order]: the result goes back to the caller's order on the way out
@@ -178,12 +212,7 @@ class SNARFDeformer:
         P, I = pts.shape[0], self.init_bones.shape[0]
         dev = self.device
         lib, st = L.lib(), L.stream()
-        J_inv = None
-        if want_jinv:
-            x, valid, fwd, J_inv = self.search(pts, want_fwd=with_grad or want_fwd, want_jinv=True)
-        else:
-            x, valid, fwd = self.search(pts, want_fwd=with_grad or want_fwd)
-        cand_x, cand_src, cnt, start, Q = self._pack_candidates(x, valid, with_src=True)
+        cand_x, cand_src, cnt, start, Q, fwd, J_inv = self._candidates(pts, with_src=True, want_fwd=with_grad or want_fwd, want_jinv=want_jinv)
         # SDF network on the packed candidates
         cg = None
         r = geometry(cand_x, with_grad=with_grad, with_feature=True)      # feature[:, 0] is the SDF
