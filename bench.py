@@ -67,7 +67,7 @@ def algorithmic_bytes(name, calls, extra=None):
         # = in-range corner loads of the step), 13 B out (x + valid; +36 B each for J_inv / fwd_J when requested).
         tot = 0
         for _, u, ex in calls:
-            tot += u * ex["I"] * (12 + 64 + 13 + (36 if ex["J_inv"] else 0) + (36 if ex["fwd_J"] else 0))
+            tot += u * ex["I"] * (12 + 64 + 13 + (36 if ex["J_inv"] else 0) + (36 if ex["fwd_J"] else 0))      # SURVEY 8(d) row (per item)
         return tot + (extra or 0) * 48
     if name in ("ia_hashgrid_fwd", "ia_hashgrid_fwd_xcd"):
         return n * (12 + 1024 + 128)             # 12 B in + 16 levels x 8 corners x 8 B gathered + 128 B out
@@ -394,8 +394,8 @@ def main():
                 c = bro
                 sec = dms / k_instr * 1e-3
                 items = max(c[2] + c[3] + c[4] + c[5] + c[6], 1)
-                comp = sum(u * (12 + ex["I"] * (13 + (36 if ex["J_inv"] else 0) + (36 if ex["fwd_J"] else 0))) + VOXEL_J_BYTES
-                           for _, u, ex in detail[dname]) / k_instr
+                comp = sum(u * (12 + (48 if ex.get("rows") else ex["I"] * 13) + ex["I"] * ((36 if ex["J_inv"] else 0) + (36 if ex["fwd_J"] else 0)))
+                           + VOXEL_J_BYTES for _, u, ex in detail[dname]) / k_instr
                 l1_bytes = c[1] * 48.0
                 l1_rate = l1_bytes / sec / 1e9
                 hbm_side = None
@@ -530,8 +530,8 @@ def count_broyden_fetches(step, dev, dfm):
         orig_spec(x, xd_tgt, voxel_J, tfs, bone_ids, J_inv, is_valid, offset, scale, cvg, dvg, eps, fwd_J=fwd_J, counters=spec)
         stats(xd_tgt, voxel_J, tfs, bone_ids, offset, scale, cvg, dvg, cnt_x)
         n_spec_items[0] += xd_tgt.shape[1] * bone_ids.shape[0]
-    def wrapped_rows(x, xd_tgt, voxel_J, tfs, bone_ids, J_inv, cnt_, slot_init, offset, scale, cvg, dvg, eps, fwd_J=None, counters=None):
-        orig_rows(x, xd_tgt, voxel_J, tfs, bone_ids, J_inv, cnt_, slot_init, offset, scale, cvg, dvg, eps, fwd_J=fwd_J, counters=spec)
+    def wrapped_rows(x, xd_tgt, voxel_J, tfs, bone_ids, J_inv, cnt_, meta, start, tot, offset, scale, cvg, dvg, eps, fwd_J=None, counters=None):
+        orig_rows(x, xd_tgt, voxel_J, tfs, bone_ids, J_inv, cnt_, meta, start, tot, offset, scale, cvg, dvg, eps, fwd_J=fwd_J, counters=spec)
         stats(xd_tgt, voxel_J, tfs, bone_ids, offset, scale, cvg, dvg, cnt_x)
         n_spec_items[0] += xd_tgt.shape[1] * bone_ids.shape[0]
     fast_snarf.fuse_broyden, fast_snarf.fuse_broyden_spec, fast_snarf.fuse_broyden_spec_rows = wrapped, wrapped_spec, wrapped_rows

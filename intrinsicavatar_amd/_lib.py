@@ -20,7 +20,7 @@ class IaError(RuntimeError):
 # optional outputs that change an entry point's compulsory traffic: ia_fuse_broyden(..., x, J_inv, is_valid, fwd_J, stream)
 _EXTRAS = {"ia_fuse_broyden": lambda a: dict(I=int(a[2].value), J_inv=bool(a[16].value), fwd_J=bool(a[18].value)),
            "ia_fuse_broyden_spec": lambda a: dict(I=int(a[1].value), J_inv=bool(a[15].value), fwd_J=bool(a[17].value)),
-           "ia_fuse_broyden_spec_rows": lambda a: dict(I=int(a[1].value), J_inv=bool(a[15].value), fwd_J=bool(a[16].value))}
+           "ia_fuse_broyden_spec_rows": lambda a: dict(I=int(a[1].value), J_inv=bool(a[15].value), fwd_J=bool(a[16].value), rows=True)}
 
 
 class _Timed:
@@ -34,7 +34,7 @@ class _Timed:
 
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
-        if not name.startswith("ia_") or name in ("ia_last_error", "ia_scan_tmp_bytes", "ia_version", "ia_hashgrid_n_entries", "ia_traverse_scratch_bytes", "ia_occgrid_tmp_bytes", "ia_hashgrid_bwd_scratch_bytes", "ia_traverse_fused_scratch_bytes", "ia_hashgrid_fwd_scratch_bytes", "ia_eikonal_partials"):
+        if not name.startswith("ia_") or name in ("ia_last_error", "ia_scan_tmp_bytes", "ia_version", "ia_hashgrid_n_entries", "ia_traverse_scratch_bytes", "ia_occgrid_tmp_bytes", "ia_hashgrid_bwd_scratch_bytes", "ia_traverse_fused_scratch_bytes", "ia_hashgrid_fwd_scratch_bytes", "ia_eikonal_partials", "ia_spec_rows_slots"):
             return fn
 
         def call(*args):

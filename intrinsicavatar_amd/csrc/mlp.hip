@@ -21,6 +21,8 @@
 //     for both operand patterns;
 //   * SDF head: g_z = softplus'(z) * W2[0,:], g_h = g_z W1 (one more MFMA GEMM), then a per-point
 //     epilogue contracts g_h with the hash-grid Jacobian (d enc / d x) -> analytic gradient.
+#include <stdlib.h>
+
 #include "mlp_tile.h"
 
 namespace {
@@ -341,6 +343,173 @@ int launch_fwd(const MlpArgs& a, hipStream_t s)
     return ia::check_launch("ia_mlp_fwd");
 }
 
+
+// ---- SDF value head, software-pipelined (ia_sdf_levels_fwd) ---------------------------------------------------------------
+// 35 -> 64 (Softplus beta=100) -> 1 on the level-major hash features.  mlp_fwd_kernel<3, ..., OUT = 1> spends a 32-point tile
+// as  [layer-1 MFMAs: 36 x 64 clk on the matrix pipe] THEN [Softplus + operand staging: ~1200 VALU instructions] THEN
+// [a 16-wide output-layer MFMA tile for ONE output column]; counters showed the VALU pipes 57 % + the matrix pipe 40 % busy =
+// 97 % of the launch -- the two halves ran back to back, never together (profiles/r02: 0.30-0.35 of the fp32 MFMA peak).
+// Here ONE wave carries TWO tiles in flight: the layer-1 MFMAs of tile t+1 are issued in the SAME instruction stream as the
+// Softplus of tile t (independent registers: the MFMA executes on the matrix pipe while the wave goes on issuing VALU work;
+// sched_group_barrier pins the 1 MFMA : ~14 VALU interleave), the output layer is a dot product done where the activations are
+// (lane-partial FMAs + one LDS transpose-reduce per tile: no 16x16x4 tile for one column, no activation round trip through
+// LDS), and the global loads of tile t+2 are in flight behind both.
+constexpr int SH_WAVES = 12;
+constexpr int SH_LDX = 37;              // 36 input columns (32 hash features | xyz | pad) + 1: odd row stride
+constexpr int SH_LDW = 37;
+
+struct ShRows { float2 q[8]; float v[2]; };
+
+__device__ __forceinline__ void sh_load(ShRows& r, const float2* __restrict__ lv, int64_t ls, const float* __restrict__ xp, int64_t p0,
+                                        int64_t n, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int i = j * 64 + lane, lvl = i >> 5, row = i & 31;
+        r.q[j] = (p0 + row < n) ? lv[(int64_t)lvl * ls + p0 + row] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {                                     // 32 rows x 3 xyz = 96 scalars
+        const int i = j * 64 + lane;
+        const int64_t p = p0 + i / 3;
+        r.v[j] = (i < 96 && p < n) ? xp[p0 * 3 + i] : 0.5f;
+    }
+}
+
+__device__ __forceinline__ void sh_store(const ShRows& r, float* __restrict__ sT, int64_t p0, int64_t n, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int i = j * 64 + lane, lvl = i >> 5, row = i & 31;
+        sT[row * SH_LDX + 2 * lvl] = r.q[j].x; sT[row * SH_LDX + 2 * lvl + 1] = r.q[j].y;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int i = j * 64 + lane;
+        if (i < 96) { const int row = i / 3, c = i - row * 3; sT[row * SH_LDX + 32 + c] = (p0 + row < n) ? r.v[j] * 2.0f - 1.0f : 0.0f; }
+    }
+    if (lane < 32) sT[lane * SH_LDX + 35] = 0.0f;
+}
+
+// value-only Softplus(beta = 100) times an output weight, straight-line: 6 full-rate instructions + exp2 + log2 (56 clk per
+// wave-activation, under the 64 clk of the 32x32x2 MFMA it hides behind).  b100 = 100 * bias, w001 = 0.01 * weight.
+//   softplus(z) = (max(bx, 0) + log(1 + exp(-|bx|))) / 100,  bx = 100 z.
+// Against torch.nn.Softplus(beta=100, threshold=20) (models/network_utils.py:240): no pass-through above the threshold (there
+// exp(-bx) < 2.1e-9 and the formula returns z to within 2 ulp), and log1p as log(1 + e) (absolute error <= 6e-8 in the
+// logarithm = 6e-10 in the activation; the SDF sums 64 of them with weights O(1): far inside the head's 5e-6 tolerance).
+__device__ __forceinline__ float softplus100_times(float acc, float b100, float w001, float part)
+{
+    const float bx = fmaf(acc, 100.0f, b100);
+    const float e = __builtin_amdgcn_exp2f(-fabsf(bx) * 1.44269504088896340736f);      // exp(-|bx|) in (0, 1]
+    const float lg2 = __builtin_amdgcn_logf(1.0f + e);                                  // log2(1 + e)
+    return fmaf(fmaf(lg2, 0.69314718055994530942f, fmaxf(bx, 0.0f)), w001, part);
+}
+
+__global__ __launch_bounds__(SH_WAVES * 64) void sdf_head_pipelined_kernel(int64_t n, const float2* __restrict__ levels,
+                                                                           const float* __restrict__ xp, const float* __restrict__ W1,
+                                                                           const float* __restrict__ b1, const float* __restrict__ Wo,
+                                                                           const float* __restrict__ bo, float* __restrict__ sdf)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sW1 = smem;                                           // [64][SH_LDW], columns 35 (pad) zero
+    float* sXall = sW1 + 64 * SH_LDW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* const sX0 = sXall + wave * 2 * 32 * SH_LDX;            // this wave's two row buffers: sX0 + b * 32 * SH_LDX
+    for (int i = tid; i < 64 * SH_LDW; i += SH_WAVES * 64) {
+        const int r = i / SH_LDW, c = i % SH_LDW;
+        sW1[i] = (c < 35) ? W1[r * 35 + c] : 0.0f;
+    }
+    __syncthreads();
+    const int lr = lane & 31, lk = lane >> 5;
+    const float w0 = 0.01f * Wo[lr], w1 = 0.01f * Wo[32 + lr], bb0 = 100.0f * b1[lr], bb1 = 100.0f * b1[32 + lr], bout = bo[0];
+    const int64_t n_tiles = (n + 31) / 32;
+    const int64_t stride = (int64_t)gridDim.x * SH_WAVES;
+    int64_t tile = (int64_t)blockIdx.x * SH_WAVES + wave;
+    if (tile >= n_tiles) return;
+
+    f32x16 accA0, accA1, accB0, accB1;
+    ShRows rows;
+    // prologue: tile 0 of this wave -> LDS buffer 0 -> layer 1 -> accA; tile 1 -> LDS buffer 1; tile 2 -> registers
+    sh_load(rows, levels, n, xp, tile * 32, n, lane);
+    sh_store(rows, sX0, tile * 32, n, lane);
+    if (tile + stride < n_tiles) sh_load(rows, levels, n, xp, (tile + stride) * 32, n, lane);
+#pragma unroll
+    for (int r = 0; r < 16; r++) { accA0[r] = 0.f; accA1[r] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < 18; kk++) {
+        const int k = 2 * kk + lk;
+        const float a = sX0[lr * SH_LDX + k], b0 = sW1[lr * SH_LDW + k], b1v = sW1[(32 + lr) * SH_LDW + k];
+        accA0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, accA0, 0, 0, 0);
+        accA1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1v, accA1, 0, 0, 0);
+    }
+    if (tile + stride < n_tiles) sh_store(rows, sX0 + 32 * SH_LDX, (tile + stride) * 32, n, lane);
+    int cur = 0;                                                  // LDS buffer holding the CONSUMED rows of `tile` (free for the reduce)
+    for (;; tile += stride) {
+        const bool have_next = tile + stride < n_tiles;           // its rows are in sXb[cur ^ 1]
+        const bool have_next2 = tile + 2 * stride < n_tiles;
+        if (have_next2) sh_load(rows, levels, n, xp, (tile + 2 * stride) * 32, n, lane);      // in flight behind everything below
+        float part[16];
+        const float* sN = sX0 + (cur ^ 1) * 32 * SH_LDX;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { accB0[r] = 0.f; accB1[r] = 0.f; }
+        if (have_next) {
+            float an = sN[lr * SH_LDX + lk], b0n = sW1[lr * SH_LDW + lk], b1n = sW1[(32 + lr) * SH_LDW + lk];
+#pragma unroll
+            for (int kk = 0; kk < 18; kk++) {
+                const float a = an, b0 = b0n, b1v = b1n;
+                if (kk + 1 < 18) {
+                    const int k = 2 * (kk + 1) + lk;
+                    an = sN[lr * SH_LDX + k]; b0n = sW1[lr * SH_LDW + k]; b1n = sW1[(32 + lr) * SH_LDW + k];
+                }
+                accB0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, accB0, 0, 0, 0);
+                if (kk < 16) part[kk] = softplus100_times(accA0[kk], bb0, w0, 0.0f);       // Softplus of tile t under the MFMAs of tile t+1
+                accB1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1v, accB1, 0, 0, 0);
+                if (kk < 16) part[kk] = softplus100_times(accA1[kk], bb1, w1, part[kk]);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);       // one activation of VALU work
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);       // the next k-step's operands
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                part[r] = softplus100_times(accA1[r], bb1, w1, softplus100_times(accA0[r], bb0, w0, 0.0f));
+        }
+        // output layer: out[row] = bo + sum over the 64 hidden units; this lane holds the partial of (row(r, lk), columns lr, 32 + lr)
+        float* sR = sX0 + cur * 32 * SH_LDX;                      // [32 rows][32 partials], row stride SH_LDX
+#pragma unroll
+        for (int r = 0; r < 16; r++) sR[((r & 3) + 8 * (r >> 2) + 4 * lk) * SH_LDX + lr] = part[r];
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) sum += sR[lr * SH_LDX + lk * 16 + j];
+        sum += __shfl_xor(sum, 32, 64);
+        const int64_t p = tile * 32 + lr;
+        if (lk == 0 && p < n) sdf[p] = sum + bout;
+        if (!have_next) break;
+        if (have_next2) sh_store(rows, sR, (tile + 2 * stride) * 32, n, lane);          // over the reduce scratch: same wave, in order
+        accA0 = accB0; accA1 = accB1;
+        cur ^= 1;
+    }
+}
+
+static int launch_sdf_head_pipelined(int64_t n, const void* levels, const float* xp, const float* W1, const float* b1, const float* Wo,
+                                     const float* bo, float* sdf, hipStream_t s)
+{
+    constexpr size_t lds = sizeof(float) * (64 * SH_LDW + SH_WAVES * 2 * 32 * SH_LDX);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)sdf_head_pipelined_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int64_t n_tiles = (n + 31) / 32;
+    int grid = (int)((n_tiles + SH_WAVES - 1) / SH_WAVES);
+    if (grid > 256) grid = 256;
+    sdf_head_pipelined_kernel<<<grid, SH_WAVES * 64, lds, s>>>(n, reinterpret_cast<const float2*>(levels), xp, W1, b1, Wo, bo, sdf);
+    return ia::check_launch("ia_sdf_levels_fwd");
+}
+
 }  // namespace
 
 // kind: 0 = SDF 35->64->13 softplus100 (optionally with analytic gradient)
@@ -387,6 +556,10 @@ IA_EXPORT int ia_sdf_levels_fwd(int64_t n, const void* levels, const float* xp, 
 {
     if (n == 0) return IA_OK;
     IA_REQUIRE(n < ((int64_t)1 << 31), "ia_sdf_levels_fwd: at most 2^31 points per call");
+    {
+        const char* e = getenv("IA_SDF_HEAD");                       // "tile": the one-tile-per-wave kernel (A / B)
+        if (!(e && e[0] == 't')) return launch_sdf_head_pipelined(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
+    }
     MlpArgs a = {};
     a.n = n;
     a.n_segs = 2;

@@ -529,11 +529,11 @@ constexpr int SPEC_ROOTS = 3;      // recorded roots per point (survivors per po
 
 // PACK: the candidate bookkeeping of the caller done here.  With eps >= 1e-4 every search that COMPLETES valid is farther than
 // eps (inf-norm, so farther than K9's 1e-4 in L2) from every root recorded before it -- the completed items ARE K9's
-// survivors as long as a point has at most SPEC_ROOTS of them.  So instead of is_valid [N,I] for a filter pass, the k-th completed
-// search of a point (k = 0 is its highest init) stores its root in slot I-1-k of the point's row of x and its init in
-// slot_init, and the lane leaves cnt[point]: the row's last cnt slots hold the candidates in ascending init order
-// (ia_deform_rows_count / ia_deform_rows_pack turn that into the packed list; rows with more than SPEC_ROOTS candidates --
-// none in 18 M points of the headline distribution -- go through K9 there).
+// survivors as long as a point has at most SPEC_ROOTS of them.  So instead of x [N,I,3] + is_valid [N,I] for a filter pass, the
+// k-th completed search of a point (k = 0 is its highest init) stores its root in x [N, SPEC_ROOTS, 3] slot k, and the lane
+// leaves cnt[point] and meta[point] = the inits of slots 0..2 in bytes 0..2: 44 bytes per point instead of 169.  A point that
+// completes a (SPEC_ROOTS+1)-th search (none in 18 M points of the headline distribution) raises *overflow: the caller then
+// redoes the batch with the is_valid + K9 path (ia_deform_rows_pack turns rows into the packed list).
 template <bool COUNT, bool PACK>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES, IA_BR2_WAVES))) void broyden_spec_kernel(
     int64_t N, int I, const float* __restrict__ xd_tgt, const float* __restrict__ voxel_J, int D, int H, int W,
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
     const float* __restrict__ scale_g, float cvg_threshold, float dvg_threshold, float eps, float* __restrict__ x,
     float* __restrict__ J_inv, uint8_t* __restrict__ is_valid, float* __restrict__ fwd_J, int pts_per_wave,
     unsigned long long* __restrict__ counters /* NULL or [5]: fetches, retired items, completed valid items, unrecorded roots, in-range corner loads */,
-    int32_t* __restrict__ cnt /* PACK: [N] */, uint8_t* __restrict__ slot_init /* PACK: [N,I] */)
+    int32_t* __restrict__ cnt /* PACK: [N] */, uint32_t* __restrict__ meta /* PACK: [N] */, int32_t* __restrict__ overflow /* PACK: [1] */)
 {
     __shared__ float s_T[16 * 12];                     // per init: rows 0..2 of its bone's 4x4 (R | t)
     for (int t = threadIdx.x; t < I * 12; t += THREADS) s_T[t] = tfs[(int64_t)bone_ids[t / 12] * 16 + (t % 12)];
@@ -563,6 +563,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
     int it = -1;                  // -1: waiting for the initial fetch
     int n_roots = 0;
     int n_done = 0;               // PACK: searches of the lane's point that completed valid
+    unsigned inits = 0;           // PACK: their inits, one byte each
     float xt[3] = {0, 0, 0}, x_l[3] = {0, 0, 0}, gx[3] = {0, 0, 0}, u[3] = {0, 0, 0};
     float Ji[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     float root[SPEC_ROOTS][3];
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
             if (init > 0) { init--; it = -1; }
             else {
                 have = false;
-                if (PACK) cnt[p_begin + pt] = n_done;
+                if (PACK) { cnt[p_begin + pt] = n_done; meta[p_begin + pt] = inits; }
             }
         }
         const unsigned long long need = __ballot(!have);
@@ -592,6 +593,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
                     it = -1;
                     n_roots = 0;
                     n_done = 0;
+                    inits = 0;
                     xt[0] = xd_tgt[(p_begin + c) * 3 + 0];
                     xt[1] = xd_tgt[(p_begin + c) * 3 + 1];
                     xt[2] = xd_tgt[(p_begin + c) * 3 + 2];
@@ -652,10 +654,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
                 if (!PACK) is_valid[index] = ok ? 1 : 0;
                 if (ok) {
                     if (PACK) {
-                        const int64_t slot = (p_begin + pt) * I + (I - 1 - n_done);
-                        x[slot * 3 + 0] = x_l[0]; x[slot * 3 + 1] = x_l[1]; x[slot * 3 + 2] = x_l[2];
-                        slot_init[slot] = (uint8_t)init;
-                        n_done++;
+                        if (n_done < SPEC_ROOTS) {
+                            const int64_t slot = (p_begin + pt) * SPEC_ROOTS + n_done;
+                            x[slot * 3 + 0] = x_l[0]; x[slot * 3 + 1] = x_l[1]; x[slot * 3 + 2] = x_l[2];
+                            inits |= (unsigned)init << (8 * n_done);
+                            n_done++;
+                        } else {
+                            *overflow = 1;                                  // a 4th candidate: the rows cannot hold it (benign race: all writers store 1)
+                        }
                     } else {
                         x[index * 3 + 0] = x_l[0]; x[index * 3 + 1] = x_l[1]; x[index * 3 + 2] = x_l[2];
                     }
@@ -722,56 +728,24 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
 }
 
 // ---- candidate rows of the PACK search -> packed candidate list ------------------------------------------------------------
-// rows_fix: a row with more than SPEC_ROOTS candidates was searched with some roots unrecorded, so its later searches were only
-// tested against the first SPEC_ROOTS: run K9 (filter.cu:10-54: drop a candidate when a LATER one lies within 1e-4) on the row,
-// keep the survivors packed at the row's end in ascending init order.  One lane per point; practically never taken.
-__global__ __launch_bounds__(THREADS) void rows_fix_kernel(int64_t N, int I, float* __restrict__ x, int32_t* __restrict__ cnt,
-                                                            uint8_t* __restrict__ slot_init)
-{
-    const int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (p >= N) return;
-    const int c = cnt[p];
-    if (c <= SPEC_ROOTS) return;
-    float* row = x + p * I * 3;
-    uint8_t* ini = slot_init + p * I;
-    float cx[16][3];                                        // the row's candidates, ascending init (slots I-c .. I-1); I <= 16
-    uint8_t ci[16];
-    for (int m = 0; m < c; m++) {
-        const int sl = I - c + m;
-        cx[m][0] = row[sl * 3]; cx[m][1] = row[sl * 3 + 1]; cx[m][2] = row[sl * 3 + 2]; ci[m] = ini[sl];
-    }
-    int kept = 0;
-    bool keep[16];
-    for (int m = 0; m < c; m++) {
-        bool k = true;
-        for (int j = m + 1; j < c && k; j++) {               // K9 tests against the UNFILTERED later candidates
-            const float d0 = cx[m][0] - cx[j][0], d1 = cx[m][1] - cx[j][1], d2 = cx[m][2] - cx[j][2];
-            const float dist = d0 * d0 + d1 * d1 + d2 * d2;
-            if ((double)dist < 0.0001 * 0.0001) k = false;
-        }
-        keep[m] = k;
-        kept += k ? 1 : 0;
-    }
-    int w = I - kept;
-    for (int m = 0; m < c; m++)
-        if (keep[m]) { row[w * 3] = cx[m][0]; row[w * 3 + 1] = cx[m][1]; row[w * 3 + 2] = cx[m][2]; ini[w] = ci[m]; w++; }
-    cnt[p] = kept;
-}
-
+// one lane per point: the row's cnt candidates were stored highest init first; the packed list is in (point, ascending init) order
 __global__ __launch_bounds__(THREADS) void rows_pack_kernel(int64_t N, int I, const float* __restrict__ x, const int32_t* __restrict__ cnt,
-                                                             const uint8_t* __restrict__ slot_init, const int32_t* __restrict__ start,
+                                                             const uint32_t* __restrict__ meta, const int32_t* __restrict__ start,
                                                              float* __restrict__ cand_x, int32_t* __restrict__ cand_src)
 {
     const int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     if (p >= N) return;
     const int c = cnt[p];
+    if (c == 0) return;
     const int64_t q0 = start[p];
+    const unsigned m = cand_src ? meta[p] : 0u;
+    const float* row = x + p * (SPEC_ROOTS * 3);
     for (int k = 0; k < c; k++) {
-        const int64_t slot = p * I + (I - c + k);
-        cand_x[(q0 + k) * 3 + 0] = x[slot * 3 + 0];
-        cand_x[(q0 + k) * 3 + 1] = x[slot * 3 + 1];
-        cand_x[(q0 + k) * 3 + 2] = x[slot * 3 + 2];
-        if (cand_src) cand_src[q0 + k] = (int32_t)(p * I + slot_init[slot]);
+        const int slot = c - 1 - k;
+        cand_x[(q0 + k) * 3 + 0] = row[slot * 3 + 0];
+        cand_x[(q0 + k) * 3 + 1] = row[slot * 3 + 1];
+        cand_x[(q0 + k) * 3 + 2] = row[slot * 3 + 2];
+        if (cand_src) cand_src[q0 + k] = (int32_t)(p * I + ((m >> (8 * slot)) & 0xffu));
     }
 }
 
@@ -1045,8 +1019,8 @@ IA_EXPORT int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt, cons
 
 static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
                        const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold, float dvg_threshold, float eps,
-                       float* x, float* J_inv, uint8_t* is_valid, float* fwd_J, uint64_t* counters, int32_t* cnt, uint8_t* slot_init,
-                       ia_stream_t stream, const char* what)
+                       float* x, float* J_inv, uint8_t* is_valid, float* fwd_J, uint64_t* counters, int32_t* cnt, uint32_t* meta,
+                       int32_t* overflow, ia_stream_t stream, const char* what)
 {
     if (N == 0) return IA_OK;
     IA_REQUIRE(I >= 1 && I <= 16, "speculative search: 1 <= I <= 16 inits");
@@ -1061,7 +1035,7 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
 #define IA_SPEC_LAUNCH(COUNT, PACK)                                                                                                    \
     broyden_spec_kernel<COUNT, PACK><<<grid, THREADS, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,         \
                                                                cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J, pts, c, cnt, \
-                                                               slot_init)
+                                                               meta, overflow)
     if (pack) { if (counters) IA_SPEC_LAUNCH(true, true); else IA_SPEC_LAUNCH(false, true); }
     else { if (counters) IA_SPEC_LAUNCH(true, false); else IA_SPEC_LAUNCH(false, false); }
 #undef IA_SPEC_LAUNCH
@@ -1074,39 +1048,35 @@ IA_EXPORT int ia_fuse_broyden_spec(int64_t N, int I, const float* xd_tgt, const 
                                    uint64_t* counters, ia_stream_t stream)
 {
     return launch_spec(false, N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x, J_inv,
-                       is_valid, fwd_J, counters, nullptr, nullptr, stream, "ia_fuse_broyden_spec");
+                       is_valid, fwd_J, counters, nullptr, nullptr, nullptr, stream, "ia_fuse_broyden_spec");
 }
 
-IA_EXPORT int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
-                                        const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold,
-                                        float dvg_threshold, float eps, float* x, float* J_inv, float* fwd_J, int32_t* cnt,
-                                        uint8_t* slot_init, uint64_t* counters, ia_stream_t stream)
-{
-    IA_REQUIRE(eps >= 1e-4f, "ia_fuse_broyden_spec_rows: eps must be >= 1e-4 (the completed searches are K9's survivors only then)");
-    return launch_spec(true, N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x, J_inv,
-                       nullptr, fwd_J, counters, cnt, slot_init, stream, "ia_fuse_broyden_spec_rows");
-}
+IA_EXPORT int ia_spec_rows_slots(void) { return SPEC_ROOTS; }
 
 extern "C" int ia_exclusive_scan_i32(const int32_t* in, int32_t* out, int32_t* total, int64_t n, void* tmp, ia_stream_t stream);
 
-IA_EXPORT int ia_deform_rows_count(int64_t N, int I, float* x, int32_t* cnt, uint8_t* slot_init, int32_t* start, int32_t* total,
-                                   void* scan_tmp, ia_stream_t stream)
+IA_EXPORT int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
+                                        const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold,
+                                        float dvg_threshold, float eps, float* x_rows, float* J_inv, float* fwd_J, int32_t* cnt,
+                                        uint32_t* meta, int32_t* start, int32_t* total_and_overflow, void* scan_tmp, uint64_t* counters,
+                                        ia_stream_t stream)
 {
-    if (N == 0) return IA_OK;
-    IA_REQUIRE(N * I < ((int64_t)1 << 31), "ia_deform_rows_count: N * I must stay below 2^31");
-    IA_REQUIRE(I >= 1 && I <= 16, "ia_deform_rows_count: 1 <= I <= 16");
-    rows_fix_kernel<<<ia::cdiv(N, THREADS), THREADS, 0, (hipStream_t)stream>>>(N, I, x, cnt, slot_init);
-    int r = ia::check_launch("ia_deform_rows_count");
+    IA_REQUIRE(eps >= 1e-4f, "ia_fuse_broyden_spec_rows: eps must be >= 1e-4 (the completed searches are K9's survivors only then)");
+    IA_REQUIRE(N * I < ((int64_t)1 << 31), "ia_fuse_broyden_spec_rows: N * I must stay below 2^31");
+    if (N == 0) return ia_exclusive_scan_i32(nullptr, nullptr, total_and_overflow, 0, scan_tmp, stream);
+    (void)hipMemsetAsync(total_and_overflow + 1, 0, sizeof(int32_t), (hipStream_t)stream);
+    int r = launch_spec(true, N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x_rows,
+                        J_inv, nullptr, fwd_J, counters, cnt, meta, total_and_overflow + 1, stream, "ia_fuse_broyden_spec_rows");
     if (r != IA_OK) return r;
-    return ia_exclusive_scan_i32(cnt, start, total, N, scan_tmp, stream);
+    return ia_exclusive_scan_i32(cnt, start, total_and_overflow, N, scan_tmp, stream);
 }
 
-IA_EXPORT int ia_deform_rows_pack(int64_t N, int I, const float* x, const int32_t* cnt, const uint8_t* slot_init, const int32_t* start,
+IA_EXPORT int ia_deform_rows_pack(int64_t N, int I, const float* x_rows, const int32_t* cnt, const uint32_t* meta, const int32_t* start,
                                   float* cand_x, int32_t* cand_src, ia_stream_t stream)
 {
     if (N == 0) return IA_OK;
-    IA_REQUIRE(cand_x != x, "ia_deform_rows_pack: cand_x must not alias x");
-    rows_pack_kernel<<<ia::cdiv(N, THREADS), THREADS, 0, (hipStream_t)stream>>>(N, I, x, cnt, slot_init, start, cand_x, cand_src);
+    IA_REQUIRE(cand_x != x_rows, "ia_deform_rows_pack: cand_x must not alias x_rows");
+    rows_pack_kernel<<<ia::cdiv(N, THREADS), THREADS, 0, (hipStream_t)stream>>>(N, I, x_rows, cnt, meta, start, cand_x, cand_src);
     return ia::check_launch("ia_deform_rows_pack");
 }
 

@@ -155,8 +155,9 @@ class SNARFDeformer:
     def _candidates(self, pts: Tensor, with_src: bool, want_fwd: bool = False, want_jinv: bool = False):
         """search + candidate bookkeeping for P posed points -> (cand_x [Q,3], cand_src [Q] | None, cnt [P], start [P], Q, fwd_J, J_inv).
         Large batches (speculative search, eps >= 1e-4): the search kernel itself leaves each point's surviving candidates in its
-        row of x plus their count (fast_snarf.fuse_broyden_spec_rows) -- no is_valid, no K9 pass; a scan and one segmented copy make
-        the packed list.  Otherwise: search() + _pack_candidates() (K9 + count + pack)."""
+        3-slot row plus their count and the scan of the counts (fast_snarf.fuse_broyden_spec_rows: 44 B per point instead of 169) --
+        no x [P,13,3], no is_valid, no K9 pass; one segmented copy makes the packed list.  A batch in which some point has a 4th
+        distinct root falls back to the other path.  Otherwise: search() + _pack_candidates() (K9 + count + pack)."""
         P, I = pts.shape[0], self.init_bones.shape[0]
         dev = self.device
         if not (self.SPEC_ROWS and self.spec_eps >= 1e-4 and P >= self.SPEC_MIN_POINTS and self.tfs.shape[0] == 1):
@@ -165,22 +166,23 @@ class SNARFDeformer:
             J_inv = r[3] if want_jinv else None
             return (*self._pack_candidates(x, valid, with_src=with_src), fwd, J_inv)
         lib, st = L.lib(), L.stream()
-        x = torch.empty((1, P, I, 3), device=dev)
+        x_rows = torch.empty((P, 3, 3), device=dev)
         Jinv = torch.empty((1, P, I, 3, 3), device=dev) if want_jinv else None
         fwd = torch.empty((1, P, I, 3, 3), device=dev) if want_fwd else None
-        cnt = torch.empty(P, dtype=torch.int32, device=dev)
-        slot_init = torch.empty((P, I), dtype=torch.uint8, device=dev)
-        fast_snarf.fuse_broyden_spec_rows(x, pts.reshape(1, P, 3), fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs, self.init_bones,
-                                          Jinv, cnt, slot_init, self.offset_kernel, self.scale_kernel, 1e-5, 1e-1, self.spec_eps, fwd_J=fwd,
-                                          counters=self.spec_counters)
-        start = torch.empty(P, dtype=torch.int32, device=dev)
-        total = torch.empty(1, dtype=torch.int32, device=dev)
-        L.check(lib.ia_deform_rows_count(L.i64(P), L.i32(I), L.ptr(x), L.ptr(cnt), L.ptr(slot_init), L.ptr(start), L.ptr(total),
-                                         L.ptr(L.scan_tmp(P, dev)), st), "ia_deform_rows_count")
-        Q = int(total.item())
+        cnt, meta, start = (torch.empty(P, dtype=torch.int32, device=dev) for _ in range(3))
+        tot = torch.empty(2, dtype=torch.int32, device=dev)
+        fast_snarf.fuse_broyden_spec_rows(x_rows, pts.reshape(1, P, 3), fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs, self.init_bones,
+                                          Jinv, cnt, meta, start, tot, self.offset_kernel, self.scale_kernel, 1e-5, 1e-1, self.spec_eps,
+                                          fwd_J=fwd, counters=self.spec_counters)
+        Q, overflow = tot.tolist()                                   # the one read-back of the call
+        if overflow:
+            # some point has a 4th distinct root: the 3-slot rows cannot hold it -- this batch goes through is_valid + K9 instead
+            del x_rows, cnt, meta, start, Jinv, fwd
+            r = self.search(pts, want_fwd=want_fwd, want_jinv=want_jinv)
+            return (*self._pack_candidates(r[0], r[1], with_src=with_src), r[2], (r[3] if want_jinv else None))
         cand_x = torch.empty((Q, 3), device=dev)
         cand_src = torch.empty(Q, dtype=torch.int32, device=dev) if with_src else None
-        L.check(lib.ia_deform_rows_pack(L.i64(P), L.i32(I), L.ptr(x), L.ptr(cnt), L.ptr(slot_init), L.ptr(start), L.ptr(cand_x),
+        L.check(lib.ia_deform_rows_pack(L.i64(P), L.i32(I), L.ptr(x_rows), L.ptr(cnt), L.ptr(meta), L.ptr(start), L.ptr(cand_x),
                                         L.ptr(cand_src), st), "ia_deform_rows_pack")
         return cand_x, cand_src, cnt, start, Q, (fwd[0] if want_fwd else None), (Jinv[0] if want_jinv else None)
 
