@@ -194,18 +194,24 @@ int ia_fuse_broyden_spec(int64_t N, int I, const float* xd_tgt /*[N,3]*/, const 
  * snarf_deformer.py:187-196 on the product path).  With eps >= 1e-4 (required) a search that completes valid is farther than
  * K9's radius from every root recorded before it, so the completed searches of a point ARE K9's survivors as long as there are
  * at most ia_spec_rows_slots() (= 3) of them.  Outputs: x_rows [N, 3, 3]: the k-th completed search of a point (k = 0: its
- * highest init) stores its root in slot k; cnt [N]; meta [N]: the inits of slots 0..2 in bytes 0..2; start [N] = exclusive scan
- * of cnt; total_and_overflow [2]: [0] = Q, [1] = 1 iff some point completed a 4th search (the rows cannot represent it: redo the
- * batch with ia_fuse_broyden_spec + K9).  44 bytes per point leave the kernel instead of 169 (x [N,I,3] + is_valid).
- * J_inv / fwd_J (optional) are written at [point, init] as in ia_fuse_broyden.  scan_tmp: ia_scan_tmp_bytes(N) bytes.
+ * highest init) stores its root in slot k; cnt [N]; meta [N]: the inits of slots 0..2 in bytes 0..2 (bit 31: the point has
+ * overflow records); start [N] = exclusive scan of cnt.  A 4th, 5th ... completed search of a point (rare) becomes a record in
+ * ovf_scratch (ia_spec_rows_overflow_bytes() bytes; chained per point through ovf_head [N], which is written for such points
+ * only); K9 runs among a point's records and the kept ones count towards cnt.  total_and_overflow [2]: [0] = Q, [1] = number of
+ * overflow records -- above ia_spec_rows_overflow_capacity() records were lost: redo the batch with ia_fuse_broyden_spec + K9.
+ * 44 bytes per point leave the kernel instead of 169 (x [N,I,3] + is_valid).  J_inv / fwd_J (optional) are written at
+ * [point, init] as in ia_fuse_broyden.  scan_tmp: ia_scan_tmp_bytes(N) bytes.
  * ia_deform_rows_pack: cand_x [Q,3] (+ cand_src [Q] = point * I + init, optional) in (point, ascending init) order. */
 int ia_spec_rows_slots(void);
+size_t ia_spec_rows_overflow_bytes(void);
+int ia_spec_rows_overflow_capacity(void);
 int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
                               const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold,
                               float dvg_threshold, float eps, float* x_rows, float* J_inv, float* fwd_J, int32_t* cnt, uint32_t* meta,
-                              int32_t* start, int32_t* total_and_overflow, void* scan_tmp, uint64_t* counters, ia_stream_t stream);
+                              int32_t* start, int32_t* ovf_head, void* ovf_scratch, int32_t* total_and_overflow, void* scan_tmp,
+                              uint64_t* counters, ia_stream_t stream);
 int ia_deform_rows_pack(int64_t N, int I, const float* x_rows, const int32_t* cnt, const uint32_t* meta, const int32_t* start,
-                        float* cand_x, int32_t* cand_src /*or NULL*/, ia_stream_t stream);
+                        const int32_t* ovf_head, const void* ovf_scratch, float* cand_x, int32_t* cand_src /*or NULL*/, ia_stream_t stream);
 /* diagnostics (no reference counterpart): runs the searches of ia_fuse_broyden without outputs and ACCUMULATES into
  * counters[17] (caller-zeroed): [0] trilinear fetches, [1] in-range corner loads, [2] converged & in-box items,
  * [3] diverged, [4] out of iterations, [5+k] items that ended after k fetches (k = 2..11).  Used by bench.py to price the

@@ -354,7 +354,6 @@ int launch_fwd(const MlpArgs& a, hipStream_t s)
 // sched_group_barrier pins the 1 MFMA : ~14 VALU interleave), the output layer is a dot product done where the activations are
 // (lane-partial FMAs + one LDS transpose-reduce per tile: no 16x16x4 tile for one column, no activation round trip through
 // LDS), and the global loads of tile t+2 are in flight behind both.
-constexpr int SH_WAVES = 12;
 constexpr int SH_LDX = 37;              // 36 input columns (32 hash features | xyz | pad) + 1: odd row stride
 constexpr int SH_LDW = 37;
 
@@ -405,6 +404,7 @@ __device__ __forceinline__ float softplus100_times(float acc, float b100, float 
     return fmaf(fmaf(lg2, 0.69314718055994530942f, fmaxf(bx, 0.0f)), w001, part);
 }
 
+template <int SH_WAVES>
 __global__ __launch_bounds__(SH_WAVES * 64) void sdf_head_pipelined_kernel(int64_t n, const float2* __restrict__ levels,
                                                                            const float* __restrict__ xp, const float* __restrict__ W1,
                                                                            const float* __restrict__ b1, const float* __restrict__ Wo,
@@ -493,6 +493,7 @@ __global__ __launch_bounds__(SH_WAVES * 64) void sdf_head_pipelined_kernel(int64
     }
 }
 
+template <int SH_WAVES>
 static int launch_sdf_head_pipelined(int64_t n, const void* levels, const float* xp, const float* W1, const float* b1, const float* Wo,
                                      const float* bo, float* sdf, hipStream_t s)
 {
@@ -500,13 +501,13 @@ static int launch_sdf_head_pipelined(int64_t n, const void* levels, const float*
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)sdf_head_pipelined_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)sdf_head_pipelined_kernel<SH_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     const int64_t n_tiles = (n + 31) / 32;
     int grid = (int)((n_tiles + SH_WAVES - 1) / SH_WAVES);
     if (grid > 256) grid = 256;
-    sdf_head_pipelined_kernel<<<grid, SH_WAVES * 64, lds, s>>>(n, reinterpret_cast<const float2*>(levels), xp, W1, b1, Wo, bo, sdf);
+    sdf_head_pipelined_kernel<SH_WAVES><<<grid, SH_WAVES * 64, lds, s>>>(n, reinterpret_cast<const float2*>(levels), xp, W1, b1, Wo, bo, sdf);
     return ia::check_launch("ia_sdf_levels_fwd");
 }
 
@@ -557,8 +558,11 @@ IA_EXPORT int ia_sdf_levels_fwd(int64_t n, const void* levels, const float* xp, 
     if (n == 0) return IA_OK;
     IA_REQUIRE(n < ((int64_t)1 << 31), "ia_sdf_levels_fwd: at most 2^31 points per call");
     {
-        const char* e = getenv("IA_SDF_HEAD");                       // "tile": the one-tile-per-wave kernel (A / B)
-        if (!(e && e[0] == 't')) return launch_sdf_head_pipelined(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
+        const char* e = getenv("IA_SDF_HEAD");                       // "tile": the one-tile-per-wave kernel; "pipe12" / "pipe8": two tiles per wave
+        if (e && e[0] == 'p') {
+            if (e[4] == '8') return launch_sdf_head_pipelined<8>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
+            return launch_sdf_head_pipelined<12>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
+        }
     }
     MlpArgs a = {};
     a.n = n;

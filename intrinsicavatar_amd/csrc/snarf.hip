@@ -531,9 +531,12 @@ constexpr int SPEC_ROOTS = 3;      // recorded roots per point (survivors per po
 // eps (inf-norm, so farther than K9's 1e-4 in L2) from every root recorded before it -- the completed items ARE K9's
 // survivors as long as a point has at most SPEC_ROOTS of them.  So instead of x [N,I,3] + is_valid [N,I] for a filter pass, the
 // k-th completed search of a point (k = 0 is its highest init) stores its root in x [N, SPEC_ROOTS, 3] slot k, and the lane
-// leaves cnt[point] and meta[point] = the inits of slots 0..2 in bytes 0..2: 44 bytes per point instead of 169.  A point that
-// completes a (SPEC_ROOTS+1)-th search (none in 18 M points of the headline distribution) raises *overflow: the caller then
-// redoes the batch with the is_valid + K9 path (ia_deform_rows_pack turns rows into the packed list).
+// leaves cnt[point] and meta[point] = the inits of slots 0..2 in bytes 0..2: 44 bytes per point instead of 169.  The rare
+// (SPEC_ROOTS+1)-th, ... completed search of a point (it was only tested against the first SPEC_ROOTS roots) goes to a global
+// overflow list as a record (point, init, root, previous record of the same point); rows_extras_kernel runs K9 among the
+// records of a point (filter.cu:10-54: drop one when a LATER init's lies within 1e-4) and adds the kept ones to cnt, and
+// ia_deform_rows_pack emits them in front of the row's candidates (their inits are lower).  Only a full list (ovf_cap) makes the
+// caller redo the batch with the is_valid + K9 path.
 template <bool COUNT, bool PACK>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES, IA_BR2_WAVES))) void broyden_spec_kernel(
     int64_t N, int I, const float* __restrict__ xd_tgt, const float* __restrict__ voxel_J, int D, int H, int W,
@@ -541,7 +544,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
     const float* __restrict__ scale_g, float cvg_threshold, float dvg_threshold, float eps, float* __restrict__ x,
     float* __restrict__ J_inv, uint8_t* __restrict__ is_valid, float* __restrict__ fwd_J, int pts_per_wave,
     unsigned long long* __restrict__ counters /* NULL or [5]: fetches, retired items, completed valid items, unrecorded roots, in-range corner loads */,
-    int32_t* __restrict__ cnt /* PACK: [N] */, uint32_t* __restrict__ meta /* PACK: [N] */, int32_t* __restrict__ overflow /* PACK: [1] */)
+    int32_t* __restrict__ cnt /* PACK: [N] */, uint32_t* __restrict__ meta /* PACK: [N] */, int32_t* __restrict__ ovf_count /* PACK: [1] */,
+    int32_t* __restrict__ ovf_head /* PACK: [N], written for points with extras only */, int32_t* __restrict__ ovf_rec /* PACK: [cap][3] point, init, prev */,
+    float* __restrict__ ovf_x /* PACK: [cap][3] */, int ovf_cap)
 {
     __shared__ float s_T[16 * 12];                     // per init: rows 0..2 of its bone's 4x4 (R | t)
     for (int t = threadIdx.x; t < I * 12; t += THREADS) s_T[t] = tfs[(int64_t)bone_ids[t / 12] * 16 + (t % 12)];
@@ -564,6 +569,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
     int n_roots = 0;
     int n_done = 0;               // PACK: searches of the lane's point that completed valid
     unsigned inits = 0;           // PACK: their inits, one byte each
+    int last_ovf = -1;            // PACK: the point's most recent overflow record
     float xt[3] = {0, 0, 0}, x_l[3] = {0, 0, 0}, gx[3] = {0, 0, 0}, u[3] = {0, 0, 0};
     float Ji[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     float root[SPEC_ROOTS][3];
@@ -578,7 +584,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
             if (init > 0) { init--; it = -1; }
             else {
                 have = false;
-                if (PACK) { cnt[p_begin + pt] = n_done; meta[p_begin + pt] = inits; }
+                if (PACK) {
+                    cnt[p_begin + pt] = n_done;
+                    meta[p_begin + pt] = inits | (last_ovf >= 0 ? 0x80000000u : 0u);
+                    if (last_ovf >= 0) ovf_head[p_begin + pt] = last_ovf;
+                }
             }
         }
         const unsigned long long need = __ballot(!have);
@@ -594,6 +604,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
                     n_roots = 0;
                     n_done = 0;
                     inits = 0;
+                    last_ovf = -1;
                     xt[0] = xd_tgt[(p_begin + c) * 3 + 0];
                     xt[1] = xd_tgt[(p_begin + c) * 3 + 1];
                     xt[2] = xd_tgt[(p_begin + c) * 3 + 2];
@@ -659,8 +670,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
                             x[slot * 3 + 0] = x_l[0]; x[slot * 3 + 1] = x_l[1]; x[slot * 3 + 2] = x_l[2];
                             inits |= (unsigned)init << (8 * n_done);
                             n_done++;
-                        } else {
-                            *overflow = 1;                                  // a 4th candidate: the rows cannot hold it (benign race: all writers store 1)
+                        } else {                                            // a 4th, 5th ... candidate of this point: overflow record
+                            const int k = atomicAdd(ovf_count, 1);
+                            if (k < ovf_cap) {
+                                ovf_rec[3 * k + 0] = (int32_t)(p_begin + pt); ovf_rec[3 * k + 1] = init; ovf_rec[3 * k + 2] = last_ovf;
+                                ovf_x[3 * k + 0] = x_l[0]; ovf_x[3 * k + 1] = x_l[1]; ovf_x[3 * k + 2] = x_l[2];
+                                last_ovf = k;
+                            }
                         }
                     } else {
                         x[index * 3 + 0] = x_l[0]; x[index * 3 + 1] = x_l[1]; x[index * 3 + 2] = x_l[2];
@@ -728,24 +744,56 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
 }
 
 // ---- candidate rows of the PACK search -> packed candidate list ------------------------------------------------------------
-// one lane per point: the row's cnt candidates were stored highest init first; the packed list is in (point, ascending init) order
+// K9 among the overflow records of a point: record k is dropped when a record of a LATER init of the same point (= one further
+// down its `prev` chain: searches complete in descending init order) lies within 1e-4; kept records count towards cnt[point]
+__global__ __launch_bounds__(THREADS) void rows_extras_kernel(const int32_t* __restrict__ ovf_count, int ovf_cap, const int32_t* __restrict__ ovf_rec,
+                                                               const float* __restrict__ ovf_x, uint8_t* __restrict__ ovf_keep,
+                                                               int32_t* __restrict__ cnt)
+{
+    const int n = min(*ovf_count, ovf_cap);
+    for (int k = blockIdx.x * THREADS + threadIdx.x; k < n; k += gridDim.x * THREADS) {
+        const float a0 = ovf_x[3 * k], a1 = ovf_x[3 * k + 1], a2 = ovf_x[3 * k + 2];
+        bool keep = true;
+        for (int j = ovf_rec[3 * k + 2]; j >= 0 && keep; j = ovf_rec[3 * j + 2]) {
+            const float d0 = a0 - ovf_x[3 * j], d1 = a1 - ovf_x[3 * j + 1], d2 = a2 - ovf_x[3 * j + 2];
+            const float dist = d0 * d0 + d1 * d1 + d2 * d2;
+            if ((double)dist < 0.0001 * 0.0001) keep = false;
+        }
+        ovf_keep[k] = keep ? 1 : 0;
+        if (keep) atomicAdd(&cnt[ovf_rec[3 * k]], 1);
+    }
+}
+
+// one lane per point: overflow records first (the chain from the head runs in ascending init order), then the row's candidates,
+// which were stored highest init first; the packed list is in (point, ascending init) order
 __global__ __launch_bounds__(THREADS) void rows_pack_kernel(int64_t N, int I, const float* __restrict__ x, const int32_t* __restrict__ cnt,
                                                              const uint32_t* __restrict__ meta, const int32_t* __restrict__ start,
+                                                             const int32_t* __restrict__ ovf_head, const int32_t* __restrict__ ovf_rec,
+                                                             const float* __restrict__ ovf_x, const uint8_t* __restrict__ ovf_keep,
                                                              float* __restrict__ cand_x, int32_t* __restrict__ cand_src)
 {
     const int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     if (p >= N) return;
-    const int c = cnt[p];
+    int c = cnt[p];
     if (c == 0) return;
-    const int64_t q0 = start[p];
-    const unsigned m = cand_src ? meta[p] : 0u;
+    int64_t q = start[p];
+    const unsigned m = meta[p];
+    if (m & 0x80000000u) {
+        for (int k = ovf_head[p]; k >= 0; k = ovf_rec[3 * k + 2]) {
+            if (!ovf_keep[k]) continue;
+            cand_x[q * 3 + 0] = ovf_x[3 * k]; cand_x[q * 3 + 1] = ovf_x[3 * k + 1]; cand_x[q * 3 + 2] = ovf_x[3 * k + 2];
+            if (cand_src) cand_src[q] = (int32_t)(p * I + ovf_rec[3 * k + 1]);
+            q++;
+        }
+        c = SPEC_ROOTS;                                    // a point with overflow records has all its row slots in use
+    }
     const float* row = x + p * (SPEC_ROOTS * 3);
     for (int k = 0; k < c; k++) {
         const int slot = c - 1 - k;
-        cand_x[(q0 + k) * 3 + 0] = row[slot * 3 + 0];
-        cand_x[(q0 + k) * 3 + 1] = row[slot * 3 + 1];
-        cand_x[(q0 + k) * 3 + 2] = row[slot * 3 + 2];
-        if (cand_src) cand_src[q0 + k] = (int32_t)(p * I + ((m >> (8 * slot)) & 0xffu));
+        cand_x[(q + k) * 3 + 0] = row[slot * 3 + 0];
+        cand_x[(q + k) * 3 + 1] = row[slot * 3 + 1];
+        cand_x[(q + k) * 3 + 2] = row[slot * 3 + 2];
+        if (cand_src) cand_src[q + k] = (int32_t)(p * I + ((m >> (8 * slot)) & 0xffu));
     }
 }
 
@@ -1020,7 +1068,8 @@ IA_EXPORT int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt, cons
 static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
                        const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold, float dvg_threshold, float eps,
                        float* x, float* J_inv, uint8_t* is_valid, float* fwd_J, uint64_t* counters, int32_t* cnt, uint32_t* meta,
-                       int32_t* overflow, ia_stream_t stream, const char* what)
+                       int32_t* ovf_count, int32_t* ovf_head, int32_t* ovf_rec, float* ovf_x, int ovf_cap, ia_stream_t stream,
+                       const char* what)
 {
     if (N == 0) return IA_OK;
     IA_REQUIRE(I >= 1 && I <= 16, "speculative search: 1 <= I <= 16 inits");
@@ -1035,7 +1084,7 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
 #define IA_SPEC_LAUNCH(COUNT, PACK)                                                                                                    \
     broyden_spec_kernel<COUNT, PACK><<<grid, THREADS, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,         \
                                                                cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J, pts, c, cnt, \
-                                                               meta, overflow)
+                                                               meta, ovf_count, ovf_head, ovf_rec, ovf_x, ovf_cap)
     if (pack) { if (counters) IA_SPEC_LAUNCH(true, true); else IA_SPEC_LAUNCH(false, true); }
     else { if (counters) IA_SPEC_LAUNCH(true, false); else IA_SPEC_LAUNCH(false, false); }
 #undef IA_SPEC_LAUNCH
@@ -1048,35 +1097,69 @@ IA_EXPORT int ia_fuse_broyden_spec(int64_t N, int I, const float* xd_tgt, const 
                                    uint64_t* counters, ia_stream_t stream)
 {
     return launch_spec(false, N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x, J_inv,
-                       is_valid, fwd_J, counters, nullptr, nullptr, nullptr, stream, "ia_fuse_broyden_spec");
+                       is_valid, fwd_J, counters, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream, "ia_fuse_broyden_spec");
 }
 
 IA_EXPORT int ia_spec_rows_slots(void) { return SPEC_ROOTS; }
 
 extern "C" int ia_exclusive_scan_i32(const int32_t* in, int32_t* out, int32_t* total, int64_t n, void* tmp, ia_stream_t stream);
 
+// overflow scratch of the rows search: [count (int32) | pad] [rec: cap x 3 int32] [x: cap x 3 float] [keep: cap bytes]
+static const int SPEC_OVF_CAP = 1 << 18;
+IA_EXPORT size_t ia_spec_rows_overflow_bytes(void) { return 64 + (size_t)SPEC_OVF_CAP * (12 + 12 + 1) + 64; }
+
+struct OvfLayout { int32_t* count; int32_t* rec; float* x; uint8_t* keep; };
+static OvfLayout ovf_layout(void* scratch)
+{
+    char* b = reinterpret_cast<char*>(scratch);
+    OvfLayout L;
+    L.count = reinterpret_cast<int32_t*>(b);
+    L.rec = reinterpret_cast<int32_t*>(b + 64);
+    L.x = reinterpret_cast<float*>(b + 64 + (size_t)SPEC_OVF_CAP * 12);
+    L.keep = reinterpret_cast<uint8_t*>(b + 64 + (size_t)SPEC_OVF_CAP * 24);
+    return L;
+}
+
 IA_EXPORT int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
                                         const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold,
                                         float dvg_threshold, float eps, float* x_rows, float* J_inv, float* fwd_J, int32_t* cnt,
-                                        uint32_t* meta, int32_t* start, int32_t* total_and_overflow, void* scan_tmp, uint64_t* counters,
-                                        ia_stream_t stream)
+                                        uint32_t* meta, int32_t* start, int32_t* ovf_head, void* ovf_scratch, int32_t* total_and_overflow,
+                                        void* scan_tmp, uint64_t* counters, ia_stream_t stream)
 {
     IA_REQUIRE(eps >= 1e-4f, "ia_fuse_broyden_spec_rows: eps must be >= 1e-4 (the completed searches are K9's survivors only then)");
     IA_REQUIRE(N * I < ((int64_t)1 << 31), "ia_fuse_broyden_spec_rows: N * I must stay below 2^31");
-    if (N == 0) return ia_exclusive_scan_i32(nullptr, nullptr, total_and_overflow, 0, scan_tmp, stream);
-    (void)hipMemsetAsync(total_and_overflow + 1, 0, sizeof(int32_t), (hipStream_t)stream);
+    hipStream_t s = (hipStream_t)stream;
+    OvfLayout o = ovf_layout(ovf_scratch);
+    (void)hipMemsetAsync(o.count, 0, sizeof(int32_t), s);
+    if (N == 0) {
+        (void)hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(int32_t), s);
+        return ia::check_launch("ia_fuse_broyden_spec_rows");
+    }
     int r = launch_spec(true, N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x_rows,
-                        J_inv, nullptr, fwd_J, counters, cnt, meta, total_and_overflow + 1, stream, "ia_fuse_broyden_spec_rows");
+                        J_inv, nullptr, fwd_J, counters, cnt, meta, o.count, ovf_head, o.rec, o.x, SPEC_OVF_CAP, stream,
+                        "ia_fuse_broyden_spec_rows");
     if (r != IA_OK) return r;
-    return ia_exclusive_scan_i32(cnt, start, total_and_overflow, N, scan_tmp, stream);
+    rows_extras_kernel<<<64, THREADS, 0, s>>>(o.count, SPEC_OVF_CAP, o.rec, o.x, o.keep, cnt);
+    r = ia::check_launch("ia_fuse_broyden_spec_rows(extras)");
+    if (r != IA_OK) return r;
+    r = ia_exclusive_scan_i32(cnt, start, total_and_overflow, N, scan_tmp, stream);
+    if (r != IA_OK) return r;
+    // [1] = number of overflow records; the caller compares it with ia_spec_rows_overflow_capacity()
+    if (hipMemcpyAsync(total_and_overflow + 1, o.count, sizeof(int32_t), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return ia::check_launch("ia_fuse_broyden_spec_rows(copy)");
+    return IA_OK;
 }
 
+IA_EXPORT int ia_spec_rows_overflow_capacity(void) { return SPEC_OVF_CAP; }
+
 IA_EXPORT int ia_deform_rows_pack(int64_t N, int I, const float* x_rows, const int32_t* cnt, const uint32_t* meta, const int32_t* start,
-                                  float* cand_x, int32_t* cand_src, ia_stream_t stream)
+                                  const int32_t* ovf_head, const void* ovf_scratch, float* cand_x, int32_t* cand_src, ia_stream_t stream)
 {
     if (N == 0) return IA_OK;
     IA_REQUIRE(cand_x != x_rows, "ia_deform_rows_pack: cand_x must not alias x_rows");
-    rows_pack_kernel<<<ia::cdiv(N, THREADS), THREADS, 0, (hipStream_t)stream>>>(N, I, x_rows, cnt, meta, start, cand_x, cand_src);
+    OvfLayout o = ovf_layout(const_cast<void*>(ovf_scratch));
+    rows_pack_kernel<<<ia::cdiv(N, THREADS), THREADS, 0, (hipStream_t)stream>>>(N, I, x_rows, cnt, meta, start, ovf_head, o.rec, o.x, o.keep,
+                                                                                cand_x, cand_src);
     return ia::check_launch("ia_deform_rows_pack");
 }
 

@@ -23,12 +23,13 @@ from . import fast_snarf
 
 class SNARFDeformer:
     INIT_BONES = [0, 1, 2, 4, 5, 10, 11, 12, 15, 16, 17, 18, 19]    # deformer_torch.py:27
-    # Speculative early filter of the search (fast_snarf.fuse_broyden_spec): batches of at least SPEC_MIN_POINTS
-    # points retire a search once it comes within SPEC_EPS metres of a root that a later init of the same point has found
-    # (K9 would drop it).  IA_BROYDEN_SPEC_EPS=0 (or spec_eps = 0) = the exact search everywhere.  Small batches -- every
-    # parity test against the oracle -- always run the exact search.
+    # Speculative early filter of the search (fast_snarf.fuse_broyden_spec[_rows]): a search is retired once it comes
+    # within SPEC_EPS metres of a root that a later init of the same point has found (K9 would drop it).  On for EVERY batch size:
+    # what a point gets must not depend on how many other points share its launch (ray-batch sharding invariance, multi-GPU =
+    # single GPU).  IA_BROYDEN_SPEC_EPS=0 (or deformer.spec_eps = 0) = the reference's exact search everywhere; the kernel-level
+    # parity tests (K8 / K9 golden vectors) call the exact entry points directly.
     SPEC_EPS = float(os.environ.get("IA_BROYDEN_SPEC_EPS", "1e-3"))
-    SPEC_MIN_POINTS = int(os.environ.get("IA_BROYDEN_SPEC_MIN_POINTS", str(1 << 20)))
+    SPEC_MIN_POINTS = int(os.environ.get("IA_BROYDEN_SPEC_MIN_POINTS", "1"))
 
     def __init__(self, lbs_voxel_final: Tensor, offset_kernel: Tensor, scale_kernel: Tensor, bbox: Tensor):
         self.lbs_voxel_final = lbs_voxel_final.contiguous().float()          # [1,24,D,H,W]
@@ -156,8 +157,8 @@ class SNARFDeformer:
         """search + candidate bookkeeping for P posed points -> (cand_x [Q,3], cand_src [Q] | None, cnt [P], start [P], Q, fwd_J, J_inv).
         Large batches (speculative search, eps >= 1e-4): the search kernel itself leaves each point's surviving candidates in its
         3-slot row plus their count and the scan of the counts (fast_snarf.fuse_broyden_spec_rows: 44 B per point instead of 169) --
-        no x [P,13,3], no is_valid, no K9 pass; one segmented copy makes the packed list.  A batch in which some point has a 4th
-        distinct root falls back to the other path.  Otherwise: search() + _pack_candidates() (K9 + count + pack)."""
+        no x [P,13,3], no is_valid, no K9 pass; one segmented copy makes the packed list.  The rare 4th.. candidates of a point go
+        through a small overflow list (K9 among them in the kernel's epilogue).  Otherwise: search() + _pack_candidates()."""
         P, I = pts.shape[0], self.init_bones.shape[0]
         dev = self.device
         if not (self.SPEC_ROWS and self.spec_eps >= 1e-4 and P >= self.SPEC_MIN_POINTS and self.tfs.shape[0] == 1):
@@ -169,21 +170,25 @@ class SNARFDeformer:
         x_rows = torch.empty((P, 3, 3), device=dev)
         Jinv = torch.empty((1, P, I, 3, 3), device=dev) if want_jinv else None
         fwd = torch.empty((1, P, I, 3, 3), device=dev) if want_fwd else None
-        cnt, meta, start = (torch.empty(P, dtype=torch.int32, device=dev) for _ in range(3))
+        cnt, meta, start, ovf_head = (torch.empty(P, dtype=torch.int32, device=dev) for _ in range(4))
+        if getattr(self, "_ovf_scratch", None) is None or self._ovf_scratch.device != dev:
+            self._ovf_scratch = torch.empty(int(lib.ia_spec_rows_overflow_bytes()), dtype=torch.uint8, device=dev)
+            self._ovf_cap = int(lib.ia_spec_rows_overflow_capacity())
         tot = torch.empty(2, dtype=torch.int32, device=dev)
         fast_snarf.fuse_broyden_spec_rows(x_rows, pts.reshape(1, P, 3), fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs, self.init_bones,
-                                          Jinv, cnt, meta, start, tot, self.offset_kernel, self.scale_kernel, 1e-5, 1e-1, self.spec_eps,
-                                          fwd_J=fwd, counters=self.spec_counters)
-        Q, overflow = tot.tolist()                                   # the one read-back of the call
-        if overflow:
-            # some point has a 4th distinct root: the 3-slot rows cannot hold it -- this batch goes through is_valid + K9 instead
+                                          Jinv, cnt, meta, start, ovf_head, self._ovf_scratch, tot, self.offset_kernel, self.scale_kernel,
+                                          1e-5, 1e-1, self.spec_eps, fwd_J=fwd, counters=self.spec_counters)
+        Q, n_over = tot.tolist()                                     # the one read-back of the call
+        self.last_overflow_records = n_over
+        if n_over > self._ovf_cap:
+            # more 4th.. candidates than the overflow list holds (never seen): this batch goes through is_valid + K9 instead
             del x_rows, cnt, meta, start, Jinv, fwd
             r = self.search(pts, want_fwd=want_fwd, want_jinv=want_jinv)
             return (*self._pack_candidates(r[0], r[1], with_src=with_src), r[2], (r[3] if want_jinv else None))
         cand_x = torch.empty((Q, 3), device=dev)
         cand_src = torch.empty(Q, dtype=torch.int32, device=dev) if with_src else None
-        L.check(lib.ia_deform_rows_pack(L.i64(P), L.i32(I), L.ptr(x_rows), L.ptr(cnt), L.ptr(meta), L.ptr(start), L.ptr(cand_x),
-                                        L.ptr(cand_src), st), "ia_deform_rows_pack")
+        L.check(lib.ia_deform_rows_pack(L.i64(P), L.i32(I), L.ptr(x_rows), L.ptr(cnt), L.ptr(meta), L.ptr(start), L.ptr(ovf_head),
+                                        L.ptr(self._ovf_scratch), L.ptr(cand_x), L.ptr(cand_src), st), "ia_deform_rows_pack")
         return cand_x, cand_src, cnt, start, Q, (fwd[0] if want_fwd else None), (Jinv[0] if want_jinv else None)
 
     @torch.no_grad()

@@ -247,11 +247,13 @@ class VolumeSDF(nn.Module):
 
     @torch.no_grad()
     def sdf_only(self, points: Tensor) -> Tensor:
-        """SDF value alone (feature[:, 0] of VolumeSDF.forward, rf/geometry.py:152-160) for the no-grad coarse queries.  Large
-        batches: XCD-partitioned hash gather whose level-major result feeds the MLP kernel directly (no [n,32] feature rows,
-        no transpose pass, 4 instead of 52 output bytes per point); values equal forward()'s (same kernels' arithmetic)."""
+        """SDF value alone (feature[:, 0] of VolumeSDF.forward, rf/geometry.py:152-160) for the no-grad coarse queries:
+        XCD-partitioned hash gather whose level-major result feeds the software-pipelined value head directly (no [n,32] feature
+        rows, no transpose pass, 4 instead of 52 output bytes per point).  EVERY batch size takes this path, so the value of a
+        point does not depend on how many other points share its launch (ray-batch sharding invariance); against forward() the
+        output layer is summed in another order (last-bit differences)."""
         n = points.shape[0]
-        if n < HASH_FWD_XCD_MIN or os.environ.get("IA_SDF_ONLY_FUSED", "1") != "1":
+        if n == 0 or os.environ.get("IA_SDF_ONLY_FUSED", "1") != "1":
             return self.forward(points, with_grad=False, with_feature=False).contiguous()
         cfg = HASH
         xp = ((points - self.center) / self.scale + 0.5).contiguous()

@@ -260,25 +260,29 @@ def test_tcnn_encoding_dropin_first_and_second_order(fields):
 
 
 def test_sdf_only_query_path_equals_the_general_one(fields):
-    """geometry.sdf_only (level-major hash result -> SDF head, one output) and deformer.deform_sdf == the general forward /
-    deform on the same points, bit for bit (same kernels' arithmetic; only what is written differs)."""
+    """geometry.sdf_only (level-major hash result -> software-pipelined value head) and deformer.deform_sdf against the general
+    forward / deform on the same points: the value head sums the output layer in another order (lane partials + LDS reduce instead
+    of an MFMA tile) and evaluates Softplus without the threshold pass-through: 2e-6 absolute (SDF in metres); and bit-identical to
+    ITSELF for every batch size / order (what ray-batch sharding relies on)."""
     from intrinsicavatar_amd import synthetic as S
     rs, rays, _ = S.build_frame(DEV, 96, 96, pose_seed=0, beta=0.01, num_samples_per_ray=64, grid_D=16, grid_H=64, grid_W=64,
                                 smooth_iters=5, hash_amp=1e-2)
     geo = rs.geometry
     g = torch.Generator().manual_seed(0)
-    for n in (fields.HASH_FWD_XCD_MIN + 37, 5):                    # fused path / small-batch fallback
+    for n in (fields.HASH_FWD_XCD_MIN + 37, 5, 33, 64 * 12 * 3 + 1):     # many tiles per wave / one ragged tile / two / exactly past a grid round
         x = (geo.center + (torch.rand((n, 3), generator=g).to(DEV) - 0.5) * geo.scale).contiguous()
         a = geo.sdf_only(x)
         b = geo.forward(x, with_grad=False, with_feature=False)
-        assert torch.equal(a, b), float((a - b).abs().max())
+        assert float((a - b).abs().max()) < 2e-6, float((a - b).abs().max())
+        k = n // 3
+        assert torch.equal(geo.sdf_only(x[k:].contiguous()), a[k:])      # the value of a point does not depend on the batch
     r = rs.deformer.transform_rays_w2s(rays.float())
     t = torch.rand((rays.shape[0], 40), generator=g).to(DEV) * 2.0 + 4.0
     pts = (r[:, None, :3] + r[:, None, 3:6] * t[..., None]).reshape(-1, 3).contiguous()
     assert pts.shape[0] > fields.HASH_FWD_XCD_MIN
     d = rs.deformer.deform(pts, geo)
     s = rs.deformer.deform_sdf(pts, geo)
-    assert torch.equal(s, d["sdf"]) and int((s < 1e5).sum()) > 1000
+    assert float((s - d["sdf"]).abs().max()) < 2e-6 and int((s < 1e5).sum()) > 1000
     # spatial ordering of big batches does not change the values either
     old = rs.SORT_MIN_POINTS
     try:

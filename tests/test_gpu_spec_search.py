@@ -85,23 +85,28 @@ def test_speculation_removes_fetches_and_changes_almost_nothing(march, eps):
     assert r["sdf_abs_gt_1e3"] < 5e-5 and r["sdf_abs_gt_1e4"] < 5e-4
 
 
-def test_product_path_uses_it_only_for_large_batches(march):
+def test_product_path_is_independent_of_the_batch(march):
+    """the product path speculates for every batch size: a point's result does not depend on which other points share its launch
+    (ray-batch sharding invariance); spec_eps = 0 gives the reference's exact search."""
     SP, rs, pts, (_, _, _, s0) = march
     dfm = rs.deformer
-    assert dfm.spec_eps > 0 and pts.shape[0] >= dfm.SPEC_MIN_POINTS
+    assert dfm.spec_eps > 0
     cnt = torch.zeros(5, dtype=torch.int64, device=DEV)
     dfm.spec_counters = cnt
     try:
-        s1 = dfm.deform_sdf(pts, rs.geometry)                       # large batch: speculative
+        s1 = dfm.deform_sdf(pts, rs.geometry)
         assert int(cnt[0]) > 0 and int(cnt[1]) > 0
         assert float((s1 != s0).float().mean()) < 2e-3
-        cnt.zero_()
-        small = pts[:50_000].contiguous()
-        s2 = dfm.deform_sdf(small, rs.geometry)                      # small batch: the exact search (parity tests live here)
-        assert int(cnt[0]) == 0
-        assert torch.equal(s2, s0[:50_000])
+        for a, b in ((0, 50_000), (123_457, 131_000), (400_000, 400_001)):
+            assert torch.equal(dfm.deform_sdf(pts[a:b].contiguous(), rs.geometry), s1[a:b])
     finally:
         dfm.spec_counters = None
+    old = dfm.spec_eps
+    try:
+        dfm.spec_eps = 0.0
+        assert torch.equal(dfm.deform_sdf(pts[:50_000].contiguous(), rs.geometry), s0[:50_000])
+    finally:
+        dfm.spec_eps = old
 
 
 def test_candidate_rows_equal_search_plus_k9_pack(march):
@@ -130,9 +135,30 @@ def test_candidate_rows_equal_search_plus_k9_pack(march):
     assert torch.equal(s_rows, s_k9)
 
 
-def test_a_batch_with_a_fourth_root_falls_back_to_k9(march):
-    """the 3-slot rows cannot hold a 4th distinct root of a point: the kernel raises the overflow flag (none of the 18 M points of
-    the headline distribution does) and the batch is redone through is_valid + K9.  The flag is forced here."""
+def test_points_with_more_than_three_roots_go_through_the_overflow_list():
+    """a skinning field with several distinct roots per point: the 4th.. completed searches of a point become overflow records, K9
+    runs among them, and the packed list equals the one of search + K9 + pack (filter.cu:10-54 semantics)."""
+    from intrinsicavatar_amd import synthetic as S
+    rs, rays, _ = S.build_frame(DEV, 64, 64, pose="aist:100", beta=0.01)
+    dfm = rs.deformer
+    g = torch.Generator().manual_seed(0)
+    lo, hi = rs.aabbs[0, :3].cpu(), rs.aabbs[0, 3:].cpu()
+    pts = (torch.rand((3_000_000, 3), generator=g) * (hi - lo) + lo).to(DEV)
+    a = dfm._candidates(pts, with_src=True)
+    assert dfm.last_overflow_records > 0, "no point of this batch has a 4th root -- test is vacuous"
+    try:
+        type(dfm).SPEC_ROWS = False
+        b = dfm._candidates(pts, with_src=True)
+    finally:
+        type(dfm).SPEC_ROWS = True
+    assert a[4] == b[4]
+    for k in (0, 1, 2, 3):
+        assert torch.equal(a[k], b[k]), k
+    assert int(a[2].max()) >= 4
+
+
+def test_a_full_overflow_list_falls_back_to_k9(march):
+    """more overflow records than the list holds (never seen; forced here): the batch is redone through is_valid + K9."""
     from intrinsicavatar_amd import fast_snarf
     SP, rs, pts, _ = march
     dfm = rs.deformer
@@ -140,9 +166,9 @@ def test_a_batch_with_a_fourth_root_falls_back_to_k9(march):
     orig = fast_snarf.fuse_broyden_spec_rows
     calls = []
 
-    def forced(x_rows, xd, vj, tfs, bones, J_inv, cnt, meta, start, tot, *a, **k):
-        orig(x_rows, xd, vj, tfs, bones, J_inv, cnt, meta, start, tot, *a, **k)
-        tot[1] = 1
+    def forced(x_rows, xd, vj, tfs, bones, J_inv, cnt, meta, start, oh, osc, tot, *a, **k):
+        orig(x_rows, xd, vj, tfs, bones, J_inv, cnt, meta, start, oh, osc, tot, *a, **k)
+        tot[1] = dfm._ovf_cap + 1
         calls.append(1)
     fast_snarf.fuse_broyden_spec_rows = forced
     try:
