@@ -546,7 +546,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
     unsigned long long* __restrict__ counters /* NULL or [5]: fetches, retired items, completed valid items, unrecorded roots, in-range corner loads */,
     int32_t* __restrict__ cnt /* PACK: [N] */, uint32_t* __restrict__ meta /* PACK: [N] */, int32_t* __restrict__ ovf_count /* PACK: [1] */,
     int32_t* __restrict__ ovf_head /* PACK: [N], written for points with extras only */, int32_t* __restrict__ ovf_rec /* PACK: [cap][3] point, init, prev */,
-    float* __restrict__ ovf_x /* PACK: [cap][3] */, int ovf_cap)
+    float* __restrict__ ovf_x /* PACK: [cap][3] */, int ovf_cap, int slots /* <= SPEC_ROOTS: roots recorded / row slots used (test hook) */)
 {
     __shared__ float s_T[16 * 12];                     // per init: rows 0..2 of its bone's 4x4 (R | t)
     for (int t = threadIdx.x; t < I * 12; t += THREADS) s_T[t] = tfs[(int64_t)bone_ids[t / 12] * 16 + (t % 12)];
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
                 if (!PACK) is_valid[index] = ok ? 1 : 0;
                 if (ok) {
                     if (PACK) {
-                        if (n_done < SPEC_ROOTS) {
+                        if (n_done < slots) {
                             const int64_t slot = (p_begin + pt) * SPEC_ROOTS + n_done;
                             x[slot * 3 + 0] = x_l[0]; x[slot * 3 + 1] = x_l[1]; x[slot * 3 + 2] = x_l[2];
                             inits |= (unsigned)init << (8 * n_done);
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
                     }
                     // a root of this point: searches of EARLIER inits that come within eps of it are duplicates-to-be
                     if (COUNT) c_valid++;
-                    if (n_roots < SPEC_ROOTS) {
+                    if (n_roots < slots) {
 #pragma unroll
                         for (int r = 0; r < SPEC_ROOTS; r++)
                             if (r == n_roots) { root[r][0] = x_l[0]; root[r][1] = x_l[1]; root[r][2] = x_l[2]; }
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(THREADS) void rows_pack_kernel(int64_t N, int I, co
             if (cand_src) cand_src[q] = (int32_t)(p * I + ovf_rec[3 * k + 1]);
             q++;
         }
-        c = SPEC_ROOTS;                                    // a point with overflow records has all its row slots in use
+        c -= (int)(q - start[p]);                          // the rest of the point's candidates sit in its row
     }
     const float* row = x + p * (SPEC_ROOTS * 3);
     for (int k = 0; k < c; k++) {
@@ -1081,10 +1081,12 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
     const int grid = ia::cdiv(n_waves * 64, THREADS);
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* c = reinterpret_cast<unsigned long long*>(counters);
+    int slots = SPEC_ROOTS;                                              // test hook: fewer recorded roots / row slots => the overflow list is used
+    if (const char* e = getenv("IA_SPEC_TEST_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= SPEC_ROOTS) slots = v; }
 #define IA_SPEC_LAUNCH(COUNT, PACK)                                                                                                    \
     broyden_spec_kernel<COUNT, PACK><<<grid, THREADS, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,         \
                                                                cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J, pts, c, cnt, \
-                                                               meta, ovf_count, ovf_head, ovf_rec, ovf_x, ovf_cap)
+                                                               meta, ovf_count, ovf_head, ovf_rec, ovf_x, ovf_cap, slots)
     if (pack) { if (counters) IA_SPEC_LAUNCH(true, true); else IA_SPEC_LAUNCH(false, true); }
     else { if (counters) IA_SPEC_LAUNCH(true, false); else IA_SPEC_LAUNCH(false, false); }
 #undef IA_SPEC_LAUNCH

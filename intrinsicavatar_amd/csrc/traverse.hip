@@ -15,6 +15,8 @@
 //     Output order is ray order then marching order, exactly as upstream.
 // Arithmetic is kept operation-for-operation identical to oracle/ia_oracle.c (this TU is
 // built with -ffp-contract=off) so edge/sample counts and t values are bit-exact.
+#include <stdlib.h>
+
 #include "ia_common.h"
 #include "t_advance.h"
 
@@ -672,6 +674,260 @@ __global__ __launch_bounds__(TR_THREADS) void traverse_fused_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The fused traversal with the rays of a tile walked in order of their SPAN inside the grid's box.
+// traverse_fused_kernel gives lane l of a 256-ray tile ray l: counters (profiles/r02_traverse_pmc.txt) show 34.7 of 64 lanes
+// active per VALU instruction -- a wave runs until its longest ray is through, and neighbouring secondary rays (random
+// directions off neighbouring surface points) cross anything between 0 and ~70 cells.  Here a tile is 1024 rays on 512 lanes:
+// a counting sort of the rays by the length of their box crossing (64 bins, LDS atomics; the slab test is the walk's own)
+// decides WHICH ray a lane walks in each of its two rounds, so the 64 rays a wave walks together have similar cell counts
+// (rays that miss the box share waves that do nothing).  Everything a ray writes goes to its own slot (LDS descriptors, the
+// global per-ray records), so outputs -- packed in ray order by the same scan / look-back / element-parallel expansion --
+// are bit-identical to traverse_fused_kernel's.  Run descriptors: 4 per ray inline (u16 counts); more runs = the in-order
+// re-walk, as before.
+constexpr int ST_THREADS = 512, ST_RAYS = 1024, ST_RUNS = 4, ST_BINS = 64;
+
+struct LdsRunSinkST {
+    float* tfirst;          // [ST_RUNS][ST_RAYS]
+    uint16_t* nsamp;        // [ST_RUNS][ST_RAYS]
+    int col;
+    int n_runs = 0, run_len = 0, n_samples = 0, n_intervals = 0;
+    __device__ __forceinline__ void emit(float t_last, float, bool continuous)
+    {
+        if (!continuous) {
+            if (n_runs > 0 && n_runs <= ST_RUNS) nsamp[(n_runs - 1) * ST_RAYS + col] = (uint16_t)run_len;
+            if (n_runs < ST_RUNS) tfirst[n_runs * ST_RAYS + col] = t_last;
+            n_runs++;
+            run_len = 0;
+            n_intervals += 2;
+        } else {
+            n_intervals++;
+        }
+        n_samples++;
+        run_len++;
+    }
+    __device__ __forceinline__ void finish()
+    {
+        if (n_runs > 0 && n_runs <= ST_RUNS) nsamp[(n_runs - 1) * ST_RAYS + col] = (uint16_t)run_len;
+    }
+};
+
+__global__ __launch_bounds__(ST_THREADS) void traverse_sorted_kernel(
+    int64_t n_rays, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    const uint32_t* __restrict__ grid_bits, int rx, int ry, int rz, const float* __restrict__ aabb_g,
+    const float* __restrict__ near_planes, const float* __restrict__ far_planes, float step_size, float cone_angle,
+    uint64_t* __restrict__ tile_state /*[n_tiles] zeroed*/, uint32_t* __restrict__ ticket /*zeroed*/, int n_tiles,
+    int64_t cap_edges, int64_t cap_samples, int64_t* __restrict__ totals /*[3]: edges, samples, overflow*/,
+    int64_t* __restrict__ iv_pinfo, int64_t* __restrict__ sm_pinfo, float* __restrict__ iv_vals,
+    uint8_t* __restrict__ iv_is_left, uint8_t* __restrict__ iv_is_right, int64_t* __restrict__ iv_ray,
+    float* __restrict__ sm_vals, int64_t* __restrict__ sm_ray, float* __restrict__ term_planes,
+    float* __restrict__ sm_ts /*or NULL*/, float* __restrict__ sm_te /*or NULL*/, float inv_bin)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
+    __shared__ float s_tfirst[ST_RUNS * ST_RAYS];
+    __shared__ uint16_t s_nsamp[ST_RUNS * ST_RAYS];
+    __shared__ uint8_t s_nruns[ST_RAYS];
+    __shared__ uint32_t s_cnt[ST_RAYS];                 // edges | samples << 16 of a ray
+    __shared__ int s_offE[ST_RAYS + 1], s_offS[ST_RAYS + 1];
+    __shared__ uint16_t s_perm[ST_RAYS];
+    __shared__ int s_hist[ST_BINS];
+    __shared__ unsigned long long s_wave_tot[ST_THREADS / 64];
+    __shared__ unsigned long long s_base;
+    __shared__ uint32_t s_tile;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    {
+        const int n_words = (rx * ry * rz + 31) >> 5;
+        const int n_vec = n_words >> 2;
+        const uint4* src = reinterpret_cast<const uint4*>(grid_bits);
+        uint4* dst = reinterpret_cast<uint4*>(s_bits);
+        for (int i = t; i < n_vec; i += ST_THREADS) dst[i] = src[i];
+        for (int i = (n_vec << 2) + t; i < n_words; i += ST_THREADS) s_bits[i] = grid_bits[i];
+    }
+    float aabb[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) aabb[k] = aabb_g[k];
+  for (;;) {
+    __syncthreads();                       // previous tile fully written; LDS descriptors free
+    if (t == 0) s_tile = atomicAdd(ticket, 1u);
+    if (t < ST_BINS) s_hist[t] = 0;
+    __syncthreads();
+    const int tile = (int)s_tile;
+    if (tile >= n_tiles) break;
+    const int64_t ray0 = (int64_t)tile * ST_RAYS;
+    const int n_here = (int)((n_rays - ray0 < ST_RAYS) ? n_rays - ray0 : ST_RAYS);
+
+    // ---- phase 0: span of every ray's box crossing -> bin; counting sort of the tile's rays by bin
+    int bin[2], rank[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int r = k * ST_THREADS + t;
+        bin[k] = 0;
+        if (r < n_here) {
+            const int64_t g = ray0 + r;
+            const float o[3] = {rays_o[g * 3], rays_o[g * 3 + 1], rays_o[g * 3 + 2]};
+            const float d[3] = {rays_d[g * 3], rays_d[g * 3 + 1], rays_d[g * 3 + 2]};
+            float tmin, tmax;
+            if (ray_aabb(o, d, aabb, tmin, tmax)) {
+                const float span = fminf(tmax, far_planes[g]) - fmaxf(tmin, near_planes[g]);
+                if (span > 0.0f) bin[k] = 1 + min((int)(span * inv_bin), ST_BINS - 2);
+            }
+        }
+        rank[k] = atomicAdd(&s_hist[bin[k]], 1);
+    }
+    __syncthreads();
+    if (wid == 0) {                                    // exclusive scan of the 64 bins
+        int v = s_hist[lane], inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(inc, off, 64); if (lane >= off) inc += u; }
+        s_hist[lane] = inc - v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; k++) s_perm[s_hist[bin[k]] + rank[k]] = (uint16_t)(k * ST_THREADS + t);
+    __syncthreads();
+
+    // ---- phase 1: walk; round k, lane t walks the (k * 512 + t)-th ray in span order
+#pragma unroll 1
+    for (int k = 0; k < 2; k++) {
+        const int r = s_perm[k * ST_THREADS + t];
+        LdsRunSinkST sink{s_tfirst, s_nsamp, r};
+        if (r < n_here) {
+            const int64_t g = ray0 + r;
+            const float o[3] = {rays_o[g * 3], rays_o[g * 3 + 1], rays_o[g * 3 + 2]};
+            const float d[3] = {rays_d[g * 3], rays_d[g * 3 + 1], rays_d[g * 3 + 2]};
+            const float near_plane = near_planes[g], far_plane = far_planes[g];
+            const float t_term = (cone_angle == 0.0f)
+                                     ? dda_walk_fast(o, d, aabb, rx, ry, rz, near_plane, far_plane, step_size, s_bits, sink)
+                                     : dda_walk(o, d, aabb, rx, ry, rz, near_plane, far_plane, step_size, cone_angle, s_bits, sink);
+            sink.finish();
+            if (term_planes) term_planes[g] = t_term;
+        }
+        s_nruns[r] = (uint8_t)min(sink.n_runs, 255);
+        s_cnt[r] = (uint32_t)sink.n_intervals | ((uint32_t)sink.n_samples << 16);
+    }
+    __syncthreads();
+
+    // ---- phase 2: workgroup exclusive scan of the per-ray counts, in ray order (thread t: rays 2t, 2t + 1)
+    const uint32_t c0 = s_cnt[2 * t], c1 = s_cnt[2 * t + 1];
+    const unsigned long long m0 = (unsigned long long)(c0 & 0xFFFFu) | ((unsigned long long)(c0 >> 16) << 32);
+    const unsigned long long m1 = (unsigned long long)(c1 & 0xFFFFu) | ((unsigned long long)(c1 >> 16) << 32);
+    const unsigned long long mine = m0 + m1;
+    unsigned long long inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long v = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += v;
+    }
+    if (lane == 63) s_wave_tot[wid] = inc;
+    __syncthreads();
+    unsigned long long wave_off = 0, wg_total = 0;
+#pragma unroll
+    for (int w = 0; w < ST_THREADS / 64; w++) {
+        const unsigned long long v = s_wave_tot[w];
+        if (w < wid) wave_off += v;
+        wg_total += v;
+    }
+    const unsigned long long excl = wave_off + inc - mine;
+    s_offE[2 * t] = (int)(excl & 0xFFFFFFFFull);
+    s_offS[2 * t] = (int)(excl >> 32);
+    s_offE[2 * t + 1] = (int)((excl + m0) & 0xFFFFFFFFull);
+    s_offS[2 * t + 1] = (int)((excl + m0) >> 32);
+    if (t == 0) { s_offE[ST_RAYS] = (int)(wg_total & 0xFFFFFFFFull); s_offS[ST_RAYS] = (int)(wg_total >> 32); }
+    const int E_wg = (int)(wg_total & 0xFFFFFFFFull), S_wg = (int)(wg_total >> 32);
+
+    // ---- phase 3: decoupled look-back (wave 0); word = flag | samples << 31 | edges
+    if (wid == 0) {
+        const uint64_t agg = (uint64_t)E_wg | ((uint64_t)S_wg << 31);
+        uint64_t exclusive = 0;
+        if (tile > 0) {
+            if (lane == 0) ts_store(tile_state + tile, TS_AGG | agg);
+            int pos = tile - 1;
+            for (;;) {
+                const int idx = pos - lane;
+                uint64_t v = TS_PREFIX;
+                if (idx >= 0) {
+                    v = ts_load(tile_state + idx);
+                    while ((v >> 62) == 0) { __builtin_amdgcn_s_sleep(1); v = ts_load(tile_state + idx); }
+                }
+                const unsigned long long is_p = __ballot((v >> 62) == 2);
+                const int first_p = is_p ? __builtin_ctzll(is_p) : 64;
+                uint64_t val = (lane <= first_p) ? (v & TS_MASK) : 0;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off, 64);
+                exclusive += val;
+                if (is_p) break;
+                pos -= 64;
+            }
+        }
+        if (lane == 0) {
+            ts_store(tile_state + tile, TS_PREFIX | (exclusive + agg));
+            s_base = exclusive;
+            if (tile == n_tiles - 1) {
+                const uint64_t tot = exclusive + agg;
+                totals[0] = (int64_t)(tot & 0x7FFFFFFFull);
+                totals[1] = (int64_t)(tot >> 31);
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t baseE = (int64_t)(s_base & 0x7FFFFFFFull), baseS = (int64_t)(s_base >> 31);
+    if (baseE + E_wg > cap_edges || baseS + S_wg > cap_samples) {
+        if (t == 0) totals[2] = 1;
+        continue;
+    }
+
+    // ---- phase 4: per-ray records, then element-parallel expansion
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int r = 2 * t + k;
+        if (r < n_here) {
+            const uint32_t c = s_cnt[r];
+            if (iv_pinfo) { iv_pinfo[2 * (ray0 + r)] = baseE + s_offE[r]; iv_pinfo[2 * (ray0 + r) + 1] = (int64_t)(c & 0xFFFFu); }
+            if (sm_pinfo) { sm_pinfo[2 * (ray0 + r)] = baseS + s_offS[r]; sm_pinfo[2 * (ray0 + r) + 1] = (int64_t)(c >> 16); }
+        }
+    }
+    for (int j = t; j < E_wg; j += ST_THREADS) {
+        int lo = 0, hi = ST_RAYS;
+#pragma unroll
+        for (int it = 0; it < 10; it++) {
+            const int mid = (lo + hi) >> 1;
+            if (s_offE[mid] <= j) lo = mid; else hi = mid;
+        }
+        const int r = lo;
+        if (s_nruns[r] > ST_RUNS) continue;                         // written in order by the re-walk below
+        int k = j - s_offE[r];
+        int sidx = s_offS[r];
+        int qn = 0;
+        int n = s_nsamp[r];
+        while (k > n) { k -= n + 1; sidx += n; qn++; n = s_nsamp[qn * ST_RAYS + r]; }
+        float tv = s_tfirst[qn * ST_RAYS + r];
+        if (cone_angle == 0.0f) tv = ia_advance(tv, step_size, k);
+        else for (int i = 0; i < k; i++) tv = tv + calc_dt(tv, cone_angle, step_size, 1e10f);
+        const int64_t ray = ray0 + r;
+        const int64_t gi = baseE + j;
+        iv_vals[gi] = tv; iv_ray[gi] = ray; iv_is_left[gi] = k < n; iv_is_right[gi] = k > 0;
+        if (k < n) {
+            const float t_next = tv + calc_dt(tv, cone_angle, step_size, 1e10f);
+            const int64_t gs = baseS + sidx + k;
+            sm_vals[gs] = (t_next + tv) * 0.5f; sm_ray[gs] = ray;
+            if (sm_ts) { sm_ts[gs] = tv; sm_te[gs] = t_next; }
+        }
+    }
+#pragma unroll 1
+    for (int k = 0; k < 2; k++) {
+        const int r = 2 * t + k;
+        if (r < n_here && s_nruns[r] > ST_RUNS) {
+            const int64_t g = ray0 + r;
+            const float o[3] = {rays_o[g * 3], rays_o[g * 3 + 1], rays_o[g * 3 + 2]};
+            const float d[3] = {rays_d[g * 3], rays_d[g * 3 + 1], rays_d[g * 3 + 2]};
+            DirectWriteSink w{iv_vals, iv_is_left, iv_is_right, iv_ray, sm_vals, sm_ray, baseE + s_offE[r], baseS + s_offS[r], g, sm_ts, sm_te};
+            (void)dda_walk(o, d, aabb, rx, ry, rz, near_planes[g], far_planes[g], step_size, cone_angle, s_bits, w);
+        }
+    }
+  }
+}
+
 }  // namespace
 
 IA_EXPORT int ia_occgrid_pack_bits(const uint8_t* binaries, int64_t n_cells, uint32_t* bits, ia_stream_t stream)
@@ -777,9 +1033,37 @@ IA_EXPORT int ia_traverse_grids_fused(int64_t n_rays, const float* rays_o, const
         (void)hipGetLastError();
         attr_set = true;
     }
-    const int tiles = ia::cdiv(n_rays, TR_THREADS);
     const int64_t sb = ia_traverse_fused_scratch_bytes(n_rays);
     if (hipMemsetAsync(scratch, 0, (size_t)sb, s) != hipSuccess) return ia::check_launch("ia_traverse_grids_fused(memset)");
+    // span-sorted tiles (1024 rays on 512 lanes) for big batches; per-ray counts are kept in 16 bits there
+    const char* tv = getenv("IA_TRAVERSE");
+    const float ext_x = 0.0f;
+    (void)ext_x;
+    bool sorted = n_rays >= (1 << 16) && lds <= 32 * 1024 + 64;
+    if (tv) sorted = (tv[0] == 's');
+    if (sorted) {
+        // the longest crossing the callers' capacities allow: cap_samples / n_rays steps; bins of 1/62 of that
+        const double max_steps = (double)cap_samples / (double)n_rays;
+        if (max_steps < 30000.0) {
+            static bool attr2 = false;
+            if (!attr2) {
+                (void)hipFuncSetAttribute((const void*)traverse_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                (void)hipGetLastError();
+                attr2 = true;
+            }
+            const int tiles_s = ia::cdiv(n_rays, ST_RAYS);
+            uint64_t* state_s = (uint64_t*)scratch;
+            uint32_t* ticket_s = (uint32_t*)(state_s + tiles_s + 1);
+            const float inv_bin = (float)(62.0 / (max_steps * (double)step_size));
+            const int grid_s = tiles_s < 512 ? tiles_s : 512;      // 2 resident workgroups per CU
+            traverse_sorted_kernel<<<grid_s, ST_THREADS, lds, s>>>(
+                n_rays, rays_o, rays_d, grid_bits, rx, ry, rz, aabb, near_planes, far_planes, step_size, cone_angle, state_s, ticket_s,
+                tiles_s, cap_edges, cap_samples, totals, iv_packed_info, sm_packed_info, iv_vals, iv_is_left, iv_is_right,
+                iv_ray_indices, sm_vals, sm_ray_indices, termination_planes, sm_t_starts, sm_t_ends, inv_bin);
+            return ia::check_launch("ia_traverse_grids_fused");
+        }
+    }
+    const int tiles = ia::cdiv(n_rays, TR_THREADS);
     uint64_t* state = (uint64_t*)scratch;
     uint32_t* ticket = (uint32_t*)(state + tiles + 1);
     const int grid = tiles < 768 ? tiles : 768;        // 3 resident workgroups per CU (53 KB of LDS each)

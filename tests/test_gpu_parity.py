@@ -131,6 +131,40 @@ def test_traverse_fused_equals_two_pass(ops, oracle):
     np.testing.assert_array_equal(N(e[0].is_right), ref["intervals"]["is_right"])
 
 
+@pytest.mark.parametrize("n", [65_536 + 77, 300_001])
+def test_traverse_span_sorted_tiles_equal_the_ray_order_kernel(ops, monkeypatch, n):
+    """the fused traversal with the rays of a 1024-ray tile walked in order of their box-crossing span (traverse_sorted_kernel,
+    big batches) against the ray-order kernel (traverse_fused_kernel) and the two-pass protocol: every output tensor equal --
+    only which lane walks which ray changes.  Grids with rays of more than 4 runs (in-order re-walk), rays that miss the box,
+    a ragged last tile."""
+    rng = np.random.default_rng(n)
+    aabb = np.array([-1.0, -1.1, -0.9, 1.0, 0.9, 1.1], np.float32)
+    o = (rng.random((n, 3)).astype(np.float32) * 2.6 - 1.3)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    near = (rng.random(n) * 0.05).astype(np.float32)
+    far = (0.2 + rng.random(n) * 1.5).astype(np.float32)
+    tr = ops["nerfacc"].traverse_grids
+    for name, grid, step in (("checker", (np.indices((64, 64, 64)).sum(0) % 2).astype(bool), 1.7 / 63),
+                             ("blob", rng.random((64, 64, 64)) < 0.08, 1.7 / 63), ("dense", rng.random((64, 64, 64)) < 0.7, 0.02)):
+        args = (T(o), T(d), T(grid)[None], T(aabb)[None], T(near), T(far), step, 0.0)
+        monkeypatch.setenv("IA_TRAVERSE", "fused")
+        a = tr(*args, method="fused", max_extent=1.75)
+        monkeypatch.setenv("IA_TRAVERSE", "sorted")
+        b = tr(*args, method="fused", max_extent=1.75)
+        monkeypatch.delenv("IA_TRAVERSE")
+        c = tr(*args, method="fused", max_extent=1.75)                 # the default choice for this size (sorted)
+        assert a[1].vals.numel() > 100_000, name
+        for other in (b, c):
+            for k in ("vals", "packed_info", "ray_indices", "is_left", "is_right"):
+                assert torch.equal(getattr(a[0], k), getattr(other[0], k)), (name, "intervals", k)
+            for k in ("vals", "packed_info", "ray_indices", "t_starts", "t_ends"):
+                assert torch.equal(getattr(a[1], k), getattr(other[1], k)), (name, "samples", k)
+            assert torch.equal(a[2], other[2]), name
+        if name == "checker":
+            assert int((a[0].packed_info[:, 1] - a[1].packed_info[:, 1]).max()) > 4      # rays with more than 4 runs
+
+
 def test_traverse_properties_full_size(ops):
     """540x540 (BASELINE config 2) -- size-independent properties instead of the (slow) oracle."""
     from intrinsicavatar_amd import synthetic as S
