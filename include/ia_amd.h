@@ -96,7 +96,8 @@ int ia_traverse_grids_fused(int64_t n_rays, const float* rays_o, const float* ra
                             int64_t* sm_packed_info, float* iv_vals, uint8_t* iv_is_left, uint8_t* iv_is_right,
                             int64_t* iv_ray_indices, float* sm_vals, int64_t* sm_ray_indices,
                             float* termination_planes, float* sm_t_starts /*[cap_samples] or NULL*/,
-                            float* sm_t_ends /*[cap_samples] or NULL*/, ia_stream_t stream);
+                            float* sm_t_ends /*[cap_samples] or NULL*/, int span_sorted /* 1: walk each 1024-ray tile in order of the rays' box-crossing span (incoherent rays); outputs identical */,
+                            ia_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* nerfacc.render_weight_from_alpha / accumulate_along_rays
@@ -209,7 +210,7 @@ int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, const float
                               const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold,
                               float dvg_threshold, float eps, float* x_rows, float* J_inv, float* fwd_J, int32_t* cnt, uint32_t* meta,
                               int32_t* start, int32_t* ovf_head, void* ovf_scratch, int32_t* total_and_overflow, void* scan_tmp,
-                              uint64_t* counters, ia_stream_t stream);
+                              uint64_t* counters, const int32_t* order /* NULL or [N]: point p = xd_tgt[order[p]] */, ia_stream_t stream);
 int ia_deform_rows_pack(int64_t N, int I, const float* x_rows, const int32_t* cnt, const uint32_t* meta, const int32_t* start,
                         const int32_t* ovf_head, const void* ovf_scratch, float* cand_x, int32_t* cand_src /*or NULL*/, ia_stream_t stream);
 /* diagnostics (no reference counterpart): runs the searches of ia_fuse_broyden without outputs and ACCUMULATES into

@@ -546,7 +546,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
     unsigned long long* __restrict__ counters /* NULL or [5]: fetches, retired items, completed valid items, unrecorded roots, in-range corner loads */,
     int32_t* __restrict__ cnt /* PACK: [N] */, uint32_t* __restrict__ meta /* PACK: [N] */, int32_t* __restrict__ ovf_count /* PACK: [1] */,
     int32_t* __restrict__ ovf_head /* PACK: [N], written for points with extras only */, int32_t* __restrict__ ovf_rec /* PACK: [cap][3] point, init, prev */,
-    float* __restrict__ ovf_x /* PACK: [cap][3] */, int ovf_cap, int slots /* <= SPEC_ROOTS: roots recorded / row slots used (test hook) */)
+    float* __restrict__ ovf_x /* PACK: [cap][3] */, int ovf_cap, int slots /* <= SPEC_ROOTS: roots recorded / row slots used (test hook) */,
+    const int32_t* __restrict__ order /* NULL or [N]: point p of this launch is xd_tgt[order[p]] (evaluation order != storage order) */)
 {
     __shared__ float s_T[16 * 12];                     // per init: rows 0..2 of its bone's 4x4 (R | t)
     for (int t = threadIdx.x; t < I * 12; t += THREADS) s_T[t] = tfs[(int64_t)bone_ids[t / 12] * 16 + (t % 12)];
@@ -605,9 +606,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
                     n_done = 0;
                     inits = 0;
                     last_ovf = -1;
-                    xt[0] = xd_tgt[(p_begin + c) * 3 + 0];
-                    xt[1] = xd_tgt[(p_begin + c) * 3 + 1];
-                    xt[2] = xd_tgt[(p_begin + c) * 3 + 2];
+                    const int64_t src = order ? (int64_t)order[p_begin + c] : p_begin + c;
+                    xt[0] = xd_tgt[src * 3 + 0];
+                    xt[1] = xd_tgt[src * 3 + 1];
+                    xt[2] = xd_tgt[src * 3 + 2];
                 }
             }
             cur += __popcll(need);
@@ -1068,8 +1070,8 @@ IA_EXPORT int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt, cons
 static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
                        const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold, float dvg_threshold, float eps,
                        float* x, float* J_inv, uint8_t* is_valid, float* fwd_J, uint64_t* counters, int32_t* cnt, uint32_t* meta,
-                       int32_t* ovf_count, int32_t* ovf_head, int32_t* ovf_rec, float* ovf_x, int ovf_cap, ia_stream_t stream,
-                       const char* what)
+                       int32_t* ovf_count, int32_t* ovf_head, int32_t* ovf_rec, float* ovf_x, int ovf_cap, const int32_t* order,
+                       ia_stream_t stream, const char* what)
 {
     if (N == 0) return IA_OK;
     IA_REQUIRE(I >= 1 && I <= 16, "speculative search: 1 <= I <= 16 inits");
@@ -1086,7 +1088,7 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
 #define IA_SPEC_LAUNCH(COUNT, PACK)                                                                                                    \
     broyden_spec_kernel<COUNT, PACK><<<grid, THREADS, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,         \
                                                                cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J, pts, c, cnt, \
-                                                               meta, ovf_count, ovf_head, ovf_rec, ovf_x, ovf_cap, slots)
+                                                               meta, ovf_count, ovf_head, ovf_rec, ovf_x, ovf_cap, slots, order)
     if (pack) { if (counters) IA_SPEC_LAUNCH(true, true); else IA_SPEC_LAUNCH(false, true); }
     else { if (counters) IA_SPEC_LAUNCH(true, false); else IA_SPEC_LAUNCH(false, false); }
 #undef IA_SPEC_LAUNCH
@@ -1099,7 +1101,7 @@ IA_EXPORT int ia_fuse_broyden_spec(int64_t N, int I, const float* xd_tgt, const 
                                    uint64_t* counters, ia_stream_t stream)
 {
     return launch_spec(false, N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x, J_inv,
-                       is_valid, fwd_J, counters, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream, "ia_fuse_broyden_spec");
+                       is_valid, fwd_J, counters, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, stream, "ia_fuse_broyden_spec");
 }
 
 IA_EXPORT int ia_spec_rows_slots(void) { return SPEC_ROOTS; }
@@ -1126,7 +1128,7 @@ IA_EXPORT int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, c
                                         const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold,
                                         float dvg_threshold, float eps, float* x_rows, float* J_inv, float* fwd_J, int32_t* cnt,
                                         uint32_t* meta, int32_t* start, int32_t* ovf_head, void* ovf_scratch, int32_t* total_and_overflow,
-                                        void* scan_tmp, uint64_t* counters, ia_stream_t stream)
+                                        void* scan_tmp, uint64_t* counters, const int32_t* order, ia_stream_t stream)
 {
     IA_REQUIRE(eps >= 1e-4f, "ia_fuse_broyden_spec_rows: eps must be >= 1e-4 (the completed searches are K9's survivors only then)");
     IA_REQUIRE(N * I < ((int64_t)1 << 31), "ia_fuse_broyden_spec_rows: N * I must stay below 2^31");
@@ -1138,7 +1140,7 @@ IA_EXPORT int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, c
         return ia::check_launch("ia_fuse_broyden_spec_rows");
     }
     int r = launch_spec(true, N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x_rows,
-                        J_inv, nullptr, fwd_J, counters, cnt, meta, o.count, ovf_head, o.rec, o.x, SPEC_OVF_CAP, stream,
+                        J_inv, nullptr, fwd_J, counters, cnt, meta, o.count, ovf_head, o.rec, o.x, SPEC_OVF_CAP, order, stream,
                         "ia_fuse_broyden_spec_rows");
     if (r != IA_OK) return r;
     rows_extras_kernel<<<64, THREADS, 0, s>>>(o.count, SPEC_OVF_CAP, o.rec, o.x, o.keep, cnt);

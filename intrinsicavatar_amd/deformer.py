@@ -153,7 +153,7 @@ class SNARFDeformer:
     SPEC_ROWS = os.environ.get("IA_BROYDEN_SPEC_ROWS", "1") == "1"
 
     @torch.no_grad()
-    def _candidates(self, pts: Tensor, with_src: bool, want_fwd: bool = False, want_jinv: bool = False):
+    def _candidates(self, pts: Tensor, with_src: bool, want_fwd: bool = False, want_jinv: bool = False, order: Optional[Tensor] = None):
         """search + candidate bookkeeping for P posed points -> (cand_x [Q,3], cand_src [Q] | None, cnt [P], start [P], Q, fwd_J, J_inv).
         Large batches (speculative search, eps >= 1e-4): the search kernel itself leaves each point's surviving candidates in its
         3-slot row plus their count and the scan of the counts (fast_snarf.fuse_broyden_spec_rows: 44 B per point instead of 169) --
@@ -162,6 +162,8 @@ class SNARFDeformer:
         P, I = pts.shape[0], self.init_bones.shape[0]
         dev = self.device
         if not (self.SPEC_ROWS and self.spec_eps >= 1e-4 and P >= self.SPEC_MIN_POINTS and self.tfs.shape[0] == 1):
+            if order is not None:
+                pts = pts[order.long()].contiguous()
             r = self.search(pts, want_fwd=want_fwd, want_jinv=want_jinv)
             x, valid, fwd = r[0], r[1], r[2]
             J_inv = r[3] if want_jinv else None
@@ -177,12 +179,14 @@ class SNARFDeformer:
         tot = torch.empty(2, dtype=torch.int32, device=dev)
         fast_snarf.fuse_broyden_spec_rows(x_rows, pts.reshape(1, P, 3), fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs, self.init_bones,
                                           Jinv, cnt, meta, start, ovf_head, self._ovf_scratch, tot, self.offset_kernel, self.scale_kernel,
-                                          1e-5, 1e-1, self.spec_eps, fwd_J=fwd, counters=self.spec_counters)
+                                          1e-5, 1e-1, self.spec_eps, fwd_J=fwd, counters=self.spec_counters, order=order)
         Q, n_over = tot.tolist()                                     # the one read-back of the call
         self.last_overflow_records = n_over
         if n_over > self._ovf_cap:
             # more 4th.. candidates than the overflow list holds (never seen): this batch goes through is_valid + K9 instead
             del x_rows, cnt, meta, start, Jinv, fwd
+            if order is not None:
+                pts = pts[order.long()].contiguous()
             r = self.search(pts, want_fwd=want_fwd, want_jinv=want_jinv)
             return (*self._pack_candidates(r[0], r[1], with_src=with_src), r[2], (r[3] if want_jinv else None))
         cand_x = torch.empty((Q, 3), device=dev)
@@ -195,12 +199,14 @@ class SNARFDeformer:
     def deform_sdf(self, pts: Tensor, geometry, order: Optional[Tensor] = None) -> Tensor:
         """SDF at posed points, nothing else: SNARFDeformer.deform with with_grad = with_feature = False as the no-grad coarse
         passes call it (coarse_alpha_fn / alpha_fn / coarse_alpha_sdf_fn).  Same search, filter and min-select as deform();
-        the candidates go through geometry.sdf_only and only sdf [P] is produced (1e5 where no candidate survives)."""
+        the candidates go through geometry.sdf_only and only sdf [P] is produced (1e5 where no candidate survives).
+        order (int32 permutation, optional): evaluate the points in that order (pts[order[k]] is the k-th point searched; the
+        search reads through the index, no gathered copy) -- the result comes back in the caller's order."""
         pts = pts.contiguous().float()
         P, I = pts.shape[0], self.init_bones.shape[0]
         dev = self.device
         lib, st = L.lib(), L.stream()
-        cand_x, _, cnt, start, Q, _, _ = self._candidates(pts, with_src=False)
+        cand_x, _, cnt, start, Q, _, _ = self._candidates(pts, with_src=False, order=order)
         csdf = geometry.sdf_only(cand_x)
         sdf = torch.empty(P, device=dev)
         if order is not None:         # pts = caller's points[order]: the result goes back to the caller's order on the way out

@@ -95,13 +95,17 @@ def fuse_broyden_spec(x: Tensor, xd_tgt: Tensor, voxel_J: ChannelLastVoxelJ, tfs
 def fuse_broyden_spec_rows(x_rows: Tensor, xd_tgt: Tensor, voxel_J: ChannelLastVoxelJ, tfs: Tensor, bone_ids: Tensor, J_inv: Tensor,
                            cnt: Tensor, meta: Tensor, start: Tensor, ovf_head: Tensor, ovf_scratch: Tensor, total_and_overflow: Tensor,
                            offset: Tensor, scale: Tensor, cvg_threshold: float, dvg_threshold: float, eps: float, fwd_J: Tensor = None,
-                           counters: Tensor = None) -> None:
+                           counters: Tensor = None, order: Tensor = None, n_points: int = None) -> None:
     """fuse_broyden_spec with the candidate bookkeeping in the kernel (ia_fuse_broyden_spec_rows; eps >= 1e-4): no x [N,I,3], no
     is_valid, no filter pass -- x_rows [N,3,3] receives each point's surviving candidates (highest init first), cnt [N] int32 their
     number, meta [N] int32 their inits (one byte each; bit 31: the point has overflow records), start [N] the exclusive scan of
     cnt, ovf_head [N] int32 + ovf_scratch (uint8 [ia_spec_rows_overflow_bytes()]) the rare 4th.. candidates, total_and_overflow [2]
-    int32 = (Q, number of overflow records).  J_inv / fwd_J at [point, init] as fuse_broyden."""
+    int32 = (Q, number of overflow records).  J_inv / fwd_J at [point, init] as fuse_broyden.
+    order (int32 [N], optional): point p of the launch is xd_tgt[0, order[p]] -- the caller's points are searched in another
+    order (spatially sorted) than they are stored, without a gathered copy."""
     B, N, _ = xd_tgt.shape
+    if order is not None:
+        N = order.shape[0]
     I = bone_ids.shape[0]
     assert B == 1 and isinstance(voxel_J, ChannelLastVoxelJ) and voxel_J.data.shape[0] == 1
     _, D, H, W, _ = voxel_J.data.shape
@@ -115,7 +119,7 @@ def fuse_broyden_spec_rows(x_rows: Tensor, xd_tgt: Tensor, voxel_J: ChannelLastV
         L.ptr(tfs.contiguous().float()), L.ptr(bone_ids.contiguous().to(torch.int32)), L.ptr(offset.reshape(3).contiguous().float()),
         L.ptr(scale.reshape(3).contiguous().float()), L.f32(cvg_threshold), L.f32(dvg_threshold), L.f32(eps), L.ptr(x_rows), L.ptr(J_inv),
         L.ptr(fwd_J), L.ptr(cnt), L.ptr(meta), L.ptr(start), L.ptr(ovf_head), L.ptr(ovf_scratch), L.ptr(total_and_overflow),
-        L.ptr(L.scan_tmp(N, xd_tgt.device)), L.ptr(counters), L.stream()), "ia_fuse_broyden_spec_rows")
+        L.ptr(L.scan_tmp(N, xd_tgt.device)), L.ptr(counters), L.ptr(order), L.stream()), "ia_fuse_broyden_spec_rows")
 
 
 def filter(x: Tensor, mask: Tensor) -> Tensor:

@@ -80,6 +80,8 @@ def traverse_grids(
     grid_bits: Optional[Tensor] = None,  # extension: pre-packed bits of `binaries` (skips re-packing)
     max_extent: Optional[float] = None,  # extension: upper bound of (far - near) over all rays, tightens the output capacity
     method: Optional[str] = None,        # extension: "fused" (single launch, default) | "two_pass"; env IA_TRAVERSE overrides
+    incoherent: bool = False,            # extension: hint -- neighbouring rays point anywhere (secondary rays): the fused kernel walks
+                                         # each tile's rays in order of their box-crossing span; outputs are identical either way
 ) -> Tuple[RayIntervals, RaySamples, Tensor]:
     """nerfacc.traverse_grids (call sites temporal_occ_grid.py:166-175, intrinsic_avatar.py:84-93).
 
@@ -110,7 +112,7 @@ def traverse_grids(
     # 1.20 ms), the two-phase protocol for one 540x540 frame of primary rays (0.14 vs 0.16 ms)
     method = method or os.environ.get("IA_TRAVERSE") or ("fused" if n_rays >= FUSED_MIN_RAYS else "two_pass")
     if method == "fused" and n_rays > 0 and step_size > 0 and cone_angle == 0.0:
-        out = _traverse_fused(args, n_rays, aabbs[0], step_size, max_extent, dev)
+        out = _traverse_fused(args, n_rays, aabbs[0], step_size, max_extent, dev, incoherent)
         if out is not None:
             return out
 
@@ -145,7 +147,7 @@ FUSED_MIN_RAYS = 1 << 19
 _AABB_DIAG = {}
 
 
-def _traverse_fused(args, n_rays, aabb, step_size, max_extent, dev):
+def _traverse_fused(args, n_rays, aabb, step_size, max_extent, dev, incoherent=False):
     """single-launch traversal into capacity-sized buffers (ia_traverse_grids_fused); None = capacity exceeded."""
     key = (aabb.data_ptr(), aabb._version)
     if key not in _AABB_DIAG:            # one tiny D2H copy per grid, not per call
@@ -171,7 +173,8 @@ def _traverse_fused(args, n_rays, aabb, step_size, max_extent, dev):
     pinfo = torch.empty((2, n_rays, 2), dtype=torch.int64, device=dev)
     L.check(lib.ia_traverse_grids_fused(*args, L.ptr(scratch), L.i64(cap_e), L.i64(cap_s), L.ptr(totals), L.ptr(pinfo[0]),
                                         L.ptr(pinfo[1]), L.ptr(iv_vals), L.ptr(iv_flags[0]), L.ptr(iv_flags[1]), L.ptr(iv_ray),
-                                        L.ptr(sm_vals), L.ptr(sm_ray), L.ptr(term), L.ptr(sm_ends[0]), L.ptr(sm_ends[1]), st),
+                                        L.ptr(sm_vals), L.ptr(sm_ray), L.ptr(term), L.ptr(sm_ends[0]), L.ptr(sm_ends[1]),
+                                        L.i32(1 if incoherent else 0), st),
             "ia_traverse_grids_fused")
     E, S, ovf = (int(v) for v in totals.tolist())          # the one host sync (output sizes are data dependent)
     if ovf:

@@ -120,11 +120,9 @@ class RenderStep:
             return torch.cat([self._sdf_at(pts[a:a + self.MAX_SEARCH_POINTS]) for a in range(0, n, self.MAX_SEARCH_POINTS)])
         if n < self.SORT_MIN_POINTS or os.environ.get("IA_SORT_POINTS", "1") != "1":
             return self.deformer.deform_sdf(pts, self.geometry)
-        lib, st = L.lib(), L.stream()
-        order = self._spatial_order(pts)
-        ps = torch.empty_like(pts)
-        L.check(lib.ia_gather_rows3_i32(L.i64(n), L.ptr(pts), L.ptr(order), L.ptr(ps), st), "ia_gather_rows3_i32")
-        return self.deformer.deform_sdf(ps, self.geometry, order=order)      # the min-select writes through `order`
+        # the search reads the points THROUGH the permutation and the min-select writes through it: no gathered copy of the points
+        # (the 12-byte random gather dragged 64-byte sectors: 4.7 x its algorithmic bytes, profiles/r02_pmc_traffic.json)
+        return self.deformer.deform_sdf(pts, self.geometry, order=self._spatial_order(pts))
 
     # ------------------------------------------------------------------ sampling (no grad)
     @torch.no_grad()
@@ -275,7 +273,7 @@ class RenderStep:
             m = ro.shape[0]
             intervals, samples, _ = nerfacc.traverse_grids(
                 ro, rd, self.binaries, self.aabbs, torch.full((m,), near, device=dev), torch.full((m,), far, device=dev),
-                step, 0.0, grid_bits=self.grid_bits, max_extent=far - near)
+                step, 0.0, grid_bits=self.grid_bits, max_extent=far - near, incoherent=True)
             if samples.vals.shape[0] > 4 * self.MAX_SEARCH_POINTS and m > 1:
                 del intervals, samples
                 work += [(c0 + m // 2, c1), (c0, c0 + m // 2)]

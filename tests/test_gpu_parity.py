@@ -148,13 +148,12 @@ def test_traverse_span_sorted_tiles_equal_the_ray_order_kernel(ops, monkeypatch,
     for name, grid, step in (("checker", (np.indices((64, 64, 64)).sum(0) % 2).astype(bool), 1.7 / 63),
                              ("blob", rng.random((64, 64, 64)) < 0.08, 1.7 / 63), ("dense", rng.random((64, 64, 64)) < 0.7, 0.02)):
         args = (T(o), T(d), T(grid)[None], T(aabb)[None], T(near), T(far), step, 0.0)
-        monkeypatch.setenv("IA_TRAVERSE", "fused")
-        a = tr(*args, method="fused", max_extent=1.75)
-        monkeypatch.setenv("IA_TRAVERSE", "sorted")
-        b = tr(*args, method="fused", max_extent=1.75)
-        monkeypatch.delenv("IA_TRAVERSE")
-        c = tr(*args, method="fused", max_extent=1.75)                 # the default choice for this size (sorted)
-        assert a[1].vals.numel() > 100_000, name
+        a = tr(*args, method="fused", max_extent=1.75)                                  # ray-order tiles
+        b = tr(*args, method="fused", max_extent=1.75, incoherent=True)                 # span-sorted tiles (what the secondary march asks for)
+        monkeypatch.setenv("IA_TRAVERSE_TILES", "span")
+        c = tr(*args, method="fused", max_extent=1.75)                                  # the A / B override
+        monkeypatch.delenv("IA_TRAVERSE_TILES")
+        assert a[1].vals.numel() > 50_000, name
         for other in (b, c):
             for k in ("vals", "packed_info", "ray_indices", "is_left", "is_right"):
                 assert torch.equal(getattr(a[0], k), getattr(other[0], k)), (name, "intervals", k)

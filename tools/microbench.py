@@ -96,7 +96,7 @@ def main():
         def fused():
             L.check(lib.ia_traverse_grids_fused(*a_, L.ptr(fs), L.i64(ce), L.i64(cs), L.ptr(totals), L.ptr(b_pi[0]), L.ptr(b_pi[1]),
                                                 L.ptr(b_iv), L.ptr(b_fl[0]), L.ptr(b_fl[1]), L.ptr(b_ir), L.ptr(b_sv), L.ptr(b_sr),
-                                                L.ptr(b_t), L.ptr(None), L.ptr(None), st))
+                                                L.ptr(b_t), L.ptr(None), L.ptr(None), L.i32(1 if "secondary" in tag else 0), st))
         us = timeit(fused)
         E_, S__, ovf = totals.tolist()
         ab = 48 * m + 16 * S__ + 14 * E_
