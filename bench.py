@@ -54,7 +54,7 @@ HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3     # fp32-in MFMA dense peak
 L1_PEAK_GBPS = 256 * 64 * 2.4    # 256 CUs x 64 B/clk (vector L1 / TCP) x 2.4 GHz = 39.3 TB/s
 VOXEL_J_BYTES = 32 * 128 * 128 * 48
-PROFILE_TAG = "r02"
+PROFILE_TAGS = ("r03", "r02")          # newest committed rocprofv3 PMC summary that knows the kernel wins
 
 
 def algorithmic_bytes(name, calls, extra=None):
@@ -97,17 +97,21 @@ PMC_KERNELS = {
 def pmc_traffic(entry, calls_per_step=None):
     """(HBM-side bytes per launch of the entry point, source) from the committed rocprofv3 PMC passes of THIS command
     (profiles/<tag>_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md), or (None, None)."""
-    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic.json")
-    if entry not in PMC_KERNELS or not os.path.exists(path):
+    if entry not in PMC_KERNELS:
         return None, None
     mode, subs = PMC_KERNELS[entry]
-    ks = json.load(open(path))["kernels"]
-    hits = [v for k, v in ks.items() if any(sub in k for sub in subs)]
-    if not hits:
-        return None, None
-    tot = sum(v["hbm_side_bytes_per_launch"] * v["launches"] for v in hits)
-    calls = sum(v["launches"] for v in hits) if mode == "alt" else max(v["launches"] for v in hits)
-    return int(tot / max(calls, 1)), f"profiles/{PROFILE_TAG}_pmc_traffic.json"
+    for tag in PROFILE_TAGS:
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+        if not os.path.exists(path):
+            continue
+        ks = json.load(open(path))["kernels"]
+        hits = [v for k, v in ks.items() if any(sub in k for sub in subs)]
+        if not hits:
+            continue
+        tot = sum(v["hbm_side_bytes_per_launch"] * v["launches"] for v in hits)
+        calls = sum(v["launches"] for v in hits) if mode == "alt" else max(v["launches"] for v in hits)
+        return int(tot / max(calls, 1)), f"profiles/{tag}_pmc_traffic.json"
+    return None, None
 
 
 def cgroup_throttle():

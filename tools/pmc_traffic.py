@@ -14,7 +14,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = os.environ.get("IA_PROFILE_TAG", "r02")
+TAG = os.environ.get("IA_PROFILE_TAG", "r03")
 CMD = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-config2",
        "--no-breakdown"] + sys.argv[1:]
 
