@@ -157,6 +157,17 @@ int ia_ray_resampling_sdf_fine(int64_t n_rays, const int32_t* packed_info, const
                                const int32_t* resample_packed_info, float* resample_starts,
                                float* resample_ends, uint8_t* is_fg_sample, ia_stream_t stream);
 
+/* Foreground compaction of a fine re-sampling (the caller side of K3 / K4: models/intrinsic_avatar.py:516-528 keeps the
+ * intervals with is_fg -- three boolean-mask gathers + unpack_info -- and packs the kept ray indices again).  A ray's re-samples
+ * are consecutive: ia_fg_count: cnt [n_rays] = kept intervals per ray, start = exclusive scan, *total = F (scan_tmp:
+ * ia_scan_tmp_bytes(n_rays)); ia_fg_compact: ray_indices i64 [F], t_starts / t_ends [F] in ray order, out_packed_info i32
+ * [n_rays,2] = pack_info(ray_indices, n_rays). */
+int ia_fg_count(int64_t n_rays, const int32_t* resampled_packed_info, const uint8_t* is_fg, int32_t* cnt, int32_t* start, int32_t* total,
+                void* scan_tmp, ia_stream_t stream);
+int ia_fg_compact(int64_t n_rays, const int32_t* resampled_packed_info, const uint8_t* is_fg, const float* starts, const float* ends,
+                  const int32_t* cnt, const int32_t* start, int64_t* ray_indices, float* t_starts, float* t_ends, int32_t* out_packed_info,
+                  ia_stream_t stream);
+
 /* ------------------------------------------------------------------------- */
 /* fast-SNARF deformer kernels (models/deformers/fast_snarf/deformer_torch.py:86-125,
  * cuda/precompute/precompute.cu:24-103, cuda/fuse_kernel/fuse_cuda_kernel_fast.cu:250-452,

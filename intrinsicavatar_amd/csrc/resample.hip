@@ -325,6 +325,42 @@ __global__ __launch_bounds__(THREADS) void k34_fine_kernel(
     }
 }
 
+
+// ---- foreground compaction of a fine re-sampling (K3 / K4 outputs) -----------------------------------------------------------
+// The caller of ray_resampling_sdf_fine keeps the foreground intervals only (models/intrinsic_avatar.py:516-528: three
+// boolean-mask gathers + unpack_info, then pack_info of the kept ray indices).  A ray's re-samples are consecutive, so: count per
+// ray -> scan over RAYS -> every ray copies its kept intervals to its place and writes its own packed_info row.
+__global__ __launch_bounds__(THREADS) void fg_count_kernel(int64_t n_rays, const int32_t* __restrict__ rpi, const uint8_t* __restrict__ is_fg,
+                                                            int32_t* __restrict__ cnt)
+{
+    const int64_t r = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (r >= n_rays) return;
+    const int b = rpi[2 * r], s = rpi[2 * r + 1];
+    int c = 0;
+    for (int j = 0; j < s; j++) c += is_fg[b + j] ? 1 : 0;
+    cnt[r] = c;
+}
+
+__global__ __launch_bounds__(THREADS) void fg_compact_kernel(int64_t n_rays, const int32_t* __restrict__ rpi, const uint8_t* __restrict__ is_fg,
+                                                              const float* __restrict__ starts, const float* __restrict__ ends,
+                                                              const int32_t* __restrict__ cnt, const int32_t* __restrict__ start,
+                                                              int64_t* __restrict__ ray_indices, float* __restrict__ t_starts,
+                                                              float* __restrict__ t_ends, int32_t* __restrict__ out_pinfo)
+{
+    const int64_t r = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (r >= n_rays) return;
+    const int c = cnt[r];
+    const int q0 = start[r];
+    out_pinfo[2 * r] = q0;                                   // (cumsum - count, count): what pack_info of the kept ray indices gives
+    out_pinfo[2 * r + 1] = c;
+    if (c == 0) return;
+    const int b = rpi[2 * r], s = rpi[2 * r + 1];
+    int q = q0;
+    for (int j = 0; j < s; j++) {
+        if (is_fg[b + j]) { ray_indices[q] = r; t_starts[q] = starts[b + j]; t_ends[q] = ends[b + j]; q++; }
+    }
+}
+
 }  // namespace
 
 IA_EXPORT int ia_resample_packed_info(int64_t n_rays, const int32_t* packed_info, int n, int add_steps,
@@ -434,4 +470,26 @@ IA_EXPORT int ia_ray_resampling_sdf_fine(int64_t n_rays, const int32_t* packed_i
         n_rays, packed_info, starts, ends, alphas, sdfs, resample_packed_info, resample_starts, resample_ends,
         is_fg_sample);
     return ia::check_launch("ia_ray_resampling_sdf_fine");
+}
+
+// count / compact the foreground intervals of a fine re-sampling; cnt, start: int32 [n_rays] (start = exclusive scan of cnt),
+// total [1] = F; out_packed_info int32 [n_rays, 2] = pack_info of the kept ray indices
+IA_EXPORT int ia_fg_count(int64_t n_rays, const int32_t* resampled_packed_info, const uint8_t* is_fg, int32_t* cnt, int32_t* start,
+                          int32_t* total, void* scan_tmp, ia_stream_t stream)
+{
+    if (n_rays == 0) return ia_exclusive_scan_i32(nullptr, nullptr, total, 0, scan_tmp, stream);
+    fg_count_kernel<<<ia::cdiv(n_rays, THREADS), THREADS, 0, (hipStream_t)stream>>>(n_rays, resampled_packed_info, is_fg, cnt);
+    int r = ia::check_launch("ia_fg_count");
+    if (r != IA_OK) return r;
+    return ia_exclusive_scan_i32(cnt, start, total, n_rays, scan_tmp, stream);
+}
+
+IA_EXPORT int ia_fg_compact(int64_t n_rays, const int32_t* resampled_packed_info, const uint8_t* is_fg, const float* starts, const float* ends,
+                            const int32_t* cnt, const int32_t* start, int64_t* ray_indices, float* t_starts, float* t_ends,
+                            int32_t* out_packed_info, ia_stream_t stream)
+{
+    if (n_rays == 0) return IA_OK;
+    fg_compact_kernel<<<ia::cdiv(n_rays, THREADS), THREADS, 0, (hipStream_t)stream>>>(n_rays, resampled_packed_info, is_fg, starts, ends, cnt,
+                                                                                      start, ray_indices, t_starts, t_ends, out_packed_info);
+    return ia::check_launch("ia_fg_compact");
 }

@@ -124,6 +124,31 @@ def ray_resampling_sdf_fine(packed_info, t_starts, t_ends, alphas, sdfs, n_sampl
     return _fine(packed_info, t_starts, t_ends, alphas, sdfs, n_samples, True)
 
 
+@torch.no_grad()
+def compact_foreground(resampled_packed_info: Tensor, starts: Tensor, ends: Tensor, is_fg: Tensor):
+    """what the caller of ray_resampling_fine / _sdf_fine does with the result (models/intrinsic_avatar.py:516-528):
+        ray_indices = unpack_info(packed_info, T)[is_fg];  t_starts = starts[is_fg];  t_ends = ends[is_fg];  pack_info(ray_indices)
+    as a count -> scan over rays -> segmented copy (ia_fg_count / ia_fg_compact): one size read-back instead of three.
+    -> (ray_indices int64 [F], t_starts [F], t_ends [F], packed_info int32 [n_rays, 2])."""
+    n_rays = resampled_packed_info.shape[0]
+    dev = starts.device
+    rpi = resampled_packed_info.to(torch.int32).contiguous()
+    fg = is_fg.contiguous()
+    st_, en_ = starts.reshape(-1).contiguous().float(), ends.reshape(-1).contiguous().float()
+    lib, st = L.lib(), L.stream()
+    cnt, start = (torch.empty(n_rays, dtype=torch.int32, device=dev) for _ in range(2))
+    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    L.check(lib.ia_fg_count(L.i64(n_rays), L.ptr(rpi), L.ptr(fg), L.ptr(cnt), L.ptr(start), L.ptr(total), L.ptr(L.scan_tmp(n_rays, dev)), st),
+            "ia_fg_count")
+    F_ = int(total.item())
+    ray_indices = torch.empty(F_, dtype=torch.int64, device=dev)
+    ts, te = torch.empty(F_, device=dev), torch.empty(F_, device=dev)
+    pinfo = torch.empty((n_rays, 2), dtype=torch.int32, device=dev)
+    L.check(lib.ia_fg_compact(L.i64(n_rays), L.ptr(rpi), L.ptr(fg), L.ptr(st_), L.ptr(en_), L.ptr(cnt), L.ptr(start), L.ptr(ray_indices),
+                              L.ptr(ts), L.ptr(te), L.ptr(pinfo), st), "ia_fg_compact")
+    return ray_indices, ts, te, pinfo
+
+
 # ----------------------------------------------------------------------------- pack / unpack
 def pack_data(data: Tensor, mask: Tensor) -> Tuple[Tensor, Tensor]:
     """lib/nerfacc/pack.py:12-43 (host-side torch ops in the reference too)."""

@@ -287,8 +287,8 @@ class RenderStep:
             alphas = laplace_alpha(sdf, t_ends - t_starts, beta)
             pinfo = lib_nerfacc.pack_info(ray_indices, m)
             rpi, rs, re, is_fg = lib_nerfacc.ray_resampling_sdf_fine(pinfo, t_starts[:, None], t_ends[:, None], alphas, sdf, 4)
-            rri = lib_nerfacc.unpack_info(rpi, rs.shape[0])
-            ray_indices, t_starts, t_ends = rri[is_fg], rs[is_fg, 0], re[is_fg, 0]
+            # keep the foreground intervals (:516-528): count -> scan over rays -> segmented copy, and the packed_info of the kept list
+            ray_indices, t_starts, t_ends, pinfo = lib_nerfacc.compact_foreground(rpi, rs, re, is_fg)
             if t_starts.numel() == 0:
                 continue                                   # no zero crossing anywhere: fully transmissive
             # rendering(rgb_alpha_fn) (:430-456, volrend.py:19-194)
@@ -314,7 +314,6 @@ class RenderStep:
                 _, normal_world, refl01 = shade_prep(d["sdf_grad"], rd, ray_indices, w2s_rot)
                 a = laplace_alpha(d["sdf"], t_ends - t_starts, beta)
                 rgbs = self.radiance(d["pts_cano"], d["feature"], refl01, normal_world)
-            pinfo = lib_nerfacc.pack_info(ray_indices, m)
             w, _ = nerfacc.render_weight_from_alpha(a, packed_info=pinfo)
             acc = nerfacc._Accumulate.apply(w, None, ray_indices, pinfo)
             tr[c0:c0 + m] = 1.0 - acc

@@ -491,3 +491,24 @@ def test_filter_compact_single_pass_equals_the_three_step_path(P, I, in_place):
     L.check(lib.ia_deform_pack_tiles(L.i64(P), L.i32(I), L.ptr(xin), L.ptr(src_local), L.ptr(start), L.ptr(cx), L.ptr(cs), L.ptr(tmp3), st),
             "pack")
     assert torch.equal(start, start0) and torch.equal(cx, cx0) and (cs is None or torch.equal(cs, cs0))
+
+
+def test_foreground_compaction_equals_the_reference_op_sequence(ops):
+    """lib_nerfacc.compact_foreground (ia_fg_count / ia_fg_compact) == unpack_info + three boolean-mask gathers + pack_info
+    (models/intrinsic_avatar.py:516-528) on K4-shaped data: rays with 0 or 4 re-samples, any subset of them foreground."""
+    LN = ops["lib"]
+    rng = np.random.default_rng(4)
+    n = 50_000
+    cnt = np.where(rng.random(n) < 0.7, 4, 0).astype(np.int32)
+    rpi = np.stack([np.cumsum(cnt) - cnt, cnt], -1).astype(np.int32)
+    Tn = int(cnt.sum())
+    starts, ends = rng.random((Tn, 1), dtype=np.float32), rng.random((Tn, 1), dtype=np.float32)
+    is_fg = rng.random(Tn) < 0.4
+    is_fg[: 4 * 10] = False                                              # leading rays without any foreground interval
+    ri, ts, te, pinfo = LN.compact_foreground(T(rpi), T(starts), T(ends), T(is_fg))
+    rri = LN.unpack_info(T(rpi), Tn)
+    m = T(is_fg)
+    assert torch.equal(ri, rri[m]) and torch.equal(ts, T(starts)[m, 0]) and torch.equal(te, T(ends)[m, 0])
+    assert torch.equal(pinfo, LN.pack_info(rri[m], n))
+    e = LN.compact_foreground(T(rpi), T(starts), T(ends), T(np.zeros(Tn, bool)))
+    assert e[0].numel() == 0 and int(e[3][:, 1].sum()) == 0
