@@ -490,162 +490,10 @@ __global__ __launch_bounds__(SH_WAVES * 64) void sdf_head_pipelined_kernel(int64
     }
 }
 
-// ---- the same pipeline with the level-major features DMA'd straight into LDS (gfx950 global_load_lds_dwordx4) ---------------
-// The hash features arrive level-major (float2 [16][n]), and the layer-1 A operand of k-step kk is exactly level kk of the tile:
-// kept LEVEL-MAJOR in LDS ([16][32 rows] float2), lane (lr, lk) reads float (kk * 32 + lr) * 2 + lk -- consecutive lanes,
-// consecutive words, no transposition.  So four wave-wide 16-byte LDS-direct loads per tile replace 8 register loads + 16
-// ds_write per lane, nothing of the next-next tile lives in registers, and the loads are issued a whole iteration before
-// their tile is multiplied.  The output-layer reduce pre-adds lane pairs (DPP) and goes through a 2 KB swizzled scratch.
-// n must be even (16-byte alignment of every level's rows); odd n takes sdf_head_pipelined_kernel.
-template <int SH_WAVES>
-__global__ __launch_bounds__(SH_WAVES * 64) void sdf_head_lds_kernel(int64_t n, const float2* __restrict__ levels,
-                                                                     const float* __restrict__ xp, const float* __restrict__ W1,
-                                                                     const float* __restrict__ b1, const float* __restrict__ Wo,
-                                                                     const float* __restrict__ bo, float* __restrict__ sdf)
-{
-    constexpr int ROWB = 16 * 32 * 2;                            // floats of one level-major row buffer (4 KB)
-    constexpr int PER_WAVE = 2 * ROWB + 2 * 128 + 512;           // 2 row buffers, 2 xyz buffers [32][4], reduce scratch [32][16]
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sW1 = smem;                                           // [64][SH_LDW]
-    float* sWv = sW1 + ((64 * SH_LDW + 3) & ~3) + (threadIdx.x >> 6) * PER_WAVE;
-    float* const sRow0 = sWv;                                     // + b * ROWB
-    float* const sXyz0 = sWv + 2 * ROWB;                          // + b * 128
-    float* const sRed = sWv + 2 * ROWB + 256;
-    const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < 64 * SH_LDW; i += SH_WAVES * 64) {
-        const int r = i / SH_LDW, c = i % SH_LDW;
-        sW1[i] = (c < 35) ? W1[r * 35 + c] : 0.0f;
-    }
-    __syncthreads();
-    const int lr = lane & 31, lk = lane >> 5;
-    const float w0 = 0.01f * Wo[lr], w1 = 0.01f * Wo[32 + lr], bb0 = 100.0f * b1[lr], bb1 = 100.0f * b1[32 + lr], bout = bo[0];
-    const int64_t n_tiles = (n + 31) / 32;
-    const int64_t stride = (int64_t)gridDim.x * SH_WAVES;
-    int64_t tile = (int64_t)blockIdx.x * SH_WAVES + (tid >> 6);
-    if (tile >= n_tiles) return;
-    // DMA of one tile: 4 instructions x (64 lanes x 16 B): lane -> (level group, 2 rows)
-    auto dma = [&](int64_t tl, float* dst) {
-        const int64_t p0 = tl * 32;
-        const int lvl_l = lane >> 4, ch = lane & 15;
-        const bool ok = p0 + 2 * ch < n;                         // n even: a 16-byte piece is wholly inside or wholly outside
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const float2* src = levels + (int64_t)(4 * g + lvl_l) * n + p0 + 2 * ch;
-            if (ok) __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(dst + g * 256), 16, 0, 0);
-        }
-    };
-    auto xyz_load = [&](int64_t tl, float v[2]) {
-        const int64_t p0 = tl * 32;
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int i = j * 64 + lane;
-            v[j] = (i < 96 && p0 + i / 3 < n) ? xp[p0 * 3 + i] : 0.5f;
-        }
-    };
-    auto xyz_store = [&](const float v[2], float* dst) {
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int i = j * 64 + lane;
-            if (i < 96) { const int row = i / 3, c = i - row * 3; dst[row * 4 + c] = v[j] * 2.0f - 1.0f; }
-        }
-        if (lane < 32) dst[lane * 4 + 3] = 0.0f;
-    };
-    auto a_operand = [&](const float* sRow, const float* sXyz, int kk) -> float {
-        return kk < 16 ? sRow[(kk * 32 + lr) * 2 + lk] : sXyz[lr * 4 + 2 * (kk - 16) + lk];
-    };
-
-    f32x16 accA0, accA1, accB0, accB1;
-    float xv[2];
-    // prologue: tile 0 -> buffer 0 -> layer 1 -> accA; tile 1 -> buffer 1 (in flight)
-    dma(tile, sRow0);
-    xyz_load(tile, xv);
-    xyz_store(xv, sXyz0);
-    if (tile + stride < n_tiles) { dma(tile + stride, sRow0 + ROWB); xyz_load(tile + stride, xv); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int r = 0; r < 16; r++) { accA0[r] = 0.f; accA1[r] = 0.f; }
-#pragma unroll
-    for (int kk = 0; kk < 18; kk++) {
-        const int k = 2 * kk + lk;
-        const float a = a_operand(sRow0, sXyz0, kk), b0 = sW1[lr * SH_LDW + k], b1v = sW1[(32 + lr) * SH_LDW + k];
-        accA0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, accA0, 0, 0, 0);
-        accA1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1v, accA1, 0, 0, 0);
-    }
-    if (tile + stride < n_tiles) xyz_store(xv, sXyz0 + 128);
-    int cur = 0;                                                  // buffer whose rows (tile `tile`) are consumed
-    for (;; tile += stride) {
-        const bool have_next = tile + stride < n_tiles;           // its rows: buffer cur ^ 1 (DMA issued one iteration ago)
-        const bool have_next2 = tile + 2 * stride < n_tiles;
-        float* sRowC = sRow0 + cur * ROWB;
-        float* sXyzC = sXyz0 + cur * 128;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the DMA of tile t+1 has landed
-        if (have_next2) { dma(tile + 2 * stride, sRowC); xyz_load(tile + 2 * stride, xv); }      // a whole iteration to land
-        float part[16];
-        const float* sN = sRow0 + (cur ^ 1) * ROWB;
-        const float* sNx = sXyz0 + (cur ^ 1) * 128;
-#pragma unroll
-        for (int r = 0; r < 16; r++) { accB0[r] = 0.f; accB1[r] = 0.f; }
-        // (a wave whose last tile has no successor runs the MFMAs below on stale rows: one wasted layer-1 per wave, no second code path)
-        {
-        float an = a_operand(sN, sNx, 0), b0n = sW1[lr * SH_LDW + lk], b1n = sW1[(32 + lr) * SH_LDW + lk];
-#pragma unroll
-        for (int kk = 0; kk < 18; kk++) {
-            const float a = an, b0 = b0n, b1v = b1n;
-            if (kk + 1 < 18) {
-                const int k = 2 * (kk + 1) + lk;
-                an = a_operand(sN, sNx, kk + 1); b0n = sW1[lr * SH_LDW + k]; b1n = sW1[(32 + lr) * SH_LDW + k];
-            }
-            accB0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, accB0, 0, 0, 0);
-            if (kk < 16) part[kk] = softplus100_times(accA0[kk], bb0, w0, 0.0f);
-            accB1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1v, accB1, 0, 0, 0);
-            if (kk < 16) part[kk] = softplus100_times(accA1[kk], bb1, w1, part[kk]);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-        }
-        }
-        // output layer: lane pairs (lr, lr ^ 1) pre-added (DPP quad_perm [1,0,3,2]), even lanes store 16 partials per row into the
-        // swizzled scratch, lane (row = lr, half = lk) sums 8 of them, the halves meet in one cross-lane add
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part[r]), 0xB1, 0xF, 0xF, true));
-            const float pr = part[r] + o;
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (!(lr & 1)) sRed[row * 16 + (((lr >> 1) + row) & 15)] = pr;
-        }
-        float sum = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 8; j++) sum += sRed[lr * 16 + ((lk * 8 + j + lr) & 15)];
-        sum += __shfl_xor(sum, 32, 64);
-        const int64_t p = tile * 32 + lr;
-        if (lk == 0 && p < n) sdf[p] = sum + bout;
-        if (!have_next) break;
-        if (have_next2) xyz_store(xv, sXyzC);
-        accA0 = accB0; accA1 = accB1;
-        cur ^= 1;
-    }
-}
-
-template <int SH_WAVES>
-static int launch_sdf_head_lds(int64_t n, const void* levels, const float* xp, const float* W1, const float* b1, const float* Wo,
-                               const float* bo, float* sdf, hipStream_t s)
-{
-    constexpr size_t lds = sizeof(float) * (((64 * SH_LDW + 3) & ~3) + SH_WAVES * (2 * 1024 + 2 * 128 + 512));
-    static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)sdf_head_lds_kernel<SH_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
-    const int64_t n_tiles = (n + 31) / 32;
-    int grid = (int)((n_tiles + SH_WAVES - 1) / SH_WAVES);
-    if (grid > 256) grid = 256;
-    sdf_head_lds_kernel<SH_WAVES><<<grid, SH_WAVES * 64, lds, s>>>(n, reinterpret_cast<const float2*>(levels), xp, W1, b1, Wo, bo, sdf);
-    return ia::check_launch("ia_sdf_levels_fwd");
-}
-
+// (tried: the same pipeline with the level-major features DMA'd straight into LDS -- gfx950 global_load_lds_dwordx4, the tile kept
+//  level-major so that the layer-1 A operand needs no transposition, nothing of the next-next tile in registers: 3.25 ms per
+//  50 M points at 12 waves per CU, exactly what this kernel does at 12 waves once both reached it without spills -- the row
+//  loads were not what limits it.  Not kept.)
 template <int SH_WAVES>
 static int launch_sdf_head_pipelined(int64_t n, const void* levels, const float* xp, const float* W1, const float* b1, const float* Wo,
                                      const float* bo, float* sdf, hipStream_t s)
@@ -711,15 +559,11 @@ IA_EXPORT int ia_sdf_levels_fwd(int64_t n, const void* levels, const float* xp, 
     if (n == 0) return IA_OK;
     IA_REQUIRE(n < ((int64_t)1 << 31), "ia_sdf_levels_fwd: at most 2^31 points per call");
     {
-        // default: two tiles per wave, 8 waves per CU (219 VGPRs, no spills): 3.38 ms per 50 M points against 4.80 ms of the
-        // one-tile-per-wave kernel ("tile") and 8.9 ms with 12 waves ("pipe12": 116 spilled registers)
+        // default: two tiles per wave, 12 waves per CU (162 VGPRs, no spills): 3.25 ms per 50 M points = 0.45 of the fp32 MFMA peak,
+        // against 4.80 ms (0.31) of the one-tile-per-wave kernel ("tile"); 8 waves per CU ("pipe8"): 3.45 ms
         const char* e = getenv("IA_SDF_HEAD");
-        if (e && e[0] == 'l' && (n & 1) == 0 && (reinterpret_cast<uintptr_t>(levels) & 15) == 0) {              // "lds8" / "lds12"
-            if (e[3] == '8') return launch_sdf_head_lds<8>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
-            return launch_sdf_head_lds<12>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
-        }
-        if (e && e[0] == 'p' && e[4] == '1') return launch_sdf_head_pipelined<12>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
-        if (!(e && e[0] == 't')) return launch_sdf_head_pipelined<8>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
+        if (e && e[0] == 'p' && e[4] == '8') return launch_sdf_head_pipelined<8>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
+        if (!(e && e[0] == 't')) return launch_sdf_head_pipelined<12>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
     }
     MlpArgs a = {};
     a.n = n;
