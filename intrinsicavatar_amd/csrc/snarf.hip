@@ -550,14 +550,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
     const int32_t* __restrict__ order /* NULL or [N]: point p of this launch is xd_tgt[order[p]] (evaluation order != storage order) */)
 {
     __shared__ float s_T[16 * 12];                     // per init: rows 0..2 of its bone's 4x4 (R | t)
+    __shared__ int s_cur;                              // points of the WORKGROUP's chunk handed out so far
     for (int t = threadIdx.x; t < I * 12; t += THREADS) s_T[t] = tfs[(int64_t)bone_ids[t / 12] * 16 + (t % 12)];
+    if (threadIdx.x == 0) s_cur = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int64_t wave_id = ((int64_t)blockIdx.x * THREADS + threadIdx.x) >> 6;
-    const int64_t p_begin = wave_id * pts_per_wave;
+    // the four waves of a workgroup pull points off ONE chunk (pts_per_wave x 4 consecutive points of the sorted order): the
+    // lanes that are busy at any time sit in a compact window of it (what the L1 sees), and the drain at the chunk's end -- lanes
+    // idle because nothing is left to pull -- is paid once per 4 x pts_per_wave points (80 points per wave: 412 ms per headline
+    // step; 320: 368 ms; 1280 per wave with private chunks: 409 ms, the waves of a CU then work too far apart)
+    const int pts_wg = pts_per_wave * (THREADS / 64);
+    const int64_t p_begin = (int64_t)blockIdx.x * pts_wg;
     if (p_begin >= N) return;
-    const int n_pts = (int)((p_begin + pts_per_wave < N) ? pts_per_wave : N - p_begin);
-    int cur = 0;                                       // points of the chunk handed out so far (wave-uniform)
+    const int n_pts = (int)((p_begin + pts_wg < N) ? pts_wg : N - p_begin);
+    bool drained = false;                              // wave-uniform: the chunk has nothing left
     const float offset[3] = {offset_g[0], offset_g[1], offset_g[2]};
     const float scale[3] = {scale_g[0], scale_g[1], scale_g[2]};
     const float cvg2 = cvg_threshold * cvg_threshold, dvg2 = dvg_threshold * dvg_threshold;
@@ -592,11 +598,15 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
                 }
             }
         }
-        const unsigned long long need = __ballot(!have);
+        const unsigned long long need = drained ? 0ull : __ballot(!have);
         if (need) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_cur, __popcll(need));
+            base = __builtin_amdgcn_readfirstlane(base);
+            drained = base + __popcll(need) >= n_pts;
             if (!have) {
                 const int rank = __popcll(need & ((1ull << lane) - 1ull));
-                const int c = cur + rank;
+                const int c = base + rank;
                 if (c < n_pts) {
                     have = true;
                     pt = c;
@@ -612,10 +622,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
                     xt[2] = xd_tgt[src * 3 + 2];
                 }
             }
-            cur += __popcll(need);
-            if (cur > n_pts) cur = n_pts;
         }
-        if (!__any(have)) break;
+        if (!__any(have)) { if (drained) break; else continue; }
         if (!have) continue;
         if (it < 0) {                                                    // a new search: x0 = R^T (xd - t) of its bone
             const float* T = s_T + init * 12;                            // T[r*4 + c], r < 3
@@ -1077,10 +1085,10 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
     IA_REQUIRE(I >= 1 && I <= 16, "speculative search: 1 <= I <= 16 inits");
     IA_REQUIRE(eps >= 0.0f, "speculative search: eps must be >= 0");
     IA_REQUIRE((int64_t)D * H * W < ((int64_t)1 << 26), "voxel grid too large for 32-bit byte offsets (48 B per voxel)");
-    int pts = 80;                                                        // points per wave (as many items as the exact schedule's chunk)
+    int pts = 320;                                                       // points per wave; a workgroup's four waves share a chunk of 4 x pts
     if (const char* e = getenv("IA_BR_SPEC_PTS")) pts = atoi(e) > 0 ? atoi(e) : pts;
-    const int64_t n_waves = (N + pts - 1) / pts;
-    const int grid = ia::cdiv(n_waves * 64, THREADS);
+    const int64_t pts_wg = (int64_t)pts * (THREADS / 64);
+    const int grid = (int)((N + pts_wg - 1) / pts_wg);
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* c = reinterpret_cast<unsigned long long*>(counters);
     int slots = SPEC_ROOTS;                                              // test hook: fewer recorded roots / row slots => the overflow list is used
