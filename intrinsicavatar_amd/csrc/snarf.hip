@@ -557,8 +557,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
     const int lane = threadIdx.x & 63;
     // the four waves of a workgroup pull points off ONE chunk (pts_per_wave x 4 consecutive points of the sorted order): the
     // lanes that are busy at any time sit in a compact window of it (what the L1 sees), and the drain at the chunk's end -- lanes
-    // idle because nothing is left to pull -- is paid once per 4 x pts_per_wave points (80 points per wave: 412 ms per headline
-    // step; 320: 368 ms; 1280 per wave with private chunks: 409 ms, the waves of a CU then work too far apart)
+    // idle because nothing is left to pull -- is paid once per 4 x pts_per_wave points.  Headline step (male-3-casual:0), ms:
+    // private chunks of 80 / 160 / 320 / 640 / 1280 / 4096 points per wave: 412 / 377 / 368 / 384 / 409 / 493 (long chunks: the resident
+    // waves of the device work too far apart in the sorted order for the L2s); shared chunks of 4 x 160 / 320 / 640 / 1280: 367 / 369 / 384 / 405
     const int pts_wg = pts_per_wave * (THREADS / 64);
     const int64_t p_begin = (int64_t)blockIdx.x * pts_wg;
     if (p_begin >= N) return;
@@ -1085,7 +1086,7 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
     IA_REQUIRE(I >= 1 && I <= 16, "speculative search: 1 <= I <= 16 inits");
     IA_REQUIRE(eps >= 0.0f, "speculative search: eps must be >= 0");
     IA_REQUIRE((int64_t)D * H * W < ((int64_t)1 << 26), "voxel grid too large for 32-bit byte offsets (48 B per voxel)");
-    int pts = 320;                                                       // points per wave; a workgroup's four waves share a chunk of 4 x pts
+    int pts = 192;                                                       // points per wave; a workgroup's four waves share a chunk of 4 x pts
     if (const char* e = getenv("IA_BR_SPEC_PTS")) pts = atoi(e) > 0 ? atoi(e) : pts;
     const int64_t pts_wg = (int64_t)pts * (THREADS / 64);
     const int grid = (int)((N + pts_wg - 1) / pts_wg);
