@@ -409,7 +409,7 @@ def main():
                 roofline.update(
                     bound="l1 (cache-gather, SURVEY 8(d)): vector-memory path, 256 CUs x 64 B/clk x 2.4 GHz",
                     achieved=round(l1_rate, 1), peak=round(L1_PEAK_GBPS, 1), frac=round(l1_rate / L1_PEAK_GBPS, 4),
-                    algorithmic_model="COUNTED trilinear fetches (ia_broyden_stats, one extra untimed step) x in-range corners x 48 B "
+                    algorithmic_model="COUNTED trilinear fetches (the search kernel's own counters / ia_broyden_stats, one extra untimed step) x in-range corners x 48 B "
                                       "through the L1 path / live HIP-event time of the entry point",
                     fetches_per_step=int(c[0]), corner_loads_per_step=int(c[1]), bytes_per_corner=48,
                     fetches_per_item=round(c[0] / items, 3), Gfetch_per_s=round(c[0] / sec / 1e9, 2),
@@ -421,8 +421,8 @@ def main():
                     hbm_side=hbm_side,
                     survey_8d_gather_bytes_GBps=round(achieved, 1),
                     compulsory_hbm_GBps=round(comp / sec / 1e9, 1), compulsory_hbm_frac=round(comp / sec / 1e9 / HBM_PEAK_GBPS, 4),
-                    note="texture-addresser bound: a 16-byte gather instruction takes ~32 clk whatever it hits -- 49 Gfetch/s with EVERY "
-                         "item on one voxel (profiles/r02_broyden_probe.json)")
+                    note="a 16-byte wave gather occupies the vector-memory path for >= 16 clk (64 lanes x 16 B at 64 B/clk); frac = 16 clk / the "
+                         "average clk per issued gather, idle lanes included (DESIGN 4.5)")
                 l1 = None
             # north star's second target (MFMA utilisation of the batched MLP evaluation), in-step: the SDF head of the no-grad
             # queries (35 -> 64 -> 1: 2 x (35 x 64 + 64) useful FLOP per point) over its live HIP-event time
