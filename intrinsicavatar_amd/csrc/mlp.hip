@@ -21,6 +21,8 @@
 //     for both operand patterns;
 //   * SDF head: g_z = softplus'(z) * W2[0,:], g_h = g_z W1 (one more MFMA GEMM), then a per-point
 //     epilogue contracts g_h with the hash-grid Jacobian (d enc / d x) -> analytic gradient.
+#include <cstring>
+#include <type_traits>
 #include <stdlib.h>
 
 #include "mlp_tile.h"
@@ -404,7 +406,7 @@ __device__ __forceinline__ float softplus100_times(float acc, float b100, float 
     return fmaf(fmaf(lg2, 0.69314718055994530942f, fmaxf(bx, 0.0f)), w001, part);
 }
 
-template <int SH_WAVES>
+template <int SH_WAVES, bool PROBE_CACHED = false>     // PROBE_CACHED (diagnostic, IA_SDF_HEAD=probe_cached): every tile reads the rows of one of 64 tiles
 __global__ __launch_bounds__(SH_WAVES * 64) void sdf_head_pipelined_kernel(int64_t n, const float2* __restrict__ levels,
                                                                            const float* __restrict__ xp, const float* __restrict__ W1,
                                                                            const float* __restrict__ b1, const float* __restrict__ Wo,
@@ -430,9 +432,10 @@ __global__ __launch_bounds__(SH_WAVES * 64) void sdf_head_pipelined_kernel(int64
     f32x16 accA0, accA1, accB0, accB1;
     ShRows rows;
     // prologue: tile 0 of this wave -> LDS buffer 0 -> layer 1 -> accA; tile 1 -> LDS buffer 1; tile 2 -> registers
-    sh_load(rows, levels, n, xp, tile * 32, n, lane);
+    auto src = [](int64_t t) -> int64_t { return PROBE_CACHED ? (t & 63) : t; };
+    sh_load(rows, levels, n, xp, src(tile) * 32, n, lane);
     sh_store(rows, sX0, tile * 32, n, lane);
-    if (tile + stride < n_tiles) sh_load(rows, levels, n, xp, (tile + stride) * 32, n, lane);
+    if (tile + stride < n_tiles) sh_load(rows, levels, n, xp, src(tile + stride) * 32, n, lane);
 #pragma unroll
     for (int r = 0; r < 16; r++) { accA0[r] = 0.f; accA1[r] = 0.f; }
 #pragma unroll
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(SH_WAVES * 64) void sdf_head_pipelined_kernel(int64
     for (;; tile += stride) {
         const bool have_next = tile + stride < n_tiles;           // its rows are in sXb[cur ^ 1]
         const bool have_next2 = tile + 2 * stride < n_tiles;
-        if (have_next2) sh_load(rows, levels, n, xp, (tile + 2 * stride) * 32, n, lane);      // in flight behind everything below
+        if (have_next2) sh_load(rows, levels, n, xp, src(tile + 2 * stride) * 32, n, lane);      // in flight behind everything below
         float part[16];
         const float* sN = sX0 + (cur ^ 1) * 32 * SH_LDX;
 #pragma unroll
@@ -490,11 +493,182 @@ __global__ __launch_bounds__(SH_WAVES * 64) void sdf_head_pipelined_kernel(int64
     }
 }
 
+// ---- second version: the same pipeline with fewer issue slots per tile ----------------------------------------------------
+// Counters on the kernel above (tools/pmc_probe.sh, 50 M points): per 32-point tile and wave 36 MFMA (64 clk each on the matrix
+// pipe: busy 50 % of the launch) against 410 other VALU, 79 LDS and ~120 scalar instructions; the VALU issue port is busy 44 %, the
+// waves spend 65 % of their cycles waiting to issue -- three in-order waves per SIMD that each carry 17 issue slots per MFMA block
+// each other.  Only 256 of the 410 VALU instructions are the Softplus; the rest was addressing, bounds selects, accumulator copies
+// and 54 single-word operand reads per tile.  Here:
+//   * rows are loaded through wave-uniform base pointers + ONE 32-bit lane offset (global_load ... saddr), indices CLAMPED to the
+//     last point instead of selected (rows past n compute garbage that is never stored) -- no 64-bit lane arithmetic, no selects;
+//   * the tile sits in LDS operand-major, [k & 1][row][k >> 1] with 20-float rows, so a lane fetches the A operands of four
+//     k-steps with one ds_read_b128 (5 reads instead of 18), and the weights the same way (10 instead of 36);
+//   * the loop is unrolled over the two accumulator sets (no copy), no exec-mask branches in the steady state;
+//   * the reduce scratch has a 36-float row stride: 4 x ds_read_b128 instead of 16 single reads.
+//   * the Softplus costs 4 instead of 6 full-rate instructions per activation: W1 and b1 are staged in LDS pre-multiplied by
+//     100 log2(e) and the bias rides in the pad column (input 1.0), so the accumulator IS y = 100 log2(e) (W1 x + b1), and
+//       softplus_100(z) = ln2 / 100 * (max(y, 0) + log2(1 + 2^-|y|))      [v_exp_f32 takes -|y| as source modifiers]
+//     with ln2 / 100 folded into the output weight.  fp32 MFMA and the fp32 VALU issue against the same 64 FLOP/clk/SIMD
+//     (counters: matrix-pipe busy + VALU busy = 94 .. 97 % of the launch in every variant of this kernel), so every VALU
+//     instruction removed is time removed.  Against the kernel above: the products round differently (1e-7 relative).
+constexpr int S2_LDK = 20;                 // operand row: 18 k-steps + 2 pad floats (80 B: 16-byte aligned, conflict-free b128)
+constexpr int S2_BUF = 64 * S2_LDK;        // floats per tile buffer: operand rows (k & 1) * 32 + row
+constexpr int S2_LDR = 36;                 // reduce scratch (inside a consumed tile buffer): 32 rows x 32 partials
+constexpr float S2_C = 144.26950408889634f;        // 100 log2(e)
+
+__device__ __forceinline__ float softplus_y_times(float y, float w, float part)      // w = ln2 / 100 * output weight
+{
+    const float e = __builtin_amdgcn_exp2f(-fabsf(y));
+    const float l = __builtin_amdgcn_logf(1.0f + e);
+    float m;                                                     // max(y, 0): fmaxf() would canonicalise the MFMA result first (2 instructions)
+    asm("v_max_f32 %0, 0, %1" : "=v"(m) : "v"(y));
+    return fmaf(m + l, w, part);
+}
+
+struct S2Rows { float2 q[8]; float v[2]; };
+
+template <int SH_WAVES>
+__global__ __launch_bounds__(SH_WAVES * 64) void sdf_head_pipelined2_kernel(int64_t n, const float2* __restrict__ levels,
+                                                                            const float* __restrict__ xp, const float* __restrict__ W1,
+                                                                            const float* __restrict__ b1, const float* __restrict__ Wo,
+                                                                            const float* __restrict__ bo, float* __restrict__ sdf)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sW = smem;                                            // [2][64][S2_LDK]: sW[((k & 1) * 64 + h) * S2_LDK + (k >> 1)] = W1[h][k]
+    float* sXall = sW + 2 * 64 * S2_LDK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* const sX0 = sXall + wave * 2 * S2_BUF;
+    for (int i = tid; i < 2 * 64 * S2_LDK; i += SH_WAVES * 64) {
+        const int par = i / (64 * S2_LDK), rem = i - par * (64 * S2_LDK), h = rem / S2_LDK, kk = rem - h * S2_LDK, k = 2 * kk + par;
+        sW[i] = (kk < 18 && k < 35) ? S2_C * W1[h * 35 + k] : (kk == 17 && k == 35) ? S2_C * b1[h] : 0.0f;
+    }
+    for (int i = lane; i < 2 * S2_BUF; i += 64) sX0[i] = 0.0f;
+    __syncthreads();
+    const int lr = lane & 31, lk = lane >> 5;
+    const float w0 = 0.0069314718055994531f * Wo[lr], w1 = 0.0069314718055994531f * Wo[32 + lr], bout = bo[0];
+    const int64_t n_tiles = (n + 31) / 32;
+    const int64_t stride = (int64_t)gridDim.x * SH_WAVES;
+    int64_t tile = (int64_t)blockIdx.x * SH_WAVES + wave;        // wave-uniform
+    if (tile >= n_tiles) return;
+
+    // loop-invariant lane parts of the addresses
+    const uint32_t lvl_half = (uint32_t)lk * (uint32_t)(n * 8);               // the odd level of a load's level pair (n < 2^28)
+    const uint32_t xi0 = (uint32_t)lane, xi1 = min(64u + (uint32_t)lane, 95u);    // xyz scalars 0 .. 95 of the tile
+    const int st_row = lr * S2_LDK;                                             // feature (row, level l): [st_row + l] and [+ 32 rows]
+    const int sx0 = ((xi0 % 3u) & 1u) * 32 * S2_LDK + (xi0 / 3u) * S2_LDK + 16 + ((xi0 % 3u) >> 1);
+    const int sx1 = ((xi1 % 3u) & 1u) * 32 * S2_LDK + (xi1 / 3u) * S2_LDK + 16 + ((xi1 % 3u) >> 1);
+    const int a_off = (lk * 32 + lr) * S2_LDK;
+    const float* const wp0 = sW + (lk * 64 + lr) * S2_LDK;
+    const float* const wp1 = wp0 + 32 * S2_LDK;
+    const char* const lvb = reinterpret_cast<const char*>(levels);
+    const char* const xpb = reinterpret_cast<const char*>(xp);
+
+    auto load_rows = [&](S2Rows& r, int64_t t) {
+        const int64_t tc = t < n_tiles ? t : n_tiles - 1;                      // past the end: the last tile again (never stored)
+        const int64_t p0 = tc * 32;
+        const uint32_t rem = (uint32_t)min((int64_t)32, n - p0);               // >= 1
+        const uint32_t voff = lvl_half + ((uint32_t)p0 + min((uint32_t)lr, rem - 1u)) * 8u;
+#pragma unroll
+        for (int j = 0; j < 8; j++) r.q[j] = *reinterpret_cast<const float2*>(lvb + (size_t)(2 * j) * (size_t)n * 8 + voff);
+        const uint32_t xb = (uint32_t)p0 * 3u, xm = rem * 3u - 1u;
+        r.v[0] = *reinterpret_cast<const float*>(xpb + (size_t)((xb + min(xi0, xm)) * 4u));
+        r.v[1] = *reinterpret_cast<const float*>(xpb + (size_t)((xb + min(xi1, xm)) * 4u));
+    };
+    auto store_rows = [&](const S2Rows& r, float* __restrict__ sT) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int lvl = 2 * j + lk;
+            sT[st_row + lvl] = r.q[j].x; sT[32 * S2_LDK + st_row + lvl] = r.q[j].y;
+        }
+        sT[sx0] = r.v[0] * 2.0f - 1.0f;
+        sT[sx1] = r.v[1] * 2.0f - 1.0f;                                        // lanes 32 .. 63 repeat scalar 95
+        sT[32 * S2_LDK + st_row + 17] = 1.0f;                                  // column 35: the bias column
+    };
+    // layer 1 of the tile in sN into (d0, d1); with SOFT the Softplus + output-layer partials of (s0, s1) run under the MFMAs
+    auto layer1 = [&](const float* __restrict__ sN, f32x16& d0, f32x16& d1, const f32x16& s0, const f32x16& s1, float* part, auto soft) {
+        constexpr bool SOFT = decltype(soft)::value;
+        const float* ap = sN + a_off;
+        f32x4 a4 = *reinterpret_cast<const f32x4*>(ap), b4 = *reinterpret_cast<const f32x4*>(wp0), c4 = *reinterpret_cast<const f32x4*>(wp1);
+#pragma unroll
+        for (int r = 0; r < 16; r++) { d0[r] = 0.f; d1[r] = 0.f; }
+#pragma unroll
+        for (int g = 0; g < 5; g++) {
+            f32x4 an = a4, bn = b4, cn = c4;
+            if (g < 3) {
+                an = *reinterpret_cast<const f32x4*>(ap + 4 * (g + 1)); bn = *reinterpret_cast<const f32x4*>(wp0 + 4 * (g + 1));
+                cn = *reinterpret_cast<const f32x4*>(wp1 + 4 * (g + 1));
+            } else if (g == 3) {
+                const float2 a2 = *reinterpret_cast<const float2*>(ap + 16), b2 = *reinterpret_cast<const float2*>(wp0 + 16),
+                             c2 = *reinterpret_cast<const float2*>(wp1 + 16);
+                an[0] = a2.x; an[1] = a2.y; bn[0] = b2.x; bn[1] = b2.y; cn[0] = c2.x; cn[1] = c2.y;
+            }
+#pragma unroll
+            for (int q = 0; q < (g < 4 ? 4 : 2); q++) {
+                const int kk = 4 * g + q;
+                d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], b4[q], d0, 0, 0, 0);
+                if (SOFT && kk < 16) part[kk] = softplus_y_times(s0[kk], w0, 0.0f);
+                d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], c4[q], d1, 0, 0, 0);
+                if (SOFT && kk < 16) part[kk] = softplus_y_times(s1[kk], w1, part[kk]);
+                if (SOFT) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);       // one activation of VALU work
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                }
+            }
+            a4 = an; b4 = bn; c4 = cn;
+        }
+    };
+    using True = std::integral_constant<bool, true>;
+    using False = std::integral_constant<bool, false>;
+    // output layer of the tile whose partials are in part[]: transpose-reduce through the consumed tile buffer sR, store
+    auto finish = [&](const float* part, float* __restrict__ sR, int64_t t) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) sR[((r & 3) + 8 * (r >> 2) + 4 * lk) * S2_LDR + lr] = part[r];
+        float sum = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(sR + lr * S2_LDR + lk * 16 + 4 * q);
+            sum += v[0]; sum += v[1]; sum += v[2]; sum += v[3];
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const int64_t p = t * 32 + lr;
+        if (lk == 0 && p < n) sdf[p] = sum + bout;
+    };
+
+    f32x16 accA0, accA1, accB0, accB1;
+    S2Rows rows;
+    float part[16];
+    float* const buf0 = sX0;
+    float* const buf1 = sX0 + S2_BUF;
+    load_rows(rows, tile);
+    store_rows(rows, buf0);
+    load_rows(rows, tile + stride);
+    layer1(buf0, accA0, accA1, accA0, accA1, part, False{});
+    store_rows(rows, buf1);
+    for (;;) {
+        // tile: Softplus(accA) under layer 1 of tile + stride (buf1 -> accB); buf0 is free: reduce scratch, then the rows of tile + 2 stride
+        load_rows(rows, tile + 2 * stride);
+        layer1(buf1, accB0, accB1, accA0, accA1, part, True{});
+        finish(part, buf0, tile);
+        tile += stride;
+        if (tile >= n_tiles) break;
+        store_rows(rows, buf0);
+        load_rows(rows, tile + 2 * stride);
+        layer1(buf0, accA0, accA1, accB0, accB1, part, True{});
+        finish(part, buf1, tile);
+        tile += stride;
+        if (tile >= n_tiles) break;
+        store_rows(rows, buf1);
+    }
+}
+
 // (tried: the same pipeline with the level-major features DMA'd straight into LDS -- gfx950 global_load_lds_dwordx4, the tile kept
 //  level-major so that the layer-1 A operand needs no transposition, nothing of the next-next tile in registers: 3.25 ms per
 //  50 M points at 12 waves per CU, exactly what this kernel does at 12 waves once both reached it without spills -- the row
 //  loads were not what limits it.  Not kept.)
-template <int SH_WAVES>
+template <int SH_WAVES, bool PROBE_CACHED = false>
 static int launch_sdf_head_pipelined(int64_t n, const void* levels, const float* xp, const float* W1, const float* b1, const float* Wo,
                                      const float* bo, float* sdf, hipStream_t s)
 {
@@ -502,13 +676,32 @@ static int launch_sdf_head_pipelined(int64_t n, const void* levels, const float*
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)sdf_head_pipelined_kernel<SH_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)sdf_head_pipelined_kernel<SH_WAVES, PROBE_CACHED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     const int64_t n_tiles = (n + 31) / 32;
     int grid = (int)((n_tiles + SH_WAVES - 1) / SH_WAVES);
     if (grid > 256) grid = 256;
-    sdf_head_pipelined_kernel<SH_WAVES><<<grid, SH_WAVES * 64, lds, s>>>(n, reinterpret_cast<const float2*>(levels), xp, W1, b1, Wo, bo, sdf);
+    sdf_head_pipelined_kernel<SH_WAVES, PROBE_CACHED><<<grid, SH_WAVES * 64, lds, s>>>(n, reinterpret_cast<const float2*>(levels), xp, W1, b1, Wo, bo, sdf);
+    return ia::check_launch("ia_sdf_levels_fwd");
+}
+
+template <int SH_WAVES>
+static int launch_sdf_head_pipelined2(int64_t n, const void* levels, const float* xp, const float* W1, const float* b1, const float* Wo,
+                                      const float* bo, float* sdf, hipStream_t s)
+{
+    constexpr size_t lds = sizeof(float) * (2 * 64 * S2_LDK + SH_WAVES * 2 * S2_BUF);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert(32 * S2_LDR <= S2_BUF, "the reduce scratch lives in a tile buffer");
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)sdf_head_pipelined2_kernel<SH_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int64_t n_tiles = (n + 31) / 32;
+    int grid = (int)((n_tiles + SH_WAVES - 1) / SH_WAVES);
+    if (grid > 256) grid = 256;
+    sdf_head_pipelined2_kernel<SH_WAVES><<<grid, SH_WAVES * 64, lds, s>>>(n, reinterpret_cast<const float2*>(levels), xp, W1, b1, Wo, bo, sdf);
     return ia::check_launch("ia_sdf_levels_fwd");
 }
 
@@ -559,11 +752,16 @@ IA_EXPORT int ia_sdf_levels_fwd(int64_t n, const void* levels, const float* xp, 
     if (n == 0) return IA_OK;
     IA_REQUIRE(n < ((int64_t)1 << 31), "ia_sdf_levels_fwd: at most 2^31 points per call");
     {
-        // default: two tiles per wave, 12 waves per CU (162 VGPRs, no spills): 3.25 ms per 50 M points = 0.45 of the fp32 MFMA peak,
-        // against 4.80 ms (0.31) of the one-tile-per-wave kernel ("tile"); 8 waves per CU ("pipe8"): 3.45 ms
+        // default ("pipe2"): two tiles per wave, 12 waves per CU, operand-major LDS tiles, rescaled Softplus (106 VGPRs): 2.92 ms per
+        // 50 M points = 0.50 of the fp32 MFMA peak (tools/sdf_head_ab.py); its predecessor "pipe12" (162 VGPRs): 3.25 ms (0.45); the
+        // one-tile-per-wave kernel "tile": 4.80 ms (0.31); "pipe8": 3.45 ms.  pipe2 addresses a level pair with a 32-bit lane offset:
+        // batches of 2^28 points and more take pipe12.
         const char* e = getenv("IA_SDF_HEAD");
-        if (e && e[0] == 'p' && e[4] == '8') return launch_sdf_head_pipelined<8>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
-        if (!(e && e[0] == 't')) return launch_sdf_head_pipelined<12>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
+        if (e && !strcmp(e, "probe_cached")) return launch_sdf_head_pipelined<12, true>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
+        if (e && !strcmp(e, "pipe8")) return launch_sdf_head_pipelined<8>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
+        if ((e && !strcmp(e, "pipe12")) || (!(e && e[0] == 't') && n >= ((int64_t)1 << 28)))
+            return launch_sdf_head_pipelined<12>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
+        if (!(e && e[0] == 't')) return launch_sdf_head_pipelined2<12>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
     }
     MlpArgs a = {};
     a.n = n;

@@ -537,8 +537,8 @@ constexpr int SPEC_ROOTS = 3;      // recorded roots per point (survivors per po
 // records of a point (filter.cu:10-54: drop one when a LATER init's lies within 1e-4) and adds the kept ones to cnt, and
 // ia_deform_rows_pack emits them in front of the row's candidates (their inits are lower).  Only a full list (ovf_cap) makes the
 // caller redo the batch with the is_valid + K9 path.
-template <bool COUNT, bool PACK>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES, IA_BR2_WAVES))) void broyden_spec_kernel(
+template <bool COUNT, bool PACK, int WG = THREADS>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES, IA_BR2_WAVES))) void broyden_spec_kernel(
     int64_t N, int I, const float* __restrict__ xd_tgt, const float* __restrict__ voxel_J, int D, int H, int W,
     const float* __restrict__ tfs, const int32_t* __restrict__ bone_ids, const float* __restrict__ offset_g,
     const float* __restrict__ scale_g, float cvg_threshold, float dvg_threshold, float eps, float* __restrict__ x,
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
 {
     __shared__ float s_T[16 * 12];                     // per init: rows 0..2 of its bone's 4x4 (R | t)
     __shared__ int s_cur;                              // points of the WORKGROUP's chunk handed out so far
-    for (int t = threadIdx.x; t < I * 12; t += THREADS) s_T[t] = tfs[(int64_t)bone_ids[t / 12] * 16 + (t % 12)];
+    for (int t = threadIdx.x; t < I * 12; t += WG) s_T[t] = tfs[(int64_t)bone_ids[t / 12] * 16 + (t % 12)];
     if (threadIdx.x == 0) s_cur = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
     // idle because nothing is left to pull -- is paid once per 4 x pts_per_wave points.  Headline step (male-3-casual:0), ms:
     // private chunks of 80 / 160 / 320 / 640 / 1280 / 4096 points per wave: 412 / 377 / 368 / 384 / 409 / 493 (long chunks: the resident
     // waves of the device work too far apart in the sorted order for the L2s); shared chunks of 4 x 160 / 320 / 640 / 1280: 367 / 369 / 384 / 405
-    const int pts_wg = pts_per_wave * (THREADS / 64);
+    const int pts_wg = pts_per_wave * (WG / 64);
     const int64_t p_begin = (int64_t)blockIdx.x * pts_wg;
     if (p_begin >= N) return;
     const int n_pts = (int)((p_begin + pts_wg < N) ? pts_wg : N - p_begin);
@@ -1088,18 +1088,24 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
     IA_REQUIRE((int64_t)D * H * W < ((int64_t)1 << 26), "voxel grid too large for 32-bit byte offsets (48 B per voxel)");
     int pts = 192;                                                       // points per wave; a workgroup's four waves share a chunk of 4 x pts
     if (const char* e = getenv("IA_BR_SPEC_PTS")) pts = atoi(e) > 0 ? atoi(e) : pts;
-    const int64_t pts_wg = (int64_t)pts * (THREADS / 64);
+    int wg = THREADS;                                                    // experiment: more waves share one chunk (IA_BR_SPEC_WG = 256 | 512 | 640 | 1024)
+    if (const char* e = getenv("IA_BR_SPEC_WG")) { const int v = atoi(e); if (v == 512 || v == 640 || v == 1024) wg = v; }
+    const int64_t pts_wg = (int64_t)pts * (wg / 64);
     const int grid = (int)((N + pts_wg - 1) / pts_wg);
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* c = reinterpret_cast<unsigned long long*>(counters);
     int slots = SPEC_ROOTS;                                              // test hook: fewer recorded roots / row slots => the overflow list is used
     if (const char* e = getenv("IA_SPEC_TEST_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= SPEC_ROOTS) slots = v; }
-#define IA_SPEC_LAUNCH(COUNT, PACK)                                                                                                    \
-    broyden_spec_kernel<COUNT, PACK><<<grid, THREADS, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,         \
+#define IA_SPEC_LAUNCH_WG(COUNT, PACK, WGS)                                                                                            \
+    broyden_spec_kernel<COUNT, PACK, WGS><<<grid, WGS, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,        \
                                                                cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J, pts, c, cnt, \
                                                                meta, ovf_count, ovf_head, ovf_rec, ovf_x, ovf_cap, slots, order)
+#define IA_SPEC_LAUNCH(COUNT, PACK)                                                                                                    \
+    do { if (wg == 512) IA_SPEC_LAUNCH_WG(COUNT, PACK, 512); else if (wg == 640) IA_SPEC_LAUNCH_WG(COUNT, PACK, 640);                   \
+         else if (wg == 1024) IA_SPEC_LAUNCH_WG(COUNT, PACK, 1024); else IA_SPEC_LAUNCH_WG(COUNT, PACK, THREADS); } while (0)
     if (pack) { if (counters) IA_SPEC_LAUNCH(true, true); else IA_SPEC_LAUNCH(false, true); }
     else { if (counters) IA_SPEC_LAUNCH(true, false); else IA_SPEC_LAUNCH(false, false); }
+#undef IA_SPEC_LAUNCH_WG
 #undef IA_SPEC_LAUNCH
     return ia::check_launch(what);
 }

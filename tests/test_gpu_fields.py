@@ -296,6 +296,30 @@ def test_sdf_only_query_path_equals_the_general_one(fields):
     assert torch.equal(s2, s) and torch.equal(s3, s)
 
 
+def test_sdf_value_head_variants_agree(fields, monkeypatch):
+    """ia_sdf_levels_fwd: the default kernel (operand-major LDS tiles, clamped loads, Softplus on 100 log2(e)-scaled weights) against
+    its predecessors ("pipe12": bit-identical to "pipe8"; "tile": the one-tile-per-wave MFMA kernel) and the general forward, on
+    ragged sizes: one point, around one and two tiles, around one round of the persistent grid, many tiles per wave."""
+    from intrinsicavatar_amd import synthetic as S
+    rs, _, _ = S.build_frame(DEV, 32, 32, pose_seed=0, beta=0.01, num_samples_per_ray=16, grid_D=16, grid_H=64, grid_W=64,
+                             smooth_iters=5, hash_amp=1e-2)
+    geo = rs.geometry
+    g = torch.Generator().manual_seed(1)
+    for n in (1, 31, 32, 33, 63, 65, 256 * 12 * 32 - 1, 256 * 12 * 32 + 1, 3_000_017):
+        x = (geo.center + (torch.rand((n, 3), generator=g).to(DEV) - 0.5) * geo.scale).contiguous()
+        out = {}
+        for v in ("pipe2", "pipe12", "pipe8", "tile"):
+            monkeypatch.setenv("IA_SDF_HEAD", v)
+            out[v] = geo.sdf_only(x).clone()
+        monkeypatch.delenv("IA_SDF_HEAD")
+        assert torch.equal(geo.sdf_only(x), out["pipe2"])                           # the default
+        assert torch.equal(out["pipe12"], out["pipe8"])
+        ref = geo.forward(x, with_grad=False, with_feature=False)
+        for v in out:
+            assert float((out[v] - ref).abs().max()) < 2e-6, (n, v)
+        assert float((out["pipe2"] - out["pipe12"]).abs().max()) < 1e-6
+
+
 def test_sdf_head_with_gradient_on_level_major_results_equals_the_row_major_path(fields, monkeypatch):
     """big batches evaluate VolumeSDF.forward(with_grad=True) from the level-major gather results (ia_hashgrid_fwd_levels +
     ia_sdf_levels_fwd_grad: no [n,32] rows, no [n,32,3] Jacobian): sdf, 13 features and the analytic gradient equal the flat gather

@@ -5,7 +5,9 @@ import json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from intrinsicavatar_amd import build; build.build()
-from intrinsicavatar_amd import synthetic as S, _lib as L
+from intrinsicavatar_amd import synthetic as S, _lib as L, fields
+if os.environ.get("IA_PROBE_LOG2"):          # experiment: smaller tables (a prefix of the parameter vector) -- what does the L2 capacity cost?
+    fields.HASH["log2_hashmap_size"] = int(os.environ["IA_PROBE_LOG2"])
 dev = "cuda:0"
 n = int(os.environ.get("IA_N", 100_000_000))
 rs, rays, _ = S.build_frame(dev, 540, 540, pose_seed=0, beta=0.01)
