@@ -559,7 +559,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
     // lanes that are busy at any time sit in a compact window of it (what the L1 sees), and the drain at the chunk's end -- lanes
     // idle because nothing is left to pull -- is paid once per 4 x pts_per_wave points.  Headline step (male-3-casual:0), ms:
     // private chunks of 80 / 160 / 320 / 640 / 1280 / 4096 points per wave: 412 / 377 / 368 / 384 / 409 / 493 (long chunks: the resident
-    // waves of the device work too far apart in the sorted order for the L2s); shared chunks of 4 x 160 / 320 / 640 / 1280: 367 / 369 / 384 / 405
+    // waves of the device work too far apart in the sorted order for the L2s); shared chunks of 4 x 160 / 320 / 640 / 1280: 367 / 369 / 384 / 405.
+    // MORE waves on one chunk do not help (same step, 192 points per wave, after the head's speed-up): workgroups of 4 / 8 / 10 / 16
+    // waves 355.8 / 367.4 / 400.7 / 377.5 ms; 16 waves x 96 points 371.3 -- the CU's L1 is not what the window buys, the L2s are
     const int pts_wg = pts_per_wave * (WG / 64);
     const int64_t p_begin = (int64_t)blockIdx.x * pts_wg;
     if (p_begin >= N) return;
