@@ -1090,24 +1090,18 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
     IA_REQUIRE((int64_t)D * H * W < ((int64_t)1 << 26), "voxel grid too large for 32-bit byte offsets (48 B per voxel)");
     int pts = 192;                                                       // points per wave; a workgroup's four waves share a chunk of 4 x pts
     if (const char* e = getenv("IA_BR_SPEC_PTS")) pts = atoi(e) > 0 ? atoi(e) : pts;
-    int wg = THREADS;                                                    // experiment: more waves share one chunk (IA_BR_SPEC_WG = 256 | 512 | 640 | 1024)
-    if (const char* e = getenv("IA_BR_SPEC_WG")) { const int v = atoi(e); if (v == 512 || v == 640 || v == 1024) wg = v; }
-    const int64_t pts_wg = (int64_t)pts * (wg / 64);
+    const int64_t pts_wg = (int64_t)pts * (THREADS / 64);
     const int grid = (int)((N + pts_wg - 1) / pts_wg);
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* c = reinterpret_cast<unsigned long long*>(counters);
     int slots = SPEC_ROOTS;                                              // test hook: fewer recorded roots / row slots => the overflow list is used
     if (const char* e = getenv("IA_SPEC_TEST_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= SPEC_ROOTS) slots = v; }
-#define IA_SPEC_LAUNCH_WG(COUNT, PACK, WGS)                                                                                            \
-    broyden_spec_kernel<COUNT, PACK, WGS><<<grid, WGS, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,        \
+#define IA_SPEC_LAUNCH(COUNT, PACK)                                                                                                    \
+    broyden_spec_kernel<COUNT, PACK><<<grid, THREADS, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,         \
                                                                cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J, pts, c, cnt, \
                                                                meta, ovf_count, ovf_head, ovf_rec, ovf_x, ovf_cap, slots, order)
-#define IA_SPEC_LAUNCH(COUNT, PACK)                                                                                                    \
-    do { if (wg == 512) IA_SPEC_LAUNCH_WG(COUNT, PACK, 512); else if (wg == 640) IA_SPEC_LAUNCH_WG(COUNT, PACK, 640);                   \
-         else if (wg == 1024) IA_SPEC_LAUNCH_WG(COUNT, PACK, 1024); else IA_SPEC_LAUNCH_WG(COUNT, PACK, THREADS); } while (0)
     if (pack) { if (counters) IA_SPEC_LAUNCH(true, true); else IA_SPEC_LAUNCH(false, true); }
     else { if (counters) IA_SPEC_LAUNCH(true, false); else IA_SPEC_LAUNCH(false, false); }
-#undef IA_SPEC_LAUNCH_WG
 #undef IA_SPEC_LAUNCH
     return ia::check_launch(what);
 }
