@@ -538,12 +538,12 @@ __global__ __launch_bounds__(SH_WAVES * 64) void sdf_head_pipelined2_kernel(int6
     float* sXall = sW + 2 * 64 * S2_LDK;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* const sX0 = sXall + wave * 2 * S2_BUF;
+    float* const sX0 = sXall + wave * S2_BUF;                    // ONE tile buffer per wave: rows of the next tile -> reduce scratch -> rows of the one after
     for (int i = tid; i < 2 * 64 * S2_LDK; i += SH_WAVES * 64) {
         const int par = i / (64 * S2_LDK), rem = i - par * (64 * S2_LDK), h = rem / S2_LDK, kk = rem - h * S2_LDK, k = 2 * kk + par;
         sW[i] = (kk < 18 && k < 35) ? S2_C * W1[h * 35 + k] : (kk == 17 && k == 35) ? S2_C * b1[h] : 0.0f;
     }
-    for (int i = lane; i < 2 * S2_BUF; i += 64) sX0[i] = 0.0f;
+    for (int i = lane; i < S2_BUF; i += 64) sX0[i] = 0.0f;
     __syncthreads();
     const int lr = lane & 31, lk = lane >> 5;
     const float w0 = 0.0069314718055994531f * Wo[lr], w1 = 0.0069314718055994531f * Wo[32 + lr], bout = bo[0];
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(SH_WAVES * 64) void sdf_head_pipelined2_kernel(int6
         r.v[0] = *reinterpret_cast<const float*>(xpb + (size_t)((xb + min(xi0, xm)) * 4u));
         r.v[1] = *reinterpret_cast<const float*>(xpb + (size_t)((xb + min(xi1, xm)) * 4u));
     };
-    auto store_rows = [&](const S2Rows& r, float* __restrict__ sT) {
+    auto store_rows = [&](const S2Rows& r, float* sT) {          // (no __restrict__ on the LDS pointers: the three uses alias on purpose)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int lvl = 2 * j + lk;
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(SH_WAVES * 64) void sdf_head_pipelined2_kernel(int6
         sT[32 * S2_LDK + st_row + 17] = 1.0f;                                  // column 35: the bias column
     };
     // layer 1 of the tile in sN into (d0, d1); with SOFT the Softplus + output-layer partials of (s0, s1) run under the MFMAs
-    auto layer1 = [&](const float* __restrict__ sN, f32x16& d0, f32x16& d1, const f32x16& s0, const f32x16& s1, float* part, auto soft) {
+    auto layer1 = [&](const float* sN, f32x16& d0, f32x16& d1, const f32x16& s0, const f32x16& s1, float* part, auto soft) {
         constexpr bool SOFT = decltype(soft)::value;
         const float* ap = sN + a_off;
         f32x4 a4 = *reinterpret_cast<const f32x4*>(ap), b4 = *reinterpret_cast<const f32x4*>(wp0), c4 = *reinterpret_cast<const f32x4*>(wp1);
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(SH_WAVES * 64) void sdf_head_pipelined2_kernel(int6
     using True = std::integral_constant<bool, true>;
     using False = std::integral_constant<bool, false>;
     // output layer of the tile whose partials are in part[]: transpose-reduce through the consumed tile buffer sR, store
-    auto finish = [&](const float* part, float* __restrict__ sR, int64_t t) {
+    auto finish = [&](const float* part, float* sR, int64_t t) {
 #pragma unroll
         for (int r = 0; r < 16; r++) sR[((r & 3) + 8 * (r >> 2) + 4 * lk) * S2_LDR + lr] = part[r];
         float sum = 0.0f;
@@ -640,27 +640,26 @@ __global__ __launch_bounds__(SH_WAVES * 64) void sdf_head_pipelined2_kernel(int6
     f32x16 accA0, accA1, accB0, accB1;
     S2Rows rows;
     float part[16];
-    float* const buf0 = sX0;
-    float* const buf1 = sX0 + S2_BUF;
+    // the wave's LDS buffer in program order (LDS operations of one wave execute in order): rows of tile + stride (read by layer 1)
+    // -> scratch of the output-layer reduce of tile -> rows of tile + 2 stride (from the registers loaded at the top of the phase)
     load_rows(rows, tile);
-    store_rows(rows, buf0);
+    store_rows(rows, sX0);
     load_rows(rows, tile + stride);
-    layer1(buf0, accA0, accA1, accA0, accA1, part, False{});
-    store_rows(rows, buf1);
+    layer1(sX0, accA0, accA1, accA0, accA1, part, False{});
+    store_rows(rows, sX0);
     for (;;) {
-        // tile: Softplus(accA) under layer 1 of tile + stride (buf1 -> accB); buf0 is free: reduce scratch, then the rows of tile + 2 stride
         load_rows(rows, tile + 2 * stride);
-        layer1(buf1, accB0, accB1, accA0, accA1, part, True{});
-        finish(part, buf0, tile);
+        layer1(sX0, accB0, accB1, accA0, accA1, part, True{});          // Softplus(accA) of tile under layer 1 of tile + stride -> accB
+        finish(part, sX0, tile);
         tile += stride;
         if (tile >= n_tiles) break;
-        store_rows(rows, buf0);
+        store_rows(rows, sX0);
         load_rows(rows, tile + 2 * stride);
-        layer1(buf0, accA0, accA1, accB0, accB1, part, True{});
-        finish(part, buf1, tile);
+        layer1(sX0, accA0, accA1, accB0, accB1, part, True{});
+        finish(part, sX0, tile);
         tile += stride;
         if (tile >= n_tiles) break;
-        store_rows(rows, buf1);
+        store_rows(rows, sX0);
     }
 }
 
@@ -690,7 +689,7 @@ template <int SH_WAVES>
 static int launch_sdf_head_pipelined2(int64_t n, const void* levels, const float* xp, const float* W1, const float* b1, const float* Wo,
                                       const float* bo, float* sdf, hipStream_t s)
 {
-    constexpr size_t lds = sizeof(float) * (2 * 64 * S2_LDK + SH_WAVES * 2 * S2_BUF);
+    constexpr size_t lds = sizeof(float) * (2 * 64 * S2_LDK + SH_WAVES * S2_BUF);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert(32 * S2_LDR <= S2_BUF, "the reduce scratch lives in a tile buffer");
     static bool attr = false;
@@ -752,16 +751,18 @@ IA_EXPORT int ia_sdf_levels_fwd(int64_t n, const void* levels, const float* xp, 
     if (n == 0) return IA_OK;
     IA_REQUIRE(n < ((int64_t)1 << 31), "ia_sdf_levels_fwd: at most 2^31 points per call");
     {
-        // default ("pipe2"): two tiles per wave, 12 waves per CU, operand-major LDS tiles, rescaled Softplus (106 VGPRs): 2.92 ms per
-        // 50 M points = 0.50 of the fp32 MFMA peak (tools/sdf_head_ab.py); its predecessor "pipe12" (162 VGPRs): 3.25 ms (0.45); the
-        // one-tile-per-wave kernel "tile": 4.80 ms (0.31); "pipe8": 3.45 ms.  pipe2 addresses a level pair with a 32-bit lane offset:
-        // batches of 2^28 points and more take pipe12.
+        // default ("pipe2"): two tiles per wave, 16 waves per CU (117 VGPRs, 5 KB of LDS per wave), operand-major LDS tiles, rescaled
+        // Softplus: 2.81 ms per 50 M points = 0.52 of the fp32 MFMA peak (tools/sdf_head_ab.py; 12 waves 2.87, 8 waves 2.97); its
+        // predecessor "pipe12" (162 VGPRs, 12 waves): 3.25 ms (0.45); the one-tile-per-wave kernel "tile": 4.80 ms (0.31); "pipe8":
+        // 3.45 ms.  pipe2 addresses a level pair with a 32-bit lane offset: batches of 2^28 points and more take pipe12.
         const char* e = getenv("IA_SDF_HEAD");
         if (e && !strcmp(e, "probe_cached")) return launch_sdf_head_pipelined<12, true>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
         if (e && !strcmp(e, "pipe8")) return launch_sdf_head_pipelined<8>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
         if ((e && !strcmp(e, "pipe12")) || (!(e && e[0] == 't') && n >= ((int64_t)1 << 28)))
             return launch_sdf_head_pipelined<12>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
-        if (!(e && e[0] == 't')) return launch_sdf_head_pipelined2<12>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
+        if (e && !strcmp(e, "pipe2w12")) return launch_sdf_head_pipelined2<12>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
+        if (e && !strcmp(e, "pipe2w8")) return launch_sdf_head_pipelined2<8>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
+        if (!(e && e[0] == 't')) return launch_sdf_head_pipelined2<16>(n, levels, xp, W1, b1, Wo, bo, sdf, (hipStream_t)stream);
     }
     MlpArgs a = {};
     a.n = n;

@@ -308,12 +308,12 @@ def test_sdf_value_head_variants_agree(fields, monkeypatch):
     for n in (1, 31, 32, 33, 63, 65, 256 * 12 * 32 - 1, 256 * 12 * 32 + 1, 3_000_017):
         x = (geo.center + (torch.rand((n, 3), generator=g).to(DEV) - 0.5) * geo.scale).contiguous()
         out = {}
-        for v in ("pipe2", "pipe12", "pipe8", "tile"):
+        for v in ("pipe2", "pipe2w12", "pipe12", "pipe8", "tile"):
             monkeypatch.setenv("IA_SDF_HEAD", v)
             out[v] = geo.sdf_only(x).clone()
         monkeypatch.delenv("IA_SDF_HEAD")
         assert torch.equal(geo.sdf_only(x), out["pipe2"])                           # the default
-        assert torch.equal(out["pipe12"], out["pipe8"])
+        assert torch.equal(out["pipe12"], out["pipe8"]) and torch.equal(out["pipe2"], out["pipe2w12"])
         ref = geo.forward(x, with_grad=False, with_feature=False)
         for v in out:
             assert float((out[v] - ref).abs().max()) < 2e-6, (n, v)

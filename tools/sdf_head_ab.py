@@ -9,7 +9,7 @@ dev = "cuda:0"
 rs, rays, _ = S.build_frame(dev, 64, 64, pose_seed=0, beta=0.01)
 geo = rs.geometry
 g = torch.Generator(device=dev).manual_seed(0)
-variants = os.environ.get("IA_VARIANTS", "pipe12,pipe2").split(",")
+variants = os.environ.get("IA_VARIANTS", "pipe12,pipe2w12,pipe2w8,pipe2").split(",")
 res = {}
 for n in (1, 31, 32, 33, 63, 64, 65, 1000, 12345, (1 << 20) + 7, 5_000_011):
     x = (geo.center + (torch.rand((n, 3), device=dev, generator=g) - 0.5) * geo.scale * 0.9).contiguous()
