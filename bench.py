@@ -149,6 +149,8 @@ def main():
     ap.add_argument("--no-config2", action="store_true", help="skip the secondary configs[1] measurement of the headline line")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the instrumented repeat (profiling runs)")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd only (no Adam step)")
+    ap.add_argument("--aten-profile", default=None, help="diagnostic: one extra step under torch.profiler; the ATen operators by device time "
+                                                          "(with input shapes) go to this file")
     ap.add_argument("--pass", dest="mode", choices=["fwd+bwd", "fwd"], default="fwd+bwd",
                     help="fwd+bwd = training-step form of render_step (BASELINE metric); fwd = inference form (config2 only)")
     args = ap.parse_args()
@@ -322,6 +324,13 @@ def main():
     # ---- ONE more step with a HIP-event pair around every C-ABI launch (on the launch stream): per-kernel durations
     # and counted units for the roofline / breakdown.  Kept out of the throughput region because the event records cost
     # host time that the un-instrumented step does not pay (ms_per_step_instrumented is reported next to it).
+    if args.aten_profile and rank == 0:
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            step()
+            torch.cuda.synchronize()
+        with open(args.aten_profile, "w") as f:
+            f.write(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=60, max_name_column_width=60))
     detail, dt_instr, k_instr = {}, 0.0, 0
     if not args.no_breakdown:
         k_instr = 1 if headline else args.steps

@@ -213,7 +213,10 @@ int ia_fuse_broyden_spec(int64_t N, int I, const float* xd_tgt /*[N,3]*/, const 
  * overflow records -- above ia_spec_rows_overflow_capacity() records were lost: redo the batch with ia_fuse_broyden_spec + K9.
  * 44 bytes per point leave the kernel instead of 169 (x [N,I,3] + is_valid).  J_inv / fwd_J (optional) are written at
  * [point, init] as in ia_fuse_broyden.  scan_tmp: ia_scan_tmp_bytes(N) bytes.
- * ia_deform_rows_pack: cand_x [Q,3] (+ cand_src [Q] = point * I + init, optional) in (point, ascending init) order. */
+ * ia_deform_rows_pack: cand_x [Q,3] (+ cand_src [Q] = point * I + init, optional) in (point, ascending init) order; with
+ * norm_center / norm_scale the candidates leave as the hash grid's unit-cube coordinates (x - center) / scale + 0.5 (the three
+ * elementwise passes of models/rf/geometry.py:155 `(points - self.center) / self.scale + 0.5` done on the way out; same IEEE
+ * operations, same bits). */
 int ia_spec_rows_slots(void);
 size_t ia_spec_rows_overflow_bytes(void);
 int ia_spec_rows_overflow_capacity(void);
@@ -223,7 +226,9 @@ int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, const float
                               int32_t* start, int32_t* ovf_head, void* ovf_scratch, int32_t* total_and_overflow, void* scan_tmp,
                               uint64_t* counters, const int32_t* order /* NULL or [N]: point p = xd_tgt[order[p]] */, ia_stream_t stream);
 int ia_deform_rows_pack(int64_t N, int I, const float* x_rows, const int32_t* cnt, const uint32_t* meta, const int32_t* start,
-                        const int32_t* ovf_head, const void* ovf_scratch, float* cand_x, int32_t* cand_src /*or NULL*/, ia_stream_t stream);
+                        const int32_t* ovf_head, const void* ovf_scratch, float* cand_x, int32_t* cand_src,
+                        const float* norm_center /* NULL or [3] (device) */, const float* norm_scale /* NULL or [3] (device) */,
+                        ia_stream_t stream);
 /* diagnostics (no reference counterpart): runs the searches of ia_fuse_broyden without outputs and ACCUMULATES into
  * counters[17] (caller-zeroed): [0] trilinear fetches, [1] in-range corner loads, [2] converged & in-box items,
  * [3] diverged, [4] out of iterations, [5+k] items that ended after k fetches (k = 2..11).  Used by bench.py to price the

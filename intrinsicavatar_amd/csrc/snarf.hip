@@ -783,18 +783,28 @@ __global__ __launch_bounds__(THREADS) void rows_pack_kernel(int64_t N, int I, co
                                                              const uint32_t* __restrict__ meta, const int32_t* __restrict__ start,
                                                              const int32_t* __restrict__ ovf_head, const int32_t* __restrict__ ovf_rec,
                                                              const float* __restrict__ ovf_x, const uint8_t* __restrict__ ovf_keep,
-                                                             float* __restrict__ cand_x, int32_t* __restrict__ cand_src)
+                                                             float* __restrict__ cand_x, int32_t* __restrict__ cand_src,
+                                                             const float* __restrict__ nc, const float* __restrict__ ns)
 {
     const int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     if (p >= N) return;
     int c = cnt[p];
     if (c == 0) return;
+    // optional: candidates leave in the hash grid's unit cube, (x - center) / scale + 0.5 (IEEE subtract, divide, add -- the bits of
+    // the three elementwise passes it replaces)
+    const bool nrm = nc != nullptr;
+    const float c0 = nrm ? nc[0] : 0.f, c1 = nrm ? nc[1] : 0.f, c2 = nrm ? nc[2] : 0.f;
+    const float s0 = nrm ? ns[0] : 1.f, s1 = nrm ? ns[1] : 1.f, s2 = nrm ? ns[2] : 1.f;
+    auto put = [&](int64_t q_, float a, float b, float d) {
+        if (nrm) { a = (a - c0) / s0 + 0.5f; b = (b - c1) / s1 + 0.5f; d = (d - c2) / s2 + 0.5f; }
+        cand_x[q_ * 3 + 0] = a; cand_x[q_ * 3 + 1] = b; cand_x[q_ * 3 + 2] = d;
+    };
     int64_t q = start[p];
     const unsigned m = meta[p];
     if (m & 0x80000000u) {
         for (int k = ovf_head[p]; k >= 0; k = ovf_rec[3 * k + 2]) {
             if (!ovf_keep[k]) continue;
-            cand_x[q * 3 + 0] = ovf_x[3 * k]; cand_x[q * 3 + 1] = ovf_x[3 * k + 1]; cand_x[q * 3 + 2] = ovf_x[3 * k + 2];
+            put(q, ovf_x[3 * k], ovf_x[3 * k + 1], ovf_x[3 * k + 2]);
             if (cand_src) cand_src[q] = (int32_t)(p * I + ovf_rec[3 * k + 1]);
             q++;
         }
@@ -803,9 +813,7 @@ __global__ __launch_bounds__(THREADS) void rows_pack_kernel(int64_t N, int I, co
     const float* row = x + p * (SPEC_ROOTS * 3);
     for (int k = 0; k < c; k++) {
         const int slot = c - 1 - k;
-        cand_x[(q + k) * 3 + 0] = row[slot * 3 + 0];
-        cand_x[(q + k) * 3 + 1] = row[slot * 3 + 1];
-        cand_x[(q + k) * 3 + 2] = row[slot * 3 + 2];
+        put(q + k, row[slot * 3 + 0], row[slot * 3 + 1], row[slot * 3 + 2]);
         if (cand_src) cand_src[q + k] = (int32_t)(p * I + ((m >> (8 * slot)) & 0xffu));
     }
 }
@@ -1168,13 +1176,15 @@ IA_EXPORT int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, c
 IA_EXPORT int ia_spec_rows_overflow_capacity(void) { return SPEC_OVF_CAP; }
 
 IA_EXPORT int ia_deform_rows_pack(int64_t N, int I, const float* x_rows, const int32_t* cnt, const uint32_t* meta, const int32_t* start,
-                                  const int32_t* ovf_head, const void* ovf_scratch, float* cand_x, int32_t* cand_src, ia_stream_t stream)
+                                  const int32_t* ovf_head, const void* ovf_scratch, float* cand_x, int32_t* cand_src,
+                                  const float* norm_center, const float* norm_scale, ia_stream_t stream)
 {
     if (N == 0) return IA_OK;
     IA_REQUIRE(cand_x != x_rows, "ia_deform_rows_pack: cand_x must not alias x_rows");
+    IA_REQUIRE((norm_center == nullptr) == (norm_scale == nullptr), "ia_deform_rows_pack: norm_center and norm_scale go together");
     OvfLayout o = ovf_layout(const_cast<void*>(ovf_scratch));
     rows_pack_kernel<<<ia::cdiv(N, THREADS), THREADS, 0, (hipStream_t)stream>>>(N, I, x_rows, cnt, meta, start, ovf_head, o.rec, o.x, o.keep,
-                                                                                cand_x, cand_src);
+                                                                                cand_x, cand_src, norm_center, norm_scale);
     return ia::check_launch("ia_deform_rows_pack");
 }
 

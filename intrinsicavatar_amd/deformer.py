@@ -153,12 +153,14 @@ class SNARFDeformer:
     SPEC_ROWS = os.environ.get("IA_BROYDEN_SPEC_ROWS", "1") == "1"
 
     @torch.no_grad()
-    def _candidates(self, pts: Tensor, with_src: bool, want_fwd: bool = False, want_jinv: bool = False, order: Optional[Tensor] = None):
+    def _candidates(self, pts: Tensor, with_src: bool, want_fwd: bool = False, want_jinv: bool = False, order: Optional[Tensor] = None,
+                    normalize=None):
         """search + candidate bookkeeping for P posed points -> (cand_x [Q,3], cand_src [Q] | None, cnt [P], start [P], Q, fwd_J, J_inv).
         Large batches (speculative search, eps >= 1e-4): the search kernel itself leaves each point's surviving candidates in its
         3-slot row plus their count and the scan of the counts (fast_snarf.fuse_broyden_spec_rows: 44 B per point instead of 169) --
         no x [P,13,3], no is_valid, no K9 pass; one segmented copy makes the packed list.  The rare 4th.. candidates of a point go
-        through a small overflow list (K9 among them in the kernel's epilogue).  Otherwise: search() + _pack_candidates()."""
+        through a small overflow list (K9 among them in the kernel's epilogue).  Otherwise: search() + _pack_candidates().
+        normalize = (center [3], scale [3]): cand_x comes back as (x - center) / scale + 0.5 (the hash grid's coordinates)."""
         P, I = pts.shape[0], self.init_bones.shape[0]
         dev = self.device
         if not (self.SPEC_ROWS and self.spec_eps >= 1e-4 and P >= self.SPEC_MIN_POINTS and self.tfs.shape[0] == 1):
@@ -167,7 +169,7 @@ class SNARFDeformer:
             r = self.search(pts, want_fwd=want_fwd, want_jinv=want_jinv)
             x, valid, fwd = r[0], r[1], r[2]
             J_inv = r[3] if want_jinv else None
-            return (*self._pack_candidates(x, valid, with_src=with_src), fwd, J_inv)
+            return self._normalized((*self._pack_candidates(x, valid, with_src=with_src), fwd, J_inv), normalize)
         lib, st = L.lib(), L.stream()
         x_rows = torch.empty((P, 3, 3), device=dev)
         Jinv = torch.empty((1, P, I, 3, 3), device=dev) if want_jinv else None
@@ -188,12 +190,20 @@ class SNARFDeformer:
             if order is not None:
                 pts = pts[order.long()].contiguous()
             r = self.search(pts, want_fwd=want_fwd, want_jinv=want_jinv)
-            return (*self._pack_candidates(r[0], r[1], with_src=with_src), r[2], (r[3] if want_jinv else None))
+            return self._normalized((*self._pack_candidates(r[0], r[1], with_src=with_src), r[2], (r[3] if want_jinv else None)), normalize)
         cand_x = torch.empty((Q, 3), device=dev)
         cand_src = torch.empty(Q, dtype=torch.int32, device=dev) if with_src else None
         L.check(lib.ia_deform_rows_pack(L.i64(P), L.i32(I), L.ptr(x_rows), L.ptr(cnt), L.ptr(meta), L.ptr(start), L.ptr(ovf_head),
-                                        L.ptr(self._ovf_scratch), L.ptr(cand_x), L.ptr(cand_src), st), "ia_deform_rows_pack")
+                                        L.ptr(self._ovf_scratch), L.ptr(cand_x), L.ptr(cand_src),
+                                        L.ptr(normalize[0].contiguous().float() if normalize else None),
+                                        L.ptr(normalize[1].contiguous().float() if normalize else None), st), "ia_deform_rows_pack")
         return cand_x, cand_src, cnt, start, Q, (fwd[0] if want_fwd else None), (Jinv[0] if want_jinv else None)
+
+    @staticmethod
+    def _normalized(res, normalize):
+        if normalize is None:
+            return res
+        return ((res[0] - normalize[0]) / normalize[1] + 0.5, *res[1:])
 
     @torch.no_grad()
     def deform_sdf(self, pts: Tensor, geometry, order: Optional[Tensor] = None) -> Tensor:
@@ -206,8 +216,9 @@ class SNARFDeformer:
         P, I = pts.shape[0], self.init_bones.shape[0]
         dev = self.device
         lib, st = L.lib(), L.stream()
-        cand_x, _, cnt, start, Q, _, _ = self._candidates(pts, with_src=False, order=order)
-        csdf = geometry.sdf_only(cand_x)
+        # the candidates leave the packing kernel in the hash grid's coordinates (three elementwise passes over [Q,3] less)
+        cand_x, _, cnt, start, Q, _, _ = self._candidates(pts, with_src=False, order=order, normalize=(geometry.center, geometry.scale))
+        csdf = geometry.sdf_only(cand_x, normalized=True)
         sdf = torch.empty(P, device=dev)
         if order is not None:         # pts = caller's points[order]: the result goes back to the caller's order on the way out
             L.check(lib.ia_deform_select_min_scatter(L.i64(P), L.ptr(start), L.ptr(cnt), L.ptr(csdf), L.ptr(order), L.ptr(sdf), st),

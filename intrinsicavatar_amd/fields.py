@@ -246,17 +246,20 @@ class VolumeSDF(nn.Module):
         return W1k, self.network.layers[0].bias, self.network.layers[2].effective(), self.network.layers[2].bias
 
     @torch.no_grad()
-    def sdf_only(self, points: Tensor) -> Tensor:
+    def sdf_only(self, points: Tensor, normalized: bool = False) -> Tensor:
         """SDF value alone (feature[:, 0] of VolumeSDF.forward, rf/geometry.py:152-160) for the no-grad coarse queries:
         XCD-partitioned hash gather whose level-major result feeds the software-pipelined value head directly (no [n,32] feature
         rows, no transpose pass, 4 instead of 52 output bytes per point).  EVERY batch size takes this path, so the value of a
         point does not depend on how many other points share its launch (ray-batch sharding invariance); against forward() the
-        output layer is summed in another order (last-bit differences)."""
+        output layer is summed in another order (last-bit differences).  normalized: `points` are already the hash grid's
+        coordinates (points - center) / scale + 0.5."""
         n = points.shape[0]
         if n == 0 or os.environ.get("IA_SDF_ONLY_FUSED", "1") != "1":
+            if normalized:
+                points = (points - 0.5) * self.scale + self.center
             return self.forward(points, with_grad=False, with_feature=False).contiguous()
         cfg = HASH
-        xp = ((points - self.center) / self.scale + 0.5).contiguous()
+        xp = points.contiguous() if normalized else ((points - self.center) / self.scale + 0.5).contiguous()
         nb = int(L.lib().ia_hashgrid_fwd_scratch_bytes(L.i64(n), L.i32(cfg["n_levels"]), L.i32(0)))
         scratch = torch.empty(nb, dtype=torch.uint8, device=xp.device)
         L.check(L.lib().ia_hashgrid_fwd_xcd(L.i64(n), L.ptr(xp), L.ptr(self.grid_params), L.i32(cfg["n_levels"]),

@@ -135,6 +135,18 @@ def test_candidate_rows_equal_search_plus_k9_pack(march):
     assert torch.equal(s_rows, s_k9)
 
 
+def test_candidates_leave_the_packing_kernel_in_hash_grid_coordinates(march):
+    """ia_deform_rows_pack with norm_center / norm_scale: (x - center) / scale + 0.5 on the way out (models/rf/geometry.py:155), the bits
+    of the three elementwise passes it replaces."""
+    SP, rs, pts, _ = march
+    dfm, geo = rs.deformer, rs.geometry
+    a = dfm._candidates(pts, with_src=True)
+    b = dfm._candidates(pts, with_src=True, normalize=(geo.center, geo.scale))
+    assert a[4] == b[4] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert torch.equal(b[0], (a[0] - geo.center) / geo.scale + 0.5)
+    assert torch.equal(geo.sdf_only(b[0], normalized=True), geo.sdf_only(a[0]))
+
+
 def test_candidates_beyond_the_row_slots_go_through_the_overflow_list(march, monkeypatch):
     """a point's 4th, 5th ... completed search (tested against the first three roots only) becomes an overflow record; K9
     (filter.cu:10-54) runs among a point's records and the kept ones are emitted in front of the row's candidates.  Points with
