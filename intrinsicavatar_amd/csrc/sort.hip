@@ -63,6 +63,8 @@ __global__ __launch_bounds__(THREADS) void scatter_rows3_i32_kernel(int64_t n, c
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// (measured: a custom onesweep config with 10 instead of rocPRIM's tuned 8 bits per pass -- 3 passes over the 30 key bits instead of 4 --
+//  is no faster: 10.9 against 10.6 ms per headline step for the eight sorts)
 size_t sort_storage_bytes(int64_t n, int drop_bits)
 {
     size_t bytes = 0;
