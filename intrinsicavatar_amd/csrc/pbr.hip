@@ -467,6 +467,160 @@ __global__ __launch_bounds__(ENV_ACC_THREADS) void env_band_accumulate_kernel(in
     }
 }
 
+// ---- the same sums from records BINNED BY BAND, in fixed point -----------------------------------------------------------------------
+// Two things were wrong with env_band_accumulate_kernel.  (1) It reads the 4-byte texel words of ALL records once per band (16
+// bands for the reference's 256 x 512 map) and then gathers the matching records' weights and gradients -- one record in 16, an
+// 8- and a 12-byte piece out of every ~380 bytes: PMC 14.8 GB per launch for 2.0 GB of records.  (2) What it spends its time on
+// is something else: LDS float atomics.  With the records binned and read contiguously the accumulation alone still took
+// 3.66 ms per headline step; the same kernel with INTEGER LDS atomics 0.27 ms, with plain (racy) read-modify-writes 0.36 ms, without
+// its flush 3.64 ms -- ds_add_f32 runs at ~0.5 lanes per clock and CU on gfx950, ds_add_u32 / u64 at the LDS's rate.
+// So: records are binned by band (count per 8192-record tile + max |g| -> one exclusive scan over [band][tile] -> scatter as
+// 24-byte AoS records: all streamed), and a band's list is summed in 64-bit FIXED POINT: contribution = round(w g S), S =
+// 2^35 / max |g| (a texel can take 2^27 maximal contributions; a contribution keeps its 24 fp32 bits down to 2^-11 of the
+// largest one and is absolute to 2^-35 of it below: tighter than any fp32 summation order), LDS ds_add_u64, one global 64-bit
+// atomic per touched texel channel into an integer image, converted and added to g_base once per texel at the end.  Integer
+// sums do not depend on the order: the texel gradient is bit-reproducible run to run (the float-atomic versions were not).
+constexpr int ENV_TILE = 8192;
+constexpr int ENV_ACC64_LDS = 144 * 1024;
+
+__global__ __launch_bounds__(ENV_ACC_THREADS) void env_bin_count_kernel(int64_t F, const uint32_t* __restrict__ rec_idx,
+                                                                        const float* __restrict__ rec_g, int TH, int n_bands, int n_tiles,
+                                                                        int32_t* __restrict__ counts /*[n_bands][n_tiles]*/,
+                                                                        uint32_t* __restrict__ gmax /* bits of max |g| */)
+{
+    __shared__ int s_h[32];
+    __shared__ uint32_t s_m;
+    if (threadIdx.x < 32) s_h[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_m = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * ENV_TILE;
+    float m = 0.0f;
+#pragma unroll
+    for (int j = 0; j < ENV_TILE / ENV_ACC_THREADS; j++) {
+        const int64_t i = base + j * ENV_ACC_THREADS + threadIdx.x;
+        const uint32_t k = i < F ? rec_idx[i] : ENV_REC_NONE;
+        const int b = k != ENV_REC_NONE ? (int)((k >> 16) & 0x7FFFu) / TH : -1;
+        if (b >= 0) m = fmaxf(m, fmaxf(fabsf(rec_g[i * 3]), fmaxf(fabsf(rec_g[i * 3 + 1]), fabsf(rec_g[i * 3 + 2]))));
+#pragma unroll 1
+        for (int bb = 0; bb < n_bands; bb++) {
+            const uint64_t mk = __ballot(b == bb);
+            if (mk && (threadIdx.x & 63) == 0) atomicAdd(&s_h[bb], __popcll(mk));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(&s_m, __float_as_uint(m));       // non-negative floats order like their bits
+    __syncthreads();
+    if (threadIdx.x < n_bands) counts[(int64_t)threadIdx.x * n_tiles + blockIdx.x] = s_h[threadIdx.x];
+    if (threadIdx.x == 0 && s_m > *gmax) atomicMax(gmax, s_m);                           // read first: same-address atomics serialise
+}
+
+struct EnvRec { uint32_t k; float ax, ay, g0, g1, g2; };      // 24 bytes
+
+__global__ __launch_bounds__(ENV_ACC_THREADS) void env_bin_scatter_kernel(int64_t F, const uint32_t* __restrict__ rec_idx,
+                                                                          const float2* __restrict__ rec_w, const float* __restrict__ rec_g,
+                                                                          int TH, int n_bands, int n_tiles, const int32_t* __restrict__ offs,
+                                                                          EnvRec* __restrict__ out)
+{
+    __shared__ int s_cur[32];                                     // next free slot of (this tile, band) in the band-sorted list
+    if (threadIdx.x < n_bands) s_cur[threadIdx.x] = offs[(int64_t)threadIdx.x * n_tiles + blockIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t base = (int64_t)blockIdx.x * ENV_TILE;
+#pragma unroll
+    for (int j = 0; j < ENV_TILE / ENV_ACC_THREADS; j++) {
+        const int64_t i = base + j * ENV_ACC_THREADS + threadIdx.x;
+        const uint32_t k = i < F ? rec_idx[i] : ENV_REC_NONE;
+        const int b = k != ENV_REC_NONE ? (int)((k >> 16) & 0x7FFFu) / TH : -1;
+        int pos = -1;
+#pragma unroll 1
+        for (int bb = 0; bb < n_bands; bb++) {
+            const uint64_t m = __ballot(b == bb);
+            if (!m) continue;
+            int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&s_cur[bb], __popcll(m));
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
+            if (b == bb) pos = wbase + __popcll(m & ((1ull << lane) - 1ull));
+        }
+        if (pos >= 0) {
+            const float2 a = rec_w[i];
+            EnvRec r;
+            r.k = k; r.ax = a.x; r.ay = a.y; r.g0 = rec_g[i * 3]; r.g1 = rec_g[i * 3 + 1]; r.g2 = rec_g[i * 3 + 2];
+            out[pos] = r;
+        }
+    }
+}
+
+__device__ __forceinline__ double env_fixed_scale(uint32_t gmax_bits)
+{
+    const float m = __uint_as_float(gmax_bits);
+    return (m > 0.0f && m < 3.0e38f) ? 34359738368.0 / (double)m : 0.0;                  // 2^35 / max |g|
+}
+
+__global__ __launch_bounds__(ENV_ACC_THREADS) void env_band_accumulate_binned_kernel(const EnvRec* __restrict__ recs,
+                                                                                     const int32_t* __restrict__ offs /*[n_bands][n_tiles]*/,
+                                                                                     const int32_t* __restrict__ total_p, int n_tiles, int H, int W,
+                                                                                     int TH, int n_bands, const uint32_t* __restrict__ gmax,
+                                                                                     unsigned long long* __restrict__ acc64 /*[H][W][3]*/)
+{
+    extern __shared__ unsigned long long s_acc64[];     // [(TH + 1)][W][3], two's complement
+    // which (band, part) is this workgroup: parts of a band = ceil(records of the band / R), R = records per workgroup
+    const int total = *total_p;
+    const double S = env_fixed_scale(*gmax);
+    if (total == 0 || S == 0.0) return;
+    const int R = max(4096, (total + ((int)gridDim.x - n_bands) - 1) / max((int)gridDim.x - n_bands, 1));
+    int band = -1, part = 0, b0 = 0, b1 = 0;
+    {
+        int w = blockIdx.x;
+        for (int b = 0; b < n_bands; b++) {
+            const int s0 = offs[(int64_t)b * n_tiles], s1 = b + 1 < n_bands ? offs[(int64_t)(b + 1) * n_tiles] : total;
+            const int parts = (s1 - s0 + R - 1) / R;
+            if (w < parts) { band = b; part = w; b0 = s0; b1 = s1; break; }
+            w -= parts;
+        }
+    }
+    if (band < 0) return;
+    const int y_lo = band * TH;
+    const int rows = min(TH + 1, H - y_lo);
+    for (int e = threadIdx.x; e < rows * W * 3; e += ENV_ACC_THREADS) s_acc64[e] = 0ull;
+    __syncthreads();
+    const int i0 = b0 + part * R, i1 = min(b1, i0 + R);
+    for (int i = i0 + threadIdx.x; i < i1; i += ENV_ACC_THREADS) {
+        const EnvRec r = recs[i];
+        const int y0 = (int)((r.k >> 16) & 0x7FFFu) - y_lo;
+        const int x0 = (int)(r.k & 0xFFFFu);
+        const int x1 = x0 + 1 == W ? 0 : x0 + 1;
+        const int y1 = (r.k >> 31) ? y0 : y0 + 1;
+        const float w00 = (1 - r.ax) * (1 - r.ay), w10 = r.ax * (1 - r.ay), w01 = (1 - r.ax) * r.ay, w11 = r.ax * r.ay;
+        const float g[3] = {r.g0, r.g1, r.g2};
+        auto add = [&](int e, float v) { atomicAdd(&s_acc64[e], (unsigned long long)__double2ll_rn((double)v * S)); };
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            if (g[c] == 0.0f) continue;
+            add((y0 * W + x0) * 3 + c, w00 * g[c]);          // the fp32 products of the float versions, summed exactly
+            add((y0 * W + x1) * 3 + c, w10 * g[c]);
+            add((y1 * W + x0) * 3 + c, w01 * g[c]);
+            add((y1 * W + x1) * 3 + c, w11 * g[c]);
+        }
+    }
+    __syncthreads();
+    unsigned long long* gb = acc64 + (int64_t)y_lo * W * 3;
+    for (int e = threadIdx.x; e < rows * W * 3; e += ENV_ACC_THREADS) {
+        const unsigned long long v = s_acc64[e];
+        if (v != 0ull) atomicAdd(gb + e, v);
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void env_fixed_finish_kernel(int64_t n, const unsigned long long* __restrict__ acc64,
+                                                                    const uint32_t* __restrict__ gmax, float* __restrict__ g_base)
+{
+    const int64_t e = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (e >= n) return;
+    const long long v = (long long)acc64[e];
+    if (v == 0) return;
+    g_base[e] += (float)((double)v / env_fixed_scale(*gmax));
+}
+
 template <int MODE>
 __global__ __launch_bounds__(THREADS) void pbr_light_bwd_kernel(
     int64_t F, const float* __restrict__ inv_pdf, const float* __restrict__ normal, const float* __restrict__ albedo,
@@ -621,11 +775,19 @@ IA_EXPORT int ia_pbr_shade(int mode, int64_t F, const float* normal, const float
 
 
 constexpr int64_t ENV_ACC_MIN_F = (int64_t)1 << 21;
+constexpr size_t ENV_FIXED_MAX_TEXELS = (size_t)1 << 21;       // 1024 x 2048
+extern "C" int64_t ia_scan_tmp_bytes(int64_t n);
+extern "C" int ia_exclusive_scan_i32(const int32_t* in, int32_t* out, int32_t* total, int64_t n, void* tmp, ia_stream_t stream);
 
 IA_EXPORT size_t ia_pbr_shade_bwd_scratch_bytes(int64_t F)
 {
     if (F < ENV_ACC_MIN_F) return 0;                 // small batches scatter with atomics directly
-    return ((((size_t)F + 3) & ~(size_t)3)) * 24 + 64;
+    // SoA records of the backward kernel (24 B each) | band-sorted AoS records (24 B each) | [32][n_tiles] counts | the same, scanned |
+    // total, max |g| | scan scratch | the 64-bit fixed-point image (sized for the largest map the fixed-point path takes: 2^21 texels)
+    const size_t n4 = ((size_t)F + 3) & ~(size_t)3;
+    const size_t n_tiles = ((size_t)F + ENV_TILE - 1) / ENV_TILE;
+    return n4 * 24 + 64 + n4 * 24 + 2 * (32 * n_tiles * 4 + 64) + 64 + (size_t)ia_scan_tmp_bytes((int64_t)(32 * n_tiles)) + 512 +
+           ENV_FIXED_MAX_TEXELS * 3 * 8;
 }
 
 IA_EXPORT int ia_pbr_shade_bwd(int mode, int64_t F, const float* normal, const float* albedo, const float* roughness,
@@ -675,10 +837,45 @@ IA_EXPORT int ia_pbr_shade_bwd(int mode, int64_t F, const float* normal, const f
             (void)hipGetLastError();
             attr = true;
         }
-        const int n_ranges = 16;
-        const size_t lds = (size_t)(TH + 1) * env_w * 3 * sizeof(float);
-        env_band_accumulate_kernel<<<8 * n_bands * (n_ranges / 8), ENV_ACC_THREADS, lds, s>>>(F, rec_idx, rec_w, rec_g, env_h, env_w, TH,
-                                                                                                n_bands, n_ranges, g_env_base);
+        const int rows64 = ENV_ACC64_LDS / (env_w * 3 * (int)sizeof(unsigned long long));
+        const int TH64 = rows64 - 1, n_bands64 = TH64 >= 1 ? (env_h + TH64 - 1) / TH64 : 0;
+        const bool fixed = !getenv("IA_ENV_GRAD_UNBINNED") && TH64 >= 1 && n_bands64 <= 32 && (size_t)env_h * env_w <= ENV_FIXED_MAX_TEXELS &&
+                           F < ((int64_t)1 << 31) - ENV_TILE;
+        if (!fixed) {
+            const int n_ranges = 16;
+            const size_t lds = (size_t)(TH + 1) * env_w * 3 * sizeof(float);
+            env_band_accumulate_kernel<<<8 * n_bands * (n_ranges / 8), ENV_ACC_THREADS, lds, s>>>(F, rec_idx, rec_w, rec_g, env_h, env_w, TH,
+                                                                                                    n_bands, n_ranges, g_env_base);
+        } else {
+            static bool attr64 = false;
+            if (!attr64) {
+                (void)hipFuncSetAttribute((const void*)env_band_accumulate_binned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ENV_ACC64_LDS);
+                (void)hipGetLastError();
+                attr64 = true;
+            }
+            const size_t n4 = ((size_t)F + 3) & ~(size_t)3;
+            const int n_tiles = (int)((F + ENV_TILE - 1) / ENV_TILE);
+            char* p = reinterpret_cast<char*>(scratch) + n4 * 24 + 64;
+            EnvRec* sorted = reinterpret_cast<EnvRec*>(p);                 p += n4 * 24;
+            int32_t* counts = reinterpret_cast<int32_t*>(p);               p += (size_t)32 * n_tiles * 4 + 64;
+            int32_t* offs = reinterpret_cast<int32_t*>(p);                 p += (size_t)32 * n_tiles * 4 + 64;
+            int32_t* total = reinterpret_cast<int32_t*>(p);
+            uint32_t* gmax = reinterpret_cast<uint32_t*>(p + 16);          p += 64;
+            void* scan_tmp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(p) + 255) & ~(uintptr_t)255);
+            p = reinterpret_cast<char*>(scan_tmp) + ia_scan_tmp_bytes((int64_t)(32 * (int64_t)n_tiles));
+            unsigned long long* acc64 = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(p) + 255) & ~(uintptr_t)255);
+            const int64_t n_img = (int64_t)env_h * env_w * 3;
+            (void)hipMemsetAsync(gmax, 0, 4, s);
+            (void)hipMemsetAsync(acc64, 0, (size_t)n_img * 8, s);
+            env_bin_count_kernel<<<n_tiles, ENV_ACC_THREADS, 0, s>>>(F, rec_idx, rec_g, TH64, n_bands64, n_tiles, counts, gmax);
+            const int rc = ia_exclusive_scan_i32(counts, offs, total, (int64_t)n_bands64 * n_tiles, scan_tmp, stream);
+            if (rc != IA_OK) return rc;
+            env_bin_scatter_kernel<<<n_tiles, ENV_ACC_THREADS, 0, s>>>(F, rec_idx, rec_w, rec_g, TH64, n_bands64, n_tiles, offs, sorted);
+            const size_t lds64 = (size_t)(TH64 + 1) * env_w * 3 * sizeof(unsigned long long);
+            env_band_accumulate_binned_kernel<<<256 + n_bands64, ENV_ACC_THREADS, lds64, s>>>(sorted, offs, total, n_tiles, env_h, env_w, TH64,
+                                                                                              n_bands64, gmax, acc64);
+            env_fixed_finish_kernel<<<ia::cdiv(n_img, THREADS), THREADS, 0, s>>>(n_img, acc64, gmax, g_env_base);
+        }
     }
     return ia::check_launch("ia_pbr_shade_bwd");
 }

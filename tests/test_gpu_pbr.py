@@ -316,9 +316,11 @@ def test_pbr_shade_backward_vs_autograd(env):
 
 @pytest.mark.parametrize("mode,hw", [("light", (256, 512)), ("uniform_light", (64, 128)), ("light", (40, 96))])
 def test_env_texel_gradient_banded_accumulation_equals_the_atomic_scatter(mode, hw, monkeypatch):
-    """large batches: ia_pbr_shade_bwd accumulates d L / d env texels through per-sample records and banded LDS sums; the
-    result is the direct atomic scatter's (IA_ENV_GRAD_ATOMIC=1) up to fp32 summation order, every other gradient is identical.
-    (256, 512) needs 13 bands, the others one; the sizes cover wrap-around in x and the clamped first / last rows."""
+    """large batches: ia_pbr_shade_bwd accumulates d L / d env texels through per-sample records and banded LDS sums -- records
+    binned by band first and summed in 64-bit fixed point (default; bit-reproducible), or every band streaming all records into float
+    LDS atomics (IA_ENV_GRAD_UNBINNED=1); the result is the direct atomic scatter's (IA_ENV_GRAD_ATOMIC=1) up to fp32 summation order,
+    every other gradient is identical.
+    (256, 512) needs 16 bands, the others one; the sizes cover wrap-around in x and the clamped first / last rows."""
     from intrinsicavatar_amd import pbr
     F = (1 << 21) + 12345
     g = torch.Generator(device=DEV).manual_seed(F + hw[0])
@@ -339,22 +341,25 @@ def test_env_texel_gradient_banded_accumulation_equals_the_atomic_scatter(mode, 
     e = pbr.EnvironmentLightTensor(base.clone()); e.update_pdf()
     gl = torch.randn(F, 3, device=DEV, generator=g)
     res = []
-    for atomic in ("1", None):
-        if atomic:
-            monkeypatch.setenv("IA_ENV_GRAD_ATOMIC", atomic)
-        else:
-            monkeypatch.delenv("IA_ENV_GRAD_ATOMIC")
+    for variant in ("IA_ENV_GRAD_ATOMIC", None, "IA_ENV_GRAD_UNBINNED", None):
+        for k in ("IA_ENV_GRAD_ATOMIC", "IA_ENV_GRAD_UNBINNED"):
+            monkeypatch.delenv(k, raising=False)
+        if variant:
+            monkeypatch.setenv(variant, "1")
         leaves = [t.clone().requires_grad_(True) for t in (n, alb, rough, met, base)]
         Lo, _, _ = pbr.pbr_shade_differentiable(mode, leaves[0], leaves[1], leaves[2], leaves[3], v, wo, tr, None, e, Rm,
                                                 inv_pdf=inv_pdf if mode == "uniform_light" else None, env_base=leaves[4])
         (Lo * gl).sum().backward()
         res.append([t.grad.clone() for t in leaves])
-    for a, b in zip(res[0][:4], res[1][:4]):
-        assert torch.equal(a, b)
-    ga, gb = res[0][4].double(), res[1][4].double()
-    assert float(ga.abs().max()) > 0
-    assert float((ga - gb).abs().max()) <= 2e-4 * float(ga.abs().max())
-    assert torch.equal(ga == 0, gb == 0)
+    monkeypatch.delenv("IA_ENV_GRAD_UNBINNED", raising=False)
+    assert torch.equal(res[1][4], res[3][4])            # the default sums in 64-bit fixed point: the same bits every run
+    for other in res[1:]:
+        for a, b in zip(res[0][:4], other[:4]):
+            assert torch.equal(a, b)
+        ga, gb = res[0][4].double(), other[4].double()
+        assert float(ga.abs().max()) > 0
+        assert float((ga - gb).abs().max()) <= 2e-4 * float(ga.abs().max())
+        assert torch.equal(ga == 0, gb == 0)
 
 
 def test_sg_environment_light_trains_through_the_estimator():
