@@ -150,15 +150,36 @@ __device__ __forceinline__ void J_inv_update(float Ji[9], float x0, float x1, fl
     const float r0 = -J00 * g0 - J01 * g1 - J02 * g2;
     const float r1 = -J10 * g0 - J11 * g1 - J12 * g2;
     const float r2 = -J20 * g0 - J21 * g1 - J22 * g2;
-    Ji[0] += c0 * (r0 + x0) / s;
-    Ji[1] += c1 * (r0 + x0) / s;
-    Ji[2] += c2 * (r0 + x0) / s;
-    Ji[3] += c0 * (r1 + x1) / s;
-    Ji[4] += c1 * (r1 + x1) / s;
-    Ji[5] += c2 * (r1 + x1) / s;
-    Ji[6] += c0 * (r2 + x2) / s;
-    Ji[7] += c1 * (r2 + x2) / s;
-    Ji[8] += c2 * (r2 + x2) / s;
+    // nine IEEE divisions by the SAME denominator (fuse_cuda_kernel_fast.cu:232-243).  hipcc expands a / s into 11 instructions:
+    //   v_div_scale (s) . v_rcp . fma . fma  [reciprocal r1 of s, one Newton step]
+    //   v_div_scale (a) . q0 = a r1 . rem0 = fma(-s, q0, a) . q1 = fma(rem0, r1, q0) . rem1 = fma(-s, q1, a) . v_div_fmas . v_div_fixup
+    // v_div_scale leaves both operands as they are -- and v_div_fmas is then a plain fma, v_div_fixup returns its first operand --
+    // unless an operand or the quotient is zero / denormal / huge, the exponents differ by 96 or more, or the numerator is below
+    // 2^-103.  With every |numerator| and |s| in [2^-40, 2^40] none of that can happen, the nine expansions compute the same r1
+    // nine times, and sharing it leaves the SAME five operations per quotient: bit-identical, 48 + 15 (range test) instead of 99
+    // VALU instructions on a kernel whose VALU is 77 % busy (tools/pmc_probe.sh).  Anything else (NaN included: the comparisons
+    // fail) takes the plain divisions.
+    const float t0 = r0 + x0, t1 = r1 + x1, t2 = r2 + x2;
+    const float n[9] = {c0 * t0, c1 * t0, c2 * t0, c0 * t1, c1 * t1, c2 * t1, c0 * t2, c1 * t2, c2 * t2};
+    const float mx = fmaxf(fmaxf(fmaxf(fabsf(n[0]), fabsf(n[1])), fmaxf(fabsf(n[2]), fabsf(n[3]))),
+                           fmaxf(fmaxf(fabsf(n[4]), fabsf(n[5])), fmaxf(fmaxf(fabsf(n[6]), fabsf(n[7])), fabsf(n[8]))));
+    const float mn = fminf(fminf(fminf(fabsf(n[0]), fabsf(n[1])), fminf(fabsf(n[2]), fabsf(n[3]))),
+                           fminf(fminf(fabsf(n[4]), fabsf(n[5])), fminf(fminf(fabsf(n[6]), fabsf(n[7])), fabsf(n[8]))));
+    const float as = fabsf(s);
+    if (mx <= 0x1p40f && mn >= 0x1p-40f && as <= 0x1p40f && as >= 0x1p-40f) {
+        float r = __builtin_amdgcn_rcpf(s);
+        r = fmaf(fmaf(-s, r, 1.0f), r, r);
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            float q = n[k] * r;
+            q = fmaf(fmaf(-s, q, n[k]), r, q);
+            q = fmaf(fmaf(-s, q, n[k]), r, q);
+            Ji[k] += q;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) Ji[k] += n[k] / s;
+    }
 }
 
 // ---- K8 -------------------------------------------------------------------------
@@ -547,7 +568,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
     int32_t* __restrict__ cnt /* PACK: [N] */, uint32_t* __restrict__ meta /* PACK: [N] */, int32_t* __restrict__ ovf_count /* PACK: [1] */,
     int32_t* __restrict__ ovf_head /* PACK: [N], written for points with extras only */, int32_t* __restrict__ ovf_rec /* PACK: [cap][3] point, init, prev */,
     float* __restrict__ ovf_x /* PACK: [cap][3] */, int ovf_cap, int slots /* <= SPEC_ROOTS: roots recorded / row slots used (test hook) */,
-    const int32_t* __restrict__ order /* NULL or [N]: point p of this launch is xd_tgt[order[p]] (evaluation order != storage order) */)
+    const int32_t* __restrict__ order /* NULL or [N]: point p of this launch is xd_tgt[order[p]] (evaluation order != storage order) */,
+    int refill_min /* idle lanes of a wave before it pulls new points */)
 {
     __shared__ float s_T[16 * 12];                     // per init: rows 0..2 of its bone's 4x4 (R | t)
     __shared__ int s_cur;                              // points of the WORKGROUP's chunk handed out so far
@@ -602,7 +624,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
                 }
             }
         }
-        const unsigned long long need = drained ? 0ull : __ballot(!have);
+        // the refill below is ~90 VALU instructions + dependent loads for the whole wave, whoever needs it: with ~1.5 lanes finishing a
+        // point per iteration it ran on practically every iteration for one or two lanes.  It now waits until refill_min lanes are idle
+        // (or nobody has work): a few lanes idle a few iterations longer, the wave executes the block a fraction as often.
+        unsigned long long need = drained ? 0ull : __ballot(!have);
+        if (need && __popcll(need) < refill_min && need != ~0ull && __any(have)) need = 0ull;
         if (need) {
             int base = 0;
             if (lane == 0) base = atomicAdd(&s_cur, __popcll(need));
@@ -1103,12 +1129,14 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
     const int grid = (int)((N + pts_wg - 1) / pts_wg);
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* c = reinterpret_cast<unsigned long long*>(counters);
+    int refill_min = 8;
+    if (const char* e = getenv("IA_BR_SPEC_REFILL")) { const int v = atoi(e); if (v >= 1 && v <= 64) refill_min = v; }
     int slots = SPEC_ROOTS;                                              // test hook: fewer recorded roots / row slots => the overflow list is used
     if (const char* e = getenv("IA_SPEC_TEST_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= SPEC_ROOTS) slots = v; }
 #define IA_SPEC_LAUNCH(COUNT, PACK)                                                                                                    \
     broyden_spec_kernel<COUNT, PACK><<<grid, THREADS, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,         \
                                                                cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J, pts, c, cnt, \
-                                                               meta, ovf_count, ovf_head, ovf_rec, ovf_x, ovf_cap, slots, order)
+                                                               meta, ovf_count, ovf_head, ovf_rec, ovf_x, ovf_cap, slots, order, refill_min)
     if (pack) { if (counters) IA_SPEC_LAUNCH(true, true); else IA_SPEC_LAUNCH(false, true); }
     else { if (counters) IA_SPEC_LAUNCH(true, false); else IA_SPEC_LAUNCH(false, false); }
 #undef IA_SPEC_LAUNCH

@@ -366,6 +366,37 @@ def test_fast_snarf_vs_golden(ops, golden_dir, schedule, monkeypatch):
         np.testing.assert_array_equal(N(sn.filter(x, valid)), g["filtered"], err_msg=layout)
 
 
+def test_fast_snarf_bit_exact_vs_the_oracle_on_a_large_batch(ops):
+    """K8 on 40 k random points x 13 inits against oracle/ia_oracle.c (plain IEEE divisions in the rank-1 update): x, J_inv, valid
+    bit for bit -- the kernel's update shares the reciprocal of the nine divisions' common denominator (snarf.hip J_inv_update)."""
+    from intrinsicavatar_amd import synthetic as S
+    from oracle import oracle as O
+    sn = ops["snarf"]
+    w, offk, sck, bbox = S.skinning_weight_grid(D=16, H=64, W=64, smooth_iters=5)
+    rig = S.make_rig(S.make_pose(3, 0.25))
+    vw, tfs, off, sc = T(w), T(rig["tfs"]), T(offk), T(sck)
+    _, _, D, H, W = vw.shape
+    vd = torch.zeros(1, 3, D, H, W, device=DEV)
+    vJ = torch.zeros(1, 12, D, H, W, device=DEV)
+    vJcl = torch.zeros(1, D, H, W, 12, device=DEV)
+    sn.precompute(vw, tfs, vd, vJ, off, sc, voxel_J_cl=vJcl)
+    n = 40_000
+    g = torch.Generator(device="cpu").manual_seed(5)
+    lo, hi = torch.from_numpy(S.body_aabb(rig["joints_posed"], 1.0)).split(3)
+    xd = (torch.rand(1, n, 3, generator=g) * (hi - lo) + lo).to(DEV)
+    x = torch.zeros(1, n, 13, 3, device=DEV)
+    Ji = torch.zeros(1, n, 13, 3, 3, device=DEV)
+    valid = torch.zeros(1, n, 13, dtype=torch.bool, device=DEV)
+    sn.fuse_broyden(x, xd, vd, sn.ChannelLastVoxelJ(vJcl), tfs, T(S.INIT_BONES), True, Ji, valid, off, sc, 1e-5, 1e-1)
+    xr, Jr, vr = O.fuse_broyden(N(xd), N(vJ), N(tfs), S.INIT_BONES, N(off), N(sc))
+    vr = vr.astype(bool)
+    assert 0.02 < vr.mean() < 0.98
+    np.testing.assert_array_equal(N(valid), vr)
+    m = vr[..., None]
+    np.testing.assert_array_equal(np.where(m, N(x), 0), np.where(m, xr, 0))
+    np.testing.assert_array_equal(np.where(m[..., None], N(Ji), 0), np.where(m[..., None], Jr, 0))
+
+
 def test_fast_snarf_roundtrip_property(ops):
     """size-independent property at a large N: forward-skinning every valid root lands on the query point."""
     from intrinsicavatar_amd import synthetic as S
