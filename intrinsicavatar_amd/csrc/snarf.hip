@@ -125,11 +125,28 @@ __device__ __forceinline__ void grid_sample_J(const float* __restrict__ vJ, int 
     const bool okz[2] = {z0 >= 0 && z0 < D, z1 >= 0 && z1 < D};
     const int lin0 = vox0 + (z0 * H + y0) * W + x0;
     const int sy = W, sz = H * W;
+    // channel-last: the byte offset of corner 0 is computed ONCE and pinned in a register (hipcc otherwise re-derives every corner's
+    // voxel index from z0, y0, x0 with two v_mad_u64_u32 and a v_mul_lo_u32 -- 24 quarter-rate instructions per fetch, as much
+    // issue time as the 96 packed multiply-adds of the interpolation); the other corners add wave-uniform constants
+    uint32_t boff0 = (uint32_t)lin0 * 48u;
+    if (LAYOUT == IA_LAYOUT_NDHWC) asm volatile("" : "+v"(boff0));
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         if (okx[c & 1] && oky[(c >> 1) & 1] && okz[(c >> 2) & 1]) {
             float v[12];
-            load_corner<LAYOUT>(vJ, vol, (int64_t)(lin0 + (c & 1) + ((c >> 1) & 1) * sy + ((c >> 2) & 1) * sz), v);
+            if (LAYOUT == IA_LAYOUT_NDHWC) {
+                const uint32_t cst = (uint32_t)((c & 1) + ((c >> 1) & 1) * sy + ((c >> 2) & 1) * sz) * 48u;     // scalar
+                const char* base = reinterpret_cast<const char*>(vJ);
+                const uint32_t boff = boff0 + cst;
+                const float4 a = *reinterpret_cast<const float4*>(base + boff);
+                const float4 b = *reinterpret_cast<const float4*>(base + boff + 16u);
+                const float4 d = *reinterpret_cast<const float4*>(base + boff + 32u);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+                v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                v[8] = d.x; v[9] = d.y; v[10] = d.z; v[11] = d.w;
+            } else {
+                load_corner<LAYOUT>(vJ, vol, (int64_t)(lin0 + (c & 1) + ((c >> 1) & 1) * sy + ((c >> 2) & 1) * sz), v);
+            }
             const v2f w2 = (v2f){wgt[c], wgt[c]};
 #pragma unroll
             for (int k = 0; k < 6; k++) acc2[k] = acc2[k] + (v2f){v[2 * k], v[2 * k + 1]} * w2;
@@ -568,8 +585,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
     int32_t* __restrict__ cnt /* PACK: [N] */, uint32_t* __restrict__ meta /* PACK: [N] */, int32_t* __restrict__ ovf_count /* PACK: [1] */,
     int32_t* __restrict__ ovf_head /* PACK: [N], written for points with extras only */, int32_t* __restrict__ ovf_rec /* PACK: [cap][3] point, init, prev */,
     float* __restrict__ ovf_x /* PACK: [cap][3] */, int ovf_cap, int slots /* <= SPEC_ROOTS: roots recorded / row slots used (test hook) */,
-    const int32_t* __restrict__ order /* NULL or [N]: point p of this launch is xd_tgt[order[p]] (evaluation order != storage order) */,
-    int refill_min /* idle lanes of a wave before it pulls new points */)
+    const int32_t* __restrict__ order /* NULL or [N]: point p of this launch is xd_tgt[order[p]] (evaluation order != storage order) */)
 {
     __shared__ float s_T[16 * 12];                     // per init: rows 0..2 of its bone's 4x4 (R | t)
     __shared__ int s_cur;                              // points of the WORKGROUP's chunk handed out so far
@@ -624,11 +640,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
                 }
             }
         }
-        // the refill below is ~90 VALU instructions + dependent loads for the whole wave, whoever needs it: with ~1.5 lanes finishing a
-        // point per iteration it ran on practically every iteration for one or two lanes.  It now waits until refill_min lanes are idle
-        // (or nobody has work): a few lanes idle a few iterations longer, the wave executes the block a fraction as often.
-        unsigned long long need = drained ? 0ull : __ballot(!have);
-        if (need && __popcll(need) < refill_min && need != ~0ull && __any(have)) need = 0ull;
+        // (measured: letting 4 .. 32 lanes go idle before the wave runs the refill below -- ~90 VALU instructions + dependent loads for
+        //  one or two lanes on most iterations -- is slower, 147 .. 149 against 144.7 ms per headline step: idle lanes cost more)
+        const unsigned long long need = drained ? 0ull : __ballot(!have);
         if (need) {
             int base = 0;
             if (lane == 0) base = atomicAdd(&s_cur, __popcll(need));
@@ -1129,14 +1143,12 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
     const int grid = (int)((N + pts_wg - 1) / pts_wg);
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* c = reinterpret_cast<unsigned long long*>(counters);
-    int refill_min = 8;
-    if (const char* e = getenv("IA_BR_SPEC_REFILL")) { const int v = atoi(e); if (v >= 1 && v <= 64) refill_min = v; }
     int slots = SPEC_ROOTS;                                              // test hook: fewer recorded roots / row slots => the overflow list is used
     if (const char* e = getenv("IA_SPEC_TEST_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= SPEC_ROOTS) slots = v; }
 #define IA_SPEC_LAUNCH(COUNT, PACK)                                                                                                    \
     broyden_spec_kernel<COUNT, PACK><<<grid, THREADS, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,         \
                                                                cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J, pts, c, cnt, \
-                                                               meta, ovf_count, ovf_head, ovf_rec, ovf_x, ovf_cap, slots, order, refill_min)
+                                                               meta, ovf_count, ovf_head, ovf_rec, ovf_x, ovf_cap, slots, order)
     if (pack) { if (counters) IA_SPEC_LAUNCH(true, true); else IA_SPEC_LAUNCH(false, true); }
     else { if (counters) IA_SPEC_LAUNCH(true, false); else IA_SPEC_LAUNCH(false, false); }
 #undef IA_SPEC_LAUNCH
