@@ -600,7 +600,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
     // waves of the device work too far apart in the sorted order for the L2s); shared chunks of 4 x 160 / 320 / 640 / 1280: 367 / 369 / 384 / 405.
     // MORE waves on one chunk do not help (same step, 192 points per wave, after the head's speed-up): workgroups of 4 / 8 / 10 / 16
     // waves 355.8 / 367.4 / 400.7 / 377.5 ms; 16 waves x 96 points 371.3 -- the CU's L1 is not what the window buys, the L2s are.
-    // Occupancy: 4 instead of 5 waves per SIMD (94 VGPRs either way) 359.8 against 352.7 ms; 6 waves (80 VGPRs: 26 spilled dwords in the loop) 480.4
+    // Occupancy: 4 instead of 5 waves per SIMD (94 VGPRs either way) 359.8 against 352.7 ms; 6 waves (80 VGPRs: 26 spilled dwords in the loop) 480.4;
+    // 6 waves with the recorded roots, the target point and the PACK counters in LDS (86 VGPRs unconstrained, 10 dwords still spilled at
+    // 80): search 187 against 143 ms -- a handful of scratch reloads per fetch cost more than the sixth wave hides
     const int pts_wg = pts_per_wave * (WG / 64);
     const int64_t p_begin = (int64_t)blockIdx.x * pts_wg;
     if (p_begin >= N) return;
