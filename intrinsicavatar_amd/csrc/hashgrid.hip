@@ -202,6 +202,7 @@ __device__ __forceinline__ void xcd_blend_store(const float2 v[8], const float p
         }
     }
     // streaming outputs bypass the caches' retention (non-temporal): the L2 should hold the level's 4 MB table, nothing else
+    // (non-temporal GATHERS of the table itself were measured too, for the levels from 13 / 9 / 5 / 0 up: 18 / 31 / 33 / 37 % slower)
     typedef float v2f __attribute__((ext_vector_type(2)));
     __builtin_nontemporal_store((v2f){a0, a1}, reinterpret_cast<v2f*>(tmp + slot));
     if (WITH_JAC) {
