@@ -62,26 +62,7 @@ __device__ __forceinline__ uint32_t grid_index(uint32_t hsize, uint32_t res, uin
     return ((hsize & (hsize - 1u)) == 0u) ? (index & (hsize - 1u)) : (index % hsize);
 }
 
-// The two x-neighbours of a cell edge are adjacent table entries far more often than not: always on the dense levels
-// (index = x + y res + z res^2) and, on the hashed levels, whenever x is even (x + 1 = x ^ 1 only flips bit 0 of
-// x ^ y P1 ^ z P2).  The vector-memory path charges per active lane and load instruction, not per byte
-// (tools/probes/tcp_mask_probe.hip), so such a pair is fetched with ONE 16-byte load instead of two 8-byte ones: a third
-// fewer gather requests over the 16 levels, identical values.
 typedef float f4_a8 __attribute__((ext_vector_type(4), aligned(8)));
-
-__device__ __forceinline__ void load_x_pair(const float2* __restrict__ tab, uint32_t i0, uint32_t i1, float2& v0, float2& v1)
-{
-    if (i1 == i0 + 1u) {
-        const f4_a8 q = *reinterpret_cast<const f4_a8*>(tab + i0);
-        v0 = make_float2(q.x, q.y); v1 = make_float2(q.z, q.w);
-    } else if (i0 == i1 + 1u) {
-        const f4_a8 q = *reinterpret_cast<const f4_a8*>(tab + i1);
-        v1 = make_float2(q.x, q.y); v0 = make_float2(q.z, q.w);
-    } else {
-        v0 = tab[i0];
-        v1 = tab[i1];
-    }
-}
 
 // forward (+ optional analytic d enc / d x)
 template <bool WITH_JAC>
@@ -123,14 +104,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
         const float wy = (c & 2) ? pos[1] : 1.0f - pos[1];
         const float wz = (c & 4) ? pos[2] : 1.0f - pos[2];
         const float w = wx * wy * wz;
-        a0 += w * v[c].x;
-        a1 += w * v[c].y;
+        a0 = fmaf(w, v[c].x, a0);       // explicit: the flat and the level-major kernels must round alike whatever hipcc contracts
+        a1 = fmaf(w, v[c].y, a1);
         if (WITH_JAC) {
             const float dx = ((c & 1) ? sc : -sc) * wy * wz;
             const float dy = ((c & 2) ? sc : -sc) * wx * wz;
             const float dz = ((c & 4) ? sc : -sc) * wx * wy;
-            j0[0] += dx * v[c].x; j0[1] += dy * v[c].x; j0[2] += dz * v[c].x;
-            j1[0] += dx * v[c].y; j1[1] += dy * v[c].y; j1[2] += dz * v[c].y;
+            j0[0] = fmaf(dx, v[c].x, j0[0]); j0[1] = fmaf(dy, v[c].x, j0[1]); j0[2] = fmaf(dz, v[c].x, j0[2]);
+            j1[0] = fmaf(dx, v[c].y, j1[0]); j1[1] = fmaf(dy, v[c].y, j1[1]); j1[2] = fmaf(dz, v[c].y, j1[2]);
         }
     }
     *reinterpret_cast<float2*>(out + i * out_stride + l * 2) = make_float2(a0, a1);
@@ -158,24 +139,64 @@ struct XcdPlan {
     int part[8], nparts[8];             // this slot covers points [part, part+1) / nparts of the batch
 };
 
-// one (point, level) of the XCD-partitioned forward: 8 gathers, trilinear blend (+ Jacobian), level-major stores
-template <bool WITH_JAC>
-__device__ __forceinline__ void xcd_gather(const float2* __restrict__ tab, uint32_t hsize, uint32_t res, float sc,
-                                           const float xs[3], float2 v[8], float pos[3])
+// Gather of the XCD-partitioned forward.  The two x-neighbours of a cell edge are adjacent table entries far more often than not:
+// always on the dense levels (index = x + y res + z res^2) and, on the hashed levels, whenever x is even (x + 1 = x ^ 1 only flips
+// bit 0 of x ^ y P1 ^ z P2), so an x-pair is one ALIGNED 16-byte load of the entry pair that holds i0 -- it also holds i1 whenever
+// i1 == i0 ^ 1 -- plus one 8-byte load of i1 (redundant in that case: same line), all UNCONDITIONAL.  (Rounds 1-2 picked one of
+// three load shapes per lane, one 16-byte load where the pair is adjacent and two 8-byte loads otherwise: a third fewer requests, but
+// hipcc compiles that into divergent blocks whose results meet in the same registers and ends every block with s_waitcnt vmcnt(0)
+// -- the ISA read "load load wait, load wait, load wait": one or two gathers in flight per lane on a kernel that is bound by gather
+// latency x requests in flight.  Straight-line, the 16 loads of a lane's two points are issued back to back and waited for once:
+// 10.7 -> 9.6 ms per 50 M points, 83.5 -> 74.7 ms per headline step.)
+// Two points of one level, straight-line: the level's index rule is chosen ONCE (wave-uniform template argument) instead of
+// inside grid_index(), so nothing splits the basic block -- 16 index computations, then 16 loads back to back, then the selects.
+//   HASHED: tiny-cuda-nn's coherent prime hash masked to the power-of-two table.
+//   dense : x + y res + z res^2, reduced modulo the table size by one conditional subtraction (the index is below twice the
+//           table size: res^3 <= hsize and every coordinate is at most res).
+template <bool HASHED>
+__device__ __forceinline__ uint32_t level_index(uint32_t hsize, uint32_t res, uint32_t px, uint32_t py, uint32_t pz)
 {
-    uint32_t pg[3];
+    if (HASHED) return ((px * 1u) ^ (py * 2654435761u) ^ (pz * 805459861u)) & (hsize - 1u);
+    const uint32_t index = px + res * (py + res * pz);
+    return index >= hsize ? index - hsize : index;
+}
+
+template <bool HASHED>
+__device__ __forceinline__ void xcd_gather2(const float2* __restrict__ tab, uint32_t hsize, uint32_t res, float sc, const float xa[3],
+                                            const float xb[3], float2 va[8], float2 vb[8], float pa[3], float pb[3])
+{
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef float f4_a16 __attribute__((ext_vector_type(4), aligned(16)));
+    uint32_t ga[3], gb[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        const float p = fmaf(sc, xs[d], 0.5f);
-        const float fl = floorf(p);
-        pg[d] = (uint32_t)(int)fl;
-        pos[d] = p - fl;
+        const float p = fmaf(sc, xa[d], 0.5f), fl = floorf(p);
+        ga[d] = (uint32_t)(int)fl; pa[d] = p - fl;
+        const float p2 = fmaf(sc, xb[d], 0.5f), fl2 = floorf(p2);
+        gb[d] = (uint32_t)(int)fl2; pb[d] = p2 - fl2;
+    }
+    uint32_t i0[8], i1[8];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        i0[c] = level_index<HASHED>(hsize, res, ga[0], ga[1] + (c & 1), ga[2] + ((c >> 1) & 1));
+        i1[c] = level_index<HASHED>(hsize, res, ga[0] + 1u, ga[1] + (c & 1), ga[2] + ((c >> 1) & 1));
+        i0[4 + c] = level_index<HASHED>(hsize, res, gb[0], gb[1] + (c & 1), gb[2] + ((c >> 1) & 1));
+        i1[4 + c] = level_index<HASHED>(hsize, res, gb[0] + 1u, gb[1] + (c & 1), gb[2] + ((c >> 1) & 1));
+    }
+    f4_a16 q[8];
+    v2f t[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        q[c] = *reinterpret_cast<const f4_a16*>(tab + (i0[c] & ~1u));
+        t[c] = *reinterpret_cast<const v2f*>(tab + i1[c]);
     }
 #pragma unroll
-    for (int c = 0; c < 8; c += 2) {
-        const uint32_t i0 = grid_index(hsize, res, pg[0], pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1));
-        const uint32_t i1 = grid_index(hsize, res, pg[0] + 1u, pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1));
-        load_x_pair(tab, i0, i1, v[c], v[c + 1]);
+    for (int c = 0; c < 8; c++) {
+        const bool odd = (i0[c] & 1u) != 0u;
+        const float2 lo = make_float2(q[c].x, q[c].y), hi = make_float2(q[c].z, q[c].w);
+        const float2 e0 = odd ? hi : lo;
+        const float2 e1 = (i1[c] == (i0[c] ^ 1u)) ? (odd ? lo : hi) : make_float2(t[c].x, t[c].y);
+        if (c < 4) { va[2 * c] = e0; va[2 * c + 1] = e1; } else { vb[2 * (c - 4)] = e0; vb[2 * (c - 4) + 1] = e1; }
     }
 }
 
@@ -191,14 +212,14 @@ __device__ __forceinline__ void xcd_blend_store(const float2 v[8], const float p
         const float wy = (c & 2) ? pos[1] : 1.0f - pos[1];
         const float wz = (c & 4) ? pos[2] : 1.0f - pos[2];
         const float w = wx * wy * wz;
-        a0 += w * v[c].x;
-        a1 += w * v[c].y;
+        a0 = fmaf(w, v[c].x, a0);       // explicit: the flat and the level-major kernels must round alike whatever hipcc contracts
+        a1 = fmaf(w, v[c].y, a1);
         if (WITH_JAC) {
             const float dx = ((c & 1) ? sc : -sc) * wy * wz;
             const float dy = ((c & 2) ? sc : -sc) * wx * wz;
             const float dz = ((c & 4) ? sc : -sc) * wx * wy;
-            j0[0] += dx * v[c].x; j0[1] += dy * v[c].x; j0[2] += dz * v[c].x;
-            j1[0] += dx * v[c].y; j1[1] += dy * v[c].y; j1[2] += dz * v[c].y;
+            j0[0] = fmaf(dx, v[c].x, j0[0]); j0[1] = fmaf(dy, v[c].x, j0[1]); j0[2] = fmaf(dz, v[c].x, j0[2]);
+            j1[0] = fmaf(dx, v[c].y, j1[0]); j1[1] = fmaf(dy, v[c].y, j1[1]); j1[2] = fmaf(dz, v[c].y, j1[2]);
         }
     }
     // streaming outputs bypass the caches' retention (non-temporal): the L2 should hold the level's 4 MB table, nothing else
@@ -241,8 +262,11 @@ __global__ __launch_bounds__(THREADS) void hash_fwd_xcd_kernel(int64_t n, const 
             const float2* tab = params + cfg.offsets[l];
             float2 va[8], vb[8];
             float pa[3], pb[3];
-            xcd_gather<WITH_JAC>(tab, hsize, res, sc, xa, va, pa);
-            xcd_gather<WITH_JAC>(tab, hsize, res, sc, xb, vb, pb);
+            // grid_index()'s rule for this level (wave-uniform): dense while res^3 fits the table, else hashed (power-of-two table)
+            const uint64_t r64 = res;
+            const bool hashed = r64 * r64 * r64 > (uint64_t)hsize;
+            if (hashed) xcd_gather2<true>(tab, hsize, res, sc, xa, xb, va, vb, pa, pb);      // a hashed level's table is 2^log2_hashmap_size entries
+            else xcd_gather2<false>(tab, hsize, res, sc, xa, xb, va, vb, pa, pb);
             xcd_blend_store<WITH_JAC>(va, pa, sc, (int64_t)l * n + i, tmp, tmp_jac);
             if (two) xcd_blend_store<WITH_JAC>(vb, pb, sc, (int64_t)l * n + i2, tmp, tmp_jac);
         }
