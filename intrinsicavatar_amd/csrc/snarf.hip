@@ -93,7 +93,7 @@ __device__ __forceinline__ void load_corner(const float* __restrict__ vJ, int64_
     }
 }
 
-template <int LAYOUT>
+template <int LAYOUT, bool PAIRS = false>
 __device__ __forceinline__ void grid_sample_J(const float* __restrict__ vJ, int vox0, int D, int H, int W, float gx, float gy,
                                               float gz, float out[12])
 {
@@ -130,6 +130,36 @@ __device__ __forceinline__ void grid_sample_J(const float* __restrict__ vJ, int 
     // issue time as the 96 packed multiply-adds of the interpolation); the other corners add wave-uniform constants
     uint32_t boff0 = (uint32_t)lin0 * 48u;
     if (LAYOUT == IA_LAYOUT_NDHWC) asm volatile("" : "+v"(boff0));
+    if (LAYOUT == IA_LAYOUT_NDHWC && PAIRS) {
+        // the two x-corners of a (y, z) edge are 96 contiguous bytes: SIX loads in flight per phase and four phases per fetch instead
+        // of three loads and eight phases (every phase ends in a wait for its own loads).  A corner outside the grid reads its
+        // in-range neighbour's address with weight 0: acc + (+-0) leaves every accumulator bit unchanged (the accumulators start at
+        // +0 and can only become -0 from two -0 addends), so the result is the reference's, which skips such corners.
+        const char* base = reinterpret_cast<const char*>(vJ);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const bool okyz = oky[e & 1] && okz[(e >> 1) & 1];
+            if (okyz && (okx[0] || okx[1])) {
+                const uint32_t cst = (uint32_t)((e & 1) * sy + ((e >> 1) & 1) * sz) * 48u;            // scalar
+                const uint32_t b0 = boff0 + cst + (okx[0] ? 0u : 48u);                                // corner x0 (or x1's voxel if x0 is outside)
+                const uint32_t b1 = boff0 + cst + (okx[1] ? 48u : 0u);                                // corner x1 (or x0's voxel)
+                const float w0 = okx[0] ? wgt[2 * e] : 0.0f, w1 = okx[1] ? wgt[2 * e + 1] : 0.0f;
+                const float4 a0 = *reinterpret_cast<const float4*>(base + b0);
+                const float4 a1 = *reinterpret_cast<const float4*>(base + b0 + 16u);
+                const float4 a2 = *reinterpret_cast<const float4*>(base + b0 + 32u);
+                const float4 c0 = *reinterpret_cast<const float4*>(base + b1);
+                const float4 c1 = *reinterpret_cast<const float4*>(base + b1 + 16u);
+                const float4 c2 = *reinterpret_cast<const float4*>(base + b1 + 32u);
+                const v2f u0 = (v2f){w0, w0}, u1 = (v2f){w1, w1};
+                acc2[0] = acc2[0] + (v2f){a0.x, a0.y} * u0; acc2[1] = acc2[1] + (v2f){a0.z, a0.w} * u0;
+                acc2[2] = acc2[2] + (v2f){a1.x, a1.y} * u0; acc2[3] = acc2[3] + (v2f){a1.z, a1.w} * u0;
+                acc2[4] = acc2[4] + (v2f){a2.x, a2.y} * u0; acc2[5] = acc2[5] + (v2f){a2.z, a2.w} * u0;
+                acc2[0] = acc2[0] + (v2f){c0.x, c0.y} * u1; acc2[1] = acc2[1] + (v2f){c0.z, c0.w} * u1;
+                acc2[2] = acc2[2] + (v2f){c1.x, c1.y} * u1; acc2[3] = acc2[3] + (v2f){c1.z, c1.w} * u1;
+                acc2[4] = acc2[4] + (v2f){c2.x, c2.y} * u1; acc2[5] = acc2[5] + (v2f){c2.z, c2.w} * u1;
+            }
+        }
+    } else {
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         if (okx[c & 1] && oky[(c >> 1) & 1] && okz[(c >> 2) & 1]) {
@@ -151,6 +181,7 @@ __device__ __forceinline__ void grid_sample_J(const float* __restrict__ vJ, int 
 #pragma unroll
             for (int k = 0; k < 6; k++) acc2[k] = acc2[k] + (v2f){v[2 * k], v[2 * k + 1]} * w2;
         }
+    }
     }
 #pragma unroll
     for (int k = 0; k < 6; k++) { out[2 * k] = acc2[k].x; out[2 * k + 1] = acc2[k].y; }
@@ -618,14 +649,19 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
     int init = 0;
     int it = -1;                  // -1: waiting for the initial fetch
     int n_roots = 0;
-    int n_done = 0;               // PACK: searches of the lane's point that completed valid
-    unsigned inits = 0;           // PACK: their inits, one byte each
-    int last_ovf = -1;            // PACK: the point's most recent overflow record
+    // PACK: searches of the lane's point that completed valid, their inits (one byte each), the point's most recent overflow record
+    __shared__ int s_state[3][WG];
+#define n_done s_state[0][threadIdx.x]
+#define inits (reinterpret_cast<unsigned*>(s_state[1])[threadIdx.x])
+#define last_ovf s_state[2][threadIdx.x]
+    n_done = 0; inits = 0; last_ovf = -1;
     float xt[3] = {0, 0, 0}, x_l[3] = {0, 0, 0}, gx[3] = {0, 0, 0}, u[3] = {0, 0, 0};
     float Ji[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    float root[SPEC_ROOTS][3];
-#pragma unroll
-    for (int r = 0; r < SPEC_ROOTS; r++) root[r][0] = root[r][1] = root[r][2] = 0.f;
+    // the recorded roots of the lane's point and its rarely touched PACK counters live in LDS (12 registers that the six loads in
+    // flight per interpolation phase need)
+    __shared__ float s_root[SPEC_ROOTS * 3][WG];
+    float* const rootp = &s_root[0][threadIdx.x];
+#define ROOT(r, k) rootp[((r) * 3 + (k)) * WG]
     unsigned c_fetch = 0, c_retired = 0, c_valid = 0, c_unrec = 0, c_corner = 0;
 
     for (;;) {
@@ -685,8 +721,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
             bool at_root = false;
 #pragma unroll
             for (int r = 0; r < SPEC_ROOTS; r++) {
-                const float d = fmaxf(fmaxf(fabsf(x_l[0] - root[r][0]), fabsf(x_l[1] - root[r][1])), fabsf(x_l[2] - root[r][2]));
-                at_root = at_root || (r < n_roots && d < eps);
+                if (r < n_roots) {
+                    const float d = fmaxf(fmaxf(fabsf(x_l[0] - ROOT(r, 0)), fabsf(x_l[1] - ROOT(r, 1))), fabsf(x_l[2] - ROOT(r, 2)));
+                    at_root = at_root || d < eps;
+                }
             }
             if (at_root) { if (!PACK) is_valid[index] = 0; if (COUNT) c_retired++; next = true; }
         }
@@ -697,7 +735,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
         const float iy = scale[1] * (x_l[1] + offset[1]);
         const float iz = scale[2] * (x_l[2] + offset[2]);
         float Jl[12];
-        grid_sample_J<IA_LAYOUT_NDHWC>(voxel_J, 0, D, H, W, ix, iy, iz, Jl);
+        grid_sample_J<IA_LAYOUT_NDHWC, true>(voxel_J, 0, D, H, W, ix, iy, iz, Jl);
         if (COUNT) { c_fetch++; c_corner += in_range_corner_count(ix, iy, iz, D, H, W); }
         if (it < 0) {
             // initial fetch: J_inv guess and g(x0)   (fuse_cuda_kernel_fast.cu:295-331)
@@ -752,7 +790,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
                     if (n_roots < slots) {
 #pragma unroll
                         for (int r = 0; r < SPEC_ROOTS; r++)
-                            if (r == n_roots) { root[r][0] = x_l[0]; root[r][1] = x_l[1]; root[r][2] = x_l[2]; }
+                            if (r == n_roots) { ROOT(r, 0) = x_l[0]; ROOT(r, 1) = x_l[1]; ROOT(r, 2) = x_l[2]; }
                         n_roots++;
                     } else if (COUNT) c_unrec++;
                 }
@@ -777,8 +815,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
         bool near = false;
 #pragma unroll
         for (int r = 0; r < SPEC_ROOTS; r++) {
-            const float d = fmaxf(fmaxf(fabsf(x_l[0] - root[r][0]), fabsf(x_l[1] - root[r][1])), fabsf(x_l[2] - root[r][2]));
-            near = near || (r < n_roots && d < eps);
+            if (r < n_roots) {
+                const float d = fmaxf(fmaxf(fabsf(x_l[0] - ROOT(r, 0)), fabsf(x_l[1] - ROOT(r, 1))), fabsf(x_l[2] - ROOT(r, 2)));
+                near = near || d < eps;
+            }
         }
         if (near) { if (!PACK) is_valid[index] = 0; if (COUNT) c_retired++; next = true; }
     }
@@ -798,6 +838,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
         }
     }
 }
+
+#undef ROOT
+#undef n_done
+#undef inits
+#undef last_ovf
 
 // ---- candidate rows of the PACK search -> packed candidate list ------------------------------------------------------------
 // K9 among the overflow records of a point: record k is dropped when a record of a LATER init of the same point (= one further
