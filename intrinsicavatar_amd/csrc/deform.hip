@@ -333,12 +333,13 @@ __global__ __launch_bounds__(THREADS) void select_min_kernel(int64_t P, const in
     const int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     if (p >= P) return;
     const int s = start[p], c = cnt[p];
+    const int64_t dst = order ? (int64_t)order[p] : p;   // order: the points were evaluated as a permutation of the caller's list
     float best = 1e5f;      // snarf_deformer.py:192
     for (int j = 0; j < c; j++) {
         const float v = cand_sdf[s + j];
         if (v < best) best = v;
     }
-    sdf_out[order ? (int64_t)order[p] : p] = best;       // order: the points were evaluated as a permutation of the caller's list
+    sdf_out[dst] = best;
 }
 
 // ---- 4. select ------------------------------------------------------------------
