@@ -1,3 +1,5 @@
+# the round's evidence run on one MI355X box (gpurun): full GPU test suite, both headline benches, micro-benchmarks, rocprofv3 kernel stats and
+# PMC traffic of the headline step; outputs under gpurun_out/, copied to profiles/ by hand
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -q > gpurun_out/r03_gpu_tests.log 2>&1; tail -5 gpurun_out/r03_gpu_tests.log
 python bench.py --steps 5 --warmup 2 > gpurun_out/r03_bench_headline.json 2> gpurun_out/r03_bench_headline.err; tail -c 600 gpurun_out/r03_bench_headline.json
