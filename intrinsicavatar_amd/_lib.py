@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libia_amd.so")
+_SO = os.environ.get("IA_AMD_LIB") or os.path.join(_HERE, "libia_amd.so")     # IA_AMD_LIB: another build of the same library (A/B runs)
 _lib = None
 
 

@@ -64,6 +64,30 @@ def test_hashgrid_fwd_and_jacobian_vs_oracle(oracle, fields):
     np.testing.assert_allclose(N(enc)[sel, :2], tri, rtol=1e-4, atol=1e-6)
 
 
+def test_hashgrid_level_major_gather_equals_the_flat_kernel_bit_for_bit(oracle, fields, monkeypatch):
+    """ia_hashgrid_fwd_xcd (one table at a time, straight-line two-point gather: aligned 16-byte pair loads + unconditional 8-byte
+    loads) against the flat kernel (one lane per (point, level), plain 8-byte gathers through grid_index): features and Jacobian
+    bit for bit, including points ON the cube's faces and points OUTSIDE the unit cube, whose wrapped cell coordinates need
+    tiny-cuda-nn's full `index % hashmap_size` on the dense levels; ragged size (odd point count)."""
+    params, _ = _params(oracle)
+    rng = np.random.default_rng(7)
+    n = fields.HASH_FWD_XCD_MIN + 4321
+    x = rng.random((n, 3)).astype(np.float32)
+    x[:8] = [[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [0, 1, 0], [1, 0, 0], [0.999999, 0.5, 0.25], [1e-7, 0.3, 0.9], [0.25, 0.25, 0.25]]
+    x[1000:6000] = (rng.random((5000, 3)) * 1.8 - 0.4).astype(np.float32)          # outside the cube on some axes
+    x[6000:6100] = (rng.random((100, 3)) * 40.0 - 20.0).astype(np.float32)         # far outside
+    out = {}
+    for m in ("flat", "xcd"):
+        monkeypatch.setenv("IA_HASH_FWD", m)
+        e, j = fields.hashgrid_forward(T(x), T(params), with_jac=True)
+        e2 = fields.hashgrid_forward(T(x), T(params), with_jac=False)
+        assert torch.equal(e, e2)
+        out[m] = (e, j)
+    monkeypatch.delenv("IA_HASH_FWD")
+    assert torch.equal(out["flat"][0], out["xcd"][0])
+    assert torch.equal(out["flat"][1], out["xcd"][1])
+
+
 def test_hashgrid_bwd_vs_oracle(oracle, fields):
     params, total = _params(oracle)
     rng = np.random.default_rng(2)
