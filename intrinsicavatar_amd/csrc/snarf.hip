@@ -101,16 +101,21 @@ __device__ __forceinline__ void grid_sample_J(const float* __restrict__ vJ, int 
     float ix = ((gx + 1.f) / 2) * (W - 1);
     float iy = ((gy + 1.f) / 2) * (H - 1);
     float iz = ((gz + 1.f) / 2) * (D - 1);
-    if (ix > 2147483646.0f || ix < -2147483648.0f || !isfinite(ix)) ix = -100.0f;
-    if (iy > 2147483646.0f || iy < -2147483648.0f || !isfinite(iy)) iy = -100.0f;
-    if (iz > 2147483646.0f || iz < -2147483648.0f || !isfinite(iz)) iz = -100.0f;
-    const int x0 = (int)floorf(ix), y0 = (int)floorf(iy), z0 = (int)floorf(iz);
+    // (2147483646.0f IS 2^31 in fp32: "ix > 2147483646.0f || ix < -2147483648.0f || !isfinite(ix)" == "not |ix| <= 2^31")
+    if (!(fabsf(ix) <= 2147483648.0f)) ix = -100.0f;
+    if (!(fabsf(iy) <= 2147483648.0f)) iy = -100.0f;
+    if (!(fabsf(iz) <= 2147483648.0f)) iz = -100.0f;
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
     const int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+    // (float)x0 == fx and (float)x1 == fx + 1 wherever a corner can be inside the grid (|ix| < 2^24); beyond that no corner
+    // is in range and no weight is used
+    const float ax1 = (fx + 1.0f) - ix, ax0 = ix - fx, ay1 = (fy + 1.0f) - iy, ay0 = iy - fy, az1 = (fz + 1.0f) - iz, az0 = iz - fz;
     const float wgt[8] = {
-        (x1 - ix) * (y1 - iy) * (z1 - iz), (ix - x0) * (y1 - iy) * (z1 - iz),
-        (x1 - ix) * (iy - y0) * (z1 - iz), (ix - x0) * (iy - y0) * (z1 - iz),
-        (x1 - ix) * (y1 - iy) * (iz - z0), (ix - x0) * (y1 - iy) * (iz - z0),
-        (x1 - ix) * (iy - y0) * (iz - z0), (ix - x0) * (iy - y0) * (iz - z0)};
+        ax1 * ay1 * az1, ax0 * ay1 * az1,
+        ax1 * ay0 * az1, ax0 * ay0 * az1,
+        ax1 * ay1 * az0, ax0 * ay1 * az0,
+        ax1 * ay0 * az0, ax0 * ay0 * az0};
     // accumulation on packed fp32 pairs (v_pk_mul_f32 / v_pk_add_f32: two IEEE-exact operations per instruction, same
     // rounding as the scalar mul and add of the reference -- this TU is built without FMA contraction -- so results stay
     // bit-exact while the 96 mul + 96 add of a fetch become 48 + 48 instructions; the kernel is ~70 % issue-bound)
@@ -136,6 +141,7 @@ __device__ __forceinline__ void grid_sample_J(const float* __restrict__ vJ, int 
         // in-range neighbour's address with weight 0: acc + (+-0) leaves every accumulator bit unchanged (the accumulators start at
         // +0 and can only become -0 from two -0 addends), so the result is the reference's, which skips such corners.
         const char* base = reinterpret_cast<const char*>(vJ);
+        // (a wave-uniform fast path without the selects, for waves whose lanes all have both x-corners in range, measured no gain)
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const bool okyz = oky[e & 1] && okz[(e >> 1) & 1];
