@@ -1094,6 +1094,7 @@ IA_EXPORT int ia_hashgrid_fwd_xcd(int64_t n, const float* x, const float* params
     if (n == 0) return IA_OK;
     IA_REQUIRE(n_features == 2, "n_features_per_level must be 2 on this path");
     IA_REQUIRE(n_levels > 0 && n_levels <= MAX_LEVELS, "n_levels out of range");
+    IA_REQUIRE((reinterpret_cast<uintptr_t>(params) & 15) == 0, "ia_hashgrid_fwd_xcd: the table must be 16-byte aligned (entry pairs are read with one aligned 16-byte load)");
     IA_REQUIRE(scratch != nullptr, "scratch required");
     HashCfg c;
     make_cfg(c, n_levels, log2_hashmap_size, base_resolution, per_level_scale);
