@@ -261,7 +261,7 @@ class VolumeSDF(nn.Module):
         cfg = HASH
         xp = points.contiguous() if normalized else ((points - self.center) / self.scale + 0.5).contiguous()
         nb = int(L.lib().ia_hashgrid_fwd_scratch_bytes(L.i64(n), L.i32(cfg["n_levels"]), L.i32(0)))
-        scratch = torch.empty(nb, dtype=torch.uint8, device=xp.device)
+        scratch = L.scratch("hash_levels", nb, xp.device)
         L.check(L.lib().ia_hashgrid_fwd_xcd(L.i64(n), L.ptr(xp), L.ptr(self.grid_params), L.i32(cfg["n_levels"]),
                                             L.i32(cfg["n_features_per_level"]), L.i32(cfg["log2_hashmap_size"]),
                                             L.i32(cfg["base_resolution"]), L.f32(cfg["per_level_scale"]), L.ptr(None), L.i32(0),
@@ -290,7 +290,7 @@ class VolumeSDF(nn.Module):
             cfg = HASH
             lib, st = L.lib(), L.stream()
             nb = int(lib.ia_hashgrid_fwd_scratch_bytes(L.i64(n), L.i32(cfg["n_levels"]), L.i32(1)))
-            scratch = torch.empty(nb, dtype=torch.uint8, device=xp.device)
+            scratch = L.scratch("hash_levels_jac", nb, xp.device)
             L.check(lib.ia_hashgrid_fwd_levels(L.i64(n), L.ptr(xp), L.ptr(self.grid_params), L.i32(cfg["n_levels"]),
                                                L.i32(cfg["n_features_per_level"]), L.i32(cfg["log2_hashmap_size"]),
                                                L.i32(cfg["base_resolution"]), L.f32(cfg["per_level_scale"]), L.i32(1), L.ptr(scratch), st),

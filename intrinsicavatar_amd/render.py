@@ -101,7 +101,7 @@ class RenderStep:
         lib, st = L.lib(), L.stream()
         order = torch.empty(n, dtype=torch.int32, device=pts.device)
         nb = int(lib.ia_morton_order_tmp_bytes(L.i64(n)))
-        tmp = torch.empty(nb, dtype=torch.uint8, device=pts.device)            # the caching allocator hands out 512-byte aligned blocks
+        tmp = L.scratch("morton", nb, pts.device)                             # 256-byte aligned (a fresh allocation's base)
         L.check(lib.ia_morton_order(L.i64(n), L.ptr(pts), origin, L.f32(inv_cell), L.i32(self.SORT_DROP_BITS), L.ptr(order), L.ptr(tmp),
                                     C.c_size_t(nb), st), "ia_morton_order")
         return order

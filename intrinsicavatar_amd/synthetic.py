@@ -268,6 +268,30 @@ def build_frame(device="cuda:0", height=128, width=128, pose_seed=0, beta=0.01, 
     return rs, rays, export
 
 
+def repose(rs, pose, occ_res=64, seed=0):
+    """the per-frame work of the reference's animation loop on an existing model (datasets/animation.py:129-130 -> the deformer's
+    `prepare`, then prepare_test_occupancy_grid, intrinsic_avatar.py:307-381): new bone transforms -> skinning grids (K10) ->
+    per-frame occupancy grid from the model.  `pose` as for build_frame(pose=...).  Returns the RenderStep (modified in place)."""
+    import torch
+    from . import render, occ_grid
+    rig = make_rig(*parse_pose(pose))
+    dfm, geo, dens = rs.deformer, rs.geometry, rs.density
+    dev = dfm.device
+    dfm.prepare(torch.from_numpy(rig["tfs"]).to(dev), torch.from_numpy(rig["w2s"]).to(dev))
+    aabb = body_aabb(rig["joints_posed"])
+    g = torch.Generator().manual_seed(seed + 7)
+    rand = torch.rand((occ_res ** 3, 3, 3), generator=g).to(dev)
+    beta_t = dens.get_beta().detach().reshape(1)
+    step = rs.render_step_size
+
+    def occ_eval_fn(x):
+        return render.laplace_alpha(dfm.deform(x, geo)["sdf"], step, beta_t)
+
+    _, binaries = occ_grid.compute_test_occupancy_grid(occ_eval_fn, torch.from_numpy(aabb).to(dev), occ_res, 3, 0.01, rand)
+    rs.binaries, rs.aabbs = binaries.contiguous(), torch.from_numpy(aabb)[None].to(dev)
+    return rs
+
+
 def export_phys(material, env_base):
     """numpy arrays of the PBR branch for the CPU oracle (oracle/render_ref.py relight_step): the material head's
     Lipschitz-normalised weights in the REFERENCE's column order [xyz(3) | hash(32) | feat(13)] (network_utils.py:396-403)
