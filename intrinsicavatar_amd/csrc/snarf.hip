@@ -1191,6 +1191,9 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
     IA_REQUIRE(eps >= 0.0f, "speculative search: eps must be >= 0");
     IA_REQUIRE((int64_t)D * H * W < ((int64_t)1 << 26), "voxel grid too large for 32-bit byte offsets (48 B per voxel)");
     int pts = 192;                                                       // points per wave; a workgroup's four waves share a chunk of 4 x pts
+    // small batches (the reference trains on 4096 rays per GPU: ~0.2 M points per search): shorter chunks, so that the launch still has
+    // two rounds of workgroups for the device's 1280 resident ones instead of a quarter of one
+    while (pts > 64 && N < (int64_t)pts * (THREADS / 64) * 2560) pts >>= 1;      // never fewer points than lanes
     if (const char* e = getenv("IA_BR_SPEC_PTS")) pts = atoi(e) > 0 ? atoi(e) : pts;
     const int64_t pts_wg = (int64_t)pts * (THREADS / 64);
     const int grid = (int)((N + pts_wg - 1) / pts_wg);
