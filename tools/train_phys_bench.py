@@ -37,6 +37,12 @@ for _ in range(K): out = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
 lib = L.lib(); lib.start(); step(); per = lib.report()
+if os.environ.get("IA_CPROFILE"):          # host side of one step: where the Python time goes (the 4096-ray step is launch-bound)
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable(); step(); torch.cuda.synchronize(); pr.disable()
+    pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(28)
+    n_launch = sum(v[0] for v in per.values())
+    sys.stderr.write(f"C-ABI launches per step: {n_launch}, kernel ms (sum of event pairs): {sum(v[1] for v in per.values()):.2f}\n")
 print(json.dumps(dict(workload=f"config 4: {n_batch} rays of a 540x540 frame, PBR training step (uniform_light, spp 512), fwd+bwd",
                       ms_per_step=round(dt * 1e3, 2), primary_rays_per_s=round(n_batch / dt, 1),
                       secondary_rays_per_step=out["stats"]["n_secondary"], secondary_rays_per_s=round(out["stats"]["n_secondary"] / dt, 1),
