@@ -135,27 +135,33 @@ int ia_unpack_data(int64_t n_rays, const int32_t* packed_info, int data_dim, con
 int ia_resample_packed_info(int64_t n_rays, const int32_t* packed_info, int n, int add_steps,
                             int32_t* resample_packed_info, int32_t* total,
                             void* tmp /* ia_scan_tmp_bytes(n_rays)+4*n_rays bytes */, ia_stream_t stream);
-/* K1 ray_resampling (cdf.cu:10-215): fg_counts/bg_counts zeroed, surface_idx = -1 by caller */
-int ia_ray_resampling(int64_t n_rays, const int32_t* packed_info, const float* starts, const float* ends,
-                      const float* weights, const float* sdfs, const int32_t* resample_packed_info,
+/* K1..K4 share one design (csrc/resample_math.h): the launch's sample positions u_j are ONE table, phase A leaves each ray's CDF as a
+ * table (one lane per ray: the only serial recurrences), phase B inverts it per OUTPUT element, 64 consecutive elements per store.
+ * n_in = number of input intervals (K2: edges), n_out = resample total of ia_resample_packed_info, tmp = ia_resample_tmp_bytes(n_rays,
+ * n_in, n) bytes of scratch.  EVERY output element is written by the kernels (the reference's launchers zero / -1 initialise them,
+ * cdf.cu:189-191,372-377,512-514: not needed here). */
+size_t ia_resample_tmp_bytes(int64_t n_rays, int64_t n_in, int n);
+/* K1 ray_resampling (cdf.cu:10-215) */
+int ia_ray_resampling(int64_t n_rays, int64_t n_in, int n, const int32_t* packed_info, const float* starts, const float* ends,
+                      const float* weights, const float* sdfs, const int32_t* resample_packed_info, int64_t n_out,
                       float* resample_ts, float* resample_offsets, int64_t* surface_idx,
-                      int64_t* resample_indices, int32_t* resample_fg_counts, int32_t* resample_bg_counts,
+                      int64_t* resample_indices, int32_t* resample_fg_counts, int32_t* resample_bg_counts, void* tmp,
                       ia_stream_t stream);
-/* K2 ray_resampling_merge (cdf.cu:217-401): every output zero-initialised by caller */
-int ia_ray_resampling_merge(int64_t n_rays, const int32_t* packed_info, const float* vals,
+/* K2 ray_resampling_merge (cdf.cu:217-401) */
+int ia_ray_resampling_merge(int64_t n_rays, int64_t n_in, int n, const int32_t* packed_info, const float* vals,
                             const uint8_t* is_left, const uint8_t* is_right, const float* weights,
                             const int32_t* resample_packed_info, float* resample_vals, float* resample_dists,
                             uint8_t* resample_is_left, uint8_t* resample_is_right, uint8_t* is_resample,
-                            uint8_t* is_fg_sample, ia_stream_t stream);
-/* K3 ray_resampling_fine (cdf.cu:403-534): outputs zero-initialised by caller */
-int ia_ray_resampling_fine(int64_t n_rays, const int32_t* packed_info, const float* starts, const float* ends,
-                           const float* weights, const int32_t* resample_packed_info, float* resample_starts,
-                           float* resample_ends, uint8_t* is_fg_sample, ia_stream_t stream);
-/* K4 ray_resampling_sdf_fine (cdf.cu:536-696): outputs zero-initialised by caller */
-int ia_ray_resampling_sdf_fine(int64_t n_rays, const int32_t* packed_info, const float* starts,
+                            uint8_t* is_fg_sample, void* tmp, ia_stream_t stream);
+/* K3 ray_resampling_fine (cdf.cu:403-534); tmp may be NULL for n <= 8 (the points of a ray stay in registers) */
+int ia_ray_resampling_fine(int64_t n_rays, int64_t n_in, int n, const int32_t* packed_info, const float* starts, const float* ends,
+                           const float* weights, const int32_t* resample_packed_info, int64_t n_out, float* resample_starts,
+                           float* resample_ends, uint8_t* is_fg_sample, void* tmp, ia_stream_t stream);
+/* K4 ray_resampling_sdf_fine (cdf.cu:536-696); tmp as K3 */
+int ia_ray_resampling_sdf_fine(int64_t n_rays, int64_t n_in, int n, const int32_t* packed_info, const float* starts,
                                const float* ends, const float* alphas, const float* sdfs,
-                               const int32_t* resample_packed_info, float* resample_starts,
-                               float* resample_ends, uint8_t* is_fg_sample, ia_stream_t stream);
+                               const int32_t* resample_packed_info, int64_t n_out, float* resample_starts,
+                               float* resample_ends, uint8_t* is_fg_sample, void* tmp, ia_stream_t stream);
 
 /* Foreground compaction of a fine re-sampling (the caller side of K3 / K4: models/intrinsic_avatar.py:516-528 keeps the
  * intervals with is_fg -- three boolean-mask gathers + unpack_info -- and packs the kept ray indices again).  A ray's re-samples

@@ -34,7 +34,7 @@ class _Timed:
 
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
-        if not name.startswith("ia_") or name in ("ia_last_error", "ia_scan_tmp_bytes", "ia_version", "ia_hashgrid_n_entries", "ia_traverse_scratch_bytes", "ia_occgrid_tmp_bytes", "ia_hashgrid_bwd_scratch_bytes", "ia_traverse_fused_scratch_bytes", "ia_hashgrid_fwd_scratch_bytes", "ia_eikonal_partials", "ia_spec_rows_slots", "ia_spec_rows_overflow_bytes", "ia_spec_rows_overflow_capacity"):
+        if not name.startswith("ia_") or name in ("ia_last_error", "ia_scan_tmp_bytes", "ia_version", "ia_hashgrid_n_entries", "ia_traverse_scratch_bytes", "ia_occgrid_tmp_bytes", "ia_hashgrid_bwd_scratch_bytes", "ia_traverse_fused_scratch_bytes", "ia_hashgrid_fwd_scratch_bytes", "ia_eikonal_partials", "ia_spec_rows_slots", "ia_spec_rows_overflow_bytes", "ia_spec_rows_overflow_capacity", "ia_resample_tmp_bytes"):
             return fn
 
         def call(*args):

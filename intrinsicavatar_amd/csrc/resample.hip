@@ -8,10 +8,13 @@
 //   pack_info (torch ops)               lib/nerfacc/pack.py:46-77
 // and the host prologue of K1..K4 (cdf.cu:177-183) without the two .item() syncs.
 //
-// Every CDF walk is inherently serial per ray; rays are independent => one ray per lane.
-// The float expression order matches oracle/ia_oracle.c exactly (TU built with
-// -ffp-contract=off), so the integer outputs (indices, counts, flags) are bit-exact.
+// K1..K4: only the two running sums of a ray are serial (its CDF, and the sample positions u_j, which are one table per launch);
+// phase A leaves them as tables (one lane per ray), phase B inverts the CDF per OUTPUT element (binary search), so that a wave
+// writes 64 consecutive elements of every output array -- see resample_math.h, which also compiles under gcc for the CPU test.
+// The float expression order matches oracle/ia_oracle.c exactly (TU built with -ffp-contract=off): bit-exact outputs.
 #include "ia_common.h"
+#include "resample_math.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -87,242 +90,214 @@ __global__ __launch_bounds__(THREADS) void unpack_data_kernel(int64_t n_rays, co
     for (int k = 0; k < data_dim; k++) out[t * data_dim + k] = data[(int64_t)(pi.x + j) * data_dim + k];
 }
 
-// ---- K1 -----------------------------------------------------------------------
-__global__ __launch_bounds__(THREADS) void k1_resampling_kernel(
-    int64_t n_rays, const int32_t* __restrict__ packed_info, const float* __restrict__ starts,
-    const float* __restrict__ ends, const float* __restrict__ weights_all, const float* __restrict__ sdfs_all,
-    const int32_t* __restrict__ resample_packed_info, float* __restrict__ resample_ts,
-    float* __restrict__ resample_offsets, int64_t* __restrict__ surface_idx, int64_t* __restrict__ resample_indices,
-    int32_t* __restrict__ resample_fg_counts, int32_t* __restrict__ resample_bg_counts)
+// ---- K1 .. K4: per-ray CDF tables + per-element inversion (arithmetic: resample_math.h) -----------------------------------------
+// Scratch of one call (ia_resample_tmp_bytes): the u-table, cdf / cmax per input interval, one 16-byte record per ray, the
+// rank -> ray list of the non-empty rays (every non-empty ray owns exactly n consecutive outputs, K1 / K3 / K4), and for K2 the
+// first[] ranks per edge.
+struct RsScratch {
+    float* utab;
+    float* cdf;
+    float* cmax;
+    ia_rs_ray* ray;
+    int32_t* rank2ray;
+    int32_t* first;
+};
+
+constexpr size_t rs_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t rs_layout(void* tmp, int64_t n_rays, int64_t n_in, int n, RsScratch* s)
 {
-    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (i >= n_rays) return;
-    const int base = packed_info[i * 2 + 0], steps = packed_info[i * 2 + 1];
-    const int rbase = resample_packed_info[i * 2 + 0], rsteps = resample_packed_info[i * 2 + 1];
-    if (steps == 0) return;
-    const float *st = starts + base, *en = ends + base, *w = weights_all + base, *sdfs = sdfs_all + base;
-    int32_t* fgc = resample_fg_counts + base;
-    float *ts = resample_ts + rbase, *offs = resample_offsets + rbase;
-    int64_t* idxs = resample_indices + rbase;
-
-    float weights_sum = 0.0f;
-    for (int j = 0; j < steps; j++) weights_sum += w[j];
-    weights_sum += fmaxf(1.0f - weights_sum, 0.0f);
-
-    const int num_bins = rsteps;
-    const float cdf_step_size = (float)((1.0f - 1.0 / num_bins) / (rsteps - 1));
-    int idx = 0, j = 0;
-    float cdf_prev = 0.0f, cdf_next = w[idx] / weights_sum;
-    float cdf_u = (float)(1.0 / (2 * num_bins));
-    float sdf_prev = sdfs[0];
-    float sdf_next = 0.0f;
-    if (steps > 1) sdf_next = sdfs[1];
-    bool found_surface = false;
-    float t_prev = 0.0f;   // == ts[j-1] (kept in a register instead of re-reading HBM)
-    int fg_here = 0;       // pending fg count of interval idx
-    float st_i = st[0], en_i = en[0];
-    int bg = 0;
-    while (j < num_bins && idx < steps) {
-        if (cdf_u < cdf_next) {
-            const float scaling = (en_i - st_i) / (cdf_next - cdf_prev);
-            const float offset = (cdf_u - cdf_prev) * scaling;
-            const float t = offset + st_i;
-            float tv;
-            if (sdf_prev >= 0 && sdf_next < 0 && !found_surface) {
-                const float sdf_approx = sdf_prev + (sdf_next - sdf_prev) * (offset / (en_i - st_i));
-                tv = sdf_approx >= 0 ? t : (j > 0 ? t_prev : st_i);
-            } else if (found_surface) {
-                tv = j > 0 ? t_prev : st_i;
-            } else {
-                tv = t;
-            }
-            ts[j] = tv;
-            t_prev = tv;
-            offs[j] = offset;
-            idxs[j] = idx + base;
-            fg_here += 1;
-            cdf_u += cdf_step_size;
-            j += 1;
-        } else if (idx < steps - 1) {
-            if (fg_here) { fgc[idx] = fg_here; fg_here = 0; }
-            idx += 1;
-            if (sdf_prev >= 0 && sdf_next < 0 && !found_surface) {
-                surface_idx[i] = idx - 1 + base;
-                found_surface = true;
-            }
-            sdf_prev = sdfs[idx];
-            sdf_next = idx < steps - 1 ? sdfs[idx + 1] : 0.0f;
-            cdf_prev = cdf_next;
-            cdf_next += w[idx] / weights_sum;
-            st_i = st[idx];
-            en_i = en[idx];
-        } else {
-            break;
-        }
-    }
-    if (fg_here) fgc[idx] = fg_here;
-    const float en_last = en[steps - 1];
-    while (j < num_bins) {
-        const float offset = 10000.f;
-        ts[j] = offset + en_last;
-        offs[j] = offset;
-        idxs[j] = steps - 1 + base;
-        j += 1;
-        bg += 1;
-    }
-    if (bg) resample_bg_counts[i] = bg;
+    char* b = reinterpret_cast<char*>(tmp);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { char* p = b ? b + o : nullptr; o += rs_align(bytes); return p; };
+    float* utab = reinterpret_cast<float*>(take(sizeof(float) * (size_t)(n + 2)));
+    float* cdf = reinterpret_cast<float*>(take(sizeof(float) * (size_t)(n_in + 1)));
+    float* cmax = reinterpret_cast<float*>(take(sizeof(float) * (size_t)(n_in + 1)));
+    ia_rs_ray* ray = reinterpret_cast<ia_rs_ray*>(take(sizeof(ia_rs_ray) * (size_t)(n_rays + 1)));
+    int32_t* rank2ray = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * (size_t)(n_rays + 1)));
+    int32_t* first = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * (size_t)(n_in + 1)));
+    if (s) { s->utab = utab; s->cdf = cdf; s->cmax = cmax; s->ray = ray; s->rank2ray = rank2ray; s->first = first; }
+    return o;
 }
 
-// ---- K2 -----------------------------------------------------------------------
-__global__ __launch_bounds__(THREADS) void k2_merge_kernel(
-    int64_t n_rays, const int32_t* __restrict__ packed_info, const float* __restrict__ vals_all,
-    const uint8_t* __restrict__ is_left_all, const uint8_t* __restrict__ is_right_all,
-    const float* __restrict__ weights_all, const int32_t* __restrict__ resample_packed_info,
-    float* __restrict__ resample_vals, float* __restrict__ resample_dists, uint8_t* __restrict__ resample_is_left,
-    uint8_t* __restrict__ resample_is_right, uint8_t* __restrict__ is_resample, uint8_t* __restrict__ is_fg_sample)
+// the launch's sample positions: n serial fp32 additions, once (every ray of the reference repeats them)
+__global__ void rs_utab_kernel(int n, int fine, float* __restrict__ utab)
 {
-    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (i >= n_rays) return;
-    const int base = packed_info[i * 2 + 0], steps = packed_info[i * 2 + 1];
-    const int rbase = resample_packed_info[i * 2 + 0];
-    const int rsteps = resample_packed_info[i * 2 + 1] - steps;
-    if (steps == 0) return;
-    const float *vals = vals_all + base, *w = weights_all + base;
-    const uint8_t *il = is_left_all + base, *ir = is_right_all + base;
-    uint8_t *fg = is_fg_sample + rbase, *ol = resample_is_left + rbase, *orr = resample_is_right + rbase,
-            *ors = is_resample + rbase;
-    float *ov = resample_vals + rbase, *od = resample_dists + rbase;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ia_rs_fill_utab(n, fine, utab);
+}
 
-    float weights_sum = 0.0f;
-    for (int j = 0; j < steps - 1; j++) weights_sum += (il[j] && ir[j + 1]) ? w[j] : 0.0f;
-    weights_sum += fmaxf(1.0f - weights_sum, 0.0f);
+// K1 phase A: one lane per ray
+__global__ __launch_bounds__(THREADS) void rs1_rays_kernel(int64_t n_rays, int n, const int32_t* __restrict__ packed_info,
+                                                           const int32_t* __restrict__ rpi, const float* __restrict__ starts,
+                                                           const float* __restrict__ ends, const float* __restrict__ weights,
+                                                           const float* __restrict__ sdfs, RsScratch s, int64_t* __restrict__ surface_idx,
+                                                           int32_t* __restrict__ fg_counts, int32_t* __restrict__ bg_counts)
+{
+    const int64_t r = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (r >= n_rays) return;
+    const int2 pi = reinterpret_cast<const int2*>(packed_info)[r];
+    if (pi.y == 0) { surface_idx[r] = -1; bg_counts[r] = 0; return; }
+    ia_rs_ray rec;
+    int32_t surf, bg;
+    ia_rs1_ray(pi.y, weights + pi.x, sdfs + pi.x, starts + pi.x, ends + pi.x, s.utab, n, s.cdf + pi.x, s.cmax + pi.x, fg_counts + pi.x, &rec,
+               &surf, &bg);
+    surface_idx[r] = surf >= 0 ? (int64_t)surf + pi.x : -1;
+    bg_counts[r] = bg;
+    reinterpret_cast<int4*>(s.ray)[r] = make_int4(rec.n_hit, rec.j_clamp, __float_as_int(rec.v_clamp), rec.k_first);
+    s.rank2ray[rpi[2 * r] / n] = (int32_t)r;
+}
 
-    const int num_bins = rsteps;
-    const float cdf_step_size = (float)((1.0f - 1.0 / num_bins) / (rsteps - 1));
-    int idx = 0, j = 0;
-    float start = 0.0f, end = 0.0f;
-    float cdf_prev = 0.0f, cdf_next = w[idx] / weights_sum;
-    float cdf_u = (float)(1.0 / (2 * num_bins));
-    start = vals[0];
-    end = steps > 1 ? vals[1] : 0.0f;
-    float v_last = start;   // == ov[j + idx] of the most recent write
-    ov[0] = start;
-    fg[0] = 1;
-    ol[0] = 1;
-    while (j < num_bins && idx < steps - 1) {
-        if (cdf_u < cdf_next) {
-            const float scaling = (end - start) / (cdf_next - cdf_prev);
-            const float offset = (cdf_u - cdf_prev) * scaling;
-            const float t = offset + start;
-            cdf_u += cdf_step_size;
-            od[j + idx] = t - v_last;
-            j += 1;
-            ov[j + idx] = t;
-            v_last = t;
-            fg[j + idx] = 1;
-            ors[j + idx] = 1;
-            ol[j + idx] = 1;
-            orr[j + idx] = 1;
-        } else {
-            od[j + idx] = end - v_last;
-            idx += 1;
-            ov[j + idx] = end;
-            v_last = end;
-            fg[j + idx] = 1;
-            orr[j + idx] = ir[idx];
-            if (idx >= steps - 1) break;
-            start = vals[idx];
-            end = vals[idx + 1];
-            if (il[idx] && ir[idx + 1]) {
-                cdf_prev = cdf_next;
-                cdf_next += w[idx] / weights_sum;
-                ol[j + idx] = 1;
-            }
+// K1 phase B: one lane per re-sample; a wave writes 64 consecutive elements of ts / offsets / indices
+__global__ __launch_bounds__(THREADS) void rs1_samples_kernel(int64_t n_out, int n, const int32_t* __restrict__ packed_info,
+                                                              const float* __restrict__ starts, const float* __restrict__ ends, RsScratch s,
+                                                              float* __restrict__ ts, float* __restrict__ offsets, int64_t* __restrict__ indices)
+{
+    const int64_t e = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (e >= n_out) return;
+    const uint32_t rank = (uint32_t)e / (uint32_t)n;
+    const int j = (int)((uint32_t)e - rank * (uint32_t)n);
+    const int r = s.rank2ray[rank];
+    const int2 pi = reinterpret_cast<const int2*>(packed_info)[r];
+    const int4 q = reinterpret_cast<const int4*>(s.ray)[r];
+    ia_rs_ray rec;
+    rec.n_hit = q.x; rec.j_clamp = q.y; rec.v_clamp = __int_as_float(q.z); rec.k_first = q.w;
+    float t, off;
+    int32_t k;
+    ia_rs1_sample(j, pi.y, &rec, starts + pi.x, ends + pi.x, s.cdf + pi.x, s.cmax + pi.x, s.utab, &t, &off, &k);
+    ts[e] = t;
+    offsets[e] = off;
+    indices[e] = (int64_t)k + pi.x;
+}
+
+// K2 phase A: one lane per ray (edge list)
+__global__ __launch_bounds__(THREADS) void rs2_rays_kernel(int64_t n_rays, int n, const int32_t* __restrict__ packed_info,
+                                                           const float* __restrict__ vals, const uint8_t* __restrict__ il,
+                                                           const uint8_t* __restrict__ ir, const float* __restrict__ weights, RsScratch s)
+{
+    const int64_t r = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (r >= n_rays) return;
+    const int2 pi = reinterpret_cast<const int2*>(packed_info)[r];
+    if (pi.y == 0) return;
+    ia_rs_ray rec;
+    ia_rs2_ray(pi.y, vals + pi.x, il + pi.x, ir + pi.x, weights + pi.x, s.utab, n, s.cdf + pi.x, s.cmax + pi.x, s.first + pi.x, &rec);
+    reinterpret_cast<int4*>(s.ray)[r] = make_int4(rec.n_hit, rec.j_clamp, __float_as_int(rec.v_clamp), rec.k_first);
+}
+
+// K2 phase B: a workgroup owns RS2_TILE consecutive rays = one contiguous range of the merged edge list; one lane per output edge
+// (ray by binary search in the tile's LDS offsets), every output array written in element order, unreached slots as zeros
+constexpr int RS2_TILE = 64;
+__global__ __launch_bounds__(THREADS) void rs2_edges_kernel(int64_t n_rays, const int32_t* __restrict__ packed_info,
+                                                            const int32_t* __restrict__ rpi, const float* __restrict__ vals,
+                                                            const uint8_t* __restrict__ il, const uint8_t* __restrict__ ir, RsScratch s,
+                                                            float* __restrict__ out_vals, float* __restrict__ out_dists,
+                                                            uint8_t* __restrict__ out_left, uint8_t* __restrict__ out_right,
+                                                            uint8_t* __restrict__ out_resample, uint8_t* __restrict__ out_fg)
+{
+    __shared__ int s_off[RS2_TILE + 1];
+    const int64_t r0 = (int64_t)blockIdx.x * RS2_TILE;
+    const int n_tile = (int)((r0 + RS2_TILE <= n_rays) ? RS2_TILE : n_rays - r0);
+    if (threadIdx.x < n_tile) s_off[threadIdx.x] = rpi[2 * (r0 + threadIdx.x)];
+    if (threadIdx.x == 0) s_off[n_tile] = rpi[2 * (r0 + n_tile - 1)] + rpi[2 * (r0 + n_tile - 1) + 1];
+    __syncthreads();
+    const int begin = s_off[0], end = s_off[n_tile];
+    for (int p = begin + threadIdx.x; p < end; p += THREADS) {
+        int lo = 0, hi = n_tile - 1;                         // last ray of the tile whose range starts at or before p
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_off[mid] <= p) lo = mid; else hi = mid - 1;
         }
-    }
-    while (idx < steps - 1) {
-        od[j + idx] = end - v_last;
-        idx += 1;
-        ov[j + idx] = end;
-        v_last = end;
-        fg[j + idx] = 1;
-        orr[j + idx] = ir[idx];
-        if (idx >= steps - 1) break;
-        start = vals[idx];
-        end = vals[idx + 1];
-        if (il[idx] && ir[idx + 1]) ol[j + idx] = 1;
+        const int64_t r = r0 + lo;
+        const int local = p - s_off[lo], cnt = s_off[lo + 1] - s_off[lo];
+        const int2 pi = reinterpret_cast<const int2*>(packed_info)[r];
+        const int4 q = reinterpret_cast<const int4*>(s.ray)[r];
+        ia_rs_ray rec;
+        rec.n_hit = q.x; rec.j_clamp = q.y; rec.v_clamp = __int_as_float(q.z); rec.k_first = q.w;
+        const ia_rs2_edge e = ia_rs2_at(local, pi.y, &rec, vals + pi.x, il + pi.x, ir + pi.x, s.cdf + pi.x, s.first + pi.x, s.utab);
+        float d = 0.0f;
+        if (local + 1 < cnt) {
+            const ia_rs2_edge f = ia_rs2_at(local + 1, pi.y, &rec, vals + pi.x, il + pi.x, ir + pi.x, s.cdf + pi.x, s.first + pi.x, s.utab);
+            if (f.used) d = f.val - e.val;
+        }
+        out_vals[p] = e.val;
+        out_dists[p] = d;
+        out_left[p] = e.left;
+        out_right[p] = e.right;
+        out_resample[p] = e.resample;
+        out_fg[p] = e.used;
     }
 }
 
-// ---- K3 / K4 --------------------------------------------------------------------
-template <bool SDF>
-__global__ __launch_bounds__(THREADS) void k34_fine_kernel(
-    int64_t n_rays, const int32_t* __restrict__ packed_info, const float* __restrict__ starts,
-    const float* __restrict__ ends, const float* __restrict__ wa_all /* weights (K3) or alphas (K4) */,
-    const float* __restrict__ sdfs_all, const int32_t* __restrict__ resample_packed_info,
-    float* __restrict__ resample_starts, float* __restrict__ resample_ends, uint8_t* __restrict__ is_fg_sample)
+// K3 / K4, few points per ray (n + 1 <= IA_RS_SMALL): one lane per ray, the ray's points in registers, its n outputs written as one
+// vector per array (the non-empty rays' outputs are consecutive, so a wave's stores are contiguous)
+template <bool SDF, int N>
+__global__ __launch_bounds__(THREADS) void rs34_small_kernel(int64_t n_rays, const int32_t* __restrict__ packed_info,
+                                                             const int32_t* __restrict__ rpi, const float* __restrict__ starts,
+                                                             const float* __restrict__ ends, const float* __restrict__ wa,
+                                                             const float* __restrict__ sdfs, float du, float u0,
+                                                             float* __restrict__ out_starts, float* __restrict__ out_ends,
+                                                             uint8_t* __restrict__ out_fg)
 {
-    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (i >= n_rays) return;
-    const int base = packed_info[i * 2 + 0], steps = packed_info[i * 2 + 1];
-    const int rbase = resample_packed_info[i * 2 + 0], rsteps = resample_packed_info[i * 2 + 1];
-    if (steps == 0) return;
-    const float *st = starts + base, *en = ends + base, *wa = wa_all + base;
-    float *os = resample_starts + rbase, *oe = resample_ends + rbase;
-    uint8_t* fg = is_fg_sample + rbase;
-
-    int idx = 0;
-    float weights_sum = 0.0f, trans = 1.0f, cdf_next;
-    if (SDF) {
-        const float* sdfs = sdfs_all + base;
-        float sdf_prev = sdfs[0];
-        bool found_surface = false;
-        while (idx < steps) {
-            idx += 1;
-            if (idx >= steps) break;
-            if (sdf_prev >= 0 && sdfs[idx] < 0 && !found_surface) {
-                idx -= 1;
-                found_surface = true;
-                break;
-            }
-            sdf_prev = sdfs[idx];
-        }
-        if (!found_surface) return;
-        const float weight = wa[idx];
-        trans *= (1.0f - wa[idx]);
-        cdf_next = weight;
+    const int64_t r = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (r >= n_rays) return;
+    const int2 pi = reinterpret_cast<const int2*>(packed_info)[r];
+    if (pi.y == 0) return;
+    float pts[IA_RS_SMALL];
+#pragma unroll
+    for (int j = 0; j < IA_RS_SMALL; j++) pts[j] = 0.0f;
+    const int hit = ia_rs34_small(SDF ? 1 : 0, N + 1, pi.y, wa + pi.x, SDF ? sdfs + pi.x : nullptr, starts + pi.x, ends + pi.x, du, u0, pts);
+    const int rb = rpi[2 * r];
+    float os[N], oe[N];
+    uint8_t fg[N];
+#pragma unroll
+    for (int q = 0; q < N; q++) {
+        os[q] = q < hit ? pts[q] : 0.0f;
+        oe[q] = q + 1 < hit ? pts[q + 1] : 0.0f;
+        fg[q] = (uint8_t)(q + 1 < hit);
+    }
+    if (N == 4) {
+        *reinterpret_cast<float4*>(out_starts + rb) = make_float4(os[0], os[1], os[2], os[3]);
+        *reinterpret_cast<float4*>(out_ends + rb) = make_float4(oe[0], oe[1], oe[2], oe[3]);
+        *reinterpret_cast<uchar4*>(out_fg + rb) = make_uchar4(fg[0], fg[1], fg[2], fg[3]);
     } else {
-        for (int j = 0; j < steps; j++) weights_sum += wa[j];
-        weights_sum += fmaxf(1.0f - weights_sum, 0.0f);
-        cdf_next = wa[idx] / weights_sum;
+#pragma unroll
+        for (int q = 0; q < N; q++) { out_starts[rb + q] = os[q]; out_ends[rb + q] = oe[q]; out_fg[rb + q] = fg[q]; }
     }
-    const int num_bins = rsteps + 1;
-    const float cdf_step_size = (float)((1.0f - 1.0 / num_bins) / rsteps);
-    int j = 0;
-    float cdf_prev = 0.0f;
-    float cdf_u = (float)(1.0 / (2 * num_bins));
-    while (j < num_bins && idx < steps) {
-        if (cdf_u < cdf_next) {
-            const float scaling = (en[idx] - st[idx]) / (cdf_next - cdf_prev);
-            const float t = (cdf_u - cdf_prev) * scaling + st[idx];
-            if (j < num_bins - 1) os[j] = t;
-            if (j > 0) { oe[j - 1] = t; fg[j - 1] = 1; }
-            cdf_u += cdf_step_size;
-            j += 1;
-        } else {
-            idx += 1;
-            if (idx >= steps) break;
-            if (SDF) {
-                const float weight = trans * wa[idx];
-                trans *= (1.0f - wa[idx]);
-                cdf_prev = cdf_next;
-                cdf_next += weight;
-            } else {
-                cdf_prev = cdf_next;
-                cdf_next += wa[idx] / weights_sum;
-            }
-        }
-    }
+}
+
+// K3 / K4, general n: phase A (tables) + phase B (one lane per output interval)
+template <bool SDF>
+__global__ __launch_bounds__(THREADS) void rs34_rays_kernel(int64_t n_rays, int n, const int32_t* __restrict__ packed_info,
+                                                            const int32_t* __restrict__ rpi, const float* __restrict__ wa,
+                                                            const float* __restrict__ sdfs, RsScratch s)
+{
+    const int64_t r = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (r >= n_rays) return;
+    const int2 pi = reinterpret_cast<const int2*>(packed_info)[r];
+    if (pi.y == 0) return;
+    ia_rs_ray rec;
+    ia_rs34_ray(SDF ? 1 : 0, pi.y, wa + pi.x, SDF ? sdfs + pi.x : nullptr, s.utab, n + 1, s.cdf + pi.x, s.cmax + pi.x, &rec);
+    reinterpret_cast<int4*>(s.ray)[r] = make_int4(rec.n_hit, rec.j_clamp, __float_as_int(rec.v_clamp), rec.k_first);
+    s.rank2ray[rpi[2 * r] / n] = (int32_t)r;
+}
+
+__global__ __launch_bounds__(THREADS) void rs34_intervals_kernel(int64_t n_out, int n, const int32_t* __restrict__ packed_info,
+                                                                 const float* __restrict__ starts, const float* __restrict__ ends, RsScratch s,
+                                                                 float* __restrict__ out_starts, float* __restrict__ out_ends,
+                                                                 uint8_t* __restrict__ out_fg)
+{
+    const int64_t e = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (e >= n_out) return;
+    const uint32_t rank = (uint32_t)e / (uint32_t)n;
+    const int q = (int)((uint32_t)e - rank * (uint32_t)n);
+    const int r = s.rank2ray[rank];
+    const int2 pi = reinterpret_cast<const int2*>(packed_info)[r];
+    const int4 h = reinterpret_cast<const int4*>(s.ray)[r];
+    ia_rs_ray rec;
+    rec.n_hit = h.x; rec.j_clamp = h.y; rec.v_clamp = __int_as_float(h.z); rec.k_first = h.w;
+    const bool has_s = q < rec.n_hit, has_e = q + 1 < rec.n_hit;
+    out_starts[e] = has_s ? ia_rs34_point(q, pi.y, &rec, starts + pi.x, ends + pi.x, s.cdf + pi.x, s.cmax + pi.x, s.utab) : 0.0f;
+    out_ends[e] = has_e ? ia_rs34_point(q + 1, pi.y, &rec, starts + pi.x, ends + pi.x, s.cdf + pi.x, s.cmax + pi.x, s.utab) : 0.0f;
+    out_fg[e] = (uint8_t)has_e;
 }
 
 
@@ -422,54 +397,101 @@ IA_EXPORT int ia_unpack_data(int64_t n_rays, const int32_t* packed_info, int dat
     return ia::check_launch("ia_unpack_data");
 }
 
-IA_EXPORT int ia_ray_resampling(int64_t n_rays, const int32_t* packed_info, const float* starts, const float* ends,
-                                const float* weights, const float* sdfs, const int32_t* resample_packed_info,
+IA_EXPORT size_t ia_resample_tmp_bytes(int64_t n_rays, int64_t n_in, int n) { return rs_layout(nullptr, n_rays, n_in, n, nullptr) + 256; }
+
+static void* rs_aligned(void* tmp) { return (void*)(((uintptr_t)tmp + 255) & ~(uintptr_t)255); }
+
+IA_EXPORT int ia_ray_resampling(int64_t n_rays, int64_t n_in, int n, const int32_t* packed_info, const float* starts, const float* ends,
+                                const float* weights, const float* sdfs, const int32_t* resample_packed_info, int64_t n_out,
                                 float* resample_ts, float* resample_offsets, int64_t* surface_idx,
-                                int64_t* resample_indices, int32_t* resample_fg_counts, int32_t* resample_bg_counts,
+                                int64_t* resample_indices, int32_t* resample_fg_counts, int32_t* resample_bg_counts, void* tmp,
                                 ia_stream_t stream)
 {
     if (n_rays == 0) return IA_OK;
-    k1_resampling_kernel<<<ia::cdiv(n_rays, THREADS), THREADS, 0, (hipStream_t)stream>>>(
-        n_rays, packed_info, starts, ends, weights, sdfs, resample_packed_info, resample_ts, resample_offsets,
-        surface_idx, resample_indices, resample_fg_counts, resample_bg_counts);
+    IA_REQUIRE(n >= 2, "ia_ray_resampling: n must be >= 2 (cdf.py:49)");
+    IA_REQUIRE(n_out >= 0 && n_out < ((int64_t)1 << 31) && n_out % n == 0, "ia_ray_resampling: n_out must be n x (rays with samples), below 2^31");
+    IA_REQUIRE(tmp != nullptr, "ia_ray_resampling: tmp (ia_resample_tmp_bytes) is required");
+    hipStream_t st = (hipStream_t)stream;
+    RsScratch s;
+    rs_layout(rs_aligned(tmp), n_rays, n_in, n, &s);
+    rs_utab_kernel<<<1, 64, 0, st>>>(n, 0, s.utab);
+    rs1_rays_kernel<<<ia::cdiv(n_rays, THREADS), THREADS, 0, st>>>(n_rays, n, packed_info, resample_packed_info, starts, ends, weights, sdfs, s,
+                                                                   surface_idx, resample_fg_counts, resample_bg_counts);
+    if (n_out > 0)
+        rs1_samples_kernel<<<ia::cdiv(n_out, THREADS), THREADS, 0, st>>>(n_out, n, packed_info, starts, ends, s, resample_ts, resample_offsets,
+                                                                         resample_indices);
     return ia::check_launch("ia_ray_resampling");
 }
 
-IA_EXPORT int ia_ray_resampling_merge(int64_t n_rays, const int32_t* packed_info, const float* vals,
+IA_EXPORT int ia_ray_resampling_merge(int64_t n_rays, int64_t n_in, int n, const int32_t* packed_info, const float* vals,
                                       const uint8_t* is_left, const uint8_t* is_right, const float* weights,
                                       const int32_t* resample_packed_info, float* resample_vals,
                                       float* resample_dists, uint8_t* resample_is_left, uint8_t* resample_is_right,
-                                      uint8_t* is_resample, uint8_t* is_fg_sample, ia_stream_t stream)
+                                      uint8_t* is_resample, uint8_t* is_fg_sample, void* tmp, ia_stream_t stream)
 {
     if (n_rays == 0) return IA_OK;
-    k2_merge_kernel<<<ia::cdiv(n_rays, THREADS), THREADS, 0, (hipStream_t)stream>>>(
-        n_rays, packed_info, vals, is_left, is_right, weights, resample_packed_info, resample_vals, resample_dists,
-        resample_is_left, resample_is_right, is_resample, is_fg_sample);
+    IA_REQUIRE(n >= 1, "ia_ray_resampling_merge: n must be >= 1");
+    IA_REQUIRE(tmp != nullptr, "ia_ray_resampling_merge: tmp (ia_resample_tmp_bytes) is required");
+    hipStream_t st = (hipStream_t)stream;
+    RsScratch s;
+    rs_layout(rs_aligned(tmp), n_rays, n_in, n, &s);
+    rs_utab_kernel<<<1, 64, 0, st>>>(n, 0, s.utab);
+    rs2_rays_kernel<<<ia::cdiv(n_rays, THREADS), THREADS, 0, st>>>(n_rays, n, packed_info, vals, is_left, is_right, weights, s);
+    rs2_edges_kernel<<<ia::cdiv(n_rays, RS2_TILE), THREADS, 0, st>>>(n_rays, packed_info, resample_packed_info, vals, is_left, is_right, s,
+                                                                     resample_vals, resample_dists, resample_is_left, resample_is_right,
+                                                                     is_resample, is_fg_sample);
     return ia::check_launch("ia_ray_resampling_merge");
 }
 
-IA_EXPORT int ia_ray_resampling_fine(int64_t n_rays, const int32_t* packed_info, const float* starts,
-                                     const float* ends, const float* weights, const int32_t* resample_packed_info,
-                                     float* resample_starts, float* resample_ends, uint8_t* is_fg_sample,
-                                     ia_stream_t stream)
+template <bool SDF>
+static int launch_fine(int64_t n_rays, int64_t n_in, int n, const int32_t* packed_info, const float* starts, const float* ends,
+                       const float* wa, const float* sdfs, const int32_t* rpi, int64_t n_out, float* out_starts, float* out_ends,
+                       uint8_t* out_fg, void* tmp, hipStream_t st, const char* what)
 {
     if (n_rays == 0) return IA_OK;
-    k34_fine_kernel<false><<<ia::cdiv(n_rays, THREADS), THREADS, 0, (hipStream_t)stream>>>(
-        n_rays, packed_info, starts, ends, weights, nullptr, resample_packed_info, resample_starts, resample_ends,
-        is_fg_sample);
-    return ia::check_launch("ia_ray_resampling_fine");
+    const int grid = ia::cdiv(n_rays, THREADS);
+    if (n + 1 <= IA_RS_SMALL && getenv("IA_RESAMPLE_TABLES") == nullptr) {
+        const int bins = n + 1;
+        const float du = (float)((1.0f - 1.0 / bins) / n);
+        const float u0 = (float)(1.0 / (2 * bins));
+#define IA_RS_CASE(N)                                                                                                                  \
+    case N:                                                                                                                            \
+        rs34_small_kernel<SDF, N><<<grid, THREADS, 0, st>>>(n_rays, packed_info, rpi, starts, ends, wa, sdfs, du, u0, out_starts, out_ends, \
+                                                            out_fg);                                                                   \
+        break;
+        switch (n) { IA_RS_CASE(1) IA_RS_CASE(2) IA_RS_CASE(3) IA_RS_CASE(4) IA_RS_CASE(5) IA_RS_CASE(6) IA_RS_CASE(7) IA_RS_CASE(8) }
+#undef IA_RS_CASE
+        return ia::check_launch(what);
+    }
+    if (tmp == nullptr) { ia::set_error("%s: tmp (ia_resample_tmp_bytes) is required", what); return IA_ERR_INVALID; }
+    if (!(n_out >= 0 && n_out < ((int64_t)1 << 31) && n_out % n == 0)) { ia::set_error("%s: n_out must be n x (rays with samples), below 2^31", what); return IA_ERR_INVALID; }
+    RsScratch s;
+    rs_layout(rs_aligned(tmp), n_rays, n_in, n, &s);
+    rs_utab_kernel<<<1, 64, 0, st>>>(n, 1, s.utab);
+    rs34_rays_kernel<SDF><<<grid, THREADS, 0, st>>>(n_rays, n, packed_info, rpi, wa, sdfs, s);
+    if (n_out > 0)
+        rs34_intervals_kernel<<<ia::cdiv(n_out, THREADS), THREADS, 0, st>>>(n_out, n, packed_info, starts, ends, s, out_starts, out_ends, out_fg);
+    return ia::check_launch(what);
 }
 
-IA_EXPORT int ia_ray_resampling_sdf_fine(int64_t n_rays, const int32_t* packed_info, const float* starts,
-                                         const float* ends, const float* alphas, const float* sdfs,
-                                         const int32_t* resample_packed_info, float* resample_starts,
-                                         float* resample_ends, uint8_t* is_fg_sample, ia_stream_t stream)
+IA_EXPORT int ia_ray_resampling_fine(int64_t n_rays, int64_t n_in, int n, const int32_t* packed_info, const float* starts,
+                                     const float* ends, const float* weights, const int32_t* resample_packed_info, int64_t n_out,
+                                     float* resample_starts, float* resample_ends, uint8_t* is_fg_sample, void* tmp,
+                                     ia_stream_t stream)
 {
-    if (n_rays == 0) return IA_OK;
-    k34_fine_kernel<true><<<ia::cdiv(n_rays, THREADS), THREADS, 0, (hipStream_t)stream>>>(
-        n_rays, packed_info, starts, ends, alphas, sdfs, resample_packed_info, resample_starts, resample_ends,
-        is_fg_sample);
-    return ia::check_launch("ia_ray_resampling_sdf_fine");
+    IA_REQUIRE(n >= 1, "ia_ray_resampling_fine: n must be >= 1");
+    return launch_fine<false>(n_rays, n_in, n, packed_info, starts, ends, weights, nullptr, resample_packed_info, n_out, resample_starts,
+                              resample_ends, is_fg_sample, tmp, (hipStream_t)stream, "ia_ray_resampling_fine");
+}
+
+IA_EXPORT int ia_ray_resampling_sdf_fine(int64_t n_rays, int64_t n_in, int n, const int32_t* packed_info, const float* starts,
+                                         const float* ends, const float* alphas, const float* sdfs,
+                                         const int32_t* resample_packed_info, int64_t n_out, float* resample_starts,
+                                         float* resample_ends, uint8_t* is_fg_sample, void* tmp, ia_stream_t stream)
+{
+    IA_REQUIRE(n >= 1, "ia_ray_resampling_sdf_fine: n must be >= 1");
+    return launch_fine<true>(n_rays, n_in, n, packed_info, starts, ends, alphas, sdfs, resample_packed_info, n_out, resample_starts,
+                             resample_ends, is_fg_sample, tmp, (hipStream_t)stream, "ia_ray_resampling_sdf_fine");
 }
 
 // count / compact the foreground intervals of a fine re-sampling; cnt, start: int32 [n_rays] (start = exclusive scan of cnt),

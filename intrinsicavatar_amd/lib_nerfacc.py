@@ -37,6 +37,12 @@ def _f32v(t: Tensor, n: Optional[int] = None) -> Tensor:
     return t.contiguous().float()
 
 
+def _resample_tmp(n_rays: int, n_in: int, n: int, dev) -> Tensor:
+    """scratch of one K1..K4 call: u-table, CDF tables, per-ray records (csrc/resample.hip)."""
+    nbytes = int(L.lib().ia_resample_tmp_bytes(L.i64(n_rays), L.i64(n_in), L.i32(n)))
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+
 # ----------------------------------------------------------------------------- K1
 @torch.no_grad()
 def ray_resampling(packed_info: Tensor, t_starts: Tensor, t_ends: Tensor, weights: Tensor, sdfs: Tensor,
@@ -54,12 +60,14 @@ def ray_resampling(packed_info: Tensor, t_starts: Tensor, t_ends: Tensor, weight
     ts = torch.empty((T, 1), dtype=torch.float32, device=dev)
     offs = torch.empty((T, 1), dtype=torch.float32, device=dev)
     idxs = torch.empty((T,), dtype=torch.int64, device=dev)
-    surface_idx = -torch.ones((n_rays,), dtype=torch.int64, device=dev)
-    fg = torch.zeros((w.shape[0],), dtype=torch.int32, device=dev)
-    bg = torch.zeros((n_rays,), dtype=torch.int32, device=dev)
-    L.check(L.lib().ia_ray_resampling(L.i64(n_rays), L.ptr(packed_info), L.ptr(st), L.ptr(en), L.ptr(w), L.ptr(sd),
-                                      L.ptr(rpi), L.ptr(ts), L.ptr(offs), L.ptr(surface_idx), L.ptr(idxs), L.ptr(fg),
-                                      L.ptr(bg), L.stream()), "ia_ray_resampling")
+    # every element of every output is written by the kernels (no -1 / zero fills)
+    surface_idx = torch.empty((n_rays,), dtype=torch.int64, device=dev)
+    fg = torch.empty((w.shape[0],), dtype=torch.int32, device=dev)
+    bg = torch.empty((n_rays,), dtype=torch.int32, device=dev)
+    tmp = _resample_tmp(n_rays, w.shape[0], n_samples, dev)
+    L.check(L.lib().ia_ray_resampling(L.i64(n_rays), L.i64(w.shape[0]), L.i32(n_samples), L.ptr(packed_info), L.ptr(st), L.ptr(en),
+                                      L.ptr(w), L.ptr(sd), L.ptr(rpi), L.i64(T), L.ptr(ts), L.ptr(offs), L.ptr(surface_idx), L.ptr(idxs),
+                                      L.ptr(fg), L.ptr(bg), L.ptr(tmp), L.stream()), "ia_ray_resampling")
     return rpi, ts, offs, idxs, fg, bg, surface_idx
 
 
@@ -78,11 +86,12 @@ def ray_resampling_merge(packed_info: Tensor, vals: Tensor, is_left: Tensor, is_
         raise RuntimeError("is_left/is_right must be bool")
     n_rays, dev = packed_info.shape[0], packed_info.device
     rpi, T = _resample_info(packed_info, n_samples, True)
-    f = torch.zeros((2, T), dtype=torch.float32, device=dev)
-    b = torch.zeros((4, T), dtype=torch.bool, device=dev)
-    L.check(L.lib().ia_ray_resampling_merge(L.i64(n_rays), L.ptr(packed_info), L.ptr(vals), L.ptr(il), L.ptr(ir),
-                                            L.ptr(w), L.ptr(rpi), L.ptr(f[0]), L.ptr(f[1]), L.ptr(b[0]), L.ptr(b[1]),
-                                            L.ptr(b[2]), L.ptr(b[3]), L.stream()), "ia_ray_resampling_merge")
+    f = torch.empty((2, T), dtype=torch.float32, device=dev)
+    b = torch.empty((4, T), dtype=torch.bool, device=dev)
+    tmp = _resample_tmp(n_rays, vals.shape[0], n_samples, dev)
+    L.check(L.lib().ia_ray_resampling_merge(L.i64(n_rays), L.i64(vals.shape[0]), L.i32(n_samples), L.ptr(packed_info), L.ptr(vals),
+                                            L.ptr(il), L.ptr(ir), L.ptr(w), L.ptr(rpi), L.ptr(f[0]), L.ptr(f[1]), L.ptr(b[0]), L.ptr(b[1]),
+                                            L.ptr(b[2]), L.ptr(b[3]), L.ptr(tmp), L.stream()), "ia_ray_resampling_merge")
     # (resampled_packed_info, vals, dists, is_left, is_right, is_resampled, is_fg_sample)
     return rpi, f[0], f[1], b[0], b[1], b[2], b[3]
 
@@ -97,18 +106,19 @@ def _fine(packed_info, t_starts, t_ends, wa, sdfs, n_samples, sdf_mode):
     st, en, wa = _f32v(t_starts), _f32v(t_ends), _f32v(wa)
     n_rays, dev = packed_info.shape[0], packed_info.device
     rpi, T = _resample_info(packed_info, n_samples, False)
-    rs = torch.zeros((T, 1), dtype=torch.float32, device=dev)
-    re = torch.zeros((T, 1), dtype=torch.float32, device=dev)
-    fg = torch.zeros((T,), dtype=torch.bool, device=dev)
+    rs = torch.empty((T, 1), dtype=torch.float32, device=dev)
+    re = torch.empty((T, 1), dtype=torch.float32, device=dev)
+    fg = torch.empty((T,), dtype=torch.bool, device=dev)
+    tmp = _resample_tmp(n_rays, wa.shape[0], n_samples, dev) if n_samples > 8 else None      # few points per ray stay in registers
     if sdf_mode:
         sd = _f32v(sdfs)
-        L.check(L.lib().ia_ray_resampling_sdf_fine(L.i64(n_rays), L.ptr(packed_info), L.ptr(st), L.ptr(en), L.ptr(wa),
-                                                   L.ptr(sd), L.ptr(rpi), L.ptr(rs), L.ptr(re), L.ptr(fg), L.stream()),
-                "ia_ray_resampling_sdf_fine")
+        L.check(L.lib().ia_ray_resampling_sdf_fine(L.i64(n_rays), L.i64(wa.shape[0]), L.i32(n_samples), L.ptr(packed_info), L.ptr(st),
+                                                   L.ptr(en), L.ptr(wa), L.ptr(sd), L.ptr(rpi), L.i64(T), L.ptr(rs), L.ptr(re), L.ptr(fg),
+                                                   L.ptr(tmp), L.stream()), "ia_ray_resampling_sdf_fine")
     else:
-        L.check(L.lib().ia_ray_resampling_fine(L.i64(n_rays), L.ptr(packed_info), L.ptr(st), L.ptr(en), L.ptr(wa),
-                                               L.ptr(rpi), L.ptr(rs), L.ptr(re), L.ptr(fg), L.stream()),
-                "ia_ray_resampling_fine")
+        L.check(L.lib().ia_ray_resampling_fine(L.i64(n_rays), L.i64(wa.shape[0]), L.i32(n_samples), L.ptr(packed_info), L.ptr(st),
+                                               L.ptr(en), L.ptr(wa), L.ptr(rpi), L.i64(T), L.ptr(rs), L.ptr(re), L.ptr(fg), L.ptr(tmp),
+                                               L.stream()), "ia_ray_resampling_fine")
     return rpi, rs, re, fg
 
 
