@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config2", action="store_true", help="skip the secondary configs[1] measurement of the headline line")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the instrumented repeat (profiling runs)")
+    ap.add_argument("--no-search-modes", action="store_true", help="skip the search-to-the-end timing / comparison of the deformer search")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd only (no Adam step)")
     ap.add_argument("--aten-profile", default=None, help="diagnostic: one extra step under torch.profiler; the ATen operators by device time "
                                                           "(with input shapes) go to this file")
@@ -303,6 +304,15 @@ def main():
             sched.step()
         return out
 
+    # CPU baseline + parity at the bench frame, BEFORE the first optimiser step: the oracle's scene bundle holds the parameters as
+    # initialised, and the same rays go through the GPU path with the same random numbers right after the workers finish
+    cpu = parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from intrinsicavatar_amd import synthetic as _S
+        env0 = sg.generate_image().detach() if headline else None
+        cpu, parity = cpu_baseline(rays, export, n_rays, headline, args.spp, _S.export_phys(mat, env0) if headline else None,
+                                   gpu_model=(rs, mat if headline else None, env0))
+
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
@@ -351,6 +361,51 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * n_rays * args.steps / dt
 
+    # ---- the deformer search of the timed path against the reference's search-to-the-end (fuse_cuda_kernel_fast.cu:252-452 +
+    # filter.cu:10-54), IN THIS RUN: (i) the same step with the early filter off (spec_eps = 0: every search runs to its end, K9 as a
+    # pass) timed next to the timed figure; (ii) on march points of this frame, the candidate sets / min-SDF of the two searches compared
+    search_modes = None
+    if headline and rank == 0 and world == 1 and not args.no_search_modes and rs.deformer.spec_eps > 0:
+        eps0 = rs.deformer.spec_eps
+        try:
+            rs.deformer.spec_eps = 0.0
+            step()
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            exact_ms = (time.perf_counter() - te) / 2 * 1e3
+        finally:
+            rs.deformer.spec_eps = eps0
+        cmp_ = None
+        try:
+            from tools import spec_search_probe as SP
+            from intrinsicavatar_amd import fast_snarf as _fs
+            pts = SP.march_points(rs, rays, 1 << 19)
+            x0, v0 = SP.search(rs.deformer, pts, None)
+            k0 = _fs.filter(x0, v0)
+            rs.deformer.spec_eps = 0.0
+            s0 = rs.deformer.deform_sdf(pts, rs.geometry)
+            rs.deformer.spec_eps = eps0
+            r_ = SP.compare(rs.deformer, rs.geometry, pts, eps0, (x0, v0, k0, s0))
+            cmp_ = dict(points=int(pts.shape[0]), candidate_set_differs=int(round(r_["set_mismatch"] * pts.shape[0])),
+                        distinct_root_lost=int(round(r_["lost_root"] * pts.shape[0])), min_sdf_bits_differ=int(round(r_["sdf_bits_differ"] * pts.shape[0])),
+                        min_sdf_max_abs_diff=r_["sdf_max_abs"], completed_items_bit_identical=r_["completed_items_bit_identical"],
+                        points_redone_with_the_filter_off=int(r_["redone_points"]), fetches_per_point=round(r_["fetches_per_point"], 2))
+            del x0, v0, k0, s0, pts
+        except Exception as e:
+            cmp_ = dict(error=f"{type(e).__name__}: {e}")
+        finally:
+            rs.deformer.spec_eps = eps0
+        search_modes = dict(
+            timed="K9-consistent early filter (csrc/snarf.hip: retire inside the eps-box of a tight later root, same voxel cell; redo a point with "
+                  "the filter off when a completed root is 1e-4 .. 2e-4 from a recorded one)",
+            eps=eps0, ms_per_step=round(ms_per_step, 3),
+            search_to_the_end=dict(ms_per_step=round(exact_ms, 3), rays_per_s=round(n_rays / (exact_ms * 1e-3), 1),
+                                   note="IA_BROYDEN_SPEC_EPS=0: all 13 searches of every point to their end + K9 pass; 2 steps after 1 warm-up, same process"),
+            vs_search_to_the_end_on_this_frame=cmp_)
+
     # ---- secondary key of the headline line: round 1's configs[1] step (radiance + SDF, no PBR branch), same frame
     config2 = None
     if headline and rank == 0 and world == 1 and not args.no_config2:
@@ -382,8 +437,16 @@ def main():
         if per_call:
             dname, (dcalls, dms) = max(per_call.items(), key=lambda kv: kv[1][1])
             bro = None
-            if dname in ("ia_fuse_broyden", "ia_fuse_broyden_spec", "ia_fuse_broyden_spec_rows") and world == 1:      # one extra untimed step (a step has collectives: single rank only)
-                bro = count_broyden_fetches(step, dev, rs.deformer)[dname]
+            if dname in ("ia_fuse_broyden", "ia_fuse_broyden_spec", "ia_fuse_broyden_spec_rows"):
+                # one extra untimed step; with N > 1 a LOCAL one on rank 0 (all chunks under no_sync, no finish(), no optimiser step:
+                # no collective is issued, the other ranks are not involved), so the roofline is the same object at every N
+                def local_step():
+                    if sync is None:
+                        return step()
+                    with sync.no_sync():
+                        return step_headline(None) if headline else step_config2(None)
+                bro = count_broyden_fetches(local_step, dev, rs.deformer)[dname]
+                zero_grads()
             ab = algorithmic_bytes(dname, detail[dname], extra=(bro[1] * k_instr if bro else None))
             stats["deform_points"] = sum(u for k in ("ia_fuse_broyden", "ia_fuse_broyden_spec", "ia_fuse_broyden_spec_rows") for _, u, _ in detail.get(k, [])) // k_instr      # counted, not estimated
             stats["hash_points"] = sum(u for k in ("ia_hashgrid_fwd", "ia_hashgrid_fwd_xcd") for _, u, _ in detail.get(k, [])) // k_instr
@@ -445,10 +508,6 @@ def main():
                                 useful_flop_per_point=flop_pt, note="fp32 MFMA (v_mfma_f32_32x32x2_f32) dense peak; in-step, live HIP events")
             breakdown = {k: dict(calls_per_step=v[0] / k_instr, ms_per_step=round(v[1] / k_instr, 3))
                          for k, v in sorted(per_call.items(), key=lambda kv: -kv[1][1])[:12]}
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            from intrinsicavatar_amd import synthetic as _S
-            cpu = cpu_baseline(rays, export, n_rays, headline, args.spp, _S.export_phys(mat, sg.generate_image().detach()) if headline else None)
         wl = (f"{args.hw}x{args.hw} frame ({n_rays} rays), fwd+bwd+Adam WITH the PBR branch: 128 samples/ray primary march, 2x importance "
               f"resampling, fast-SNARF deformer (13 inits), SDF/radiance/material fields, samples_per_pixel={args.spp} volume-interaction "
               f"re-samples per ray, render_mode=light (one light-importance-sampled secondary ray per foreground re-sample, training form), "
@@ -479,7 +538,8 @@ def main():
                        "peak_device_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                        "parallelism": f"frame/ray-batch sharding x{world}", "samples": stats,
                        "library_sources_sha256_16": _build.source_fingerprint(), "library_built_from": _build.built_fingerprint()},
-            "roofline": roofline, "mfma": mfma, "cpu_baseline": cpu, "kernel_breakdown_ms_per_step": breakdown,
+            "roofline": roofline, "mfma": mfma, "cpu_baseline": cpu, "parity_on_bench_frame": parity, "deformer_search": search_modes,
+            "kernel_breakdown_ms_per_step": breakdown,
             "ms_per_step_instrumented": round(dt_instr / max(k_instr, 1) * 1e3, 3),
             "abi_kernel_ms_per_step": round(total_ms / max(k_instr, 1), 3),
             "secondary_rays_per_s": (round(world * stats.get("n_secondary", 0) * args.steps / dt, 1) if headline else None),
@@ -573,7 +633,59 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(rays, export, n_rays, headline, spp, phys=None):
+def parity_on_bench_frame(gpu_model, sample, edges, refs, spp, dev):
+    """the CPU oracle's renderings of the cpu_baseline sample (one .npz per worker) against the GPU path on the SAME rays with
+    the SAME random numbers (a worker draws light_u [spp,3] then shuffle_u [n,spp] from default_rng(first ray index),
+    oracle/render_ref.py relight_step): per map max / p99 / mean absolute difference, and the discrete flips counted."""
+    from intrinsicavatar_amd import pbr
+    rs, mat, env_img = gpu_model
+    keys = ("comp_rgb", "comp_normal", "opacity", "depth", "albedo", "roughness", "metallic", "comp_rgb_phys")
+    errs = {k: [] for k in keys}
+    flips = dict(rays=0, sample_count=0, has_samples=0, resampled_layout=0, n_fg_ref=0, n_fg_gpu=0)
+    emitter = None
+    if spp:
+        emitter = pbr.EnvironmentLightTensor(env_img)
+        emitter.update_pdf()
+    white = torch.ones(3, device=dev)
+    with torch.no_grad():
+        for k, ref in enumerate(refs):
+            a, b = edges[k], edges[k + 1]
+            if b <= a:
+                continue
+            r = torch.from_numpy(sample[a:b]).to(dev)
+            if spp:
+                rng = np.random.default_rng(a)
+                light_u = torch.from_numpy(rng.random((spp, 3), dtype=np.float32)).to(dev)
+                shuffle_u = torch.from_numpy(rng.random((b - a, spp), dtype=np.float32)).to(dev)
+                out = rs.relight(r, mat, emitter, spp, light_u, shuffle_u, background_color=white, global_illumination=True)
+            else:
+                out = rs.forward(r)
+            for key in keys:
+                if key in ref and key in out:
+                    errs[key].append(np.abs(out[key].detach().cpu().numpy().reshape(b - a, -1) - ref[key].reshape(b - a, -1)).max(-1))
+            cg, cr = out["packed_info"][:, 1].cpu().numpy(), ref["packed_info"][:, 1]
+            flips["rays"] += b - a
+            flips["sample_count"] += int((cg != cr).sum())
+            flips["has_samples"] += int(((cg > 0) != (cr > 0)).sum())
+            if "resampled_packed_info" in ref and "resampled_packed_info" in out:
+                flips["resampled_layout"] += int((out["resampled_packed_info"].cpu().numpy() != ref["resampled_packed_info"]).any(-1).sum())
+                flips["n_fg_ref"] += int(ref["n_fg"])
+                flips["n_fg_gpu"] += int(out["stats"]["n_fg"])
+    maps = {}
+    for key, v in errs.items():
+        if v:
+            e = np.concatenate(v)
+            maps[key] = dict(max=float(e.max()), p99=float(np.quantile(e, 0.99)), mean=float(e.mean()))
+    return dict(rays=flips["rays"], maps_abs_err=maps,
+                flips=dict(rays_with_other_sample_count=flips["sample_count"], rays_hit_vs_miss=flips["has_samples"],
+                           rays_with_other_resample_layout=flips["resampled_layout"],
+                           foreground_resamples=(flips["n_fg_gpu"], flips["n_fg_ref"])),
+                against="oracle/render_ref.py (relight_step eval form / render_step) on the cpu_baseline sample of the timed frame, same rays and "
+                        "random numbers, parameters as initialised (before the first optimiser step); comp_rgb_phys is a Monte-Carlo estimate: a "
+                        "visibility sample that falls on the other side of a threshold moves a pixel by Lo / spp")
+
+
+def cpu_baseline(rays, export, n_rays, headline, spp, phys=None, gpu_model=None):
     """the CPU oracle (oracle/: a port of the reference's algorithm, test infrastructure) timed on this box's host cores on a
     bounded sample of the same frame: one single-threaded worker process per core (oracle/cpu_worker.py), each on its share
     of the sample; rate = sample rays / slowest worker's compute time.  Forward only: the oracle has no backward."""
@@ -593,15 +705,23 @@ def cpu_baseline(rays, export, n_rays, headline, spp, phys=None):
         env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
         tc = time.perf_counter()
         procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", f"{td}/scene.npz", f"{td}/rays.npy", str(edges[k]),
-                                   str(edges[k + 1]), str(spp if headline else 0)], cwd=ROOT, env=env, stdout=subprocess.PIPE,
-                                  stderr=subprocess.DEVNULL) for k in range(cores)]
+                                   str(edges[k + 1]), str(spp if headline else 0), f"{td}/out{k}.npz"], cwd=ROOT, env=env,
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for k in range(cores)]
         times = []
         for p_ in procs:
             out, _ = p_.communicate(timeout=600)
             if p_.returncode != 0:
-                return dict(value=None, unit="rays/s", cores=cores, kind="port", sample="worker failed")
+                return dict(value=None, unit="rays/s", cores=cores, kind="port", sample="worker failed"), None
             times.append(float(out.decode().strip().splitlines()[-1]))
         wall = time.perf_counter() - tc
+        # the rays the oracle just rendered, rendered by the GPU path with the same random numbers: parity AT the bench frame
+        parity = None
+        if gpu_model is not None:
+            try:
+                parity = parity_on_bench_frame(gpu_model, sample, edges, [dict(np.load(f"{td}/out{k}.npz")) for k in range(cores)],
+                                               spp if headline else 0, rays.device)
+            except Exception as e:              # a diagnostic must not take the measurement down
+                parity = dict(error=f"{type(e).__name__}: {e}")
     tcpu = max(times)
     form = (f"relight_step (render_step FORWARD with the PBR branch at {spp} spp: render_mode=light in its eval form -- shared light "
             f"directions shuffled per ray --, secondary rays + indirect shading on)") if headline else \
@@ -609,7 +729,7 @@ def cpu_baseline(rays, export, n_rays, headline, spp, phys=None):
     return dict(value=round(len(sample) / tcpu, 1), unit="rays/s", cores=cores, kind="port", passes="forward only (the oracle has no backward)",
                 sample=f"every {stride}th ray of the same 540x540 frame ({len(sample)} rays), oracle/render_ref.py {form}; {cores} "
                        f"single-threaded worker processes, slowest {tcpu:.1f} s, mean {sum(times) / len(times):.1f} s, {wall:.1f} s incl. start-up",
-                single_core_rays_per_s=round(len(sample) / sum(times), 2))
+                single_core_rays_per_s=round(len(sample) / sum(times), 2)), parity
 
 
 if __name__ == "__main__":

@@ -195,28 +195,31 @@ int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt /*[B,N,3]*/, co
                     float* fwd_J /*[B,N,I,3,3] or NULL: forward LBS Jacobian at each root (= fwd_tfs, deformer_torch.py:49-52)*/,
                     ia_stream_t stream);
 int ia_filter(int64_t N, int I, const float* x /*[1,N,I,3]*/, const uint8_t* mask, uint8_t* out, ia_stream_t stream);
-/* ia_fuse_broyden with a SPECULATIVE EARLY FILTER (product path of the big no-grad query batches; B = 1, channel-last grid;
+/* ia_fuse_broyden with a K9-CONSISTENT EARLY FILTER (product path of every query batch; B = 1, channel-last grid;
  * no reference counterpart -- the reference runs every search to its end and lets filter.cu:10-54 drop the duplicates).
  * One lane owns one point and searches its inits in REVERSE order; a search whose next position comes within `eps`
- * (inf-norm, canonical metres) of a root that a LATER init of the same point converged to is retired (is_valid = 0): it
- * would end on that root, where K9 keeps the later init.  Items that are not retired are computed with the operation
- * sequence of ia_fuse_broyden (bit-identical x / J_inv / fwd_J / is_valid); eps = 0 retires nothing.  Mis-prediction rates
- * on the headline distribution: DESIGN.md 4.5, tests/test_gpu_spec_search.py.
- * counters: NULL or uint64[5], caller-zeroed, accumulated: fetches issued, retired items, completed valid items, roots
- * that found the per-point root list (3) full, in-range corner loads of the fetches. */
+ * (inf-norm, canonical metres) of a TIGHT root (|J_inv|_F <= 2.5) that a LATER init of the same point converged to, inside
+ * that root's voxel cell, while its own |J_inv|_F <= 3, is retired (is_valid = 0): it would end within K9's 1e-4 of that
+ * root, or fail -- K9 drops it either way.  A completed root between 1e-4 and 2e-4 of a recorded one (or a 4th distinct
+ * root) makes the lane search its point again with the filter off.  Items that are not retired are computed with the operation
+ * sequence of ia_fuse_broyden (bit-identical x / J_inv / fwd_J / is_valid), and ia_filter of the result equals ia_filter of
+ * ia_fuse_broyden's on all but ~1e-7 of the points (1 of 16.4 M on the headline frame, profiles/r04_spec_search_probe.json;
+ * DESIGN.md 4.5, tests/test_gpu_spec_search.py); eps = 0 retires nothing.
+ * counters: NULL or uint64[5], caller-zeroed, accumulated: fetches issued, retired items, completed valid items, points
+ * searched again with the filter off, in-range corner loads of the fetches. */
 int ia_fuse_broyden_spec(int64_t N, int I, const float* xd_tgt /*[N,3]*/, const float* voxel_J_cl /*[D,H,W,12]*/, int D, int H, int W,
                          const float* tfs /*[24,4,4]*/, const int32_t* bone_ids, const float* offset, const float* scale,
                          float cvg_threshold, float dvg_threshold, float eps, float* x /*[N,I,3]*/, float* J_inv /*[N,I,3,3] or NULL*/,
                          uint8_t* is_valid /*[N,I]*/, float* fwd_J /*[N,I,3,3] or NULL*/, uint64_t* counters, ia_stream_t stream);
 /* The same search with the CANDIDATE BOOKKEEPING done in the kernel (replaces is_valid + filter.cu:10-54 + the mask indexing of
- * snarf_deformer.py:187-196 on the product path).  With eps >= 1e-4 (required) a search that completes valid is farther than
- * K9's radius from every root recorded before it, so the completed searches of a point ARE K9's survivors as long as there are
- * at most ia_spec_rows_slots() (= 3) of them.  Outputs: x_rows [N, 3, 3]: the k-th completed search of a point (k = 0: its
- * highest init) stores its root in slot k; cnt [N]; meta [N]: the inits of slots 0..2 in bytes 0..2 (bit 31: the point has
- * overflow records); start [N] = exclusive scan of cnt.  A 4th, 5th ... completed search of a point (rare) becomes a record in
- * ovf_scratch (ia_spec_rows_overflow_bytes() bytes; chained per point through ovf_head [N], which is written for such points
- * only); K9 runs among a point's records and the kept ones count towards cnt.  total_and_overflow [2]: [0] = Q, [1] = number of
- * overflow records -- above ia_spec_rows_overflow_capacity() records were lost: redo the batch with ia_fuse_broyden_spec + K9.
+ * snarf_deformer.py:187-196 on the product path).  A search that completes valid is compared with the point's recorded roots:
+ * within K9's 1e-4 it is a duplicate, from 2e-4 up it is a candidate and gets the next of the point's ia_spec_rows_slots() (= 3)
+ * row slots; in between, or with the row full, the point is searched again with the filter off and K9 runs literally on its 13
+ * results.  Outputs: x_rows [N, 3, 3]: the k-th candidate of a point (k = 0: its highest init) in slot k; cnt [N]; meta [N]: the
+ * inits of slots 0..2 in bytes 0..2 (bit 31: the point has overflow records: a 4th, 5th ... survivor of a redone point, chained
+ * per point through ovf_head [N], which is written for such points only); start [N] = exclusive scan of cnt; ovf_scratch:
+ * ia_spec_rows_overflow_bytes() bytes.  total_and_overflow [2]: [0] = Q, [1] = number of points redone -- above
+ * ia_spec_rows_overflow_capacity() results were lost: redo the batch with ia_fuse_broyden_spec + K9.
  * 44 bytes per point leave the kernel instead of 169 (x [N,I,3] + is_valid).  J_inv / fwd_J (optional) are written at
  * [point, init] as in ia_fuse_broyden.  scan_tmp: ia_scan_tmp_bytes(N) bytes.
  * ia_deform_rows_pack: cand_x [Q,3] (+ cand_src [Q] = point * I + init, optional) in (point, ascending init) order; with

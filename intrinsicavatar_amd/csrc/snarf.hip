@@ -573,20 +573,30 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
     }
 }
 
-// ---- K8 + speculative early filter (product path; B == 1, channel-last grid) ------------------------------------------------
-// 13 searches per point yield ~1.3 surviving roots: ~58 % of the searches converge, most of them onto a root that a LATER
-// init also finds -- and K9 (filter.cu:10-54) keeps only the LAST member of such a cluster.  Here one lane owns one POINT and
+// ---- K8 + K9-consistent early filter (product path; B == 1, channel-last grid) -----------------------------------------------
+// 13 searches per point yield ~1.2 surviving roots: ~58 % of the searches converge, most of them onto a root that a LATER
+// init also finds -- and K9 (filter.cu:10-54) drops every root that has a later one within 1e-4.  Here one lane owns one POINT and
 // walks its inits in REVERSE order (I-1 .. 0), so when init i runs every later init has already finished and the roots they
-// converged to are known exactly.  Before every fetch (at x_k, k >= 0: the start x_0 included) the lane tests
-// |x_k - r|_inf < eps against the recorded roots r of its point: a search that has come within eps of a root found by a
-// later init is going to end on that root (or fail) -- either way K9 would drop it -- so it is retired (is_valid = 0) and
-// its remaining fetches are never issued.  Everything that is NOT retired runs the operation sequence of broyden_kernel:
-// surviving candidates are bit-identical to the exact search.  What speculation can change (measured): a point
-// loses a candidate only if two DISTINCT roots lie within eps of each other (or a search within eps of a root would have
-// moved on to another one), and duplicates that the exact search leaves 1e-4 .. eps apart (K9 keeps both) collapse to the
-// later one.  eps = 0 never retires (the test is strict).  Scheduling as broyden_persistent2_kernel: every loop iteration
-// is exactly one trilinear fetch per busy lane; a lane that finishes a search starts its point's next init at once, a lane
-// that finishes a point pulls the wave's next point (ballot + popcount, wave-private cursor).
+// converged to are known exactly.  A search is RETIRED (its remaining fetches never issued) before a fetch at x_k when all of:
+//   (a) |x_k - r|_inf < eps for a recorded root r of a later init;
+//   (b) r is TIGHT: the Frobenius norm of Broyden's J_inv at r is <= SPEC_TAU.  Every search that converges to the true root
+//       behind r stops inside {|g| < cvg} around it, i.e. within ~cvg |J^-1| of it: for a tight root all of them end within a few
+//       1e-5 of r -- inside K9's radius, so K9 would drop the retired search whatever its exact end point;
+//   (c) x_k lies in the SAME voxel cell as r (shrunk by SPEC_CELL_MARGIN): g is piecewise polynomial with kinks on the cell faces, and
+//       two distinct well-conditioned roots closer than eps only occur across a kink;
+//   (d) the search's own J_inv estimate has norm <= SPEC_TAU_SELF (k >= 1): it is not sliding along a near-singular valley, where
+//       it could stop farther than 1e-4 from r.
+// (a)-(c) are ONE box test per recorded root: the eps-box around r intersected with r's cell, empty for a root that is not tight.
+// A search that COMPLETES valid is compared (L2, K9's expression) with the recorded roots: below 1e-4 it is a duplicate K9 drops;
+// from 2e-4 up it is recorded (K9 keeps it: every later valid root, retired ones included, lies within 1e-4 of a recorded one);
+// in between -- or when the SPEC_ROOTS slots are full -- the lane REDOES THE POINT with the filter off (all 13 searches to their
+// end) and hands the 13 results to rows_flagged_kernel, which applies K9 literally.  Measured on the headline frame's 16.4 M march
+// points (tools/k9_rule_probe.py, profiles/r04_k9_rule_probe_*.json): 40.7 % fewer fetches than the exact search, candidate set
+// different from K9's on 1 point (6e-8), no distinct root lost, 1.8e-4 of the points redone; the synthetic pose: 31 % fewer, 0
+// of 18.0 M points different.  Everything that is not retired runs the operation sequence of broyden_kernel: surviving
+// candidates are bit-identical to the exact search's.  eps = 0 never retires.  Scheduling as broyden_persistent2_kernel: every
+// loop iteration is exactly one trilinear fetch per busy lane; a lane that finishes a search starts its point's next init at
+// once, a lane that finishes a point pulls the workgroup's next point.
 __device__ __forceinline__ unsigned in_range_corner_count(float gx, float gy, float gz, int D, int H, int W)
 {
     float ix = ((gx + 1.f) / 2) * (W - 1), iy = ((gy + 1.f) / 2) * (H - 1), iz = ((gz + 1.f) / 2) * (D - 1);
@@ -600,28 +610,34 @@ __device__ __forceinline__ unsigned in_range_corner_count(float gx, float gy, fl
     return cx * cy * cz;
 }
 
-constexpr int SPEC_ROOTS = 3;      // recorded roots per point (survivors per point average 1.3; a 4th root is simply not recorded)
+constexpr int SPEC_ROOTS = 3;              // recorded roots per point (survivors per point average 1.2; a 4th sends the point to the exact redo)
+constexpr float SPEC_TAU = 2.5f;           // a root is tight when |J_inv|_F <= SPEC_TAU (a rotation has sqrt(3) = 1.73)
+constexpr float SPEC_TAU_SELF = 3.0f;      // a search may be retired while its own |J_inv|_F <= SPEC_TAU_SELF
+constexpr float SPEC_CELL_MARGIN = 4e-6f;  // the cell box of a root is shrunk by this much (canonical metres) on every side
+constexpr int SPEC_FLAG_CAP = 1 << 16;     // points per launch that can be redone exactly (1.8e-4 of the points are)
 
-// PACK: the candidate bookkeeping of the caller done here.  With eps >= 1e-4 every search that COMPLETES valid is farther than
-// eps (inf-norm, so farther than K9's 1e-4 in L2) from every root recorded before it -- the completed items ARE K9's
-// survivors as long as a point has at most SPEC_ROOTS of them.  So instead of x [N,I,3] + is_valid [N,I] for a filter pass, the
-// k-th completed search of a point (k = 0 is its highest init) stores its root in x [N, SPEC_ROOTS, 3] slot k, and the lane
-// leaves cnt[point] and meta[point] = the inits of slots 0..2 in bytes 0..2: 44 bytes per point instead of 169.  The rare
-// (SPEC_ROOTS+1)-th, ... completed search of a point (it was only tested against the first SPEC_ROOTS roots) goes to a global
-// overflow list as a record (point, init, root, previous record of the same point); rows_extras_kernel runs K9 among the
-// records of a point (filter.cu:10-54: drop one when a LATER init's lies within 1e-4) and adds the kept ones to cnt, and
-// ia_deform_rows_pack emits them in front of the row's candidates (their inits are lower).  Only a full list (ovf_cap) makes the
-// caller redo the batch with the is_valid + K9 path.
+// flagged points: the 13 results of the exact redo, for rows_flagged_kernel
+struct SpecFlag {
+    int32_t* count;      // [1]
+    int32_t* point;      // [cap]
+    uint32_t* valid;     // [cap] bit i: init i converged inside the box
+    float* x;            // [cap][16][3]
+    int cap;
+};
+
+// PACK: the candidate bookkeeping of the caller done here: the k-th recorded root of a point (k = 0 is its highest init) goes to
+// x [N, SPEC_ROOTS, 3] slot k, and the lane leaves cnt[point] and meta[point] = the inits of slots 0..2 in bytes 0..2: 44 bytes per
+// point instead of 169 (x [N,I,3] + is_valid [N,I]), no filter pass.  Flagged points leave cnt = 0 and their record; rows_flagged_kernel
+// fills in their rows (and overflow records for a 4th, 5th ... survivor).
 template <bool COUNT, bool PACK, int WG = THREADS>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES, IA_BR2_WAVES))) void broyden_spec_kernel(
     int64_t N, int I, const float* __restrict__ xd_tgt, const float* __restrict__ voxel_J, int D, int H, int W,
     const float* __restrict__ tfs, const int32_t* __restrict__ bone_ids, const float* __restrict__ offset_g,
     const float* __restrict__ scale_g, float cvg_threshold, float dvg_threshold, float eps, float* __restrict__ x,
     float* __restrict__ J_inv, uint8_t* __restrict__ is_valid, float* __restrict__ fwd_J, int pts_per_wave,
-    unsigned long long* __restrict__ counters /* NULL or [5]: fetches, retired items, completed valid items, unrecorded roots, in-range corner loads */,
-    int32_t* __restrict__ cnt /* PACK: [N] */, uint32_t* __restrict__ meta /* PACK: [N] */, int32_t* __restrict__ ovf_count /* PACK: [1] */,
-    int32_t* __restrict__ ovf_head /* PACK: [N], written for points with extras only */, int32_t* __restrict__ ovf_rec /* PACK: [cap][3] point, init, prev */,
-    float* __restrict__ ovf_x /* PACK: [cap][3] */, int ovf_cap, int slots /* <= SPEC_ROOTS: roots recorded / row slots used (test hook) */,
+    unsigned long long* __restrict__ counters /* NULL or [5]: fetches, retired items, completed valid items, points redone exactly, in-range corner loads */,
+    int32_t* __restrict__ cnt /* PACK: [N] */, uint32_t* __restrict__ meta /* PACK: [N] */, SpecFlag flag /* PACK */,
+    int slots /* <= SPEC_ROOTS: roots recorded / row slots used (test hook) */,
     const int32_t* __restrict__ order /* NULL or [N]: point p of this launch is xd_tgt[order[p]] (evaluation order != storage order) */)
 {
     __shared__ float s_T[16 * 12];                     // per init: rows 0..2 of its bone's 4x4 (R | t)
@@ -648,27 +664,35 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
     const float offset[3] = {offset_g[0], offset_g[1], offset_g[2]};
     const float scale[3] = {scale_g[0], scale_g[1], scale_g[2]};
     const float cvg2 = cvg_threshold * cvg_threshold, dvg2 = dvg_threshold * dvg_threshold;
+    // voxel cell f of axis a covers canonical x in [f cell_w + cell_o, (f + 1) cell_w + cell_o)   (g = scale (x + offset), f = floor(((g + 1) / 2) (dim - 1)))
+    // (wave-uniform: pinned in scalar registers -- the divisions leave them in vector registers otherwise, which this kernel has none to spare)
+    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    const float cell_w[3] = {uni(2.0f / ((W - 1) * scale[0])), uni(2.0f / ((H - 1) * scale[1])), uni(2.0f / ((D - 1) * scale[2]))};
+    const float cell_o[3] = {uni(-1.0f / scale[0] - offset[0]), uni(-1.0f / scale[1] - offset[1]), uni(-1.0f / scale[2] - offset[2])};
 
     bool have = false;            // lane owns a point
     bool next = false;            // current search ended: move to the point's next init (or give the point up)
     int pt = 0;                   // the lane's point, relative to the wave's chunk
     int init = 0;
     int it = -1;                  // -1: waiting for the initial fetch
-    int n_roots = 0;
-    // PACK: searches of the lane's point that completed valid, their inits (one byte each), the point's most recent overflow record
+    int n_roots = 0;              // recorded roots of the lane's point (stays 0 while the point is redone exactly)
+    // rarely touched per-lane state lives in LDS: [0] roots recorded as candidates (PACK) or -1 = the point is being REDONE EXACTLY,
+    // [1] their inits, one byte each (exact redo: the valid mask of the 13 searches), [2] the point's record in the flagged list
     __shared__ int s_state[3][WG];
 #define n_done s_state[0][threadIdx.x]
 #define inits (reinterpret_cast<unsigned*>(s_state[1])[threadIdx.x])
-#define last_ovf s_state[2][threadIdx.x]
-    n_done = 0; inits = 0; last_ovf = -1;
+#define flag_rec s_state[2][threadIdx.x]
+    n_done = 0; inits = 0; flag_rec = -1;
     float xt[3] = {0, 0, 0}, x_l[3] = {0, 0, 0}, gx[3] = {0, 0, 0}, u[3] = {0, 0, 0};
     float Ji[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    // the recorded roots of the lane's point and its rarely touched PACK counters live in LDS (12 registers that the six loads in
-    // flight per interpolation phase need)
-    __shared__ float s_root[SPEC_ROOTS * 3][WG];
+    // per recorded root: the root (for K9's distance when a later search completes) and its RETIREMENT BOX = eps-box around it
+    // intersected with its (shrunk) voxel cell; lo = +inf for a root that is not tight
+    __shared__ float s_root[SPEC_ROOTS * 9][WG];
     float* const rootp = &s_root[0][threadIdx.x];
-#define ROOT(r, k) rootp[((r) * 3 + (k)) * WG]
-    unsigned c_fetch = 0, c_retired = 0, c_valid = 0, c_unrec = 0, c_corner = 0;
+#define ROOT(r, k) rootp[((r) * 9 + (k)) * WG]
+#define BOXLO(r, k) rootp[((r) * 9 + 3 + (k)) * WG]
+#define BOXHI(r, k) rootp[((r) * 9 + 6 + (k)) * WG]
+    unsigned c_fetch = 0, c_retired = 0, c_valid = 0, c_redo = 0, c_corner = 0;
 
     for (;;) {
         // ---- transitions: next init of the lane's point, or the wave's next point ----
@@ -678,9 +702,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
             else {
                 have = false;
                 if (PACK) {
-                    cnt[p_begin + pt] = n_done;
-                    meta[p_begin + pt] = inits | (last_ovf >= 0 ? 0x80000000u : 0u);
-                    if (last_ovf >= 0) ovf_head[p_begin + pt] = last_ovf;
+                    if (n_done < 0) {                                    // exact redo finished: hand the 13 results over
+                        cnt[p_begin + pt] = 0;
+                        meta[p_begin + pt] = 0u;
+                        if (flag_rec >= 0) { flag.point[flag_rec] = (int32_t)(p_begin + pt); flag.valid[flag_rec] = inits; }
+                    } else {
+                        cnt[p_begin + pt] = n_done;
+                        meta[p_begin + pt] = inits;
+                    }
                 }
             }
         }
@@ -703,7 +732,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
                     n_roots = 0;
                     n_done = 0;
                     inits = 0;
-                    last_ovf = -1;
+                    flag_rec = -1;
                     const int64_t src = order ? (int64_t)order[p_begin + c] : p_begin + c;
                     xt[0] = xd_tgt[src * 3 + 0];
                     xt[1] = xd_tgt[src * 3 + 1];
@@ -722,15 +751,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
         }
         const int64_t index = (p_begin + pt) * I + init;
         if (it < 0) {
-            // the rigid inverse of a bone that owns the point IS the root (up to rounding): a search that STARTS within eps of a
-            // root a later init has found is retired before its first fetch
+            // the rigid inverse of a bone that owns the point IS the root (up to rounding): a search that STARTS inside the retirement
+            // box of a root a later init has found is retired before its first fetch
             bool at_root = false;
 #pragma unroll
             for (int r = 0; r < SPEC_ROOTS; r++) {
-                if (r < n_roots) {
-                    const float d = fmaxf(fmaxf(fabsf(x_l[0] - ROOT(r, 0)), fabsf(x_l[1] - ROOT(r, 1))), fabsf(x_l[2] - ROOT(r, 2)));
-                    at_root = at_root || d < eps;
-                }
+                if (r < n_roots)
+                    at_root = at_root || (x_l[0] >= BOXLO(r, 0) && x_l[0] < BOXHI(r, 0) && x_l[1] >= BOXLO(r, 1) && x_l[1] < BOXHI(r, 1) &&
+                                          x_l[2] >= BOXLO(r, 2) && x_l[2] < BOXHI(r, 2));
             }
             if (at_root) { if (!PACK) is_valid[index] = 0; if (COUNT) c_retired++; next = true; }
         }
@@ -764,23 +792,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
                 const bool ok = ix >= -1 && ix <= 1 && iy >= -1 && iy <= 1 && iz >= -1 && iz <= 1;
                 if (!PACK) is_valid[index] = ok ? 1 : 0;
                 if (ok) {
-                    if (PACK) {
-                        if (n_done < slots) {
-                            const int64_t slot = (p_begin + pt) * SPEC_ROOTS + n_done;
-                            x[slot * 3 + 0] = x_l[0]; x[slot * 3 + 1] = x_l[1]; x[slot * 3 + 2] = x_l[2];
-                            inits |= (unsigned)init << (8 * n_done);
-                            n_done++;
-                        } else {                                            // a 4th, 5th ... candidate of this point: overflow record
-                            const int k = atomicAdd(ovf_count, 1);
-                            if (k < ovf_cap) {
-                                ovf_rec[3 * k + 0] = (int32_t)(p_begin + pt); ovf_rec[3 * k + 1] = init; ovf_rec[3 * k + 2] = last_ovf;
-                                ovf_x[3 * k + 0] = x_l[0]; ovf_x[3 * k + 1] = x_l[1]; ovf_x[3 * k + 2] = x_l[2];
-                                last_ovf = k;
-                            }
-                        }
-                    } else {
-                        x[index * 3 + 0] = x_l[0]; x[index * 3 + 1] = x_l[1]; x[index * 3 + 2] = x_l[2];
-                    }
+                    if (COUNT) c_valid++;
+                    if (!PACK) { x[index * 3 + 0] = x_l[0]; x[index * 3 + 1] = x_l[1]; x[index * 3 + 2] = x_l[2]; }
                     if (J_inv) {
                         float* Jo = J_inv + index * 9;
 #pragma unroll
@@ -791,14 +804,78 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
                         Fo[0] = Jl[0]; Fo[1] = Jl[1]; Fo[2] = Jl[2]; Fo[3] = Jl[4]; Fo[4] = Jl[5]; Fo[5] = Jl[6];
                         Fo[6] = Jl[8]; Fo[7] = Jl[9]; Fo[8] = Jl[10];
                     }
-                    // a root of this point: searches of EARLIER inits that come within eps of it are duplicates-to-be
-                    if (COUNT) c_valid++;
-                    if (n_roots < slots) {
+                    if (n_done < 0) {
+                        // exact redo of a flagged point: every result goes to the point's record (PACK), nothing is recorded as a root
+                        if (PACK) {
+                            inits |= 1u << init;
+                            if (flag_rec >= 0) {
+                                float* fx = flag.x + ((int64_t)flag_rec * 16 + init) * 3;
+                                fx[0] = x_l[0]; fx[1] = x_l[1]; fx[2] = x_l[2];
+                            }
+                        }
+                    } else {
+                        // K9 against the recorded roots (filter.cu:38-45: squared L2 distance below 1e-4^2 drops the earlier init)
+                        float dmin = 1e30f;
 #pragma unroll
-                        for (int r = 0; r < SPEC_ROOTS; r++)
-                            if (r == n_roots) { ROOT(r, 0) = x_l[0]; ROOT(r, 1) = x_l[1]; ROOT(r, 2) = x_l[2]; }
-                        n_roots++;
-                    } else if (COUNT) c_unrec++;
+                        for (int r = 0; r < SPEC_ROOTS; r++) {
+                            if (r < n_roots) {
+                                const float d0 = x_l[0] - ROOT(r, 0), d1 = x_l[1] - ROOT(r, 1), d2 = x_l[2] - ROOT(r, 2);
+                                dmin = fminf(dmin, d0 * d0 + d1 * d1 + d2 * d2);
+                            }
+                        }
+                        const bool dup = (double)dmin < 0.0001 * 0.0001;
+                        if (!dup && ((double)dmin < 0.0002 * 0.0002 || n_roots >= slots)) {
+                            // neither surely a duplicate nor surely distinct from every later valid root (or no slot left): the lane
+                            // searches this point again with the filter off and lets rows_flagged_kernel apply K9 to all 13 results
+                            if (COUNT) c_redo++;
+                            n_done = -1;
+                            inits = 0;
+                            n_roots = 0;
+                            if (PACK) {
+                                const int k = atomicAdd(flag.count, 1);
+                                flag_rec = k < flag.cap ? k : -1;            // a full list is reported through the count
+                            }
+                            init = I - 1;
+                            it = -1;
+                            continue;
+                        }
+                        if (!dup) {
+                            if (PACK) {
+                                const int64_t slot = (p_begin + pt) * SPEC_ROOTS + n_done;
+                                x[slot * 3 + 0] = x_l[0]; x[slot * 3 + 1] = x_l[1]; x[slot * 3 + 2] = x_l[2];
+                                inits |= (unsigned)init << (8 * n_done);
+                                n_done++;
+                            }
+                            // record the root with its retirement box: the eps-box cut to the root's voxel cell; empty unless tight.
+                            // (explicit fma chains / precomputed cell pitch: ~35 instead of ~170 VALU instructions in a block that some
+                            //  lane of the wave enters on almost every iteration; the box only has to lie INSIDE the cell, which the margin
+                            //  guarantees against the few ulps these roundings can move it)
+                            const float jn2 = fmaf(Ji[8], Ji[8], fmaf(Ji[7], Ji[7], fmaf(Ji[6], Ji[6], fmaf(Ji[5], Ji[5], fmaf(Ji[4], Ji[4],
+                                              fmaf(Ji[3], Ji[3], fmaf(Ji[2], Ji[2], fmaf(Ji[1], Ji[1], Ji[0] * Ji[0]))))))));
+                            const bool tight = jn2 <= SPEC_TAU * SPEC_TAU;
+                            const float gc[3] = {ix, iy, iz};
+                            const int dim[3] = {W, H, D};
+                            float lo[3], hi[3];
+#pragma unroll
+                            for (int a = 0; a < 3; a++) {
+                                // cell [f, f + 1) of the interpolation coordinate ((g + 1) / 2) (dim - 1) (the fetch's own expression),
+                                // mapped back to canonical space: x = f cell_w + cell_o
+                                const float f = floorf(((gc[a] + 1.f) / 2) * (dim[a] - 1));
+                                const float c_lo = fmaf(f, cell_w[a], cell_o[a]), c_hi = c_lo + cell_w[a];
+                                const float a_lo = fminf(c_lo, c_hi) + SPEC_CELL_MARGIN, a_hi = fmaxf(c_lo, c_hi) - SPEC_CELL_MARGIN;
+                                lo[a] = tight ? fmaxf(a_lo, x_l[a] - eps) : INFINITY;
+                                hi[a] = fminf(a_hi, x_l[a] + eps);
+                            }
+#pragma unroll
+                            for (int r = 0; r < SPEC_ROOTS; r++)
+                                if (r == n_roots) {
+                                    ROOT(r, 0) = x_l[0]; ROOT(r, 1) = x_l[1]; ROOT(r, 2) = x_l[2];
+                                    BOXLO(r, 0) = lo[0]; BOXLO(r, 1) = lo[1]; BOXLO(r, 2) = lo[2];
+                                    BOXHI(r, 0) = hi[0]; BOXHI(r, 1) = hi[1]; BOXHI(r, 2) = hi[2];
+                                }
+                            n_roots++;
+                        }
+                    }
                 }
                 next = true;
                 continue;
@@ -817,57 +894,88 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
         u[1] = -Ji[3] * gx[0] + -Ji[4] * gx[1] + -Ji[5] * gx[2];
         u[2] = -Ji[6] * gx[0] + -Ji[7] * gx[1] + -Ji[8] * gx[2];
         x_l[0] += u[0]; x_l[1] += u[1]; x_l[2] += u[2];
-        // ---- speculative early filter: the next fetch position against the roots later inits converged to ----
+        // ---- early filter: the next fetch position against the retirement boxes of the roots later inits converged to ----
         bool near = false;
 #pragma unroll
         for (int r = 0; r < SPEC_ROOTS; r++) {
-            if (r < n_roots) {
-                const float d = fmaxf(fmaxf(fabsf(x_l[0] - ROOT(r, 0)), fabsf(x_l[1] - ROOT(r, 1))), fabsf(x_l[2] - ROOT(r, 2)));
-                near = near || d < eps;
-            }
+            if (r < n_roots)
+                near = near || (x_l[0] >= BOXLO(r, 0) && x_l[0] < BOXHI(r, 0) && x_l[1] >= BOXLO(r, 1) && x_l[1] < BOXHI(r, 1) &&
+                                x_l[2] >= BOXLO(r, 2) && x_l[2] < BOXHI(r, 2));
         }
-        if (near) { if (!PACK) is_valid[index] = 0; if (COUNT) c_retired++; next = true; }
+        if (near) {
+            const float jn2 = fmaf(Ji[8], Ji[8], fmaf(Ji[7], Ji[7], fmaf(Ji[6], Ji[6], fmaf(Ji[5], Ji[5], fmaf(Ji[4], Ji[4],
+                              fmaf(Ji[3], Ji[3], fmaf(Ji[2], Ji[2], fmaf(Ji[1], Ji[1], Ji[0] * Ji[0]))))))));
+            if (jn2 <= SPEC_TAU_SELF * SPEC_TAU_SELF) { if (!PACK) is_valid[index] = 0; if (COUNT) c_retired++; next = true; }
+        }
     }
     if (COUNT) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             c_fetch += __shfl_down(c_fetch, off, 64); c_retired += __shfl_down(c_retired, off, 64);
-            c_valid += __shfl_down(c_valid, off, 64); c_unrec += __shfl_down(c_unrec, off, 64);
+            c_valid += __shfl_down(c_valid, off, 64); c_redo += __shfl_down(c_redo, off, 64);
             c_corner += __shfl_down(c_corner, off, 64);
         }
         if (lane == 0) {
             atomicAdd(&counters[0], (unsigned long long)c_fetch);
             atomicAdd(&counters[1], (unsigned long long)c_retired);
             atomicAdd(&counters[2], (unsigned long long)c_valid);
-            atomicAdd(&counters[3], (unsigned long long)c_unrec);
+            atomicAdd(&counters[3], (unsigned long long)c_redo);
             atomicAdd(&counters[4], (unsigned long long)c_corner);
         }
     }
 }
 
 #undef ROOT
+#undef BOXLO
+#undef BOXHI
 #undef n_done
 #undef inits
-#undef last_ovf
+#undef flag_rec
 
 // ---- candidate rows of the PACK search -> packed candidate list ------------------------------------------------------------
-// K9 among the overflow records of a point: record k is dropped when a record of a LATER init of the same point (= one further
-// down its `prev` chain: searches complete in descending init order) lies within 1e-4; kept records count towards cnt[point]
-__global__ __launch_bounds__(THREADS) void rows_extras_kernel(const int32_t* __restrict__ ovf_count, int ovf_cap, const int32_t* __restrict__ ovf_rec,
-                                                               const float* __restrict__ ovf_x, uint8_t* __restrict__ ovf_keep,
-                                                               int32_t* __restrict__ cnt)
+// the points the search redid exactly: K9 as filter.cu:10-54 writes it, on all 13 results (init i is dropped when a LATER valid
+// init lies within 1e-4); the survivors with the three highest inits fill the point's row, the others become overflow records
+// (chained per point, lowest init at the head, keep = 1), cnt = their number
+__global__ __launch_bounds__(THREADS) void rows_flagged_kernel(SpecFlag flag, int I, float* __restrict__ x_rows, int32_t* __restrict__ cnt,
+                                                               uint32_t* __restrict__ meta, int32_t* __restrict__ ovf_count, int ovf_cap,
+                                                               int32_t* __restrict__ ovf_head, int32_t* __restrict__ ovf_rec,
+                                                               float* __restrict__ ovf_x, uint8_t* __restrict__ ovf_keep)
 {
-    const int n = min(*ovf_count, ovf_cap);
+    const int n = min(*flag.count, flag.cap);
     for (int k = blockIdx.x * THREADS + threadIdx.x; k < n; k += gridDim.x * THREADS) {
-        const float a0 = ovf_x[3 * k], a1 = ovf_x[3 * k + 1], a2 = ovf_x[3 * k + 2];
-        bool keep = true;
-        for (int j = ovf_rec[3 * k + 2]; j >= 0 && keep; j = ovf_rec[3 * j + 2]) {
-            const float d0 = a0 - ovf_x[3 * j], d1 = a1 - ovf_x[3 * j + 1], d2 = a2 - ovf_x[3 * j + 2];
-            const float dist = d0 * d0 + d1 * d1 + d2 * d2;
-            if ((double)dist < 0.0001 * 0.0001) keep = false;
+        const int64_t p = flag.point[k];
+        const uint32_t valid = flag.valid[k];
+        const float* fx = flag.x + (int64_t)k * 16 * 3;
+        int kept = 0, last = -1;
+        uint32_t m = 0;
+        for (int i = I - 1; i >= 0; i--) {
+            if (!((valid >> i) & 1u)) continue;
+            bool keep = true;
+            for (int j = i + 1; j < I && keep; j++) {
+                if (!((valid >> j) & 1u)) continue;
+                const float d0 = fx[3 * i] - fx[3 * j], d1 = fx[3 * i + 1] - fx[3 * j + 1], d2 = fx[3 * i + 2] - fx[3 * j + 2];
+                const float dist = d0 * d0 + d1 * d1 + d2 * d2;
+                if ((double)dist < 0.0001 * 0.0001) keep = false;
+            }
+            if (!keep) continue;
+            if (kept < SPEC_ROOTS) {
+                float* row = x_rows + (p * SPEC_ROOTS + kept) * 3;
+                row[0] = fx[3 * i]; row[1] = fx[3 * i + 1]; row[2] = fx[3 * i + 2];
+                m |= (uint32_t)i << (8 * kept);
+            } else {
+                const int q = atomicAdd(ovf_count, 1);
+                if (q < ovf_cap) {
+                    ovf_rec[3 * q + 0] = (int32_t)p; ovf_rec[3 * q + 1] = i; ovf_rec[3 * q + 2] = last;
+                    ovf_x[3 * q + 0] = fx[3 * i]; ovf_x[3 * q + 1] = fx[3 * i + 1]; ovf_x[3 * q + 2] = fx[3 * i + 2];
+                    ovf_keep[q] = 1;
+                    last = q;
+                }
+            }
+            kept++;
         }
-        ovf_keep[k] = keep ? 1 : 0;
-        if (keep) atomicAdd(&cnt[ovf_rec[3 * k]], 1);
+        cnt[p] = kept;
+        meta[p] = m | (last >= 0 ? 0x80000000u : 0u);
+        if (last >= 0) ovf_head[p] = last;
     }
 }
 
@@ -1183,12 +1291,11 @@ IA_EXPORT int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt, cons
 static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
                        const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold, float dvg_threshold, float eps,
                        float* x, float* J_inv, uint8_t* is_valid, float* fwd_J, uint64_t* counters, int32_t* cnt, uint32_t* meta,
-                       int32_t* ovf_count, int32_t* ovf_head, int32_t* ovf_rec, float* ovf_x, int ovf_cap, const int32_t* order,
-                       ia_stream_t stream, const char* what)
+                       SpecFlag flag, const int32_t* order, ia_stream_t stream, const char* what)
 {
     if (N == 0) return IA_OK;
-    IA_REQUIRE(I >= 1 && I <= 16, "speculative search: 1 <= I <= 16 inits");
-    IA_REQUIRE(eps >= 0.0f, "speculative search: eps must be >= 0");
+    IA_REQUIRE(I >= 1 && I <= 16, "early-filter search: 1 <= I <= 16 inits");
+    IA_REQUIRE(eps >= 0.0f, "early-filter search: eps must be >= 0");
     IA_REQUIRE((int64_t)D * H * W < ((int64_t)1 << 26), "voxel grid too large for 32-bit byte offsets (48 B per voxel)");
     int pts = 192;                                                       // points per wave; a workgroup's four waves share a chunk of 4 x pts
     // small batches (the reference trains on 4096 rays per GPU: ~0.2 M points per search): shorter chunks, so that the launch still has
@@ -1199,12 +1306,12 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
     const int grid = (int)((N + pts_wg - 1) / pts_wg);
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* c = reinterpret_cast<unsigned long long*>(counters);
-    int slots = SPEC_ROOTS;                                              // test hook: fewer recorded roots / row slots => the overflow list is used
+    int slots = SPEC_ROOTS;                                              // test hook: fewer recorded roots / row slots => more points take the exact redo
     if (const char* e = getenv("IA_SPEC_TEST_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= SPEC_ROOTS) slots = v; }
 #define IA_SPEC_LAUNCH(COUNT, PACK)                                                                                                    \
     broyden_spec_kernel<COUNT, PACK><<<grid, THREADS, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,         \
                                                                cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J, pts, c, cnt, \
-                                                               meta, ovf_count, ovf_head, ovf_rec, ovf_x, ovf_cap, slots, order)
+                                                               meta, flag, slots, order)
     if (pack) { if (counters) IA_SPEC_LAUNCH(true, true); else IA_SPEC_LAUNCH(false, true); }
     else { if (counters) IA_SPEC_LAUNCH(true, false); else IA_SPEC_LAUNCH(false, false); }
 #undef IA_SPEC_LAUNCH
@@ -1216,19 +1323,22 @@ IA_EXPORT int ia_fuse_broyden_spec(int64_t N, int I, const float* xd_tgt, const 
                                    float dvg_threshold, float eps, float* x, float* J_inv, uint8_t* is_valid, float* fwd_J,
                                    uint64_t* counters, ia_stream_t stream)
 {
+    SpecFlag none = {nullptr, nullptr, nullptr, nullptr, 0};
     return launch_spec(false, N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x, J_inv,
-                       is_valid, fwd_J, counters, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, stream, "ia_fuse_broyden_spec");
+                       is_valid, fwd_J, counters, nullptr, nullptr, none, nullptr, stream, "ia_fuse_broyden_spec");
 }
 
 IA_EXPORT int ia_spec_rows_slots(void) { return SPEC_ROOTS; }
 
 extern "C" int ia_exclusive_scan_i32(const int32_t* in, int32_t* out, int32_t* total, int64_t n, void* tmp, ia_stream_t stream);
 
-// overflow scratch of the rows search: [count (int32) | pad] [rec: cap x 3 int32] [x: cap x 3 float] [keep: cap bytes]
+// scratch of the rows search: [overflow count | flagged count | pad] [rec: cap x 3 int32] [x: cap x 3 float] [keep: cap bytes]
+// [flagged: point (int32) | valid mask (uint32) | x (16 x 3 float)] x SPEC_FLAG_CAP
 static const int SPEC_OVF_CAP = 1 << 18;
-IA_EXPORT size_t ia_spec_rows_overflow_bytes(void) { return 64 + (size_t)SPEC_OVF_CAP * (12 + 12 + 1) + 64; }
+static const size_t SPEC_OVF_BYTES = 64 + (size_t)SPEC_OVF_CAP * (12 + 12 + 1) + 64;
+IA_EXPORT size_t ia_spec_rows_overflow_bytes(void) { return SPEC_OVF_BYTES + (size_t)SPEC_FLAG_CAP * (4 + 4 + 16 * 12) + 64; }
 
-struct OvfLayout { int32_t* count; int32_t* rec; float* x; uint8_t* keep; };
+struct OvfLayout { int32_t* count; int32_t* rec; float* x; uint8_t* keep; SpecFlag flag; };
 static OvfLayout ovf_layout(void* scratch)
 {
     char* b = reinterpret_cast<char*>(scratch);
@@ -1237,7 +1347,20 @@ static OvfLayout ovf_layout(void* scratch)
     L.rec = reinterpret_cast<int32_t*>(b + 64);
     L.x = reinterpret_cast<float*>(b + 64 + (size_t)SPEC_OVF_CAP * 12);
     L.keep = reinterpret_cast<uint8_t*>(b + 64 + (size_t)SPEC_OVF_CAP * 24);
+    char* f = b + ((SPEC_OVF_BYTES + 63) & ~(size_t)63);
+    L.flag.count = reinterpret_cast<int32_t*>(b) + 1;
+    L.flag.point = reinterpret_cast<int32_t*>(f);
+    L.flag.valid = reinterpret_cast<uint32_t*>(f + (size_t)SPEC_FLAG_CAP * 4);
+    L.flag.x = reinterpret_cast<float*>(f + (size_t)SPEC_FLAG_CAP * 8);
+    L.flag.cap = SPEC_FLAG_CAP;
     return L;
+}
+
+// total_and_overflow [1] <- max(flagged points / their capacity, overflow records / their capacity) scaled to the flagged capacity:
+// anything above ia_spec_rows_overflow_capacity() means results were lost and the caller redoes the batch through is_valid + K9
+__global__ void rows_report_kernel(const int32_t* __restrict__ counts, int32_t* __restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = counts[0] > SPEC_OVF_CAP ? SPEC_FLAG_CAP + 1 : counts[1];
 }
 
 IA_EXPORT int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
@@ -1246,31 +1369,28 @@ IA_EXPORT int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, c
                                         uint32_t* meta, int32_t* start, int32_t* ovf_head, void* ovf_scratch, int32_t* total_and_overflow,
                                         void* scan_tmp, uint64_t* counters, const int32_t* order, ia_stream_t stream)
 {
-    IA_REQUIRE(eps >= 1e-4f, "ia_fuse_broyden_spec_rows: eps must be >= 1e-4 (the completed searches are K9's survivors only then)");
     IA_REQUIRE(N * I < ((int64_t)1 << 31), "ia_fuse_broyden_spec_rows: N * I must stay below 2^31");
     hipStream_t s = (hipStream_t)stream;
     OvfLayout o = ovf_layout(ovf_scratch);
-    (void)hipMemsetAsync(o.count, 0, sizeof(int32_t), s);
+    (void)hipMemsetAsync(o.count, 0, 2 * sizeof(int32_t), s);
     if (N == 0) {
         (void)hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(int32_t), s);
         return ia::check_launch("ia_fuse_broyden_spec_rows");
     }
     int r = launch_spec(true, N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x_rows,
-                        J_inv, nullptr, fwd_J, counters, cnt, meta, o.count, ovf_head, o.rec, o.x, SPEC_OVF_CAP, order, stream,
-                        "ia_fuse_broyden_spec_rows");
+                        J_inv, nullptr, fwd_J, counters, cnt, meta, o.flag, order, stream, "ia_fuse_broyden_spec_rows");
     if (r != IA_OK) return r;
-    rows_extras_kernel<<<64, THREADS, 0, s>>>(o.count, SPEC_OVF_CAP, o.rec, o.x, o.keep, cnt);
-    r = ia::check_launch("ia_fuse_broyden_spec_rows(extras)");
+    rows_flagged_kernel<<<64, THREADS, 0, s>>>(o.flag, I, x_rows, cnt, meta, o.count, SPEC_OVF_CAP, ovf_head, o.rec, o.x, o.keep);
+    r = ia::check_launch("ia_fuse_broyden_spec_rows(flagged)");
     if (r != IA_OK) return r;
     r = ia_exclusive_scan_i32(cnt, start, total_and_overflow, N, scan_tmp, stream);
     if (r != IA_OK) return r;
-    // [1] = number of overflow records; the caller compares it with ia_spec_rows_overflow_capacity()
-    if (hipMemcpyAsync(total_and_overflow + 1, o.count, sizeof(int32_t), hipMemcpyDeviceToDevice, s) != hipSuccess)
-        return ia::check_launch("ia_fuse_broyden_spec_rows(copy)");
-    return IA_OK;
+    // [1] = number of points redone exactly; the caller compares it with ia_spec_rows_overflow_capacity()
+    rows_report_kernel<<<1, 64, 0, s>>>(o.count, total_and_overflow + 1);
+    return ia::check_launch("ia_fuse_broyden_spec_rows(report)");
 }
 
-IA_EXPORT int ia_spec_rows_overflow_capacity(void) { return SPEC_OVF_CAP; }
+IA_EXPORT int ia_spec_rows_overflow_capacity(void) { return SPEC_FLAG_CAP; }
 
 IA_EXPORT int ia_deform_rows_pack(int64_t N, int I, const float* x_rows, const int32_t* cnt, const uint32_t* meta, const int32_t* start,
                                   const int32_t* ovf_head, const void* ovf_scratch, float* cand_x, int32_t* cand_src,

@@ -23,11 +23,14 @@ from . import fast_snarf
 
 class SNARFDeformer:
     INIT_BONES = [0, 1, 2, 4, 5, 10, 11, 12, 15, 16, 17, 18, 19]    # deformer_torch.py:27
-    # Speculative early filter of the search (fast_snarf.fuse_broyden_spec[_rows]): a search is retired once it comes
-    # within SPEC_EPS metres of a root that a later init of the same point has found (K9 would drop it).  On for EVERY batch size:
-    # what a point gets must not depend on how many other points share its launch (ray-batch sharding invariance, multi-GPU =
-    # single GPU).  IA_BROYDEN_SPEC_EPS=0 (or deformer.spec_eps = 0) = the reference's exact search everywhere; the kernel-level
-    # parity tests (K8 / K9 golden vectors) call the exact entry points directly.
+    # K9-consistent early filter of the search (fast_snarf.fuse_broyden_spec[_rows], csrc/snarf.hip): a search is retired
+    # once it comes within SPEC_EPS metres of a TIGHT root that a later init of the same point has found, inside that root's voxel
+    # cell (K9 would drop it wherever exactly it ends); a point whose completed roots leave K9's decision open is searched again with
+    # the filter off.  The candidate set equals search-to-the-end + K9 on all but ~1e-7 of the points (1 of 16.4 M on the headline
+    # frame, profiles/r04_spec_search_probe.json), candidates bit-identical.  On for EVERY batch size: what a point gets must not
+    # depend on how many other points share its launch (ray-batch sharding invariance, multi-GPU = single GPU).
+    # IA_BROYDEN_SPEC_EPS=0 (or deformer.spec_eps = 0) = the reference's search-to-the-end everywhere; the kernel-level parity tests
+    # (K8 / K9 golden vectors) call those entry points directly.
     SPEC_EPS = float(os.environ.get("IA_BROYDEN_SPEC_EPS", "1e-3"))
     SPEC_MIN_POINTS = int(os.environ.get("IA_BROYDEN_SPEC_MIN_POINTS", "1"))
 
@@ -39,7 +42,7 @@ class SNARFDeformer:
         self.device = self.lbs_voxel_final.device
         self.init_bones = torch.tensor(self.INIT_BONES, dtype=torch.int32, device=self.device)
         self.spec_eps = self.SPEC_EPS
-        self.spec_counters = None            # optional int64 [5] device tensor: accumulated by the speculative search (bench.py)
+        self.spec_counters = None            # optional int64 [5] device tensor: accumulated by the early-filter search (bench.py)
         self.tfs = None
         self.voxel_J_cl = None
         self.voxel_d = None
@@ -156,10 +159,10 @@ class SNARFDeformer:
     def _candidates(self, pts: Tensor, with_src: bool, want_fwd: bool = False, want_jinv: bool = False, order: Optional[Tensor] = None,
                     normalize=None):
         """search + candidate bookkeeping for P posed points -> (cand_x [Q,3], cand_src [Q] | None, cnt [P], start [P], Q, fwd_J, J_inv).
-        Large batches (speculative search, eps >= 1e-4): the search kernel itself leaves each point's surviving candidates in its
-        3-slot row plus their count and the scan of the counts (fast_snarf.fuse_broyden_spec_rows: 44 B per point instead of 169) --
-        no x [P,13,3], no is_valid, no K9 pass; one segmented copy makes the packed list.  The rare 4th.. candidates of a point go
-        through a small overflow list (K9 among them in the kernel's epilogue).  Otherwise: search() + _pack_candidates().
+        Default (early-filter search): the search kernel itself leaves each point's surviving candidates in its 3-slot row plus their
+        count and the scan of the counts (fast_snarf.fuse_broyden_spec_rows: 44 B per point instead of 169) -- no x [P,13,3], no
+        is_valid, no K9 pass; one segmented copy makes the packed list.  Points the kernel redid with the filter off (~2e-4) get their
+        rows from K9 on all 13 results (rows_flagged_kernel; a 4th.. survivor as an overflow record).  spec_eps = 0: search() + _pack_candidates().
         normalize = (center [3], scale [3]): cand_x comes back as (x - center) / scale + 0.5 (the hash grid's coordinates)."""
         P, I = pts.shape[0], self.init_bones.shape[0]
         dev = self.device
@@ -183,9 +186,9 @@ class SNARFDeformer:
                                           Jinv, cnt, meta, start, ovf_head, self._ovf_scratch, tot, self.offset_kernel, self.scale_kernel,
                                           1e-5, 1e-1, self.spec_eps, fwd_J=fwd, counters=self.spec_counters, order=order)
         Q, n_over = tot.tolist()                                     # the one read-back of the call
-        self.last_overflow_records = n_over
+        self.last_overflow_records = n_over                          # points the kernel searched again with the filter off
         if n_over > self._ovf_cap:
-            # more 4th.. candidates than the overflow list holds (never seen): this batch goes through is_valid + K9 instead
+            # more points to redo than the flagged list holds (never seen): this batch goes through is_valid + K9 instead
             del x_rows, cnt, meta, start, Jinv, fwd
             if order is not None:
                 pts = pts[order.long()].contiguous()

@@ -72,10 +72,12 @@ def fuse_broyden(x: Tensor, xd_tgt: Tensor, voxel: Tensor, voxel_J, tfs: Tensor,
 def fuse_broyden_spec(x: Tensor, xd_tgt: Tensor, voxel_J: ChannelLastVoxelJ, tfs: Tensor, bone_ids: Tensor, J_inv: Tensor,
                       is_valid: Tensor, offset: Tensor, scale: Tensor, cvg_threshold: float, dvg_threshold: float, eps: float,
                       fwd_J: Tensor = None, counters: Tensor = None) -> None:
-    """fuse_broyden with the speculative early filter (ia_fuse_broyden_spec; B = 1, channel-last grid): a search that comes within
-    `eps` of a root found by a LATER init of its point is retired -- K9 (filter.cu:10-54) would drop it.  Everything that is not
-    retired is bit-identical to fuse_broyden.  No counterpart in the reference; used by SNARFDeformer.search for large batches.
-    counters: optional int64 [5] (accumulated): fetches, retired items, completed valid items, unrecorded roots, corner loads."""
+    """fuse_broyden with the K9-consistent early filter (ia_fuse_broyden_spec; B = 1, channel-last grid): a search that comes within
+    `eps` of a TIGHT root found by a LATER init of its point, inside that root's voxel cell, is retired -- K9 (filter.cu:10-54) would
+    drop it wherever exactly it ends; points whose completed roots leave K9's decision open are searched again with the filter off
+    (csrc/snarf.hip).  Everything that is not retired is bit-identical to fuse_broyden, and filter() of the result equals filter()
+    of fuse_broyden's on all but ~1e-7 of the points.  No counterpart in the reference; used by SNARFDeformer.search.
+    counters: optional int64 [5] (accumulated): fetches, retired items, completed valid items, points redone, corner loads."""
     B, N, _ = xd_tgt.shape
     I = bone_ids.shape[0]
     assert B == 1 and isinstance(voxel_J, ChannelLastVoxelJ) and voxel_J.data.shape[0] == 1
@@ -96,11 +98,12 @@ def fuse_broyden_spec_rows(x_rows: Tensor, xd_tgt: Tensor, voxel_J: ChannelLastV
                            cnt: Tensor, meta: Tensor, start: Tensor, ovf_head: Tensor, ovf_scratch: Tensor, total_and_overflow: Tensor,
                            offset: Tensor, scale: Tensor, cvg_threshold: float, dvg_threshold: float, eps: float, fwd_J: Tensor = None,
                            counters: Tensor = None, order: Tensor = None, n_points: int = None) -> None:
-    """fuse_broyden_spec with the candidate bookkeeping in the kernel (ia_fuse_broyden_spec_rows; eps >= 1e-4): no x [N,I,3], no
-    is_valid, no filter pass -- x_rows [N,3,3] receives each point's surviving candidates (highest init first), cnt [N] int32 their
-    number, meta [N] int32 their inits (one byte each; bit 31: the point has overflow records), start [N] the exclusive scan of
-    cnt, ovf_head [N] int32 + ovf_scratch (uint8 [ia_spec_rows_overflow_bytes()]) the rare 4th.. candidates, total_and_overflow [2]
-    int32 = (Q, number of overflow records).  J_inv / fwd_J at [point, init] as fuse_broyden.
+    """fuse_broyden_spec with the candidate bookkeeping in the kernel (ia_fuse_broyden_spec_rows): no x [N,I,3], no is_valid, no
+    filter pass -- x_rows [N,3,3] receives each point's surviving candidates (highest init first), cnt [N] int32 their number,
+    meta [N] int32 their inits (one byte each; bit 31: the point has overflow records), start [N] the exclusive scan of cnt,
+    ovf_head [N] int32 + ovf_scratch (uint8 [ia_spec_rows_overflow_bytes()]): the records of the points the kernel redid with the
+    filter off and their 4th.. survivors, total_and_overflow [2] int32 = (Q, number of points redone; above
+    ia_spec_rows_overflow_capacity() results were lost).  J_inv / fwd_J at [point, init] as fuse_broyden.
     order (int32 [N], optional): point p of the launch is xd_tgt[0, order[p]] -- the caller's points are searched in another
     order (spatially sorted) than they are stored, without a gathered copy."""
     B, N, _ = xd_tgt.shape

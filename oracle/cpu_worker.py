@@ -1,9 +1,11 @@
 """CPU ORACLE (test infrastructure): one worker process of bench.py's multi-core `cpu_baseline` leg.
 
-    python -m oracle.cpu_worker <scene.npz> <rays.npy> <start> <end> <spp | 0>
+    python -m oracle.cpu_worker <scene.npz> <rays.npy> <start> <end> <spp | 0> [<out.npz>]
 
 loads the scene bundle written by bench.py, runs oracle/render_ref.py on rays[start:end] (relight_step when spp > 0, else
-render_step) and prints the seconds the computation took (interpreter start-up and loading excluded)."""
+render_step) and prints the seconds the computation took (interpreter start-up and loading excluded).  With <out.npz> the
+rendered maps and per-ray sample counts are kept: bench.py renders the same rays with the same random numbers on the GPU and
+reports the differences (`parity_on_bench_frame`)."""
 import sys
 import time
 
@@ -45,10 +47,16 @@ def main():
     r = np.load(rays)[a:b]
     t0 = time.perf_counter()
     if spp > 0:
-        R.relight_step(sc, r, spp=spp, seed=a, global_illumination=True)
+        out = R.relight_step(sc, r, spp=spp, seed=a, global_illumination=True)
     else:
-        R.render_step(sc, r)
-    print(f"{time.perf_counter() - t0:.4f}")
+        out = R.render_step(sc, r)
+    dt = time.perf_counter() - t0
+    if len(sys.argv) > 6:
+        keep = {k: np.asarray(out[k]) for k in ("comp_rgb", "comp_normal", "opacity", "depth", "albedo", "roughness", "metallic",
+                                                "comp_rgb_phys", "packed_info", "resampled_packed_info") if k in out}
+        keep["n_fg"] = np.asarray(out["stats"].get("n_fg", 0))
+        np.savez(sys.argv[6], **keep)
+    print(f"{dt:.4f}")
 
 
 if __name__ == "__main__":

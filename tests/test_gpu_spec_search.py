@@ -1,12 +1,15 @@
-"""GPU (MI355X): the speculative early filter of the Broyden search (ia_fuse_broyden_spec, csrc/snarf.hip), the product path
-of the big no-grad query batches.  The reference runs all 13 searches of a point to their end (fuse_cuda_kernel_fast.cu:252-452)
-and filter.cu:10-54 keeps the LAST member of every cluster of coinciding roots; the speculative search walks a point's inits
-in reverse and retires a search once it comes within eps of a root a later init has found.
+"""GPU (MI355X): the K9-consistent early filter of the Broyden search (ia_fuse_broyden_spec[_rows], csrc/snarf.hip), the product
+path of every query batch.  The reference runs all 13 searches of a point to their end (fuse_cuda_kernel_fast.cu:252-452) and
+filter.cu:10-54 drops every root that has a later init's root within 1e-4; the product search walks a point's inits in reverse and
+retires a search once it enters the retirement box of a TIGHT root a later init has found (same voxel cell, within eps, own
+J_inv estimate sane: K9 would drop it wherever exactly it ends), and redoes a point with the filter off when a completed root is
+neither surely a duplicate nor surely distinct (snarf.hip).
 
-Bars: eps = 0 is the exact search, bit for bit; with eps > 0 every COMPLETED item is the exact search's item bit for bit (so
-every surviving candidate is), at least a quarter of the fetches are gone, and what speculation changes downstream stays under
-the stated rates on the secondary-march point distribution (the same quantities tools/spec_search_probe.py reports for the
-headline distribution in profiles/r03_spec_search_probe.json)."""
+Bars: eps = 0 is the exact search, bit for bit; with the default eps every COMPLETED item is the exact search's item bit for
+bit, at least a quarter of the fetches are gone, the candidate SET after K9 equals the exact search's on all but <= 2 points of
+the batch, no distinct root is lost, and the min-over-candidates SDF is bit-identical wherever the sets agree (the same
+quantities tools/spec_search_probe.py reports for the headline distribution in profiles/r04_spec_search_probe.json: 1 point of
+16.4 M differs)."""
 import numpy as np
 import pytest
 import torch
@@ -41,7 +44,9 @@ def test_eps_zero_is_the_exact_search(march):
     x2, v2 = SP.search(rs.deformer, pts, 0.0)                       # the variant without counters (the one the product path runs)
     assert torch.equal(v0, v2) and torch.equal(torch.where(v0[..., None], x0, torch.zeros_like(x0)), torch.where(v2[..., None], x2, torch.zeros_like(x2)))
     c = cnt.cpu().tolist()
-    assert c[1] == 0 and c[2] == int(v0.sum())                      # nothing retired; completed valid items = valid items
+    # nothing retired; completed valid items = valid items, plus the 13 searches again of every point that was redone (a completed
+    # root between 1e-4 and 2e-4 of a recorded one sends its point through the exact redo whatever eps is)
+    assert c[1] == 0 and int(v0.sum()) <= c[2] <= int(v0.sum()) + 13 * c[3] and c[3] < 1e-3 * pts.shape[0]
 
 
 def test_outputs_with_jinv_and_fwd_J_are_the_exact_ones(march):
@@ -79,10 +84,11 @@ def test_speculation_removes_fetches_and_changes_almost_nothing(march, eps):
     assert r["completed_items_bit_identical"]
     exact_fetches = SP.compare(rs.deformer, rs.geometry, pts, 0.0, ref)["fetches"]
     assert r["fetches"] <= 0.75 * exact_fetches, (r["fetches"], exact_fetches)
-    assert abs(r["survivors_per_point"] - float(ref[2].float().sum() / pts.shape[0])) < 2e-3
-    assert r["set_mismatch"] < 1e-3            # mostly duplicates the exact search leaves 1e-4 .. eps apart (K9 keeps both there)
-    assert r["lost_root"] < 5e-5               # a DISTINCT root (> 1 mm from every speculative candidate) is lost
-    assert r["sdf_abs_gt_1e3"] < 5e-5 and r["sdf_abs_gt_1e4"] < 5e-4
+    P = pts.shape[0]
+    assert r["set_mismatch"] * P <= 2.5        # the candidate set after K9 is the exact search's (headline distribution: 1 point of 16.4 M)
+    assert r["lost_root"] == 0.0               # no DISTINCT root (> 1 mm from every kept candidate) is lost
+    assert r["sdf_bits_differ"] * P <= 2.5 and r["sdf_abs_gt_1e3"] == 0.0
+    assert 0 < r["redone_points"] < 1e-3 * P   # points the kernel searched again with the filter off
 
 
 def test_product_path_is_independent_of_the_batch(march):
@@ -96,7 +102,7 @@ def test_product_path_is_independent_of_the_batch(march):
     try:
         s1 = dfm.deform_sdf(pts, rs.geometry)
         assert int(cnt[0]) > 0 and int(cnt[1]) > 0
-        assert float((s1 != s0).float().mean()) < 2e-3
+        assert int((s1 != s0).sum()) <= 2
         for a, b in ((0, 50_000), (123_457, 131_000), (400_000, 400_001)):
             assert torch.equal(dfm.deform_sdf(pts[a:b].contiguous(), rs.geometry), s1[a:b])
     finally:
@@ -147,42 +153,38 @@ def test_candidates_leave_the_packing_kernel_in_hash_grid_coordinates(march):
     assert torch.equal(geo.sdf_only(b[0], normalized=True), geo.sdf_only(a[0]))
 
 
-def test_candidates_beyond_the_row_slots_go_through_the_overflow_list(march, monkeypatch):
-    """a point's 4th, 5th ... completed search (tested against the first three roots only) becomes an overflow record; K9
-    (filter.cu:10-54) runs among a point's records and the kept ones are emitted in front of the row's candidates.  Points with
-    four distinct roots are ~1e-8 of the march distribution, so the kernel's test hook IA_SPEC_TEST_SLOTS=1 is used: ONE recorded
-    root / row slot -- every further root of a point, and every duplicate of it that now runs to completion, goes through the
-    overflow list.  The result is K9 on the exact search's candidates minus those retired near the first root: compared with
-    search + K9 + pack of the exact search (counts equal on >= 99.9 % of the points, candidates bit-equal where they are)."""
+def test_points_that_run_out_of_row_slots_are_redone_exactly(march, monkeypatch):
+    """a completed root that finds the point's row full (a 4th distinct root: ~1e-8 of the march distribution), or that lies between
+    1e-4 and 2e-4 of a recorded one, sends its point through the exact redo: all 13 searches with the filter off, K9 applied to the
+    13 results as filter.cu:10-54 writes it (rows_flagged_kernel), survivors beyond the row's three slots as overflow records.  The
+    kernel's test hook IA_SPEC_TEST_SLOTS=1 leaves ONE slot, so every point with a second root takes that path (tens of thousands
+    here, some with four and more survivors): the packed candidate lists must equal exact search + K9 + pack for EVERY point."""
     SP, rs, pts, _ = march
     dfm = rs.deformer
     sub = pts[:1_500_000].contiguous()
     old = dfm.spec_eps
     try:
         dfm.spec_eps = 0.0
+        type(dfm).SPEC_ROWS = False
         want = dfm._candidates(sub, with_src=True)                   # exact search + K9 + pack
     finally:
         dfm.spec_eps = old
+        type(dfm).SPEC_ROWS = True
     monkeypatch.setenv("IA_SPEC_TEST_SLOTS", "1")
     got = dfm._candidates(sub, with_src=True)
     monkeypatch.delenv("IA_SPEC_TEST_SLOTS")
-    n_rec = dfm.last_overflow_records
-    assert n_rec > 10_000, n_rec
-    cg, cw = got[2], want[2]
-    same = cg == cw
-    assert float(same.float().mean()) >= 0.999
-    assert int(cg.max()) >= 3
-    assert int(cg.sum()) < int((cg > 0).sum()) + n_rec                # K9 dropped duplicate records
-    # candidates of the points whose counts agree: same positions and sources, in (point, ascending init) order
-    sel = torch.nonzero(same & (cg > 0))[:, 0]
-    for j in range(int(cg.max())):
-        m = sel[cg[sel] > j]
-        ig, iw = got[3][m].long() + j, want[3][m].long() + j
-        assert torch.equal(got[0][ig], want[0][iw]) and torch.equal(got[1][ig], want[1][iw]), j
+    assert dfm.last_overflow_records > 10_000, dfm.last_overflow_records
+    assert int(got[2].max()) >= 4                                     # some point has more survivors than the row holds
+    diff = int((got[2] != want[2]).sum())
+    assert diff <= 2, diff                                            # counts per point (the filter itself may differ on ~1e-7 of the points)
+    if diff == 0:
+        assert got[4] == want[4]
+        for k in (0, 1, 3):                                           # cand_x, cand_src, start
+            assert torch.equal(got[k], want[k]), k
 
 
 def test_a_full_overflow_list_falls_back_to_k9(march):
-    """more overflow records than the list holds (never seen; forced here): the batch is redone through is_valid + K9."""
+    """more points to redo than the flagged list holds (never seen; forced here): the batch is redone through is_valid + K9."""
     from intrinsicavatar_amd import fast_snarf
     SP, rs, pts, _ = march
     dfm = rs.deformer

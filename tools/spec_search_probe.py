@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
-"""Speculative early filter of the Broyden search (ia_fuse_broyden_spec) on the point distribution of the headline step's
-secondary march, in the spatial order the product path uses: per eps -- time, fetches issued (counters of the kernel), and how
-often speculation changes anything downstream:
+"""K9-consistent early filter of the Broyden search (ia_fuse_broyden_spec; snarf.hip) on the point distribution of the headline
+step's secondary march (IA_POSE, default the bench's male-3-casual:0), in the spatial order the product path uses: per eps -- time,
+fetches issued (counters of the kernel), points redone with the filter off, and how often the filter changes anything downstream:
 
   set_mismatch      points whose post-K9 candidate set (filter.cu:10-54) differs from the exact search's
   sdf_bits_differ   points whose min-over-candidates SDF differs in any bit
   sdf_abs_gt_1e-4   ... by more than 1e-4 (canonical metres) / 1e-3
   lost_root         points where the exact search keeps a candidate with no speculative candidate within 1 mm
 
-Prints JSON (profiles/r03_spec_search_probe.json)."""
+Prints JSON (profiles/r04_spec_search_probe.json)."""
 import json, os, sys
 import numpy as np
 import torch
@@ -88,7 +88,7 @@ def compare(dfm, geo, pts, eps, ref):
         dmin = (xs0[:, i:i + 1, :] - xs1).abs().amax(-1).amin(-1)
         lost |= k0[0, :, i] & (dmin > 1e-3)
     c = cnt.cpu().tolist()
-    return dict(eps=eps, fetches=c[0], retired_items=c[1], completed_valid=c[2], unrecorded_roots=c[3], corner_loads=c[4],
+    return dict(eps=eps, fetches=c[0], retired_items=c[1], completed_valid=c[2], redone_points=c[3], corner_loads=c[4],
                 fetches_per_point=c[0] / P, completed_items_bit_identical=bool(same_x),
                 set_mismatch=float(set_mismatch.float().mean()), sdf_bits_differ=float((s1 != s0).float().mean()),
                 sdf_abs_gt_1e4=float((dsdf > 1e-4).float().mean()), sdf_abs_gt_1e3=float((dsdf > 1e-3).float().mean()),
@@ -98,7 +98,8 @@ def compare(dfm, geo, pts, eps, ref):
 
 def main():
     n_sec = int(os.environ.get("IA_NSEC", str(1 << 21)))
-    rs, rays, _ = S.build_frame(dev, 540, 540, pose_seed=0, beta=0.01)
+    pose = os.environ.get("IA_POSE", "male-3-casual:0")
+    rs, rays, _ = S.build_frame(dev, 540, 540, pose_seed=0, beta=0.01, pose=(None if pose == "synthetic:0" else pose))
     pts = march_points(rs, rays, n_sec)
     dfm, geo = rs.deformer, rs.geometry
     P = pts.shape[0]
@@ -115,9 +116,9 @@ def main():
                                      L.ptr(dfm.tfs), L.ptr(dfm.init_bones), L.ptr(dfm.offset_kernel), L.ptr(dfm.scale_kernel),
                                      L.f32(1e-5), L.f32(1e-1), L.ptr(cstat), L.stream()), "ia_broyden_stats")
     cs = cstat.cpu().tolist()
-    res = dict(points=P, exact=dict(ms=timed(lambda: search(dfm, pts, None)), fetches=cs[0], corner_loads=cs[1], fetches_per_point=cs[0] / P,
+    res = dict(pose=pose, points=P, exact=dict(ms=timed(lambda: search(dfm, pts, None)), fetches=cs[0], corner_loads=cs[1], fetches_per_point=cs[0] / P,
                                     survivors_per_point=float(k0.float().sum() / P)), spec=[])
-    for eps in [float(e) for e in os.environ.get("IA_EPS_LIST", "0,2.5e-4,5e-4,1e-3,2e-3,5e-3").split(",")]:
+    for eps in [float(e) for e in os.environ.get("IA_EPS_LIST", "0,5e-4,1e-3,2e-3").split(",")]:
         r = compare(dfm, geo, pts, eps, (x0, v0, k0, s0))
         r["ms"] = timed(lambda: search(dfm, pts, eps))
         r["Gfetch_per_s"] = r["fetches"] / r["ms"] / 1e6
