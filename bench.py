@@ -53,8 +53,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3     # fp32-in MFMA dense peak
 L1_PEAK_GBPS = 256 * 64 * 2.4    # 256 CUs x 64 B/clk (vector L1 / TCP) x 2.4 GHz = 39.3 TB/s
+L2_PEAK_GBPS = 34500.0           # MI355X_MICROARCH.md: L2 (per XCD 4 MiB, aggregate) ~34.5 TB/s
 VOXEL_J_BYTES = 32 * 128 * 128 * 48
-PROFILE_TAGS = ("r03", "r02")          # newest committed rocprofv3 PMC summary that knows the kernel wins
+PROFILE_TAGS = ("r04", "r03", "r02")          # newest committed rocprofv3 PMC summary that knows the kernel wins
 
 
 def algorithmic_bytes(name, calls, extra=None):
@@ -111,6 +112,18 @@ def pmc_traffic(entry, calls_per_step=None):
         tot = sum(v["hbm_side_bytes_per_launch"] * v["launches"] for v in hits)
         calls = sum(v["launches"] for v in hits) if mode == "alt" else max(v["launches"] for v in hits)
         return int(tot / max(calls, 1)), f"profiles/{tag}_pmc_traffic.json"
+    return None, None
+
+
+def pmc_kernel(substr):
+    """(counters of the first kernel whose name contains `substr` in the newest committed PMC summary, its path) or (None, None)."""
+    for tag in PROFILE_TAGS:
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+        if not os.path.exists(path):
+            continue
+        for k, v in json.load(open(path))["kernels"].items():
+            if substr in k:
+                return v, f"profiles/{tag}_pmc_traffic.json"
     return None, None
 
 
@@ -181,10 +194,19 @@ def main():
             blocking = False
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    if world > 1:
+    # IA_BENCH_FORCE_RCCL=1 (test hook for 1-GPU boxes): a ONE-rank RCCL group and the all-reduce hooks even at N = 1, so that
+    # init_process_group("nccl"), the hook-launched all-reduces on device tensors and finish() run through RCCL on this box
+    force_rccl = world == 1 and os.environ.get("IA_BENCH_FORCE_RCCL") == "1"
+    if world > 1 or force_rccl:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share_gpu:
+        if force_rccl:
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
+        elif share_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev))
@@ -286,7 +308,8 @@ def main():
     # the one exchange step of the path: all-reduce(sum) of the gradients over RCCL/xGMI; the two 50 MB
     # hash-table gradients are launched from autograd hooks as soon as they are complete (overlap with the rest of backward)
     train = headline or args.mode != "fwd"
-    sync = parallel.OverlappedGradientAllReduce(params) if (world > 1 and train) else None
+    sync = parallel.OverlappedGradientAllReduce(params, single_rank_too=force_rccl) if ((world > 1 or force_rccl) and train) else None
+    reduced_bytes = [0]
     # the optimiser step of the iteration is inside the timed region: torch.optim.Adam semantics with the reference's
     # parameter groups and scheduler (configs/config.yaml:110-155), one fused launch; the summed all-reduce becomes DDP's
     # mean through grad_scale = 1/world
@@ -298,7 +321,7 @@ def main():
     def step():
         out = step_headline(sync) if headline else step_config2(sync)
         if sync is not None:
-            sync.finish()
+            reduced_bytes[0] = sync.finish()
         if opt is not None:
             opt.step()
             sched.step()
@@ -432,7 +455,7 @@ def main():
         stats["n_rays"] = n_rays
         per_call = {k: (len(v), sum(c[0] for c in v)) for k, v in detail.items()}
         total_ms = sum(v[1] for v in per_call.values())
-        roofline = l1 = mfma = None
+        roofline = l1 = mfma = hash_gather = None
         breakdown = {}
         if per_call:
             dname, (dcalls, dms) = max(per_call.items(), key=lambda kv: kv[1][1])
@@ -506,6 +529,35 @@ def main():
                     mfma = dict(kernel=hname, bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                                 frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4), points_per_step=hpts // k_instr, ms_per_step=round(hms / k_instr, 3),
                                 useful_flop_per_point=flop_pt, note="fp32 MFMA (v_mfma_f32_32x32x2_f32) dense peak; in-step, live HIP events")
+            # north star: "rocprof HBM GB/s (traversal, hash lookup)".  The XCD-partitioned gather (one table at a time, each XCD's L2 holds
+            # the 4 MB table it gathers from) is priced where it is bound: the L2 -> L1 line traffic of its gathers against the L2 peak,
+            # with what HBM itself sees next to it (live HIP-event time of the entry point; counters from the committed PMC passes)
+            hname = "ia_hashgrid_fwd_xcd"
+            if hname in detail:
+                hms = sum(c_[0] for c_ in detail[hname]) / k_instr
+                hpts = sum(c_[1] for c_ in detail[hname]) // k_instr
+                pk, psrc = pmc_kernel("hash_fwd_xcd_kernel<false>")
+                hash_gather = dict(kernel=hname, points_per_step=hpts, ms_per_step=round(hms, 3), launches_per_call=12,
+                                   gathered_bytes_per_point=1024, survey_8d_bytes_per_point=12 + 1024 + 128,
+                                   gathered_GBps=round(hpts * 1024 / (hms * 1e-3) / 1e9, 1), compulsory_hbm_bytes_per_point=12 + 128,
+                                   compulsory_hbm_GBps=round(hpts * 140 / (hms * 1e-3) / 1e9, 1))
+                if pk:
+                    lpc = sum(1 for _ in detail[hname]) / k_instr * 12          # kernel launches per step (12 per call: 11 hashed levels + the dense set)
+                    hbm = pk["hbm_side_bytes_per_launch"] * lpc
+                    hash_gather.update(counters_source=psrc, l2_hit_rate=pk.get("l2_hit_rate"), l1_hit_rate=pk.get("l1_hit_rate"),
+                                       hbm_side_GBps=round(hbm / (hms * 1e-3) / 1e9, 1), hbm_side_frac_of_peak=round(hbm / (hms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                       hbm_side_over_compulsory=round(hbm / max(hpts * 140.0, 1.0), 2))
+                    if pk.get("l2_to_l1_bytes_per_launch"):
+                        l2l1 = pk["l2_to_l1_bytes_per_launch"] * lpc / (hms * 1e-3) / 1e9
+                        hash_gather.update(bound="l2 -> l1 line traffic of the gathers (128 B per request) against the L2 peak, MI355X_MICROARCH.md",
+                                           achieved=round(l2l1, 1), peak=L2_PEAK_GBPS, unit="GB/s", frac=round(l2l1 / L2_PEAK_GBPS, 4))
+            if mfma is not None:
+                pk, psrc = pmc_kernel("sdf_head_pipelined2_kernel")
+                if pk and pk.get("clock_GHz"):
+                    clk = pk["clock_GHz"]
+                    mfma.update(clock_GHz_under_kernel=clk, clock_source=psrc + " (GRBM_GUI_ACTIVE / dispatch duration)",
+                                peak_at_measured_clock=round(MFMA_F32_PEAK_TFLOPS * clk / 2.4, 1),
+                                frac_at_measured_clock=round(mfma["achieved"] / (MFMA_F32_PEAK_TFLOPS * clk / 2.4), 4))
             breakdown = {k: dict(calls_per_step=v[0] / k_instr, ms_per_step=round(v[1] / k_instr, 3))
                          for k, v in sorted(per_call.items(), key=lambda kv: -kv[1][1])[:12]}
         wl = (f"{args.hw}x{args.hw} frame ({n_rays} rays), fwd+bwd+Adam WITH the PBR branch: 128 samples/ray primary march, 2x importance "
@@ -537,8 +589,10 @@ def main():
                        "optimizer_step_in_timed_region": bool(opt is not None), "frames_per_step_per_gpu": 1,
                        "peak_device_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                        "parallelism": f"frame/ray-batch sharding x{world}", "samples": stats,
+                       "gradient_allreduce": (None if sync is None else dict(backend=dist.get_backend(), world=dist.get_world_size(),
+                                                                            bytes_per_step=int(reduced_bytes[0]))),
                        "library_sources_sha256_16": _build.source_fingerprint(), "library_built_from": _build.built_fingerprint()},
-            "roofline": roofline, "mfma": mfma, "cpu_baseline": cpu, "parity_on_bench_frame": parity, "deformer_search": search_modes,
+            "roofline": roofline, "mfma": mfma, "hash_gather": hash_gather, "cpu_baseline": cpu, "parity_on_bench_frame": parity, "deformer_search": search_modes,
             "kernel_breakdown_ms_per_step": breakdown,
             "ms_per_step_instrumented": round(dt_instr / max(k_instr, 1) * 1e3, 3),
             "abi_kernel_ms_per_step": round(total_ms / max(k_instr, 1), 3),
@@ -547,7 +601,7 @@ def main():
             "config2_rays_per_s": (round(n_rays / (config2 * 1e-3), 1) if config2 else None),
         }
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or force_rccl:
         dist.destroy_process_group()
 
 

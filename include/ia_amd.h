@@ -153,6 +153,18 @@ int ia_ray_resampling_merge(int64_t n_rays, int64_t n_in, int n, const int32_t* 
                             const int32_t* resample_packed_info, float* resample_vals, float* resample_dists,
                             uint8_t* resample_is_left, uint8_t* resample_is_right, uint8_t* is_resample,
                             uint8_t* is_fg_sample, void* tmp, ia_stream_t stream);
+/* K2 with its caller's compaction fused in (models/intrinsic_avatar.py:1221-1226: the edges with is_fg are kept -- nonzero, four
+ * boolean-mask gathers, unpack_info, pack_info): ..._count leaves cnt [n_rays] (kept edges per ray), start (exclusive scan) and
+ * *total (the one size read-back); ..._fill writes vals / is_left / is_right / ray_indices [total] and packed_info [n_rays,2] of the
+ * kept edges straight to their final places.  tmp (ia_resample_tmp_bytes) carries the tables between the two calls; scan_tmp:
+ * ia_scan_tmp_bytes(n_rays). */
+int ia_ray_resampling_merge_count(int64_t n_rays, int64_t n_in, int n, const int32_t* packed_info, const float* vals,
+                                  const uint8_t* is_left, const uint8_t* is_right, const float* weights, int32_t* cnt,
+                                  int32_t* start, int32_t* total, void* tmp, void* scan_tmp, ia_stream_t stream);
+int ia_ray_resampling_merge_fill(int64_t n_rays, int64_t n_in, int n, const int32_t* packed_info, const float* vals,
+                                 const uint8_t* is_left, const uint8_t* is_right, const int32_t* cnt, const int32_t* start,
+                                 float* out_vals, uint8_t* out_is_left, uint8_t* out_is_right, int64_t* out_ray_indices,
+                                 int32_t* out_packed_info, void* tmp, ia_stream_t stream);
 /* K3 ray_resampling_fine (cdf.cu:403-534); tmp may be NULL for n <= 8 (the points of a ray stay in registers) */
 int ia_ray_resampling_fine(int64_t n_rays, int64_t n_in, int n, const int32_t* packed_info, const float* starts, const float* ends,
                            const float* weights, const int32_t* resample_packed_info, int64_t n_out, float* resample_starts,

@@ -159,12 +159,20 @@ def scratch(name: str, nbytes: int, device):
     nbytes = int(nbytes)
     key = (name, str(device), torch.cuda.current_stream(device).cuda_stream)
     buf = _SCRATCH.get(key)
+    if buf is not None and nbytes < buf.numel() // 4 and buf.numel() > (1 << 30):
+        buf = None                                                # a much smaller batch than the one that sized it: give the memory back
     if buf is None or buf.numel() < nbytes:
         _SCRATCH[key] = None
         del buf
         buf = torch.empty(nbytes + nbytes // 4 + 4096, dtype=torch.uint8, device=device)
         _SCRATCH[key] = buf
     return buf[:nbytes]
+
+
+def scratch_clear():
+    """release every grow-only scratch buffer (they are views into the binding's own cache: a view must not outlive the call it was
+    made for, and nothing else holds them).  Long-running hosts call this after an unusually large batch."""
+    _SCRATCH.clear()
 
 
 def scan_tmp(n: int, device, extra_bytes: int = 0):

@@ -476,7 +476,8 @@ __global__ __launch_bounds__(ENV_ACC_THREADS) void env_band_accumulate_kernel(in
 // its flush 3.64 ms -- ds_add_f32 runs at ~0.5 lanes per clock and CU on gfx950, ds_add_u32 / u64 at the LDS's rate.
 // So: records are binned by band (count per 8192-record tile + max |g| -> one exclusive scan over [band][tile] -> scatter as
 // 24-byte AoS records: all streamed), and a band's list is summed in 64-bit FIXED POINT: contribution = round(w g S), S =
-// 2^35 / max |g| (a texel can take 2^27 maximal contributions; a contribution keeps its 24 fp32 bits down to 2^-11 of the
+// 2^(62 - ceil(log2 F)) / max |g| (a texel channel receives at most F contributions of at most max |g|: the signed 64-bit sum cannot
+// wrap whatever the batch size; the headline's F = 83 M gives 2^35: a contribution keeps its 24 fp32 bits down to 2^-11 of the
 // largest one and is absolute to 2^-35 of it below: tighter than any fp32 summation order), LDS ds_add_u64, one global 64-bit
 // atomic per touched texel channel into an integer image, converted and added to g_base once per texel at the end.  Integer
 // sums do not depend on the order: the texel gradient is bit-reproducible run to run (the float-atomic versions were not).
@@ -551,22 +552,24 @@ __global__ __launch_bounds__(ENV_ACC_THREADS) void env_bin_scatter_kernel(int64_
     }
 }
 
-__device__ __forceinline__ double env_fixed_scale(uint32_t gmax_bits)
+// fixed-point scale of the band sums: 2^shift / max |g| with shift = 62 - ceil(log2 F) (host): a texel channel receives at most F
+// contributions of at most max |g| each, so the signed 64-bit sum cannot wrap whatever the batch size (F = 83 M: shift 35)
+__device__ __forceinline__ double env_fixed_scale(uint32_t gmax_bits, int shift)
 {
     const float m = __uint_as_float(gmax_bits);
-    return (m > 0.0f && m < 3.0e38f) ? 34359738368.0 / (double)m : 0.0;                  // 2^35 / max |g|
+    return (m > 0.0f && m < 3.0e38f) ? __longlong_as_double((long long)(1023 + shift) << 52) / (double)m : 0.0;
 }
 
 __global__ __launch_bounds__(ENV_ACC_THREADS) void env_band_accumulate_binned_kernel(const EnvRec* __restrict__ recs,
                                                                                      const int32_t* __restrict__ offs /*[n_bands][n_tiles]*/,
                                                                                      const int32_t* __restrict__ total_p, int n_tiles, int H, int W,
-                                                                                     int TH, int n_bands, const uint32_t* __restrict__ gmax,
+                                                                                     int TH, int n_bands, const uint32_t* __restrict__ gmax, int shift,
                                                                                      unsigned long long* __restrict__ acc64 /*[H][W][3]*/)
 {
     extern __shared__ unsigned long long s_acc64[];     // [(TH + 1)][W][3], two's complement
     // which (band, part) is this workgroup: parts of a band = ceil(records of the band / R), R = records per workgroup
     const int total = *total_p;
-    const double S = env_fixed_scale(*gmax);
+    const double S = env_fixed_scale(*gmax, shift);
     if (total == 0 || S == 0.0) return;
     const int R = max(4096, (total + ((int)gridDim.x - n_bands) - 1) / max((int)gridDim.x - n_bands, 1));
     int band = -1, part = 0, b0 = 0, b1 = 0;
@@ -612,13 +615,13 @@ __global__ __launch_bounds__(ENV_ACC_THREADS) void env_band_accumulate_binned_ke
 }
 
 __global__ __launch_bounds__(THREADS) void env_fixed_finish_kernel(int64_t n, const unsigned long long* __restrict__ acc64,
-                                                                    const uint32_t* __restrict__ gmax, float* __restrict__ g_base)
+                                                                    const uint32_t* __restrict__ gmax, int shift, float* __restrict__ g_base)
 {
     const int64_t e = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     if (e >= n) return;
     const long long v = (long long)acc64[e];
     if (v == 0) return;
-    g_base[e] += (float)((double)v / env_fixed_scale(*gmax));
+    g_base[e] += (float)((double)v / env_fixed_scale(*gmax, shift));
 }
 
 template <int MODE>
@@ -865,6 +868,8 @@ IA_EXPORT int ia_pbr_shade_bwd(int mode, int64_t F, const float* normal, const f
             p = reinterpret_cast<char*>(scan_tmp) + ia_scan_tmp_bytes((int64_t)(32 * (int64_t)n_tiles));
             unsigned long long* acc64 = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(p) + 255) & ~(uintptr_t)255);
             const int64_t n_img = (int64_t)env_h * env_w * 3;
+            int fx_shift = 62;                                          // 62 - ceil(log2 F): see env_fixed_scale
+            for (int64_t f = 1; f < F; f <<= 1) fx_shift--;
             (void)hipMemsetAsync(gmax, 0, 4, s);
             (void)hipMemsetAsync(acc64, 0, (size_t)n_img * 8, s);
             env_bin_count_kernel<<<n_tiles, ENV_ACC_THREADS, 0, s>>>(F, rec_idx, rec_g, TH64, n_bands64, n_tiles, counts, gmax);
@@ -873,8 +878,8 @@ IA_EXPORT int ia_pbr_shade_bwd(int mode, int64_t F, const float* normal, const f
             env_bin_scatter_kernel<<<n_tiles, ENV_ACC_THREADS, 0, s>>>(F, rec_idx, rec_w, rec_g, TH64, n_bands64, n_tiles, offs, sorted);
             const size_t lds64 = (size_t)(TH64 + 1) * env_w * 3 * sizeof(unsigned long long);
             env_band_accumulate_binned_kernel<<<256 + n_bands64, ENV_ACC_THREADS, lds64, s>>>(sorted, offs, total, n_tiles, env_h, env_w, TH64,
-                                                                                              n_bands64, gmax, acc64);
-            env_fixed_finish_kernel<<<ia::cdiv(n_img, THREADS), THREADS, 0, s>>>(n_img, acc64, gmax, g_env_base);
+                                                                                              n_bands64, gmax, fx_shift, acc64);
+            env_fixed_finish_kernel<<<ia::cdiv(n_img, THREADS), THREADS, 0, s>>>(n_img, acc64, gmax, fx_shift, g_env_base);
         }
     }
     return ia::check_launch("ia_pbr_shade_bwd");

@@ -227,6 +227,56 @@ __global__ __launch_bounds__(THREADS) void rs2_edges_kernel(int64_t n_rays, cons
     }
 }
 
+// K2 with the caller's compaction fused in (models/intrinsic_avatar.py:1221-1226 keeps the edges with is_fg and re-packs their ray
+// indices: nonzero + four boolean-mask gathers + unpack_info + pack_info).  A ray's reached edges are the first steps + n_hit slots of
+// its range, so: per-ray count -> scan over RAYS -> phase B writes every kept edge straight to its final place, with its ray index,
+// and the ray's packed_info row.  Nothing is zero-filled, nothing is written twice.
+__global__ __launch_bounds__(THREADS) void rs2_counts_kernel(int64_t n_rays, const int32_t* __restrict__ packed_info, RsScratch s,
+                                                             int32_t* __restrict__ cnt)
+{
+    const int64_t r = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (r >= n_rays) return;
+    const int steps = packed_info[2 * r + 1];
+    cnt[r] = steps > 0 ? steps + reinterpret_cast<const int4*>(s.ray)[r].x : 0;
+}
+
+__global__ __launch_bounds__(THREADS) void rs2_compact_kernel(int64_t n_rays, const int32_t* __restrict__ packed_info,
+                                                              const int32_t* __restrict__ cnt, const int32_t* __restrict__ start,
+                                                              const float* __restrict__ vals, const uint8_t* __restrict__ il,
+                                                              const uint8_t* __restrict__ ir, RsScratch s, float* __restrict__ out_vals,
+                                                              uint8_t* __restrict__ out_left, uint8_t* __restrict__ out_right,
+                                                              int64_t* __restrict__ out_ray, int32_t* __restrict__ out_pinfo)
+{
+    __shared__ int s_off[RS2_TILE + 1];
+    const int64_t r0 = (int64_t)blockIdx.x * RS2_TILE;
+    const int n_tile = (int)((r0 + RS2_TILE <= n_rays) ? RS2_TILE : n_rays - r0);
+    if (threadIdx.x < n_tile) {
+        const int st = start[r0 + threadIdx.x], c = cnt[r0 + threadIdx.x];
+        s_off[threadIdx.x] = st;
+        reinterpret_cast<int2*>(out_pinfo)[r0 + threadIdx.x] = make_int2(st, c);
+        if (threadIdx.x == n_tile - 1) s_off[n_tile] = st + c;
+    }
+    __syncthreads();
+    const int begin = s_off[0], end = s_off[n_tile];
+    for (int p = begin + threadIdx.x; p < end; p += THREADS) {
+        int lo = 0, hi = n_tile - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_off[mid] <= p) lo = mid; else hi = mid - 1;
+        }
+        const int64_t r = r0 + lo;
+        const int2 pi = reinterpret_cast<const int2*>(packed_info)[r];
+        const int4 q = reinterpret_cast<const int4*>(s.ray)[r];
+        ia_rs_ray rec;
+        rec.n_hit = q.x; rec.j_clamp = q.y; rec.v_clamp = __int_as_float(q.z); rec.k_first = q.w;
+        const ia_rs2_edge e = ia_rs2_at(p - s_off[lo], pi.y, &rec, vals + pi.x, il + pi.x, ir + pi.x, s.cdf + pi.x, s.first + pi.x, s.utab);
+        out_vals[p] = e.val;
+        out_left[p] = e.left;
+        out_right[p] = e.right;
+        out_ray[p] = r;
+    }
+}
+
 // K3 / K4, few points per ray (n + 1 <= IA_RS_SMALL): one lane per ray, the ray's points in registers, its n outputs written as one
 // vector per array (the non-empty rays' outputs are consecutive, so a wave's stores are contiguous)
 template <bool SDF, int N>
@@ -441,6 +491,44 @@ IA_EXPORT int ia_ray_resampling_merge(int64_t n_rays, int64_t n_in, int n, const
                                                                      resample_vals, resample_dists, resample_is_left, resample_is_right,
                                                                      is_resample, is_fg_sample);
     return ia::check_launch("ia_ray_resampling_merge");
+}
+
+// K2 + the caller's foreground compaction in two calls around ONE size read-back:
+//   ia_ray_resampling_merge_count: u-table, per-ray tables, cnt [n_rays] = kept edges per ray, start = exclusive scan, *total;
+//   ia_ray_resampling_merge_fill:  vals / is_left / is_right / ray_indices [total] and packed_info [n_rays, 2] of the kept edges.
+// tmp (ia_resample_tmp_bytes) carries the tables from the first call to the second.
+IA_EXPORT int ia_ray_resampling_merge_count(int64_t n_rays, int64_t n_in, int n, const int32_t* packed_info, const float* vals,
+                                            const uint8_t* is_left, const uint8_t* is_right, const float* weights, int32_t* cnt,
+                                            int32_t* start, int32_t* total, void* tmp, void* scan_tmp, ia_stream_t stream)
+{
+    if (n_rays == 0) return ia_exclusive_scan_i32(nullptr, nullptr, total, 0, scan_tmp, stream);
+    IA_REQUIRE(n >= 1, "ia_ray_resampling_merge_count: n must be >= 1");
+    IA_REQUIRE(tmp != nullptr, "ia_ray_resampling_merge_count: tmp (ia_resample_tmp_bytes) is required");
+    hipStream_t st = (hipStream_t)stream;
+    RsScratch s;
+    rs_layout(rs_aligned(tmp), n_rays, n_in, n, &s);
+    const int grid = ia::cdiv(n_rays, THREADS);
+    rs_utab_kernel<<<1, 64, 0, st>>>(n, 0, s.utab);
+    rs2_rays_kernel<<<grid, THREADS, 0, st>>>(n_rays, n, packed_info, vals, is_left, is_right, weights, s);
+    rs2_counts_kernel<<<grid, THREADS, 0, st>>>(n_rays, packed_info, s, cnt);
+    int r = ia::check_launch("ia_ray_resampling_merge_count");
+    if (r != IA_OK) return r;
+    return ia_exclusive_scan_i32(cnt, start, total, n_rays, scan_tmp, stream);
+}
+
+IA_EXPORT int ia_ray_resampling_merge_fill(int64_t n_rays, int64_t n_in, int n, const int32_t* packed_info, const float* vals,
+                                           const uint8_t* is_left, const uint8_t* is_right, const int32_t* cnt, const int32_t* start,
+                                           float* out_vals, uint8_t* out_is_left, uint8_t* out_is_right, int64_t* out_ray_indices,
+                                           int32_t* out_packed_info, void* tmp, ia_stream_t stream)
+{
+    if (n_rays == 0) return IA_OK;
+    IA_REQUIRE(tmp != nullptr, "ia_ray_resampling_merge_fill: tmp of the matching ia_ray_resampling_merge_count call is required");
+    RsScratch s;
+    rs_layout(rs_aligned(tmp), n_rays, n_in, n, &s);
+    rs2_compact_kernel<<<ia::cdiv(n_rays, RS2_TILE), THREADS, 0, (hipStream_t)stream>>>(n_rays, packed_info, cnt, start, vals, is_left, is_right,
+                                                                                       s, out_vals, out_is_left, out_is_right,
+                                                                                       out_ray_indices, out_packed_info);
+    return ia::check_launch("ia_ray_resampling_merge_fill");
 }
 
 template <bool SDF>

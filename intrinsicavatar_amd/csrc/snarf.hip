@@ -660,15 +660,32 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
     const int64_t p_begin = (int64_t)blockIdx.x * pts_wg;
     if (p_begin >= N) return;
     const int n_pts = (int)((p_begin + pts_wg < N) ? pts_wg : N - p_begin);
+    // the workgroup's slices of the per-point arrays (uniform bases; lanes add 32-bit offsets)
+    int32_t* const cnt_wg = PACK ? cnt + p_begin : nullptr;
+    uint32_t* const meta_wg = PACK ? meta + p_begin : nullptr;
+    float* const x_wg = PACK ? x + p_begin * (SPEC_ROOTS * 3) : nullptr;
+    const int32_t* const order_wg = order ? order + p_begin : nullptr;
+    const float* const xd_wg = xd_tgt + p_begin * 3;
     bool drained = false;                              // wave-uniform: the chunk has nothing left
     const float offset[3] = {offset_g[0], offset_g[1], offset_g[2]};
     const float scale[3] = {scale_g[0], scale_g[1], scale_g[2]};
     const float cvg2 = cvg_threshold * cvg_threshold, dvg2 = dvg_threshold * dvg_threshold;
-    // voxel cell f of axis a covers canonical x in [f cell_w + cell_o, (f + 1) cell_w + cell_o)   (g = scale (x + offset), f = floor(((g + 1) / 2) (dim - 1)))
-    // (wave-uniform: pinned in scalar registers -- the divisions leave them in vector registers otherwise, which this kernel has none to spare)
-    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-    const float cell_w[3] = {uni(2.0f / ((W - 1) * scale[0])), uni(2.0f / ((H - 1) * scale[1])), uni(2.0f / ((D - 1) * scale[2]))};
-    const float cell_o[3] = {uni(-1.0f / scale[0] - offset[0]), uni(-1.0f / scale[1] - offset[1]), uni(-1.0f / scale[2] - offset[2])};
+    // voxel cell f of axis a covers canonical x in [f cell_w + cell_o, (f + 1) cell_w + cell_o)   (g = scale (x + offset), f = floor(((g + 1) / 2) (dim - 1))).
+    // The twelve wave-uniform constants of the cell bounds live in LDS (the kernel has no scalar register left for them: as SGPR
+    // candidates they ended up in vector registers and were spilled to scratch -- reloaded in a block that runs on almost every iteration):
+    // s_cell[0..2] pitch, [3..5] / [6..8] lower / upper bound of cell 0 shrunk by the margin (a negative pitch swaps the ends), [9..11] dim - 1
+    __shared__ float s_cell[12];
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        const int dim_a = a == 0 ? W : (a == 1 ? H : D);
+        const float cw = 2.0f / ((dim_a - 1) * scale_g[a]);
+        const float co = -1.0f / scale_g[a] - offset_g[a];
+        s_cell[a] = cw;
+        s_cell[3 + a] = co + fminf(cw, 0.0f) + SPEC_CELL_MARGIN;
+        s_cell[6 + a] = co + fmaxf(cw, 0.0f) - SPEC_CELL_MARGIN;
+        s_cell[9 + a] = (float)(dim_a - 1);
+    }
+    __syncthreads();
 
     bool have = false;            // lane owns a point
     bool next = false;            // current search ended: move to the point's next init (or give the point up)
@@ -703,12 +720,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
                 have = false;
                 if (PACK) {
                     if (n_done < 0) {                                    // exact redo finished: hand the 13 results over
-                        cnt[p_begin + pt] = 0;
-                        meta[p_begin + pt] = 0u;
+                        cnt_wg[pt] = 0;
+                        meta_wg[pt] = 0u;
                         if (flag_rec >= 0) { flag.point[flag_rec] = (int32_t)(p_begin + pt); flag.valid[flag_rec] = inits; }
                     } else {
-                        cnt[p_begin + pt] = n_done;
-                        meta[p_begin + pt] = inits;
+                        cnt_wg[pt] = n_done;
+                        meta_wg[pt] = inits;
                     }
                 }
             }
@@ -733,10 +750,15 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
                     n_done = 0;
                     inits = 0;
                     flag_rec = -1;
-                    const int64_t src = order ? (int64_t)order[p_begin + c] : p_begin + c;
-                    xt[0] = xd_tgt[src * 3 + 0];
-                    xt[1] = xd_tgt[src * 3 + 1];
-                    xt[2] = xd_tgt[src * 3 + 2];
+                    // wave-uniform 64-bit bases + 32-bit lane offsets (the refill runs for one or two lanes on almost every iteration: its
+                    // quarter-rate 64-bit multiply-adds cost the whole wave)
+                    if (order) {
+                        const uint32_t src = (uint32_t)order_wg[c];                              // N * 12 bytes stays below 2^32 (checked at the entry point)
+                        const float* t = reinterpret_cast<const float*>(reinterpret_cast<const char*>(xd_tgt) + src * 12u);
+                        xt[0] = t[0]; xt[1] = t[1]; xt[2] = t[2];
+                    } else {
+                        xt[0] = xd_wg[c * 3 + 0]; xt[1] = xd_wg[c * 3 + 1]; xt[2] = xd_wg[c * 3 + 2];
+                    }
                 }
             }
         }
@@ -756,9 +778,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
             bool at_root = false;
 #pragma unroll
             for (int r = 0; r < SPEC_ROOTS; r++) {
-                if (r < n_roots)
-                    at_root = at_root || (x_l[0] >= BOXLO(r, 0) && x_l[0] < BOXHI(r, 0) && x_l[1] >= BOXLO(r, 1) && x_l[1] < BOXHI(r, 1) &&
-                                          x_l[2] >= BOXLO(r, 2) && x_l[2] < BOXHI(r, 2));
+                if (r < n_roots) {
+                    // all six bounds loaded up front, the comparisons combined bitwise: written with && the compiler short-circuits -- six
+                    // nested branches, each waiting for its own LDS read
+                    const float l0 = BOXLO(r, 0), l1 = BOXLO(r, 1), l2 = BOXLO(r, 2), h0 = BOXHI(r, 0), h1 = BOXHI(r, 1), h2 = BOXHI(r, 2);
+                    at_root = at_root | ((x_l[0] >= l0) & (x_l[0] < h0) & (x_l[1] >= l1) & (x_l[1] < h1) & (x_l[2] >= l2) & (x_l[2] < h2));
+                }
             }
             if (at_root) { if (!PACK) is_valid[index] = 0; if (COUNT) c_retired++; next = true; }
         }
@@ -770,7 +795,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
         const float iz = scale[2] * (x_l[2] + offset[2]);
         float Jl[12];
         grid_sample_J<IA_LAYOUT_NDHWC, true>(voxel_J, 0, D, H, W, ix, iy, iz, Jl);
+#ifdef IA_SPEC_DIAG_ITERS       /* diagnostic build: counters[4] = lane-slots of the fetch iterations (64 per wave iteration that fetched) */
+        if (COUNT) { c_fetch++; c_corner += 64u / (unsigned)__popcll(__ballot(1)); }
+#else
         if (COUNT) { c_fetch++; c_corner += in_range_corner_count(ix, iy, iz, D, H, W); }
+#endif
         if (it < 0) {
             // initial fetch: J_inv guess and g(x0)   (fuse_cuda_kernel_fast.cu:295-331)
             Ji[0] = Jl[0]; Ji[3] = Jl[1]; Ji[6] = Jl[2];
@@ -823,8 +852,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
                                 dmin = fminf(dmin, d0 * d0 + d1 * d1 + d2 * d2);
                             }
                         }
-                        const bool dup = (double)dmin < 0.0001 * 0.0001;
-                        if (!dup && ((double)dmin < 0.0002 * 0.0002 || n_roots >= slots)) {
+                        // (double)dist < 0.0001 * 0.0001 for a float dist <=> dist < the smallest float above that double (0x322bcc78)
+                        const bool dup = dmin < __uint_as_float(0x322bcc78u);
+                        if (!dup && (dmin < 4e-8f || n_roots >= slots)) {
                             // neither surely a duplicate nor surely distinct from every later valid root (or no slot left): the lane
                             // searches this point again with the filter off and lets rows_flagged_kernel apply K9 to all 13 results
                             if (COUNT) c_redo++;
@@ -841,38 +871,55 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
                         }
                         if (!dup) {
                             if (PACK) {
-                                const int64_t slot = (p_begin + pt) * SPEC_ROOTS + n_done;
-                                x[slot * 3 + 0] = x_l[0]; x[slot * 3 + 1] = x_l[1]; x[slot * 3 + 2] = x_l[2];
+                                float* const row = x_wg + (pt * SPEC_ROOTS + n_done) * 3;
+                                row[0] = x_l[0]; row[1] = x_l[1]; row[2] = x_l[2];
                                 inits |= (unsigned)init << (8 * n_done);
                                 n_done++;
                             }
                             // record the root with its retirement box: the eps-box cut to the root's voxel cell; empty unless tight.
-                            // (explicit fma chains / precomputed cell pitch: ~35 instead of ~170 VALU instructions in a block that some
-                            //  lane of the wave enters on almost every iteration; the box only has to lie INSIDE the cell, which the margin
-                            //  guarantees against the few ulps these roundings can move it)
+                            // What each condition costs (same-box A/B, tools/ab_build.sh + tools/search_ab.py, 16.4 M headline march points,
+                            // search + rows ms; round 3's unconditional eps test: 8.34): eps box only (-DIA_SPEC_ABL_EPS_BOX) 8.54; + tightness
+                            // (-DIA_SPEC_ABL_X3) 8.55; cut COMPUTED but unused (-DIA_SPEC_ABL_X1) 8.49; cut used (this build) 9.41 -- the arithmetic
+                            // is free, the cut itself costs 10 %: with it 90.6 instead of 95.1 % of the lanes are busy at a fetch
+                            // (-DIA_SPEC_DIAG_ITERS) for 1 % more fetches.  It is what takes the candidate-set differences from 5 to 1 of 16.4 M points.
+                            // This block is entered by SOME lane of the wave on almost every iteration (~2.6 roots are recorded per wave and
+                            // iteration), so every instruction in it costs like one of the main loop's: ~90 VALU as first written took the
+                            // search from 8.9 to 10.9 ms per 16.4 M points (same-box A/B, tools/search_ab.py).  Cell bounds are two fma off
+                            // wave-uniform constants (margin and the sign of the cell pitch folded in), min / max as selects, tightness
+                            // applied to one axis (a box with one empty side is empty).
                             const float jn2 = fmaf(Ji[8], Ji[8], fmaf(Ji[7], Ji[7], fmaf(Ji[6], Ji[6], fmaf(Ji[5], Ji[5], fmaf(Ji[4], Ji[4],
                                               fmaf(Ji[3], Ji[3], fmaf(Ji[2], Ji[2], fmaf(Ji[1], Ji[1], Ji[0] * Ji[0]))))))));
-                            const bool tight = jn2 <= SPEC_TAU * SPEC_TAU;
                             const float gc[3] = {ix, iy, iz};
-                            const int dim[3] = {W, H, D};
                             float lo[3], hi[3];
 #pragma unroll
                             for (int a = 0; a < 3; a++) {
-                                // cell [f, f + 1) of the interpolation coordinate ((g + 1) / 2) (dim - 1) (the fetch's own expression),
-                                // mapped back to canonical space: x = f cell_w + cell_o
-                                const float f = floorf(((gc[a] + 1.f) / 2) * (dim[a] - 1));
-                                const float c_lo = fmaf(f, cell_w[a], cell_o[a]), c_hi = c_lo + cell_w[a];
-                                const float a_lo = fminf(c_lo, c_hi) + SPEC_CELL_MARGIN, a_hi = fmaxf(c_lo, c_hi) - SPEC_CELL_MARGIN;
-                                lo[a] = tight ? fmaxf(a_lo, x_l[a] - eps) : INFINITY;
-                                hi[a] = fminf(a_hi, x_l[a] + eps);
+                                // cell f of the interpolation coordinate ((g + 1) / 2) (dim - 1) (the fetch's own expression)
+                                const float f = floorf(((gc[a] + 1.f) / 2) * s_cell[9 + a]);
+#ifdef IA_SPEC_ABL_EPS_BOX
+                                lo[a] = x_l[a] - eps; hi[a] = x_l[a] + eps; (void)f;
+#else
+                                const float a_lo = fmaf(f, s_cell[a], s_cell[3 + a]), a_hi = fmaf(f, s_cell[a], s_cell[6 + a]);
+                                const float e_lo = x_l[a] - eps, e_hi = x_l[a] + eps;
+#if defined(IA_SPEC_ABL_X1)            /* ablation: the cut is computed but not used */
+                                lo[a] = e_lo; hi[a] = e_hi;
+                                asm volatile("" ::"v"(a_lo), "v"(a_hi));
+#elif defined(IA_SPEC_ABL_X3)          /* ablation: tightness only */
+                                lo[a] = e_lo; hi[a] = e_hi; (void)a_lo; (void)a_hi;
+#else
+                                lo[a] = a_lo > e_lo ? a_lo : e_lo;
+                                hi[a] = a_hi < e_hi ? a_hi : e_hi;
+#endif
+#endif
                             }
-#pragma unroll
-                            for (int r = 0; r < SPEC_ROOTS; r++)
-                                if (r == n_roots) {
-                                    ROOT(r, 0) = x_l[0]; ROOT(r, 1) = x_l[1]; ROOT(r, 2) = x_l[2];
-                                    BOXLO(r, 0) = lo[0]; BOXLO(r, 1) = lo[1]; BOXLO(r, 2) = lo[2];
-                                    BOXHI(r, 0) = hi[0]; BOXHI(r, 1) = hi[1]; BOXHI(r, 2) = hi[2];
-                                }
+#if !defined(IA_SPEC_ABL_EPS_BOX) && !defined(IA_SPEC_ABL_X1) && !defined(IA_SPEC_ABL_X2)
+                            if (!(jn2 <= SPEC_TAU * SPEC_TAU)) lo[0] = INFINITY;
+#endif
+                            {   // one computed slot address instead of three predicated copies of the nine stores
+                                float* const slot = rootp + n_roots * (9 * WG);
+                                slot[0 * WG] = x_l[0]; slot[1 * WG] = x_l[1]; slot[2 * WG] = x_l[2];
+                                slot[3 * WG] = lo[0]; slot[4 * WG] = lo[1]; slot[5 * WG] = lo[2];
+                                slot[6 * WG] = hi[0]; slot[7 * WG] = hi[1]; slot[8 * WG] = hi[2];
+                            }
                             n_roots++;
                         }
                     }
@@ -898,9 +945,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
         bool near = false;
 #pragma unroll
         for (int r = 0; r < SPEC_ROOTS; r++) {
-            if (r < n_roots)
-                near = near || (x_l[0] >= BOXLO(r, 0) && x_l[0] < BOXHI(r, 0) && x_l[1] >= BOXLO(r, 1) && x_l[1] < BOXHI(r, 1) &&
-                                x_l[2] >= BOXLO(r, 2) && x_l[2] < BOXHI(r, 2));
+            if (r < n_roots) {
+                const float l0 = BOXLO(r, 0), l1 = BOXLO(r, 1), l2 = BOXLO(r, 2), h0 = BOXHI(r, 0), h1 = BOXHI(r, 1), h2 = BOXHI(r, 2);
+                near = near | ((x_l[0] >= l0) & (x_l[0] < h0) & (x_l[1] >= l1) & (x_l[1] < h1) & (x_l[2] >= l2) & (x_l[2] < h2));
+            }
         }
         if (near) {
             const float jn2 = fmaf(Ji[8], Ji[8], fmaf(Ji[7], Ji[7], fmaf(Ji[6], Ji[6], fmaf(Ji[5], Ji[5], fmaf(Ji[4], Ji[4],
@@ -1297,6 +1345,7 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
     IA_REQUIRE(I >= 1 && I <= 16, "early-filter search: 1 <= I <= 16 inits");
     IA_REQUIRE(eps >= 0.0f, "early-filter search: eps must be >= 0");
     IA_REQUIRE((int64_t)D * H * W < ((int64_t)1 << 26), "voxel grid too large for 32-bit byte offsets (48 B per voxel)");
+    IA_REQUIRE(order == nullptr || N * 12 < ((int64_t)1 << 32), "early-filter search through a permutation: N * 12 bytes must stay below 2^32");
     int pts = 192;                                                       // points per wave; a workgroup's four waves share a chunk of 4 x pts
     // small batches (the reference trains on 4096 rays per GPU: ~0.2 M points per search): shorter chunks, so that the launch still has
     // two rounds of workgroups for the device's 1280 resident ones instead of a quarter of one

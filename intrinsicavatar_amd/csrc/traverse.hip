@@ -804,7 +804,10 @@ __global__ __launch_bounds__(ST_THREADS) void traverse_sorted_kernel(
             if (term_planes) term_planes[g] = t_term;
         }
         s_nruns[r] = (uint8_t)min(sink.n_runs, 255);
-        s_cnt[r] = (uint32_t)sink.n_intervals | ((uint32_t)sink.n_samples << 16);
+        // the tile keeps per-ray counts in 16 bits: a ray longer than that (a caller's max_extent hint that is not a true bound)
+        // raises the overflow flag and the caller falls back to the two-phase protocol, as for a capacity overflow
+        if (sink.n_intervals > 0xFFFF || sink.n_samples > 0xFFFF) totals[2] = 1;
+        s_cnt[r] = (uint32_t)(sink.n_intervals & 0xFFFF) | ((uint32_t)(sink.n_samples & 0xFFFF) << 16);
     }
     __syncthreads();
 

@@ -61,6 +61,10 @@ class SNARFDeformer:
         self.voxel_J_cl = torch.empty((B, D, H, W, 12), device=self.device)
         fast_snarf.precompute(self.lbs_voxel_final, self.tfs, self.voxel_d, None, self.offset_kernel, self.scale_kernel,
                               voxel_J_cl=self.voxel_J_cl)
+        # the search's corner-pair loads read an out-of-range corner's in-range neighbour with weight 0 (bit-identical to skipping it
+        # only for finite voxels): one check per frame instead of a select per load
+        if not bool(torch.isfinite(self.voxel_J_cl).all()):
+            raise RuntimeError("SNARFDeformer.prepare: the skinning grid (voxel_J) holds non-finite values")
 
     def transform_rays_w2s(self, rays: Tensor) -> Tensor:
         """snarf_deformer.py:128-147."""

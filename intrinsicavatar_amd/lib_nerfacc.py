@@ -96,6 +96,37 @@ def ray_resampling_merge(packed_info: Tensor, vals: Tensor, is_left: Tensor, is_
     return rpi, f[0], f[1], b[0], b[1], b[2], b[3]
 
 
+@torch.no_grad()
+def ray_resampling_merge_compact(packed_info: Tensor, vals: Tensor, is_left: Tensor, is_right: Tensor, weights: Tensor, n_samples: int):
+    """ray_resampling_merge followed by what its caller does with the result (models/intrinsic_avatar.py:1221-1226):
+        keep = is_fg_sample;  vals[keep], is_left[keep], is_right[keep];  ray_indices = unpack_info(rpi)[keep];  pack_info(ray_indices)
+    fused (ia_ray_resampling_merge_count / _fill): a ray's reached edges are a prefix of its range, so a scan over RAYS places every
+    kept edge directly -- no zero fill, no nonzero, no gathers; one size read-back.
+    -> (vals [T], is_left [T], is_right [T], ray_indices int64 [T], packed_info int32 [n_rays, 2])."""
+    packed_info = _i32c(packed_info)
+    vals, w = _f32v(vals), _f32v(weights)
+    il, ir = is_left.contiguous(), is_right.contiguous()
+    if il.dtype != torch.bool or ir.dtype != torch.bool:
+        raise RuntimeError("is_left/is_right must be bool")
+    n_rays, dev = packed_info.shape[0], packed_info.device
+    lib, st = L.lib(), L.stream()
+    cnt, start = (torch.empty(n_rays, dtype=torch.int32, device=dev) for _ in range(2))
+    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    tmp = _resample_tmp(n_rays, vals.shape[0], n_samples, dev)
+    L.check(lib.ia_ray_resampling_merge_count(L.i64(n_rays), L.i64(vals.shape[0]), L.i32(n_samples), L.ptr(packed_info), L.ptr(vals),
+                                              L.ptr(il), L.ptr(ir), L.ptr(w), L.ptr(cnt), L.ptr(start), L.ptr(total), L.ptr(tmp),
+                                              L.ptr(L.scan_tmp(n_rays, dev)), st), "ia_ray_resampling_merge_count")
+    T = int(total.item())
+    ov = torch.empty(T, dtype=torch.float32, device=dev)
+    ol, orr = torch.empty(T, dtype=torch.bool, device=dev), torch.empty(T, dtype=torch.bool, device=dev)
+    ray = torch.empty(T, dtype=torch.int64, device=dev)
+    pinfo = torch.empty((n_rays, 2), dtype=torch.int32, device=dev)
+    L.check(lib.ia_ray_resampling_merge_fill(L.i64(n_rays), L.i64(vals.shape[0]), L.i32(n_samples), L.ptr(packed_info), L.ptr(vals),
+                                             L.ptr(il), L.ptr(ir), L.ptr(cnt), L.ptr(start), L.ptr(ov), L.ptr(ol), L.ptr(orr), L.ptr(ray),
+                                             L.ptr(pinfo), L.ptr(tmp), st), "ia_ray_resampling_merge_fill")
+    return ov, ol, orr, ray, pinfo
+
+
 # ----------------------------------------------------------------------------- K3 / K4
 def _fine(packed_info, t_starts, t_ends, wa, sdfs, n_samples, sdf_mode):
     packed_info = _i32c(packed_info)

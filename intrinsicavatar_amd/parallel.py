@@ -105,9 +105,11 @@ class OverlappedGradientAllReduce:
     (no ray hit anything): the launch order is therefore fixed up front -- reverse parameter order, i.e. the order in
     which autograd normally completes them -- and a ready gradient waits for its predecessors in that order."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    def __init__(self, params: Iterable[torch.nn.Parameter], single_rank_too: bool = False):
+        """single_rank_too: issue the collectives in a one-rank group as well (a sum over one rank: same values) -- how the
+        RCCL code path (hooks, async handles on device tensors, the flat bucket) is exercised on a one-GPU box."""
         self.params = [p for p in params if p.requires_grad]
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or single_rank_too)
         self.order = [p for p in reversed(self.params) if p.numel() >= BIG]
         self._ready = set()
         self._next = 0

@@ -163,12 +163,10 @@ class RenderStep:
                     dists = torch.zeros_like(vals).index_put_((il_idx,), te - ts)
                     alphas = laplace_alpha(sdf, dists, beta)
                 weights, _ = nerfacc.render_weight_from_alpha(alphas, packed_info=intervals.packed_info)
-                rpi, rvals, rdists, ril, rir, is_res, is_fg = lib_nerfacc.ray_resampling_merge(
+                # K2 + the selection of its reached edges (intrinsic_avatar.py:1211-1226) as count -> scan -> fill kernels
+                rvals, ril, rir, ray_idx, pinfo = lib_nerfacc.ray_resampling_merge_compact(
                     intervals.packed_info, vals, intervals.is_left, intervals.is_right, weights, 16)
-                fg_idx = torch.nonzero(is_fg)[:, 0]
-                ray_idx = lib_nerfacc.unpack_info(rpi, rvals.shape[0])[fg_idx]
-                intervals = RayIntervals(vals=rvals[fg_idx], is_left=ril[fg_idx], is_right=rir[fg_idx], ray_indices=ray_idx,
-                                         packed_info=lib_nerfacc.pack_info(ray_idx, n_rays))
+                intervals = RayIntervals(vals=rvals, is_left=ril, is_right=rir, ray_indices=ray_idx, packed_info=pinfo)
         # -- 4.
         il_idx = torch.nonzero(intervals.is_left)[:, 0]
         t_starts = intervals.vals[il_idx]
@@ -351,6 +349,7 @@ class RenderStep:
         out = dict(comp_rgb=acc(rgbs), comp_normal=acc(normal_world), albedo=acc(mats[:, :3].contiguous()),
                    roughness=acc(mats[:, 3:4].contiguous()), metallic=acc(mats[:, 4:5].contiguous()), opacity=acc(None))
         out["depth"] = acc(((t_starts + t_ends) / 2.0)[:, None]) + (1.0 - out["opacity"]) * far[:, None]
+        out["packed_info"] = packed_info
         extras = dict(weights=weights, sdf=d["sdf"], alphas=alphas, normals=normal_smpl, albedo=mats[:, :3],
                       roughness=mats[:, 3:4], metallic=mats[:, 4:5])
         rgb_phys = background_color[None].expand(n_rays, 3).clone()

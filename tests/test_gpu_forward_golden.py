@@ -4,9 +4,11 @@ reference's state_dict loads under its own keys), same rays, same explicit rando
 mis / mats in the eval form and `light` in train() mode; plus the per-frame pieces the model runs before forward_
 (ForwardDeformer.switch_to_explicit + precompute, prepare_test_occupancy_grid :307-381).
 
-Bars as in tests/test_forward_golden_cpu.py (which holds the CPU oracle to the same fixture): output keys / shapes / dtypes of
-the reference's dict; sample counts within 0.5 %; step-5 maps 2e-3 (normals 4e-3) on >= 98.5 % of the pixels; Monte-Carlo
-images 2 % + 2e-2 on >= 97 % of the pixels and 2 % in the mean."""
+Bars (round 4): every float key of the output dict is held to (max, p99, mean) of its per-pixel absolute difference, set at 3 x what
+tools/parity_table.py observed on the MI355X (profiles/r04_parity_table.json; BASELINE.md section 3 quotes the table) -- the maximum
+is a HARD cap over all 784 pixels, not a fraction-of-pixels catch-all; discrete outputs (sample counts, rays_valid*, ray indices)
+are compared exactly, with a stated upper bound on flips (observed: none).  For scale: the CPU oracle differs from the same fixture by
+1.3e-4 (comp_rgb) / 8.5e-4 (comp_normal) / 1.3e-3 (comp_rgb_phys)."""
 import numpy as np
 import pytest
 import torch
@@ -42,33 +44,61 @@ def _close(name, a, b, tol, frac=0.985, mean_tol=None):
         assert err.mean() < mean_tol, (name, float(err.mean()))
 
 
-def _check_common(d, ref, mode):
+# (max, p99, mean) of the per-pixel absolute difference to the reference's forward_: 3 x the MI355X observation, worst eval run
+BARS_EVAL = {
+    "comp_rgb": (2.8e-3, 9.5e-5, 1.2e-5), "comp_rgb_full": (2.0e-3, 6.5e-5, 8.4e-6), "comp_normal": (1.3e-2, 3.6e-4, 5.3e-5),
+    "comp_albedo": (1.8e-6, 1.1e-6, 1.3e-7), "comp_albedo_full": (1.8e-6, 1.1e-6, 1.3e-7),
+    "comp_roughness": (2.2e-6, 1.2e-6, 1.3e-7), "comp_roughness_full": (7.2e-7, 4.7e-7, 1.2e-7),
+    "comp_metallic": (2.2e-6, 1.4e-6, 1.3e-7), "comp_metallic_full": (7.2e-7, 5.4e-7, 1.2e-7),
+    "opacity": (4.2e-6, 2.7e-6, 2.4e-7), "depth": (7.2e-6, 5.8e-6, 6.9e-7),
+}
+BARS_TRAIN = {       # train(): jittered near plane + the training occupancy grid -- other samples than the eval runs
+    "comp_rgb": (6.5e-3, 9.8e-5, 2.0e-5), "comp_rgb_full": (4.3e-3, 7.0e-5, 1.5e-5), "comp_normal": (3.3e-2, 3.1e-4, 9.0e-5),
+    "comp_albedo": (2.0e-6, 9.3e-7, 1.3e-7), "comp_albedo_full": (2.0e-6, 9.3e-7, 1.3e-7),
+    "comp_roughness": (2.6e-6, 1.2e-6, 1.3e-7), "comp_roughness_full": (7.2e-7, 3.8e-7, 1.2e-7),
+    "comp_metallic": (2.6e-6, 1.2e-6, 1.3e-7), "comp_metallic_full": (7.2e-7, 5.4e-7, 1.3e-7),
+    "opacity": (4.9e-6, 2.2e-6, 2.5e-7), "depth": (1.1e-5, 5.8e-6, 7.5e-7),
+}
+# Monte-Carlo images, per run (a visibility sample on the other side of a threshold moves a pixel by Lo / spp)
+BARS_MC = {
+    "light_16_nogi": {"comp_rgb_phys": (4.0e-3, 1.1e-4, 9.6e-6), "comp_demod_phys": (7.7e-3, 3.7e-4, 2.6e-5), "comp_rgb_phys_full": (4.0e-3, 1.3e-4, 1.2e-5), "comp_demod_phys_full": (3.8e-3, 3.1e-4, 1.8e-5)},
+    "light_64_gi": {"comp_rgb_phys": (2.5e-3, 1.6e-4, 1.2e-5), "comp_demod_phys": (5.1e-3, 4.8e-4, 4.0e-5), "comp_rgb_phys_full": (1.4e-3, 1.4e-4, 9.6e-6), "comp_demod_phys_full": (6.2e-4, 1.8e-4, 9.1e-6)},
+    "uniform_light_512_gi": {"comp_rgb_phys": (2.3e-2, 2.8e-4, 4.2e-5), "comp_demod_phys": (7.0e-2, 7.6e-4, 1.4e-4), "comp_rgb_phys_full": (1.5e-2, 2.5e-4, 2.9e-5), "comp_demod_phys_full": (2.4e-3, 1.8e-4, 1.4e-5)},
+    "mis_16_gi": {"comp_rgb_phys": (1.2e-2, 7.2e-4, 4.8e-5), "comp_demod_phys": (3.5e-2, 3.2e-3, 1.8e-4), "comp_rgb_phys_full": (2.0e-2, 1.3e-3, 6.4e-5), "comp_demod_phys_full": (4.4e-2, 1.9e-3, 1.4e-4)},
+    "mats_16_gi": {"comp_rgb_phys": (2.2e-2, 1.3e-3, 9.4e-5), "comp_demod_phys": (6.7e-2, 5.1e-3, 3.2e-4), "comp_rgb_phys_full": (3.1e-2, 2.0e-3, 1.2e-4), "comp_demod_phys_full": (7.6e-2, 2.4e-3, 2.3e-4)},
+    "light_16_gi_train": {"comp_rgb_phys": (4.7e-4, 1.3e-4, 7.2e-6), "comp_demod_phys": (1.8e-3, 3.5e-4, 2.3e-5), "comp_rgb_phys_full": (6.0e-4, 1.4e-4, 8.7e-6), "comp_demod_phys_full": (1.1e-3, 1.9e-4, 1.3e-5)},
+}
+
+
+def _held(name, a, b, bar):
+    """per-pixel absolute difference within (max, p99, mean); the max is a hard cap over every pixel."""
+    err = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    err = err.reshape(err.shape[0], -1).max(-1)
+    got = (float(err.max()), float(np.quantile(err, 0.99)), float(err.mean()))
+    assert got[0] <= bar[0] and got[1] <= bar[1] and got[2] <= bar[2], (name, got, bar)
+
+
+def _check_common(d, ref, tag, bars=None):
     for k in ref:
         assert tuple(d[k].shape) == ref[k].shape, (k, tuple(d[k].shape), ref[k].shape)
         assert N(d[k]).dtype.kind == ref[k].dtype.kind, (k, N(d[k]).dtype, ref[k].dtype)
-    n_ref = int(ref["num_samples"][0])
-    assert abs(int(d["num_samples"][0]) - n_ref) <= 0.005 * n_ref, (int(d["num_samples"][0]), n_ref)
-    assert (N(d["rays_valid"]) == ref["rays_valid"]).mean() >= 0.995
-    for k in ("comp_rgb_bg", "comp_albedo_bg", "comp_metallic_bg", "comp_roughness_bg", "rays_valid_bg", "num_samples_bg"):
-        np.testing.assert_allclose(N(d[k]).astype(np.float64), ref[k].astype(np.float64), atol=1e-6, err_msg=k)
-    for k, tol in (("comp_rgb", 2e-3), ("comp_normal", 4e-3), ("comp_albedo", 2e-3), ("comp_roughness", 2e-3), ("comp_metallic", 2e-3),
-                   ("opacity", 2e-3), ("comp_rgb_full", 4e-3), ("comp_albedo_full", 2e-3)):
-        _close(k, N(d[k]), ref[k], tol, mean_tol=5e-4)
-    _close("depth", N(d["depth"]), ref["depth"], 5e-3)
-
-
-def _check_mc_images(d, ref, keys=("comp_rgb_phys", "comp_demod_phys"), rows=None):
+    # discrete outputs: exact on the MI355X; upper bounds on what a sample at a threshold may flip
+    assert abs(int(d["num_samples"][0]) - int(ref["num_samples"][0])) <= 2, (int(d["num_samples"][0]), int(ref["num_samples"][0]))
+    for k in ("rays_valid", "rays_valid_phys", "rays_valid_full", "rays_valid_phys_full"):
+        assert int((N(d[k]) != ref[k]).sum()) <= 1, k
+    for k in ("rays_valid_bg", "rays_valid_phys_bg", "num_samples_bg"):
+        assert np.array_equal(N(d[k]), ref[k]), k
+    for k in ("comp_rgb_bg", "comp_albedo_bg", "comp_metallic_bg", "comp_roughness_bg"):
+        np.testing.assert_allclose(N(d[k]).astype(np.float64), ref[k].astype(np.float64), atol=1e-7, err_msg=k)
+    for k, bar in (bars or BARS_EVAL).items():
+        _held(k, N(d[k]), ref[k], bar)
+    for k, bar in BARS_MC[tag].items():
+        _held(k, N(d[k]), ref[k], bar)
+    # the Monte-Carlo images also agree in the mean over the hit pixels
     hit = ref["rays_valid"][:, 0]
-    for k in keys:
+    for k in ("comp_rgb_phys", "comp_demod_phys"):
         a, b = N(d[k]), ref[k]
-        if rows is not None:
-            a, b, h = a[:rows], b[:rows], hit[:rows]
-        else:
-            h = hit
-        tol = 2e-2 * np.abs(b).max(-1) + 2e-2
-        err = np.abs(a - b).max(-1)
-        assert (err <= tol).mean() >= 0.97, (k, float((err > tol).mean()), float(err.max()))
-        assert abs(a[h].mean() - b[h].mean()) <= 2e-2 * abs(b[h].mean()), (k, a[h].mean(), b[h].mean())
+        assert abs(a[hit].mean() - b[hit].mean()) <= 2e-3 * abs(b[hit].mean()), (k, a[hit].mean(), b[hit].mean())
 
 
 @pytest.mark.parametrize("tag", list(FG.RUNS))
@@ -85,10 +115,9 @@ def test_forward_eval_vs_the_references_own_forward(G, tag):
                     background_color=T(G["background_color"]), global_illumination=gi, render_mode=mode, scatter_u=scatter_u)
     ref = {str(k): G[f"{tag}_out_{k}"] for k in G[tag + "_out_keys"]}
     assert sorted(d) == sorted(ref), sorted(set(d) ^ set(ref))
-    _check_common(d, ref, mode)
-    _check_mc_images(d, ref)
+    _check_common(d, ref, tag)
     if mode == "uniform_light":
-        _close("visibility", N(d["visibility"]), ref["visibility"], 3e-2, frac=0.97)
+        _held("visibility", N(d["visibility"]), ref["visibility"], (4.6e-3, 1.3e-5, 9.7e-6))
 
 
 def test_forward_train_mode_vs_the_references_own_forward(G):
@@ -107,28 +136,21 @@ def test_forward_train_mode_vs_the_references_own_forward(G):
     assert sorted(d) == sorted(ref), sorted(set(d) ^ set(ref))
     n_ref = int(ref["num_samples"][0])
     n_gpu = int(d["num_samples"][0])
-    assert abs(n_gpu - n_ref) <= 0.005 * n_ref
     per_sample = ("sdf_samples", "sdf_grad_samples", "sdf_laplace_samples", "weights", "points", "intervals", "ray_indices")
-    _check_common({k: v for k, v in d.items() if k not in per_sample}, {k: v for k, v in ref.items() if k not in per_sample}, "light")
-    for k in ("normals_orientation_loss_map", "albedo_smoothness_loss_map", "roughness_smoothness_loss_map", "metallic_smoothness_loss_map"):
+    _check_common({k: v for k, v in d.items() if k not in per_sample}, {k: v for k, v in ref.items() if k not in per_sample}, tag,
+                  bars=BARS_TRAIN)
+    # the sample SET is the reference's (observed on the MI355X: identical); the per-sample keys are only comparable then
+    assert n_gpu == n_ref and np.array_equal(N(d["ray_indices"]), ref["ray_indices"])
+    for k, bar in (("normals_orientation_loss_map", (1.6e-2, 1.3e-4, 4.1e-5)), ("albedo_smoothness_loss_map", (1.3e-10, 4.4e-11, 5e-12)),
+                   ("roughness_smoothness_loss_map", (8.8e-11, 4.7e-11, 3.6e-12)), ("metallic_smoothness_loss_map", (6.4e-11, 3.1e-11, 2.9e-12)),
+                   # K2 inserts its edges by inverting a CDF of fp32 weights: a last-bit difference in a weight moves an edge by an ulp or two
+                   ("points", (4.6e-5, 2.9e-6, 1.8e-7)), ("intervals", (9.2e-5, 4.3e-6, 3.1e-7)), ("weights", (2.4e-5, 8.6e-6, 4.5e-7)),
+                   ("sdf_samples", (5.2e-5, 1.7e-6, 1.9e-7)),
+                   # the SDF gradient jumps across the faces of the hash grid's cells: a sample within an ulp of a face may take the other side
+                   ("sdf_grad_samples", (2.2, 3.0e-3, 4.0e-4))):
         a, b = N(d[k]), ref[k]
-        assert a.shape == b.shape
-        if n_gpu == n_ref:            # the jitter noise is indexed by sample: only comparable when the sample sets coincide
-            _close(k, a, b, 5e-3 * max(1.0, float(np.abs(b).max())), frac=0.97)
-    if n_gpu == n_ref and np.array_equal(N(d["ray_indices"]), ref["ray_indices"]):
-        # K2 inserts its edges by inverting a CDF of fp32 weights: a last-bit difference in a weight moves an edge by an ulp or two
-        assert (np.abs(N(d["points"]) - ref["points"]) <= 2e-5).mean() >= 0.999
-        assert (np.abs(N(d["intervals"]) - ref["intervals"]) <= 2e-5).mean() >= 0.999 and np.abs(N(d["intervals"]) - ref["intervals"]).max() < 1e-3
-        _close("weights", N(d["weights"])[:, None], ref["weights"][:, None], 2e-3, frac=0.99)
-        _close("sdf_samples", N(d["sdf_samples"])[:, None], ref["sdf_samples"][:, None], 1e-4, frac=0.99)
-        _close("sdf_grad_samples", N(d["sdf_grad_samples"]), ref["sdf_grad_samples"], 5e-3, frac=0.99)
-        assert float(np.abs(ref["sdf_laplace_samples"]).max()) == 0.0 and float(d["sdf_laplace_samples"].abs().max()) == 0.0
-    # per-point light: image on the rays before the first pixel that disagrees (a fg / bg flip re-pairs every later uniform)
-    a, b = N(d["comp_rgb_phys"]), ref["comp_rgb_phys"]
-    tol = 2e-2 * np.abs(b).max(-1) + 2e-2
-    bad = np.nonzero(np.abs(a - b).max(-1) > tol)[0]
-    first_bad = int(bad[0]) if bad.size else a.shape[0]
-    assert first_bad >= 0.3 * a.shape[0], first_bad
+        _held(k, a if a.ndim > 1 else a[:, None], b if b.ndim > 1 else b[:, None], bar)
+    assert float(np.abs(ref["sdf_laplace_samples"]).max()) == 0.0 and float(d["sdf_laplace_samples"].abs().max()) == 0.0
 
 
 def test_per_frame_preparation_vs_the_reference(G):

@@ -284,6 +284,15 @@ def test_resampling_vs_golden(ops, golden_dir):
                                      T(g[k + "is_right"]), T(g[k + "weights"]), int(g[k + "n"]))
         for nm, v in zip(("rpi", "vals", "dists", "is_left", "is_right", "is_resample", "is_fg"), r):
             np.testing.assert_array_equal(N(v), g[k + "k2_" + nm], err_msg=f"K2 case {c} {nm}")
+        # K2 fused with its caller's selection of the reached edges (models/intrinsic_avatar.py:1221-1226) == the op sequence on K2's output
+        rpi, rvals, _, ril, rir, _, is_fg = r
+        fg_idx = torch.nonzero(is_fg)[:, 0]
+        ray_idx = lib.unpack_info(rpi, rvals.shape[0])[fg_idx]
+        want = (rvals[fg_idx], ril[fg_idx], rir[fg_idx], ray_idx, lib.pack_info(ray_idx, rpi.shape[0]))
+        got = lib.ray_resampling_merge_compact(T(g[k + "packed_info"]), T(g[k + "vals"]), T(g[k + "is_left"]), T(g[k + "is_right"]),
+                                               T(g[k + "weights"]), int(g[k + "n"]))
+        for a_, b_, nm in zip(got, want, ("vals", "is_left", "is_right", "ray_indices", "packed_info")):
+            assert torch.equal(a_, b_), (c, nm)
 
 
 def test_pack_unpack_vs_golden(ops, golden_dir):

@@ -5,8 +5,8 @@ Floating-point tolerance: the field kernels use fma / MFMA and device exp/log, t
 values differ by ~1e-6 relative, so a CDF comparison inside the importance resampling can flip for a
 vanishing fraction of rays; and the analytic normal is piecewise constant per hash cell, so a sample within
 rounding distance of a cell face can get the neighbouring cell's normal (-> a different radiance input).
-Stated bar: sample counts equal for >= 99.5 % of rays, images within 2e-3 absolute for >= 98.5 % of pixels
-(never off by more than 0.15), mean abs error < 2e-4."""
+Stated bar (round 4): sample counts per ray identical (at most 2 rays may differ), every map held to (max, p99, mean) of its
+per-pixel absolute difference at 3 x the MI355X observation, the maximum as a hard cap over all pixels (BARS_RENDER)."""
 import numpy as np
 import pytest
 import torch
@@ -25,6 +25,13 @@ def frame():
                          grid_W=64, smooth_iters=5, hash_amp=2e-3)
 
 
+# observed on the MI355X (max / p99 / mean): comp_rgb 1.06e-2 / 5.2e-5 / 6.2e-6, opacity 4.1e-5 / 2.0e-6 / 1.1e-7, comp_normal 8.0e-2 /
+# 2.5e-4 / 3.3e-5, depth 2.9e-5 / 2.4e-6 / 2.8e-7.  The maxima of comp_rgb / comp_normal are ONE pixel each: the analytic normal is
+# piecewise constant per hash cell and a sample within an ulp of a cell face takes the neighbouring cell's normal (p99 is 200 x lower)
+BARS_RENDER = {"comp_rgb": (3.2e-2, 1.6e-4, 1.9e-5), "opacity": (1.3e-4, 6.0e-6, 3.3e-7), "comp_normal": (0.25, 7.5e-4, 1.0e-4),
+               "depth": (9.0e-5, 7.2e-6, 8.6e-7)}
+
+
 def test_render_step_vs_oracle(frame, oracle):
     from oracle import render_ref as R
     rs, rays, export = frame
@@ -37,11 +44,18 @@ def test_render_step_vs_oracle(frame, oracle):
     cnt = out["packed_info"][:, 1].cpu().numpy()
     cnt_ref = ref["packed_info"][:, 1]
     assert (cnt == cnt_ref).mean() >= 0.995, (cnt != cnt_ref).sum()
-    for k, tol in (("comp_rgb", 2e-3), ("opacity", 2e-3), ("comp_normal", 4e-3), ("depth", 5e-3)):
+    # (max, p99, mean) of the per-pixel absolute difference: 3 x the MI355X observation (printed with -s), the max a hard cap over all
+    # 16 384 pixels; sample counts per ray: observed identical, at most 2 rays may differ
+    assert int((cnt != cnt_ref).sum()) <= 2, int((cnt != cnt_ref).sum())
+    bad = []
+    for k, bar in BARS_RENDER.items():
         a, b = out[k].cpu().numpy(), ref[k]
         err = np.abs(a - b).max(-1)
-        assert (err < tol).mean() >= 0.985 and err.max() < 0.15, (k, float(err.max()), float((err >= tol).mean()))
-        assert err.mean() < 2e-4, (k, float(err.mean()))
+        got = (float(err.max()), float(np.quantile(err, 0.99)), float(err.mean()))
+        print("render_step vs oracle", k, got)
+        if not (got[0] <= bar[0] and got[1] <= bar[1] and got[2] <= bar[2]):
+            bad.append((k, got, bar))
+    assert not bad, bad
     hit = ref["opacity"][:, 0] > 0.5
     assert 0.02 < hit.mean() < 0.9
     # compositing invariants
@@ -144,7 +158,10 @@ def test_config1_static_neutral_pose_vs_oracle(oracle):
     assert out["stats"]["n_edges0"] == ref["stats"]["n_edges0"] and out["stats"]["n_samples0"] == ref["stats"]["n_samples0"]
     cnt, cnt_ref = out["packed_info"][:, 1].cpu().numpy(), ref["packed_info"][:, 1]
     assert (cnt == cnt_ref).mean() >= 0.995
-    for k, tol in (("comp_rgb", 2e-3), ("opacity", 2e-3), ("comp_normal", 4e-3), ("depth", 5e-3)):
+    assert int((cnt != cnt_ref).sum()) <= 2
+    for k, bar in BARS_RENDER.items():
         err = np.abs(out[k].cpu().numpy() - ref[k]).max(-1)
-        assert (err < tol).mean() >= 0.985 and err.mean() < 2e-4, (k, float(err.max()), float(err.mean()))
+        got = (float(err.max()), float(np.quantile(err, 0.99)), float(err.mean()))
+        print("config1 vs oracle", k, got)
+        assert got[0] <= bar[0] and got[1] <= bar[1] and got[2] <= bar[2], (k, got, bar)
     assert 0.02 < (ref["opacity"][:, 0] > 0.5).mean() < 0.9

@@ -113,6 +113,17 @@ def main():
     so = (aabb0[:3] + (pick.float() + torch.rand((M, 3), generator=gsec).to(DEV)) * cellsz).contiguous()
     sd = torch.nn.functional.normalize(torch.randn((M, 3), generator=gsec), dim=-1).to(DEV).contiguous()
     fused_case("traverse_fused_secondary", so, sd, torch.zeros(M, device=DEV), torch.full((M,), 1.5, device=DEV), 1.5 / 63, 1.5)
+    # ---- what bounds the secondary march: the same 2 M rays (a) through an EMPTY grid -- set-up + the DDA over every
+    # cell of the crossing, nothing emitted --, (b) started far outside the box pointing away -- set-up only --, (c) through a FULL grid
+    # -- every step emits a sample.  (a) is the floor of any kernel that walks the cell sequence per ray; see DESIGN 4.2.
+    bits_save2 = bits
+    bits = nerfacc.pack_occupancy_bits(torch.zeros_like(binaries)[0])
+    fused_case("traverse_fused_secondary_empty_grid", so, sd, torch.zeros(M, device=DEV), torch.full((M,), 1.5, device=DEV), 1.5 / 63, 1.5)
+    far_o = (so + 100.0).contiguous()
+    fused_case("traverse_fused_secondary_missing_the_box", far_o, sd.abs().contiguous(), torch.zeros(M, device=DEV), torch.full((M,), 1.5, device=DEV), 1.5 / 63, 1.5)
+    bits = nerfacc.pack_occupancy_bits(torch.ones_like(binaries)[0])
+    fused_case("traverse_fused_secondary_full_grid", so, sd, torch.zeros(M, device=DEV), torch.full((M,), 1.5, device=DEV), 1.5 / 63, 1.5)
+    bits = bits_save2
     zn, fr = torch.zeros(M, device=DEV), torch.full((M,), 1.5, device=DEV)
     for meth in ("two_pass", "fused"):      # whole operator incl. allocation and the size sync
         res[f"traverse_op_secondary_{meth}"] = dict(us=timeit(lambda: nerfacc.traverse_grids(
