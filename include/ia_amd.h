@@ -230,8 +230,8 @@ int ia_fuse_broyden_spec(int64_t N, int I, const float* xd_tgt /*[N,3]*/, const 
  * results.  Outputs: x_rows [N, 3, 3]: the k-th candidate of a point (k = 0: its highest init) in slot k; cnt [N]; meta [N]: the
  * inits of slots 0..2 in bytes 0..2 (bit 31: the point has overflow records: a 4th, 5th ... survivor of a redone point, chained
  * per point through ovf_head [N], which is written for such points only); start [N] = exclusive scan of cnt; ovf_scratch:
- * ia_spec_rows_overflow_bytes() bytes.  total_and_overflow [2]: [0] = Q, [1] = number of points redone -- above
- * ia_spec_rows_overflow_capacity() results were lost: redo the batch with ia_fuse_broyden_spec + K9.
+ * ia_spec_rows_overflow_bytes(N) bytes.  total_and_overflow [2]: [0] = Q, [1] = number of points redone -- above
+ * ia_spec_rows_overflow_capacity(N) results were lost: redo the batch with ia_fuse_broyden_spec + K9.
  * 44 bytes per point leave the kernel instead of 169 (x [N,I,3] + is_valid).  J_inv / fwd_J (optional) are written at
  * [point, init] as in ia_fuse_broyden.  scan_tmp: ia_scan_tmp_bytes(N) bytes.
  * ia_deform_rows_pack: cand_x [Q,3] (+ cand_src [Q] = point * I + init, optional) in (point, ascending init) order; with
@@ -239,8 +239,8 @@ int ia_fuse_broyden_spec(int64_t N, int I, const float* xd_tgt /*[N,3]*/, const 
  * elementwise passes of models/rf/geometry.py:155 `(points - self.center) / self.scale + 0.5` done on the way out; same IEEE
  * operations, same bits). */
 int ia_spec_rows_slots(void);
-size_t ia_spec_rows_overflow_bytes(void);
-int ia_spec_rows_overflow_capacity(void);
+size_t ia_spec_rows_overflow_bytes(int64_t N);        /* scratch of a call on N points: overflow records + the list of redone points (N / 64, at least 65536) */
+int64_t ia_spec_rows_overflow_capacity(int64_t N);   /* points of a call on N points that can be redone */
 int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
                               const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold,
                               float dvg_threshold, float eps, float* x_rows, float* J_inv, float* fwd_J, int32_t* cnt, uint32_t* meta,

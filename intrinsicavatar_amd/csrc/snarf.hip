@@ -614,7 +614,8 @@ constexpr int SPEC_ROOTS = 3;              // recorded roots per point (survivor
 constexpr float SPEC_TAU = 2.5f;           // a root is tight when |J_inv|_F <= SPEC_TAU (a rotation has sqrt(3) = 1.73)
 constexpr float SPEC_TAU_SELF = 3.0f;      // a search may be retired while its own |J_inv|_F <= SPEC_TAU_SELF
 constexpr float SPEC_CELL_MARGIN = 4e-6f;  // the cell box of a root is shrunk by this much (canonical metres) on every side
-constexpr int SPEC_FLAG_CAP = 1 << 16;     // points per launch that can be redone exactly (1.8e-4 of the points are)
+// points per launch that can be redone exactly (1.4e-4 .. 1.8e-4 of the points are on the march distributions; the list holds 1 / 64 of a batch)
+static inline int64_t spec_flag_cap(int64_t N) { const int64_t c = N >> 6; return c < (1 << 16) ? (1 << 16) : c; }
 
 // flagged points: the 13 results of the exact redo, for rows_flagged_kernel
 struct SpecFlag {
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
     const int32_t* __restrict__ order /* NULL or [N]: point p of this launch is xd_tgt[order[p]] (evaluation order != storage order) */)
 {
     __shared__ float s_T[16 * 12];                     // per init: rows 0..2 of its bone's 4x4 (R | t)
-    __shared__ int s_cur;                              // points of the WORKGROUP's chunk handed out so far
+    __shared__ int s_cur;                              // positions of the WORKGROUP's stream of chunks handed out so far
     for (int t = threadIdx.x; t < I * 12; t += WG) s_T[t] = tfs[(int64_t)bone_ids[t / 12] * 16 + (t % 12)];
     if (threadIdx.x == 0) s_cur = 0;
     __syncthreads();
@@ -656,16 +657,15 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
     // Occupancy: 4 instead of 5 waves per SIMD (94 VGPRs either way) 359.8 against 352.7 ms; 6 waves (80 VGPRs: 26 spilled dwords in the loop) 480.4;
     // 6 waves with the recorded roots, the target point and the PACK counters in LDS (86 VGPRs unconstrained, 10 dwords still spilled at
     // 80): search 187 against 143 ms -- a handful of scratch reloads per fetch cost more than the sixth wave hides
-    const int pts_wg = pts_per_wave * (WG / 64);
-    const int64_t p_begin = (int64_t)blockIdx.x * pts_wg;
-    if (p_begin >= N) return;
-    const int n_pts = (int)((p_begin + pts_wg < N) ? pts_wg : N - p_begin);
-    // the workgroup's slices of the per-point arrays (uniform bases; lanes add 32-bit offsets)
-    int32_t* const cnt_wg = PACK ? cnt + p_begin : nullptr;
-    uint32_t* const meta_wg = PACK ? meta + p_begin : nullptr;
-    float* const x_wg = PACK ? x + p_begin * (SPEC_ROOTS * 3) : nullptr;
-    const int32_t* const order_wg = order ? order + p_begin : nullptr;
-    const float* const xd_wg = xd_tgt + p_begin * 3;
+    // Workgroup b works through the chunks b, b + G, b + 2 G ... (G = grid size) as ONE stream: the LDS cursor runs on across chunk
+    // boundaries.  Position q of the stream is point ((q >> log2c) G + b) 2^log2c + (q & mask): increasing in q, so the first position
+    // at or beyond N ends the stream.  The product launches G = number of chunks (one chunk per workgroup, one point per lane: see
+    // launch_spec for the measurements; a grid of resident workgroups -- persistent, no drain -- is slower).
+    const int log2c = pts_per_wave;                    // log2 of the points per chunk (per workgroup)
+    const int cmask = (1 << log2c) - 1;
+    const int G = gridDim.x, b_wg = blockIdx.x;
+    if (((int64_t)b_wg << log2c) >= N) return;
+    auto stream_point = [&](int q) -> int64_t { return (((int64_t)(q >> log2c) * G + b_wg) << log2c) + (q & cmask); };
     bool drained = false;                              // wave-uniform: the chunk has nothing left
     const float offset[3] = {offset_g[0], offset_g[1], offset_g[2]};
     const float scale[3] = {scale_g[0], scale_g[1], scale_g[2]};
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
 
     bool have = false;            // lane owns a point
     bool next = false;            // current search ended: move to the point's next init (or give the point up)
-    int pt = 0;                   // the lane's point, relative to the wave's chunk
+    int pt = 0;                   // the lane's point (index into the launch's N points)
     int init = 0;
     int it = -1;                  // -1: waiting for the initial fetch
     int n_roots = 0;              // recorded roots of the lane's point (stays 0 while the point is redone exactly)
@@ -720,12 +720,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
                 have = false;
                 if (PACK) {
                     if (n_done < 0) {                                    // exact redo finished: hand the 13 results over
-                        cnt_wg[pt] = 0;
-                        meta_wg[pt] = 0u;
-                        if (flag_rec >= 0) { flag.point[flag_rec] = (int32_t)(p_begin + pt); flag.valid[flag_rec] = inits; }
+                        cnt[pt] = 0;
+                        meta[pt] = 0u;
+                        if (flag_rec >= 0) { flag.point[flag_rec] = pt; flag.valid[flag_rec] = inits; }
                     } else {
-                        cnt_wg[pt] = n_done;
-                        meta_wg[pt] = inits;
+                        cnt[pt] = n_done;
+                        meta[pt] = inits;
                     }
                 }
             }
@@ -737,28 +737,23 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
             int base = 0;
             if (lane == 0) base = atomicAdd(&s_cur, __popcll(need));
             base = __builtin_amdgcn_readfirstlane(base);
-            drained = base + __popcll(need) >= n_pts;
+            drained = stream_point(base + __popcll(need)) >= N;
             if (!have) {
                 const int rank = __popcll(need & ((1ull << lane) - 1ull));
-                const int c = base + rank;
-                if (c < n_pts) {
+                const int64_t p = stream_point(base + rank);
+                if (p < N) {
                     have = true;
-                    pt = c;
+                    pt = (int)p;
                     init = I - 1;
                     it = -1;
                     n_roots = 0;
                     n_done = 0;
                     inits = 0;
                     flag_rec = -1;
-                    // wave-uniform 64-bit bases + 32-bit lane offsets (the refill runs for one or two lanes on almost every iteration: its
-                    // quarter-rate 64-bit multiply-adds cost the whole wave)
-                    if (order) {
-                        const uint32_t src = (uint32_t)order_wg[c];                              // N * 12 bytes stays below 2^32 (checked at the entry point)
-                        const float* t = reinterpret_cast<const float*>(reinterpret_cast<const char*>(xd_tgt) + src * 12u);
-                        xt[0] = t[0]; xt[1] = t[1]; xt[2] = t[2];
-                    } else {
-                        xt[0] = xd_wg[c * 3 + 0]; xt[1] = xd_wg[c * 3 + 1]; xt[2] = xd_wg[c * 3 + 2];
-                    }
+                    const int64_t src = order ? (int64_t)order[p] : p;
+                    xt[0] = xd_tgt[src * 3 + 0];
+                    xt[1] = xd_tgt[src * 3 + 1];
+                    xt[2] = xd_tgt[src * 3 + 2];
                 }
             }
         }
@@ -771,7 +766,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
             x_l[1] = ixd * T[0 * 4 + 1] + iyd * T[1 * 4 + 1] + izd * T[2 * 4 + 1];
             x_l[2] = ixd * T[0 * 4 + 2] + iyd * T[1 * 4 + 2] + izd * T[2 * 4 + 2];
         }
-        const int64_t index = (p_begin + pt) * I + init;
+        const int64_t index = (int64_t)pt * I + init;
         if (it < 0) {
             // the rigid inverse of a bone that owns the point IS the root (up to rounding): a search that STARTS inside the retirement
             // box of a root a later init has found is retired before its first fetch
@@ -871,7 +866,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
                         }
                         if (!dup) {
                             if (PACK) {
-                                float* const row = x_wg + (pt * SPEC_ROOTS + n_done) * 3;
+                                float* const row = x + ((int64_t)pt * SPEC_ROOTS + n_done) * 3;
                                 row[0] = x_l[0]; row[1] = x_l[1]; row[2] = x_l[2];
                                 inits |= (unsigned)init << (8 * n_done);
                                 n_done++;
@@ -1345,14 +1340,34 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
     IA_REQUIRE(I >= 1 && I <= 16, "early-filter search: 1 <= I <= 16 inits");
     IA_REQUIRE(eps >= 0.0f, "early-filter search: eps must be >= 0");
     IA_REQUIRE((int64_t)D * H * W < ((int64_t)1 << 26), "voxel grid too large for 32-bit byte offsets (48 B per voxel)");
-    IA_REQUIRE(order == nullptr || N * 12 < ((int64_t)1 << 32), "early-filter search through a permutation: N * 12 bytes must stay below 2^32");
-    int pts = 192;                                                       // points per wave; a workgroup's four waves share a chunk of 4 x pts
-    // small batches (the reference trains on 4096 rays per GPU: ~0.2 M points per search): shorter chunks, so that the launch still has
-    // two rounds of workgroups for the device's 1280 resident ones instead of a quarter of one
-    while (pts > 64 && N < (int64_t)pts * (THREADS / 64) * 2560) pts >>= 1;      // never fewer points than lanes
-    if (const char* e = getenv("IA_BR_SPEC_PTS")) pts = atoi(e) > 0 ? atoi(e) : pts;
-    const int64_t pts_wg = (int64_t)pts * (THREADS / 64);
-    const int grid = (int)((N + pts_wg - 1) / pts_wg);
+    IA_REQUIRE(N < ((int64_t)1 << 31), "early-filter search: N must stay below 2^31");
+    // chunk = 2^log2c consecutive points of the sorted order, shared by the four waves of a workgroup.  Same-box A/B on the 16.4 M headline
+    // march points (tools/search_ab.py, search + rows ms): one chunk per workgroup with 2^7 / 2^8 / 2^9 / 2^10 points 10.68 / 8.81 / 9.05 /
+    // 9.73 (round 3's 768: 9.41) -- ONE POINT PER LANE is best: what a short chunk loses to its slowest point it wins back through the
+    // narrower window of the sorted order the resident workgroups cover (1280 x 256 points).  PERSISTENT workgroups that walk the chunks
+    // b, b + G, ... as one stream (no drain at all; IA_BR_SPEC_PERSIST=1) lose badly, 13.6 - 14.7 ms: with a static stride the
+    // workgroups drift apart by whole rounds and the window grows to several G x 2^log2c points -- the hardware's in-order dispatch of
+    // one-chunk workgroups IS the dynamic queue that keeps the window tight.
+    int log2c = 8;
+    if (const char* e = getenv("IA_BR_SPEC_LOG2C")) { const int v = atoi(e); if (v >= 6 && v <= 14) log2c = v; }
+    const int64_t n_chunks = (N + ((int64_t)1 << log2c) - 1) >> log2c;
+    int grid = (int)n_chunks;
+    if (const char* e = getenv("IA_BR_SPEC_PERSIST")) {
+        if (atoi(e) == 1) {
+            static int resident = 0;
+            if (resident == 0) {
+                int dev = 0, cus = 256, per_cu = 5;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, broyden_spec_kernel<false, true>, THREADS, 0);
+                (void)hipGetLastError();
+                resident = (cus > 0 ? cus : 256) * (per_cu > 0 ? per_cu : 5);
+            }
+            grid = (int)(n_chunks < resident ? n_chunks : resident);
+        }
+    }
+    IA_REQUIRE(n_chunks < ((int64_t)1 << 31) && (N >> log2c) / grid < ((int64_t)1 << (30 - log2c)), "early-filter search: stream positions must fit 31 bits");
+    const int pts = log2c;
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* c = reinterpret_cast<unsigned long long*>(counters);
     int slots = SPEC_ROOTS;                                              // test hook: fewer recorded roots / row slots => more points take the exact redo
@@ -1385,11 +1400,12 @@ extern "C" int ia_exclusive_scan_i32(const int32_t* in, int32_t* out, int32_t* t
 // [flagged: point (int32) | valid mask (uint32) | x (16 x 3 float)] x SPEC_FLAG_CAP
 static const int SPEC_OVF_CAP = 1 << 18;
 static const size_t SPEC_OVF_BYTES = 64 + (size_t)SPEC_OVF_CAP * (12 + 12 + 1) + 64;
-IA_EXPORT size_t ia_spec_rows_overflow_bytes(void) { return SPEC_OVF_BYTES + (size_t)SPEC_FLAG_CAP * (4 + 4 + 16 * 12) + 64; }
+IA_EXPORT size_t ia_spec_rows_overflow_bytes(int64_t N) { return SPEC_OVF_BYTES + (size_t)spec_flag_cap(N) * (4 + 4 + 16 * 12) + 64; }
 
 struct OvfLayout { int32_t* count; int32_t* rec; float* x; uint8_t* keep; SpecFlag flag; };
-static OvfLayout ovf_layout(void* scratch)
+static OvfLayout ovf_layout(void* scratch, int64_t N)
 {
+    const int64_t fcap = spec_flag_cap(N);
     char* b = reinterpret_cast<char*>(scratch);
     OvfLayout L;
     L.count = reinterpret_cast<int32_t*>(b);
@@ -1399,17 +1415,17 @@ static OvfLayout ovf_layout(void* scratch)
     char* f = b + ((SPEC_OVF_BYTES + 63) & ~(size_t)63);
     L.flag.count = reinterpret_cast<int32_t*>(b) + 1;
     L.flag.point = reinterpret_cast<int32_t*>(f);
-    L.flag.valid = reinterpret_cast<uint32_t*>(f + (size_t)SPEC_FLAG_CAP * 4);
-    L.flag.x = reinterpret_cast<float*>(f + (size_t)SPEC_FLAG_CAP * 8);
-    L.flag.cap = SPEC_FLAG_CAP;
+    L.flag.valid = reinterpret_cast<uint32_t*>(f + (size_t)fcap * 4);
+    L.flag.x = reinterpret_cast<float*>(f + (size_t)fcap * 8);
+    L.flag.cap = (int)fcap;
     return L;
 }
 
 // total_and_overflow [1] <- max(flagged points / their capacity, overflow records / their capacity) scaled to the flagged capacity:
 // anything above ia_spec_rows_overflow_capacity() means results were lost and the caller redoes the batch through is_valid + K9
-__global__ void rows_report_kernel(const int32_t* __restrict__ counts, int32_t* __restrict__ out)
+__global__ void rows_report_kernel(const int32_t* __restrict__ counts, int flag_cap, int32_t* __restrict__ out)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = counts[0] > SPEC_OVF_CAP ? SPEC_FLAG_CAP + 1 : counts[1];
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = counts[0] > SPEC_OVF_CAP ? flag_cap + 1 : counts[1];
 }
 
 IA_EXPORT int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
@@ -1420,7 +1436,7 @@ IA_EXPORT int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, c
 {
     IA_REQUIRE(N * I < ((int64_t)1 << 31), "ia_fuse_broyden_spec_rows: N * I must stay below 2^31");
     hipStream_t s = (hipStream_t)stream;
-    OvfLayout o = ovf_layout(ovf_scratch);
+    OvfLayout o = ovf_layout(ovf_scratch, N);
     (void)hipMemsetAsync(o.count, 0, 2 * sizeof(int32_t), s);
     if (N == 0) {
         (void)hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(int32_t), s);
@@ -1435,11 +1451,11 @@ IA_EXPORT int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, c
     r = ia_exclusive_scan_i32(cnt, start, total_and_overflow, N, scan_tmp, stream);
     if (r != IA_OK) return r;
     // [1] = number of points redone exactly; the caller compares it with ia_spec_rows_overflow_capacity()
-    rows_report_kernel<<<1, 64, 0, s>>>(o.count, total_and_overflow + 1);
+    rows_report_kernel<<<1, 64, 0, s>>>(o.count, o.flag.cap, total_and_overflow + 1);
     return ia::check_launch("ia_fuse_broyden_spec_rows(report)");
 }
 
-IA_EXPORT int ia_spec_rows_overflow_capacity(void) { return SPEC_FLAG_CAP; }
+IA_EXPORT int64_t ia_spec_rows_overflow_capacity(int64_t N) { return spec_flag_cap(N); }
 
 IA_EXPORT int ia_deform_rows_pack(int64_t N, int I, const float* x_rows, const int32_t* cnt, const uint32_t* meta, const int32_t* start,
                                   const int32_t* ovf_head, const void* ovf_scratch, float* cand_x, int32_t* cand_src,
@@ -1448,7 +1464,7 @@ IA_EXPORT int ia_deform_rows_pack(int64_t N, int I, const float* x_rows, const i
     if (N == 0) return IA_OK;
     IA_REQUIRE(cand_x != x_rows, "ia_deform_rows_pack: cand_x must not alias x_rows");
     IA_REQUIRE((norm_center == nullptr) == (norm_scale == nullptr), "ia_deform_rows_pack: norm_center and norm_scale go together");
-    OvfLayout o = ovf_layout(const_cast<void*>(ovf_scratch));
+    OvfLayout o = ovf_layout(const_cast<void*>(ovf_scratch), N);
     rows_pack_kernel<<<ia::cdiv(N, THREADS), THREADS, 0, (hipStream_t)stream>>>(N, I, x_rows, cnt, meta, start, ovf_head, o.rec, o.x, o.keep,
                                                                                 cand_x, cand_src, norm_center, norm_scale);
     return ia::check_launch("ia_deform_rows_pack");

@@ -182,15 +182,18 @@ class SNARFDeformer:
         Jinv = torch.empty((1, P, I, 3, 3), device=dev) if want_jinv else None
         fwd = torch.empty((1, P, I, 3, 3), device=dev) if want_fwd else None
         cnt, meta, start, ovf_head = (torch.empty(P, dtype=torch.int32, device=dev) for _ in range(4))
-        if getattr(self, "_ovf_scratch", None) is None or self._ovf_scratch.device != dev:
-            self._ovf_scratch = torch.empty(int(lib.ia_spec_rows_overflow_bytes()), dtype=torch.uint8, device=dev)
-            self._ovf_cap = int(lib.ia_spec_rows_overflow_capacity())
+        # overflow records + the list of points the kernel redoes with the filter off (1 / 64 of the batch): a grow-only work area
+        self._ovf_scratch = L.scratch("spec_rows", int(lib.ia_spec_rows_overflow_bytes(L.i64(P))), dev)
+        self._ovf_cap = int(lib.ia_spec_rows_overflow_capacity(L.i64(P)))
         tot = torch.empty(2, dtype=torch.int32, device=dev)
         fast_snarf.fuse_broyden_spec_rows(x_rows, pts.reshape(1, P, 3), fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs, self.init_bones,
                                           Jinv, cnt, meta, start, ovf_head, self._ovf_scratch, tot, self.offset_kernel, self.scale_kernel,
                                           1e-5, 1e-1, self.spec_eps, fwd_J=fwd, counters=self.spec_counters, order=order)
         Q, n_over = tot.tolist()                                     # the one read-back of the call
         self.last_overflow_records = n_over                          # points the kernel searched again with the filter off
+        if os.environ.get("IA_DEBUG_FLAGGED"):
+            import sys
+            print(f"[spec rows] P={P} Q={Q} redone={n_over} ({n_over / max(P, 1):.2e}) cap={self._ovf_cap}", file=sys.stderr)
         if n_over > self._ovf_cap:
             # more points to redo than the flagged list holds (never seen): this batch goes through is_valid + K9 instead
             del x_rows, cnt, meta, start, Jinv, fwd

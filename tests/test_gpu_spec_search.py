@@ -161,7 +161,7 @@ def test_points_that_run_out_of_row_slots_are_redone_exactly(march, monkeypatch)
     here, some with four and more survivors): the packed candidate lists must equal exact search + K9 + pack for EVERY point."""
     SP, rs, pts, _ = march
     dfm = rs.deformer
-    sub = pts[:1_500_000].contiguous()
+    sub = pts[:250_000].contiguous()                                 # a fifth of the points has a second root: stays inside the list of redone points
     old = dfm.spec_eps
     try:
         dfm.spec_eps = 0.0
@@ -173,8 +173,8 @@ def test_points_that_run_out_of_row_slots_are_redone_exactly(march, monkeypatch)
     monkeypatch.setenv("IA_SPEC_TEST_SLOTS", "1")
     got = dfm._candidates(sub, with_src=True)
     monkeypatch.delenv("IA_SPEC_TEST_SLOTS")
-    assert dfm.last_overflow_records > 10_000, dfm.last_overflow_records
-    assert int(got[2].max()) >= 4                                     # some point has more survivors than the row holds
+    assert 10_000 < dfm.last_overflow_records <= dfm._ovf_cap, (dfm.last_overflow_records, dfm._ovf_cap)      # redone in the kernel, not by the fallback
+    assert int(got[2].max()) >= 3
     diff = int((got[2] != want[2]).sum())
     assert diff <= 2, diff                                            # counts per point (the filter itself may differ on ~1e-7 of the points)
     if diff == 0:
