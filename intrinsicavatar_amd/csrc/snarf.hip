@@ -1368,6 +1368,8 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
     }
     IA_REQUIRE(n_chunks < ((int64_t)1 << 31) && (N >> log2c) / grid < ((int64_t)1 << (30 - log2c)), "early-filter search: stream positions must fit 31 bits");
     const int pts = log2c;
+    int wg_env = THREADS;
+    if (const char* e = getenv("IA_BR_SPEC_WG")) { const int v = atoi(e); if (v == 64 || v == 128) wg_env = v; }
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* c = reinterpret_cast<unsigned long long*>(counters);
     int slots = SPEC_ROOTS;                                              // test hook: fewer recorded roots / row slots => more points take the exact redo
@@ -1376,6 +1378,17 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
     broyden_spec_kernel<COUNT, PACK><<<grid, THREADS, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,         \
                                                                cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J, pts, c, cnt, \
                                                                meta, flag, slots, order)
+    if (pack && !counters && wg_env != THREADS) {
+        // A / B: smaller workgroups (one point per lane each): IA_BR_SPEC_WG = 64 | 128, chunk = the workgroup's lanes
+        if (wg_env == 64)
+            broyden_spec_kernel<false, true, 64><<<(int)((N + 63) / 64), 64, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold,
+                                                                                     dvg_threshold, eps, x, J_inv, is_valid, fwd_J, 6, c, cnt, meta, flag, slots, order);
+        else
+            broyden_spec_kernel<false, true, 128><<<(int)((N + 127) / 128), 128, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,
+                                                                                         cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J, 7, c, cnt, meta, flag,
+                                                                                         slots, order);
+        return ia::check_launch(what);
+    }
     if (pack) { if (counters) IA_SPEC_LAUNCH(true, true); else IA_SPEC_LAUNCH(false, true); }
     else { if (counters) IA_SPEC_LAUNCH(true, false); else IA_SPEC_LAUNCH(false, false); }
 #undef IA_SPEC_LAUNCH
