@@ -87,7 +87,9 @@ int ia_traverse_grids_fill(
  * fall back to the two-phase protocol above.  The flag arrays need NOT be zeroed.  sm_t_starts / sm_t_ends (both or
  * neither): the interval ends per SAMPLE, i.e. iv_vals[iv_is_left] / iv_vals[iv_is_right] as every caller of traverse_grids
  * forms them next (occ_grid sampling, models/intrinsic_avatar.py:396-428), without the two boolean-mask gathers.  scratch:
- * ia_traverse_fused_scratch_bytes(n_rays) bytes. */
+ * ia_traverse_fused_scratch_bytes(n_rays) bytes.  termination_planes [n_rays] or NULL: with NULL a ray's walk ends where it leaves
+ * the cell box of the OCCUPIED cells (nothing is emitted beyond it; the plane -- t after the last, empty cells -- is the only output
+ * that needs the rest of the walk); intervals / samples are identical either way. */
 int64_t ia_traverse_fused_scratch_bytes(int64_t n_rays);
 int ia_traverse_grids_fused(int64_t n_rays, const float* rays_o, const float* rays_d, const uint32_t* grid_bits,
                             int rx, int ry, int rz, const float* aabb, const float* near_planes,

@@ -437,7 +437,7 @@ __device__ __forceinline__ float catch_up(float t, float step, float half, float
 template <class Sink>
 __device__ __forceinline__ float dda_walk_fast(const float o[3], const float d[3], const float aabb[6], int rx, int ry,
                                                int rz, float near_plane, float far_plane, float step, const uint32_t* s_bits,
-                                               Sink& sink)
+                                               Sink& sink, const int* occ_box = nullptr /* LDS: cell box of the occupied cells, lo[3] hi[3] */)
 {
     const int res[3] = {rx, ry, rz};
     float t_last = near_plane;
@@ -464,6 +464,21 @@ __device__ __forceinline__ float dda_walk_fast(const float o[3], const float d[3
         stp[a] = (int)sf;
         delta[a] = (d[a] == 0.0f) ? this_tmax : vs / d[a] * sf;
         ovf[a] = fin + stp[a];
+    }
+    if (occ_box) {
+        // Nothing is emitted outside the box of the OCCUPIED cells: a ray that is beyond it on some axis and does not move back can stop,
+        // and the walk of every other ray ends when it steps out of it (the per-axis end index is tightened: no extra test in the cell loop).
+        // Only the termination plane -- t_last after the last, empty cells -- needs the rest of the walk: callers that want it pass no box.
+        bool dead = false;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const int lo = occ_box[a], hi = occ_box[3 + a];
+            const int last = ovf[a] - stp[a];                 // the walk visits cur[a] .. last on this axis, monotonically
+            dead = dead || (stp[a] >= 0 ? (cur[a] > hi || last < lo) : (cur[a] < lo || last > hi));
+            if (stp[a] > 0) ovf[a] = min(ovf[a], hi + 1);
+            else if (stp[a] < 0) ovf[a] = max(ovf[a], lo - 1);
+        }
+        if (dead) return t_last;
     }
     // the stretch in front of the box: every lane does it here, together (closed-form jump), so the divergent code in
     // the cell loop below stays tiny; `pending` = max of the deferred empty-cell thresholds inside the box
@@ -501,6 +516,35 @@ __device__ __forceinline__ float dda_walk_fast(const float o[3], const float d[3
     }
     while (!(t_last + half >= pending)) t_last += step;
     return t_last;
+}
+
+// cell box of the occupied cells of the staged bit grid -> s_box[6] = lo x, y, z, hi x, y, z (lo > hi: nothing is occupied).  A word holds 32
+// consecutive z of one (x, y) when rz is a multiple of 32 (the reference's 64^3 grids); other shapes keep the whole grid.  Call between
+// two barriers: after the grid is staged, before the first walk.
+__device__ __forceinline__ void occupied_cell_box(const uint32_t* s_bits, int rx, int ry, int rz, int* s_box, int tid, int nthreads)
+{
+    if (tid < 3) s_box[tid] = 0x7fffffff;
+    else if (tid < 6) s_box[tid] = -1;
+    __syncthreads();
+    if ((rz & 31) != 0) {
+        if (tid == 0) { s_box[0] = 0; s_box[1] = 0; s_box[2] = 0; s_box[3] = rx - 1; s_box[4] = ry - 1; s_box[5] = rz - 1; }
+        return;
+    }
+    const int n_words = (rx * ry * rz) >> 5, wz = rz >> 5;
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+    for (int w = tid; w < n_words; w += nthreads) {
+        const uint32_t v = s_bits[w];
+        if (v == 0u) continue;
+        const int col = w / wz, zb = (w - col * wz) << 5;
+        const int x = col / ry, y = col - x * ry;
+        lo[0] = min(lo[0], x); hi[0] = max(hi[0], x);
+        lo[1] = min(lo[1], y); hi[1] = max(hi[1], y);
+        lo[2] = min(lo[2], zb + __builtin_ctz(v)); hi[2] = max(hi[2], zb + 31 - __builtin_clz(v));
+    }
+    if (hi[0] >= 0) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { atomicMin(&s_box[a], lo[a]); atomicMax(&s_box[3 + a], hi[a]); }
+    }
 }
 
 __device__ __forceinline__ uint64_t ts_load(const uint64_t* p)
@@ -543,6 +587,10 @@ __global__ __launch_bounds__(TR_THREADS) void traverse_fused_kernel(
     float aabb[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) aabb[k] = aabb_g[k];
+    __shared__ int s_box[6];
+    __syncthreads();
+    occupied_cell_box(s_bits, rx, ry, rz, s_box, threadIdx.x, TR_THREADS);
+    const int* const occ_box = term_planes ? nullptr : s_box;
     // persistent workgroups: the bit grid is staged once, tiles are pulled off the ticket counter until none is left
     // (per-tile staging + workgroup launch were 141 us of the 674 us of a 2 M-ray batch)
   for (;;) {
@@ -563,7 +611,7 @@ __global__ __launch_bounds__(TR_THREADS) void traverse_fused_kernel(
         for (int k = 0; k < 3; k++) { o[k] = rays_o[tid * 3 + k]; d[k] = rays_d[tid * 3 + k]; }
         near_plane = near_planes[tid]; far_plane = far_planes[tid];
         t_term = (cone_angle == 0.0f)
-                     ? dda_walk_fast(o, d, aabb, rx, ry, rz, near_plane, far_plane, step_size, s_bits, sink)
+                     ? dda_walk_fast(o, d, aabb, rx, ry, rz, near_plane, far_plane, step_size, s_bits, sink, occ_box)
                      : dda_walk(o, d, aabb, rx, ry, rz, near_plane, far_plane, step_size, cone_angle, s_bits, sink);
         sink.finish();
     }
@@ -747,6 +795,10 @@ __global__ __launch_bounds__(ST_THREADS) void traverse_sorted_kernel(
     float aabb[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) aabb[k] = aabb_g[k];
+    __shared__ int s_box[6];
+    __syncthreads();
+    occupied_cell_box(s_bits, rx, ry, rz, s_box, t, ST_THREADS);
+    const int* const occ_box = term_planes ? nullptr : s_box;
   for (;;) {
     __syncthreads();                       // previous tile fully written; LDS descriptors free
     if (t == 0) s_tile = atomicAdd(ticket, 1u);
@@ -798,7 +850,7 @@ __global__ __launch_bounds__(ST_THREADS) void traverse_sorted_kernel(
             const float d[3] = {rays_d[g * 3], rays_d[g * 3 + 1], rays_d[g * 3 + 2]};
             const float near_plane = near_planes[g], far_plane = far_planes[g];
             const float t_term = (cone_angle == 0.0f)
-                                     ? dda_walk_fast(o, d, aabb, rx, ry, rz, near_plane, far_plane, step_size, s_bits, sink)
+                                     ? dda_walk_fast(o, d, aabb, rx, ry, rz, near_plane, far_plane, step_size, s_bits, sink, occ_box)
                                      : dda_walk(o, d, aabb, rx, ry, rz, near_plane, far_plane, step_size, cone_angle, s_bits, sink);
             sink.finish();
             if (term_planes) term_planes[g] = t_term;

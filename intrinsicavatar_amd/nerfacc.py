@@ -82,7 +82,9 @@ def traverse_grids(
     method: Optional[str] = None,        # extension: "fused" (single launch, default) | "two_pass"; env IA_TRAVERSE overrides
     incoherent: bool = False,            # extension: hint -- neighbouring rays point anywhere (secondary rays): the fused kernel walks
                                          # each tile's rays in order of their box-crossing span; outputs are identical either way
-) -> Tuple[RayIntervals, RaySamples, Tensor]:
+    termination_planes: bool = True,     # extension: False -> the third result is None and the fused kernel stops a ray where it leaves the
+                                         # box of the occupied cells (intervals / samples identical); render_step never reads the planes
+) -> Tuple[RayIntervals, RaySamples, Optional[Tensor]]:
     """nerfacc.traverse_grids (call sites temporal_occ_grid.py:166-175, intrinsic_avatar.py:84-93).
 
     One grid level (m == 1), which is what the reference always passes."""
@@ -112,7 +114,7 @@ def traverse_grids(
     # 1.20 ms), the two-phase protocol for one 540x540 frame of primary rays (0.14 vs 0.16 ms)
     method = method or os.environ.get("IA_TRAVERSE") or ("fused" if n_rays >= FUSED_MIN_RAYS else "two_pass")
     if method == "fused" and n_rays > 0 and step_size > 0 and cone_angle == 0.0:
-        out = _traverse_fused(args, n_rays, aabbs[0], step_size, max_extent, dev, incoherent)
+        out = _traverse_fused(args, n_rays, aabbs[0], step_size, max_extent, dev, incoherent, termination_planes)
         if out is not None:
             return out
 
@@ -140,14 +142,14 @@ def traverse_grids(
                              is_left=iv_flags[0], is_right=iv_flags[1])
     samples = RaySamples(vals=sm_vals, packed_info=pinfo[1], ray_indices=sm_ray,
                          is_valid=torch.ones(S, dtype=torch.bool, device=dev))
-    return intervals, samples, term
+    return intervals, samples, (term if termination_planes else None)
 
 
 FUSED_MIN_RAYS = 1 << 19
 _AABB_DIAG = {}
 
 
-def _traverse_fused(args, n_rays, aabb, step_size, max_extent, dev, incoherent=False):
+def _traverse_fused(args, n_rays, aabb, step_size, max_extent, dev, incoherent=False, termination_planes=True):
     """single-launch traversal into capacity-sized buffers (ia_traverse_grids_fused); None = capacity exceeded."""
     key = (aabb.data_ptr(), aabb._version)
     if key not in _AABB_DIAG:            # one tiny D2H copy per grid, not per call
@@ -169,7 +171,7 @@ def _traverse_fused(args, n_rays, aabb, step_size, max_extent, dev, incoherent=F
     sm_vals = torch.empty(cap_s, dtype=torch.float32, device=dev)
     sm_ray = torch.empty(cap_s, dtype=torch.int64, device=dev)
     sm_ends = torch.empty((2, cap_s), dtype=torch.float32, device=dev)
-    term = torch.empty(n_rays, dtype=torch.float32, device=dev)
+    term = torch.empty(n_rays, dtype=torch.float32, device=dev) if termination_planes else None
     pinfo = torch.empty((2, n_rays, 2), dtype=torch.int64, device=dev)
     L.check(lib.ia_traverse_grids_fused(*args, L.ptr(scratch), L.i64(cap_e), L.i64(cap_s), L.ptr(totals), L.ptr(pinfo[0]),
                                         L.ptr(pinfo[1]), L.ptr(iv_vals), L.ptr(iv_flags[0]), L.ptr(iv_flags[1]), L.ptr(iv_ray),
@@ -351,6 +353,6 @@ class OccGridEstimator(torch.nn.Module):
             near_planes += torch.rand_like(near_planes) * render_step_size
         intervals, samples, _ = traverse_grids(rays_o, rays_d, self.binaries, self.aabbs, near_planes=near_planes,
                                                far_planes=far_planes, step_size=render_step_size,
-                                               cone_angle=cone_angle)
+                                               cone_angle=cone_angle, termination_planes=False)
         t_starts, t_ends = samples.interval_ends(intervals)
         return intervals, samples.ray_indices, t_starts, t_ends

@@ -92,7 +92,7 @@ class TemporalOccGridEstimator(torch.nn.Module):
         intervals, samples, _ = nerfacc.traverse_grids(rays_o, rays_d, self.binaries[lvl:lvl + 1], self.aabbs[lvl:lvl + 1],
                                                        near_planes=near_planes, far_planes=far_planes,
                                                        step_size=render_step_size, cone_angle=cone_angle,
-                                                       grid_bits=self._grid_bits(lvl))
+                                                       grid_bits=self._grid_bits(lvl), termination_planes=False)
         return (intervals, samples.ray_indices) + samples.interval_ends(intervals)
 
     @torch.no_grad()

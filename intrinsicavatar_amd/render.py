@@ -140,7 +140,7 @@ class RenderStep:
         if jitter is not None:
             near_planes = near_planes + jitter * self.render_step_size
         intervals, samples, _ = nerfacc.traverse_grids(rays_o, rays_d, self.binaries, self.aabbs, near_planes, far_planes,
-                                                       self.render_step_size, 0.0, grid_bits=self.grid_bits)
+                                                       self.render_step_size, 0.0, grid_bits=self.grid_bits, termination_planes=False)
         stats = dict(n_edges0=intervals.vals.shape[0], n_samples0=samples.vals.shape[0])
         # -- 3. importance resampling.  Host syncs are kept to the data-dependent sizes: boolean-mask indexing (one
         # nonzero + sync per use in the reference) is replaced by ONE index list per edge set, and the pairing
@@ -271,7 +271,7 @@ class RenderStep:
             m = ro.shape[0]
             intervals, samples, _ = nerfacc.traverse_grids(
                 ro, rd, self.binaries, self.aabbs, torch.full((m,), near, device=dev), torch.full((m,), far, device=dev),
-                step, 0.0, grid_bits=self.grid_bits, max_extent=far - near, incoherent=True)
+                step, 0.0, grid_bits=self.grid_bits, max_extent=far - near, incoherent=True, termination_planes=False)
             if samples.vals.shape[0] > 4 * self.MAX_SEARCH_POINTS and m > 1:
                 del intervals, samples
                 work += [(c0 + m // 2, c1), (c0, c0 + m // 2)]

@@ -164,6 +164,49 @@ def test_traverse_span_sorted_tiles_equal_the_ray_order_kernel(ops, monkeypatch,
             assert int((a[0].packed_info[:, 1] - a[1].packed_info[:, 1]).max()) > 4      # rays with more than 4 runs
 
 
+@pytest.mark.parametrize("incoherent", [False, True])
+def test_traverse_without_termination_planes_stops_at_the_occupied_box(ops, incoherent):
+    """termination_planes=False (what render_step asks for): the fused kernels end a ray's walk where it leaves the cell box of the
+    occupied cells.  Every interval / sample tensor must equal the full walk's: grids whose occupied cells fill a small part of the
+    box, touch its faces, are a single cell, are empty; rz not a multiple of 32 (whole-grid box); rays starting inside, beyond and
+    beside the occupied region, axis-parallel rays (d == 0 on two axes)."""
+    rng = np.random.default_rng(11)
+    n = 200_003
+    aabb = np.array([-1.0, -1.1, -0.9, 1.0, 0.9, 1.1], np.float32)
+    o = (rng.random((n, 3)).astype(np.float32) * 2.6 - 1.3)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:3000] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 3000)] * rng.choice([-1.0, 1.0], (3000, 1)).astype(np.float32)
+    near = (rng.random(n) * 0.05).astype(np.float32)
+    far = (0.2 + rng.random(n) * 2.5).astype(np.float32)
+    tr = ops["nerfacc"].traverse_grids
+
+    def region(shape, lo, hi, p):
+        g = np.zeros(shape, bool)
+        sl = tuple(slice(a, b + 1) for a, b in zip(lo, hi))
+        g[sl] = rng.random(g[sl].shape) < p
+        g[tuple(lo)] = g[tuple(hi)] = True
+        return g
+
+    grids = (("body", region((64, 64, 64), (20, 8, 25), (44, 57, 40), 0.3)),
+             ("corner", region((64, 64, 64), (0, 0, 0), (9, 63, 5), 0.5)),
+             ("far_corner", region((64, 64, 64), (50, 60, 33), (63, 63, 63), 0.5)),
+             ("one_cell", region((64, 64, 64), (31, 32, 33), (31, 32, 33), 1.0)),
+             ("empty", np.zeros((64, 64, 64), bool)),
+             ("full", np.ones((32, 32, 32), bool)),
+             ("rz48", region((32, 32, 48), (5, 6, 7), (20, 21, 40), 0.4)))
+    for name, grid in grids:
+        args = (T(o), T(d), T(grid)[None], T(aabb)[None], T(near), T(far), 2.0 / 63, 0.0)
+        a = tr(*args, method="fused", max_extent=2.8, incoherent=incoherent)
+        b = tr(*args, method="fused", max_extent=2.8, incoherent=incoherent, termination_planes=False)
+        assert a[2] is not None and b[2] is None
+        assert (a[1].vals.numel() > 0) == (name != "empty") and (a[1].vals.numel() > 2_000 or name in ("one_cell", "empty")), name
+        for k in ("vals", "packed_info", "ray_indices", "is_left", "is_right"):
+            assert torch.equal(getattr(a[0], k), getattr(b[0], k)), (name, "intervals", k)
+        for k in ("vals", "packed_info", "ray_indices", "t_starts", "t_ends"):
+            assert torch.equal(getattr(a[1], k), getattr(b[1], k)), (name, "samples", k)
+
+
 def test_traverse_properties_full_size(ops):
     """540x540 (BASELINE config 2) -- size-independent properties instead of the (slow) oracle."""
     from intrinsicavatar_amd import synthetic as S

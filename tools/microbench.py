@@ -96,13 +96,15 @@ def main():
         def fused():
             L.check(lib.ia_traverse_grids_fused(*a_, L.ptr(fs), L.i64(ce), L.i64(cs), L.ptr(totals), L.ptr(b_pi[0]), L.ptr(b_pi[1]),
                                                 L.ptr(b_iv), L.ptr(b_fl[0]), L.ptr(b_fl[1]), L.ptr(b_ir), L.ptr(b_sv), L.ptr(b_sr),
-                                                L.ptr(b_t), L.ptr(None), L.ptr(None), L.i32(1 if "secondary" in tag else 0), st))
+                                                L.ptr(None if "no_planes" in tag else b_t), L.ptr(None), L.ptr(None),
+                                                L.i32(1 if "secondary" in tag else 0), st))
         us = timeit(fused)
         E_, S__, ovf = totals.tolist()
         ab = 48 * m + 16 * S__ + 14 * E_
         res[tag] = dict(n_rays=m, E=E_, S=S__, overflow=ovf, us=us, alg_bytes=ab, gbps=ab / us / 1e3, frac_of_8TBps=ab / us / 1e3 / 8000)
 
     fused_case("traverse_fused_primary", ro, rd, near, far, step, 4.3301)
+    fused_case("traverse_fused_primary_no_planes", ro, rd, near, far, step, 4.3301)       # what render_step asks for: walk ends at the occupied box
     M = int(os.environ.get("IA_SECONDARY", "2097152"))
     gsec = torch.Generator().manual_seed(3)
     occ = torch.nonzero(binaries[0])                     # [K,3] occupied cells
@@ -113,6 +115,7 @@ def main():
     so = (aabb0[:3] + (pick.float() + torch.rand((M, 3), generator=gsec).to(DEV)) * cellsz).contiguous()
     sd = torch.nn.functional.normalize(torch.randn((M, 3), generator=gsec), dim=-1).to(DEV).contiguous()
     fused_case("traverse_fused_secondary", so, sd, torch.zeros(M, device=DEV), torch.full((M,), 1.5, device=DEV), 1.5 / 63, 1.5)
+    fused_case("traverse_fused_secondary_no_planes", so, sd, torch.zeros(M, device=DEV), torch.full((M,), 1.5, device=DEV), 1.5 / 63, 1.5)
     # ---- what bounds the secondary march: the same 2 M rays (a) through an EMPTY grid -- set-up + the DDA over every
     # cell of the crossing, nothing emitted --, (b) started far outside the box pointing away -- set-up only --, (c) through a FULL grid
     # -- every step emits a sample.  (a) is the floor of any kernel that walks the cell sequence per ray; see DESIGN 4.2.
