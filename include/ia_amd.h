@@ -188,6 +188,20 @@ int ia_fg_compact(int64_t n_rays, const int32_t* resampled_packed_info, const ui
                   const int32_t* cnt, const int32_t* start, int64_t* ray_indices, float* t_starts, float* t_ends, int32_t* out_packed_info,
                   ia_stream_t stream);
 
+/* The samples of an interval list -- what forward_ forms from RayIntervals after every re-sampling (models/intrinsic_avatar.py:1242-1247:
+ * t_starts = vals[is_left], t_ends = vals[is_right], ray_indices[is_left], pack_info; and alpha_fn :1000-1030) -- as flag -> scan -> fill
+ * over the EDGES, one size read-back: ia_interval_samples_count: pos i32 [n_edges] = exclusive scan of is_left, *total = S (scan_tmp:
+ * ia_scan_tmp_bytes(n_edges)); ia_interval_samples_fill: left_idx i64 [S] (or NULL) = indices of the left edges, t_starts / t_ends [S]
+ * (right edge = left edge + 1), sample_ray_indices i64 [S], sample_packed_info i32 [n_rays,2] = pack_info(sample_ray_indices, n_rays).
+ * ia_samples_to_edges: out[e] = is_left[e] ? sample_vals[pos[e]] : fill  (`x = fill; x[is_left] = sample_vals`, :1022-1025). */
+int ia_interval_samples_count(int64_t n_edges, const uint8_t* is_left, int32_t* pos, int32_t* total, void* scan_tmp, ia_stream_t stream);
+int ia_interval_samples_fill(int64_t n_rays, int64_t n_edges, const int32_t* edge_packed_info, const float* vals,
+                             const int64_t* ray_indices, const uint8_t* is_left, const int32_t* pos, const int32_t* total,
+                             int64_t* left_idx, float* t_starts, float* t_ends, int64_t* sample_ray_indices,
+                             int32_t* sample_packed_info, ia_stream_t stream);
+int ia_samples_to_edges(int64_t n_edges, const uint8_t* is_left, const int32_t* pos, const float* sample_vals, float fill, float* out,
+                        ia_stream_t stream);
+
 /* ------------------------------------------------------------------------- */
 /* fast-SNARF deformer kernels (models/deformers/fast_snarf/deformer_torch.py:86-125,
  * cuda/precompute/precompute.cu:24-103, cuda/fuse_kernel/fuse_cuda_kernel_fast.cu:250-452,

@@ -355,6 +355,47 @@ __global__ __launch_bounds__(THREADS) void rs34_intervals_kernel(int64_t n_out, 
 // The caller of ray_resampling_sdf_fine keeps the foreground intervals only (models/intrinsic_avatar.py:516-528: three
 // boolean-mask gathers + unpack_info, then pack_info of the kept ray indices).  A ray's re-samples are consecutive, so: count per
 // ray -> scan over RAYS -> every ray copies its kept intervals to its place and writes its own packed_info row.
+// ---- samples of an interval (edge) list: element-parallel over EDGES (a scan of the left-edge flags places every sample; every
+// output is written by consecutive lanes).  pos[e] = number of left edges before e.
+__global__ __launch_bounds__(THREADS) void left_flags_kernel(int64_t n_edges, const uint8_t* __restrict__ is_left, int32_t* __restrict__ flag)
+{
+    const int64_t e = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (e < n_edges) flag[e] = is_left[e] ? 1 : 0;
+}
+
+__global__ __launch_bounds__(THREADS) void interval_samples_kernel(int64_t n_rays, int64_t n_edges, const int32_t* __restrict__ edge_pinfo,
+                                                                   const float* __restrict__ vals, const int64_t* __restrict__ ray_indices,
+                                                                   const uint8_t* __restrict__ is_left, const int32_t* __restrict__ pos,
+                                                                   const int32_t* __restrict__ total, int64_t* __restrict__ left_idx,
+                                                                   float* __restrict__ t_starts, float* __restrict__ t_ends,
+                                                                   int64_t* __restrict__ out_ray, int32_t* __restrict__ out_pinfo)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i < n_edges && is_left[i]) {
+        const int32_t p = pos[i];
+        if (left_idx) left_idx[p] = i;
+        t_starts[p] = vals[i];
+        t_ends[p] = vals[i + 1 < n_edges ? i + 1 : i];                 // a left edge is followed by its right edge
+        out_ray[p] = ray_indices[i];
+    }
+    if (i < n_rays) {                                                  // pack_info of the samples' ray indices
+        // (start, count) as lib/nerfacc/pack.py:72-75 forms them: start = samples in front of the ray, also for a ray without samples
+        const int32_t s0 = edge_pinfo[2 * i], c = edge_pinfo[2 * i + 1];
+        const int32_t a = (s0 < n_edges) ? pos[s0] : *total;
+        const int32_t b = ((int64_t)s0 + c < n_edges) ? pos[s0 + c] : *total;
+        out_pinfo[2 * i] = a;
+        out_pinfo[2 * i + 1] = b - a;
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void samples_to_edges_kernel(int64_t n_edges, const uint8_t* __restrict__ is_left,
+                                                                   const int32_t* __restrict__ pos, const float* __restrict__ sample_vals,
+                                                                   float fill, float* __restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (e < n_edges) out[e] = is_left[e] ? sample_vals[pos[e]] : fill;
+}
+
 __global__ __launch_bounds__(THREADS) void fg_count_kernel(int64_t n_rays, const int32_t* __restrict__ rpi, const uint8_t* __restrict__ is_fg,
                                                             int32_t* __restrict__ cnt)
 {
@@ -602,4 +643,40 @@ IA_EXPORT int ia_fg_compact(int64_t n_rays, const int32_t* resampled_packed_info
     fg_compact_kernel<<<ia::cdiv(n_rays, THREADS), THREADS, 0, (hipStream_t)stream>>>(n_rays, resampled_packed_info, is_fg, starts, ends, cnt,
                                                                                       start, ray_indices, t_starts, t_ends, out_packed_info);
     return ia::check_launch("ia_fg_compact");
+}
+
+// the samples of an interval list (models/intrinsic_avatar.py:1242-1247 and :1000-1030: vals[is_left], vals[is_right],
+// ray_indices[is_left], pack_info) as flag -> scan -> fill over the EDGES: pos int32 [n_edges] (exclusive scan of is_left), *total = S
+IA_EXPORT int ia_interval_samples_count(int64_t n_edges, const uint8_t* is_left, int32_t* pos, int32_t* total, void* scan_tmp,
+                                        ia_stream_t stream)
+{
+    if (n_edges == 0) return ia_exclusive_scan_i32(nullptr, nullptr, total, 0, scan_tmp, stream);
+    IA_REQUIRE(n_edges < ((int64_t)1 << 31), "ia_interval_samples_count: n_edges must be below 2^31");
+    left_flags_kernel<<<ia::cdiv(n_edges, THREADS), THREADS, 0, (hipStream_t)stream>>>(n_edges, is_left, pos);
+    int r = ia::check_launch("ia_interval_samples_count");
+    if (r != IA_OK) return r;
+    return ia_exclusive_scan_i32(pos, pos, total, n_edges, scan_tmp, stream);
+}
+
+IA_EXPORT int ia_interval_samples_fill(int64_t n_rays, int64_t n_edges, const int32_t* edge_packed_info, const float* vals,
+                                       const int64_t* ray_indices, const uint8_t* is_left, const int32_t* pos, const int32_t* total,
+                                       int64_t* left_idx, float* t_starts, float* t_ends, int64_t* sample_ray_indices,
+                                       int32_t* sample_packed_info, ia_stream_t stream)
+{
+    const int64_t n = n_rays > n_edges ? n_rays : n_edges;
+    if (n == 0) return IA_OK;
+    interval_samples_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n_rays, n_edges, edge_packed_info, vals, ray_indices,
+                                                                                      is_left, pos, total, left_idx, t_starts, t_ends,
+                                                                                      sample_ray_indices, sample_packed_info);
+    return ia::check_launch("ia_interval_samples_fill");
+}
+
+// out[e] = is_left[e] ? sample_vals[pos[e]] : fill -- a per-sample quantity back on the edge list (the scatter of alpha_fn's
+// `sdf[is_left] = ...`, models/intrinsic_avatar.py:1017-1027, as a gather with coalesced stores)
+IA_EXPORT int ia_samples_to_edges(int64_t n_edges, const uint8_t* is_left, const int32_t* pos, const float* sample_vals, float fill,
+                                  float* out, ia_stream_t stream)
+{
+    if (n_edges == 0) return IA_OK;
+    samples_to_edges_kernel<<<ia::cdiv(n_edges, THREADS), THREADS, 0, (hipStream_t)stream>>>(n_edges, is_left, pos, sample_vals, fill, out);
+    return ia::check_launch("ia_samples_to_edges");
 }

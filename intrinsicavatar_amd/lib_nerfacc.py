@@ -190,6 +190,57 @@ def compact_foreground(resampled_packed_info: Tensor, starts: Tensor, ends: Tens
     return ray_indices, ts, te, pinfo
 
 
+class IntervalSamples:
+    """the samples of an interval (edge) list: t_starts / t_ends [S], ray_indices int64 [S], packed_info int32 [n_rays, 2], and `pos`
+    (int32 [n_edges], number of left edges in front of an edge) to carry per-sample values back onto the edges (to_edges)."""
+
+    def __init__(self, is_left, pos, t_starts, t_ends, ray_indices, packed_info):
+        self.is_left, self.pos = is_left, pos
+        self.t_starts, self.t_ends, self.ray_indices, self.packed_info = t_starts, t_ends, ray_indices, packed_info
+
+    def to_edges(self, sample_vals: Tensor, fill: float) -> Tensor:
+        """`x = full(n_edges, fill); x[is_left] = sample_vals` (alpha_fn, models/intrinsic_avatar.py:1022-1025) as a gather."""
+        sv = _f32v(sample_vals)
+        if sv.shape[0] != self.t_starts.shape[0]:
+            raise RuntimeError("to_edges: one value per sample expected")
+        out = torch.empty(self.pos.shape[0], dtype=torch.float32, device=sv.device)
+        L.check(L.lib().ia_samples_to_edges(L.i64(out.shape[0]), L.ptr(self.is_left), L.ptr(self.pos), L.ptr(sv), L.f32(fill), L.ptr(out),
+                                            L.stream()), "ia_samples_to_edges")
+        return out
+
+
+@torch.no_grad()
+def interval_samples(packed_info: Tensor, vals: Tensor, is_left: Tensor, ray_indices: Tensor) -> IntervalSamples:
+    """what forward_ does with a RayIntervals after every re-sampling (models/intrinsic_avatar.py:1242-1247):
+        t_starts = vals[is_left];  t_ends = vals[is_right];  ray_indices = ray_indices[is_left];  pack_info(ray_indices)
+    as flag -> scan -> fill over the edges (ia_interval_samples_count / _fill): one size read-back instead of a nonzero, three gathers
+    and pack_info's own."""
+    packed_info = _i32c(packed_info)
+    vals = _f32v(vals)
+    il = is_left.contiguous()
+    if il.dtype != torch.bool:
+        raise RuntimeError("is_left must be bool")
+    ray_indices = ray_indices.contiguous()
+    if ray_indices.dtype != torch.int64:
+        raise RuntimeError("ray_indices must be int64")
+    n_rays, n_edges, dev = packed_info.shape[0], vals.shape[0], vals.device
+    if il.shape[0] != n_edges or ray_indices.shape[0] != n_edges:
+        raise RuntimeError("vals, is_left and ray_indices must have one entry per edge")
+    lib, st = L.lib(), L.stream()
+    pos = torch.empty(n_edges, dtype=torch.int32, device=dev)
+    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    L.check(lib.ia_interval_samples_count(L.i64(n_edges), L.ptr(il), L.ptr(pos), L.ptr(total), L.ptr(L.scan_tmp(n_edges, dev)), st),
+            "ia_interval_samples_count")
+    S = int(total.item())
+    ts, te = torch.empty(S, dtype=torch.float32, device=dev), torch.empty(S, dtype=torch.float32, device=dev)
+    ray = torch.empty(S, dtype=torch.int64, device=dev)
+    pinfo = torch.empty((n_rays, 2), dtype=torch.int32, device=dev)
+    L.check(lib.ia_interval_samples_fill(L.i64(n_rays), L.i64(n_edges), L.ptr(packed_info), L.ptr(vals), L.ptr(ray_indices), L.ptr(il),
+                                         L.ptr(pos), L.ptr(total), L.ptr(None), L.ptr(ts), L.ptr(te), L.ptr(ray), L.ptr(pinfo), st),
+            "ia_interval_samples_fill")
+    return IntervalSamples(il, pos, ts, te, ray, pinfo)
+
+
 # ----------------------------------------------------------------------------- pack / unpack
 def pack_data(data: Tensor, mask: Tensor) -> Tuple[Tensor, Tensor]:
     """lib/nerfacc/pack.py:12-43 (host-side torch ops in the reference too)."""

@@ -155,24 +155,18 @@ class RenderStep:
                     sdf_merge = torch.where(intervals.is_left, torch.minimum(sdf, nxt), torch.full_like(sdf, 1e10))
                     alphas = laplace_alpha(sdf_merge, self.render_step_size, beta)
                 else:              # alpha_fn: SDF at interval mid-points
-                    il_idx = torch.nonzero(intervals.is_left)[:, 0]
-                    ts, te = vals[il_idx], vals[il_idx + 1]
-                    pts = ray_points(rays_o, rays_d, intervals.ray_indices[il_idx], ts, te)
+                    smp = lib_nerfacc.interval_samples(intervals.packed_info, vals, intervals.is_left, intervals.ray_indices)
+                    pts = ray_points(rays_o, rays_d, smp.ray_indices, smp.t_starts, smp.t_ends)
                     sdf_curr = self._sdf_at(pts)
-                    sdf = torch.full_like(vals, 1e10).index_put_((il_idx,), sdf_curr)
-                    dists = torch.zeros_like(vals).index_put_((il_idx,), te - ts)
-                    alphas = laplace_alpha(sdf, dists, beta)
+                    alphas = laplace_alpha(smp.to_edges(sdf_curr, 1e10), smp.to_edges(smp.t_ends - smp.t_starts, 0.0), beta)
                 weights, _ = nerfacc.render_weight_from_alpha(alphas, packed_info=intervals.packed_info)
                 # K2 + the selection of its reached edges (intrinsic_avatar.py:1211-1226) as count -> scan -> fill kernels
                 rvals, ril, rir, ray_idx, pinfo = lib_nerfacc.ray_resampling_merge_compact(
                     intervals.packed_info, vals, intervals.is_left, intervals.is_right, weights, 16)
                 intervals = RayIntervals(vals=rvals, is_left=ril, is_right=rir, ray_indices=ray_idx, packed_info=pinfo)
         # -- 4.
-        il_idx = torch.nonzero(intervals.is_left)[:, 0]
-        t_starts = intervals.vals[il_idx]
-        t_ends = intervals.vals[il_idx + 1] if il_idx.numel() > 0 else intervals.vals[il_idx]
-        ray_indices = intervals.ray_indices[il_idx]
-        packed_info = lib_nerfacc.pack_info(ray_indices, n_rays)
+        smp = lib_nerfacc.interval_samples(intervals.packed_info, intervals.vals, intervals.is_left, intervals.ray_indices)
+        t_starts, t_ends, ray_indices, packed_info = smp.t_starts, smp.t_ends, smp.ray_indices, smp.packed_info
         stats["n_samples"] = t_starts.shape[0]
         return rays_o, rays_d, far, t_starts, t_ends, ray_indices, packed_info, stats
 

@@ -336,6 +336,39 @@ def test_resampling_vs_golden(ops, golden_dir):
                                                T(g[k + "weights"]), int(g[k + "n"]))
         for a_, b_, nm in zip(got, want, ("vals", "is_left", "is_right", "ray_indices", "packed_info")):
             assert torch.equal(a_, b_), (c, nm)
+        # ... and the samples forward_ forms from the kept edges (models/intrinsic_avatar.py:1242-1247) == the boolean-mask op sequence
+        _check_interval_samples(lib, got[4], got[0], got[1], got[2], got[3], (c, "merge"))
+
+
+def _check_interval_samples(lib, pinfo, vals, is_left, is_right, ray_indices, tag):
+    smp = lib.interval_samples(pinfo, vals, is_left, ray_indices)
+    assert int(is_left.sum()) == int(is_right.sum())
+    assert torch.equal(smp.t_starts, vals[is_left]), tag
+    assert torch.equal(smp.t_ends, vals[is_right]), tag
+    assert torch.equal(smp.ray_indices, ray_indices[is_left]), tag
+    assert torch.equal(smp.packed_info, lib.pack_info(ray_indices[is_left], pinfo.shape[0])), tag
+    x = torch.rand(smp.t_starts.shape[0], device=vals.device)
+    want = torch.full_like(vals, 1e10)
+    want[is_left] = x
+    assert torch.equal(smp.to_edges(x, 1e10), want), tag
+
+
+def test_interval_samples_equal_the_mask_ops_on_a_march(ops):
+    """lib_nerfacc.interval_samples on the edge list of a primary march (rays without edges, rays whose edges hold several runs, the
+    last ray ending the list) and on an empty list."""
+    from intrinsicavatar_amd import synthetic as S
+    sc = S.make_scene(160, 160, pose_seed=1)
+    rays = sc["rays"]
+    n = rays.shape[0]
+    iv, sm, _ = ops["nerfacc"].traverse_grids(T(rays[:, :3]), T(rays[:, 3:6]), T(sc["binaries"])[None], T(sc["aabb"])[None],
+                                              torch.zeros(n, device=DEV), torch.full((n,), 1e10, device=DEV), 4.3301 / 128)
+    assert sm.vals.numel() > 20_000 and int((iv.packed_info[:, 1] == 0).sum()) > 100
+    _check_interval_samples(ops["lib"], iv.packed_info, iv.vals, iv.is_left, iv.is_right, iv.ray_indices, "march")
+    smp = ops["lib"].interval_samples(iv.packed_info, iv.vals, iv.is_left, iv.ray_indices)
+    assert torch.equal(smp.packed_info.long(), sm.packed_info) and torch.equal((smp.t_starts + smp.t_ends) * 0.5, sm.vals)
+    # no edges at all: empty outputs, (0, 0) rows
+    e = ops["lib"].interval_samples(torch.zeros((7, 2), dtype=torch.int32, device=DEV), iv.vals[:0], iv.is_left[:0], iv.ray_indices[:0])
+    assert e.t_starts.numel() == 0 and e.ray_indices.numel() == 0 and int(e.packed_info.abs().sum()) == 0
 
 
 def test_pack_unpack_vs_golden(ops, golden_dir):
