@@ -653,14 +653,14 @@ def count_broyden_fetches(step, dev, dfm):
         orig(x, xd_tgt, voxel, voxel_J, tfs, bone_ids, align_corners, J_inv, is_valid, offset, scale, cvg, dvg, fwd_J=fwd_J)
         stats(xd_tgt, voxel_J, tfs, bone_ids, offset, scale, cvg, dvg, cnt)
 
-    def wrapped_spec(x, xd_tgt, voxel_J, tfs, bone_ids, J_inv, is_valid, offset, scale, cvg, dvg, eps, fwd_J=None, counters=None):
-        orig_spec(x, xd_tgt, voxel_J, tfs, bone_ids, J_inv, is_valid, offset, scale, cvg, dvg, eps, fwd_J=fwd_J, counters=spec)
+    def wrapped_spec(x, xd_tgt, voxel_J, tfs, bone_ids, J_inv, is_valid, offset, scale, cvg, dvg, eps, fwd_J=None, counters=None, cell_tight=None):
+        orig_spec(x, xd_tgt, voxel_J, tfs, bone_ids, J_inv, is_valid, offset, scale, cvg, dvg, eps, fwd_J=fwd_J, counters=spec, cell_tight=cell_tight)
         stats(xd_tgt, voxel_J, tfs, bone_ids, offset, scale, cvg, dvg, cnt_x)
         n_spec_items[0] += xd_tgt.shape[1] * bone_ids.shape[0]
     def wrapped_rows(x, xd_tgt, voxel_J, tfs, bone_ids, J_inv, cnt_, meta, start, oh, osc, tot, offset, scale, cvg, dvg, eps, fwd_J=None, counters=None,
-                     order=None, n_points=None):
+                     order=None, n_points=None, cell_tight=None):
         orig_rows(x, xd_tgt, voxel_J, tfs, bone_ids, J_inv, cnt_, meta, start, oh, osc, tot, offset, scale, cvg, dvg, eps, fwd_J=fwd_J, counters=spec,
-                  order=order)
+                  order=order, cell_tight=cell_tight)
         stats(xd_tgt, voxel_J, tfs, bone_ids, offset, scale, cvg, dvg, cnt_x)
         n_spec_items[0] += xd_tgt.shape[1] * bone_ids.shape[0]
     fast_snarf.fuse_broyden, fast_snarf.fuse_broyden_spec, fast_snarf.fuse_broyden_spec_rows = wrapped, wrapped_spec, wrapped_rows

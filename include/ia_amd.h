@@ -233,12 +233,22 @@ int ia_filter(int64_t N, int I, const float* x /*[1,N,I,3]*/, const uint8_t* mas
  * sequence of ia_fuse_broyden (bit-identical x / J_inv / fwd_J / is_valid), and ia_filter of the result equals ia_filter of
  * ia_fuse_broyden's on all but ~1e-7 of the points (1 of 16.4 M on the headline frame, profiles/r04_spec_search_probe.json;
  * DESIGN.md 4.5, tests/test_gpu_spec_search.py); eps = 0 retires nothing.
+ * cell_tight: NULL or uint8 [D,H,W] from ia_cell_tightness: a root in a voxel cell where the TRUE Jacobian of the skinning map is not
+ * tight everywhere (a fold of the map nearby: two roots 1e-4 ... 1e-3 apart that both look tight to Broyden's estimate) retires
+ * nothing.  With the table the differences above vanish: 0 of 145 M points on the eight reference poses
+ * (profiles/r04_spec_search_probe_poses.jsonl); without it the rule is round-4a's.
  * counters: NULL or uint64[5], caller-zeroed, accumulated: fetches issued, retired items, completed valid items, points
  * searched again with the filter off, in-range corner loads of the fetches. */
+/* per voxel cell (entry = the cell whose LOW corner is the voxel; the last index of an axis holds 0): 1 iff at 27 sample points of
+ * the cell det(dg/dx) keeps one sign and |(dg/dx)^-1|_F <= tau, dg/dx = A(x) + sum_c dw_c/dx (A_c x + b_c) the true Jacobian of
+ * g(x) = A(x) x + b(x) - xd on the trilinear voxel_J (weight-gradient term included).  Once per pose, next to ia_precompute. */
+int ia_cell_tightness(int D, int H, int W, const float* voxel_J_cl /*[D,H,W,12]*/, const float* offset, const float* scale, float tau,
+                      uint8_t* cell_tight /*[D,H,W]*/, ia_stream_t stream);
 int ia_fuse_broyden_spec(int64_t N, int I, const float* xd_tgt /*[N,3]*/, const float* voxel_J_cl /*[D,H,W,12]*/, int D, int H, int W,
                          const float* tfs /*[24,4,4]*/, const int32_t* bone_ids, const float* offset, const float* scale,
                          float cvg_threshold, float dvg_threshold, float eps, float* x /*[N,I,3]*/, float* J_inv /*[N,I,3,3] or NULL*/,
-                         uint8_t* is_valid /*[N,I]*/, float* fwd_J /*[N,I,3,3] or NULL*/, uint64_t* counters, ia_stream_t stream);
+                         uint8_t* is_valid /*[N,I]*/, float* fwd_J /*[N,I,3,3] or NULL*/, uint64_t* counters,
+                         const uint8_t* cell_tight /* NULL or [D,H,W] */, ia_stream_t stream);
 /* The same search with the CANDIDATE BOOKKEEPING done in the kernel (replaces is_valid + filter.cu:10-54 + the mask indexing of
  * snarf_deformer.py:187-196 on the product path).  A search that completes valid is compared with the point's recorded roots:
  * within K9's 1e-4 it is a duplicate, from 2e-4 up it is a candidate and gets the next of the point's ia_spec_rows_slots() (= 3)
@@ -261,7 +271,8 @@ int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, const float
                               const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold,
                               float dvg_threshold, float eps, float* x_rows, float* J_inv, float* fwd_J, int32_t* cnt, uint32_t* meta,
                               int32_t* start, int32_t* ovf_head, void* ovf_scratch, int32_t* total_and_overflow, void* scan_tmp,
-                              uint64_t* counters, const int32_t* order /* NULL or [N]: point p = xd_tgt[order[p]] */, ia_stream_t stream);
+                              uint64_t* counters, const int32_t* order /* NULL or [N]: point p = xd_tgt[order[p]] */,
+                              const uint8_t* cell_tight /* NULL or [D,H,W] (ia_cell_tightness) */, ia_stream_t stream);
 int ia_deform_rows_pack(int64_t N, int I, const float* x_rows, const int32_t* cnt, const uint32_t* meta, const int32_t* start,
                         const int32_t* ovf_head, const void* ovf_scratch, float* cand_x, int32_t* cand_src,
                         const float* norm_center /* NULL or [3] (device) */, const float* norm_scale /* NULL or [3] (device) */,

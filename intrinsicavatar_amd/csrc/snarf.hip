@@ -611,8 +611,14 @@ __device__ __forceinline__ unsigned in_range_corner_count(float gx, float gy, fl
 }
 
 constexpr int SPEC_ROOTS = 3;              // recorded roots per point (survivors per point average 1.2; a 4th sends the point to the exact redo)
-constexpr float SPEC_TAU = 2.5f;           // a root is tight when |J_inv|_F <= SPEC_TAU (a rotation has sqrt(3) = 1.73)
-constexpr float SPEC_TAU_SELF = 3.0f;      // a search may be retired while its own |J_inv|_F <= SPEC_TAU_SELF
+#ifndef IA_SPEC_TAU                        // (-D overrides: rule sweeps through tools/ab_build.sh)
+#define IA_SPEC_TAU 2.5f
+#endif
+#ifndef IA_SPEC_TAU_SELF
+#define IA_SPEC_TAU_SELF 3.0f
+#endif
+constexpr float SPEC_TAU = IA_SPEC_TAU;           // a root is tight when |J_inv|_F <= SPEC_TAU (a rotation has sqrt(3) = 1.73)
+constexpr float SPEC_TAU_SELF = IA_SPEC_TAU_SELF; // a search may be retired while its own |J_inv|_F <= SPEC_TAU_SELF
 constexpr float SPEC_CELL_MARGIN = 4e-6f;  // the cell box of a root is shrunk by this much (canonical metres) on every side
 // points per launch that can be redone exactly (1.4e-4 .. 1.8e-4 of the points are on the march distributions; the list holds 1 / 64 of a batch)
 static inline int64_t spec_flag_cap(int64_t N) { const int64_t c = N >> 6; return c < (1 << 16) ? (1 << 16) : c; }
@@ -639,7 +645,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
     unsigned long long* __restrict__ counters /* NULL or [5]: fetches, retired items, completed valid items, points redone exactly, in-range corner loads */,
     int32_t* __restrict__ cnt /* PACK: [N] */, uint32_t* __restrict__ meta /* PACK: [N] */, SpecFlag flag /* PACK */,
     int slots /* <= SPEC_ROOTS: roots recorded / row slots used (test hook) */,
-    const int32_t* __restrict__ order /* NULL or [N]: point p of this launch is xd_tgt[order[p]] (evaluation order != storage order) */)
+    const int32_t* __restrict__ order /* NULL or [N]: point p of this launch is xd_tgt[order[p]] (evaluation order != storage order) */,
+    const uint8_t* __restrict__ cell_tight /* NULL or [D,H,W] (ia_cell_tightness): a root in a cell with 0 gets no retirement box */)
 {
     __shared__ float s_T[16 * 12];                     // per init: rows 0..2 of its bone's 4x4 (R | t)
     __shared__ int s_cur;                              // positions of the WORKGROUP's stream of chunks handed out so far
@@ -885,11 +892,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
                             const float jn2 = fmaf(Ji[8], Ji[8], fmaf(Ji[7], Ji[7], fmaf(Ji[6], Ji[6], fmaf(Ji[5], Ji[5], fmaf(Ji[4], Ji[4],
                                               fmaf(Ji[3], Ji[3], fmaf(Ji[2], Ji[2], fmaf(Ji[1], Ji[1], Ji[0] * Ji[0]))))))));
                             const float gc[3] = {ix, iy, iz};
-                            float lo[3], hi[3];
+                            float lo[3], hi[3], fcell[3];
 #pragma unroll
                             for (int a = 0; a < 3; a++) {
                                 // cell f of the interpolation coordinate ((g + 1) / 2) (dim - 1) (the fetch's own expression)
                                 const float f = floorf(((gc[a] + 1.f) / 2) * s_cell[9 + a]);
+                                fcell[a] = f;
 #ifdef IA_SPEC_ABL_EPS_BOX
                                 lo[a] = x_l[a] - eps; hi[a] = x_l[a] + eps; (void)f;
 #else
@@ -909,6 +917,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
 #if !defined(IA_SPEC_ABL_EPS_BOX) && !defined(IA_SPEC_ABL_X1) && !defined(IA_SPEC_ABL_X2)
                             if (!(jn2 <= SPEC_TAU * SPEC_TAU)) lo[0] = INFINITY;
 #endif
+                            if (cell_tight) {
+                                // (d') the TRUE Jacobian must be tight all over the root's cell (cell_tightness_kernel): Broyden's estimate above
+                                // does not see a fold of the skinning map next to r.  The cell index is exact in float (D H W < 2^24); a valid
+                                // root lies inside the grid, so its cell is an entry of the table (the last index of an axis holds 0)
+                                const float ci = fmaf(fmaf(fcell[2], s_cell[10] + 1.0f, fcell[1]), s_cell[9] + 1.0f, fcell[0]);
+                                if (cell_tight[(int)ci] == 0) lo[0] = INFINITY;
+                            }
                             {   // one computed slot address instead of three predicated copies of the nine stores
                                 float* const slot = rootp + n_roots * (9 * WG);
                                 slot[0 * WG] = x_l[0]; slot[1 * WG] = x_l[1]; slot[2 * WG] = x_l[2];
@@ -1268,6 +1283,68 @@ __global__ __launch_bounds__(THREADS) void filter_kernel(int64_t N, int I, const
     }
 }
 
+
+// ---- per voxel cell: is the skinning map x -> A(x) x + b(x) TIGHT everywhere in the cell?  (the retirement veto of broyden_spec_kernel)
+// The early filter retires a search next to a recorded root r on the promise that every search converging near r ends within K9's
+// 1e-4 of it.  Broyden's J_inv at r cannot vouch for that: it starts from the bone's rigid inverse and only learns g along the steps
+// the search took, so next to a FOLD of the skinning map (det dg/dx = 0: two roots 1e-4 ... 1e-3 apart in a flat valley of |g| < cvg)
+// it still reads ~1.7 while the true Jacobian is near singular (tools/k9_mismatch_dump.py: every candidate-set difference left on the
+// reference poses was such a pair).  The TRUE Jacobian is dg_i/dx_a = A_ia + sum_c dw_c/dx_a (A_c x + b_c)_i -- the weight-gradient term
+// included -- and inside one cell it is a polynomial of the eight corner matrices: out [D,H,W] (entry = the cell whose LOW corner is the
+// voxel; the last index of every axis is no cell: 0) = 1 iff at all 27 sample points of the cell (fractions 0.02 / 0.5 / 0.98 per axis)
+// det has one sign and |J^-1|_F = |cof J|_F / |det J| <= tau.  A root in a cell with 0 gets no retirement box.
+__global__ __launch_bounds__(THREADS) void cell_tightness_kernel(int D, int H, int W, const float* __restrict__ voxel_J_cl,
+                                                                 const float* __restrict__ offset, const float* __restrict__ scale, float tau,
+                                                                 uint8_t* __restrict__ out)
+{
+    const int64_t vox = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (vox >= (int64_t)D * H * W) return;
+    const int cx = (int)(vox % W), cy = (int)((vox / W) % H), cz = (int)(vox / ((int64_t)W * H));
+    if (cx >= W - 1 || cy >= H - 1 || cz >= D - 1) { out[vox] = 0; return; }
+    float v[8][12];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const float* src = voxel_J_cl + (vox + (c & 1) + (int64_t)((c >> 1) & 1) * W + (int64_t)((c >> 2) & 1) * W * H) * 12;
+#pragma unroll
+        for (int k = 0; k < 12; k++) v[c][k] = src[k];
+    }
+    const int dims[3] = {W, H, D}, idx[3] = {cx, cy, cz};
+    float dco[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) dco[a] = scale[a] * (float)(dims[a] - 1) * 0.5f;
+    const float fr[3] = {0.02f, 0.5f, 0.98f};
+    bool ok = true;
+    float sgn = 0.0f;
+    for (int s = 0; s < 27 && ok; s++) {
+        const float t[3] = {fr[s % 3], fr[(s / 3) % 3], fr[s / 9]};
+        float x[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) x[a] = (((float)idx[a] + t[a]) / (float)(dims[a] - 1) * 2.0f - 1.0f) / scale[a] - offset[a];
+        float J[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const float wx = (c & 1) ? t[0] : 1.0f - t[0], wy = (c & 2) ? t[1] : 1.0f - t[1], wz = (c & 4) ? t[2] : 1.0f - t[2];
+            const float w = wx * wy * wz;
+            const float dw[3] = {((c & 1) ? 1.0f : -1.0f) * wy * wz * dco[0], ((c & 2) ? 1.0f : -1.0f) * wx * wz * dco[1],
+                                 ((c & 4) ? 1.0f : -1.0f) * wx * wy * dco[2]};
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const float p = v[c][4 * i] * x[0] + v[c][4 * i + 1] * x[1] + v[c][4 * i + 2] * x[2] + v[c][4 * i + 3];
+#pragma unroll
+                for (int a = 0; a < 3; a++) J[3 * i + a] += w * v[c][4 * i + a] + dw[a] * p;
+            }
+        }
+        const float c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
+        const float c10 = J[2] * J[7] - J[1] * J[8], c11 = J[0] * J[8] - J[2] * J[6], c12 = J[1] * J[6] - J[0] * J[7];
+        const float c20 = J[1] * J[5] - J[2] * J[4], c21 = J[2] * J[3] - J[0] * J[5], c22 = J[0] * J[4] - J[1] * J[3];
+        const float det = J[0] * c00 + J[1] * c01 + J[2] * c02;
+        const float cof2 = c00 * c00 + c01 * c01 + c02 * c02 + c10 * c10 + c11 * c11 + c12 * c12 + c20 * c20 + c21 * c21 + c22 * c22;
+        if (s == 0) sgn = det;
+        ok = (det * sgn > 0.0f) && (cof2 <= tau * tau * det * det);      // (false for NaN)
+    }
+    out[vox] = ok ? 1 : 0;
+}
+
 }  // namespace
 
 IA_EXPORT int ia_precompute(int B, int D, int H, int W, const float* voxel_w, const float* tfs, const float* offset,
@@ -1279,6 +1356,16 @@ IA_EXPORT int ia_precompute(int B, int D, int H, int W, const float* voxel_w, co
     precompute_kernel<<<grid, THREADS, 0, (hipStream_t)stream>>>(B, D, H, W, voxel_w, tfs, offset, scale, voxel_d,
                                                                  voxel_J, voxel_J_cl);
     return ia::check_launch("ia_precompute");
+}
+
+// uint8 [D,H,W]: 1 = the cell whose low corner is the voxel is tight (cell_tightness_kernel); the veto table of the early-filter search
+IA_EXPORT int ia_cell_tightness(int D, int H, int W, const float* voxel_J_cl, const float* offset, const float* scale, float tau,
+                                uint8_t* cell_tight, ia_stream_t stream)
+{
+    IA_REQUIRE(D > 1 && H > 1 && W > 1 && tau > 0.0f, "ia_cell_tightness: bad grid shape or tau");
+    cell_tightness_kernel<<<ia::cdiv((int64_t)D * H * W, THREADS), THREADS, 0, (hipStream_t)stream>>>(D, H, W, voxel_J_cl, offset, scale, tau,
+                                                                                                      cell_tight);
+    return ia::check_launch("ia_cell_tightness");
 }
 
 IA_EXPORT int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt, const float* voxel_J, int layout, int D,
@@ -1334,7 +1421,7 @@ IA_EXPORT int ia_fuse_broyden(int B, int64_t N, int I, const float* xd_tgt, cons
 static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
                        const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold, float dvg_threshold, float eps,
                        float* x, float* J_inv, uint8_t* is_valid, float* fwd_J, uint64_t* counters, int32_t* cnt, uint32_t* meta,
-                       SpecFlag flag, const int32_t* order, ia_stream_t stream, const char* what)
+                       SpecFlag flag, const int32_t* order, const uint8_t* cell_tight, ia_stream_t stream, const char* what)
 {
     if (N == 0) return IA_OK;
     IA_REQUIRE(I >= 1 && I <= 16, "early-filter search: 1 <= I <= 16 inits");
@@ -1377,16 +1464,16 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
 #define IA_SPEC_LAUNCH(COUNT, PACK)                                                                                                    \
     broyden_spec_kernel<COUNT, PACK><<<grid, THREADS, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,         \
                                                                cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J, pts, c, cnt, \
-                                                               meta, flag, slots, order)
+                                                               meta, flag, slots, order, cell_tight)
     if (pack && !counters && wg_env != THREADS) {
         // A / B: smaller workgroups (one point per lane each): IA_BR_SPEC_WG = 64 | 128, chunk = the workgroup's lanes
         if (wg_env == 64)
             broyden_spec_kernel<false, true, 64><<<(int)((N + 63) / 64), 64, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold,
-                                                                                     dvg_threshold, eps, x, J_inv, is_valid, fwd_J, 6, c, cnt, meta, flag, slots, order);
+                                                                                     dvg_threshold, eps, x, J_inv, is_valid, fwd_J, 6, c, cnt, meta, flag, slots, order, cell_tight);
         else
             broyden_spec_kernel<false, true, 128><<<(int)((N + 127) / 128), 128, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,
                                                                                          cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J, 7, c, cnt, meta, flag,
-                                                                                         slots, order);
+                                                                                         slots, order, cell_tight);
         return ia::check_launch(what);
     }
     if (pack) { if (counters) IA_SPEC_LAUNCH(true, true); else IA_SPEC_LAUNCH(false, true); }
@@ -1398,11 +1485,11 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
 IA_EXPORT int ia_fuse_broyden_spec(int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
                                    const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold,
                                    float dvg_threshold, float eps, float* x, float* J_inv, uint8_t* is_valid, float* fwd_J,
-                                   uint64_t* counters, ia_stream_t stream)
+                                   uint64_t* counters, const uint8_t* cell_tight, ia_stream_t stream)
 {
     SpecFlag none = {nullptr, nullptr, nullptr, nullptr, 0};
     return launch_spec(false, N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x, J_inv,
-                       is_valid, fwd_J, counters, nullptr, nullptr, none, nullptr, stream, "ia_fuse_broyden_spec");
+                       is_valid, fwd_J, counters, nullptr, nullptr, none, nullptr, cell_tight, stream, "ia_fuse_broyden_spec");
 }
 
 IA_EXPORT int ia_spec_rows_slots(void) { return SPEC_ROOTS; }
@@ -1445,7 +1532,7 @@ IA_EXPORT int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, c
                                         const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold,
                                         float dvg_threshold, float eps, float* x_rows, float* J_inv, float* fwd_J, int32_t* cnt,
                                         uint32_t* meta, int32_t* start, int32_t* ovf_head, void* ovf_scratch, int32_t* total_and_overflow,
-                                        void* scan_tmp, uint64_t* counters, const int32_t* order, ia_stream_t stream)
+                                        void* scan_tmp, uint64_t* counters, const int32_t* order, const uint8_t* cell_tight, ia_stream_t stream)
 {
     IA_REQUIRE(N * I < ((int64_t)1 << 31), "ia_fuse_broyden_spec_rows: N * I must stay below 2^31");
     hipStream_t s = (hipStream_t)stream;
@@ -1456,7 +1543,7 @@ IA_EXPORT int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, c
         return ia::check_launch("ia_fuse_broyden_spec_rows");
     }
     int r = launch_spec(true, N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x_rows,
-                        J_inv, nullptr, fwd_J, counters, cnt, meta, o.flag, order, stream, "ia_fuse_broyden_spec_rows");
+                        J_inv, nullptr, fwd_J, counters, cnt, meta, o.flag, order, cell_tight, stream, "ia_fuse_broyden_spec_rows");
     if (r != IA_OK) return r;
     rows_flagged_kernel<<<64, THREADS, 0, s>>>(o.flag, I, x_rows, cnt, meta, o.count, SPEC_OVF_CAP, ovf_head, o.rec, o.x, o.keep);
     r = ia::check_launch("ia_fuse_broyden_spec_rows(flagged)");

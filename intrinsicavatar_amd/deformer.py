@@ -26,8 +26,11 @@ class SNARFDeformer:
     # K9-consistent early filter of the search (fast_snarf.fuse_broyden_spec[_rows], csrc/snarf.hip): a search is retired
     # once it comes within SPEC_EPS metres of a TIGHT root that a later init of the same point has found, inside that root's voxel
     # cell (K9 would drop it wherever exactly it ends); a point whose completed roots leave K9's decision open is searched again with
-    # the filter off.  The candidate set equals search-to-the-end + K9 on all but ~1e-7 of the points (1 of 16.4 M on the headline
-    # frame, profiles/r04_spec_search_probe.json), candidates bit-identical.  On for EVERY batch size: what a point gets must not
+    # the filter off; a root in a voxel cell where the TRUE Jacobian of the skinning map is not tight everywhere (cell_tight: per pose,
+    # fast_snarf.cell_tightness) retires nothing -- next to a fold of the map Broyden's estimate is blind.  The candidate set equals
+    # search-to-the-end + K9 on every point measured (0 of 145 M march points on the eight reference poses,
+    # profiles/r04_spec_search_probe_poses.jsonl; without the cell table 3e-7 of them differed), candidates bit-identical.  IA_SPEC_CELL_TAU=0
+    # switches the table off (A / B).  On for EVERY batch size: what a point gets must not
     # depend on how many other points share its launch (ray-batch sharding invariance, multi-GPU = single GPU).
     # IA_BROYDEN_SPEC_EPS=0 (or deformer.spec_eps = 0) = the reference's search-to-the-end everywhere; the kernel-level parity tests
     # (K8 / K9 golden vectors) call those entry points directly.
@@ -45,6 +48,7 @@ class SNARFDeformer:
         self.spec_counters = None            # optional int64 [5] device tensor: accumulated by the early-filter search (bench.py)
         self.tfs = None
         self.voxel_J_cl = None
+        self.cell_tight = None
         self.voxel_d = None
         self.w2s = None
 
@@ -65,6 +69,10 @@ class SNARFDeformer:
         # only for finite voxels): one check per frame instead of a select per load
         if not bool(torch.isfinite(self.voxel_J_cl).all()):
             raise RuntimeError("SNARFDeformer.prepare: the skinning grid (voxel_J) holds non-finite values")
+        # veto table of the early filter: cells where the true Jacobian of the skinning map is tight (one small kernel per pose)
+        tau = float(os.environ.get("IA_SPEC_CELL_TAU", str(fast_snarf.CELL_TAU)))
+        self.cell_tight = (fast_snarf.cell_tightness(fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.offset_kernel, self.scale_kernel, tau)
+                           if (tau > 0 and B == 1) else None)
 
     def transform_rays_w2s(self, rays: Tensor) -> Tensor:
         """snarf_deformer.py:128-147."""
@@ -92,7 +100,7 @@ class SNARFDeformer:
         if self.spec_eps > 0.0 and P >= self.SPEC_MIN_POINTS and self.tfs.shape[0] == 1:
             fast_snarf.fuse_broyden_spec(x, pts.reshape(1, P, 3), fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs,
                                          self.init_bones, Jinv, valid, self.offset_kernel, self.scale_kernel, 1e-5, 1e-1,
-                                         self.spec_eps, fwd_J=fwd, counters=self.spec_counters)
+                                         self.spec_eps, fwd_J=fwd, counters=self.spec_counters, cell_tight=self.cell_tight)
         else:
             fast_snarf.fuse_broyden(x, pts.reshape(1, P, 3), None, fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs,
                                     self.init_bones, True, Jinv, valid, self.offset_kernel, self.scale_kernel, 1e-5, 1e-1,
@@ -188,7 +196,8 @@ class SNARFDeformer:
         tot = torch.empty(2, dtype=torch.int32, device=dev)
         fast_snarf.fuse_broyden_spec_rows(x_rows, pts.reshape(1, P, 3), fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs, self.init_bones,
                                           Jinv, cnt, meta, start, ovf_head, self._ovf_scratch, tot, self.offset_kernel, self.scale_kernel,
-                                          1e-5, 1e-1, self.spec_eps, fwd_J=fwd, counters=self.spec_counters, order=order)
+                                          1e-5, 1e-1, self.spec_eps, fwd_J=fwd, counters=self.spec_counters, order=order,
+                                          cell_tight=self.cell_tight)
         Q, n_over = tot.tolist()                                     # the one read-back of the call
         self.last_overflow_records = n_over                          # points the kernel searched again with the filter off
         if os.environ.get("IA_DEBUG_FLAGGED"):

@@ -40,6 +40,30 @@ def precompute(voxel_w: Tensor, tfs: Tensor, voxel_d: Tensor, voxel_J: Tensor, o
             "ia_precompute")
 
 
+CELL_TAU = 2.5        # a voxel cell is tight when |(dg/dx)^-1|_F <= CELL_TAU all over it (a rotation has sqrt(3) = 1.73)
+
+
+def cell_tightness(voxel_J: ChannelLastVoxelJ, offset: Tensor, scale: Tensor, tau: float = CELL_TAU) -> Tensor:
+    """uint8 [D,H,W] veto table of the early-filter search (ia_cell_tightness; once per pose, after precompute): 1 = the TRUE Jacobian
+    of the skinning map -- weight-gradient term included -- keeps its sign and |J^-1|_F <= tau at 27 sample points of the voxel cell.
+    A root in a cell with 0 retires no search: next to a fold of the map two roots sit 1e-4 ... 1e-3 apart and Broyden's own J_inv
+    estimate cannot tell (csrc/snarf.hip cell_tightness_kernel).  No counterpart in the reference."""
+    assert isinstance(voxel_J, ChannelLastVoxelJ) and voxel_J.data.shape[0] == 1
+    _, D, H, W, _ = voxel_J.data.shape
+    out = torch.empty((D, H, W), dtype=torch.uint8, device=voxel_J.data.device)
+    L.check(L.lib().ia_cell_tightness(L.i32(D), L.i32(H), L.i32(W), L.ptr(voxel_J.data), L.ptr(offset.reshape(3).contiguous().float()),
+                                      L.ptr(scale.reshape(3).contiguous().float()), L.f32(tau), L.ptr(out), L.stream()), "ia_cell_tightness")
+    return out
+
+
+def _cell_tight_arg(cell_tight, voxel_J):
+    if cell_tight is None:
+        return None
+    if cell_tight.dtype != torch.uint8 or tuple(cell_tight.shape) != tuple(voxel_J.data.shape[1:4]) or not cell_tight.is_contiguous():
+        raise RuntimeError("cell_tight must be a contiguous uint8 [D,H,W] tensor (fast_snarf.cell_tightness)")
+    return cell_tight
+
+
 def fuse_broyden(x: Tensor, xd_tgt: Tensor, voxel: Tensor, voxel_J, tfs: Tensor, bone_ids: Tensor,
                  align_corners: bool, J_inv: Tensor, is_valid: Tensor, offset: Tensor, scale: Tensor,
                  cvg_threshold: float, dvg_threshold: float, fwd_J: Tensor = None) -> None:
@@ -71,12 +95,14 @@ def fuse_broyden(x: Tensor, xd_tgt: Tensor, voxel: Tensor, voxel_J, tfs: Tensor,
 
 def fuse_broyden_spec(x: Tensor, xd_tgt: Tensor, voxel_J: ChannelLastVoxelJ, tfs: Tensor, bone_ids: Tensor, J_inv: Tensor,
                       is_valid: Tensor, offset: Tensor, scale: Tensor, cvg_threshold: float, dvg_threshold: float, eps: float,
-                      fwd_J: Tensor = None, counters: Tensor = None) -> None:
+                      fwd_J: Tensor = None, counters: Tensor = None, cell_tight: Tensor = None) -> None:
     """fuse_broyden with the K9-consistent early filter (ia_fuse_broyden_spec; B = 1, channel-last grid): a search that comes within
     `eps` of a TIGHT root found by a LATER init of its point, inside that root's voxel cell, is retired -- K9 (filter.cu:10-54) would
     drop it wherever exactly it ends; points whose completed roots leave K9's decision open are searched again with the filter off
     (csrc/snarf.hip).  Everything that is not retired is bit-identical to fuse_broyden, and filter() of the result equals filter()
-    of fuse_broyden's on all but ~1e-7 of the points.  No counterpart in the reference; used by SNARFDeformer.search.
+    of fuse_broyden's on all but ~1e-7 of the points -- on all points measured (145 M on eight poses) with cell_tight = cell_tightness(...),
+    the veto table that keeps roots next to a fold of the skinning map from retiring anything.  No counterpart in the reference; used by
+    SNARFDeformer.search.
     counters: optional int64 [5] (accumulated): fetches, retired items, completed valid items, points redone, corner loads."""
     B, N, _ = xd_tgt.shape
     I = bone_ids.shape[0]
@@ -91,13 +117,13 @@ def fuse_broyden_spec(x: Tensor, xd_tgt: Tensor, voxel_J: ChannelLastVoxelJ, tfs
         L.i64(N), L.i32(I), L.ptr(xd_tgt.contiguous().float()), L.ptr(voxel_J.data), L.i32(D), L.i32(H), L.i32(W),
         L.ptr(tfs.contiguous().float()), L.ptr(bone_ids.contiguous().to(torch.int32)), L.ptr(offset.reshape(3).contiguous().float()),
         L.ptr(scale.reshape(3).contiguous().float()), L.f32(cvg_threshold), L.f32(dvg_threshold), L.f32(eps), L.ptr(x), L.ptr(J_inv),
-        L.ptr(is_valid), L.ptr(fwd_J), L.ptr(counters), L.stream()), "ia_fuse_broyden_spec")
+        L.ptr(is_valid), L.ptr(fwd_J), L.ptr(counters), L.ptr(_cell_tight_arg(cell_tight, voxel_J)), L.stream()), "ia_fuse_broyden_spec")
 
 
 def fuse_broyden_spec_rows(x_rows: Tensor, xd_tgt: Tensor, voxel_J: ChannelLastVoxelJ, tfs: Tensor, bone_ids: Tensor, J_inv: Tensor,
                            cnt: Tensor, meta: Tensor, start: Tensor, ovf_head: Tensor, ovf_scratch: Tensor, total_and_overflow: Tensor,
                            offset: Tensor, scale: Tensor, cvg_threshold: float, dvg_threshold: float, eps: float, fwd_J: Tensor = None,
-                           counters: Tensor = None, order: Tensor = None, n_points: int = None) -> None:
+                           counters: Tensor = None, order: Tensor = None, n_points: int = None, cell_tight: Tensor = None) -> None:
     """fuse_broyden_spec with the candidate bookkeeping in the kernel (ia_fuse_broyden_spec_rows): no x [N,I,3], no is_valid, no
     filter pass -- x_rows [N,3,3] receives each point's surviving candidates (highest init first), cnt [N] int32 their number,
     meta [N] int32 their inits (one byte each; bit 31: the point has overflow records), start [N] the exclusive scan of cnt,
@@ -122,7 +148,8 @@ def fuse_broyden_spec_rows(x_rows: Tensor, xd_tgt: Tensor, voxel_J: ChannelLastV
         L.ptr(tfs.contiguous().float()), L.ptr(bone_ids.contiguous().to(torch.int32)), L.ptr(offset.reshape(3).contiguous().float()),
         L.ptr(scale.reshape(3).contiguous().float()), L.f32(cvg_threshold), L.f32(dvg_threshold), L.f32(eps), L.ptr(x_rows), L.ptr(J_inv),
         L.ptr(fwd_J), L.ptr(cnt), L.ptr(meta), L.ptr(start), L.ptr(ovf_head), L.ptr(ovf_scratch), L.ptr(total_and_overflow),
-        L.ptr(L.scan_tmp(N, xd_tgt.device)), L.ptr(counters), L.ptr(order), L.stream()), "ia_fuse_broyden_spec_rows")
+        L.ptr(L.scan_tmp(N, xd_tgt.device)), L.ptr(counters), L.ptr(order), L.ptr(_cell_tight_arg(cell_tight, voxel_J)), L.stream()),
+        "ia_fuse_broyden_spec_rows")
 
 
 def filter(x: Tensor, mask: Tensor) -> Tensor:

@@ -56,6 +56,73 @@ def sample_J(vJ, g):
     return out
 
 
+def true_jinv_norm(vJ, x, offk, sck, with_det=False):
+    """Frobenius norm of the inverse of the TRUE Jacobian of g(x) = A(x) x + b(x) - xd at x [n,3]  ([A | b] = the trilinear voxel_J):
+    dg_i/dx_a = A_ia + sum_c dw_c/dx_a (A_c x + b_c)_i -- the weight-gradient term Broyden's estimate only learns along its own steps."""
+    D, H, W, _ = vJ.shape
+    g = (x + offk) * sck
+    ix = (g[:, 0] + 1) / 2 * (W - 1)
+    iy = (g[:, 1] + 1) / 2 * (H - 1)
+    iz = (g[:, 2] + 1) / 2 * (D - 1)
+    dcoord = torch.stack([sck[0] * (W - 1) / 2, sck[1] * (H - 1) / 2, sck[2] * (D - 1) / 2]) if sck.dim() == 1 else None
+    sc3 = sck.reshape(-1)[:3]
+    dco = torch.stack([sc3[0] * (W - 1) / 2, sc3[1] * (H - 1) / 2, sc3[2] * (D - 1) / 2])
+    fx, fy, fz = ix.floor(), iy.floor(), iz.floor()
+    x0, y0, z0 = fx.long(), fy.long(), fz.long()
+    flat = vJ.reshape(-1, 12)
+    n = x.shape[0]
+    A = torch.zeros((n, 3, 3), device=x.device)
+    Gd = torch.zeros((n, 3, 3), device=x.device)               # sum_c dw_c/dx_a p_c  -> [n, i, a]
+    tx, ty, tz = ix - fx, iy - fy, iz - fz
+    for c in range(8):
+        cx, cy, cz = c & 1, (c >> 1) & 1, (c >> 2) & 1
+        xx, yy, zz = x0 + cx, y0 + cy, z0 + cz
+        wx, wy, wz = (tx if cx else 1 - tx), (ty if cy else 1 - ty), (tz if cz else 1 - tz)
+        sx, sy, sz = (1.0 if cx else -1.0), (1.0 if cy else -1.0), (1.0 if cz else -1.0)
+        ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H) & (zz >= 0) & (zz < D)
+        lin = (zz.clamp(0, D - 1) * H + yy.clamp(0, H - 1)) * W + xx.clamp(0, W - 1)
+        v = torch.where(ok[:, None], flat[lin], torch.zeros((), device=x.device)).reshape(n, 3, 4)
+        p_c = torch.einsum("nij,nj->ni", v[:, :, :3], x) + v[:, :, 3]
+        A += v[:, :, :3] * (wx * wy * wz)[:, None, None]
+        dw = torch.stack([sx * wy * wz * dco[0], wx * sy * wz * dco[1], wx * wy * sz * dco[2]], -1)      # [n, a]
+        Gd += p_c[:, :, None] * dw[:, None, :]
+    J = A + Gd
+    det = torch.linalg.det(J)
+    Jinv = torch.linalg.inv(torch.where((det.abs() > 1e-12)[:, None, None], J, torch.eye(3, device=x.device).expand(n, 3, 3) * 1e-6))
+    if with_det:
+        return Jinv.reshape(n, 9).norm(dim=-1), det
+    return Jinv.reshape(n, 9).norm(dim=-1)
+
+
+def cell_table(vJ, offk, sck, m=3):
+    """per voxel cell (iz, iy, ix), ix in [0, W - 2] ...: max over m^3 sample points inside the cell of |J_true^-1|_F, +inf where det J changes
+    sign among the samples (a fold of the skinning map crosses the cell) -> [D-1, H-1, W-1].  What a precompute pass would store per pose."""
+    D, H, W, _ = vJ.shape
+    dev = vJ.device
+    sc3, of3 = sck.reshape(-1)[:3], offk.reshape(-1)[:3]
+    fr = (torch.arange(m, device=dev, dtype=torch.float32) + 0.5) / m if m > 1 else torch.tensor([0.5], device=dev)
+    if m > 1:
+        fr = torch.linspace(0.02, 0.98, m, device=dev)
+    out = torch.zeros((D - 1, H - 1, W - 1), device=dev)
+    sign_min = torch.full((D - 1, H - 1, W - 1), 1e30, device=dev)
+    sign_max = torch.full((D - 1, H - 1, W - 1), -1e30, device=dev)
+    iz, iy, ix = torch.meshgrid(torch.arange(D - 1, device=dev), torch.arange(H - 1, device=dev), torch.arange(W - 1, device=dev), indexing="ij")
+    for a in fr.tolist():
+        for b in fr.tolist():
+            for c in fr.tolist():
+                gx = (ix.float() + c) / (W - 1) * 2 - 1
+                gy = (iy.float() + b) / (H - 1) * 2 - 1
+                gz = (iz.float() + a) / (D - 1) * 2 - 1
+                g = torch.stack([gx, gy, gz], -1).reshape(-1, 3)
+                x = g / sc3 - of3
+                nrm, det = true_jinv_norm(vJ, x, offk, sck, with_det=True)
+                out = torch.maximum(out, nrm.reshape(out.shape))
+                sign_min = torch.minimum(sign_min, det.reshape(out.shape))
+                sign_max = torch.maximum(sign_max, det.reshape(out.shape))
+    out = torch.where((sign_min > 0) | (sign_max < 0), out, torch.full_like(out, float("inf")))
+    return out
+
+
 def search(xd, vJ, tfs, bones, offk, sck):
     """all inits of all points -> traj [P,I,ITERS+1,3] (x_k = position of fetch k), nfetch [P,I], valid [P,I], xfin [P,I,3],
     jn [P,I] (Frobenius norm of J_inv at the end)."""
@@ -69,9 +136,11 @@ def search(xd, vJ, tfs, bones, offk, sck):
     traj = torch.full((n, ITERS + 1, 3), float("nan"), device=dev)
     traj[:, 0] = x
     jtraj = torch.zeros((n, ITERS + 1), device=dev)          # |J_inv|_F the step to x_k was made with (k >= 1)
+    gtraj = torch.zeros((n, ITERS + 1), device=dev)          # |g(x_k)|_2
     Jl = sample_J(vJ, (x + offk) * sck).reshape(n, 3, 4)
     Ji = Jl[:, :, :3].transpose(1, 2).contiguous()
     g = torch.einsum("nij,nj->ni", Jl[:, :, :3], x) + Jl[:, :, 3] - xt
+    gtraj[:, 0] = g.norm(dim=-1)
     live = torch.ones(n, dtype=torch.bool, device=dev)
     nfetch = torch.ones(n, dtype=torch.int32, device=dev)
     valid = torch.zeros(n, dtype=torch.bool, device=dev)
@@ -89,6 +158,7 @@ def search(xd, vJ, tfs, bones, offk, sck):
         nrm = (gn * gn).sum(-1)
         x[idx] = xn
         traj[idx, it + 1] = xn
+        gtraj[idx, it + 1] = nrm.sqrt()
         nfetch[idx] += 1
         conv = nrm < CVG * CVG
         div = ~conv & ~(nrm <= DVG * DVG)
@@ -106,6 +176,7 @@ def search(xd, vJ, tfs, bones, offk, sck):
         g[ci] = gn[cont]
         live[idx[~cont]] = False
     jn = Ji.reshape(n, 9).norm(dim=-1)
+    search.gtraj = gtraj.reshape(P, I, ITERS + 1)            # (side channel: keeps the 6-tuple of the callers)
     return traj.reshape(P, I, ITERS + 1, 3), nfetch.reshape(P, I), valid.reshape(P, I), xfin.reshape(P, I, 3), jn.reshape(P, I), jtraj.reshape(P, I, ITERS + 1)
 
 
@@ -129,7 +200,8 @@ def cell_id(x, offk, sck, dims):
     return (iz * 1024 + iy) * 1024 + ix
 
 
-def evaluate(traj, nfetch, valid, xfin, jn, keep_exact, eps, tau, kappa, k0, samecell=0, cells=None, tau2=1e9, jtraj=None, slots=3, zone=2e-4, examples=None):
+def evaluate(traj, nfetch, valid, xfin, jn, keep_exact, eps, tau, kappa, k0, samecell=0, cells=None, tau2=1e9, jtraj=None, slots=3, zone=2e-4, examples=None,
+             steep=0.0, gtraj=None, tautrue=0.0, jn_true=None, taucell=0.0, jn_cell=None):
     """-> dict of SUMS over the chunk's points."""
     P, I = valid.shape
     dev = valid.device
@@ -150,6 +222,12 @@ def evaluate(traj, nfetch, valid, xfin, jn, keep_exact, eps, tau, kappa, k0, sam
         okr = (d < eps) & (have & tight)[:, None, :]
         if samecell:
             okr &= cells[0][:, i, :, None] == rcell[:, None, :]
+        if steep > 0:
+            # g must be as steep around r as a tight root promises, seen from the last point whose g is known: |g(x_{k-1})| >= steep |x_{k-1} - r|
+            # (a flat valley -- a fold of the skinning map -- holds two roots 1e-4 ... 1e-3 apart that both look tight to Broyden's estimate)
+            dprev = (xk[:, :-1, None, :] - roots[:, None, :, :]).norm(dim=-1)          # [P,K-1,S]
+            okp = gtraj[:, i, :-1, None] >= steep * dprev
+            okr[:, 1:] &= okp
         near = okr.any(-1)                                             # [P,K]
         if jtraj is not None:
             near &= jtraj[:, i] <= tau2
@@ -175,7 +253,8 @@ def evaluate(traj, nfetch, valid, xfin, jn, keep_exact, eps, tau, kappa, k0, sam
         keep[:, i] = rec
         pi = torch.nonzero(rec)[:, 0]
         roots[pi, n_roots[pi]] = xf[pi]
-        tight[pi, n_roots[pi]] = jn[pi, i] <= tau
+        tight[pi, n_roots[pi]] = (jn[pi, i] <= tau) & ((jn_true[pi, i] <= tautrue) if tautrue > 0 else True) & \
+            ((jn_cell[pi, i] <= taucell) if taucell > 0 else True)
         if samecell:
             rcell[pi, n_roots[pi]] = cells[1][pi, i]
         n_roots[pi] += 1
@@ -199,6 +278,19 @@ def evaluate(traj, nfetch, valid, xfin, jn, keep_exact, eps, tau, kappa, k0, sam
 
 def rules():
     out = []
+    if os.environ.get("IA_RULES") == "cell":
+        out.append(dict(eps=1e-3, tau=2.5, kappa=1e9, k0=1, samecell=1, tau2=3.0))
+        for taucell, tau in itertools.product((2.0, 2.25, 2.5, 3.0), (2.5, 1e9)):
+            out.append(dict(eps=1e-3, tau=tau, kappa=1e9, k0=1, samecell=1, tau2=3.0, taucell=taucell))
+        return out
+    if os.environ.get("IA_RULES") == "true":
+        for tautrue, tau in itertools.product((0.0, 2.5, 3.0, 4.0, 6.0), (2.5, 1e9)):
+            out.append(dict(eps=1e-3, tau=tau, kappa=1e9, k0=1, samecell=1, tau2=3.0, tautrue=tautrue))
+        return out
+    if os.environ.get("IA_RULES") == "steep":
+        for steep, k0, tau, tau2 in itertools.product((0.0, 0.1, 0.2, 0.3, 0.5), (1, 0), (2.5,), (3.0,)):
+            out.append(dict(eps=1e-3, tau=tau, kappa=1e9, k0=k0, samecell=1, tau2=tau2, steep=steep))
+        return out
     for eps, tau, sc, tau2 in itertools.product((1e-3, 2e-3), (2.2, 2.5), (0, 1), (3.0, 6.0, 1e9)):
         out.append(dict(eps=eps, tau=tau, kappa=1e9, k0=1, samecell=sc, tau2=tau2))
     return out
@@ -232,11 +324,28 @@ def main():
     jn_hist = torch.zeros(len(jn_edges) - 1, dtype=torch.long)
     dd_hist = torch.zeros((len(jn_edges) - 1, len(dd_edges) - 1), dtype=torch.long)
     examples = []
+    ctab = None
     for c0 in range(0, P, chunk):
         x = xd[c0:c0 + chunk]
         traj, nfetch, valid, xfin, jn, jtraj = search(x, vJ, tfs, bones, offk, sck)
         keep_exact = k9(xfin, valid)
         cells = (cell_id(traj, offk, sck, vJ.shape[:3]), cell_id(xfin, offk, sck, vJ.shape[:3]))
+        jn_cell = None
+        if any(r.get("taucell", 0) > 0 for r in rl):
+            if ctab is None:
+                ctab = cell_table(vJ, offk, sck, int(os.environ.get("IA_CELL_M", "3")))
+                print("# cell table: finite", float(torch.isfinite(ctab).float().mean()), "<=2.5", float((ctab <= 2.5).float().mean()), file=sys.stderr)
+            D_, H_, W_ = vJ.shape[:3]
+            gq = (xfin.reshape(-1, 3) + offk) * sck
+            cx = ((gq[:, 0] + 1) / 2 * (W_ - 1)).floor().long()
+            cy = ((gq[:, 1] + 1) / 2 * (H_ - 1)).floor().long()
+            cz = ((gq[:, 2] + 1) / 2 * (D_ - 1)).floor().long()
+            inside = (cx >= 0) & (cx < W_ - 1) & (cy >= 0) & (cy < H_ - 1) & (cz >= 0) & (cz < D_ - 1)
+            v = ctab[cz.clamp(0, D_ - 2), cy.clamp(0, H_ - 2), cx.clamp(0, W_ - 2)]
+            jn_cell = torch.where(inside, v, torch.full_like(v, float("inf"))).reshape(xfin.shape[:2])
+        jn_true = None
+        if any(r.get("tautrue", 0) > 0 for r in rl):
+            jn_true = true_jinv_norm(vJ, xfin.reshape(-1, 3), offk, sck).reshape(xfin.shape[:2])
         tot["fetches_exact"] += int(nfetch.long().sum())
         tot["survivors"] += int(keep_exact.sum())
         tot["valid"] += int(valid.sum())
@@ -257,10 +366,13 @@ def main():
         jn_hist += torch.histc(torch.bucketize(jn[keep_exact].cpu(), jn_edges[1:-1]).float(), bins=len(jn_edges) - 1, min=0, max=len(jn_edges) - 1).long()
         for r, a in zip(rl, acc):
             e = evaluate(traj, nfetch, valid, xfin, jn, keep_exact, r["eps"], r["tau"], r["kappa"], r["k0"], r["samecell"], cells, r["tau2"], jtraj,
-                         examples=(examples if (r["eps"] == 1e-3 and r["tau"] == 2.5 and r["samecell"] == 1 and r["tau2"] == 3.0) else None))
+                         examples=(examples if (r["eps"] == 1e-3 and r["tau"] == 2.5 and r["samecell"] == 1 and r["tau2"] == 3.0 and not r.get("steep")) else None),
+                         steep=r.get("steep", 0.0), gtraj=search.gtraj, tautrue=r.get("tautrue", 0.0), jn_true=jn_true,
+                         taucell=r.get("taucell", 0.0), jn_cell=jn_cell)
             for k in a:
                 a[k] += e[k]
         del traj, jtraj
+        search.gtraj = None
     res = dict(points=P, fetches_per_point_exact=tot["fetches_exact"] / P, survivors_per_point=tot["survivors"] / P,
                valid_per_point=tot["valid"] / P, jn_edges=jn_edges.tolist(), jn_hist_survivors=jn_hist.tolist(),
                dup_dist_edges=dd_edges.tolist(), dup_dist_hist_by_jn=dd_hist.tolist(), rules=[], examples=examples[:40])
@@ -269,7 +381,7 @@ def main():
                                  flagged=a["flagged"] / P, set_mismatch=a["mismatch"] / P, lost_root=a["lost"] / P, extra=a["extra"] / P))
     print(json.dumps(res))
     for r in res["rules"]:
-        print(f"# eps={r['eps']:g} tau={r['tau']:g} kappa={r['kappa']:g} k0={r['k0']} samecell={r['samecell']} tau2={r['tau2']:g}: fetches {r['fetches_per_point']:.2f} (-{100 * r['saved']:.1f} %) "
+        print(f"# eps={r['eps']:g} tau={r['tau']:g} kappa={r['kappa']:g} k0={r['k0']} samecell={r['samecell']} tau2={r['tau2']:g} steep={r.get('steep', 0):g} tautrue={r.get('tautrue', 0):g} taucell={r.get('taucell', 0):g}: fetches {r['fetches_per_point']:.2f} (-{100 * r['saved']:.1f} %) "
               f"flagged {r['flagged']:.2e} mismatch {r['set_mismatch']:.2e} lost {r['lost_root']:.2e} extra {r['extra']:.2e}", file=sys.stderr)
 
 

@@ -48,7 +48,7 @@ def search(dfm, pts, eps, counters=None):
                                 dfm.scale_kernel, 1e-5, 1e-1)
     else:
         fast_snarf.fuse_broyden_spec(x, pts.reshape(1, P, 3), vj, dfm.tfs, dfm.init_bones, None, valid, dfm.offset_kernel,
-                                     dfm.scale_kernel, 1e-5, 1e-1, eps, counters=counters)
+                                     dfm.scale_kernel, 1e-5, 1e-1, eps, counters=counters, cell_tight=dfm.cell_tight)
     return x, valid
 
 
