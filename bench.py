@@ -422,8 +422,10 @@ def main():
         finally:
             rs.deformer.spec_eps = eps0
         search_modes = dict(
-            timed="K9-consistent early filter (csrc/snarf.hip: retire inside the eps-box of a tight later root, same voxel cell; redo a point with "
-                  "the filter off when a completed root is 1e-4 .. 2e-4 from a recorded one)",
+            timed="K9-consistent early filter (csrc/snarf.hip: retire inside the eps-box of a tight later root, same voxel cell, only where the TRUE "
+                  "skinning Jacobian is tight all over that cell (ia_cell_tightness); redo a point with the filter off when a completed root is "
+                  "1e-4 .. 2e-4 from a recorded one)",
+            cell_tightness_table=rs.deformer.cell_tight is not None,
             eps=eps0, ms_per_step=round(ms_per_step, 3),
             search_to_the_end=dict(ms_per_step=round(exact_ms, 3), rays_per_s=round(n_rays / (exact_ms * 1e-3), 1),
                                    note="IA_BROYDEN_SPEC_EPS=0: all 13 searches of every point to their end + K9 pass; 2 steps after 1 warm-up, same process"),
