@@ -585,15 +585,18 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(IA_BR2_
 //   (c) x_k lies in the SAME voxel cell as r (shrunk by SPEC_CELL_MARGIN): g is piecewise polynomial with kinks on the cell faces, and
 //       two distinct well-conditioned roots closer than eps only occur across a kink;
 //   (d) the search's own J_inv estimate has norm <= SPEC_TAU_SELF (k >= 1): it is not sliding along a near-singular valley, where
-//       it could stop farther than 1e-4 from r.
-// (a)-(c) are ONE box test per recorded root: the eps-box around r intersected with r's cell, empty for a root that is not tight.
+//       it could stop farther than 1e-4 from r;
+//   (e) the TRUE Jacobian of the skinning map is tight all over r's cell (cell_tight, cell_tightness_kernel above): Broyden's estimate
+//       of (b) is blind to a fold of the map next to r, where two roots sit 1e-4 ... 1e-3 apart in a flat valley of |g| < cvg.
+// (a)-(c), (e) are ONE box test per recorded root: the eps-box around r intersected with r's cell, empty for a root that is not tight.
 // A search that COMPLETES valid is compared (L2, K9's expression) with the recorded roots: below 1e-4 it is a duplicate K9 drops;
 // from 2e-4 up it is recorded (K9 keeps it: every later valid root, retired ones included, lies within 1e-4 of a recorded one);
 // in between -- or when the SPEC_ROOTS slots are full -- the lane REDOES THE POINT with the filter off (all 13 searches to their
-// end) and hands the 13 results to rows_flagged_kernel, which applies K9 literally.  Measured on the headline frame's 16.4 M march
-// points (tools/k9_rule_probe.py, profiles/r04_k9_rule_probe_*.json): 40.7 % fewer fetches than the exact search, candidate set
-// different from K9's on 1 point (6e-8), no distinct root lost, 1.8e-4 of the points redone; the synthetic pose: 31 % fewer, 0
-// of 18.0 M points different.  Everything that is not retired runs the operation sequence of broyden_kernel: surviving
+// end) and hands the 13 results to rows_flagged_kernel, which applies K9 literally.  Measured on the march points of the eight reference
+// poses (tools/spec_search_probe.py, profiles/r04_spec_search_probe_poses.jsonl; 145.8 M points): 29 ... 41 % fewer fetches than the
+// exact search, candidate set identical to K9's on EVERY point (without (e): 1 ... 12 points per pose differ, 3e-7), 1.8e-4 of the
+// points redone.  eps: larger boxes are not safe (2e-3 / 3e-3 / 5e-3: 1 / 3 / 6 differing points on one of the poses) and buy little
+// (-11 % fetches, -3 % time at 5e-3).  Everything that is not retired runs the operation sequence of broyden_kernel: surviving
 // candidates are bit-identical to the exact search's.  eps = 0 never retires.  Scheduling as broyden_persistent2_kernel: every
 // loop iteration is exactly one trilinear fetch per busy lane; a lane that finishes a search starts its point's next init at
 // once, a lane that finishes a point pulls the workgroup's next point.

@@ -278,6 +278,10 @@ def evaluate(traj, nfetch, valid, xfin, jn, keep_exact, eps, tau, kappa, k0, sam
 
 def rules():
     out = []
+    if os.environ.get("IA_RULES") == "eps":
+        for eps, tau2, taucell in itertools.product((1e-3, 2e-3, 5e-3, 2e-2), (3.0, 1e9), (2.5, 2.0)):
+            out.append(dict(eps=eps, tau=2.5, kappa=1e9, k0=1, samecell=1, tau2=tau2, taucell=taucell))
+        return out
     if os.environ.get("IA_RULES") == "cell":
         out.append(dict(eps=1e-3, tau=2.5, kappa=1e9, k0=1, samecell=1, tau2=3.0))
         for taucell, tau in itertools.product((2.0, 2.25, 2.5, 3.0), (2.5, 1e9)):
