@@ -120,7 +120,20 @@ def cell_table(vJ, offk, sck, m=3):
                 sign_min = torch.minimum(sign_min, det.reshape(out.shape))
                 sign_max = torch.maximum(sign_max, det.reshape(out.shape))
     out = torch.where((sign_min > 0) | (sign_max < 0), out, torch.full_like(out, float("inf")))
+    cell_table.sign = torch.where(sign_min > 0, 1, torch.where(sign_max < 0, -1, 0)).to(torch.int8)
     return out
+
+
+def dilate_table(ctab, sign, tau):
+    """tight3 [D-1,H-1,W-1] bool: the cell AND its 26 neighbours are tight (<= tau) with ONE sign of det (cells outside the grid count as
+    not tight): the skinning map is coherently oriented and steep on the whole neighbourhood, so no second root exists within a cell width."""
+    import torch.nn.functional as F
+    t = (ctab <= tau)
+    pos = (t & (sign > 0)).float()[None, None]
+    neg = (t & (sign < 0)).float()[None, None]
+    allpos = -F.max_pool3d(-F.pad(pos, (1, 1, 1, 1, 1, 1), value=0.0), 3, 1) > 0.5
+    allneg = -F.max_pool3d(-F.pad(neg, (1, 1, 1, 1, 1, 1), value=0.0), 3, 1) > 0.5
+    return (allpos | allneg)[0, 0]
 
 
 def search(xd, vJ, tfs, bones, offk, sck):
@@ -278,6 +291,11 @@ def evaluate(traj, nfetch, valid, xfin, jn, keep_exact, eps, tau, kappa, k0, sam
 
 def rules():
     out = []
+    if os.environ.get("IA_RULES") == "nocell":
+        out.append(dict(eps=1e-3, tau=2.5, kappa=1e9, k0=1, samecell=1, tau2=3.0, taucell=2.5))
+        for eps, tau2, taucell, dil in itertools.product((1e-3, 2e-3), (3.0, 1e9), (2.5, 2.0), (1, 0)):
+            out.append(dict(eps=eps, tau=2.5, kappa=1e9, k0=1, samecell=0, tau2=tau2, taucell=taucell, dilate=dil))
+        return out
     if os.environ.get("IA_RULES") == "eps":
         for eps, tau2, taucell in itertools.product((1e-3, 2e-3, 5e-3, 2e-2), (3.0, 1e9), (2.5, 2.0)):
             out.append(dict(eps=eps, tau=2.5, kappa=1e9, k0=1, samecell=1, tau2=tau2, taucell=taucell))
@@ -329,6 +347,7 @@ def main():
     dd_hist = torch.zeros((len(jn_edges) - 1, len(dd_edges) - 1), dtype=torch.long)
     examples = []
     ctab = None
+    dtabs = {}
     for c0 in range(0, P, chunk):
         x = xd[c0:c0 + chunk]
         traj, nfetch, valid, xfin, jn, jtraj = search(x, vJ, tfs, bones, offk, sck)
@@ -347,6 +366,13 @@ def main():
             inside = (cx >= 0) & (cx < W_ - 1) & (cy >= 0) & (cy < H_ - 1) & (cz >= 0) & (cz < D_ - 1)
             v = ctab[cz.clamp(0, D_ - 2), cy.clamp(0, H_ - 2), cx.clamp(0, W_ - 2)]
             jn_cell = torch.where(inside, v, torch.full_like(v, float("inf"))).reshape(xfin.shape[:2])
+            jn_cell_dil = {}
+            for tc in sorted({r.get("taucell", 0) for r in rl if r.get("dilate")}):
+                if tc not in dtabs:
+                    dtabs[tc] = dilate_table(ctab, cell_table.sign, tc)
+                    print("# dilated table tau", tc, "tight3", float(dtabs[tc].float().mean()), "tight", float((ctab <= tc).float().mean()), file=sys.stderr)
+                vd = dtabs[tc][cz.clamp(0, D_ - 2), cy.clamp(0, H_ - 2), cx.clamp(0, W_ - 2)]
+                jn_cell_dil[tc] = torch.where(inside & vd, torch.zeros_like(v), torch.full_like(v, float("inf"))).reshape(xfin.shape[:2])
         jn_true = None
         if any(r.get("tautrue", 0) > 0 for r in rl):
             jn_true = true_jinv_norm(vJ, xfin.reshape(-1, 3), offk, sck).reshape(xfin.shape[:2])
@@ -372,7 +398,7 @@ def main():
             e = evaluate(traj, nfetch, valid, xfin, jn, keep_exact, r["eps"], r["tau"], r["kappa"], r["k0"], r["samecell"], cells, r["tau2"], jtraj,
                          examples=(examples if (r["eps"] == 1e-3 and r["tau"] == 2.5 and r["samecell"] == 1 and r["tau2"] == 3.0 and not r.get("steep")) else None),
                          steep=r.get("steep", 0.0), gtraj=search.gtraj, tautrue=r.get("tautrue", 0.0), jn_true=jn_true,
-                         taucell=r.get("taucell", 0.0), jn_cell=jn_cell)
+                         taucell=r.get("taucell", 0.0), jn_cell=(jn_cell_dil[r["taucell"]] if r.get("dilate") else jn_cell))
             for k in a:
                 a[k] += e[k]
         del traj, jtraj
@@ -385,7 +411,7 @@ def main():
                                  flagged=a["flagged"] / P, set_mismatch=a["mismatch"] / P, lost_root=a["lost"] / P, extra=a["extra"] / P))
     print(json.dumps(res))
     for r in res["rules"]:
-        print(f"# eps={r['eps']:g} tau={r['tau']:g} kappa={r['kappa']:g} k0={r['k0']} samecell={r['samecell']} tau2={r['tau2']:g} steep={r.get('steep', 0):g} tautrue={r.get('tautrue', 0):g} taucell={r.get('taucell', 0):g}: fetches {r['fetches_per_point']:.2f} (-{100 * r['saved']:.1f} %) "
+        print(f"# eps={r['eps']:g} tau={r['tau']:g} kappa={r['kappa']:g} k0={r['k0']} samecell={r['samecell']} tau2={r['tau2']:g} steep={r.get('steep', 0):g} tautrue={r.get('tautrue', 0):g} taucell={r.get('taucell', 0):g} dilate={r.get('dilate', 0)}: fetches {r['fetches_per_point']:.2f} (-{100 * r['saved']:.1f} %) "
               f"flagged {r['flagged']:.2e} mismatch {r['set_mismatch']:.2e} lost {r['lost_root']:.2e} extra {r['extra']:.2e}", file=sys.stderr)
 
 
