@@ -1437,7 +1437,9 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
     // narrower window of the sorted order the resident workgroups cover (1280 x 256 points).  PERSISTENT workgroups that walk the chunks
     // b, b + G, ... as one stream (no drain at all; IA_BR_SPEC_PERSIST=1) lose badly, 13.6 - 14.7 ms: with a static stride the
     // workgroups drift apart by whole rounds and the window grows to several G x 2^log2c points -- the hardware's in-order dispatch of
-    // one-chunk workgroups IS the dynamic queue that keeps the window tight.
+    // one-chunk workgroups IS the dynamic queue that keeps the window tight.  Chunks of MORE points than lanes (the lanes that finish first
+    // take the extra ones while the chunk's slow points are still running) lose as well: 288 / 320 / 384 points per 256 lanes 10.11 / 9.94 /
+    // 9.70 ms against 8.90 (same box, search + rows): a second point started late in the workgroup's life extends it by a whole search.
     int log2c = 8;
     if (const char* e = getenv("IA_BR_SPEC_LOG2C")) { const int v = atoi(e); if (v >= 6 && v <= 14) log2c = v; }
     const int64_t n_chunks = (N + ((int64_t)1 << log2c) - 1) >> log2c;
