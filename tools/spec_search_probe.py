@@ -100,7 +100,7 @@ def main():
     n_sec = int(os.environ.get("IA_NSEC", str(1 << 21)))
     pose = os.environ.get("IA_POSE", "male-3-casual:0")
     rs, rays, _ = S.build_frame(dev, 540, 540, pose_seed=0, beta=0.01, pose=(None if pose == "synthetic:0" else pose))
-    pts = march_points(rs, rays, n_sec)
+    pts = march_points(rs, rays, n_sec, seed=int(os.environ.get("IA_SEED", "0")))       # IA_SEED: another draw of the secondary rays
     dfm, geo = rs.deformer, rs.geometry
     P = pts.shape[0]
     os.environ["IA_BROYDEN_SCHEDULE"] = "persistent"
@@ -116,7 +116,7 @@ def main():
                                      L.ptr(dfm.tfs), L.ptr(dfm.init_bones), L.ptr(dfm.offset_kernel), L.ptr(dfm.scale_kernel),
                                      L.f32(1e-5), L.f32(1e-1), L.ptr(cstat), L.stream()), "ia_broyden_stats")
     cs = cstat.cpu().tolist()
-    res = dict(pose=pose, points=P, exact=dict(ms=timed(lambda: search(dfm, pts, None)), fetches=cs[0], corner_loads=cs[1], fetches_per_point=cs[0] / P,
+    res = dict(pose=pose, seed=int(os.environ.get("IA_SEED", "0")), points=P, exact=dict(ms=timed(lambda: search(dfm, pts, None)), fetches=cs[0], corner_loads=cs[1], fetches_per_point=cs[0] / P,
                                     survivors_per_point=float(k0.float().sum() / P)), spec=[])
     for eps in [float(e) for e in os.environ.get("IA_EPS_LIST", "0,5e-4,1e-3,2e-3").split(",")]:
         r = compare(dfm, geo, pts, eps, (x0, v0, k0, s0))
