@@ -101,6 +101,18 @@ def main():
     pose = os.environ.get("IA_POSE", "male-3-casual:0")
     rs, rays, _ = S.build_frame(dev, 540, 540, pose_seed=0, beta=0.01, pose=(None if pose == "synthetic:0" else pose))
     pts = march_points(rs, rays, n_sec, seed=int(os.environ.get("IA_SEED", "0")))       # IA_SEED: another draw of the secondary rays
+    if os.environ.get("IA_POINTS") == "box":          # another distribution: uniform in the frame's bounding box (most points far from the body)
+        g = torch.Generator().manual_seed(int(os.environ.get("IA_SEED", "0")))
+        lo, hi = rs.aabbs[0, :3], rs.aabbs[0, 3:]
+        q = (torch.rand((pts.shape[0], 3), generator=g).to(dev) * (hi - lo) + lo).contiguous()
+        pts = q[rs._spatial_order(q).long()].contiguous()
+    elif os.environ.get("IA_POINTS") == "primary":    # the edges of the primary march (camera rays)
+        r = rs.deformer.transform_rays_w2s(rays.float())
+        ro, rd = r[:, :3].contiguous(), r[:, 3:6].contiguous()
+        iv, sm, _ = nerfacc.traverse_grids(ro, rd, rs.binaries, rs.aabbs, torch.zeros(ro.shape[0], device=dev), torch.full((ro.shape[0],), 1e10, device=dev),
+                                           rs.render_step_size, 0.0, grid_bits=rs.grid_bits)
+        q = render.ray_points(ro, rd, iv.ray_indices, iv.vals)
+        pts = q[rs._spatial_order(q).long()].contiguous()
     dfm, geo = rs.deformer, rs.geometry
     P = pts.shape[0]
     os.environ["IA_BROYDEN_SCHEDULE"] = "persistent"
