@@ -219,7 +219,10 @@ def main():
     # reservation moves the remaining growth in front of the warm-up.  288 GB of HBM: the arena is under half of the device.
     torch.cuda.memory._set_allocator_settings("roundup_power2_divisions:8")
     if not share_gpu:
-        _arena = torch.empty((136 if args.workload == "headline" else 24) << 30, dtype=torch.uint8, device=dev)
+        # (with the secondary march on its own streams most of the working set lives in THEIR pools: a smaller reservation for the caller's)
+        multi = int(os.environ.get("IA_SECONDARY_STREAMS", "2")) > 1
+        _arena = torch.empty(int(os.environ.get("IA_BENCH_ARENA_GIB", ("16" if multi else "136") if args.workload == "headline" else "24")) << 30,
+                             dtype=torch.uint8, device=dev)
         del _arena
     from intrinsicavatar_amd import build
     _build = build
@@ -365,6 +368,14 @@ def main():
         with open(args.aten_profile, "w") as f:
             f.write(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=60, max_name_column_width=60))
     detail, dt_instr, k_instr = {}, 0.0, 0
+    # The instrumented step runs the secondary march on ONE stream: a roofline prices a kernel that has the device to itself, and the
+    # timed region's streams (render.RenderStep.SECONDARY_STREAMS) let launches of two chunks share it.
+    timed_streams = rs.SECONDARY_STREAMS
+    rs.SECONDARY_STREAMS = 1
+    if timed_streams > 1 and not args.no_breakdown:
+        torch.cuda.empty_cache()          # the working set moves from the side streams' pools to the caller's: hand the cached blocks back first
+        step()                            # ... and one untimed step to fill the caller's pool again (~130 GiB of hipMalloc)
+        torch.cuda.synchronize()
     if not args.no_breakdown:
         k_instr = 1 if headline else args.steps
         lib.start()
@@ -377,6 +388,9 @@ def main():
         if os.environ.get("IA_BENCH_DETAIL"):       # per-launch (ms, units) of the instrumented step(s), for tuning
             for name_, calls_ in sorted(detail.items(), key=lambda kv: -sum(c[0] for c in kv[1]))[:10]:
                 print(name_, [(round(c[0], 2), c[1]) for c in calls_], file=sys.stderr)
+    rs.SECONDARY_STREAMS = timed_streams
+    if timed_streams > 1 and not args.no_breakdown:
+        torch.cuda.empty_cache()
     if world > 1:
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -506,6 +520,8 @@ def main():
                 roofline.update(
                     bound="l1 (cache-gather, SURVEY 8(d)): vector-memory path, 256 CUs x 64 B/clk x 2.4 GHz",
                     achieved=round(l1_rate, 1), peak=round(L1_PEAK_GBPS, 1), frac=round(l1_rate / L1_PEAK_GBPS, 4),
+                    launch_durations=("live HIP events of one extra step with the secondary march on ONE stream (the kernel has the device to itself); "
+                                      f"the timed region runs it on {timed_streams}"),
                     algorithmic_model="COUNTED trilinear fetches (the search kernel's own counters / ia_broyden_stats, one extra untimed step) x in-range corners x 48 B "
                                       "through the L1 path / live HIP-event time of the entry point",
                     fetches_per_step=int(c[0]), corner_loads_per_step=int(c[1]), bytes_per_corner=48,
@@ -590,7 +606,9 @@ def main():
                        "host_cpu_throttled_ms_in_timed_region": (None if not (thr0 and thr1) else round((thr1[1] - thr0[1]) / 1e3, 1)),
                        "optimizer_step_in_timed_region": bool(opt is not None), "frames_per_step_per_gpu": 1,
                        "peak_device_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                       "peak_reserved_memory_GiB": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1),
                        "parallelism": f"frame/ray-batch sharding x{world}", "samples": stats,
+                       "secondary_march_streams": timed_streams,
                        "gradient_allreduce": (None if sync is None else dict(backend=dist.get_backend(), world=dist.get_world_size(),
                                                                             bytes_per_step=int(reduced_bytes[0]))),
                        "library_sources_sha256_16": _build.source_fingerprint(), "library_built_from": _build.built_fingerprint()},

@@ -191,19 +191,20 @@ class SNARFDeformer:
         fwd = torch.empty((1, P, I, 3, 3), device=dev) if want_fwd else None
         cnt, meta, start, ovf_head = (torch.empty(P, dtype=torch.int32, device=dev) for _ in range(4))
         # overflow records + the list of points the kernel redoes with the filter off (1 / 64 of the batch): a grow-only work area
-        self._ovf_scratch = L.scratch("spec_rows", int(lib.ia_spec_rows_overflow_bytes(L.i64(P))), dev)
-        self._ovf_cap = int(lib.ia_spec_rows_overflow_capacity(L.i64(P)))
+        # (locals, not attributes: concurrent calls on several streams -- render.compute_indirect_radiance -- each have their own)
+        ovf_scratch = L.scratch("spec_rows", int(lib.ia_spec_rows_overflow_bytes(L.i64(P))), dev)
+        ovf_cap = self._ovf_cap = int(lib.ia_spec_rows_overflow_capacity(L.i64(P)))
         tot = torch.empty(2, dtype=torch.int32, device=dev)
         fast_snarf.fuse_broyden_spec_rows(x_rows, pts.reshape(1, P, 3), fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs, self.init_bones,
-                                          Jinv, cnt, meta, start, ovf_head, self._ovf_scratch, tot, self.offset_kernel, self.scale_kernel,
+                                          Jinv, cnt, meta, start, ovf_head, ovf_scratch, tot, self.offset_kernel, self.scale_kernel,
                                           1e-5, 1e-1, self.spec_eps, fwd_J=fwd, counters=self.spec_counters, order=order,
                                           cell_tight=self.cell_tight)
         Q, n_over = tot.tolist()                                     # the one read-back of the call
         self.last_overflow_records = n_over                          # points the kernel searched again with the filter off
         if os.environ.get("IA_DEBUG_FLAGGED"):
             import sys
-            print(f"[spec rows] P={P} Q={Q} redone={n_over} ({n_over / max(P, 1):.2e}) cap={self._ovf_cap}", file=sys.stderr)
-        if n_over > self._ovf_cap:
+            print(f"[spec rows] P={P} Q={Q} redone={n_over} ({n_over / max(P, 1):.2e}) cap={ovf_cap}", file=sys.stderr)
+        if n_over > ovf_cap:
             # more points to redo than the flagged list holds (never seen): this batch goes through is_valid + K9 instead
             del x_rows, cnt, meta, start, Jinv, fwd
             if order is not None:
@@ -213,7 +214,7 @@ class SNARFDeformer:
         cand_x = torch.empty((Q, 3), device=dev)
         cand_src = torch.empty(Q, dtype=torch.int32, device=dev) if with_src else None
         L.check(lib.ia_deform_rows_pack(L.i64(P), L.i32(I), L.ptr(x_rows), L.ptr(cnt), L.ptr(meta), L.ptr(start), L.ptr(ovf_head),
-                                        L.ptr(self._ovf_scratch), L.ptr(cand_x), L.ptr(cand_src),
+                                        L.ptr(ovf_scratch), L.ptr(cand_x), L.ptr(cand_src),
                                         L.ptr(normalize[0].contiguous().float() if normalize else None),
                                         L.ptr(normalize[1].contiguous().float() if normalize else None), st), "ia_deform_rows_pack")
         return cand_x, cand_src, cnt, start, Q, (fwd[0] if want_fwd else None), (Jinv[0] if want_jinv else None)

@@ -256,11 +256,69 @@ class RenderStep:
         step = (far - near) / (n_secondary - 1)
         beta = self._beta()
         w2s_rot = self.deformer.w2s[:3, :3].contiguous()
+        # Chunks are independent (rays are): with SECONDARY_STREAMS > 1 they are worked off by that many host threads, each on its own
+        # HIP stream, so that the kernels of two chunks share the device -- the search (vector-memory path + VALU), the hash gather
+        # (L1 misses in flight) and the SDF head (matrix pipe) are bound by different units, and every chunk has data-dependent size
+        # read-backs during which its stream would otherwise leave the GPU to the tail of one kernel.  Two PROCESSES on one GPU reach
+        # 1.16 x the throughput of one on the headline step (tools/runs/r04_two_processes_one_gpu.sh); inside one process two streams
+        # get 4 % (340.7 -> 326.5 ms per step, same box), a third stream nothing more (tools/runs/r04_streams_ab.sh).  Results do not depend on the chunking (ray-batch sharding invariance),
+        # so they are bit-identical to the serial loop (tests/test_gpu_relight_oracle.py).
+        n_streams = self.SECONDARY_STREAMS if (M > self.SECONDARY_STREAMS_MIN_RAYS and dev.type == "cuda") else 1
+        if n_streams > 1:
+            # 5 / 8 of the serial chunk per stream: the live working set of two chunks stays that of one serial chunk (141 against 144 GiB on
+            # the headline step); what grows is the allocator's reserve -- every stream has its own pool (216 GiB reserved at 10 Mi rays per
+            # chunk, 236 at 16 Mi for the same 4 %)
+            chunk = max(chunk * 5 // 8, 1 << 18)
         # ray chunks of at most `chunk` rays; a chunk whose march produced more sample points than four search batches is split
         # in two and marched again (the march costs ~1 ms): the working set is bounded in SAMPLES, not only in rays
         work = [(c0, min(c0 + chunk, M)) for c0 in range(0, M, chunk)][::-1]
-        while work:
-            c0, c1 = work.pop()
+        args = (rays_o, rays_d, near, far, step, beta, w2s_rot, tr, rgb)
+        if n_streams <= 1 or len(work) <= 1:
+            self._secondary_chunks(work, None, *args)
+            return tr, rgb
+        import threading
+        _ = self.grid_bits                                      # lazily cached host-side state: made before the threads start
+        main = torch.cuda.current_stream(dev)
+        if getattr(self, "_side_streams", None) is None or len(self._side_streams) != n_streams or self._side_streams[0].device != dev:
+            self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+        lock, errors = threading.Lock(), []
+
+        def worker(side):
+            try:
+                with torch.cuda.device(dev), torch.cuda.stream(side), torch.no_grad():      # device, stream and grad mode are per thread
+                    self._secondary_chunks(work, lock, *args)
+            except BaseException as e:                                                       # noqa: B902 -- re-raised by the caller
+                errors.append(e)
+        threads = []
+        for side in self._side_streams:
+            side.wait_stream(main)                              # inputs were produced on the caller's stream
+            threads.append(threading.Thread(target=worker, args=(side,), daemon=True))
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for side in self._side_streams:
+            main.wait_stream(side)                              # tr / rgb are read on the caller's stream
+        if errors:
+            raise errors[0]
+        return tr, rgb
+
+    SECONDARY_STREAMS = int(os.environ.get("IA_SECONDARY_STREAMS", "2"))
+    SECONDARY_STREAMS_MIN_RAYS = 1 << 20
+
+    def _secondary_chunks(self, work, lock, rays_o, rays_d, near, far, step, beta, w2s_rot, tr, rgb):
+        """works chunks off `work` (shared between the streams' threads when lock is given) into tr / rgb."""
+        dev = rays_o.device
+        while True:
+            if lock is not None:
+                with lock:
+                    if not work:
+                        return
+                    c0, c1 = work.pop()
+            else:
+                if not work:
+                    return
+                c0, c1 = work.pop()
             ro, rd = rays_o[c0:c1].contiguous(), rays_d[c0:c1].contiguous()
             m = ro.shape[0]
             intervals, samples, _ = nerfacc.traverse_grids(
@@ -268,7 +326,11 @@ class RenderStep:
                 step, 0.0, grid_bits=self.grid_bits, max_extent=far - near, incoherent=True, termination_planes=False)
             if samples.vals.shape[0] > 4 * self.MAX_SEARCH_POINTS and m > 1:
                 del intervals, samples
-                work += [(c0 + m // 2, c1), (c0, c0 + m // 2)]
+                if lock is not None:
+                    with lock:
+                        work.extend([(c0 + m // 2, c1), (c0, c0 + m // 2)])
+                else:
+                    work.extend([(c0 + m // 2, c1), (c0, c0 + m // 2)])
                 continue
             t_starts, t_ends = samples.interval_ends(intervals)
             ray_indices = samples.ray_indices
@@ -310,7 +372,6 @@ class RenderStep:
             acc = nerfacc._Accumulate.apply(w, None, ray_indices, pinfo)
             tr[c0:c0 + m] = 1.0 - acc
             rgb[c0:c0 + m] = nerfacc._Accumulate.apply(w, rgbs, ray_indices, pinfo)
-        return tr, rgb
 
     # ------------------------------------------------------------------ relighting (render_mode = light)
     @torch.no_grad()

@@ -220,6 +220,41 @@ def test_volume_interaction_kernels_vs_reference_op_sequence(setup, spp):
     torch.testing.assert_close(T_a.grad, T_b.grad, rtol=2e-5, atol=1e-7)
 
 
+def test_secondary_march_on_two_streams_equals_the_serial_loop(setup):
+    """compute_indirect_radiance works its ray chunks off on SECONDARY_STREAMS host threads, each with its own HIP stream (the kernels of
+    two chunks share the device): rays are independent, so transmittance and indirect radiance must be bit-identical to the serial loop --
+    whichever thread takes which chunk, with uneven chunks, and when the caller itself runs on a side stream."""
+    rs, rays, mat, env, sc = setup(64)
+    out = rs.forward(rays)
+    hit = torch.nonzero(out["opacity"][:, 0] > 0.5)[:, 0]
+    assert hit.numel() > 200
+    g = torch.Generator().manual_seed(5)
+    M = 700_001
+    r = rs.deformer.transform_rays_w2s(rays.float())
+    pick = hit[torch.randint(0, hit.shape[0], (M,), generator=g).to(DEV)]
+    o = (r[pick, :3] + r[pick, 3:6] * out["depth"][pick]).contiguous()
+    d = torch.nn.functional.normalize(torch.randn((M, 3), generator=g), dim=-1).to(DEV).contiguous()
+    saved = rs.SECONDARY_STREAMS, rs.SECONDARY_STREAMS_MIN_RAYS
+    try:
+        rs.SECONDARY_STREAMS_MIN_RAYS = 1000
+        rs.SECONDARY_STREAMS = 1
+        tr1, rgb1 = rs.compute_indirect_radiance(o, d, chunk=150_000)
+        assert 0.02 < float((tr1 < 0.5).float().mean()) < 0.98 and float(rgb1.abs().sum()) > 0
+        for n_streams, chunk in ((2, 240_000), (3, 160_001), (2, 1 << 24)):
+            rs.SECONDARY_STREAMS = n_streams
+            tr2, rgb2 = rs.compute_indirect_radiance(o, d, chunk=chunk)
+            assert torch.equal(tr1, tr2) and torch.equal(rgb1, rgb2), (n_streams, chunk)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            rs.SECONDARY_STREAMS = 2
+            tr3, rgb3 = rs.compute_indirect_radiance(o, d, chunk=150_000)
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(tr1, tr3) and torch.equal(rgb1, rgb3)
+    finally:
+        rs.SECONDARY_STREAMS, rs.SECONDARY_STREAMS_MIN_RAYS = saved
+
+
 def test_relight_full_size_properties():
     """BASELINE config 3 at FULL size (540x540, render_mode=light, spp 256, GI off) through size-independent properties:
     one K1 re-sample block of spp entries per ray with samples, fg / bg split consistent with the counts, per-ray re-sampled
