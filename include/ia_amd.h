@@ -98,7 +98,7 @@ int ia_traverse_grids_fused(int64_t n_rays, const float* rays_o, const float* ra
                             int64_t* sm_packed_info, float* iv_vals, uint8_t* iv_is_left, uint8_t* iv_is_right,
                             int64_t* iv_ray_indices, float* sm_vals, int64_t* sm_ray_indices,
                             float* termination_planes, float* sm_t_starts /*[cap_samples] or NULL*/,
-                            float* sm_t_ends /*[cap_samples] or NULL*/, int span_sorted /* 1: walk each 1024-ray tile in order of the rays' box-crossing span (incoherent rays); outputs identical */,
+                            float* sm_t_ends /*[cap_samples] or NULL*/, int span_sorted /* != 0: walk each 1024-ray tile in order of the rays' box-crossing span (incoherent rays); outputs identical.  n > 1: n = upper bound of the samples of one ray (the sort's bins; with 1 it is cap_samples / n_rays -- capacities may be sized for the average ray) */,
                             ia_stream_t stream);
 
 /* ------------------------------------------------------------------------- */

@@ -1097,8 +1097,9 @@ IA_EXPORT int ia_traverse_grids_fused(int64_t n_rays, const float* rays_o, const
     bool sorted = span_sorted != 0 && n_rays >= (1 << 14) && lds <= 32 * 1024 + 64;
     if (const char* tv = getenv("IA_TRAVERSE_TILES")) sorted = (tv[0] == 's') && lds <= 32 * 1024 + 64;
     if (sorted) {
-        // the longest crossing the callers' capacities allow: cap_samples / n_rays steps; bins of 1/62 of that
-        const double max_steps = (double)cap_samples / (double)n_rays;
+        // the longest crossing: span_sorted > 1 is the caller's bound of the samples per ray (capacities may be sized for the AVERAGE ray),
+        // else what the capacities allow, cap_samples / n_rays steps; bins of 1/62 of that
+        const double max_steps = span_sorted > 1 ? (double)span_sorted : (double)cap_samples / (double)n_rays;
         if (max_steps < 30000.0) {
             static bool attr2 = false;
             if (!attr2) {

@@ -146,6 +146,7 @@ def traverse_grids(
 
 
 FUSED_MIN_RAYS = 1 << 19
+FUSED_CAP_PER_RAY = int(os.environ.get("IA_TRAVERSE_CAP_PER_RAY", "24"))
 _AABB_DIAG = {}
 
 
@@ -158,7 +159,11 @@ def _traverse_fused(args, n_rays, aabb, step_size, max_extent, dev, incoherent=F
         _AABB_DIAG[key] = float((a[3:] - a[:3]).norm())
     extent = _AABB_DIAG[key] if max_extent is None else min(_AABB_DIAG[key], float(max_extent))
     smax = int(math.ceil(extent / step_size)) + 2
-    cap_s = n_rays * smax
+    # capacity: the worst case is smax samples on every ray; a batch of rays averages far fewer (secondary rays of the headline step: 9 of 66,
+    # primary rays 1.2 of 130), and the capacity-sized arrays stay alive behind the returned views.  FUSED_CAP_PER_RAY samples per ray on
+    # average (at least 2 M samples) are provided; a batch that needs more raises the kernel's overflow flag and goes through the
+    # two-phase protocol (exact sizes) -- same results, 23 instead of 78 GB behind the views of a 16 Mi-ray chunk.
+    cap_s = min(n_rays * smax, max(n_rays * FUSED_CAP_PER_RAY, 1 << 21))
     cap_e = cap_s + 8 * n_rays
     if cap_e >= (1 << 31):
         return None
@@ -176,7 +181,7 @@ def _traverse_fused(args, n_rays, aabb, step_size, max_extent, dev, incoherent=F
     L.check(lib.ia_traverse_grids_fused(*args, L.ptr(scratch), L.i64(cap_e), L.i64(cap_s), L.ptr(totals), L.ptr(pinfo[0]),
                                         L.ptr(pinfo[1]), L.ptr(iv_vals), L.ptr(iv_flags[0]), L.ptr(iv_flags[1]), L.ptr(iv_ray),
                                         L.ptr(sm_vals), L.ptr(sm_ray), L.ptr(term), L.ptr(sm_ends[0]), L.ptr(sm_ends[1]),
-                                        L.i32(1 if incoherent else 0), st),
+                                        L.i32(max(smax, 2) if incoherent else 0), st),
             "ia_traverse_grids_fused")
     E, S, ovf = (int(v) for v in totals.tolist())          # the one host sync (output sizes are data dependent)
     if ovf:

@@ -88,7 +88,14 @@ def test_traverse_grids_edge_cases(ops, oracle):
     assert iv.vals.numel() == 0 and iv.packed_info.shape == (0, 2)
 
 
-def test_traverse_fused_equals_two_pass(ops, oracle):
+@pytest.fixture
+def worst_case_capacity(ops, monkeypatch):
+    """the fused traversal sizes its outputs for FUSED_CAP_PER_RAY samples per ray on average and falls back to the two-phase protocol
+    beyond that; tests of the fused kernels on dense grids ask for the worst-case capacity so that the fused path is what runs."""
+    monkeypatch.setattr(ops["nerfacc"], "FUSED_CAP_PER_RAY", 1 << 20)
+
+
+def test_traverse_fused_equals_two_pass(ops, oracle, worst_case_capacity):
     """the single-launch traversal (ticketed tiles + look-back scan + element-parallel expansion) returns exactly the
     two-phase outputs: many-run rays (> 8 runs: in-order slow path), secondary-march style rays starting inside the box
     with a far clip, a ragged last tile, and the capacity-overflow fallback."""
@@ -132,7 +139,7 @@ def test_traverse_fused_equals_two_pass(ops, oracle):
 
 
 @pytest.mark.parametrize("n", [65_536 + 77, 300_001])
-def test_traverse_span_sorted_tiles_equal_the_ray_order_kernel(ops, monkeypatch, n):
+def test_traverse_span_sorted_tiles_equal_the_ray_order_kernel(ops, monkeypatch, n, worst_case_capacity):
     """the fused traversal with the rays of a 1024-ray tile walked in order of their box-crossing span (traverse_sorted_kernel,
     big batches) against the ray-order kernel (traverse_fused_kernel) and the two-pass protocol: every output tensor equal --
     only which lane walks which ray changes.  Grids with rays of more than 4 runs (in-order re-walk), rays that miss the box,
@@ -164,8 +171,35 @@ def test_traverse_span_sorted_tiles_equal_the_ray_order_kernel(ops, monkeypatch,
             assert int((a[0].packed_info[:, 1] - a[1].packed_info[:, 1]).max()) > 4      # rays with more than 4 runs
 
 
+def test_traverse_average_sized_capacity_falls_back_when_a_batch_needs_more(ops):
+    """default capacity = FUSED_CAP_PER_RAY samples per ray on average: a dense grid needs more, the kernel raises its overflow flag and the
+    call goes through the two-phase protocol -- same intervals / samples as with the worst-case capacity."""
+    rng = np.random.default_rng(4)
+    n = 600_000
+    aabb = np.array([-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], np.float32)
+    o = (rng.random((n, 3)).astype(np.float32) * 1.6 - 0.8)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    grid = rng.random((64, 64, 64)) < 0.7
+    nf = ops["nerfacc"]
+    args = (T(o), T(d), T(grid)[None], T(aabb)[None], torch.zeros(n, device=DEV), torch.full((n,), 1.5, device=DEV), 0.011, 0.0)
+    a = nf.traverse_grids(*args, method="fused", max_extent=1.5)
+    assert a[1].vals.numel() > nf.FUSED_CAP_PER_RAY * n and a[1].t_starts is None          # fell back
+    saved = nf.FUSED_CAP_PER_RAY
+    try:
+        nf.FUSED_CAP_PER_RAY = 1 << 20
+        b = nf.traverse_grids(*args, method="fused", max_extent=1.5)
+    finally:
+        nf.FUSED_CAP_PER_RAY = saved
+    assert b[1].t_starts is not None
+    for k in ("vals", "packed_info", "ray_indices", "is_left", "is_right"):
+        assert torch.equal(getattr(a[0], k), getattr(b[0], k)), k
+    for k in ("vals", "packed_info", "ray_indices"):
+        assert torch.equal(getattr(a[1], k), getattr(b[1], k)), k
+
+
 @pytest.mark.parametrize("incoherent", [False, True])
-def test_traverse_without_termination_planes_stops_at_the_occupied_box(ops, incoherent):
+def test_traverse_without_termination_planes_stops_at_the_occupied_box(ops, incoherent, worst_case_capacity):
     """termination_planes=False (what render_step asks for): the fused kernels end a ray's walk where it leaves the cell box of the
     occupied cells.  Every interval / sample tensor must equal the full walk's: grids whose occupied cells fill a small part of the
     box, touch its faces, are a single cell, are empty; rz not a multiple of 32 (whole-grid box); rays starting inside, beyond and

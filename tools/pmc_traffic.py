@@ -24,7 +24,7 @@ CMD = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup
 def run_pass(name, counters):
     d = f"/tmp/pmc_{name}"
     subprocess.run(["rm", "-rf", d])
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", IA_SECONDARY_STREAMS="1")      # per-launch counters of kernels that have the device to themselves
     subprocess.run(["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + CMD,
                    cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
