@@ -153,11 +153,13 @@ _AABB_DIAG = {}
 def _traverse_fused(args, n_rays, aabb, step_size, max_extent, dev, incoherent=False, termination_planes=True):
     """single-launch traversal into capacity-sized buffers (ia_traverse_grids_fused); None = capacity exceeded."""
     key = (aabb.data_ptr(), aabb._version)
-    if key not in _AABB_DIAG:            # one tiny D2H copy per grid, not per call
+    diag = _AABB_DIAG.get(key)
+    if diag is None:                     # one tiny D2H copy per grid, not per call (several host threads may get here at once: no read-back of the dict)
         a = aabb.detach().float().cpu()
+        diag = float((a[3:] - a[:3]).norm())
         _AABB_DIAG.clear()
-        _AABB_DIAG[key] = float((a[3:] - a[:3]).norm())
-    extent = _AABB_DIAG[key] if max_extent is None else min(_AABB_DIAG[key], float(max_extent))
+        _AABB_DIAG[key] = diag
+    extent = diag if max_extent is None else min(diag, float(max_extent))
     smax = int(math.ceil(extent / step_size)) + 2
     # capacity: the worst case is smax samples on every ray; a batch of rays averages far fewer (secondary rays of the headline step: 9 of 66,
     # primary rays 1.2 of 130), and the capacity-sized arrays stay alive behind the returned views.  FUSED_CAP_PER_RAY samples per ray on

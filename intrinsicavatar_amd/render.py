@@ -83,20 +83,26 @@ class RenderStep:
     MAX_SEARCH_POINTS = int(os.environ.get("IA_MAX_SEARCH_POINTS", str(150_000_000)))
     SORT_DROP_BITS = int(os.environ.get("IA_SORT_DROP_BITS", "0"))     # low Morton bits left unsorted (0, 3 or 6)
 
+    def _sort_grid_params(self):
+        """(origin, 1 / cell) of the Morton grid of _spatial_order, cached per occupancy box (ONE attribute assignment: several host threads
+        may ask at once)."""
+        gkey = (self.aabbs.data_ptr(), self.aabbs._version)
+        c = getattr(self, "_sort_grid_cache", None)
+        if c is None or c[0] != gkey:
+            # 10 bits per axis over the bounding box of the occupancy grid (every marched sample lies inside it): 2.5 mm cells for
+            # a 2.5 m box.  Measured on the headline step: 1 cm cells 970 ms, 5 mm 948 ms, 2.5 mm 946 ms, 4 cm 1019 ms
+            box = self.aabbs[0].tolist()
+            ext = max(box[3] - box[0], box[4] - box[1], box[5] - box[2]) + 0.04
+            c = (gkey, [box[0] - 0.02, box[1] - 0.02, box[2] - 0.02], float(os.environ.get("IA_SORT_INV_CELL", 1023.0 / ext)))
+            self._sort_grid_cache = c
+        return c[1], c[2]
+
     @torch.no_grad()
     def _spatial_order(self, pts: Tensor) -> Tensor:
         """int32 permutation that lists posed-space points by the Morton code of their cell (ia_morton_order)."""
         n = pts.shape[0]
         import ctypes as C
-        gkey = (self.aabbs.data_ptr(), self.aabbs._version)
-        if getattr(self, "_sort_grid_key", None) != gkey:
-            self._sort_grid_key = gkey
-            # 10 bits per axis over the bounding box of the occupancy grid (every marched sample lies inside it): 2.5 mm cells for
-            # a 2.5 m box.  Measured on the headline step: 1 cm cells 970 ms, 5 mm 948 ms, 2.5 mm 946 ms, 4 cm 1019 ms
-            box = self.aabbs[0].tolist()
-            ext = max(box[3] - box[0], box[4] - box[1], box[5] - box[2]) + 0.04
-            self._sort_grid = ([box[0] - 0.02, box[1] - 0.02, box[2] - 0.02], float(os.environ.get("IA_SORT_INV_CELL", 1023.0 / ext)))
-        lo, inv_cell = self._sort_grid
+        lo, inv_cell = self._sort_grid_params()
         origin = (C.c_float * 3)(*lo)
         lib, st = L.lib(), L.stream()
         order = torch.empty(n, dtype=torch.int32, device=pts.device)
@@ -277,7 +283,7 @@ class RenderStep:
             self._secondary_chunks(work, None, *args)
             return tr, rgb
         import threading
-        _ = self.grid_bits                                      # lazily cached host-side state: made before the threads start
+        _ = self.grid_bits, self._sort_grid_params()            # lazily cached host-side state: made before the threads start
         main = torch.cuda.current_stream(dev)
         if getattr(self, "_side_streams", None) is None or len(self._side_streams) != n_streams or self._side_streams[0].device != dev:
             self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
