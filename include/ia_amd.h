@@ -239,9 +239,11 @@ int ia_filter(int64_t N, int I, const float* x /*[1,N,I,3]*/, const uint8_t* mas
  * (profiles/r04_spec_search_probe_poses.jsonl); without it the rule is round-4a's.
  * counters: NULL or uint64[5], caller-zeroed, accumulated: fetches issued, retired items, completed valid items, points
  * searched again with the filter off, in-range corner loads of the fetches. */
-/* per voxel cell (entry = the cell whose LOW corner is the voxel; the last index of an axis holds 0): 1 iff at 27 sample points of
- * the cell det(dg/dx) keeps one sign and |(dg/dx)^-1|_F <= tau, dg/dx = A(x) + sum_c dw_c/dx (A_c x + b_c) the true Jacobian of
- * g(x) = A(x) x + b(x) - xd on the trilinear voxel_J (weight-gradient term included).  Once per pose, next to ia_precompute. */
+/* per voxel cell (entry = the cell whose LOW corner is the voxel; the last index of an axis holds 0): bit 0 set iff at 27 sample points
+ * of the cell det(dg/dx) keeps one sign and |(dg/dx)^-1|_F <= tau, dg/dx = A(x) + sum_c dw_c/dx (A_c x + b_c) the true Jacobian of
+ * g(x) = A(x) x + b(x) - xd on the trilinear voxel_J (weight-gradient term included); bit 2: that sign is positive; bit 1: the cell's
+ * 26 neighbours are tight too, with the same sign (the map is coherently oriented on the neighbourhood: the retirement box of a root
+ * there is not cut to its cell).  Once per pose, next to ia_precompute. */
 int ia_cell_tightness(int D, int H, int W, const float* voxel_J_cl /*[D,H,W,12]*/, const float* offset, const float* scale, float tau,
                       uint8_t* cell_tight /*[D,H,W]*/, ia_stream_t stream);
 int ia_fuse_broyden_spec(int64_t N, int I, const float* xd_tgt /*[N,3]*/, const float* voxel_J_cl /*[D,H,W,12]*/, int D, int H, int W,

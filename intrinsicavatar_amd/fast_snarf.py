@@ -44,9 +44,10 @@ CELL_TAU = 2.5        # a voxel cell is tight when |(dg/dx)^-1|_F <= CELL_TAU al
 
 
 def cell_tightness(voxel_J: ChannelLastVoxelJ, offset: Tensor, scale: Tensor, tau: float = CELL_TAU) -> Tensor:
-    """uint8 [D,H,W] veto table of the early-filter search (ia_cell_tightness; once per pose, after precompute): 1 = the TRUE Jacobian
-    of the skinning map -- weight-gradient term included -- keeps its sign and |J^-1|_F <= tau at 27 sample points of the voxel cell.
-    A root in a cell with 0 retires no search: next to a fold of the map two roots sit 1e-4 ... 1e-3 apart and Broyden's own J_inv
+    """uint8 [D,H,W] veto table of the early-filter search (ia_cell_tightness; once per pose, after precompute): bit 0 = the TRUE Jacobian
+    of the skinning map -- weight-gradient term included -- keeps its sign and |J^-1|_F <= tau at 27 sample points of the voxel cell
+    (bit 2: the sign; bit 1: the 26 neighbouring cells are tight with the same sign, and the retirement box of a root there needs no cut
+    to its cell).  A root in a cell without bit 0 retires no search: next to a fold of the map two roots sit 1e-4 ... 1e-3 apart and Broyden's own J_inv
     estimate cannot tell (csrc/snarf.hip cell_tightness_kernel).  No counterpart in the reference."""
     assert isinstance(voxel_J, ChannelLastVoxelJ) and voxel_J.data.shape[0] == 1
     _, D, H, W, _ = voxel_J.data.shape

@@ -93,7 +93,7 @@ def test_speculation_removes_fetches_and_changes_almost_nothing(march, eps):
 
 
 def test_cell_tightness_table_against_a_float64_evaluation(march):
-    """ia_cell_tightness: per voxel cell, 1 iff the TRUE Jacobian of g(x) = A(x) x + b(x) - xd (weight-gradient term included) keeps the sign
+    """ia_cell_tightness: per voxel cell, bit 0 set iff the TRUE Jacobian of g(x) = A(x) x + b(x) - xd (weight-gradient term included) keeps the sign
     of its determinant and |J^-1|_F <= 2.5 at the cell's 27 sample points.  Against the same quantity in float64 torch on 40 000 random
     cells + the cells the march's roots fall into; cells within 1e-3 (relative) of the threshold or of det = 0 may go either way."""
     from intrinsicavatar_amd import fast_snarf
@@ -143,10 +143,23 @@ def test_cell_tightness_table_against_a_float64_evaluation(march):
     one_sign = (dmin > 0) | (dmax < 0)
     want = one_sign & (worst <= fast_snarf.CELL_TAU)
     clear = ((worst - fast_snarf.CELL_TAU).abs() > 1e-3 * fast_snarf.CELL_TAU) & (torch.minimum(dmin.abs(), dmax.abs()) > 1e-6)
-    got = tab[cz, cy, cx].bool()
+    got = (tab[cz, cy, cx] & 1).bool()
     assert int(clear.sum()) > 0.99 * n
     assert torch.equal(got[clear], want[clear]), int((got[clear] != want[clear]).sum())
     assert 0.02 < float((~want).float().mean()) < 0.6            # both kinds of cells are sampled
+    # bit 2: the sign of det in a tight cell; bit 1: the cell and its 26 neighbours are tight with ONE sign (no cell cut of the retirement box)
+    sign_pos = (tab[cz, cy, cx] & 4).bool()
+    assert torch.equal(sign_pos[clear & want], (dmin > 0)[clear & want])
+    assert int(((tab & 1) == 0).logical_and((tab & 6) != 0).sum()) == 0          # bits 1 / 2 only on tight cells
+    import torch.nn.functional as F
+    pos = ((tab & 5) == 5).float()[None, None]
+    neg = ((tab & 5) == 1).float()[None, None]
+    allpos = -F.max_pool3d(-F.pad(pos, (1, 1, 1, 1, 1, 1), value=0.0), 3, 1) > 0.5
+    allneg = -F.max_pool3d(-F.pad(neg, (1, 1, 1, 1, 1, 1), value=0.0), 3, 1) > 0.5
+    free3 = (allpos | allneg)[0, 0]
+    free3[:, :, -2:] = False; free3[:, -2:, :] = False; free3[-2:, :, :] = False   # a neighbour that is no cell (last index of an axis): keep the cut
+    assert torch.equal((tab & 2).bool(), free3)
+    assert 0.4 < float(free3[:-1, :-1, :-1].float().mean()) < float((tab & 1)[:-1, :-1, :-1].float().mean())
 
 
 def test_without_the_cell_table_the_rule_is_round_4a(march):

@@ -214,13 +214,14 @@ def cell_id(x, offk, sck, dims):
 
 
 def evaluate(traj, nfetch, valid, xfin, jn, keep_exact, eps, tau, kappa, k0, samecell=0, cells=None, tau2=1e9, jtraj=None, slots=3, zone=2e-4, examples=None,
-             steep=0.0, gtraj=None, tautrue=0.0, jn_true=None, taucell=0.0, jn_cell=None):
+             steep=0.0, gtraj=None, tautrue=0.0, jn_true=None, taucell=0.0, jn_cell=None, jn_free3=None):
     """-> dict of SUMS over the chunk's points."""
     P, I = valid.shape
     dev = valid.device
     roots = torch.zeros((P, slots, 3), device=dev)
     rcell = torch.zeros((P, slots), dtype=torch.long, device=dev)
     tight = torch.zeros((P, slots), dtype=torch.bool, device=dev)
+    free3 = torch.zeros((P, slots), dtype=torch.bool, device=dev)
     n_roots = torch.zeros(P, dtype=torch.long, device=dev)
     flagged = torch.zeros(P, dtype=torch.bool, device=dev)
     keep = torch.zeros((P, I), dtype=torch.bool, device=dev)
@@ -233,8 +234,10 @@ def evaluate(traj, nfetch, valid, xfin, jn, keep_exact, eps, tau, kappa, k0, sam
         have = slot_ids[None, :] < n_roots[:, None]                    # [P,S]
         d = (xk[:, :, None, :] - roots[:, None, :, :]).abs().amax(-1)  # [P,K,S]
         okr = (d < eps) & (have & tight)[:, None, :]
-        if samecell:
+        if samecell == 1:
             okr &= cells[0][:, i, :, None] == rcell[:, None, :]
+        elif samecell == 2:              # hybrid: no cut for a root whose 27-cell neighbourhood is tight with one orientation (free3)
+            okr &= (cells[0][:, i, :, None] == rcell[:, None, :]) | free3[:, None, :]
         if steep > 0:
             # g must be as steep around r as a tight root promises, seen from the last point whose g is known: |g(x_{k-1})| >= steep |x_{k-1} - r|
             # (a flat valley -- a fold of the skinning map -- holds two roots 1e-4 ... 1e-3 apart that both look tight to Broyden's estimate)
@@ -270,6 +273,8 @@ def evaluate(traj, nfetch, valid, xfin, jn, keep_exact, eps, tau, kappa, k0, sam
             ((jn_cell[pi, i] <= taucell) if taucell > 0 else True)
         if samecell:
             rcell[pi, n_roots[pi]] = cells[1][pi, i]
+        if samecell == 2:
+            free3[pi, n_roots[pi]] = jn_free3[pi, i]
         n_roots[pi] += 1
     total_exact = nfetch.long().sum(-1)
     fetches = torch.where(flagged, fetches + total_exact, fetches)
@@ -291,6 +296,11 @@ def evaluate(traj, nfetch, valid, xfin, jn, keep_exact, eps, tau, kappa, k0, sam
 
 def rules():
     out = []
+    if os.environ.get("IA_RULES") == "hybrid":
+        out.append(dict(eps=1e-3, tau=2.5, kappa=1e9, k0=1, samecell=1, tau2=3.0, taucell=2.5))
+        for tau3 in (2.5, 2.0):
+            out.append(dict(eps=1e-3, tau=2.5, kappa=1e9, k0=1, samecell=2, tau2=3.0, taucell=2.5, tau3=tau3))
+        return out
     if os.environ.get("IA_RULES") == "nocell":
         out.append(dict(eps=1e-3, tau=2.5, kappa=1e9, k0=1, samecell=1, tau2=3.0, taucell=2.5))
         for eps, tau2, taucell, dil in itertools.product((1e-3, 2e-3), (3.0, 1e9), (2.5, 2.0), (1, 0)):
@@ -367,6 +377,13 @@ def main():
             v = ctab[cz.clamp(0, D_ - 2), cy.clamp(0, H_ - 2), cx.clamp(0, W_ - 2)]
             jn_cell = torch.where(inside, v, torch.full_like(v, float("inf"))).reshape(xfin.shape[:2])
             jn_cell_dil = {}
+            jn_free3_by = {}
+            for t3 in sorted({r["tau3"] for r in rl if r.get("tau3")}):
+                if ("f", t3) not in dtabs:
+                    dtabs[("f", t3)] = dilate_table(ctab, cell_table.sign, t3)
+                    print("# free3 table tau3", t3, float(dtabs[("f", t3)].float().mean()), file=sys.stderr)
+                vf = dtabs[("f", t3)][cz.clamp(0, D_ - 2), cy.clamp(0, H_ - 2), cx.clamp(0, W_ - 2)]
+                jn_free3_by[t3] = (inside & vf).reshape(xfin.shape[:2])
             for tc in sorted({r.get("taucell", 0) for r in rl if r.get("dilate")}):
                 if tc not in dtabs:
                     dtabs[tc] = dilate_table(ctab, cell_table.sign, tc)
@@ -398,7 +415,8 @@ def main():
             e = evaluate(traj, nfetch, valid, xfin, jn, keep_exact, r["eps"], r["tau"], r["kappa"], r["k0"], r["samecell"], cells, r["tau2"], jtraj,
                          examples=(examples if (r["eps"] == 1e-3 and r["tau"] == 2.5 and r["samecell"] == 1 and r["tau2"] == 3.0 and not r.get("steep")) else None),
                          steep=r.get("steep", 0.0), gtraj=search.gtraj, tautrue=r.get("tautrue", 0.0), jn_true=jn_true,
-                         taucell=r.get("taucell", 0.0), jn_cell=(jn_cell_dil[r["taucell"]] if r.get("dilate") else jn_cell))
+                         taucell=r.get("taucell", 0.0), jn_cell=(jn_cell_dil[r["taucell"]] if r.get("dilate") else jn_cell),
+                         jn_free3=(jn_free3_by[r["tau3"]] if r.get("tau3") else None))
             for k in a:
                 a[k] += e[k]
         del traj, jtraj
@@ -411,7 +429,7 @@ def main():
                                  flagged=a["flagged"] / P, set_mismatch=a["mismatch"] / P, lost_root=a["lost"] / P, extra=a["extra"] / P))
     print(json.dumps(res))
     for r in res["rules"]:
-        print(f"# eps={r['eps']:g} tau={r['tau']:g} kappa={r['kappa']:g} k0={r['k0']} samecell={r['samecell']} tau2={r['tau2']:g} steep={r.get('steep', 0):g} tautrue={r.get('tautrue', 0):g} taucell={r.get('taucell', 0):g} dilate={r.get('dilate', 0)}: fetches {r['fetches_per_point']:.2f} (-{100 * r['saved']:.1f} %) "
+        print(f"# eps={r['eps']:g} tau={r['tau']:g} kappa={r['kappa']:g} k0={r['k0']} samecell={r['samecell']} tau2={r['tau2']:g} steep={r.get('steep', 0):g} tautrue={r.get('tautrue', 0):g} taucell={r.get('taucell', 0):g} dilate={r.get('dilate', 0)} tau3={r.get('tau3', 0):g}: fetches {r['fetches_per_point']:.2f} (-{100 * r['saved']:.1f} %) "
               f"flagged {r['flagged']:.2e} mismatch {r['set_mismatch']:.2e} lost {r['lost_root']:.2e} extra {r['extra']:.2e}", file=sys.stderr)
 
 
