@@ -300,6 +300,9 @@ def rules():
         out.append(dict(eps=1e-3, tau=2.5, kappa=1e9, k0=1, samecell=1, tau2=3.0, taucell=2.5))
         for tau3 in (2.5, 2.0):
             out.append(dict(eps=1e-3, tau=2.5, kappa=1e9, k0=1, samecell=2, tau2=3.0, taucell=2.5, tau3=tau3))
+        for eps in (1.5e-3, 2e-3, 3e-3):
+            out.append(dict(eps=eps, tau=2.5, kappa=1e9, k0=1, samecell=2, tau2=3.0, taucell=2.5, tau3=2.5))
+            out.append(dict(eps=eps, tau=2.0, kappa=1e9, k0=1, samecell=2, tau2=3.0, taucell=2.0, tau3=2.0))
         return out
     if os.environ.get("IA_RULES") == "nocell":
         out.append(dict(eps=1e-3, tau=2.5, kappa=1e9, k0=1, samecell=1, tau2=3.0, taucell=2.5))
