@@ -344,6 +344,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    _flush_c_stdout()            # RCCL's start-up banner (C stdio, block-buffered on a pipe) leaves every rank NOW, not after the JSON line
     lib = L.lib()
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides, nothing else running
     thr0 = cgroup_throttle()
@@ -620,9 +621,22 @@ def main():
             "config2_ms_per_step": (round(config2, 3) if config2 else None),
             "config2_rays_per_s": (round(n_rays / (config2 * 1e-3), 1) if config2 else None),
         }
-        print(json.dumps(line))
+        _flush_c_stdout()
+        print(json.dumps(line), flush=True)          # the ONE line of the contract, and the last thing on stdout
     if world > 1 or force_rccl:
         dist.destroy_process_group()
+    _flush_c_stdout()
+
+
+def _flush_c_stdout():
+    """libraries that write to C stdout (RCCL prints a version banner when its first communicator is made) sit in a block buffer when
+    stdout is a pipe and would come out at exit, AFTER the JSON line a driver reads last: flush them where they happen."""
+    import ctypes
+    try:
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+    except Exception:       # noqa: BLE001 -- best effort
+        pass
 
 
 def self_launch_ranks(n_gpus, script=None):

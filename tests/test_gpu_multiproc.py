@@ -197,7 +197,10 @@ def test_bench_step_through_rccl_on_one_rank():
     p = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--hw", "64", "--spp", "16", "--ray-chunk", "2048",
                         "--no-cpu-baseline", "--no-config2", "--no-search-modes"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
-    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert lines[-1].startswith("{"), lines[-3:]          # the JSON line is the LAST thing on stdout (RCCL's banner is flushed before it)
+    assert sum(l.startswith("{") for l in lines) == 1
+    line = json.loads(lines[-1])
     ar = line["config"]["gradient_allreduce"]
     assert ar["backend"] == "nccl" and ar["world"] == 1 and ar["bytes_per_step"] > 90e6, ar      # two 50.4 MB tables + the small bucket
     assert line["roofline"] is not None and line["value"] > 0
