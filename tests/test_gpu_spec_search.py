@@ -92,6 +92,29 @@ def test_speculation_removes_fetches_and_changes_almost_nothing(march, eps):
     assert 0 < r["redone_points"] < 1e-3 * P   # points the kernel searched again with the filter off
 
 
+def test_candidate_sets_equal_on_the_hardest_reference_pose():
+    """aist frame 319 (out-of-distribution animation pose): the pose on which the filter WITHOUT the cell table differed from
+    search-to-the-end + K9 most often (12 of 18.1 M march points, two distinct roots lost; tools/k9_mismatch_dump.py: pairs of roots next
+    to a fold of the skinning map).  4.5 M march points: candidate sets, min-SDF bits identical; without the table the same batch differs."""
+    from tools import spec_search_probe as SP
+    from intrinsicavatar_amd import synthetic as S, fast_snarf
+    rs, rays, _ = S.build_frame(DEV, 540, 540, pose_seed=0, beta=0.01, pose="aist:319")
+    pts = SP.march_points(rs, rays, 1 << 19)
+    assert pts.shape[0] > 4_000_000
+    dfm = rs.deformer
+    x0, v0 = SP.search(dfm, pts, None)
+    k0 = fast_snarf.filter(x0, v0)
+    old = dfm.spec_eps
+    dfm.spec_eps = 0.0
+    s0 = dfm.deform_sdf(pts, rs.geometry)
+    dfm.spec_eps = old
+    r = SP.compare(dfm, rs.geometry, pts, 1e-3, (x0, v0, k0, s0))
+    assert r["completed_items_bit_identical"] and r["set_mismatch"] == 0.0 and r["lost_root"] == 0.0 and r["sdf_max_abs"] == 0.0, r
+    assert r["fetches"] < 0.75 * int(torch.zeros(1).item() + 49.7 * pts.shape[0])          # ~35 of 49.7 fetches per point
+    frac_vetoed = 1.0 - float((dfm.cell_tight[:-1, :-1, :-1] & 1).float().mean())
+    assert 0.02 < frac_vetoed < 0.2, frac_vetoed
+
+
 def test_cell_tightness_table_against_a_float64_evaluation(march):
     """ia_cell_tightness: per voxel cell, bit 0 set iff the TRUE Jacobian of g(x) = A(x) x + b(x) - xd (weight-gradient term included) keeps the sign
     of its determinant and |J^-1|_F <= 2.5 at the cell's 27 sample points.  Against the same quantity in float64 torch on 40 000 random
