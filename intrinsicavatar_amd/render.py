@@ -274,7 +274,7 @@ class RenderStep:
             # 5 / 8 of the serial chunk per stream: the live working set of two chunks stays that of one serial chunk (141 against 144 GiB on
             # the headline step); what grows is the allocator's reserve -- every stream has its own pool (216 GiB reserved at 10 Mi rays per
             # chunk, 236 at 16 Mi for the same 4 %)
-            chunk = max(chunk * 5 // 8, 1 << 18)
+            chunk = max(min(chunk * 5 // 8, -(-M // n_streams)), self.SECONDARY_MIN_CHUNK)      # ... a batch that fits one chunk is split over the streams
         # ray chunks of at most `chunk` rays; a chunk whose march produced more sample points than four search batches is split
         # in two and marched again (the march costs ~1 ms): the working set is bounded in SAMPLES, not only in rays
         work = [(c0, min(c0 + chunk, M)) for c0 in range(0, M, chunk)][::-1]
@@ -310,7 +310,10 @@ class RenderStep:
         return tr, rgb
 
     SECONDARY_STREAMS = int(os.environ.get("IA_SECONDARY_STREAMS", "2"))
-    SECONDARY_STREAMS_MIN_RAYS = 1 << 20
+    # below ~8 M rays the kernels of a chunk no longer fill the device and splitting them makes it worse (config-4 shape, 1 M secondary rays:
+    # 21.8 ms per step serial, 24.2 on two streams)
+    SECONDARY_STREAMS_MIN_RAYS = int(os.environ.get("IA_SECONDARY_STREAMS_MIN_RAYS", str(1 << 23)))
+    SECONDARY_MIN_CHUNK = 1 << 22
 
     def _secondary_chunks(self, work, lock, rays_o, rays_d, near, far, step, beta, w2s_rot, tr, rgb):
         """works chunks off `work` (shared between the streams' threads when lock is given) into tr / rgb."""

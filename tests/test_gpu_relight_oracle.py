@@ -234,9 +234,9 @@ def test_secondary_march_on_two_streams_equals_the_serial_loop(setup):
     pick = hit[torch.randint(0, hit.shape[0], (M,), generator=g).to(DEV)]
     o = (r[pick, :3] + r[pick, 3:6] * out["depth"][pick]).contiguous()
     d = torch.nn.functional.normalize(torch.randn((M, 3), generator=g), dim=-1).to(DEV).contiguous()
-    saved = rs.SECONDARY_STREAMS, rs.SECONDARY_STREAMS_MIN_RAYS
+    saved = rs.SECONDARY_STREAMS, rs.SECONDARY_STREAMS_MIN_RAYS, rs.SECONDARY_MIN_CHUNK
     try:
-        rs.SECONDARY_STREAMS_MIN_RAYS = 1000
+        rs.SECONDARY_STREAMS_MIN_RAYS = rs.SECONDARY_MIN_CHUNK = 1000
         rs.SECONDARY_STREAMS = 1
         tr1, rgb1 = rs.compute_indirect_radiance(o, d, chunk=150_000)
         assert 0.02 < float((tr1 < 0.5).float().mean()) < 0.98 and float(rgb1.abs().sum()) > 0
@@ -252,7 +252,7 @@ def test_secondary_march_on_two_streams_equals_the_serial_loop(setup):
         torch.cuda.current_stream().wait_stream(side)
         assert torch.equal(tr1, tr3) and torch.equal(rgb1, rgb3)
     finally:
-        rs.SECONDARY_STREAMS, rs.SECONDARY_STREAMS_MIN_RAYS = saved
+        rs.SECONDARY_STREAMS, rs.SECONDARY_STREAMS_MIN_RAYS, rs.SECONDARY_MIN_CHUNK = saved
 
 
 def test_relight_full_size_properties():
