@@ -267,7 +267,9 @@ class RenderStep:
         # (L1 misses in flight) and the SDF head (matrix pipe) are bound by different units, and every chunk has data-dependent size
         # read-backs during which its stream would otherwise leave the GPU to the tail of one kernel.  Two PROCESSES on one GPU reach
         # 1.16 x the throughput of one on the headline step (tools/runs/r04_two_processes_one_gpu.sh); inside one process two streams
-        # get 4 % (340.7 -> 326.5 ms per step, same box), a third stream nothing more (tools/runs/r04_streams_ab.sh).  Results do not depend on the chunking (ray-batch sharding invariance),
+        # get 4 % (340.7 -> 326.5 ms per step, same box), a third stream nothing more (tools/runs/r04_streams_ab.sh); starting the second
+        # thread only when the first one's first search has run (so that the streams sit in different phases of a chunk) changes nothing
+        # (314.1 / 315.1 against 315.0 / 312.4 ms).  Results do not depend on the chunking (ray-batch sharding invariance),
         # so they are bit-identical to the serial loop (tests/test_gpu_relight_oracle.py).
         n_streams = self.SECONDARY_STREAMS if (M > self.SECONDARY_STREAMS_MIN_RAYS and dev.type == "cuda") else 1
         if n_streams > 1:
