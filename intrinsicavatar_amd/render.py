@@ -315,7 +315,7 @@ class RenderStep:
     # below ~8 M rays the kernels of a chunk no longer fill the device and splitting them makes it worse (config-4 shape, 1 M secondary rays:
     # 21.8 ms per step serial, 24.2 on two streams)
     SECONDARY_STREAMS_MIN_RAYS = int(os.environ.get("IA_SECONDARY_STREAMS_MIN_RAYS", str(1 << 23)))
-    SECONDARY_MIN_CHUNK = 1 << 22
+    SECONDARY_MIN_CHUNK = int(os.environ.get("IA_SECONDARY_MIN_CHUNK", str(1 << 22)))
 
     def _secondary_chunks(self, work, lock, rays_o, rays_d, near, far, step, beta, w2s_rot, tr, rgb):
         """works chunks off `work` (shared between the streams' threads when lock is given) into tr / rgb."""
