@@ -243,19 +243,37 @@ __global__ __launch_bounds__(THREADS) void light_shuffle_kernel(int64_t n_rays, 
 }
 
 // ---- emitter.sample: inverse CDF over the flattened pmf + uniform jitter inside the texel ----------------------------
+constexpr int ES_PER_WG = 4096;            // samples per workgroup (the block table is loaded once per workgroup)
 __global__ __launch_bounds__(THREADS) void envlight_sample_kernel(int64_t k, const float* __restrict__ u, const double* __restrict__ cdf,
-                                                                   int H, int W, const float* __restrict__ rot /*[9] or NULL*/,
+                                                                   int H, int W, int log2b, const float* __restrict__ rot /*[9] or NULL*/,
                                                                    float* __restrict__ dirs)
 {
-    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (i >= k) return;
+    // searchsorted(cdf, target, right=True) -- the first index with cdf[idx] > target -- in two levels: the LAST entry of every block of
+    // 2^log2b entries sits in LDS (<= 4096 doubles, loaded once per workgroup of ES_PER_WG samples); the first block whose last entry is
+    // above the target holds the answer (cdf is non-decreasing), and the search inside it touches one or two cache lines instead of the
+    // ~20 dependent loads of a search over the whole map.  Same index as the one-level search.
+    extern __shared__ __attribute__((aligned(16))) double s_last[];
     const int64_t n = (int64_t)H * W;
-    const double target = (double)u[3 * i] * cdf[n - 1];
-    // searchsorted(cdf, target, right=True): first index with cdf[idx] > target
-    int64_t lo = 0, hi = n;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (cdf[mid] > target) hi = mid; else lo = mid + 1;
+    const int64_t bsz = (int64_t)1 << log2b;
+    const int nb = (int)((n + bsz - 1) >> log2b);
+    for (int j = threadIdx.x; j < nb; j += THREADS) { const int64_t e = ((int64_t)(j + 1) << log2b); s_last[j] = cdf[(e < n ? e : n) - 1]; }
+    __syncthreads();
+    const double total = s_last[nb - 1];
+  for (int64_t i = (int64_t)blockIdx.x * ES_PER_WG + threadIdx.x, i_end = min(k, ((int64_t)blockIdx.x + 1) * ES_PER_WG); i < i_end; i += THREADS) {
+    const double target = (double)u[3 * i] * total;
+    int b0 = 0, b1 = nb;
+    while (b0 < b1) {
+        const int mid = (b0 + b1) >> 1;
+        if (s_last[mid] > target) b1 = mid; else b0 = mid + 1;
+    }
+    int64_t lo = n;
+    if (b0 < nb) {
+        int64_t hi = min(((int64_t)(b0 + 1)) << log2b, n);
+        lo = (int64_t)b0 << log2b;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (cdf[mid] > target) hi = mid; else lo = mid + 1;
+        }
     }
     if (lo > n - 1) lo = n - 1;
     const int64_t y = lo / W, x = lo % W;
@@ -273,6 +291,7 @@ __global__ __launch_bounds__(THREADS) void envlight_sample_kernel(int64_t k, con
         d0 = e0 / nn; d1 = e1 / nn; d2 = e2 / nn;
     }
     dirs[3 * i] = d0; dirs[3 * i + 1] = d1; dirs[3 * i + 2] = d2;
+  }
 }
 
 // ---- secondary rays: cosine mask -> compact list ----------------------------------------------------------------------
@@ -546,7 +565,12 @@ IA_EXPORT int ia_envlight_sample(int64_t k, const float* u, const double* cdf, i
 {
     if (k == 0) return IA_OK;
     IA_REQUIRE(env_h > 0 && env_w > 0, "environment map must be non-empty");
-    envlight_sample_kernel<<<ia::cdiv(k, THREADS), THREADS, 0, (hipStream_t)stream>>>(k, u, cdf, env_h, env_w, rot, dirs);
+    const int64_t n = (int64_t)env_h * env_w;
+    int log2b = 6;                                       // blocks of >= 64 entries, at most 4096 of them (32 KB of LDS)
+    while (((n + ((int64_t)1 << log2b) - 1) >> log2b) > 4096) log2b++;
+    const int nb = (int)((n + ((int64_t)1 << log2b) - 1) >> log2b);
+    envlight_sample_kernel<<<ia::cdiv(k, ES_PER_WG), THREADS, (size_t)nb * sizeof(double), (hipStream_t)stream>>>(k, u, cdf, env_h, env_w, log2b,
+                                                                                                                  rot, dirs);
     return ia::check_launch("ia_envlight_sample");
 }
 

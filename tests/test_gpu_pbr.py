@@ -70,6 +70,32 @@ def test_envlight_eval_pdf_sample_vs_oracle(env):
     assert (N(env.pdf(T(s)))[:, 0] > 10).mean() > 0.5
 
 
+@pytest.mark.parametrize("H,W", [(37, 53), (64, 128), (512, 1024), (1000, 2001)])
+def test_envlight_sample_two_level_search_equals_searchsorted(H, W):
+    """ia_envlight_sample finds the texel of a uniform by a two-level search (block ends in LDS, then inside one block): the texel must be
+    torch.searchsorted(cdf, u * cdf[-1], right=True) clamped to the last texel -- maps whose size is no multiple of the block, more blocks
+    than one table holds at 64 entries per block, samples past one workgroup's share, uniforms at 0 and just below 1, flat stretches of the
+    CDF (zero-probability texels)."""
+    from intrinsicavatar_amd import _lib as L
+    g = torch.Generator().manual_seed(H * W)
+    pmf = torch.rand(H * W, generator=g, dtype=torch.float64) ** 8
+    pmf[torch.rand(H * W, generator=g) < 0.3] = 0.0                     # flat stretches
+    cdf = torch.cumsum(pmf, 0).to(DEV)
+    k = 3 * 4096 + 77
+    u = torch.rand((k, 3), generator=g)
+    u[0, 0], u[1, 0], u[2, 0] = 0.0, float(np.nextafter(np.float32(1.0), np.float32(0.0))), 0.5
+    u[:, 1:] = 0.5                                                      # texel centres: the direction identifies the texel
+    u = u.to(DEV).contiguous()
+    dirs = torch.empty((k, 3), device=DEV)
+    L.check(L.lib().ia_envlight_sample(L.i64(k), L.ptr(u), L.ptr(cdf), L.i32(H), L.i32(W), L.ptr(None), L.ptr(dirs), L.stream()), "ia_envlight_sample")
+    idx = torch.searchsorted(cdf, u[:, 0].double() * cdf[-1], right=True).clamp(max=H * W - 1)
+    y, x = (idx // W).double(), (idx % W).double()
+    phi, th = ((x + 0.5) / W - 0.5) * 2 * math.pi, (y + 0.5) / H * math.pi
+    want = torch.stack([torch.sin(th) * torch.sin(phi), torch.cos(th), -torch.sin(th) * torch.cos(phi)], -1).float()
+    assert torch.equal(dirs, want) or float((dirs - want).abs().max()) < 2e-7          # (device sin / cos in double, rounded once)
+    assert int(idx.min()) >= 0 and len(torch.unique(idx)) > min(1000, H * W // 4)
+
+
 def test_pbr_light_shade_vs_oracle(env):
     from oracle import pbr_ref as PR
     from intrinsicavatar_amd import pbr
