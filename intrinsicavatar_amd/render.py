@@ -276,7 +276,10 @@ class RenderStep:
             # 5 / 8 of the serial chunk per stream: the live working set of two chunks stays that of one serial chunk (141 against 144 GiB on
             # the headline step); what grows is the allocator's reserve -- every stream has its own pool (216 GiB reserved at 10 Mi rays per
             # chunk, 236 at 16 Mi for the same 4 %)
-            chunk = max(min(chunk * 5 // 8, -(-M // n_streams)), self.SECONDARY_MIN_CHUNK)      # ... a batch that fits one chunk is split over the streams
+            cmax = max(min(chunk * 5 // 8, -(-M // n_streams)), self.SECONDARY_MIN_CHUNK)
+            # equal chunks, a multiple of the streams: the static assignment below (chunk j to thread j mod n) is then balanced
+            n_chunks = n_streams * (-(-M // (n_streams * cmax)))
+            chunk = -(-M // n_chunks)
         # ray chunks of at most `chunk` rays; a chunk whose march produced more sample points than four search batches is split
         # in two and marched again (the march costs ~1 ms): the working set is bounded in SAMPLES, not only in rays
         work = [(c0, min(c0 + chunk, M)) for c0 in range(0, M, chunk)][::-1]
