@@ -52,6 +52,23 @@ def shade_prep(sdf_grad: Tensor, rays_d: Tensor, ray_indices: Tensor, w2s_rot: T
     return ns, nw, rf
 
 
+def plan_secondary_chunks(M: int, chunk: int, n_streams: int = 1, min_chunk: int = 1 << 22):
+    """[(c0, c1), ...] covering rays [0, M) for compute_indirect_radiance.  One stream: chunks of `chunk` rays (the last one shorter).
+    Several streams: at most 5 / 8 of `chunk` per stream -- the live working set of two chunks stays that of one serial chunk (141 against
+    144 GiB on the headline step; what grows is the allocator's reserve, one pool per stream) --, EQUAL chunks, their number a multiple of
+    the streams, so that the static assignment (chunk j to thread j mod n) is balanced; a batch that fits one chunk is split over the
+    streams; min_chunk bounds the chunk size from below for batches of more than n_streams * min_chunk rays (the caller only takes the
+    streams for large batches, SECONDARY_STREAMS_MIN_RAYS)."""
+    if M <= 0:
+        return []
+    if n_streams > 1:
+        cmax = max(min(chunk * 5 // 8, -(-M // n_streams)), min_chunk, 1)
+        n_chunks = n_streams * (-(-M // (n_streams * cmax)))
+        chunk = -(-M // n_chunks)
+    chunk = max(int(chunk), 1)
+    return [(c0, min(c0 + chunk, M)) for c0 in range(0, M, chunk)]
+
+
 class RenderStep:
     """One frame's render_step.  `occ_binaries` [1,64,64,64] bool + `occ_aabb` [1,6] = the (test-time)
     occupancy grid of the frame (prepare_test_occupancy_grid, intrinsic_avatar.py:360-381)."""
@@ -272,17 +289,9 @@ class RenderStep:
         # (314.1 / 315.1 against 315.0 / 312.4 ms).  Results do not depend on the chunking (ray-batch sharding invariance),
         # so they are bit-identical to the serial loop (tests/test_gpu_relight_oracle.py).
         n_streams = self.SECONDARY_STREAMS if (M > self.SECONDARY_STREAMS_MIN_RAYS and dev.type == "cuda") else 1
-        if n_streams > 1:
-            # 5 / 8 of the serial chunk per stream: the live working set of two chunks stays that of one serial chunk (141 against 144 GiB on
-            # the headline step); what grows is the allocator's reserve -- every stream has its own pool (216 GiB reserved at 10 Mi rays per
-            # chunk, 236 at 16 Mi for the same 4 %)
-            cmax = max(min(chunk * 5 // 8, -(-M // n_streams)), self.SECONDARY_MIN_CHUNK)
-            # equal chunks, a multiple of the streams: the static assignment below (chunk j to thread j mod n) is then balanced
-            n_chunks = n_streams * (-(-M // (n_streams * cmax)))
-            chunk = -(-M // n_chunks)
-        # ray chunks of at most `chunk` rays; a chunk whose march produced more sample points than four search batches is split
+        # ray chunks (plan_secondary_chunks); a chunk whose march produced more sample points than four search batches is split
         # in two and marched again (the march costs ~1 ms): the working set is bounded in SAMPLES, not only in rays
-        work = [(c0, min(c0 + chunk, M)) for c0 in range(0, M, chunk)][::-1]
+        work = plan_secondary_chunks(M, chunk, n_streams, self.SECONDARY_MIN_CHUNK)[::-1]
         args = (rays_o, rays_d, near, far, step, beta, w2s_rot, tr, rgb)
         if n_streams <= 1 or len(work) <= 1:
             self._secondary_chunks(work, None, *args)
