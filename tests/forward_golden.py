@@ -121,3 +121,40 @@ def gpu_scene(G, tag, dev="cuda:0"):
     env = pbr.EnvironmentLightTensor(T(G["hdri"]))
     env.update_pdf()
     return rs, mat, env, T(G["rays"])
+
+
+# ----------------------------------------------------------------------------- golden_backward.npz: summaries of a table gradient
+SUBSAMPLE = 32
+
+
+def _S():
+    from intrinsicavatar_amd import synthetic as S
+    return S
+
+
+def subsample_mask(idx):
+    """1-in-SUBSAMPLE selection of table entries by a hash of the FLOAT index (numpy uint64 arithmetic, closed form)."""
+    h = (idx.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)
+    return (h % np.uint64(SUBSAMPLE)) == 0
+
+
+def level_offsets():
+    from tests import torch_ref as TR
+    return np.asarray(TR.hash_cfg()[0], dtype=np.int64)
+
+
+def table_gradient_summary(g):
+    """g: flat float gradient of one table's `params` (entries x 2 features) -> dict of arrays (see the module docstring)."""
+    off = level_offsets() * 2                                        # float offsets of the 16 levels (+ end)
+    g64 = g.astype(np.float64)
+    probe = _S().hash_table_values(g.size, 4242, 1.0).astype(np.float64)
+    out = dict(level_sum=np.array([g64[off[i]:off[i + 1]].sum() for i in range(len(off) - 1)]),
+               level_l1=np.array([np.abs(g64[off[i]:off[i + 1]]).sum() for i in range(len(off) - 1)]),
+               level_l2=np.array([np.sqrt((g64[off[i]:off[i + 1]] ** 2).sum()) for i in range(len(off) - 1)]),
+               level_probe=np.array([(g64[off[i]:off[i + 1]] * probe[off[i]:off[i + 1]]).sum() for i in range(len(off) - 1)]),
+               level_nnz=np.array([int((g[off[i]:off[i + 1]] != 0).sum()) for i in range(len(off) - 1)]))
+    nz = np.nonzero(g)[0]
+    keep = nz[subsample_mask(nz)]
+    out["sub_index"] = keep.astype(np.int32)
+    out["sub_value"] = g[keep].astype(np.float32)
+    return out
