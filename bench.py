@@ -436,7 +436,22 @@ def main():
             cmp_ = dict(error=f"{type(e).__name__}: {e}")
         finally:
             rs.deformer.spec_eps = eps0
+        # (iii) the product path's own canary (SNARFDeformer.spec_canary, IA_SPEC_CANARY): one more untimed step in which every
+        # 1024th point of EVERY search batch of the step is searched again to the end + K9 and compared with the row the
+        # early-filter search left (count, inits, bit-identical roots); must be 0
+        canary = None
+        try:
+            rs.deformer.spec_canary = 1024
+            rs.deformer.canary_totals(reset=True)
+            step()
+            cc = rs.deformer.canary_totals()
+            canary = dict(every=1024, points_checked=int(cc[0]), candidate_rows_differ=int(cc[1]), overflow_points_count_only=int(cc[2]))
+        except Exception as e:
+            canary = dict(error=f"{type(e).__name__}: {e}")
+        finally:
+            rs.deformer.spec_canary = 0
         search_modes = dict(
+            canary_on_one_step=canary,
             timed="K9-consistent early filter (csrc/snarf.hip: retire inside the eps-box of a tight later root, same voxel cell, only where the TRUE "
                   "skinning Jacobian is tight all over that cell (ia_cell_tightness); redo a point with the filter off when a completed root is "
                   "1e-4 .. 2e-4 from a recorded one)",

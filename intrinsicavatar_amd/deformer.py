@@ -13,6 +13,7 @@ from typing import Optional
 
 import ctypes as C
 import os
+import threading
 
 import torch
 from torch import Tensor
@@ -46,11 +47,26 @@ class SNARFDeformer:
         self.init_bones = torch.tensor(self.INIT_BONES, dtype=torch.int32, device=self.device)
         self.spec_eps = self.SPEC_EPS
         self.spec_counters = None            # optional int64 [5] device tensor: accumulated by the early-filter search (bench.py)
+        self._tls = threading.local()        # per-call diagnostics of _candidates, per host thread (the secondary march runs it on several)
+        self.spec_canary = self.SPEC_CANARY  # every k-th point of a batch is searched again to the end and compared (0 = off)
+        self._canary_parts = []              # one int64 [3] device accumulator per host thread / stream (canary_totals() adds them up)
+        self._canary_lock = threading.Lock()
         self.tfs = None
         self.voxel_J_cl = None
         self.cell_tight = None
+        self._voxels_finite = None
         self.voxel_d = None
         self.w2s = None
+
+    @property
+    def last_overflow_records(self) -> int:
+        """points the early-filter kernel searched again with the filter off, in THIS thread's last _candidates call."""
+        return getattr(self._tls, "n_over", 0)
+
+    @property
+    def _ovf_cap(self) -> int:
+        """capacity of the list of such points in this thread's last _candidates call (ia_spec_rows_overflow_capacity(P))."""
+        return getattr(self._tls, "ovf_cap", 0)
 
     # -- per frame -------------------------------------------------------------------
     def prepare(self, tfs: Tensor, w2s: Tensor):
@@ -66,13 +82,20 @@ class SNARFDeformer:
         fast_snarf.precompute(self.lbs_voxel_final, self.tfs, self.voxel_d, None, self.offset_kernel, self.scale_kernel,
                               voxel_J_cl=self.voxel_J_cl)
         # the search's corner-pair loads read an out-of-range corner's in-range neighbour with weight 0 (bit-identical to skipping it
-        # only for finite voxels): one check per frame instead of a select per load
-        if not bool(torch.isfinite(self.voxel_J_cl).all()):
-            raise RuntimeError("SNARFDeformer.prepare: the skinning grid (voxel_J) holds non-finite values")
+        # only for finite voxels): one check per frame instead of a select per load.  The flag stays on the device and is read next
+        # to the first size read-back of a search on this pose (_check_voxels) -- no host sync of its own
+        self._voxels_finite = torch.isfinite(self.voxel_J_cl).all()
         # veto table of the early filter: cells where the true Jacobian of the skinning map is tight (one small kernel per pose)
         tau = float(os.environ.get("IA_SPEC_CELL_TAU", str(fast_snarf.CELL_TAU)))
         self.cell_tight = (fast_snarf.cell_tightness(fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.offset_kernel, self.scale_kernel, tau)
                            if (tau > 0 and B == 1) else None)
+
+    def _check_voxels(self):
+        f = self._voxels_finite
+        if f is not None:
+            self._voxels_finite = None
+            if not bool(f):
+                raise RuntimeError("SNARFDeformer.prepare: the skinning grid (voxel_J) holds non-finite values")
 
     def transform_rays_w2s(self, rays: Tensor) -> Tensor:
         """snarf_deformer.py:128-147."""
@@ -153,12 +176,14 @@ class SNARFDeformer:
                                                  L.ptr(src), L.ptr(None), L.ptr(total), L.ptr(tmp), C.c_size_t(tmp.numel() * 8), st),
                     "ia_deform_filter_compact")
             Q = int(total.item())
+            self._check_voxels()
             return x.reshape(-1, 3)[:Q], (src[:Q] if with_src else None), cnt, start, Q
         nbytes = int(lib.ia_deform_filter_tiles_tmp_bytes(L.i64(P)))
         tmp = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
         L.check(lib.ia_deform_filter_tiles(L.i64(P), L.i32(I), L.ptr(x), L.ptr(valid), L.ptr(cnt), L.ptr(start), L.ptr(src), L.ptr(None),
                                            L.ptr(total), L.ptr(tmp), C.c_size_t(tmp.numel() * 8), st), "ia_deform_filter_tiles")
         Q = int(total.item())
+        self._check_voxels()
         cand_x = torch.empty((Q, 3), device=dev)
         cand_src = torch.empty(Q, dtype=torch.int32, device=dev) if with_src else None
         L.check(lib.ia_deform_pack_tiles(L.i64(P), L.i32(I), L.ptr(x), L.ptr(src), L.ptr(start), L.ptr(cand_x), L.ptr(cand_src),
@@ -193,14 +218,15 @@ class SNARFDeformer:
         # overflow records + the list of points the kernel redoes with the filter off (1 / 64 of the batch): a grow-only work area
         # (locals, not attributes: concurrent calls on several streams -- render.compute_indirect_radiance -- each have their own)
         ovf_scratch = L.scratch("spec_rows", int(lib.ia_spec_rows_overflow_bytes(L.i64(P))), dev)
-        ovf_cap = self._ovf_cap = int(lib.ia_spec_rows_overflow_capacity(L.i64(P)))
+        ovf_cap = self._tls.ovf_cap = int(lib.ia_spec_rows_overflow_capacity(L.i64(P)))
         tot = torch.empty(2, dtype=torch.int32, device=dev)
         fast_snarf.fuse_broyden_spec_rows(x_rows, pts.reshape(1, P, 3), fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs, self.init_bones,
                                           Jinv, cnt, meta, start, ovf_head, ovf_scratch, tot, self.offset_kernel, self.scale_kernel,
                                           1e-5, 1e-1, self.spec_eps, fwd_J=fwd, counters=self.spec_counters, order=order,
                                           cell_tight=self.cell_tight)
         Q, n_over = tot.tolist()                                     # the one read-back of the call
-        self.last_overflow_records = n_over                          # points the kernel searched again with the filter off
+        self._tls.n_over = n_over                                    # points the kernel searched again with the filter off
+        self._check_voxels()
         if os.environ.get("IA_DEBUG_FLAGGED"):
             import sys
             print(f"[spec rows] P={P} Q={Q} redone={n_over} ({n_over / max(P, 1):.2e}) cap={ovf_cap}", file=sys.stderr)
@@ -211,6 +237,8 @@ class SNARFDeformer:
                 pts = pts[order.long()].contiguous()
             r = self.search(pts, want_fwd=want_fwd, want_jinv=want_jinv)
             return self._normalized((*self._pack_candidates(r[0], r[1], with_src=with_src), r[2], (r[3] if want_jinv else None)), normalize)
+        if self.spec_canary > 0:
+            self._canary(pts, order, x_rows, cnt, meta)
         cand_x = torch.empty((Q, 3), device=dev)
         cand_src = torch.empty(Q, dtype=torch.int32, device=dev) if with_src else None
         L.check(lib.ia_deform_rows_pack(L.i64(P), L.i32(I), L.ptr(x_rows), L.ptr(cnt), L.ptr(meta), L.ptr(start), L.ptr(ovf_head),
@@ -218,6 +246,63 @@ class SNARFDeformer:
                                         L.ptr(normalize[0].contiguous().float() if normalize else None),
                                         L.ptr(normalize[1].contiguous().float() if normalize else None), st), "ia_deform_rows_pack")
         return cand_x, cand_src, cnt, start, Q, (fwd[0] if want_fwd else None), (Jinv[0] if want_jinv else None)
+
+    SPEC_CANARY = int(os.environ.get("IA_SPEC_CANARY", "0"))
+
+    @torch.no_grad()
+    def _canary(self, pts: Tensor, order: Optional[Tensor], x_rows: Tensor, cnt: Tensor, meta: Tensor):
+        """runtime check of the early filter (IA_SPEC_CANARY=k, deformer.spec_canary): every k-th point of the batch is searched again
+        with all 13 inits run to their end + K9 (fuse_broyden + filter: the reference's fuse_cuda_kernel_fast.cu:252-452 and
+        filter.cu:10-54 semantics) and its candidate set is compared with the row the early-filter search left -- same count, same
+        inits, bit-identical roots.  Accumulates on the device (canary_totals(): points checked, points that differ, points with
+        overflow records -- a 4th survivor; only their count is compared); no host sync.  ~1.7 / k of the search time."""
+        P, I = cnt.shape[0], self.init_bones.shape[0]
+        dev = pts.device
+        k = int(self.spec_canary)
+        idx = torch.arange(getattr(self._tls, "canary_phase", 0) % k, P, k, device=dev)
+        self._tls.canary_phase = getattr(self._tls, "canary_phase", 0) + 7          # another residue class every call
+        if idx.numel() == 0:
+            return
+        src = order.long()[idx] if order is not None else idx
+        sub = pts[src].contiguous()
+        n = sub.shape[0]
+        x = torch.empty((1, n, I, 3), device=dev)
+        valid = torch.empty((1, n, I), dtype=torch.bool, device=dev)
+        fast_snarf.fuse_broyden(x, sub.reshape(1, n, 3), None, fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs, self.init_bones,
+                                True, None, valid, self.offset_kernel, self.scale_kernel, 1e-5, 1e-1)
+        keep = fast_snarf.filter(x, valid)[0]                                        # [n, I] after K9
+        x = x[0]
+        c, m, rows = cnt[idx].long(), meta[idx], x_rows[idx]
+        flagged = m < 0                                                              # bit 31: rows + overflow records
+        bad = c != keep.sum(1)
+        inits = torch.arange(I, device=dev)
+        want_bits = (keep.long() << inits[None]).sum(1)                              # the surviving inits as a bit set
+        got_bits = torch.zeros_like(want_bits)
+        for j in range(3):
+            live = (c > j) & ~flagged
+            init = ((m >> (8 * j)) & 0xFF).long().clamp(max=I - 1)
+            got_bits = got_bits | torch.where(live, torch.ones_like(c) << init, torch.zeros_like(c))
+            ref = torch.gather(x, 1, init[:, None, None].expand(n, 1, 3))[:, 0]
+            same = (rows[:, j].view(torch.int32) == ref.view(torch.int32)).all(1)
+            bad = bad | (live & ~same)
+        bad = bad | (~flagged & (got_bits != want_bits))
+        acc = getattr(self._tls, "canary", None)
+        if acc is None:                  # this thread's accumulator (its stream orders the updates)
+            acc = self._tls.canary = torch.zeros(3, dtype=torch.int64, device=dev)
+            with self._canary_lock:
+                self._canary_parts.append(acc)
+        acc += torch.stack([torch.full((), n, dtype=torch.int64, device=dev), bad.sum(), flagged.sum()])
+
+    def canary_totals(self, reset: bool = False):
+        """(points checked, points whose candidate row differs from search-to-the-end + K9, overflow points compared by count only)
+        since the last reset, over all threads; synchronises the device."""
+        torch.cuda.synchronize(self.device)
+        with self._canary_lock:
+            tot = [int(v) for v in torch.stack(self._canary_parts).sum(0).tolist()] if self._canary_parts else [0, 0, 0]
+            if reset:
+                for a in self._canary_parts:
+                    a.zero_()
+        return tuple(tot)
 
     @staticmethod
     def _normalized(res, normalize):

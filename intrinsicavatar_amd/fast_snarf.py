@@ -141,6 +141,11 @@ def fuse_broyden_spec_rows(x_rows: Tensor, xd_tgt: Tensor, voxel_J: ChannelLastV
     _, D, H, W, _ = voxel_J.data.shape
     assert x_rows.shape == (N, 3, 3) and all(t.shape == (N,) and t.dtype == torch.int32 for t in (cnt, meta, start, ovf_head))
     assert total_and_overflow.shape == (2,) and total_and_overflow.dtype == torch.int32
+    # the work area grows with N (flagged list of max(65536, N / 64) entries): a caller's buffer sized for another N would be overrun
+    need = int(L.lib().ia_spec_rows_overflow_bytes(L.i64(N)))
+    if ovf_scratch.dtype != torch.uint8 or not ovf_scratch.is_contiguous() or ovf_scratch.numel() < need:
+        raise RuntimeError(f"ovf_scratch must be a contiguous uint8 tensor of at least ia_spec_rows_overflow_bytes(N={N}) = {need} bytes "
+                           f"(got {ovf_scratch.dtype}, {ovf_scratch.numel()})")
     for t in (x_rows, J_inv, fwd_J, cnt, meta, start):
         if t is not None and not t.is_contiguous():
             raise RuntimeError("outputs must be contiguous")

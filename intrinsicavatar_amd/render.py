@@ -55,16 +55,18 @@ def shade_prep(sdf_grad: Tensor, rays_d: Tensor, ray_indices: Tensor, w2s_rot: T
 def plan_secondary_chunks(M: int, chunk: int, n_streams: int = 1, min_chunk: int = 1 << 22):
     """[(c0, c1), ...] covering rays [0, M) for compute_indirect_radiance.  One stream: chunks of `chunk` rays (the last one shorter).
     Several streams: at most 5 / 8 of `chunk` per stream -- the live working set of two chunks stays that of one serial chunk (141 against
-    144 GiB on the headline step; what grows is the allocator's reserve, one pool per stream) --, EQUAL chunks, their number a multiple of
-    the streams, so that the static assignment (chunk j to thread j mod n) is balanced; a batch that fits one chunk is split over the
-    streams; min_chunk bounds the chunk size from below for batches of more than n_streams * min_chunk rays (the caller only takes the
-    streams for large batches, SECONDARY_STREAMS_MIN_RAYS)."""
+    144 GiB on the headline step; what grows is the allocator's reserve, one pool per stream) --, EQUAL chunks (sizes differ by at most one
+    ray), their number a multiple of the streams, so that the static assignment (chunk j to thread j mod n) is balanced; a batch that
+    fits one chunk is split over the streams; min_chunk bounds the chunk size from below for batches of more than n_streams * min_chunk
+    rays (the caller only takes the streams for large batches, SECONDARY_STREAMS_MIN_RAYS).  With fewer rays than chunks the empty
+    chunks are dropped (then, and only then, the count is not a multiple of the streams)."""
     if M <= 0:
         return []
     if n_streams > 1:
         cmax = max(min(chunk * 5 // 8, -(-M // n_streams)), min_chunk, 1)
         n_chunks = n_streams * (-(-M // (n_streams * cmax)))
-        chunk = -(-M // n_chunks)
+        bounds = [M * i // n_chunks for i in range(n_chunks + 1)]            # bounds[i] = M i / n: equal to within one ray
+        return [(a, b) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
     chunk = max(int(chunk), 1)
     return [(c0, min(c0 + chunk, M)) for c0 in range(0, M, chunk)]
 
@@ -288,13 +290,13 @@ class RenderStep:
         # thread only when the first one's first search has run (so that the streams sit in different phases of a chunk) changes nothing
         # (314.1 / 315.1 against 315.0 / 312.4 ms).  Results do not depend on the chunking (ray-batch sharding invariance),
         # so they are bit-identical to the serial loop (tests/test_gpu_relight_oracle.py).
-        n_streams = self.SECONDARY_STREAMS if (M > self.SECONDARY_STREAMS_MIN_RAYS and dev.type == "cuda") else 1
+        n_streams = self._secondary_streams_for(M, chunk, dev)
         # ray chunks (plan_secondary_chunks); a chunk whose march produced more sample points than four search batches is split
         # in two and marched again (the march costs ~1 ms): the working set is bounded in SAMPLES, not only in rays
         work = plan_secondary_chunks(M, chunk, n_streams, self.SECONDARY_MIN_CHUNK)[::-1]
         args = (rays_o, rays_d, near, far, step, beta, w2s_rot, tr, rgb)
         if n_streams <= 1 or len(work) <= 1:
-            self._secondary_chunks(work, None, *args)
+            self._secondary_chunks(work, *args)
             return tr, rgb
         import threading
         _ = self.grid_bits, self._sort_grid_params()            # lazily cached host-side state: made before the threads start
@@ -311,8 +313,8 @@ class RenderStep:
         def worker(side, my_work):
             try:
                 with torch.cuda.device(dev), torch.cuda.stream(side), torch.no_grad():      # device, stream and grad mode are per thread
-                    self._secondary_chunks(my_work, None, *args)
-            except BaseException as e:                                                       # noqa: B902 -- re-raised by the caller
+                    self._secondary_chunks(my_work, *args)
+            except BaseException as e:                                                       # noqa: B902 -- handled by the caller
                 errors.append(e)
         threads = []
         for side, my_work in zip(self._side_streams, works):
@@ -325,28 +327,49 @@ class RenderStep:
         for side in self._side_streams:
             main.wait_stream(side)                              # tr / rgb are read on the caller's stream
         if errors:
+            if all(isinstance(e, torch.cuda.OutOfMemoryError) for e in errors):
+                # the side streams' allocator pools did not fit after all (another process on the GPU, a smaller device): give their
+                # blocks back and march the batch again on the caller's stream, one chunk at a time -- same results, chunking-invariant
+                del errors[:]
+                self._side_streams = None
+                torch.cuda.synchronize(dev)
+                torch.cuda.empty_cache()
+                self.secondary_stream_fallbacks = getattr(self, "secondary_stream_fallbacks", 0) + 1
+                tr.fill_(1.0)
+                rgb.zero_()
+                self._secondary_chunks(plan_secondary_chunks(M, chunk, 1)[::-1], *args)
+                return tr, rgb
             raise errors[0]
         return tr, rgb
 
     SECONDARY_STREAMS = int(os.environ.get("IA_SECONDARY_STREAMS", "2"))
+    # bytes of device memory a marched ray of a chunk keeps live at the peak of its chunk on the headline scene (9 samples per ray on
+    # average x (search outputs + sorted copies + level-major hash features)): 142 GiB live for 2 x 10.5 Mi rays = ~7 KB per ray
+    SECONDARY_BYTES_PER_RAY = int(os.environ.get("IA_SECONDARY_BYTES_PER_RAY", "7168"))
+
+    def _secondary_streams_for(self, M: int, chunk: int, dev) -> int:
+        """how many HIP streams / host threads the secondary march of M rays takes.  Each side stream has its own caching-allocator pool
+        (measured: 184 GiB reserved against 142 GiB live on the headline step, for 3-4 % of the step), so the streams are only taken
+        when the device has room for that: free + this process's cached-but-unused memory >= 2 x the working set of the chunks in
+        flight; otherwise the serial loop runs (IA_SECONDARY_STREAMS=1 forces it).  An OOM inside the threads falls back to it too."""
+        n = self.SECONDARY_STREAMS
+        if n <= 1 or dev.type != "cuda" or M <= self.SECONDARY_STREAMS_MIN_RAYS:
+            return 1
+        plan = plan_secondary_chunks(M, chunk, n, self.SECONDARY_MIN_CHUNK)
+        in_flight = n * max(b - a for a, b in plan) * self.SECONDARY_BYTES_PER_RAY
+        free, _total = torch.cuda.mem_get_info(dev)
+        cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        return n if free + cached >= 2 * in_flight else 1
     # below ~8 M rays the kernels of a chunk no longer fill the device and splitting them makes it worse (config-4 shape, 1 M secondary rays:
     # 21.8 ms per step serial, 24.2 on two streams)
     SECONDARY_STREAMS_MIN_RAYS = int(os.environ.get("IA_SECONDARY_STREAMS_MIN_RAYS", str(1 << 23)))
     SECONDARY_MIN_CHUNK = int(os.environ.get("IA_SECONDARY_MIN_CHUNK", str(1 << 22)))
 
-    def _secondary_chunks(self, work, lock, rays_o, rays_d, near, far, step, beta, w2s_rot, tr, rgb):
-        """works chunks off `work` (shared between the streams' threads when lock is given) into tr / rgb."""
+    def _secondary_chunks(self, work, rays_o, rays_d, near, far, step, beta, w2s_rot, tr, rgb):
+        """works the chunks of `work` (this thread's own list, last one first) into tr / rgb."""
         dev = rays_o.device
-        while True:
-            if lock is not None:
-                with lock:
-                    if not work:
-                        return
-                    c0, c1 = work.pop()
-            else:
-                if not work:
-                    return
-                c0, c1 = work.pop()
+        while work:
+            c0, c1 = work.pop()
             ro, rd = rays_o[c0:c1].contiguous(), rays_d[c0:c1].contiguous()
             m = ro.shape[0]
             intervals, samples, _ = nerfacc.traverse_grids(
@@ -354,11 +377,7 @@ class RenderStep:
                 step, 0.0, grid_bits=self.grid_bits, max_extent=far - near, incoherent=True, termination_planes=False)
             if samples.vals.shape[0] > 4 * self.MAX_SEARCH_POINTS and m > 1:
                 del intervals, samples
-                if lock is not None:
-                    with lock:
-                        work.extend([(c0 + m // 2, c1), (c0, c0 + m // 2)])
-                else:
-                    work.extend([(c0 + m // 2, c1), (c0, c0 + m // 2)])
+                work.extend([(c0 + m // 2, c1), (c0, c0 + m // 2)])
                 continue
             t_starts, t_ends = samples.interval_ends(intervals)
             ray_indices = samples.ray_indices

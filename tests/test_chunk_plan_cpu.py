@@ -26,7 +26,7 @@ def test_stream_plan_is_balanced(M, n):
     _covers(ch, M)
     sizes = [c1 - c0 for c0, c1 in ch]
     assert len(ch) % n == 0
-    assert max(sizes) - min(sizes) <= len(ch)                      # equal up to the rounding of the last chunk
+    assert max(sizes) - min(sizes) <= 1                            # bounds[i] = M i / n
     assert max(sizes) <= max((1 << 24) * 5 // 8, 1 << 22)
     per_thread = [sum(sizes[k::n]) for k in range(n)]
     assert max(per_thread) - min(per_thread) <= len(ch)
@@ -41,4 +41,21 @@ def test_stream_plan_small_batches_and_the_minimum_chunk():
     assert len(ch) in (1, 2)
     ch = plan(700_001, 240_000, 2, min_chunk=1000)                 # the GPU test's shape: six chunks of 116 667 rays
     _covers(ch, 700_001)
-    assert len(ch) == 6 and ch[-1] == (583_335, 700_001)
+    assert len(ch) == 6 and ch[-1] == (583_334, 700_001)
+
+
+def test_stream_plan_properties_on_random_small_inputs():
+    """the fuzz of the round-4 review (M = 321, chunk 24, n = 4, min_chunk 16 gave 23 chunks): the number of chunks is a multiple of the
+    streams whenever there are at least as many rays as chunks, sizes differ by at most one ray, coverage is exact."""
+    import random
+    rnd = random.Random(0)
+    for _ in range(20000):
+        M, chunk, n, mc = rnd.randint(1, 5000), rnd.randint(1, 400), rnd.randint(2, 5), rnd.randint(1, 64)
+        ch = plan(M, chunk, n, mc)
+        _covers(ch, M)
+        sizes = [b - a for a, b in ch]
+        assert max(sizes) - min(sizes) <= 1, (M, chunk, n, mc)
+        cmax = max(min(chunk * 5 // 8, -(-M // n)), mc, 1)
+        want = n * (-(-M // (n * cmax)))
+        assert len(ch) == min(want, M) and (len(ch) % n == 0 or M < want), (M, chunk, n, mc, len(ch))
+        assert max(sizes) <= cmax

@@ -312,3 +312,41 @@ def test_a_full_overflow_list_falls_back_to_k9(march):
     assert calls and got[4] == want[4]
     for k in (0, 1, 2, 3):
         assert torch.equal(got[k], want[k]), k
+
+
+def test_canary_counts_nothing_on_the_product_path_and_catches_a_loosened_filter(march):
+    """SNARFDeformer.spec_canary (IA_SPEC_CANARY): every k-th point of a batch searched again to the end + K9 and compared with the row
+    the early-filter search left.  Product settings: 0 differ.  With the cell-tightness veto off and eps = 5e-3 (~2e-4 of
+    the candidate sets differ) the canary reports it -- it is a detector, not a constant."""
+    SP, rs, pts, _ = march
+    dfm = rs.deformer
+    old = (dfm.spec_canary, dfm.spec_eps, dfm.cell_tight)
+    try:
+        dfm.spec_canary = 4
+        dfm.canary_totals(reset=True)
+        order = torch.randperm(pts.shape[0], device=DEV).to(torch.int32)
+        dfm._candidates(pts, with_src=False)
+        dfm._candidates(pts, with_src=True, order=order)                     # through the permutation as well
+        n, bad, ovf = dfm.canary_totals(reset=True)
+        assert n >= pts.shape[0] // 2 - 2 and bad == 0 and ovf <= 4, (n, bad, ovf)
+        dfm.spec_eps, dfm.cell_tight = 5e-3, None
+        dfm._candidates(pts, with_src=False)
+        n2, bad2, _ = dfm.canary_totals(reset=True)
+        assert n2 >= pts.shape[0] // 4 - 1 and 0 < bad2 < 2e-3 * n2, (n2, bad2)
+    finally:
+        dfm.spec_canary, dfm.spec_eps, dfm.cell_tight = old
+
+
+def test_overflow_scratch_of_the_wrong_size_is_refused(march):
+    """fuse_broyden_spec_rows checks the work area against ia_spec_rows_overflow_bytes(N) (it grows with N)."""
+    from intrinsicavatar_amd import fast_snarf, _lib as L
+    SP, rs, pts, _ = march
+    dfm = rs.deformer
+    P = 100_000
+    sub = pts[:P].contiguous()
+    i32 = lambda: torch.empty(P, dtype=torch.int32, device=DEV)      # noqa: E731
+    small = torch.empty(int(L.lib().ia_spec_rows_overflow_bytes(L.i64(P))) - 1, dtype=torch.uint8, device=DEV)
+    with pytest.raises(RuntimeError, match="ovf_scratch"):
+        fast_snarf.fuse_broyden_spec_rows(torch.empty((P, 3, 3), device=DEV), sub[None], fast_snarf.ChannelLastVoxelJ(dfm.voxel_J_cl), dfm.tfs,
+                                          dfm.init_bones, None, i32(), i32(), i32(), i32(), small, torch.empty(2, dtype=torch.int32, device=DEV),
+                                          dfm.offset_kernel, dfm.scale_kernel, 1e-5, 1e-1, 1e-3)
