@@ -607,8 +607,11 @@ int ia_morton_keys(int64_t n, const float* pts /*[n,3]*/, const float* origin_ho
 int ia_gather_rows3(int64_t n, const float* src, const int64_t* order, float* dst, ia_stream_t stream);
 int ia_scatter_f32(int64_t n, const float* src, const int64_t* order, float* dst, ia_stream_t stream);
 /* the same ordering in one call: order [n] int32 = stable argsort of the Morton codes restricted to their bits [drop_bits, 30)
- * (device radix sort of (key, index) pairs; 32-bit indices and 3 instead of 4 digit passes for drop_bits = 6), with the int32
- * forms of the gather / scatter.  tmp: ia_morton_order_tmp_bytes(n) bytes, 256-byte aligned. */
+ * (hand-written LSD radix sort of (key, index) pairs, csrc/sort.hip: three 10-bit passes of count -> scan -> ranked scatter, no
+ * workgroup waits for another one), with the int32 forms of the gather / scatter.  tmp: ia_morton_order_tmp_bytes(n) bytes,
+ * 256-byte aligned.  ia_sort_rank_mode(): 1 = in-wave ranks by LDS atomics with return (checked on the device at the first sort),
+ * 2 = by ballots (IA_SORT_RANK=ballot or the check failed), 0 = no sort has run yet. */
+int ia_sort_rank_mode(void);
 size_t ia_morton_order_tmp_bytes(int64_t n);
 int ia_morton_order(int64_t n, const float* pts /*[n,3]*/, const float* origin_host3, float inv_cell, int drop_bits,
                     int32_t* order /*[n]*/, void* tmp, size_t tmp_bytes, ia_stream_t stream);

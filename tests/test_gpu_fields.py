@@ -391,3 +391,39 @@ def test_morton_order_is_a_stable_key_sort(drop_bits):
     back = torch.empty(n, device=DEV)
     L.check(lib.ia_scatter_f32_i32(L.i64(n), L.ptr(ps[:, 0].contiguous()), L.ptr(order), L.ptr(back), st), "scatter")
     assert torch.equal(back, pts[:, 0])
+
+
+def test_morton_order_ranks_by_lds_atomics_on_this_device_and_the_ballot_path_agrees():
+    """csrc/sort.hip ranks the 64 elements of a wave instruction by one LDS atomic-with-return per lane, which is only stable if the
+    LDS serves the lanes of one instruction in ascending order -- the library checks that on the device before its first sort
+    (ia_sort_rank_mode() == 1 on gfx950) and otherwise ranks by ballots; IA_SORT_RANK=ballot forces that path (a fresh process:
+    the mode is decided once), which must produce the same permutation."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, torch, sys
+from intrinsicavatar_amd import _lib as L
+lib, st = L.lib(), L.stream()
+n = 2_500_011
+g = torch.Generator(device="cuda:0").manual_seed(5)
+pts = (torch.rand(n, 3, device="cuda:0", generator=g) * 3.0 - 1.5).contiguous()
+pts[::3] = pts[1::3][: pts[::3].shape[0]]
+origin = (C.c_float * 3)(-2.0, -2.0, -2.0)
+keys = torch.empty(n, dtype=torch.int32, device="cuda:0")
+L.check(lib.ia_morton_keys(L.i64(n), L.ptr(pts), origin, L.f32(100.0), L.ptr(keys), st), "keys")
+order = torch.empty(n, dtype=torch.int32, device="cuda:0")
+nb = int(lib.ia_morton_order_tmp_bytes(L.i64(n)))
+tmp = torch.empty(nb, dtype=torch.uint8, device="cuda:0")
+L.check(lib.ia_morton_order(L.i64(n), L.ptr(pts), origin, L.f32(100.0), L.i32(0), L.ptr(order), L.ptr(tmp), C.c_size_t(nb), st), "order")
+assert torch.equal(order.long(), torch.sort(keys, stable=True)[1])
+print("MODE", int(lib.ia_sort_rank_mode()))
+'''
+    import os
+    modes = {}
+    for rank in ("", "ballot"):
+        env = dict(os.environ, IA_SORT_RANK=rank)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        modes[rank] = int(r.stdout.strip().split("MODE")[-1])
+    assert modes == {"": 1, "ballot": 2}, modes
