@@ -347,6 +347,7 @@ def main():
     _flush_c_stdout()            # RCCL's start-up banner (C stdio, block-buffered on a pipe) leaves every rank NOW, not after the JSON line
     lib = L.lib()
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides, nothing else running
+    torch.cuda.reset_peak_memory_stats()          # the peaks reported are those of the timed steps (not of the up-front arena)
     thr0 = cgroup_throttle()
     cpu0 = time.process_time()
     t0 = time.perf_counter()
@@ -356,6 +357,8 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    streams_taken = getattr(rs, "last_secondary_streams", None)      # what the timed steps ran (RenderStep._secondary_streams_for: memory-gated)
+    peak_alloc_timed, peak_reserved_timed = torch.cuda.max_memory_allocated(), torch.cuda.max_memory_reserved()
     cpu_busy = (time.process_time() - cpu0) / max(dt, 1e-9)          # CPUs this rank kept busy during the timed region
     thr1 = cgroup_throttle()
     # ---- ONE more step with a HIP-event pair around every C-ABI launch (on the launch stream): per-kernel durations
@@ -621,10 +624,10 @@ def main():
                        "host_numa_node": numa_node, "host_cpus_busy": round(cpu_busy, 2), "blocking_sync": bool(blocking),
                        "host_cpu_throttled_ms_in_timed_region": (None if not (thr0 and thr1) else round((thr1[1] - thr0[1]) / 1e3, 1)),
                        "optimizer_step_in_timed_region": bool(opt is not None), "frames_per_step_per_gpu": 1,
-                       "peak_device_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-                       "peak_reserved_memory_GiB": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1),
+                       "peak_device_memory_GiB": round(peak_alloc_timed / 2 ** 30, 1),
+                       "peak_reserved_memory_GiB": round(peak_reserved_timed / 2 ** 30, 1),
                        "parallelism": f"frame/ray-batch sharding x{world}", "samples": stats,
-                       "secondary_march_streams": timed_streams,
+                       "secondary_march_streams": timed_streams, "secondary_march_streams_taken": streams_taken,
                        "gradient_allreduce": (None if sync is None else dict(backend=dist.get_backend(), world=dist.get_world_size(),
                                                                             bytes_per_step=int(reduced_bytes[0]))),
                        "library_sources_sha256_16": _build.source_fingerprint(), "library_built_from": _build.built_fingerprint()},

@@ -350,16 +350,20 @@ class RenderStep:
     def _secondary_streams_for(self, M: int, chunk: int, dev) -> int:
         """how many HIP streams / host threads the secondary march of M rays takes.  Each side stream has its own caching-allocator pool
         (measured: 184 GiB reserved against 142 GiB live on the headline step, for 3-4 % of the step), so the streams are only taken
-        when the device has room for that: free + this process's cached-but-unused memory >= 2 x the working set of the chunks in
-        flight; otherwise the serial loop runs (IA_SECONDARY_STREAMS=1 forces it).  An OOM inside the threads falls back to it too."""
+        when the device has room for that: free + this process's cached-but-unused memory >= 1.3 x the working set of the chunks in
+        flight (the measured reserve / live ratio); otherwise the serial loop runs (IA_SECONDARY_STREAMS=1 forces it: 99 GiB live /
+        113 GiB reserved on the headline step, 3 % slower).  An OOM inside the threads falls back to it too."""
         n = self.SECONDARY_STREAMS
         if n <= 1 or dev.type != "cuda" or M <= self.SECONDARY_STREAMS_MIN_RAYS:
+            self.last_secondary_streams = 1
             return 1
         plan = plan_secondary_chunks(M, chunk, n, self.SECONDARY_MIN_CHUNK)
         in_flight = n * max(b - a for a, b in plan) * self.SECONDARY_BYTES_PER_RAY
         free, _total = torch.cuda.mem_get_info(dev)
         cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-        return n if free + cached >= 2 * in_flight else 1
+        n = n if free + cached >= 1.3 * in_flight else 1
+        self.last_secondary_streams = n
+        return n
     # below ~8 M rays the kernels of a chunk no longer fill the device and splitting them makes it worse (config-4 shape, 1 M secondary rays:
     # 21.8 ms per step serial, 24.2 on two streams)
     SECONDARY_STREAMS_MIN_RAYS = int(os.environ.get("IA_SECONDARY_STREAMS_MIN_RAYS", str(1 << 23)))

@@ -328,7 +328,7 @@ def test_canary_counts_nothing_on_the_product_path_and_catches_a_loosened_filter
         dfm._candidates(pts, with_src=False)
         dfm._candidates(pts, with_src=True, order=order)                     # through the permutation as well
         n, bad, ovf = dfm.canary_totals(reset=True)
-        assert n >= pts.shape[0] // 2 - 2 and bad == 0 and ovf <= 4, (n, bad, ovf)
+        assert n >= pts.shape[0] // 2 - 2 and bad == 0 and ovf <= 1e-4 * n, (n, bad, ovf)     # ovf: points with a 4th survivor (count compared only)
         dfm.spec_eps, dfm.cell_tight = 5e-3, None
         dfm._candidates(pts, with_src=False)
         n2, bad2, _ = dfm.canary_totals(reset=True)
