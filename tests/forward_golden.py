@@ -158,3 +158,103 @@ def table_gradient_summary(g):
     out["sub_index"] = keep.astype(np.int32)
     out["sub_value"] = g[keep].astype(np.float32)
     return out
+
+
+# ----------------------------------------------------------------------------- outliers of the SDF gradient, explained sample by sample
+def explain_gradient_outliers(rs, pts_gpu, pts_ref, grad_ref, thresh, max_shift=1e-3, k_ulp=16, dev="cuda:0"):
+    """Why a few samples' SDF gradients differ by O(0.1) between the HIP path and a CPU implementation of the same step
+    (tools/grad_outlier_probe.py, profiles/r05_grad_outliers.json: 241 of 211 195 samples above 10 x p99, every one of them with
+    the HIP field AT THE ORACLE'S sample point within 5e-7 of the oracle's gradient):
+      A. the two pipelines do not evaluate the field at bit-identical sample points -- the K2 / K4 edges come from inverting a CDF of
+         fp32 weights, 6 % of the samples differ in t by an ulp or more -- and the gradient of this field is steep (Softplus beta = 100)
+         and piecewise constant in the cell index of every hash level, so a shift of 1e-6 can change it by 0.1;
+      B. at an IDENTICAL point two implementations can still pick different cells when a level coordinate x01 * scale + 0.5 lies within
+         an ulp of an integer (fmaf here, multiply-then-add in torch).
+    Checked per outlier, for posed-space sample points `pts_gpu` (this path's), `pts_ref` (the other implementation's) [m,3] and the
+    other implementation's gradient `grad_ref` [m,3]:
+      same_point    |pts_gpu - pts_ref|_inf <= max_shift (it IS the same sample);
+      field_agrees  A: the HIP field evaluated AT THE OTHER IMPLEMENTATION'S point returns its gradient within `thresh`;
+      face_flip     B: otherwise -- a level coordinate of that point's root is within k_ulp ulp of a cell face, and evaluated on the
+                    other side of that face (64 ulp across: 1e-5 of a cell) the HIP field returns the other gradient within `thresh`.
+      near_tie      C: otherwise -- the point has a second candidate root whose SDF is within 2e-5 of the selected minimum (the min over
+                    the candidates, snarf_deformer.py:192-231, is decided by the last bits) and THAT candidate's gradient is the other one.
+      jump_nearby   D: otherwise -- within 4e-6 m of that point (probes along the axes and the diagonal) the HIP path returns the other
+                    gradient: the sample sits on a discontinuity of the composed map point -> root -> gradient that the hash-face test
+                    does not see, e.g. where Broyden's |g| < 1e-5 stop (fuse_cuda_kernel_fast.cu:252-452) takes one more iteration and
+                    the root moves by ~1e-5 (seen on 1 of 12 712 samples of the golden frame).
+    explained = same_point and (A or B or C or D).  -> (explained [m] bool, dict of the conditions + residuals)."""
+    import torch
+    from tests import torch_ref as TR
+    geo, dfm = rs.geometry, rs.deformer
+    pg = torch.as_tensor(pts_gpu, device=dev).float().contiguous()
+    pr = torch.as_tensor(pts_ref, device=dev).float().contiguous()
+    ref = torch.as_tensor(grad_ref, device=dev).float()
+    m = pg.shape[0]
+    if m == 0:
+        z = np.zeros(0, bool)
+        return z, dict(same_point=z, field_agrees=z, face_flip=z, near_tie=z, jump_nearby=z, cell_changes=z, residual=np.zeros(0), shift=np.zeros(0))
+    with torch.no_grad():
+        dg = dfm.deform(pg, geo, with_grad=True, with_feature=False)
+        dr = dfm.deform(pr, geo, with_grad=True, with_feature=False, want_fwd=True)
+        shift = (pg - pr).abs().max(-1)[0]
+        residual = (dr["sdf_grad"] - ref).abs().max(-1)[0]
+        scales = torch.tensor(TR.hash_cfg()[2], device=dev, dtype=torch.float32)          # [16]
+
+        def level_pos(xc):
+            x01 = ((xc - geo.center) / geo.scale + 0.5).float()
+            return x01, x01[:, None, :] * scales[None, :, None] + 0.5                     # [m,3], [m,16,3]
+        _, pos_g = level_pos(dg["pts_cano"])
+        x01, pos = level_pos(dr["pts_cano"])
+        cell_changes = (torch.floor(pos_g) != torch.floor(pos)).reshape(m, -1).any(1)
+        same_point = shift <= max_shift
+        field_agrees = residual <= thresh
+        # B: nudge across a near face, at the other implementation's point
+        sel = dr["sel"].long().clamp(min=0)
+        c2w = dr["fwd_J"].reshape(-1, 3, 3)[dr["cand_src"].long()[sel]]
+        face = torch.round(pos)
+        ulp = torch.nextafter(pos.abs(), torch.full_like(pos, float("inf"))) - pos.abs()
+        near = (pos - face).abs() <= k_ulp * ulp
+        best = torch.full((m,), float("inf"), device=dev)
+        lv, ax = torch.nonzero((near & ~field_agrees[:, None, None]).any(0), as_tuple=True)
+        for l_, a_ in zip(lv.tolist(), ax.tolist()):
+            who = near[:, l_, a_] & ~field_agrees
+            side = torch.where(pos[:, l_, a_] >= face[:, l_, a_], -1.0, 1.0)              # to the OTHER side of the face
+            target = face[:, l_, a_] + side * 64 * ulp[:, l_, a_]
+            xt = x01.clone()
+            xt[:, a_] = torch.where(who, (target - 0.5) / scales[l_], x01[:, a_])
+            _, g, _ = geo(((xt - 0.5) * geo.scale + geo.center).contiguous(), with_grad=True, with_feature=True)
+            err = ((c2w * g[:, None, :]).sum(-1) - ref).abs().max(-1)[0]
+            best = torch.where(who, torch.minimum(best, err), best)
+        face_flip = ~field_agrees & (best <= thresh)
+        # C: another candidate within 2e-5 of the minimum SDF carries the other gradient
+        near_tie = torch.zeros(m, dtype=torch.bool, device=dev)
+        left = torch.nonzero(~field_agrees & ~face_flip)[:, 0]
+        if left.numel() > 0:
+            pl = pr[left].contiguous()
+            cand_x, cand_src, cnt, start, Q, fwd, _ = dfm._candidates(pl, with_src=True, want_fwd=True)
+            _, cg, cf = geo(cand_x, with_grad=True, with_feature=True)
+            cw = (fwd.reshape(-1, 3, 3)[cand_src.long()] * cg[:, None, :]).sum(-1)          # pushed-forward gradient of every candidate
+            csdf = cf[:, 0]
+            for j in range(left.numel()):
+                a, n_ = int(start[j]), int(cnt[j])
+                if n_ < 2:
+                    continue
+                sd, gw = csdf[a:a + n_], cw[a:a + n_]
+                close = (sd - sd.min()) <= 2e-5
+                hit = close & ((gw - ref[left[j]][None]).abs().max(-1)[0] <= thresh)
+                near_tie[left[j]] = bool(close.sum() >= 2 and hit.any())
+        jump_nearby = torch.zeros(m, dtype=torch.bool, device=dev)
+        left = torch.nonzero(~field_agrees & ~face_flip & ~near_tie)[:, 0]
+        if left.numel() > 0:
+            dirs = torch.tensor([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0], [0.57735, 0.57735, 0.57735]], device=dev)
+            for step in (1e-6, 2e-6, 4e-6):
+                for sgn in (-1.0, 1.0):
+                    for dv in dirs:
+                        q = (pr[left] + sgn * step * dv[None]).contiguous()
+                        e_ = (dfm.deform(q, geo, with_grad=True, with_feature=False)["sdf_grad"] - ref[left]).abs().max(-1)[0]
+                        jump_nearby[left] |= e_ <= thresh
+        explained = same_point & (field_agrees | face_flip | near_tie | jump_nearby)
+    c = lambda t: t.cpu().numpy()      # noqa: E731
+    return c(explained), dict(same_point=c(same_point), field_agrees=c(field_agrees), face_flip=c(face_flip), near_tie=c(near_tie),
+                              jump_nearby=c(jump_nearby), cell_changes=c(cell_changes), residual=c(torch.where(field_agrees, residual, torch.minimum(residual, best))),
+                              shift=c(shift))

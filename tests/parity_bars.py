@@ -1,0 +1,69 @@
+"""(max, p99, mean) bars of the end-to-end parity tests.
+
+Every float comparison of the HIP path with the oracle / the reference's own forward_ goes through `held(name, a, b, cap)`:
+per row (pixel, sample) the maximum absolute difference over the channels, then (max over ALL rows, 99th percentile, mean).
+The three numbers must stay within the bar of `name` in tests/golden/parity_bars.json -- 3 x what the MI355X showed
+(tools/make_parity_bars.py turns an observation run into that file) -- AND within `cap`, the hard limit written next to the call
+in the test: a bar file regenerated on a defective build cannot raise a limit above what the test's author accepted.  The maximum is
+over every row: there is no fraction-of-pixels allowance anywhere.
+
+Observation run (writes the observed triples, bars are not needed):   IA_PARITY_OBSERVE=gpurun_out/parity_obs.json pytest -m gpu ...
+"""
+import atexit
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PATH = os.path.join(HERE, "golden", "parity_bars.json")
+BARS = json.load(open(PATH))["bars"] if os.path.exists(PATH) else {}
+_OBS_PATH = os.environ.get("IA_PARITY_OBSERVE")
+_OBS = {}
+
+
+def triple(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b)
+    err = err.reshape(err.shape[0], -1).max(-1) if err.ndim > 1 else err
+    if err.size == 0:
+        return (0.0, 0.0, 0.0)
+    return (float(err.max()), float(np.quantile(err, 0.99)), float(err.mean()))
+
+
+def held(name, a, b, cap):
+    """assert the (max, p99, mean) absolute difference of a vs b within min(bar[name], cap); returns the observed triple."""
+    got = triple(a, b)
+    assert all(np.isfinite(got)), (name, got)
+    if _OBS_PATH:
+        _OBS[name] = got
+    bar = BARS.get(name)
+    if bar is None:
+        assert _OBS_PATH, f"no bar for '{name}' in tests/golden/parity_bars.json (make one: IA_PARITY_OBSERVE + tools/make_parity_bars.py)"
+        bar = cap
+    lim = tuple(min(x, y) for x, y in zip(bar, cap))
+    assert got[0] <= lim[0] and got[1] <= lim[1] and got[2] <= lim[2], (name, got, lim)
+    return got
+
+
+def count(name, n, cap):
+    """a discrete difference (flipped samples, rays with another count): observed n must stay within the stated bound `cap`."""
+    if _OBS_PATH:
+        _OBS[name] = (float(n),)
+    assert n <= cap, (name, n, cap)
+    return n
+
+
+@atexit.register
+def _write():
+    if _OBS_PATH and _OBS:
+        old = {}
+        if os.path.exists(_OBS_PATH):
+            try:
+                old = json.load(open(_OBS_PATH))
+            except Exception:
+                old = {}
+        old.update({k: list(v) for k, v in _OBS.items()})
+        os.makedirs(os.path.dirname(os.path.abspath(_OBS_PATH)), exist_ok=True)
+        json.dump(old, open(_OBS_PATH, "w"), indent=0, sort_keys=True)

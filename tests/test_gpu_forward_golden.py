@@ -151,6 +151,31 @@ def test_forward_train_mode_vs_the_references_own_forward(G):
         a, b = N(d[k]), ref[k]
         _held(k, a if a.ndim > 1 else a[:, None], b if b.ndim > 1 else b[:, None], bar)
     assert float(np.abs(ref["sdf_laplace_samples"]).max()) == 0.0 and float(d["sdf_laplace_samples"].abs().max()) == 0.0
+    # ---- the outliers of the SDF gradient are hash-cell-face flips, and nothing else (checked, not asserted by comment;
+    # tests/forward_golden.explain_gradient_outliers): for every sample whose gradient is more than 10 x p99 away from the reference's,
+    # it is the same sample (|shift| <= 1e-3), and the HIP field AT THE REFERENCE'S point returns the reference's gradient -- the difference is
+    # the sample position (K2's CDF inversion of fp32 weights) -- or, at an identical point, the other side of a hash-cell face a few ulp away does
+    g_gpu, g_ref = N(d["sdf_grad_samples"]), ref["sdf_grad_samples"]
+    err = np.abs(g_gpu - g_ref).max(-1)
+    thresh = 10.0 * float(np.quantile(err, 0.99))
+    out_s = np.nonzero(err > thresh)[0]
+    r_smpl = rs.deformer.transform_rays_w2s(rays.float())
+    ri = d["ray_indices"].long()
+    sel_ = torch.from_numpy(out_s).to(DEV)
+    pts_gpu = (r_smpl[ri, :3] + r_smpl[ri, 3:6] * d["points"][:, None])[sel_]
+    pts_ref = (r_smpl[ri, :3] + r_smpl[ri, 3:6] * T(ref["points"])[:, None])[sel_]
+    explained, why = FG.explain_gradient_outliers(rs, pts_gpu, pts_ref, g_ref[out_s], thresh)
+    assert explained.all(), ("sdf_grad_samples outliers that are NOT cell-face flips", out_s[~explained].tolist(),
+                             {k: v[~explained].tolist() for k, v in why.items()}, thresh)
+    # the pixel maps that carry the gradient: an outlier pixel (10 x p99) owns an outlier sample
+    rays_with_flip = set(N(ri)[out_s].tolist())
+    for k in ("comp_normal", "normals_orientation_loss_map"):
+        e = np.abs(N(d[k]) - ref[k]).reshape(ref[k].shape[0], -1).max(-1)
+        bad_px = np.nonzero(e > 10.0 * float(np.quantile(e, 0.99)))[0]
+        assert set(bad_px.tolist()) <= rays_with_flip, (k, sorted(set(bad_px.tolist()) - rays_with_flip))
+    print(f"cell-face check: {out_s.size} gradient outliers of {err.size} samples (> {thresh:.2e}), all explained: "
+          f"{int(why['field_agrees'].sum())} by position, {int(why['face_flip'].sum())} cell-face flips, {int(why['near_tie'].sum())} near ties, "
+          f"{int(why['jump_nearby'].sum())} jumps within 4e-6 m")
 
 
 def test_per_frame_preparation_vs_the_reference(G):

@@ -12,6 +12,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests import parity_bars as PB
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -158,7 +160,7 @@ def test_headline_forward_vs_oracle_per_point(oracle):
     assert ts.shape[0] == rst["n_samples"] and rst["n_fg"] > 2000
     vi = out["volume_interaction"]
     assert np.array_equal(N(vi.resampled_packed_info), ref["resampled_packed_info"])
-    assert abs(vi.F - rst["n_fg"]) <= 0.002 * rst["n_fg"] + 2
+    assert abs(vi.F - rst["n_fg"]) <= max(2, int(2e-5 * rst["n_fg"]))
     # per-ray foreground counts -> the common prefix
     cnt_g = N(vi.fg_ray_cnt).astype(np.int64)
     rri = np.repeat(np.nonzero(ref["resampled_packed_info"][:, 1] > 0)[0], spp)
@@ -169,25 +171,24 @@ def test_headline_forward_vs_oracle_per_point(oracle):
     assert F0 >= 0.5 * rst["n_fg"], (r0, F0, rst["n_fg"])
     # light directions: same uniforms through the same CDF (fp64 both sides); a CDF threshold can fall on the other texel
     dg, dr = N(out["out_dirs"])[:F0], ref["out_dirs"][:F0]
-    assert (np.abs(dg - dr).max(-1) < 1e-4).mean() >= 0.999
     same_dir = np.abs(dg - dr).max(-1) < 1e-4
+    PB.count("headline_call/light_dirs_on_another_texel", int((~same_dir).sum()), max(2, int(1e-4 * same_dir.size)))
+    PB.held("headline_call/light_dirs", dg[same_dir], dr[same_dir], (1e-4, 2e-6, 5e-7))
     tr_g, tr_r = N(out["secondary_tr"])[:F0, 0], ref["secondary_tr"][:F0, 0]
     agree = np.abs(tr_g - tr_r) <= 2e-3
-    assert agree[same_dir].mean() >= 0.99, float(agree[same_dir].mean())
+    PB.count("headline_call/secondary_rays_with_another_visibility", int((~agree[same_dir]).sum()), max(4, int(2e-3 * same_dir.sum())))
     ok = agree & same_dir
     Lo_g, Lo_r = N(out["fg_Lo"])[:F0][ok], ref["fg_Lo"][:F0][ok]
     scale = np.abs(Lo_r).mean() + 1e-6
-    assert (np.abs(Lo_g - Lo_r).max(-1) <= 5e-3 * scale + 5e-3 * np.abs(Lo_r).max(-1)).mean() >= 0.99
+    PB.held("headline_call/fg_Lo_over_mean", Lo_g / scale, Lo_r / scale, (25.0, 3e-2, 4e-3))
     # the light pdf the estimator divides by, against the oracle's on the same directions
     dw = dr @ sc.w2s[:3, :3]
     dw = dw / np.maximum(np.linalg.norm(dw, axis=-1, keepdims=True), 1e-6)
     pdf_r = Pb.envlight_pdf(Pb.envlight_pmf(sc.env_base), dw.astype(np.float32))
     pdf_g = N(emitter.pdf(T(dw.astype(np.float32))))[:, 0]
-    assert (np.abs(pdf_g - pdf_r) <= 1e-4 * np.abs(pdf_r) + 1e-7).mean() >= 0.999
+    PB.held("headline_call/light_pdf_rel", pdf_g / np.maximum(np.abs(pdf_r), 1e-7), pdf_r / np.maximum(np.abs(pdf_r), 1e-7), (1e-3, 1e-5, 2e-6))
     # image on the prefix rays
     img_g, img_r = N(out["comp_rgb_phys"])[:r0], ref["comp_rgb_phys"][:r0]
-    err = np.abs(img_g - img_r).max(-1)
-    tol = 2e-2 * np.abs(img_r).max(-1) + 2e-2
-    assert (err <= tol).mean() >= 0.98, ((err > tol).mean(), err.max())
+    PB.held("headline_call/comp_rgb_phys", img_g, img_r, (0.3, 3e-2, 1.5e-3))
     has = ref["resampled_packed_info"][:r0, 1] > 0
-    assert abs(img_g[has].mean() - img_r[has].mean()) <= 1e-2 * abs(img_r[has].mean())
+    assert abs(img_g[has].mean() - img_r[has].mean()) <= 2e-3 * abs(img_r[has].mean())

@@ -1,10 +1,13 @@
 """GPU (MI355X): the hot path on frames of the reference's OWN pose files (tests/golden/reference_poses.npz: four training frames of
 load/peoplesnapshot/male-3-casual/poses/anim_nerf_train.npz, four out-of-distribution frames of load/animation/aist/poses.npz,
 translation re-based as datasets/animation.py:129-130) driven through plain forward kinematics -- BASELINE configs 2-5 name these
-files.  Same bars as the synthetic-pose tests (tests/test_gpu_render.py, tests/test_gpu_relight_oracle.py)."""
+files.  Bars: (max, p99, mean) per key over EVERY pixel, 3 x the MI355X observation under the hard caps written here
+(tests/parity_bars.py); discrete outputs exact up to a stated number of flips."""
 import numpy as np
 import pytest
 import torch
+
+from tests import parity_bars as PB
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -56,23 +59,25 @@ def test_render_step_vs_oracle_on_reference_poses(oracle, pose):
     assert sr["n_samples0"] > 3000
     assert st["n_edges0"] == sr["n_edges0"] and st["n_samples0"] == sr["n_samples0"]      # marching: bit-exact
     cnt, cnt_ref = N(out["packed_info"][:, 1]), ref["packed_info"][:, 1]
-    assert (cnt == cnt_ref).mean() >= 0.995
-    for k, tol in (("comp_rgb", 2e-3), ("opacity", 2e-3), ("comp_normal", 4e-3), ("depth", 5e-3)):
-        err = np.abs(N(out[k]) - ref[k]).max(-1)
-        assert (err < tol).mean() >= 0.985 and err.max() < 0.15 and err.mean() < 2e-4, (k, float(err.max()), float(err.mean()))
+    PB.count(f"refpose/{pose}/rays_with_another_sample_count", int((cnt != cnt_ref).sum()), 2)
+    # hard caps: one sample on the other side of a hash-cell face moves ONE pixel's normal by ~0.1 and its colour by ~1e-2
+    for k, cap in (("comp_rgb", (3e-2, 1.5e-3, 1e-4)), ("opacity", (4e-4, 3e-5, 2e-6)), ("comp_normal", (0.25, 5e-3, 1e-3)),
+                   ("depth", (3e-4, 3e-5, 3e-6))):
+        PB.held(f"refpose/{pose}/{k}", N(out[k]), ref[k], cap)
 
 
 def test_relight_vs_oracle_on_an_animation_pose(oracle):
-    """BASELINE config 5 shape (animation pose, render_mode=light, global illumination on) at an oracle-sized frame."""
+    """BASELINE config 5 (animation OOD pose, render_mode=light, samples_per_pixel=1024, global illumination on) on an oracle-sized
+    subsample of the frame's rays (24 x 24; the oracle marches ~0.6 M secondary rays for them)."""
     from intrinsicavatar_amd import synthetic as S, fields, pbr
     from oracle import render_ref as R
     from tests.test_gpu_relight_oracle import hdri
-    rs, rays, export = _frame("aist:100", 32)
+    rs, rays, export = _frame("aist:100", 24)
     mat = fields.VolumeMaterial(seed=2).to(DEV)
     env = pbr.EnvironmentLightTensor(T(hdri()))
     env.update_pdf()
     sc = R.Scene(**export, **S.export_phys(mat, env.base))
-    n, spp = rays.shape[0], 64
+    n, spp = rays.shape[0], 1024
     rng = np.random.default_rng(7)
     light_u, shuffle_u = rng.random((spp, 3), dtype=np.float32), rng.random((n, spp), dtype=np.float32)
     bg = np.array([0.2, 0.4, 0.6], np.float32)
@@ -80,12 +85,11 @@ def test_relight_vs_oracle_on_an_animation_pose(oracle):
     d = rs.forward_(rays, mat, env, spp, T(light_u), T(shuffle_u), background_color=T(bg), global_illumination=True)
     want = R.forward_output_dict(ref, bg, "light")
     assert sorted(d) == sorted(want)
-    assert ref["stats"]["n_fg"] > 1000
-    assert abs(int(d["num_samples"][0]) - int(want["num_samples"][0])) <= 0.005 * int(want["num_samples"][0])
-    for k, tol in (("comp_rgb", 2e-3), ("comp_albedo", 2e-3), ("opacity", 2e-3), ("comp_rgb_full", 4e-3)):
-        err = np.abs(N(d[k]) - want[k]).max(-1)
-        assert (err < tol).mean() >= 0.985, (k, float(err.max()))
-    for k in ("comp_rgb_phys", "comp_demod_phys", "comp_rgb_phys_full"):
-        a, b = N(d[k]), want[k]
-        tol = 2e-2 * np.abs(b).max(-1) + 2e-2
-        assert (np.abs(a - b).max(-1) <= tol).mean() >= 0.97, k
+    assert ref["stats"]["n_fg"] > 50_000
+    PB.count("refpose/aist:100/num_samples_diff", abs(int(d["num_samples"][0]) - int(want["num_samples"][0])), 2)
+    for k, cap in (("comp_rgb", (3e-2, 1.5e-3, 1e-4)), ("comp_albedo", (3e-4, 2e-5, 1e-6)), ("opacity", (4e-4, 3e-5, 2e-6)),
+                   ("comp_rgb_full", (3e-2, 1.5e-3, 1e-4)), ("comp_normal", (0.25, 5e-3, 1e-3))):
+        PB.held(f"refpose/aist:100/relight/{k}", N(d[k]), want[k], cap)
+    # Monte-Carlo images (spp 1024): a visibility sample on the other side of a threshold moves a pixel by Lo / spp
+    for k, cap in (("comp_rgb_phys", (0.1, 1e-2, 5e-4)), ("comp_demod_phys", (0.3, 3e-2, 1.5e-3)), ("comp_rgb_phys_full", (0.1, 1e-2, 5e-4))):
+        PB.held(f"refpose/aist:100/relight/{k}", N(d[k]), want[k], cap)

@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests import parity_bars as PB
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -66,11 +68,10 @@ def test_relight_light_mode_vs_oracle(setup, hw, spp, gi):
     assert st["n_samples"] == rst["n_samples"] and rst["n_fg"] > 500
     # ---- step 5: materials composite (rendering_with_normals_mats_sdf); the bars of the radiance-only parity test
     # (tests/test_gpu_render.py): 2e-3 abs (normals 4e-3) on >= 98.5 % of the pixels, mean < 2e-4
-    for k, tol in (("comp_rgb", 2e-3), ("comp_normal", 4e-3), ("albedo", 2e-3), ("roughness", 2e-3), ("metallic", 2e-3),
-                   ("opacity", 2e-3)):
-        err = np.abs(N(out[k]) - ref[k]).max(-1)
-        assert (err < tol).mean() >= 0.985 and err.max() < 0.15 and err.mean() < (5e-4 if k == "comp_normal" else 2e-4), \
-            (k, err.max(), err.mean())
+    tag = f"relight/{hw}x{hw}_spp{spp}_{'gi' if gi else 'nogi'}"
+    for k, cap in (("comp_rgb", (3e-2, 1.5e-3, 1e-4)), ("comp_normal", (0.25, 5e-3, 1e-3)), ("albedo", (3e-3, 3e-5, 3e-6)),
+                   ("roughness", (3e-3, 3e-5, 3e-6)), ("metallic", (3e-3, 3e-5, 3e-6)), ("opacity", (4e-4, 3e-5, 2e-6))):
+        PB.held(f"{tag}/{k}", N(out[k]), ref[k], cap)
     # ---- step 6: volume-interaction re-sampling.  K1 is bit-exact given identical weights / sdfs; the weights here come from
     # fp32 field kernels (tolerance), so a CDF threshold can fall on the other side for a few re-samples: layout (packed
     # info = which rays own spp re-samples) exact, sampled interval index equal for >= 99.5 % of the re-samples
@@ -78,8 +79,9 @@ def test_relight_light_mode_vs_oracle(setup, hw, spp, gi):
     assert st["n_resampled"] == rst["n_resampled"] == spp * int((ref["packed_info"][:, 1] > 0).sum())
     fg_ref = np.zeros(rst["n_resampled"], bool); fg_ref[ref["fg_indices"]] = True
     fg_gpu = np.zeros(st["n_resampled"], bool); fg_gpu[N(out["fg_indices"])] = True
-    assert (fg_ref == fg_gpu).mean() >= 0.998
-    assert abs(st["n_fg"] - rst["n_fg"]) <= 0.002 * rst["n_fg"] + 2
+    # foreground / background flags of the re-samples: observed identical; a CDF threshold may move a handful
+    PB.count(f"{tag}/resamples_with_another_fg_flag", int((fg_ref != fg_gpu).sum()), max(2, int(2e-5 * fg_ref.size)))
+    assert abs(st["n_fg"] - rst["n_fg"]) <= max(2, int(2e-5 * rst["n_fg"]))
     np.testing.assert_allclose(N(out["resampled_weights"]).sum(), ref["resampled_weights"].sum(), rtol=1e-3)
     # re-sampled weights of a ray sum to AT MOST 1: bg weights sum to the transmittance, fg weights to the opacity minus
     # the weight of the intervals that received no re-sample (the reference drops those, models/pbr/utils.py:137-152)
@@ -87,7 +89,7 @@ def test_relight_light_mode_vs_oracle(setup, hw, spp, gi):
     has = ref["resampled_packed_info"][:, 1] > 0
     rw_ref = np.zeros(n); np.add.at(rw_ref, ref["k1"]["midpoints"][:, 0].shape[0] and np.repeat(np.nonzero(has)[0], spp), ref["resampled_weights"])
     assert rw_sum[has].max() <= 1.0 + 2e-4
-    assert (np.abs(rw_sum - rw_ref) <= 2e-3).mean() >= 0.998, float((np.abs(rw_sum - rw_ref) > 2e-3).mean())      # a ray whose fg / bg split differs
+    PB.held(f"{tag}/resampled_weight_sum_per_ray", rw_sum, rw_ref, (0.2, 1e-4, 1e-4))      # a ray whose fg / bg split differs by one re-sample: 1 / spp
     # ---- step 7: secondary rays.  Same re-sample <-> light-direction pairing (shuffle), visibility agreement per sample
     same = fg_ref & fg_gpu
     pos_g = np.cumsum(fg_gpu) - 1
@@ -95,21 +97,22 @@ def test_relight_light_mode_vs_oracle(setup, hw, spp, gi):
     ig, ir = pos_g[same], pos_r[same]
     assert np.array_equal(N(out["shuffled"])[ig], ref["shuffled"][ir])
     tr_g, tr_r = N(out["secondary_tr"])[ig, 0], ref["secondary_tr"][ir, 0]
-    assert (np.abs(tr_g - tr_r) <= 2e-3).mean() >= 0.99, (np.abs(tr_g - tr_r) > 2e-3).mean()
-    assert abs(st["n_secondary"] - rst["n_secondary"]) <= 0.005 * rst["n_secondary"] + 2
+    # secondary transmittance per re-sample: a ray that grazes a zero crossing can resolve it the other way (0 <-> 1): counted, bounded
+    PB.count(f"{tag}/secondary_rays_with_another_visibility", int((np.abs(tr_g - tr_r) > 2e-3).sum()), max(4, int(2e-3 * tr_r.size)))
+    assert abs(st["n_secondary"] - rst["n_secondary"]) <= max(2, int(1e-4 * rst["n_secondary"]))
     # ---- step 8: estimator + composite.  Per re-sample radiance (where visibility agrees) and the image
     ok = np.abs(tr_g - tr_r) <= 2e-3
     Lo_g, Lo_r = N(out["fg_Lo"])[ig][ok], ref["fg_Lo"][ir][ok]
     scale = np.abs(Lo_r).mean() + 1e-6
-    assert (np.abs(Lo_g - Lo_r).max(-1) <= 5e-3 * scale + 5e-3 * np.abs(Lo_r).max(-1)).mean() >= 0.99
+    # outgoing radiance of every re-sample whose visibility agrees, relative to the frame's mean radiance
+    PB.held(f"{tag}/fg_Lo_over_mean", Lo_g / scale, Lo_r / scale, (25.0, 3e-2, 4e-3))
     img_g, img_r = N(out["comp_rgb_phys"]), ref["comp_rgb_phys"]
     assert np.isfinite(img_g).all()
     nohit = ~has
     np.testing.assert_array_equal(img_g[nohit], np.tile(bg[None], (int(nohit.sum()), 1)))
-    err = np.abs(img_g - img_r).max(-1)
-    tol = 2e-2 * np.abs(img_r).max(-1) + 2e-2          # Monte-Carlo image: a flipped visibility sample moves a pixel by Lo / spp
-    assert (err <= tol).mean() >= 0.98, ((err > tol).mean(), err.max())
-    assert abs(img_g[has].mean() - img_r[has].mean()) <= 1e-2 * abs(img_r[has].mean())
+    # Monte-Carlo image: a flipped visibility sample moves a pixel by Lo / spp
+    PB.held(f"{tag}/comp_rgb_phys", img_g, img_r, (0.3, 3e-2, 1.5e-3))
+    assert abs(img_g[has].mean() - img_r[has].mean()) <= 2e-3 * abs(img_r[has].mean())
 
 
 def test_light_shuffle_is_a_per_ray_permutation_matching_the_oracle(setup):
@@ -324,17 +327,16 @@ def test_relight_uniform_light_mode_vs_oracle(setup):
     fg_ref = np.zeros(ref["stats"]["n_resampled"], bool); fg_ref[ref["fg_indices"]] = True
     fg_gpu = np.zeros(out["stats"]["n_resampled"], bool); fg_gpu[N(out["fg_indices"])] = True
     same = fg_ref & fg_gpu
-    assert same.sum() >= 0.998 * fg_ref.sum()
+    PB.count("relight/uniform_light/resamples_with_another_fg_flag", int((fg_ref != fg_gpu).sum()), max(2, int(2e-5 * fg_ref.size)))
     ig, ir = (np.cumsum(fg_gpu) - 1)[same], (np.cumsum(fg_ref) - 1)[same]
     assert np.array_equal(N(out["shuffled"])[ig], ref["shuffled"][ir])
     tr_g, tr_r = N(out["secondary_tr"])[ig, 0], ref["secondary_tr"][ir, 0]
     ok = np.abs(tr_g - tr_r) <= 2e-3
-    assert ok.mean() >= 0.99
+    PB.count("relight/uniform_light/secondary_rays_with_another_visibility", int((~ok).sum()), max(4, int(2e-3 * ok.size)))
     Lo_g, Lo_r = N(out["fg_Lo"])[ig][ok], ref["fg_Lo"][ir][ok]
-    assert (np.abs(Lo_g - Lo_r).max(-1) <= 5e-3 * (np.abs(Lo_r).mean() + 1e-6) + 5e-3 * np.abs(Lo_r).max(-1)).mean() >= 0.99
+    scale = np.abs(Lo_r).mean() + 1e-6
+    PB.held("relight/uniform_light/fg_Lo_over_mean", Lo_g / scale, Lo_r / scale, (25.0, 3e-2, 4e-3))
     has = ref["resampled_packed_info"][:, 1] > 0
-    for k, tol in (("comp_rgb_phys", 2e-2), ("visibility", 2e-2)):
-        a, b = N(out[k]), ref[k]
-        err = np.abs(a - b).max(-1)
-        assert (err <= tol * np.abs(b).max(-1) + tol).mean() >= 0.98, (k, float(err.max()))
+    for k, cap in (("comp_rgb_phys", (0.3, 3e-2, 1.5e-3)), ("visibility", (0.1, 1e-2, 5e-4))):
+        PB.held(f"relight/uniform_light/{k}", N(out[k]), ref[k], cap)
     assert float(N(out["visibility"])[has].max()) <= 2.0 + 1e-4 and float(N(out["visibility"])[~has].max(initial=0.0)) == 0.0
