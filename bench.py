@@ -147,6 +147,8 @@ def build_headline(dev, hw, spp, rank, pose):
 
 
 def main():
+    if os.environ.get("IA_SWITCH_INTERVAL"):          # experiment: the interpreter's thread switch interval (two host threads feed two streams)
+        sys.setswitchinterval(float(os.environ["IA_SWITCH_INTERVAL"]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -243,6 +245,9 @@ def main():
     target_mask = (torch.rand(n_rays, generator=g) > 0.5).float().to(dev)
     torch.manual_seed(99 + rank)
     bg = torch.ones(3, device=dev)
+    frame_pipeline = int(os.environ.get("IA_FRAME_PIPELINE", "0"))       # experiment: n half-frames in flight (train_phys.forward_backward_phys_pipelined)
+    if frame_pipeline > 1 and args.workload == "headline":
+        args.ray_chunk = -(-n_rays // frame_pipeline)
     chunks = [(c0, min(c0 + args.ray_chunk, n_rays)) for c0 in range(0, n_rays, args.ray_chunk)]
     chunk_views = [(rays[a:b].contiguous(), target_rgb[a:b].contiguous(), target_mask[a:b].contiguous(), (b - a) / n_rays)
                    for a, b in chunks]
@@ -274,6 +279,16 @@ def main():
         emitter = pbr.EnvironmentLightTensor(leaf.detach())
         emitter.update_pdf()                                        # pbr_light_forward: `if self.training: update_pdf()`
         tot = dict(n_samples=0, n_edges0=0, n_samples0=0, n_resampled=0, n_fg=0, n_secondary=0)
+        if frame_pipeline > 1 and sync is None and len(chunk_views) > 1:
+            from intrinsicavatar_amd import train_phys as _tp
+            got = _tp.forward_backward_phys_pipelined(rs, chunk_views, mat, emitter, args.spp, n_workers=frame_pipeline, render_mode="light",
+                                                      env_base=leaf, background_color=bg, global_illumination=True, light_sampling="per_point")
+            for k in tot:
+                tot[k] = int(got.get(k, 0))
+            if leaf.grad is not None:
+                img.backward(leaf.grad)
+            totals.update(tot)
+            return dict(stats=tot)
         for ci, (r, t, m, frac) in enumerate(chunk_views):
             last = ci == len(chunk_views) - 1
             ctx = sync.no_sync() if (sync is not None and not last) else _null()

@@ -58,22 +58,37 @@ __global__ __launch_bounds__(THREADS) void count_rays_kernel(int64_t n_samples, 
 }
 
 // ---- K5..K7 -------------------------------------------------------------------
+// K5 as a segmented fill (the reference's pack.cu:7-28 walks a ray's samples with one thread): a wave takes 64 rays, every
+// lane loads one (start, count), and the wave then fills the rays' segments one after the other, all 64 lanes storing consecutive
+// elements -- a ray of the volume-interaction re-sampling (1024 entries, models/pbr/utils.py:113-135) is 16 fully coalesced 512-byte
+// stores instead of 1024 scattered 8-byte ones.  Any packed_info the reference kernel accepts gives the same result (segments need not
+// be ordered).
 __global__ __launch_bounds__(THREADS) void unpack_info_kernel(int64_t n_rays, const int32_t* __restrict__ packed_info,
                                                                int64_t* __restrict__ ray_indices)
 {
-    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (i >= n_rays) return;
-    const int2 pi = reinterpret_cast<const int2*>(packed_info)[i];
-    for (int j = 0; j < pi.y; ++j) ray_indices[pi.x + j] = i;
+    const int lane = threadIdx.x & 63;
+    const int64_t ray0 = ((int64_t)blockIdx.x * THREADS + threadIdx.x) - lane;          // first ray of this wave
+    const int64_t mine = ray0 + lane;
+    int2 pi = make_int2(0, 0);
+    if (mine < n_rays) pi = reinterpret_cast<const int2*>(packed_info)[mine];
+    unsigned long long todo = __ballot(pi.y > 0);
+    while (todo) {
+        const int k = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int start = __builtin_amdgcn_readlane(pi.x, k), cnt = __builtin_amdgcn_readlane(pi.y, k);
+        for (int j = lane; j < cnt; j += 64) ray_indices[(int64_t)start + j] = ray0 + k;
+    }
 }
 
+// one lane per (ray, slot) of the [n_rays, n_samples] mask
 __global__ __launch_bounds__(THREADS) void unpack_mask_kernel(int64_t n_rays, const int32_t* __restrict__ packed_info,
                                                                int n_samples, uint8_t* __restrict__ masks)
 {
-    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (i >= n_rays) return;
-    const int steps = packed_info[2 * i + 1];
-    for (int j = 0; j < steps; ++j) masks[i * n_samples + j] = 1;
+    const int64_t t = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (t >= n_rays * (int64_t)n_samples) return;
+    const int64_t r = t / n_samples;
+    const int j = (int)(t - r * n_samples);
+    if (j < packed_info[2 * r + 1]) masks[t] = 1;
 }
 
 __global__ __launch_bounds__(THREADS) void unpack_data_kernel(int64_t n_rays, const int32_t* __restrict__ packed_info,
@@ -473,8 +488,8 @@ IA_EXPORT int ia_unpack_info(int64_t n_rays, const int32_t* packed_info, int64_t
 IA_EXPORT int ia_unpack_info_to_mask(int64_t n_rays, const int32_t* packed_info, int n_samples, uint8_t* masks,
                                      ia_stream_t stream)
 {
-    if (n_rays == 0) return IA_OK;
-    unpack_mask_kernel<<<ia::cdiv(n_rays, THREADS), THREADS, 0, (hipStream_t)stream>>>(n_rays, packed_info, n_samples,
+    if (n_rays == 0 || n_samples <= 0) return IA_OK;
+    unpack_mask_kernel<<<ia::cdiv(n_rays * (int64_t)n_samples, THREADS), THREADS, 0, (hipStream_t)stream>>>(n_rays, packed_info, n_samples,
                                                                                        masks);
     return ia::check_launch("ia_unpack_info_to_mask");
 }

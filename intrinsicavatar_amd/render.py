@@ -276,6 +276,9 @@ class RenderStep:
         headline step against 2 Mi); the sample points of a chunk go through the search in batches of <= MAX_SEARCH_POINTS."""
         M = rays_o.shape[0]
         dev = rays_o.device
+        hook = getattr(self._march_hooks, "enter", None)          # frame pipelining (train_phys.forward_backward_phys_pipelined): this
+        if hook is not None:                                      # thread's half-frame reaches its secondary march
+            hook()
         tr = torch.ones((M, 1), device=dev)
         rgb = torch.zeros((M, 3), device=dev)
         step = (far - near) / (n_secondary - 1)
@@ -342,6 +345,8 @@ class RenderStep:
             raise errors[0]
         return tr, rgb
 
+    import threading as _threading
+    _march_hooks = _threading.local()          # per host thread: .enter (callable) / .streams (override of SECONDARY_STREAMS)
     SECONDARY_STREAMS = int(os.environ.get("IA_SECONDARY_STREAMS", "2"))
     # bytes of device memory a marched ray of a chunk keeps live at the peak of its chunk on the headline scene (9 samples per ray on
     # average x (search outputs + sorted copies + level-major hash features)): 142 GiB live for 2 x 10.5 Mi rays = ~7 KB per ray
@@ -353,7 +358,7 @@ class RenderStep:
         when the device has room for that: free + this process's cached-but-unused memory >= 1.3 x the working set of the chunks in
         flight (the measured reserve / live ratio); otherwise the serial loop runs (IA_SECONDARY_STREAMS=1 forces it: 99 GiB live /
         113 GiB reserved on the headline step, 3 % slower).  An OOM inside the threads falls back to it too."""
-        n = self.SECONDARY_STREAMS
+        n = getattr(self._march_hooks, "streams", None) or self.SECONDARY_STREAMS
         if n <= 1 or dev.type != "cuda" or M <= self.SECONDARY_STREAMS_MIN_RAYS:
             self.last_secondary_streams = 1
             return 1

@@ -200,3 +200,59 @@ def training_loss_phys(out: Dict[str, Tensor], target_rgb: Tensor, target_mask: 
         if lambda_orient > 0.0:
             loss = loss + lambda_orient * out["normals_orientation_loss_map"].mean()
     return loss
+
+
+def forward_backward_phys_pipelined(rs, views, material, emitter, spp: int, n_workers: int = 2, **kw) -> Dict[str, int]:
+    """Several ray chunks of ONE frame in flight: `views` = [(rays, target_rgb, target_mask, loss_scale), ...] as a caller would pass
+    them to RenderStep.forward_backward_phys one after the other (gradient accumulation over the chunks of a frame).  Here worker k
+    takes the chunks k, k + n_workers, ... on its own HIP stream and host thread, and -- what makes it pay -- worker k + 1 starts when
+    worker k ENTERS its secondary march: the primary sampling / shading / backward of one half-frame (many small kernels and the
+    size read-backs, which leave most of the device idle) then run under the other half-frame's march (search, hash gather, SDF head:
+    the part that fills the device).  Two processes on one GPU showed the head-room (1.16 x); symmetric workers that
+    start together stay in the same phase and gain nothing.
+    Results: every chunk's forward is what forward_backward_phys computes for it (ray-batch sharding invariance); the parameter
+    gradients are the sum of the chunks' gradients -- with two chunks a two-term sum, which is the same bits in either order.
+    Each worker marches its secondary rays on ONE stream (its own)."""
+    import threading
+    dev = views[0][0].device
+    main = torch.cuda.current_stream(dev)
+    n_workers = max(1, min(n_workers, len(views)))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_workers)]
+    entered = [threading.Event() for _ in range(n_workers)]
+    errors, stats = [], [None] * len(views)
+    _ = rs.grid_bits, rs._sort_grid_params()            # lazily cached host-side state: made before the threads start
+
+    def worker(k):
+        try:
+            if k > 0:
+                entered[k - 1].wait()                   # start when the previous worker's first chunk reaches its march
+            rs._march_hooks.streams = 1
+            rs._march_hooks.enter = entered[k].set
+            with torch.cuda.device(dev), torch.cuda.stream(streams[k]):
+                for ci in range(k, len(views), n_workers):
+                    r, t, m, frac = views[ci]
+                    o = rs.forward_backward_phys(r, t, material, emitter, spp, None, None, target_mask=m, loss_scale=frac, **kw)
+                    stats[ci] = {a: int(b) for a, b in o["stats"].items() if isinstance(b, (int, float))}
+                    del o
+        except BaseException as e:                      # noqa: B902 -- re-raised by the caller
+            errors.append(e)
+        finally:
+            entered[k].set()                            # never leave the next worker waiting
+            rs._march_hooks.enter = None
+            rs._march_hooks.streams = None
+    threads = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(n_workers)]
+    for s_ in streams:
+        s_.wait_stream(main)
+    for t_ in threads:
+        t_.start()
+    for t_ in threads:
+        t_.join()
+    for s_ in streams:
+        main.wait_stream(s_)
+    if errors:
+        raise errors[0]
+    tot: Dict[str, int] = {}
+    for st in stats:
+        for a, b in (st or {}).items():
+            tot[a] = tot.get(a, 0) + b
+    return tot

@@ -662,3 +662,26 @@ def test_foreground_compaction_equals_the_reference_op_sequence(ops):
     assert torch.equal(pinfo, LN.pack_info(rri[m], n))
     e = LN.compact_foreground(T(rpi), T(starts), T(ends), T(np.zeros(Tn, bool)))
     assert e[0].numel() == 0 and int(e[3][:, 1].sum()) == 0
+
+
+def test_unpack_info_segmented_fill_on_long_unordered_and_empty_segments():
+    """K5 as a wave-level segmented fill (csrc/resample.hip): the shape lib.nerfacc.unpack_info sees from the volume-interaction
+    re-sampling (1024 entries per non-empty ray, models/pbr/utils.py:113-135), empty rays, ragged counts, and segments that are not in
+    ray order -- against the definition (pack.cu:7-28: ray i owns [start_i, start_i + count_i))."""
+    from intrinsicavatar_amd import lib_nerfacc as lib
+    rng = np.random.default_rng(11)
+    for n_rays, make in ((5000, lambda r: np.where(r.random(5000) < 0.4, 1024, 0)), (70001, lambda r: r.integers(0, 40, 70001)),
+                         (129, lambda r: r.integers(0, 3000, 129)), (1, lambda r: np.array([77]))):
+        cnt = make(rng).astype(np.int64)
+        perm = rng.permutation(n_rays)                                  # segment order != ray order
+        start = np.zeros(n_rays, np.int64)
+        start[perm] = np.cumsum(cnt[perm]) - cnt[perm]
+        S_ = int(cnt.sum())
+        want = np.full(S_, -1, np.int64)
+        for i in np.nonzero(cnt)[0]:
+            want[start[i]:start[i] + cnt[i]] = i
+        pi = torch.from_numpy(np.stack([start, cnt], 1).astype(np.int32)).to(DEV)
+        got = lib.unpack_info(pi, S_)
+        assert got.dtype == torch.int64 and np.array_equal(N(got), want), n_rays
+        m = lib._unpack_info_to_mask(pi, int(cnt.max()))
+        assert np.array_equal(N(m), np.arange(int(cnt.max()))[None, :] < cnt[:, None])
