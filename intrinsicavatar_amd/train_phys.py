@@ -217,7 +217,11 @@ def forward_backward_phys_pipelined(rs, views, material, emitter, spp: int, n_wo
     dev = views[0][0].device
     main = torch.cuda.current_stream(dev)
     n_workers = max(1, min(n_workers, len(views)))
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_workers)]
+    # the workers' streams live as long as the RenderStep: the caching allocator keeps one pool per stream, and a fresh stream per
+    # step would strand the previous step's blocks in dead pools
+    streams = getattr(rs, "_pipeline_streams", None)
+    if streams is None or len(streams) != n_workers or streams[0].device != dev:
+        streams = rs._pipeline_streams = [torch.cuda.Stream(device=dev) for _ in range(n_workers)]
     entered = [threading.Event() for _ in range(n_workers)]
     errors, stats = [], [None] * len(views)
     _ = rs.grid_bits, rs._sort_grid_params()            # lazily cached host-side state: made before the threads start

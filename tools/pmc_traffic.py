@@ -16,7 +16,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = os.environ.get("IA_PROFILE_TAG", "r04")
+TAG = os.environ.get("IA_PROFILE_TAG", "r05")
 CMD = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-config2",
        "--no-breakdown", "--no-search-modes"] + sys.argv[1:]
 
@@ -26,7 +26,7 @@ def run_pass(name, counters):
     subprocess.run(["rm", "-rf", d])
     env = dict(os.environ, TMPDIR="/tmp", IA_SECONDARY_STREAMS="1")      # per-launch counters of kernels that have the device to themselves
     subprocess.run(["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + CMD,
-                   cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+                   cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, timeout=900)
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     seen, cnt = set(), collections.Counter()

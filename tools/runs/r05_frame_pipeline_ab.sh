@@ -5,6 +5,7 @@ OUT=$R/gpurun_out/r05_frame_pipeline_ab.jsonl
 : > $OUT
 for rep in 1 2; do
 for fp in 0 2; do
+    if [ $fp = 2 ]; then export IA_SECONDARY_CHUNK=6291456; else unset IA_SECONDARY_CHUNK; fi      # two half-frames in flight: half the chunk each
     IA_FRAME_PIPELINE=$fp timeout 400 python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-config2 --no-breakdown --no-search-modes 2>$R/gpurun_out/fp_err_$fp.txt | tail -1 | python -c "
 import sys, json
 b = json.loads(sys.stdin.read())
