@@ -296,11 +296,66 @@ __global__ __launch_bounds__(THREADS) void hash_fwd_xcd_kernel(int64_t n, const 
     const int np = plan.nparts[slot];
     const int64_t per = (n + np - 1) / np;
     const int64_t lo = per * plan.part[slot], hi = (lo + per < n) ? lo + per : n;
+#ifdef IA_HASH_FOUR
+    // experiment (round 5): FOUR points per lane and iteration (32 independent loads issued before the first blend) -- the straight-line
+    // gather of round 3 made "two in flight" real; does four help now?  Measured: DESIGN 4.3.
+    {
+        const int64_t stride4 = nchunks * THREADS;
+        for (int64_t i = lo + chunk * THREADS + threadIdx.x; i < hi; i += 4 * stride4) {
+            int64_t ix[4];
+            bool ok[4];
+            float xs[4][3];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int64_t j = i + q * stride4;
+                ok[q] = j < hi;
+                ix[q] = ok[q] ? j : i;
+#pragma unroll
+                for (int d = 0; d < 3; d++) xs[q][d] = __builtin_nontemporal_load(x + ix[q] * 3 + d);
+            }
+            for (int l = plan.first_level[slot]; l < plan.first_level[slot] + plan.n_level[slot]; l++) {
+                const float sc = cfg.scale[l];
+                const uint32_t res = cfg.res[l], hsize = cfg.offsets[l + 1] - cfg.offsets[l];
+                const float2* tab = params + cfg.offsets[l];
+                float2 v[4][8];
+                float p[4][3];
+                const uint64_t r64 = res;
+                const bool hashed = r64 * r64 * r64 > (uint64_t)hsize;
+                if (hashed && (hsize & (hsize - 1u)) == 0u) {
+                    xcd_gather2<true>(tab, hsize, res, sc, xs[0], xs[1], v[0], v[1], p[0], p[1]);
+                    xcd_gather2<true>(tab, hsize, res, sc, xs[2], xs[3], v[2], v[3], p[2], p[3]);
+                } else if (!hashed) {
+                    xcd_gather2<false>(tab, hsize, res, sc, xs[0], xs[1], v[0], v[1], p[0], p[1]);
+                    xcd_gather2<false>(tab, hsize, res, sc, xs[2], xs[3], v[2], v[3], p[2], p[3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) xcd_gather<WITH_JAC>(tab, hsize, res, sc, xs[q], v[q], p[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (ok[q]) xcd_blend_store<WITH_JAC>(v[q], p[q], sc, (int64_t)l * n + ix[q], tmp, tmp_jac);
+            }
+        }
+        return;
+    }
+#endif
+#ifdef IA_HASH_CONTIGUOUS
+    // experiment (round 5): every workgroup owns ONE contiguous range of the slot's (spatially sorted) points and walks it 512 points at
+    // a time -- consecutive iterations of a workgroup are neighbours in space (vector-L1 reuse across iterations) instead of the
+    // grid-stride sweep in which the resident workgroups together cover a window.  Measured: DESIGN 4.3.
+    const int64_t per_wg = ((hi - lo + nchunks - 1) / nchunks + 2 * THREADS - 1) / (2 * THREADS) * (2 * THREADS);
+    const int64_t wlo = lo + chunk * per_wg, whi = (wlo + per_wg < hi) ? wlo + per_wg : hi;
+    const int64_t stride = THREADS;
+    for (int64_t i = wlo + threadIdx.x; i < whi; i += 2 * stride) {
+        const int64_t i2 = i + stride;
+        const int64_t hi = whi;
+#else
     const int64_t stride = nchunks * THREADS;
     // two points per lane and iteration: the gathers of both (16 independent 8-byte loads) are issued before either
     // blend -- the kernel is bound by L2 gather latency x requests in flight, not by bandwidth (L2 hit 0.91)
     for (int64_t i = lo + chunk * THREADS + threadIdx.x; i < hi; i += 2 * stride) {
         const int64_t i2 = i + stride;
+#endif
         const bool two = i2 < hi;
         const int64_t ib = two ? i2 : i;
         const float xa[3] = {__builtin_nontemporal_load(x + i * 3 + 0), __builtin_nontemporal_load(x + i * 3 + 1),
@@ -1137,13 +1192,16 @@ IA_EXPORT int ia_hashgrid_fwd_xcd(int64_t n, const float* x, const float* params
     // slowest level of a pass: per-level cost for 100 M sorted points on the whole device is 1.18 ms (level 5) ... 1.83
     // (level 12) ... 2.42 ms (level 15), 3.47 ms for the five dense levels together = 21.8 ms against 26.9 ms for the passes.
     static const bool by_level = !(getenv("IA_HASH_XCD_PLAN") && getenv("IA_HASH_XCD_PLAN")[0] == 'p');
+    // experiment knob (round 5): hashed levels per launch (default 1).  Two levels per launch read the coordinates half as often and put
+    // 8 MB of tables in front of every XCD's 4 MB L2 -- measured: DESIGN 4.3.
+    static const int lpl = getenv("IA_HASH_LEVELS_PER_LAUNCH") ? max(1, atoi(getenv("IA_HASH_LEVELS_PER_LAUNCH"))) : 1;
     if (by_level) {
-        for (int u = (n_small > 0 ? -1 : 0); u < n_levels - n_small; u++) {
+        for (int u = (n_small > 0 ? -1 : 0); u < n_levels - n_small; u += (u < 0 ? 1 : lpl)) {
             XcdPlan plan;
             plan.straight = 1;
             for (int k = 0; k < 8; k++) {
                 plan.first_level[k] = u < 0 ? 0 : n_small + u;
-                plan.n_level[k] = u < 0 ? n_small : 1;
+                plan.n_level[k] = u < 0 ? n_small : min(lpl, n_levels - n_small - u);
                 plan.part[k] = k; plan.nparts[k] = 8;
             }
             if (dy_dx) hash_fwd_xcd_kernel<true><<<8 * chunks, THREADS, 0, s>>>(n, x, (const float2*)params, c, plan, tmp, tmp_jac);

@@ -518,11 +518,24 @@ constexpr float S2_C = 144.26950408889634f;        // 100 log2(e)
 
 __device__ __forceinline__ float softplus_y_times(float y, float w, float part)      // w = ln2 / 100 * output weight
 {
+#ifdef IA_SOFTPLUS_SKIP
+    // experiment (round 5): skip the two transcendentals when EVERY lane of the wave is saturated (|y| >= 24: 2^-|y| is
+    // below half an ulp of 1, log2(1 + e) = 0 exactly in fp32).  Measured with tools/sdf_head_probe.py -- see DESIGN 4.4.
+    float l = 0.0f;
+    if (__ballot(fabsf(y) < 24.0f) != 0ull) {
+        const float e_ = __builtin_amdgcn_exp2f(-fabsf(y));
+        l = __builtin_amdgcn_logf(1.0f + e_);
+    }
+    float m_;
+    asm("v_max_f32 %0, 0, %1" : "=v"(m_) : "v"(y));
+    return fmaf(m_ + l, w, part);
+#else
     const float e = __builtin_amdgcn_exp2f(-fabsf(y));
     const float l = __builtin_amdgcn_logf(1.0f + e);
     float m;                                                     // max(y, 0): fmaxf() would canonicalise the MFMA result first (2 instructions)
     asm("v_max_f32 %0, 0, %1" : "=v"(m) : "v"(y));
     return fmaf(m + l, w, part);
+#endif
 }
 
 struct S2Rows { float2 q[8]; float v[2]; };
