@@ -103,8 +103,7 @@ def shade_differentiable_phys(rs, material, emitter, rays_o: Tensor, rays_d: Ten
     vf = valid[:, None].float()
     feat = out * vf
     sdf = torch.where(valid, out[:, 0], torch.full_like(out[:, 0], 1e5))
-    dflt_g = torch.zeros((1, 3), device=dev)
-    dflt_g[0, 2] = 1.0
+    dflt_g = torch.nn.functional.pad(torch.ones((1, 1), device=dev), (2, 0))       # [0, 0, 1] without a host -> device scalar copy (a sync)
     sdf_grad = torch.where(valid[:, None], (c2w * grad_c[:, None, :]).sum(-1), dflt_g)
     w2s_rot = dfm.w2s[:3, :3].contiguous()
     normal_smpl, normal_world, refl01 = train._ShadePrep.apply(sdf_grad, rays_d, ray_indices, w2s_rot)
