@@ -87,11 +87,19 @@ constexpr int NBMAX = 1 << MAXB;
 constexpr int CT = 256;                  // threads of the count kernel (same tiles)
 constexpr int CI = TILE / CT;
 
-__device__ __forceinline__ uint32_t morton_key(const float* __restrict__ pts, int64_t i, float ox, float oy, float oz, float inv_cell)
+// raster > 0 (experiment, IA_SORT_RASTER_BITS): the low 3 * raster key bits order the cells of a 2^raster-cube x-fastest (z, y, x)
+// instead of bit-interleaved -- consecutive points then run along x, the direction in which tiny-cuda-nn's hash keeps 16 neighbouring
+// cells in one 128-byte line.  Any bijection of the cell bits is a valid schedule (results do not depend on the order).
+__device__ __forceinline__ uint32_t morton_key(const float* __restrict__ pts, int64_t i, float ox, float oy, float oz, float inv_cell, int raster = 0)
 {
     const float fx = (pts[3 * i] - ox) * inv_cell, fy = (pts[3 * i + 1] - oy) * inv_cell, fz = (pts[3 * i + 2] - oz) * inv_cell;
     const uint32_t x = (uint32_t)fminf(fmaxf(fx, 0.0f), 1023.0f), y = (uint32_t)fminf(fmaxf(fy, 0.0f), 1023.0f),
                    z = (uint32_t)fminf(fmaxf(fz, 0.0f), 1023.0f);
+    if (raster > 0) {
+        const uint32_t m = (1u << raster) - 1u;
+        const uint32_t hi = spread10(x >> raster) | (spread10(y >> raster) << 1) | (spread10(z >> raster) << 2);
+        return (hi << (3 * raster)) | ((z & m) << (2 * raster)) | ((y & m) << raster) | (x & m);
+    }
     return spread10(x) | (spread10(y) << 1) | (spread10(z) << 2);
 }
 
@@ -116,7 +124,7 @@ __device__ __forceinline__ uint64_t digit_peers(uint32_t digit, int bits, bool v
 template <bool FIRST>
 __global__ __launch_bounds__(CT) void radix_count_kernel(int64_t n, const float* __restrict__ pts, float ox, float oy, float oz, float inv_cell,
                                                           uint32_t* __restrict__ keys /* FIRST: out */, const uint2* __restrict__ pairs /* !FIRST: in */,
-                                                          int shift, int bits, int32_t* __restrict__ hist, int ntiles)
+                                                          int shift, int bits, int32_t* __restrict__ hist, int ntiles, int raster)
 {
     __shared__ int32_t s_hist[NBMAX];
     const int nb = 1 << bits;
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(CT) void radix_count_kernel(int64_t n, const float*
             const int64_t i = base + (int64_t)(r0 + r) * CT;
             key[r] = 0;
             if (i < n) {
-                if (FIRST) { key[r] = morton_key(pts, i, ox, oy, oz, inv_cell); keys[i] = key[r]; }
+                if (FIRST) { key[r] = morton_key(pts, i, ox, oy, oz, inv_cell, raster); keys[i] = key[r]; }
                 else key[r] = pairs[i].x;
             }
         }
@@ -436,6 +444,7 @@ IA_EXPORT int ia_morton_order(int64_t n, const float* pts, const float* origin_h
     int32_t* hist = reinterpret_cast<int32_t*>(base + 4 * p.col);
     int32_t* offs = reinterpret_cast<int32_t*>(base + 4 * p.col + p.hist_bytes);
     void* scan_tmp = base + 4 * p.col + 2 * p.hist_bytes;
+    static const int raster = getenv("IA_SORT_RASTER_BITS") ? atoi(getenv("IA_SORT_RASTER_BITS")) : 0;       // experiment knob, see morton_key
     const size_t lds = (size_t)2 * TILE * sizeof(uint32_t);
     // once per process: 64 KB of dynamic LDS per workgroup (above the 48 KB default), and the device check of the atomic ranking
     static std::once_flag once;
@@ -466,9 +475,9 @@ IA_EXPORT int ia_morton_order(int64_t n, const float* pts, const float* origin_h
         const int nb = 1 << p.bits[k];
         if (first)
             radix_count_kernel<true><<<p.ntiles, CT, 0, s>>>(n, pts, origin_host3[0], origin_host3[1], origin_host3[2], inv_cell, keys0, nullptr,
-                                                             p.shift[k], p.bits[k], hist, p.ntiles);
+                                                             p.shift[k], p.bits[k], hist, p.ntiles, raster);
         else
-            radix_count_kernel<false><<<p.ntiles, CT, 0, s>>>(n, nullptr, 0.f, 0.f, 0.f, 0.f, nullptr, pin, p.shift[k], p.bits[k], hist, p.ntiles);
+            radix_count_kernel<false><<<p.ntiles, CT, 0, s>>>(n, nullptr, 0.f, 0.f, 0.f, 0.f, nullptr, pin, p.shift[k], p.bits[k], hist, p.ntiles, 0);
         const int nchunks = (p.ntiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
         int32_t* chunk_sum = reinterpret_cast<int32_t*>(scan_tmp);
         int32_t* chunk_off = chunk_sum + (size_t)NBMAX * nchunks;
