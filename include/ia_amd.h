@@ -279,6 +279,17 @@ int ia_deform_rows_pack(int64_t N, int I, const float* x_rows, const int32_t* cn
                         const int32_t* ovf_head, const void* ovf_scratch, float* cand_x, int32_t* cand_src,
                         const float* norm_center /* NULL or [3] (device) */, const float* norm_scale /* NULL or [3] (device) */,
                         ia_stream_t stream);
+/* the same in the SPLIT layout for the SDF-only queries: every point's first candidate (lowest init) at first_pos[p] + first_tile_off[p / 1024]
+ * (out: first_pos [N] = exclusive count of points that have candidates inside the point's tile of 1024, first_tile_off [ceil(N / 1024)] = the
+ * tiles' offsets; n_first [1], DEVICE: the number of such points), its other candidates from n_first on, point-major -- the two sub-lists are
+ * each spatially coherent in canonical space, which the hash gather that follows needs (a second candidate lies on another body part).
+ * scan_tmp: ia_scan_tmp_bytes(N / 1024 + 1) + 4 (N / 1024 + 1) + 512 bytes.  ia_deform_select_min_split = ia_deform_select_min[_scatter] over
+ * that list (order may be NULL). */
+int ia_deform_rows_pack_split(int64_t N, int I, const float* x_rows, const int32_t* cnt, const uint32_t* meta, const int32_t* start,
+                              const int32_t* ovf_head, const void* ovf_scratch, int32_t* first_pos, int32_t* first_tile_off, int32_t* n_first,
+                              float* cand_x, const float* norm_center, const float* norm_scale, void* scan_tmp, ia_stream_t stream);
+int ia_deform_select_min_split(int64_t P, const int32_t* start, const int32_t* cnt, const int32_t* first_pos, const int32_t* first_tile_off,
+                               const int32_t* n_first, const float* cand_sdf, const int32_t* order, float* sdf, ia_stream_t stream);
 /* diagnostics (no reference counterpart): runs the searches of ia_fuse_broyden without outputs and ACCUMULATES into
  * counters[17] (caller-zeroed): [0] trilinear fetches, [1] in-range corner loads, [2] converged & in-box items,
  * [3] diverged, [4] out of iterations, [5+k] items that ended after k fetches (k = 2..11).  Used by bench.py to price the

@@ -342,6 +342,30 @@ __global__ __launch_bounds__(THREADS) void select_min_kernel(int64_t P, const in
     sdf_out[dst] = best;
 }
 
+// the same over the SPLIT candidate list of ia_deform_rows_pack_split (first candidates at first_pos[p], the others from n_first on)
+__global__ __launch_bounds__(THREADS) void select_min_split_kernel(int64_t P, const int32_t* __restrict__ start, const int32_t* __restrict__ cnt,
+                                                                    const int32_t* __restrict__ first_pos, const int32_t* __restrict__ first_tile_off,
+                                                                    const int32_t* __restrict__ n_first, const float* __restrict__ cand_sdf,
+                                                                    const int32_t* __restrict__ order, float* __restrict__ sdf_out)
+{
+    const int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (p >= P) return;
+    const int c = cnt[p];
+    const int64_t dst = order ? (int64_t)order[p] : p;
+    float best = 1e5f;      // snarf_deformer.py:192
+    if (c > 0) {
+        const int64_t fp = (int64_t)first_pos[p] + first_tile_off[p >> 10];         // tiles of 1024 points (ia_deform_rows_pack_split)
+        const float v0 = cand_sdf[fp];
+        if (v0 < best) best = v0;
+        const int64_t tail = (int64_t)*n_first + ((int64_t)start[p] - fp) - 1;
+        for (int j = 1; j < c; j++) {
+            const float v = cand_sdf[tail + j];
+            if (v < best) best = v;
+        }
+    }
+    sdf_out[dst] = best;
+}
+
 // ---- 4. select ------------------------------------------------------------------
 __global__ __launch_bounds__(THREADS) void select_kernel(
     int64_t P, const int32_t* __restrict__ start, const int32_t* __restrict__ cnt, const float* __restrict__ cand_x,
@@ -679,6 +703,15 @@ IA_EXPORT int ia_deform_select_min(int64_t P, const int32_t* start, const int32_
 }
 
 // the same, for points that were evaluated in another order than the caller's: sdf[order[p]] = min over the candidates of p
+IA_EXPORT int ia_deform_select_min_split(int64_t P, const int32_t* start, const int32_t* cnt, const int32_t* first_pos, const int32_t* first_tile_off,
+                                         const int32_t* n_first, const float* cand_sdf, const int32_t* order, float* sdf, ia_stream_t stream)
+{
+    if (P == 0) return IA_OK;
+    IA_REQUIRE(first_pos != nullptr && first_tile_off != nullptr && n_first != nullptr, "ia_deform_select_min_split: first_pos, first_tile_off and n_first are required");
+    select_min_split_kernel<<<ia::cdiv(P, THREADS), THREADS, 0, (hipStream_t)stream>>>(P, start, cnt, first_pos, first_tile_off, n_first, cand_sdf, order, sdf);
+    return ia::check_launch("ia_deform_select_min_split");
+}
+
 IA_EXPORT int ia_deform_select_min_scatter(int64_t P, const int32_t* start, const int32_t* cnt, const float* cand_sdf,
                                            const int32_t* order, float* sdf, ia_stream_t stream)
 {

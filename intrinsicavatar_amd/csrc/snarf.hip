@@ -1055,12 +1055,20 @@ __global__ __launch_bounds__(THREADS) void rows_flagged_kernel(SpecFlag flag, in
 
 // one lane per point: overflow records first (the chain from the head runs in ascending init order), then the row's candidates,
 // which were stored highest init first; the packed list is in (point, ascending init) order
+constexpr int FIRST_TILE_PACK = 1024;          // = FIRST_TILE (defined with its scan kernel below)
+// SPLIT layout (first_pos / first_tile_off / n_first given; SDF-only queries): a point's FIRST candidate (lowest init) goes to
+// fp = first_pos[p] + first_tile_off[p / 1024] -- the exclusive count of points with candidates -- and its 2nd, 3rd ... to the tail at
+// n_first + (start[p] - fp) + (k - 1).  A second candidate lies
+// on another body part in canonical space; kept between its neighbours' first candidates it costs the hash gather 6 % (tools/cand_order_probe.py):
+// the two sub-lists are each in point order, i.e. each spatially coherent.
 __global__ __launch_bounds__(THREADS) void rows_pack_kernel(int64_t N, int I, const float* __restrict__ x, const int32_t* __restrict__ cnt,
                                                              const uint32_t* __restrict__ meta, const int32_t* __restrict__ start,
                                                              const int32_t* __restrict__ ovf_head, const int32_t* __restrict__ ovf_rec,
                                                              const float* __restrict__ ovf_x, const uint8_t* __restrict__ ovf_keep,
                                                              float* __restrict__ cand_x, int32_t* __restrict__ cand_src,
-                                                             const float* __restrict__ nc, const float* __restrict__ ns)
+                                                             const float* __restrict__ nc, const float* __restrict__ ns,
+                                                             const int32_t* __restrict__ first_pos = nullptr, const int32_t* __restrict__ first_tile_off = nullptr,
+                                                             const int32_t* __restrict__ n_first = nullptr)
 {
     const int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     if (p >= N) return;
@@ -1075,23 +1083,53 @@ __global__ __launch_bounds__(THREADS) void rows_pack_kernel(int64_t N, int I, co
         if (nrm) { a = (a - c0) / s0 + 0.5f; b = (b - c1) / s1 + 0.5f; d = (d - c2) / s2 + 0.5f; }
         cand_x[q_ * 3 + 0] = a; cand_x[q_ * 3 + 1] = b; cand_x[q_ * 3 + 2] = d;
     };
-    int64_t q = start[p];
+    // position of the point's j-th candidate in ascending-init order
+    const int64_t st = start[p];
+    const int64_t fp = first_pos ? (int64_t)first_pos[p] + first_tile_off[p / FIRST_TILE_PACK] : 0, tail = first_pos ? (int64_t)*n_first + (st - fp) - 1 : 0;
+    auto pos = [&](int j) -> int64_t { return first_pos ? (j == 0 ? fp : tail + j) : st + j; };
+    int j = 0;
     const unsigned m = meta[p];
     if (m & 0x80000000u) {
         for (int k = ovf_head[p]; k >= 0; k = ovf_rec[3 * k + 2]) {
             if (!ovf_keep[k]) continue;
+            const int64_t q = pos(j);
             put(q, ovf_x[3 * k], ovf_x[3 * k + 1], ovf_x[3 * k + 2]);
             if (cand_src) cand_src[q] = (int32_t)(p * I + ovf_rec[3 * k + 1]);
-            q++;
+            j++;
         }
-        c -= (int)(q - start[p]);                          // the rest of the point's candidates sit in its row
+        c -= j;                                            // the rest of the point's candidates sit in its row
     }
     const float* row = x + p * (SPEC_ROOTS * 3);
     for (int k = 0; k < c; k++) {
         const int slot = c - 1 - k;
-        put(q + k, row[slot * 3 + 0], row[slot * 3 + 1], row[slot * 3 + 2]);
-        if (cand_src) cand_src[q + k] = (int32_t)(p * I + ((m >> (8 * slot)) & 0xffu));
+        const int64_t q = pos(j + k);
+        put(q, row[slot * 3 + 0], row[slot * 3 + 1], row[slot * 3 + 2]);
+        if (cand_src) cand_src[q] = (int32_t)(p * I + ((m >> (8 * slot)) & 0xffu));
     }
+}
+
+// exclusive count of "has candidates" inside tiles of FIRST_TILE points (first_local) + the tile totals; the tile offsets come from a scan of
+// the (few) totals, and the consumers add them on the fly: position of p's first candidate = first_local[p] + first_tile_off[p / FIRST_TILE]
+constexpr int FIRST_TILE = 1024;
+__global__ __launch_bounds__(256) void first_scan_tiles_kernel(int64_t N, const int32_t* __restrict__ cnt, int32_t* __restrict__ first_local,
+                                                                int32_t* __restrict__ tile_sums)
+{
+    __shared__ int s_w[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * FIRST_TILE + (int64_t)threadIdx.x * 4;
+    int v[4], local = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = (base + k < N && cnt[base + k] > 0) ? 1 : 0; local += v[k]; }
+    int inc = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int run = inc - local;
+    for (int w = 0; w < wave; w++) run += s_w[w];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { if (base + k < N) first_local[base + k] = run; run += v[k]; }
+    if (threadIdx.x == 255) tile_sums[blockIdx.x] = run;
 }
 
 // ---- K8 diagnostics ---------------------------------------------------------------
@@ -1608,6 +1646,34 @@ IA_EXPORT int ia_deform_rows_pack(int64_t N, int I, const float* x_rows, const i
     rows_pack_kernel<<<ia::cdiv(N, THREADS), THREADS, 0, (hipStream_t)stream>>>(N, I, x_rows, cnt, meta, start, ovf_head, o.rec, o.x, o.keep,
                                                                                 cand_x, cand_src, norm_center, norm_scale);
     return ia::check_launch("ia_deform_rows_pack");
+}
+
+// ia_deform_rows_pack in the SPLIT layout (rows_pack_kernel).  Outputs for the reader (ia_deform_select_min_split): first_pos [N] int32 =
+// exclusive count of points that have candidates INSIDE the point's tile of 1024, first_tile_off [ceil(N / 1024)] int32 = the tiles' offsets,
+// n_first [1] int32 (DEVICE) = the number of such points; the first candidate of p sits at first_pos[p] + first_tile_off[p / 1024], its other
+// candidates from n_first on, point-major.  scan_tmp: ia_scan_tmp_bytes(N / 1024 + 1) + 4 (N / 1024 + 1) + 512 bytes.
+IA_EXPORT int ia_deform_rows_pack_split(int64_t N, int I, const float* x_rows, const int32_t* cnt, const uint32_t* meta, const int32_t* start,
+                                        const int32_t* ovf_head, const void* ovf_scratch, int32_t* first_pos, int32_t* first_tile_off,
+                                        int32_t* n_first, float* cand_x, const float* norm_center, const float* norm_scale, void* scan_tmp,
+                                        ia_stream_t stream)
+{
+    if (N == 0) return IA_OK;
+    static_assert(FIRST_TILE == FIRST_TILE_PACK, "one tile size");
+    IA_REQUIRE(cand_x != x_rows, "ia_deform_rows_pack_split: cand_x must not alias x_rows");
+    IA_REQUIRE((norm_center == nullptr) == (norm_scale == nullptr), "ia_deform_rows_pack_split: norm_center and norm_scale go together");
+    IA_REQUIRE(first_pos != nullptr && first_tile_off != nullptr && n_first != nullptr && scan_tmp != nullptr,
+               "ia_deform_rows_pack_split: first_pos, first_tile_off, n_first and scan_tmp are required");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t tiles = (N + FIRST_TILE - 1) / FIRST_TILE;
+    int32_t* sums = reinterpret_cast<int32_t*>(scan_tmp);
+    void* tmp = reinterpret_cast<char*>(scan_tmp) + (((size_t)tiles * 4 + 255) & ~(size_t)255);
+    first_scan_tiles_kernel<<<(int)tiles, 256, 0, s>>>(N, cnt, first_pos, sums);
+    const int r = ia_exclusive_scan_i32(sums, first_tile_off, n_first, tiles, tmp, stream);
+    if (r != IA_OK) return r;
+    OvfLayout o = ovf_layout(const_cast<void*>(ovf_scratch), N);
+    rows_pack_kernel<<<ia::cdiv(N, THREADS), THREADS, 0, s>>>(N, I, x_rows, cnt, meta, start, ovf_head, o.rec, o.x, o.keep, cand_x, nullptr,
+                                                              norm_center, norm_scale, first_pos, first_tile_off, n_first);
+    return ia::check_launch("ia_deform_rows_pack_split");
 }
 
 IA_EXPORT int ia_filter(int64_t N, int I, const float* x, const uint8_t* mask, uint8_t* out, ia_stream_t stream)

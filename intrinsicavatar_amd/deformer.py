@@ -194,13 +194,16 @@ class SNARFDeformer:
 
     @torch.no_grad()
     def _candidates(self, pts: Tensor, with_src: bool, want_fwd: bool = False, want_jinv: bool = False, order: Optional[Tensor] = None,
-                    normalize=None):
+                    normalize=None, split: bool = False):
         """search + candidate bookkeeping for P posed points -> (cand_x [Q,3], cand_src [Q] | None, cnt [P], start [P], Q, fwd_J, J_inv).
         Default (early-filter search): the search kernel itself leaves each point's surviving candidates in its 3-slot row plus their
         count and the scan of the counts (fast_snarf.fuse_broyden_spec_rows: 44 B per point instead of 169) -- no x [P,13,3], no
         is_valid, no K9 pass; one segmented copy makes the packed list.  Points the kernel redid with the filter off (~2e-4) get their
         rows from K9 on all 13 results (rows_flagged_kernel; a 4th.. survivor as an overflow record).  spec_eps = 0: search() + _pack_candidates().
-        normalize = (center [3], scale [3]): cand_x comes back as (x - center) / scale + 0.5 (the hash grid's coordinates)."""
+        normalize = (center [3], scale [3]): cand_x comes back as (x - center) / scale + 0.5 (the hash grid's coordinates).
+        split (SDF-only queries, with_src False): the list comes back in the SPLIT layout of ia_deform_rows_pack_split -- every point's first
+        candidate at first_pos[p], the others from n_first on -- and the tuple ends with (first_pos, n_first); None, None when the batch took
+        another path (the caller then reads the list point-major); first_pos = (in-tile positions [P], tile offsets [ceil(P / 1024)])."""
         P, I = pts.shape[0], self.init_bones.shape[0]
         dev = self.device
         if not (self.SPEC_ROWS and self.spec_eps >= 1e-4 and P >= self.SPEC_MIN_POINTS and self.tfs.shape[0] == 1):
@@ -209,7 +212,8 @@ class SNARFDeformer:
             r = self.search(pts, want_fwd=want_fwd, want_jinv=want_jinv)
             x, valid, fwd = r[0], r[1], r[2]
             J_inv = r[3] if want_jinv else None
-            return self._normalized((*self._pack_candidates(x, valid, with_src=with_src), fwd, J_inv), normalize)
+            res = self._normalized((*self._pack_candidates(x, valid, with_src=with_src), fwd, J_inv), normalize)
+            return res + (None, None) if split else res
         lib, st = L.lib(), L.stream()
         x_rows = torch.empty((P, 3, 3), device=dev)
         Jinv = torch.empty((1, P, I, 3, 3), device=dev) if want_jinv else None
@@ -236,17 +240,31 @@ class SNARFDeformer:
             if order is not None:
                 pts = pts[order.long()].contiguous()
             r = self.search(pts, want_fwd=want_fwd, want_jinv=want_jinv)
-            return self._normalized((*self._pack_candidates(r[0], r[1], with_src=with_src), r[2], (r[3] if want_jinv else None)), normalize)
+            res = self._normalized((*self._pack_candidates(r[0], r[1], with_src=with_src), r[2], (r[3] if want_jinv else None)), normalize)
+            return res + (None, None) if split else res
         if self.spec_canary > 0:
             self._canary(pts, order, x_rows, cnt, meta)
         cand_x = torch.empty((Q, 3), device=dev)
+        if split and not with_src and not want_fwd and not want_jinv and self.SPLIT_CANDIDATES:
+            tiles = (P + 1023) // 1024
+            first_pos = torch.empty(P, dtype=torch.int32, device=dev)
+            tile_off_n = torch.empty(tiles + 1, dtype=torch.int32, device=dev)         # [tiles] offsets + [1] n_first
+            L.check(lib.ia_deform_rows_pack_split(L.i64(P), L.i32(I), L.ptr(x_rows), L.ptr(cnt), L.ptr(meta), L.ptr(start), L.ptr(ovf_head),
+                                                  L.ptr(ovf_scratch), L.ptr(first_pos), L.ptr(tile_off_n), L.ptr(tile_off_n[tiles:]), L.ptr(cand_x),
+                                                  L.ptr(normalize[0].contiguous().float() if normalize else None),
+                                                  L.ptr(normalize[1].contiguous().float() if normalize else None),
+                                                  L.ptr(L.scan_tmp(tiles + 1, dev, extra_bytes=4 * tiles + 1024)), st), "ia_deform_rows_pack_split")
+            return cand_x, None, cnt, start, Q, None, None, (first_pos, tile_off_n[:tiles]), tile_off_n[tiles:]
         cand_src = torch.empty(Q, dtype=torch.int32, device=dev) if with_src else None
         L.check(lib.ia_deform_rows_pack(L.i64(P), L.i32(I), L.ptr(x_rows), L.ptr(cnt), L.ptr(meta), L.ptr(start), L.ptr(ovf_head),
                                         L.ptr(ovf_scratch), L.ptr(cand_x), L.ptr(cand_src),
                                         L.ptr(normalize[0].contiguous().float() if normalize else None),
                                         L.ptr(normalize[1].contiguous().float() if normalize else None), st), "ia_deform_rows_pack")
-        return cand_x, cand_src, cnt, start, Q, (fwd[0] if want_fwd else None), (Jinv[0] if want_jinv else None)
+        res = (cand_x, cand_src, cnt, start, Q, (fwd[0] if want_fwd else None), (Jinv[0] if want_jinv else None))
+        return res + (None, None) if split else res
 
+    # the SDF-only queries gather their candidates in the split layout (first candidates, then the rest: -6 % in the hash gather)
+    SPLIT_CANDIDATES = os.environ.get("IA_SPLIT_CANDIDATES", "1") == "1"
     SPEC_CANARY = int(os.environ.get("IA_SPEC_CANARY", "0"))
 
     @torch.no_grad()
@@ -322,10 +340,14 @@ class SNARFDeformer:
         dev = self.device
         lib, st = L.lib(), L.stream()
         # the candidates leave the packing kernel in the hash grid's coordinates (three elementwise passes over [Q,3] less)
-        cand_x, _, cnt, start, Q, _, _ = self._candidates(pts, with_src=False, order=order, normalize=(geometry.center, geometry.scale))
+        cand_x, _, cnt, start, Q, _, _, first_pos, n_first = self._candidates(pts, with_src=False, order=order,
+                                                                             normalize=(geometry.center, geometry.scale), split=True)
         csdf = geometry.sdf_only(cand_x, normalized=True)
         sdf = torch.empty(P, device=dev)
-        if order is not None:         # pts = caller's points[order]: the result goes back to the caller's order on the way out
+        if first_pos is not None:     # split layout: first candidates at first_pos, the others from n_first on
+            L.check(lib.ia_deform_select_min_split(L.i64(P), L.ptr(start), L.ptr(cnt), L.ptr(first_pos[0]), L.ptr(first_pos[1]), L.ptr(n_first),
+                                                   L.ptr(csdf), L.ptr(order), L.ptr(sdf), st), "ia_deform_select_min_split")
+        elif order is not None:         # pts = caller's points[order]: the result goes back to the caller's order on the way out
             L.check(lib.ia_deform_select_min_scatter(L.i64(P), L.ptr(start), L.ptr(cnt), L.ptr(csdf), L.ptr(order), L.ptr(sdf), st),
                     "ia_deform_select_min_scatter")
         else:

@@ -350,3 +350,35 @@ def test_overflow_scratch_of_the_wrong_size_is_refused(march):
         fast_snarf.fuse_broyden_spec_rows(torch.empty((P, 3, 3), device=DEV), sub[None], fast_snarf.ChannelLastVoxelJ(dfm.voxel_J_cl), dfm.tfs,
                                           dfm.init_bones, None, i32(), i32(), i32(), i32(), small, torch.empty(2, dtype=torch.int32, device=DEV),
                                           dfm.offset_kernel, dfm.scale_kernel, 1e-5, 1e-1, 1e-3)
+
+
+def test_split_candidate_layout_gives_the_same_sdf_and_the_same_candidates(march):
+    """SDF-only queries gather their candidates in the split layout (ia_deform_rows_pack_split: first candidates in point order, the others
+    after them) because a point's second candidate lies on another body part (-6 % in the hash gather).  Same candidates, same min-SDF, bit
+    for bit, with and without the spatial permutation; points with a 4th survivor (overflow records) included."""
+    SP, rs, pts, _ = march
+    dfm, geo = rs.deformer, rs.geometry
+    order = torch.randperm(pts.shape[0], device=DEV).to(torch.int32)
+    cls = type(dfm)
+    try:
+        cls.SPLIT_CANDIDATES = False
+        want = dfm.deform_sdf(pts, geo)
+        want_o = dfm.deform_sdf(pts, geo, order=order)
+        a = dfm._candidates(pts, with_src=False)
+        cls.SPLIT_CANDIDATES = True
+        got = dfm.deform_sdf(pts, geo)
+        got_o = dfm.deform_sdf(pts, geo, order=order)
+        b = dfm._candidates(pts, with_src=False, split=True)
+    finally:
+        cls.SPLIT_CANDIDATES = True
+    assert torch.equal(got, want) and torch.equal(got_o, want_o) and torch.equal(want, want_o)
+    cand_a, cnt, start, Q = a[0], a[2], a[3], a[4]
+    cand_b, n_first = b[0], int(b[8])
+    first_pos = b[7][0] + b[7][1][torch.arange(pts.shape[0], device=DEV) // 1024]
+    assert b[4] == Q and n_first == int((cnt > 0).sum()) and int(cnt.max()) >= 3
+    has = cnt > 0
+    assert torch.equal(cand_b[first_pos[has].long()], cand_a[start[has].long()])                      # first candidates
+    more = torch.nonzero(cnt > 1)[:, 0]
+    tail = n_first + (start[more] - first_pos[more]).long()
+    assert torch.equal(cand_b[tail], cand_a[start[more].long() + 1])                                   # second candidates
+    assert torch.equal(torch.sort(cand_b.reshape(-1))[0], torch.sort(cand_a.reshape(-1))[0])           # the same multiset
