@@ -146,6 +146,57 @@ def build_headline(dev, hw, spp, rank, pose):
     return rs, rays, export, mat, sg
 
 
+def measure_config4(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, steps=10):
+    """the reference's own training batch (BASELINE configs[3]; configs/sampler/edge.yaml:2, configs/config.yaml: uniform_light, spp 512):
+    n_batch rays on the subject of the bench frame, RenderStep.forward_backward_phys + the fused Adam step.  Returns the line's `config4`
+    object: ms per step, rays/s, and the search launches of one step (points, ms) -- the step's one large search batch is its secondary
+    march (~2 100 march points per ray), not the 4096 rays' own samples."""
+    from intrinsicavatar_amd import _lib as L, optim, pbr
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        hit = torch.nonzero(rs.forward(rays)["opacity"][:, 0] > 0.5)[:, 0]          # pixels on the subject, like the trainer's fg sampler
+    sel = hit[torch.randint(0, hit.shape[0], (n_batch,), generator=g).to(dev)]
+    batch = rays[sel].contiguous()
+    target = torch.rand((n_batch, 3), generator=g).to(dev)
+    tmask = torch.ones(n_batch, device=dev)
+    light_u = torch.rand((spp, 3), generator=g).to(dev)             # uniform_light: one stratified direction set per step (intrinsic_avatar.py:1392-1400)
+    shuffle_u = torch.rand((n_batch, spp), generator=g).to(dev)     # the per-ray spp shuffle
+    params = rs.parameters() + [p for p in mat.parameters() if p.requires_grad] + list(sg.parameters())
+    opt, sched = optim.reference_optimizer(rs, material=mat, emitter=sg)
+
+    def s4():
+        for p in params:
+            p.grad = None
+        img = sg.generate_image()
+        leaf = img.detach().requires_grad_(True)
+        emitter = pbr.EnvironmentLightTensor(leaf.detach())
+        emitter.update_pdf()
+        o = rs.forward_backward_phys(batch, target, mat, emitter, spp, light_u, shuffle_u, target_mask=tmask, render_mode="uniform_light",
+                                     env_base=leaf, background_color=bg)
+        if leaf.grad is not None:
+            img.backward(leaf.grad)
+        opt.step()
+        sched.step()
+        return o
+    for _ in range(3):
+        o = s4()
+    torch.cuda.synchronize()
+    tc = time.perf_counter()
+    for _ in range(steps):
+        o = s4()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - tc) / steps * 1e3
+    lib = L.lib()
+    lib.start()
+    o = s4()
+    det = lib.report(detail=True)
+    search = [(round(c[0], 3), int(c[1])) for k in ("ia_fuse_broyden_spec_rows", "ia_fuse_broyden") for c in det.get(k, [])]
+    return dict(workload=f"{n_batch} rays on the subject of the bench frame, PBR training step (uniform_light, spp {spp}), fwd+bwd+Adam",
+                ms_per_step=round(ms, 3), rays_per_s=round(n_batch / (ms * 1e-3), 1), secondary_rays_per_step=int(o["stats"]["n_secondary"]),
+                kernel_ms_per_step=round(sum(c[0] for v in det.values() for c in v), 3),
+                search_launches_ms_points=search)
+
+
 def main():
     if os.environ.get("IA_SWITCH_INTERVAL"):          # experiment: the interpreter's thread switch interval (two host threads feed two streams)
         sys.setswitchinterval(float(os.environ["IA_SWITCH_INTERVAL"]))
@@ -162,6 +213,7 @@ def main():
                          "aist:{0,100,200,319} (animation, out of distribution), or synthetic:K (N(0, 0.25) joint angles, rounds 1-2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config2", action="store_true", help="skip the secondary configs[1] measurement of the headline line")
+    ap.add_argument("--no-config4", action="store_true", help="skip the 4096-ray training-batch measurement (configs[3] shape) of the headline line")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the instrumented repeat (profiling runs)")
     ap.add_argument("--no-search-modes", action="store_true", help="skip the search-to-the-end timing / comparison of the deformer search")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd only (no Adam step)")
@@ -500,6 +552,12 @@ def main():
         torch.cuda.synchronize()
         config2 = (time.perf_counter() - tc) / 10 * 1e3
 
+    # ---- third key: BASELINE configs[3] shape = the reference's OWN training batch (configs/sampler/edge.yaml:2: 4096 rays per step
+    # and GPU; PBR branch, render_mode=uniform_light, spp 512, fwd + bwd + Adam), rays drawn on the subject of the same frame
+    config4 = None
+    if headline and rank == 0 and world == 1 and not args.no_config4:
+        config4 = measure_config4(rs, rays, mat, sg, dev, bg)
+
     if rank == 0:
         stats = dict(out["stats"])
         stats["n_rays"] = n_rays
@@ -651,6 +709,7 @@ def main():
             "ms_per_step_instrumented": round(dt_instr / max(k_instr, 1) * 1e3, 3),
             "abi_kernel_ms_per_step": round(total_ms / max(k_instr, 1), 3),
             "secondary_rays_per_s": (round(world * stats.get("n_secondary", 0) * args.steps / dt, 1) if headline else None),
+            "config4": config4,
             "config2_ms_per_step": (round(config2, 3) if config2 else None),
             "config2_rays_per_s": (round(n_rays / (config2 * 1e-3), 1) if config2 else None),
         }

@@ -805,7 +805,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
         float Jl[12];
         grid_sample_J<IA_LAYOUT_NDHWC, true>(voxel_J, 0, D, H, W, ix, iy, iz, Jl);
 #ifdef IA_SPEC_DIAG_ITERS       /* diagnostic build: counters[4] = lane-slots of the fetch iterations (64 per wave iteration that fetched) */
-        if (COUNT) { c_fetch++; c_corner += 64u / (unsigned)__popcll(__ballot(1)); }
+        if (COUNT) { c_fetch++; c_corner += (__ffsll((long long)__ballot(1)) - 1 == lane) ? 64u : 0u; }      // exact: one lane of the wave adds the 64 slots
 #else
         if (COUNT) { c_fetch++; c_corner += in_range_corner_count(ix, iy, iz, D, H, W); }
 #endif
@@ -1539,8 +1539,13 @@ static int launch_spec(bool pack, int64_t N, int I, const float* xd_tgt, const f
     unsigned long long* c = reinterpret_cast<unsigned long long*>(counters);
     int slots = SPEC_ROOTS;                                              // test hook: fewer recorded roots / row slots => more points take the exact redo
     if (const char* e = getenv("IA_SPEC_TEST_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= SPEC_ROOTS) slots = v; }
+    // IA_BR_SPEC_PAD_LDS = bytes of (unused) dynamic LDS added to the launch: 31.5 KB of static LDS let five workgroups share a CU's 160 KB;
+    // 8 KB more make it four (96 VGPRs x 4 waves per SIMD: 128 VGPRs per SIMD stay free for ONE wave of another stream's kernel that
+    // needs no LDS -- the hash gather, 104 VGPRs).  Used with the search token of deformer.py (one search on the device at a time).
+    static int pad_lds = -1;
+    if (pad_lds < 0) { const char* e = getenv("IA_BR_SPEC_PAD_LDS"); const int v = e ? atoi(e) : 0; pad_lds = (v > 0 && v <= 32768) ? v : 0; }
 #define IA_SPEC_LAUNCH(COUNT, PACK)                                                                                                    \
-    broyden_spec_kernel<COUNT, PACK><<<grid, THREADS, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,         \
+    broyden_spec_kernel<COUNT, PACK><<<grid, THREADS, pad_lds, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,   \
                                                                cvg_threshold, dvg_threshold, eps, x, J_inv, is_valid, fwd_J, pts, c, cnt, \
                                                                meta, flag, slots, order, cell_tight)
     if (pack && !counters && wg_env != THREADS) {

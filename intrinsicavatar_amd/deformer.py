@@ -191,6 +191,10 @@ class SNARFDeformer:
         return cand_x, cand_src, cnt, start, Q
 
     SPEC_ROWS = os.environ.get("IA_BROYDEN_SPEC_ROWS", "1") == "1"
+    SEARCH_TOKEN = os.environ.get("IA_SEARCH_TOKEN", "0") == "1"
+    SEARCH_TOKEN_MIN_POINTS = int(os.environ.get("IA_SEARCH_TOKEN_MIN_POINTS", str(1 << 22)))
+    _search_lock = __import__("threading").Lock()
+    _search_event = None
 
     @torch.no_grad()
     def _candidates(self, pts: Tensor, with_src: bool, want_fwd: bool = False, want_jinv: bool = False, order: Optional[Tensor] = None,
@@ -224,10 +228,26 @@ class SNARFDeformer:
         ovf_scratch = L.scratch("spec_rows", int(lib.ia_spec_rows_overflow_bytes(L.i64(P))), dev)
         ovf_cap = self._tls.ovf_cap = int(lib.ia_spec_rows_overflow_capacity(L.i64(P)))
         tot = torch.empty(2, dtype=torch.int32, device=dev)
-        fast_snarf.fuse_broyden_spec_rows(x_rows, pts.reshape(1, P, 3), fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs, self.init_bones,
-                                          Jinv, cnt, meta, start, ovf_head, ovf_scratch, tot, self.offset_kernel, self.scale_kernel,
-                                          1e-5, 1e-1, self.spec_eps, fwd_J=fwd, counters=self.spec_counters, order=order,
-                                          cell_tight=self.cell_tight)
+        # IA_SEARCH_TOKEN=1 (experiment, measured without effect -- DESIGN 4.5): one search on the DEVICE at a time; this stream's search
+        # starts when the previous search of any stream has finished, so that a search shares the device with another stream's gather /
+        # head kernels instead of with another search
+        token = self.SEARCH_TOKEN and P >= self.SEARCH_TOKEN_MIN_POINTS
+        if token:
+            self._search_lock.acquire()
+        try:
+            if token and self._search_event is not None:
+                torch.cuda.current_stream(dev).wait_event(self._search_event)
+            fast_snarf.fuse_broyden_spec_rows(x_rows, pts.reshape(1, P, 3), fast_snarf.ChannelLastVoxelJ(self.voxel_J_cl), self.tfs, self.init_bones,
+                                              Jinv, cnt, meta, start, ovf_head, ovf_scratch, tot, self.offset_kernel, self.scale_kernel,
+                                              1e-5, 1e-1, self.spec_eps, fwd_J=fwd, counters=self.spec_counters, order=order,
+                                              cell_tight=self.cell_tight)
+            if token:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                type(self)._search_event = ev
+        finally:
+            if token:
+                self._search_lock.release()
         Q, n_over = tot.tolist()                                     # the one read-back of the call
         self._tls.n_over = n_over                                    # points the kernel searched again with the filter off
         self._check_voxels()
