@@ -350,6 +350,52 @@ __global__ __launch_bounds__(THREADS) void hash_fwd_xcd_kernel(int64_t n, const 
         const int64_t i2 = i + stride;
         const int64_t hi = whi;
 #else
+#ifdef IA_HASH_PREFETCH
+    // experiment (round 5): the NEXT iteration's coordinates are requested while this iteration's gathers are in flight -- an iteration
+    // was "coordinates (HBM stream, non-temporal) -> wait -> 16 gathers -> wait -> blend": two memory latencies in series on a kernel
+    // that is bound by latency x requests in flight.  111 VGPRs before, 4 waves per SIMD up to 128.  Measured: DESIGN 4.3.
+    {
+        const int64_t stride = nchunks * THREADS;
+        int64_t i = lo + chunk * THREADS + threadIdx.x;
+        if (i >= hi) return;
+        float xa[3], xb[3];
+        {
+            const int64_t ib0 = (i + stride < hi) ? i + stride : i;
+#pragma unroll
+            for (int d = 0; d < 3; d++) { xa[d] = __builtin_nontemporal_load(x + i * 3 + d); xb[d] = __builtin_nontemporal_load(x + ib0 * 3 + d); }
+        }
+        for (; i < hi; i += 2 * stride) {
+            const int64_t i2 = i + stride;
+            const bool two = i2 < hi;
+            const int64_t in = i + 2 * stride;
+            const int64_t ja = in < hi ? in : i, jb = (in + stride < hi) ? in + stride : ja;
+            float na[3], nb[3];
+            // issued IN FRONT of the gathers: both requests are in flight together (max of the two latencies instead of their sum)
+#pragma unroll
+            for (int d = 0; d < 3; d++) { na[d] = __builtin_nontemporal_load(x + ja * 3 + d); nb[d] = __builtin_nontemporal_load(x + jb * 3 + d); }
+            for (int l = plan.first_level[slot]; l < plan.first_level[slot] + plan.n_level[slot]; l++) {
+                const float sc = cfg.scale[l];
+                const uint32_t res = cfg.res[l], hsize = cfg.offsets[l + 1] - cfg.offsets[l];
+                const float2* tab = params + cfg.offsets[l];
+                float2 va[8], vb[8];
+                float pa[3], pb[3];
+                const uint64_t r64 = res;
+                const bool hashed = r64 * r64 * r64 > (uint64_t)hsize;
+                if (plan.straight && hashed && (hsize & (hsize - 1u)) == 0u) xcd_gather2<true>(tab, hsize, res, sc, xa, xb, va, vb, pa, pb);
+                else if (plan.straight && !hashed) xcd_gather2<false>(tab, hsize, res, sc, xa, xb, va, vb, pa, pb);
+                else {
+                    xcd_gather<WITH_JAC>(tab, hsize, res, sc, xa, va, pa);
+                    xcd_gather<WITH_JAC>(tab, hsize, res, sc, xb, vb, pb);
+                }
+                xcd_blend_store<WITH_JAC>(va, pa, sc, (int64_t)l * n + i, tmp, tmp_jac);
+                if (two) xcd_blend_store<WITH_JAC>(vb, pb, sc, (int64_t)l * n + i2, tmp, tmp_jac);
+            }
+#pragma unroll
+            for (int d = 0; d < 3; d++) { xa[d] = na[d]; xb[d] = nb[d]; }
+        }
+        return;
+    }
+#endif
     const int64_t stride = nchunks * THREADS;
     // two points per lane and iteration: the gathers of both (16 independent 8-byte loads) are issued before either
     // blend -- the kernel is bound by L2 gather latency x requests in flight, not by bandwidth (L2 hit 0.91)

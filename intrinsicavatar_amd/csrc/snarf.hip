@@ -617,6 +617,11 @@ __device__ __forceinline__ unsigned in_range_corner_count(float gx, float gy, fl
     return cx * cy * cz;
 }
 
+#ifdef IA_SPEC_DIAG_CELLS
+#define IA_DIAG_CELLS_ON 1
+#else
+#define IA_DIAG_CELLS_ON 0
+#endif
 constexpr int SPEC_ROOTS = 3;              // recorded roots per point (survivors per point average 1.2; a 4th sends the point to the exact redo)
 #ifndef IA_SPEC_TAU                        // (-D overrides: rule sweeps through tools/ab_build.sh)
 #define IA_SPEC_TAU 2.5f
@@ -794,7 +799,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
                     at_root = at_root | ((x_l[0] >= l0) & (x_l[0] < h0) & (x_l[1] >= l1) & (x_l[1] < h1) & (x_l[2] >= l2) & (x_l[2] < h2));
                 }
             }
-            if (at_root) { if (!PACK) is_valid[index] = 0; if (COUNT) c_retired++; next = true; }
+            if (at_root) { if (!PACK) is_valid[index] = 0; if (COUNT && !IA_DIAG_CELLS_ON) c_retired++; next = true; }
         }
         // a lane retired here sits this fetch out (it starts its next search in the next iteration)
         if (next) continue;
@@ -806,6 +811,20 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
         grid_sample_J<IA_LAYOUT_NDHWC, true>(voxel_J, 0, D, H, W, ix, iy, iz, Jl);
 #ifdef IA_SPEC_DIAG_ITERS       /* diagnostic build: counters[4] = lane-slots of the fetch iterations (64 per wave iteration that fetched) */
         if (COUNT) { c_fetch++; c_corner += (__ffsll((long long)__ballot(1)) - 1 == lane) ? 64u : 0u; }      // exact: one lane of the wave adds the 64 slots
+#ifdef IA_SPEC_DIAG_CELLS       /* counters[1] = fetches in the voxel cell of the wave's first active lane, counters[2] = ... of the first lane outside that cell */
+        if (COUNT) {
+            const float fx_ = ((ix + 1.f) / 2) * (W - 1), fy_ = ((iy + 1.f) / 2) * (H - 1), fz_ = ((iz + 1.f) / 2) * (D - 1);
+            const bool fin = fabsf(fx_) < 1e6f && fabsf(fy_) < 1e6f && fabsf(fz_) < 1e6f;
+            const int cell = fin ? (((int)floorf(fz_) + 512) << 20) | (((int)floorf(fy_) + 512) << 10) | ((int)floorf(fx_) + 512) : -1 - lane;
+            const int lead = __builtin_amdgcn_readfirstlane(cell);
+            const unsigned long long rest = __ballot(cell != lead);
+            c_retired += (cell == lead) ? 1u : 0u;
+            if (rest) {
+                const int second = __shfl(cell, __ffsll((long long)rest) - 1, 64);
+                c_valid += (cell == second) ? 1u : 0u;
+            }
+        }
+#endif
 #else
         if (COUNT) { c_fetch++; c_corner += in_range_corner_count(ix, iy, iz, D, H, W); }
 #endif
@@ -830,7 +849,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
                 const bool ok = ix >= -1 && ix <= 1 && iy >= -1 && iy <= 1 && iz >= -1 && iz <= 1;
                 if (!PACK) is_valid[index] = ok ? 1 : 0;
                 if (ok) {
-                    if (COUNT) c_valid++;
+                    if (COUNT && !IA_DIAG_CELLS_ON) c_valid++;
                     if (!PACK) { x[index * 3 + 0] = x_l[0]; x[index * 3 + 1] = x_l[1]; x[index * 3 + 2] = x_l[2]; }
                     if (J_inv) {
                         float* Jo = J_inv + index * 9;
@@ -979,7 +998,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
         if (near) {
             const float jn2 = fmaf(Ji[8], Ji[8], fmaf(Ji[7], Ji[7], fmaf(Ji[6], Ji[6], fmaf(Ji[5], Ji[5], fmaf(Ji[4], Ji[4],
                               fmaf(Ji[3], Ji[3], fmaf(Ji[2], Ji[2], fmaf(Ji[1], Ji[1], Ji[0] * Ji[0]))))))));
-            if (jn2 <= SPEC_TAU_SELF * SPEC_TAU_SELF) { if (!PACK) is_valid[index] = 0; if (COUNT) c_retired++; next = true; }
+            if (jn2 <= SPEC_TAU_SELF * SPEC_TAU_SELF) { if (!PACK) is_valid[index] = 0; if (COUNT && !IA_DIAG_CELLS_ON) c_retired++; next = true; }
         }
     }
     if (COUNT) {
