@@ -262,12 +262,16 @@ int ia_fuse_broyden_spec(int64_t N, int I, const float* xd_tgt /*[N,3]*/, const 
  * ia_spec_rows_overflow_capacity(N) results were lost: redo the batch with ia_fuse_broyden_spec + K9.
  * 44 bytes per point leave the kernel instead of 169 (x [N,I,3] + is_valid).  J_inv / fwd_J (optional) are written at
  * [point, init] as in ia_fuse_broyden.  scan_tmp: ia_scan_tmp_bytes(N) bytes.
+ * SMALL batches (N <= IA_BR_SMALL_MAX, default 2^18 = the list's minimum capacity; the reference's 4096-ray training batches,
+ * configs/sampler/edge.yaml:2): one lane per (point, init) search, every search run to its end (fuse_cuda_kernel_fast.cu:252-452 as
+ * written), all N points through the list of redone points and K9 applied literally (filter.cu:10-54) -- the 13 searches of a point
+ * side by side instead of one after the other in one lane; same outputs ([1] = 0 then).
  * ia_deform_rows_pack: cand_x [Q,3] (+ cand_src [Q] = point * I + init, optional) in (point, ascending init) order; with
  * norm_center / norm_scale the candidates leave as the hash grid's unit-cube coordinates (x - center) / scale + 0.5 (the three
  * elementwise passes of models/rf/geometry.py:155 `(points - self.center) / self.scale + 0.5` done on the way out; same IEEE
  * operations, same bits). */
 int ia_spec_rows_slots(void);
-size_t ia_spec_rows_overflow_bytes(int64_t N);        /* scratch of a call on N points: overflow records + the list of redone points (N / 64, at least 65536) */
+size_t ia_spec_rows_overflow_bytes(int64_t N);        /* scratch of a call on N points: overflow records + the list of redone points (N / 64, at least 2^18) */
 int64_t ia_spec_rows_overflow_capacity(int64_t N);   /* points of a call on N points that can be redone */
 int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, const float* voxel_J_cl, int D, int H, int W, const float* tfs,
                               const int32_t* bone_ids, const float* offset, const float* scale, float cvg_threshold,

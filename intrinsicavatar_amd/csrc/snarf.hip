@@ -633,7 +633,8 @@ constexpr float SPEC_TAU = IA_SPEC_TAU;           // a root is tight when |J_inv
 constexpr float SPEC_TAU_SELF = IA_SPEC_TAU_SELF; // a search may be retired while its own |J_inv|_F <= SPEC_TAU_SELF
 constexpr float SPEC_CELL_MARGIN = 4e-6f;  // the cell box of a root is shrunk by this much (canonical metres) on every side
 // points per launch that can be redone exactly (1.4e-4 .. 1.8e-4 of the points are on the march distributions; the list holds 1 / 64 of a batch)
-static inline int64_t spec_flag_cap(int64_t N) { const int64_t c = N >> 6; return c < (1 << 16) ? (1 << 16) : c; }
+// (at least 2^18 records, 52 MB: a SMALL batch -- broyden_items_rows_kernel below -- sends every point through the list)
+static inline int64_t spec_flag_cap(int64_t N) { const int64_t c = N >> 6; return c < (1 << 18) ? (1 << 18) : c; }
 
 // flagged points: the 13 results of the exact redo, for rows_flagged_kernel
 struct SpecFlag {
@@ -1024,6 +1025,92 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(IA_BR2_WAVES
 #undef n_done
 #undef inits
 #undef flag_rec
+
+// ---- small batches: all 13 searches of a point side by side ----------------------------------------------------------------
+// broyden_spec_kernel walks the 13 inits of a point one after the other in ONE lane (that order is what lets it retire duplicates);
+// a batch of fewer points than the device has lanes (the reference's 4096-ray training batches: 50 .. 200 k sample points per call)
+// then takes as long as its slowest point -- ~100 dependent fetches, 0.4 ms -- however few points there are.  Here one lane owns one
+// (point, init) item and runs the exact search to its end (the operation sequence of broyden_kernel, channel-last grid, x-pair loads),
+// the results go straight into the flagged list -- record p = point p, all N points -- and rows_flagged_kernel applies K9 literally
+// (filter.cu:10-54) and fills rows / cnt / meta / overflow records exactly as it does for the points the early filter hands over.
+// Same candidates as the early-filter search wherever that search is K9-consistent (everywhere measured); by construction the
+// reference's semantics.  B == 1.
+__global__ __launch_bounds__(THREADS) void broyden_items_rows_kernel(
+    int64_t N, int I, const float* __restrict__ xd_tgt, const float* __restrict__ voxel_J, int D, int H, int W,
+    const float* __restrict__ tfs, const int32_t* __restrict__ bone_ids, const float* __restrict__ offset_g,
+    const float* __restrict__ scale_g, float cvg_threshold, float dvg_threshold, float* __restrict__ J_inv, float* __restrict__ fwd_J,
+    SpecFlag flag, const int32_t* __restrict__ order)
+{
+    const int64_t index = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (index == 0) *flag.count = (int32_t)N;
+    if (index >= N * I) return;
+    const int64_t p = index / I;
+    const int i_init = (int)(index - p * I);
+    if (i_init == 0) flag.point[p] = (int32_t)p;
+    const float offset[3] = {offset_g[0], offset_g[1], offset_g[2]};
+    const float scale[3] = {scale_g[0], scale_g[1], scale_g[2]};
+    const int64_t src = order ? (int64_t)order[p] : p;
+    float gx[3], gx_new[3] = {0, 0, 0}, xt[3], x_l[3];
+    xt[0] = xd_tgt[src * 3 + 0]; xt[1] = xd_tgt[src * 3 + 1]; xt[2] = xd_tgt[src * 3 + 2];
+    const float* T = tfs + (int64_t)bone_ids[i_init] * 16;
+    const float ixd = xt[0] - T[0 * 4 + 3], iyd = xt[1] - T[1 * 4 + 3], izd = xt[2] - T[2 * 4 + 3];
+    x_l[0] = ixd * T[0 * 4 + 0] + iyd * T[1 * 4 + 0] + izd * T[2 * 4 + 0];
+    x_l[1] = ixd * T[0 * 4 + 1] + iyd * T[1 * 4 + 1] + izd * T[2 * 4 + 1];
+    x_l[2] = ixd * T[0 * 4 + 2] + iyd * T[1 * 4 + 2] + izd * T[2 * 4 + 2];
+    float Jl[12];
+    grid_sample_J<IA_LAYOUT_NDHWC, true>(voxel_J, 0, D, H, W, scale[0] * (x_l[0] + offset[0]), scale[1] * (x_l[1] + offset[1]),
+                                         scale[2] * (x_l[2] + offset[2]), Jl);
+    float Ji[9];
+    Ji[0] = Jl[0]; Ji[3] = Jl[1]; Ji[6] = Jl[2];
+    Ji[1] = Jl[4]; Ji[4] = Jl[5]; Ji[7] = Jl[6];
+    Ji[2] = Jl[8]; Ji[5] = Jl[9]; Ji[8] = Jl[10];
+    for (int it = 0; it < 10; it++) {
+        const float J00 = Ji[0], J01 = Ji[1], J02 = Ji[2], J10 = Ji[3], J11 = Ji[4], J12 = Ji[5], J20 = Ji[6], J21 = Ji[7], J22 = Ji[8];
+        if (it == 0) {
+            gx[0] = Jl[0] * x_l[0] + Jl[1] * x_l[1] + Jl[2] * x_l[2] + Jl[3];
+            gx[1] = Jl[4] * x_l[0] + Jl[5] * x_l[1] + Jl[6] * x_l[2] + Jl[7];
+            gx[2] = Jl[8] * x_l[0] + Jl[9] * x_l[1] + Jl[10] * x_l[2] + Jl[11];
+            gx[0] = gx[0] - xt[0]; gx[1] = gx[1] - xt[1]; gx[2] = gx[2] - xt[2];
+        } else {
+            gx[0] = gx_new[0]; gx[1] = gx_new[1]; gx[2] = gx_new[2];
+        }
+        const float u0 = -J00 * gx[0] + -J01 * gx[1] + -J02 * gx[2];
+        const float u1 = -J10 * gx[0] + -J11 * gx[1] + -J12 * gx[2];
+        const float u2 = -J20 * gx[0] + -J21 * gx[1] + -J22 * gx[2];
+        x_l[0] += u0; x_l[1] += u1; x_l[2] += u2;
+        const float ix = scale[0] * (x_l[0] + offset[0]);
+        const float iy = scale[1] * (x_l[1] + offset[1]);
+        const float iz = scale[2] * (x_l[2] + offset[2]);
+        grid_sample_J<IA_LAYOUT_NDHWC, true>(voxel_J, 0, D, H, W, ix, iy, iz, Jl);
+        gx_new[0] = Jl[0] * x_l[0] + Jl[1] * x_l[1] + Jl[2] * x_l[2] + Jl[3] - xt[0];
+        gx_new[1] = Jl[4] * x_l[0] + Jl[5] * x_l[1] + Jl[6] * x_l[2] + Jl[7] - xt[1];
+        gx_new[2] = Jl[8] * x_l[0] + Jl[9] * x_l[1] + Jl[10] * x_l[2] + Jl[11] - xt[2];
+        const float norm_gx = gx_new[0] * gx_new[0] + gx_new[1] * gx_new[1] + gx_new[2] * gx_new[2];
+        if (norm_gx < cvg_threshold * cvg_threshold) {
+            const bool ok = ix >= -1 && ix <= 1 && iy >= -1 && iy <= 1 && iz >= -1 && iz <= 1;
+            if (ok) {
+                float* fx = flag.x + (p * 16 + i_init) * 3;
+                fx[0] = x_l[0]; fx[1] = x_l[1]; fx[2] = x_l[2];
+                atomicOr(&flag.valid[p], 1u << i_init);
+                if (J_inv) {
+                    float* Jo = J_inv + index * 9;
+                    Jo[0] = J00; Jo[1] = J01; Jo[2] = J02; Jo[3] = J10; Jo[4] = J11; Jo[5] = J12; Jo[6] = J20; Jo[7] = J21; Jo[8] = J22;
+                }
+                if (fwd_J) {
+                    float* Fo = fwd_J + index * 9;
+                    Fo[0] = Jl[0]; Fo[1] = Jl[1]; Fo[2] = Jl[2]; Fo[3] = Jl[4]; Fo[4] = Jl[5]; Fo[5] = Jl[6];
+                    Fo[6] = Jl[8]; Fo[7] = Jl[9]; Fo[8] = Jl[10];
+                }
+            }
+            return;
+        } else if (norm_gx > dvg_threshold * dvg_threshold) {
+            return;
+        }
+        J_inv_update(Ji, u0, u1, u2, gx_new[0] - gx[0], gx_new[1] - gx[1], gx_new[2] - gx[2]);
+    }
+}
+
+__global__ void zero_i32_kernel(int32_t* __restrict__ p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = 0; }
 
 // ---- candidate rows of the PACK search -> packed candidate list ------------------------------------------------------------
 // the points the search redid exactly: K9 as filter.cu:10-54 writes it, on all 13 results (init i is dropped when a LATER valid
@@ -1644,12 +1731,30 @@ IA_EXPORT int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, c
         (void)hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(int32_t), s);
         return ia::check_launch("ia_fuse_broyden_spec_rows");
     }
-    int r = launch_spec(true, N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x_rows,
+    // small batches (IA_BR_SMALL_MAX points, default 2^18 = the flagged list's minimum capacity; 0 = off): every (point, init) search in its own lane, all points through the
+    // flagged list -- see broyden_items_rows_kernel.  (counters = the fetch statistics of the early-filter kernel: that kernel runs.)
+    // config-4 step, ms per call, early-filter kernel -> this path: 54 k points 0.395 -> 0.157, 115 k 0.536 -> 0.234, 180 k 0.516 -> 0.333
+    int64_t small_max = (int64_t)1 << 18;                               // (read per call: the tests switch it)
+    if (const char* e = getenv("IA_BR_SMALL_MAX")) { small_max = atoll(e); if (small_max > ((int64_t)1 << 18)) small_max = (int64_t)1 << 18; }
+    const bool small = N <= small_max && N <= o.flag.cap && I <= 16 && counters == nullptr;
+    int r;
+    if (small) {
+        IA_REQUIRE(I >= 1 && I <= 16, "ia_fuse_broyden_spec_rows: 1 <= I <= 16 inits");
+        IA_REQUIRE((int64_t)D * H * W < ((int64_t)1 << 26), "voxel grid too large for 32-bit byte offsets (48 B per voxel)");
+        (void)hipMemsetAsync(o.flag.valid, 0, (size_t)N * sizeof(uint32_t), s);
+        broyden_items_rows_kernel<<<ia::cdiv(N * I, THREADS), THREADS, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,
+                                                                              cvg_threshold, dvg_threshold, J_inv, fwd_J, o.flag, order);
+        r = ia::check_launch("ia_fuse_broyden_spec_rows(items)");
+    } else {
+        r = launch_spec(true, N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale, cvg_threshold, dvg_threshold, eps, x_rows,
                         J_inv, nullptr, fwd_J, counters, cnt, meta, o.flag, order, cell_tight, stream, "ia_fuse_broyden_spec_rows");
+    }
     if (r != IA_OK) return r;
-    rows_flagged_kernel<<<64, THREADS, 0, s>>>(o.flag, I, x_rows, cnt, meta, o.count, SPEC_OVF_CAP, ovf_head, o.rec, o.x, o.keep);
+    rows_flagged_kernel<<<(small ? (int)ia::cdiv(N, THREADS) : 64), THREADS, 0, s>>>(o.flag, I, x_rows, cnt, meta, o.count, SPEC_OVF_CAP, ovf_head,
+                                                                                    o.rec, o.x, o.keep);
     r = ia::check_launch("ia_fuse_broyden_spec_rows(flagged)");
     if (r != IA_OK) return r;
+    if (small) zero_i32_kernel<<<1, 64, 0, s>>>(o.flag.count);        // "points redone exactly" of the report below: none, by design
     r = ia_exclusive_scan_i32(cnt, start, total_and_overflow, N, scan_tmp, stream);
     if (r != IA_OK) return r;
     // [1] = number of points redone exactly; the caller compares it with ia_spec_rows_overflow_capacity()

@@ -279,8 +279,10 @@ def test_points_that_run_out_of_row_slots_are_redone_exactly(march, monkeypatch)
         dfm.spec_eps = old
         type(dfm).SPEC_ROWS = True
     monkeypatch.setenv("IA_SPEC_TEST_SLOTS", "1")
+    monkeypatch.setenv("IA_BR_SMALL_MAX", "0")                        # the early-filter kernel, whatever the batch size
     got = dfm._candidates(sub, with_src=True)
     monkeypatch.delenv("IA_SPEC_TEST_SLOTS")
+    monkeypatch.delenv("IA_BR_SMALL_MAX")
     assert 10_000 < dfm.last_overflow_records <= dfm._ovf_cap, (dfm.last_overflow_records, dfm._ovf_cap)      # redone in the kernel, not by the fallback
     assert int(got[2].max()) >= 3
     diff = int((got[2] != want[2]).sum())
@@ -382,3 +384,31 @@ def test_split_candidate_layout_gives_the_same_sdf_and_the_same_candidates(march
     tail = n_first + (start[more] - first_pos[more]).long()
     assert torch.equal(cand_b[tail], cand_a[start[more].long() + 1])                                   # second candidates
     assert torch.equal(torch.sort(cand_b.reshape(-1))[0], torch.sort(cand_a.reshape(-1))[0])           # the same multiset
+
+
+def test_small_batches_search_all_inits_side_by_side_with_the_same_candidates(march, monkeypatch):
+    """batches of up to IA_BR_SMALL_MAX points (default 2^18: the reference's 4096-ray training batches) run one lane per (point, init)
+    search to its end and K9 literally (broyden_items_rows_kernel + rows_flagged_kernel) instead of the early-filter kernel's 13 serial
+    searches per lane: the packed candidates, their source inits, the per-point counts and the Jacobians of every candidate are the
+    early-filter path's, bit for bit -- through a permutation as well."""
+    SP, rs, pts, _ = march
+    dfm = rs.deformer
+    for n, with_order in ((1, False), (777, False), (60_000, True), (262_144, False)):
+        sub = pts[1000:1000 + n].contiguous()
+        order = torch.randperm(n, device=DEV).to(torch.int32) if with_order else None
+        monkeypatch.setenv("IA_BR_SMALL_MAX", "0")
+        want = dfm._candidates(sub, with_src=True, want_fwd=True, want_jinv=True, order=order)
+        assert dfm._tls.n_over >= 0
+        monkeypatch.delenv("IA_BR_SMALL_MAX")
+        got = dfm._candidates(sub, with_src=True, want_fwd=True, want_jinv=True, order=order)
+        assert dfm._tls.n_over == 0                                     # nothing "redone": every point went through the list by design
+        assert got[4] == want[4], (n, got[4], want[4])
+        for k in (0, 1, 2, 3):                                          # cand_x, cand_src, cnt, start
+            assert torch.equal(got[k], want[k]), (n, k)
+        src = got[1].long()
+        for k in (5, 6):                                                # fwd_J, J_inv [P, I, 3, 3]: rows of the candidates
+            a, b = got[k].reshape(-1, 9)[src], want[k].reshape(-1, 9)[src]
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (n, k)
+    # the SDF-only product call on a small batch = the rows of the full batch
+    s_full = dfm.deform_sdf(pts[:300_000].contiguous(), rs.geometry)
+    assert torch.equal(dfm.deform_sdf(pts[:40_000].contiguous(), rs.geometry), s_full[:40_000])
