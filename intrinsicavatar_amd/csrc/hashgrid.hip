@@ -285,8 +285,13 @@ __device__ __forceinline__ void xcd_blend_store(const float2 v[8], const float p
     }
 }
 
+#ifdef IA_HASH_WAVES        /* experiment: pin the gather's occupancy (waves per SIMD) */
+#define IA_HASH_OCC __attribute__((amdgpu_waves_per_eu(IA_HASH_WAVES, IA_HASH_WAVES)))
+#else
+#define IA_HASH_OCC
+#endif
 template <bool WITH_JAC>
-__global__ __launch_bounds__(THREADS) void hash_fwd_xcd_kernel(int64_t n, const float* __restrict__ x,
+__global__ __launch_bounds__(THREADS) IA_HASH_OCC void hash_fwd_xcd_kernel(int64_t n, const float* __restrict__ x,
                                                                 const float2* __restrict__ params, HashCfg cfg, XcdPlan plan,
                                                                 float2* __restrict__ tmp /*[L][n]*/,
                                                                 float* __restrict__ tmp_jac /*[L][n][6]*/)

@@ -195,7 +195,7 @@ def test_bench_step_through_rccl_on_one_rank():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--hw", "64", "--spp", "16", "--ray-chunk", "2048",
-                        "--no-cpu-baseline", "--no-config2", "--no-search-modes"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--no-config2", "--no-config4", "--no-search-modes"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert lines[-1].startswith("{"), lines[-3:]          # the JSON line is the LAST thing on stdout (RCCL's banner is flushed before it)

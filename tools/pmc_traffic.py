@@ -17,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = os.environ.get("IA_PROFILE_TAG", "r05")
-CMD = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-config2",
+CMD = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-config2", "--no-config4",
        "--no-breakdown", "--no-search-modes"] + sys.argv[1:]
 
 

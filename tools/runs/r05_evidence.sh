@@ -5,10 +5,10 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 timeout 900 python $R/bench.py --steps 7 --warmup 2 > $O/r05_bench_headline.json 2> $O/r05_bench_headline.err
 export IA_SECONDARY_STREAMS=1
-rm -rf /tmp/kt && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-config2 --no-breakdown --no-search-modes > /dev/null 2>&1
+rm -rf /tmp/kt && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-config2 --no-config4 --no-breakdown --no-search-modes > /dev/null 2>&1
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/r05_headline_kernel_stats.csv
 unset IA_SECONDARY_STREAMS
-rm -rf /tmp/kt2 && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-config2 --no-breakdown --no-search-modes > /dev/null 2>&1
+rm -rf /tmp/kt2 && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-config2 --no-config4 --no-breakdown --no-search-modes > /dev/null 2>&1
 cp $(find /tmp/kt2 -name "*kernel_stats.csv" | head -1) $O/r05_headline_kernel_stats_two_streams.csv
 timeout 300 python $R/tools/microbench.py > $O/r05_microbench.json 2>/dev/null
 timeout 300 python $R/tools/relight_bench.py --spp 256 > $O/r05_relight_spp256.json 2>/dev/null
