@@ -1242,7 +1242,11 @@ IA_EXPORT int ia_hashgrid_fwd_xcd(int64_t n, const float* x, const float* params
     // balanced by construction.  Giving each XCD its own level (passes A / B below, IA_HASH_XCD_PLAN=passes) is bound by the
     // slowest level of a pass: per-level cost for 100 M sorted points on the whole device is 1.18 ms (level 5) ... 1.83
     // (level 12) ... 2.42 ms (level 15), 3.47 ms for the five dense levels together = 21.8 ms against 26.9 ms for the passes.
-    static const bool by_level = !(getenv("IA_HASH_XCD_PLAN") && getenv("IA_HASH_XCD_PLAN")[0] == 'p');
+    // Small batches (< 300 k points: the reference's 4096-ray training batches) take the two passes instead: twelve launches of a batch that
+    // fills the device for a few microseconds cost more than the passes' imbalance (tools/small_gather_probe.py, gather ms, level / passes:
+    // 140 k points 0.184 / 0.101, 206 k 0.223 / 0.147, 557 k 0.287 / 0.335, 1 M 0.445 / 0.581, 10 M 2.19 / 3.02).
+    static const int plan_env = getenv("IA_HASH_XCD_PLAN") ? (getenv("IA_HASH_XCD_PLAN")[0] == 'p' ? 1 : 2) : 0;      // 1: passes, 2: by level, 0: by size
+    const bool by_level = plan_env == 2 || (plan_env == 0 && n >= 300000);
     // experiment knob (round 5): hashed levels per launch (default 1).  Two levels per launch read the coordinates half as often and put
     // 8 MB of tables in front of every XCD's 4 MB L2 -- measured: DESIGN 4.3.
     static const int lpl = getenv("IA_HASH_LEVELS_PER_LAUNCH") ? max(1, atoi(getenv("IA_HASH_LEVELS_PER_LAUNCH"))) : 1;
