@@ -155,6 +155,8 @@ def measure_config4(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, steps=10)
     g = torch.Generator().manual_seed(4)
     with torch.no_grad():
         hit = torch.nonzero(rs.forward(rays)["opacity"][:, 0] > 0.5)[:, 0]          # pixels on the subject, like the trainer's fg sampler
+    if hit.shape[0] == 0:
+        return None                                                 # a frame without the subject (tiny --hw): nothing to sample
     sel = hit[torch.randint(0, hit.shape[0], (n_batch,), generator=g).to(dev)]
     batch = rays[sel].contiguous()
     target = torch.rand((n_batch, 3), generator=g).to(dev)

@@ -120,6 +120,21 @@ def test_bench_starts_its_own_ranks():
     assert line["config"]["samples"]["n_fg"] > 0 and line["config"]["samples"]["n_secondary"] > 0
 
 
+def test_bench_line_of_one_rank_carries_the_objects_the_contract_names():
+    """`python bench.py` on one GPU (small frame): ONE JSON line with the contract's keys, `roofline` and `cpu_baseline`, and the
+    secondary workloads `config4` (the reference's 4096-ray training batch) and `config2_ms_per_step`."""
+    line = _run_line(["bench.py", "--steps", "1", "--warmup", "1", "--hw", "96", "--spp", "16", "--no-search-modes"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["vs_baseline"] is None and line["dtype"] == "f32"
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"]) and 0 < line["roofline"]["frac"] <= 1
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+    c4 = line["config4"]
+    assert c4 is not None and c4["ms_per_step"] > 0 and c4["secondary_rays_per_step"] > 0 and len(c4["search_launches_ms_points"]) >= 3
+    assert line["config2_ms_per_step"] > 0
+
+
 def test_relight_bench_starts_its_own_ranks():
     line = _run_line(["tools/relight_bench.py", "--gpus", "2", "--frames", "2", "--hw", "48", "--spp", "16"])
     assert line["n_gpus"] == 2 and line["frames"] == 2 and line["secondary_rays"] > 0
