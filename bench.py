@@ -37,6 +37,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # before the HIP runtime initialises (intrinsicavatar_amd/__init__.py: launch path)
+
 # one process per GPU: the host side of a rank is one launch thread.  Library thread pools default to the number of
 # visible CPUs (256 on the GPU boxes, 8 ranks per node) while a container's CPU quota is a fraction of that; an
 # oversubscribed pool burns the cgroup quota and the launch thread gets throttled with it.

@@ -14,6 +14,14 @@ All compute runs in hand-written HIP kernels behind the C ABI of include/ia_amd.
 """
 __version__ = "0.1.0"
 
+import os as _os
+
+# Host tuning: kernel arguments in device memory (a shorter launch path of the HIP runtime; read when the runtime initialises, i.e. at
+# the process's first device call -- import this package before touching the GPU, or export the variable).  The path issues hundreds of
+# launches per step: the reference's 4096-ray training step 21.4 -> 20.8 ms, the headline step 309.5 -> 307.5 ms (same box, alternating,
+# profiles/r05_dev_kernarg.txt).  An explicit setting in the environment wins.
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 
 def install_aliases() -> None:
     """make the reference's own import statements resolve to this package:
