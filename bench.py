@@ -148,17 +148,17 @@ def build_headline(dev, hw, spp, rank, pose):
     return rs, rays, export, mat, sg
 
 
-def measure_config4(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, steps=10):
-    """the reference's own training batch (BASELINE configs[3]; configs/sampler/edge.yaml:2, configs/config.yaml: uniform_light, spp 512):
-    n_batch rays on the subject of the bench frame, RenderStep.forward_backward_phys + the fused Adam step.  Returns the line's `config4`
-    object: ms per step, rays/s, and the search launches of one step (points, ms) -- the step's one large search batch is its secondary
-    march (~2 100 march points per ray), not the 4096 rays' own samples."""
-    from intrinsicavatar_amd import _lib as L, optim, pbr
-    g = torch.Generator().manual_seed(4)
+def build_config4_step(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, seed=4, sync=None, grad_scale=1.0):
+    """the reference's own training batch (BASELINE configs[3]; configs/sampler/edge.yaml:2, configs/config.yaml:46-48: uniform_light, spp 512):
+    n_batch rays on the subject of the bench frame, RenderStep.forward_backward_phys + the fused Adam step.  -> (step callable, workload
+    string) or (None, None) on a frame without the subject.  sync: parallel.OverlappedGradientAllReduce of a multi-rank run (the step
+    then ends with sync.finish() before the optimiser step; grad_scale = 1 / world makes the summed all-reduce DDP's mean)."""
+    from intrinsicavatar_amd import optim, pbr
+    g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         hit = torch.nonzero(rs.forward(rays)["opacity"][:, 0] > 0.5)[:, 0]          # pixels on the subject, like the trainer's fg sampler
     if hit.shape[0] == 0:
-        return None                                                 # a frame without the subject (tiny --hw): nothing to sample
+        return None, None                                           # a frame without the subject (tiny --hw): nothing to sample
     sel = hit[torch.randint(0, hit.shape[0], (n_batch,), generator=g).to(dev)]
     batch = rays[sel].contiguous()
     target = torch.rand((n_batch, 3), generator=g).to(dev)
@@ -166,7 +166,7 @@ def measure_config4(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, steps=10)
     light_u = torch.rand((spp, 3), generator=g).to(dev)             # uniform_light: one stratified direction set per step (intrinsic_avatar.py:1392-1400)
     shuffle_u = torch.rand((n_batch, spp), generator=g).to(dev)     # the per-ray spp shuffle
     params = rs.parameters() + [p for p in mat.parameters() if p.requires_grad] + list(sg.parameters())
-    opt, sched = optim.reference_optimizer(rs, material=mat, emitter=sg)
+    opt, sched = optim.reference_optimizer(rs, grad_scale=grad_scale, material=mat, emitter=sg)
 
     def s4():
         for p in params:
@@ -179,9 +179,25 @@ def measure_config4(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, steps=10)
                                      env_base=leaf, background_color=bg)
         if leaf.grad is not None:
             img.backward(leaf.grad)
+        if sync is not None:
+            s4.reduced_bytes = sync.finish()
         opt.step()
         sched.step()
         return o
+    s4.reduced_bytes = 0
+    s4.params = params
+    return s4, f"{n_batch} rays on the subject of the bench frame, PBR training step (uniform_light, spp {spp}), fwd+bwd+Adam"
+
+
+def measure_config4(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, steps=10):
+    """Returns the line's `config4` object: ms per step, rays/s, the search launches of one step (points, ms) -- the step's one large
+    search batch is its secondary march (~2 100 march points per ray), not the 4096 rays' own samples -- and the host-orchestration
+    figures of SURVEY 8(f) row 2 for one step: device launches, host read-backs, idle fraction of the device time line
+    (tools/launch_audit.py: torch.profiler + sync debug mode)."""
+    from intrinsicavatar_amd import _lib as L
+    s4, wl = build_config4_step(rs, rays, mat, sg, dev, bg, n_batch, spp)
+    if s4 is None:
+        return None
     for _ in range(3):
         o = s4()
     torch.cuda.synchronize()
@@ -195,10 +211,18 @@ def measure_config4(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, steps=10)
     o = s4()
     det = lib.report(detail=True)
     search = [(round(c[0], 3), int(c[1])) for k in ("ia_fuse_broyden_spec_rows", "ia_fuse_broyden") for c in det.get(k, [])]
-    return dict(workload=f"{n_batch} rays on the subject of the bench frame, PBR training step (uniform_light, spp {spp}), fwd+bwd+Adam",
+    host = None
+    try:
+        from tools import launch_audit as LA
+        a = LA.audit(s4, warm=0)
+        host = dict(launches=a["device_launches"], aten_or_runtime_launches=a["aten_or_runtime_launches"], readbacks=a["readbacks"],
+                    idle_frac=a["idle_frac"], span_ms_under_profiler=a["span_ms"], busy_ms_under_profiler=a["busy_ms"])
+    except Exception as e:              # a diagnostic must not take the measurement down
+        host = dict(error=f"{type(e).__name__}: {e}")
+    return dict(workload=wl,
                 ms_per_step=round(ms, 3), rays_per_s=round(n_batch / (ms * 1e-3), 1), secondary_rays_per_step=int(o["stats"]["n_secondary"]),
                 kernel_ms_per_step=round(sum(c[0] for v in det.values() for c in v), 3),
-                search_launches_ms_points=search)
+                search_launches_ms_points=search, **(host or {}))
 
 
 def main():

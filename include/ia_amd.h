@@ -423,8 +423,8 @@ int ia_laplace_alpha_bwd(int64_t n, const float* sdf, const float* dists, float 
  * (models/rf/geometry.py:165-172, create_graph=True). */
 int ia_sh4_bwd(int64_t n, const float* d01, const float* g_sh, int g_stride, float* g_d01, ia_stream_t stream);
 int ia_shade_prep_bwd(int64_t n, const float* sdf_grad, const float* rays_d, const int64_t* ray_indices,
-                      const float* w2s_rot, const float* g_normal_world /*or NULL*/, const float* g_refl01,
-                      float* g_sdf_grad, ia_stream_t stream);
+                      const float* w2s_rot, const float* g_normal_world /*or NULL*/, const float* g_refl01 /*or NULL*/,
+                      const float* g_normal_smpl /*or NULL: gradient of g / max(|g|, 1e-6)*/, float* g_sdf_grad, ia_stream_t stream);
 /* data-path backward of the two-hidden-layer ReLU MLPs (kind 1 radiance, 2 material; sigmoid output):
  * g_x [n, gx_stride] = d L / d assembled input row; X/A1/A2 (layer inputs) and G1/G2/G3 (pre-activation
  * gradients) are emitted for the weight-gradient GEMMs dW_l = G_l^T A_{l-1} (plain library GEMM). */
@@ -664,6 +664,56 @@ int ia_deform_select_min(int64_t P, const int32_t* start, const int32_t* cnt, co
 /* ... for points evaluated as a permutation of the caller's list: sdf[order[p]] = the minimum of point p */
 int ia_deform_select_min_scatter(int64_t P, const int32_t* start, const int32_t* cnt, const float* cand_sdf, const int32_t* order,
                                  float* sdf, ia_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* Per-step operators of a training step (csrc/stepops.hip; SURVEY 8(f) row 2: host orchestration).  Each replaces a chain of
+ * element-wise / reduce operators that the reference issues through torch (and their autograd backward chains) by one launch each way;
+ * a 4096-ray training batch (configs/sampler/edge.yaml:2) is bound by the host's launch rate, not by a kernel.
+ *
+ * ia_normalize_points: out = (x - center) / scale + 0.5 -- the [0,1]^3 coordinates of a hash grid (models/rf/geometry.py:155,
+ *   models/rf/radiance.py:115).  x, out [n,3]; center, scale [3] on the device.
+ * ia_effective_weights(_bwd): the weight matrix a fused MLP kernel reads, from the parameters of one linear layer.
+ *   mode 0 plain Linear (models/network_utils.py:232-244), 1 weight norm  g * v / |v|_row (nn.utils.weight_norm, :201-244; g [M]),
+ *   2 Lipschitz normalisation v * min(softplus(c) / sum_row |v|, 1) (LipshitzMLP, :396-403; g = c, ONE scalar).
+ *   src [N] int32 (NULL: identity): parameter column of output column j (the kernels' column order [hash | xyz | ...]);
+ *   mul [N] (NULL: 1): mask of output column j (ProgressiveBandHashGrid level mask :79-100, SH band mask models/rf/radiance.py:140-155).
+ *   _bwd: g_out [M,N] -> g_v [M,N] (parameter column order; every column must appear in src) and g_g ([M] mode 1, [1] mode 2).
+ * ia_sg_image(_bwd): EnvironmentLightSG.generate_image (lib/torch_pbr, absent; call site models/intrinsic_avatar.py:281-305):
+ *   out[row, col] = sum_k softplus(mu_k) exp(exp(log_lambda_k) (d(row, col) . normalize(axis_k) - 1)), d = the equirectangular direction
+ *   convention of ia_envlight_eval; out [H,W,3].  _bwd: g_img -> g_axis [K,3], g_log_lambda [K], g_mu [K,3]; tmp: ia_sg_image_bwd_tmp_bytes(K).
+ * ia_envlight_pdf_tables: emitter.update_pdf (:777-781): pmf [H*W] fp32 = luminance x sin(theta), normalised in double; cdf [H*W] double =
+ *   running sum of the fp32 pmf (what ia_envlight_sample searches).
+ * ia_uniform_sphere_stratified: emitter.sample_uniform_sphere_stratified(n_rays, 16, 32) (:680-689): u [n_theta*n_phi,2] ->
+ *   dirs [n_theta*n_phi,3] (z = 1 - 2 (i + u0) / n_theta, phi = 2 pi (j + u1) / n_phi), inv_pdf [n_theta*n_phi] = 4 pi.
+ * ia_material_affine(_bwd): VolumeMaterial.forward's output ranges (models/pbr/material.py:44-50): m [n,5] sigmoid outputs ->
+ *   albedo [n,3], roughness [n], metallic [n]; _bwd: NULL gradient = zero.
+ * ia_phys_loss(_bwd): the default loss composition of IntrinsicAvatarSystem.training_step (systems/intrinsic_avatar.py:165-252):
+ *   terms[0] = mean |comp_rgb - target|, [1] = mean |comp_rgb_phys - target|, [2] = BCE(clamp(opacity, 1e-3, 1 - 1e-3), mask),
+ *   [3] = sum of eik_partials[k][0] (ia_eikonal), [4] = t0 + lambda_eik t3 / eik_denom + lambda_mask t2 + lambda_phys t1.  NULL
+ *   comp_rgb_phys / target_mask / eik_partials drop their term.  _bwd: g_loss [1] (device) -> gradients of the three maps and g_eik_sum [1].
+ * ia_edge_min_sdf: coarse_alpha_fn's interval SDF (models/intrinsic_avatar.py:980-990): out[i] = is_left[i] ? min(sdf[i], sdf[i+1]) : 1e10. */
+int ia_normalize_points(int64_t n, const float* x, const float* center, const float* scale, float* out, ia_stream_t stream);
+int ia_effective_weights(int mode, int M, int N, const float* g, const float* v, const int* src, const float* mul, float* out,
+                         ia_stream_t stream);
+int ia_effective_weights_bwd(int mode, int M, int N, const float* g, const float* v, const int* src, const float* mul, const float* g_out,
+                             float* g_v, float* g_g, ia_stream_t stream);
+int ia_sg_image(int K, int H, int W, const float* axis, const float* log_lambda, const float* mu, float* out, ia_stream_t stream);
+int64_t ia_sg_image_bwd_tmp_bytes(int K);
+int ia_sg_image_bwd(int K, int H, int W, const float* axis, const float* log_lambda, const float* mu, const float* g_img, void* tmp,
+                    float* g_axis, float* g_log_lambda, float* g_mu, ia_stream_t stream);
+int ia_envlight_pdf_tables(int H, int W, const float* base, float* pmf, double* cdf, ia_stream_t stream);
+int ia_uniform_sphere_stratified(int n_theta, int n_phi, const float* u, float* dirs, float* inv_pdf, ia_stream_t stream);
+int ia_material_affine(int64_t n, const float* m, float albedo_scale, float albedo_bias, float roughness_scale, float roughness_bias,
+                       float metallic_scale, float metallic_bias, float* albedo, float* roughness, float* metallic, ia_stream_t stream);
+int ia_material_affine_bwd(int64_t n, const float* g_albedo, const float* g_roughness, const float* g_metallic, float albedo_scale,
+                           float roughness_scale, float metallic_scale, float* g_m, ia_stream_t stream);
+int ia_phys_loss(int64_t n, const float* comp_rgb, const float* comp_rgb_phys, const float* opacity, const float* target_rgb,
+                 const float* target_mask, const float* eik_partials, int eik_k, float lambda_phys, float lambda_mask, float lambda_eik,
+                 float eik_denom, float* terms, ia_stream_t stream);
+int ia_phys_loss_bwd(int64_t n, const float* comp_rgb, const float* comp_rgb_phys, const float* opacity, const float* target_rgb,
+                     const float* target_mask, const float* g_loss, float lambda_phys, float lambda_mask, float lambda_eik, float eik_denom,
+                     float* g_comp_rgb, float* g_comp_rgb_phys, float* g_opacity, float* g_eik_sum, ia_stream_t stream);
+int ia_edge_min_sdf(int64_t n_edges, const float* sdf, const uint8_t* is_left, float* out, ia_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,7 @@ SOURCES = {
     "sort.hip": ["-ffp-contract=off"],
     "occgrid.hip": [],
     "optim.hip": ["-ffp-contract=off"],
+    "stepops.hip": ["-ffp-contract=off"],
 }
 
 

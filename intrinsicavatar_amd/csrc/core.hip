@@ -86,12 +86,61 @@ __global__ void copy_one_kernel(const T* src, T* dst) { *dst = *src; }
 template <typename T>
 __global__ void zero_one_kernel(T* dst) { *dst = 0; }
 
+// Small inputs (the per-ray count tables of a 4096-ray training batch, the tile sums of a larger scan): ONE workgroup walks the whole array
+// in chunks of 1024 x SCAN_ITEMS elements with a running carry and writes the total itself -- one launch instead of the four of the tiled
+// protocol (tiles, tile sums, copy of the total, add-back); the 4096-ray step issued 75 scan launches (profiles/r05_config4_kernel_stats.csv).
+constexpr int SCAN_SMALL_THREADS = 1024;
+constexpr int64_t SCAN_SMALL_MAX = 1 << 17;
+template <typename T>
+__global__ __launch_bounds__(SCAN_SMALL_THREADS) void scan_small_kernel(const T* in, T* out, T* total, int64_t n)
+{
+    __shared__ T wave_tot[SCAN_SMALL_THREADS / 64];
+    __shared__ T carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t chunk = 0; chunk < n; chunk += (int64_t)SCAN_SMALL_THREADS * SCAN_ITEMS) {
+        const int64_t base = chunk + (int64_t)tid * SCAN_ITEMS;
+        T v[SCAN_ITEMS];
+        T local = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) {
+            v[k] = (base + k < n) ? in[base + k] : (T)0;
+            local += v[k];
+        }
+        const T inc = wave_inclusive_scan(local, lane);
+        if (lane == 63) wave_tot[wid] = inc;
+        __syncthreads();
+        T wave_off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < SCAN_SMALL_THREADS / 64; w++) {
+            const T t = wave_tot[w];
+            if (w < wid) wave_off += t;
+            tot += t;
+        }
+        T run = carry_s + wave_off + inc - local;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) {
+            if (base + k < n) out[base + k] = run;
+            run += v[k];
+        }
+        __syncthreads();                      // every thread has read carry_s and wave_tot
+        if (tid == 0) carry_s += tot;
+        __syncthreads();
+    }
+    if (tid == 0 && total) *total = carry_s;
+}
+
 template <typename T>
 int scan_impl(const T* in, T* out, T* total, int64_t n, void* tmp, hipStream_t s)
 {
     if (n <= 0) {
         if (total) zero_one_kernel<T><<<1, 1, 0, s>>>(total);
         return ia::check_launch("scan(empty)");
+    }
+    if (n <= SCAN_SMALL_MAX) {
+        scan_small_kernel<T><<<1, SCAN_SMALL_THREADS, 0, s>>>(in, out, total, n);
+        return ia::check_launch("scan(small)");
     }
     // level buffers carved from tmp (8-byte slots)
     int64_t* slots = (int64_t*)tmp;

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(THREADS) void shade_prep_bwd_kernel(int64_t n, cons
                                                                   const float* __restrict__ rays_d,
                                                                   const int64_t* __restrict__ ray_indices,
                                                                   const float* __restrict__ R, const float* __restrict__ g_nw,
-                                                                  const float* __restrict__ g_refl01,
+                                                                  const float* __restrict__ g_refl01, const float* __restrict__ g_ns,
                                                                   float* __restrict__ g_sdf_grad)
 {
     const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
@@ -499,10 +499,10 @@ __global__ __launch_bounds__(THREADS) void shade_prep_bwd_kernel(int64_t n, cons
     float G[3];
     float gr_dot_nw = 0.f;
 #pragma unroll
-    for (int c = 0; c < 3; c++) gr_dot_nw += 0.5f * g_refl01[i * 3 + c] * nw[c];
+    for (int c = 0; c < 3; c++) gr_dot_nw += 0.5f * (g_refl01 ? g_refl01[i * 3 + c] : 0.f) * nw[c];
 #pragma unroll
     for (int c = 0; c < 3; c++)
-        G[c] = (g_nw ? g_nw[i * 3 + c] : 0.f) + 2.0f * dt * 0.5f * g_refl01[i * 3 + c] - 2.0f * gr_dot_nw * vw[c];
+        G[c] = (g_nw ? g_nw[i * 3 + c] : 0.f) + 2.0f * dt * 0.5f * (g_refl01 ? g_refl01[i * 3 + c] : 0.f) - 2.0f * gr_dot_nw * vw[c];
     float Gu[3];
     if (len > 1e-6f) {
         const float dn = nw[0] * G[0] + nw[1] * G[1] + nw[2] * G[2];
@@ -512,8 +512,17 @@ __global__ __launch_bounds__(THREADS) void shade_prep_bwd_kernel(int64_t n, cons
 #pragma unroll
         for (int c = 0; c < 3; c++) Gu[c] = G[c] / 1e-6f;
     }
+    // normal_smpl = g / max(|g|, 1e-6) (the BRDF's normal in the PBR branch): its gradient joins here instead of in five torch launches
+    float gs[3] = {0.f, 0.f, 0.f};
+    if (g_ns) {
+        const float nrm = fmaxf(sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]), 1e-6f);
+        const float ns[3] = {g[0] / nrm, g[1] / nrm, g[2] / nrm};
+        const float dsn = g_ns[i * 3 + 0] * ns[0] + g_ns[i * 3 + 1] * ns[1] + g_ns[i * 3 + 2] * ns[2];
 #pragma unroll
-    for (int a = 0; a < 3; a++) g_sdf_grad[i * 3 + a] = Gu[0] * R[a * 3 + 0] + Gu[1] * R[a * 3 + 1] + Gu[2] * R[a * 3 + 2];
+        for (int c = 0; c < 3; c++) gs[c] = (g_ns[i * 3 + c] - dsn * ns[c]) / nrm;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) g_sdf_grad[i * 3 + a] = Gu[0] * R[a * 3 + 0] + Gu[1] * R[a * 3 + 1] + Gu[2] * R[a * 3 + 2] + gs[a];
 }
 
 // alpha = 1 - exp(-sigma(sdf) * dist), sigma = Laplace CDF density (density.py:25-30)
@@ -741,11 +750,11 @@ IA_EXPORT int ia_shade_prep(int64_t n, const float* sdf_grad, const float* rays_
 
 IA_EXPORT int ia_shade_prep_bwd(int64_t n, const float* sdf_grad, const float* rays_d, const int64_t* ray_indices,
                                 const float* w2s_rot, const float* g_normal_world, const float* g_refl01,
-                                float* g_sdf_grad, ia_stream_t stream)
+                                const float* g_normal_smpl, float* g_sdf_grad, ia_stream_t stream)
 {
     if (n == 0) return IA_OK;
     shade_prep_bwd_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, sdf_grad, rays_d, ray_indices, w2s_rot,
-                                                                                   g_normal_world, g_refl01, g_sdf_grad);
+                                                                                   g_normal_world, g_refl01, g_normal_smpl, g_sdf_grad);
     return ia::check_launch("ia_shade_prep_bwd");
 }
 

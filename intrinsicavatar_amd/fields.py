@@ -9,8 +9,8 @@ checkpoints load unchanged:
   LaplaceDensity        models/rf/density.py:19-34
 
 The kernels take EFFECTIVE weights; weight-norm, Lipschitz normalisation, progressive level masks
-and the kernels' column order ([hash 32 | xyz 3 | ...]) are folded in here with tiny torch ops on
-the (<= 64x67) matrices, which keeps them differentiable for training.
+and the kernels' column order ([hash 32 | xyz 3 | ...]) are folded in here: one ia_effective_weights
+launch per linear layer (differentiable: _EffW), cached per parameter epoch for the no-grad queries.
 """
 import ctypes as C
 import os
@@ -142,6 +142,90 @@ def _weight_norm(g: Tensor, v: Tensor) -> Tensor:
     return g * v / v.norm(dim=1, keepdim=True)
 
 
+# The effective weights of a head (weight norm / Lipschitz normalisation, level masks, the kernels' column order) are a function of
+# the parameters alone, and a training step asks for them once per field query: five no-grad SDF queries + the differentiable pass
+# recomputed ~50 elementwise launches each time, 40 % of the ATen launches of a 4096-ray step (profiles/r06_launch_audit_before.json).
+# They are cached per "parameter epoch": PARAM_EPOCH counts the in-place updates made BEHIND torch's back (optim.Adam writes the
+# parameters through raw pointers, which does not bump Tensor._version); updates made through torch bump _version, which is part of
+# the key as well.  Only no-grad requests are served from the cache (a graph-carrying result must not outlive its backward).
+PARAM_EPOCH = [0]
+
+
+def params_changed():
+    """to be called by whoever writes parameters through raw device pointers (optim.Adam.step does)."""
+    PARAM_EPOCH[0] += 1
+
+
+def _cache_key(params, *extra):
+    return (PARAM_EPOCH[0], tuple((p.data_ptr(), p._version) for p in params), *extra)
+
+
+def _cached_nograd(mod, name, key, make, keep=()):
+    """`make()` evaluated under no_grad once per key; contiguous detached tensors.  keep: tensors whose (data_ptr, _version) is part
+    of the key and which are not owned by the module -- the entry holds them, so their storage cannot be reused under the same key."""
+    c = mod.__dict__.get("_wcache")
+    if c is None:
+        c = mod.__dict__["_wcache"] = {}
+    hit = c.get(name)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    with torch.no_grad():
+        val = tuple(t.detach().contiguous() for t in make())
+    c[name] = (key, val, tuple(keep))
+    return val          # (the other tensors of a key are the module's own parameters / buffers: alive as long as the module)
+
+
+def normalize_points(x: Tensor, center: Tensor, scale: Tensor) -> Tensor:
+    """(x - center) / scale + 0.5 in one launch (ia_normalize_points): the [0,1]^3 coordinates of a hash grid."""
+    x = x.contiguous().float()
+    out = torch.empty_like(x)
+    L.check(L.lib().ia_normalize_points(L.i64(x.shape[0]), L.ptr(x), L.ptr(center), L.ptr(scale), L.ptr(out), L.stream()), "ia_normalize_points")
+    return out
+
+
+class _EffW(torch.autograd.Function):
+    """ia_effective_weights / _bwd: (g, v) -> the matrix a fused MLP kernel reads.  mode 0 plain, 1 weight norm (g [M,1]), 2 Lipschitz
+    (g = softplus^-1 of the bound, [1]); src int32 [N] / mul float [N]: column order and masks (None: identity / ones)."""
+
+    @staticmethod
+    def forward(ctx, mode, g, v, src, mul):
+        v = v.contiguous()
+        gg = g.contiguous() if g is not None else None
+        M, N = v.shape
+        out = torch.empty((M, N), device=v.device)
+        L.check(L.lib().ia_effective_weights(L.i32(mode), L.i32(M), L.i32(N), L.ptr(gg), L.ptr(v), L.ptr(src), L.ptr(mul), L.ptr(out), L.stream()),
+                "ia_effective_weights")
+        ctx.mode = mode
+        ctx.save_for_backward(gg, v, src, mul)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        gg, v, src, mul = ctx.saved_tensors
+        M, N = v.shape
+        g_v = torch.empty_like(v)
+        g_g = torch.empty_like(gg) if gg is not None else None
+        L.check(L.lib().ia_effective_weights_bwd(L.i32(ctx.mode), L.i32(M), L.i32(N), L.ptr(gg), L.ptr(v), L.ptr(src), L.ptr(mul),
+                                                 L.ptr(g_out.contiguous()), L.ptr(g_v), L.ptr(g_g), L.stream()), "ia_effective_weights_bwd")
+        return None, g_g, g_v, None, None
+
+
+def _col_tables(mod, name, src_cols, mul_parts):
+    """(src int32 [N], mul float [N]) of a layer's column order, cached on the module per identity / version of the mask tensors."""
+    key = tuple((t.data_ptr(), t._version) if isinstance(t, Tensor) else t for t in mul_parts)
+    c = mod.__dict__.setdefault("_coltab", {})
+    hit = c.get(name)
+    if hit is None or hit[0] != key:
+        dev = next(t.device for t in mul_parts if isinstance(t, Tensor))
+        src = torch.tensor(src_cols, dtype=torch.int32, device=dev)
+        with torch.no_grad():
+            mul = torch.cat([t.reshape(-1).float() if isinstance(t, Tensor) else torch.ones(int(t), device=dev) for t in mul_parts]).contiguous()
+        # the entry keeps its mask tensors ALIVE: (data_ptr, _version) identifies a tensor only as long as its storage cannot be
+        # handed to another one (a freed level mask's block comes back for the next level's mask at the same address)
+        hit = c[name] = (key, src, mul, tuple(t for t in mul_parts if isinstance(t, Tensor)))
+    return hit[1], hit[2]
+
+
 class _WNLinear(nn.Module):
     """nn.utils.weight_norm(nn.Linear) parameter layout: weight_g [out,1], weight_v [out,in], bias."""
 
@@ -151,8 +235,11 @@ class _WNLinear(nn.Module):
         self.weight_v = nn.Parameter(torch.zeros(dim_out, dim_in))
         self.bias = nn.Parameter(torch.zeros(dim_out))
 
-    def effective(self):
-        return _weight_norm(self.weight_g, self.weight_v)
+    def effective(self, src=None, mul=None):
+        """g * v / |v|_row (ia_effective_weights mode 1; differentiable), optionally in another column order with column masks."""
+        if not self.weight_v.is_cuda:
+            return _weight_norm(self.weight_g, self.weight_v)          # host-side exports (synthetic.export: the oracle's scene bundle)
+        return _EffW.apply(1, self.weight_g, self.weight_v, src, mul)
 
 
 class _Linear(nn.Module):
@@ -184,8 +271,13 @@ class ProgressiveMask:
     def mask(self, global_step: int, device) -> Tensor:
         lvl = min(self.start_level + max(global_step - self.start_step, 0) // self.update_steps, self.n_levels)
         self.current_level = lvl
-        m = torch.zeros(self.n_levels * self.F, device=device)
-        m[: lvl * self.F] = 1.0
+        key = (lvl, str(device))
+        cache = self.__dict__.setdefault("_masks", {})          # one tensor per (level count, device), kept: not one per call
+        m = cache.get(key)
+        if m is None:
+            m = torch.zeros(self.n_levels * self.F, device=device)
+            m[: lvl * self.F] = 1.0
+            cache[key] = m
         return m
 
     def level_bits(self) -> int:
@@ -238,12 +330,22 @@ class VolumeSDF(nn.Module):
     def grid_params(self):
         return self.encoding.encoding.encoding.params
 
+    _SRC0 = list(range(3, 35)) + [0, 1, 2]                          # reference column order [xyz | hash] -> kernel order [hash | xyz]
+
+    def _effective_weights(self):
+        l0, l2 = self.network.layers[0], self.network.layers[2]
+        mask = self.prog.mask(self.global_step, l0.weight_v.device)
+        src, mul = _col_tables(self, "l0", self._SRC0, (mask, 3))
+        return l0.effective(src, mul), l0.bias, l2.effective(), l2.bias
+
     def effective_weights(self):
-        """kernel column order [hash(32) | xyz(3)], level mask folded into W1."""
-        W1 = self.network.layers[0].effective()                     # [64,35] reference order [xyz | hash]
-        mask = self.prog.mask(self.global_step, W1.device)
-        W1k = torch.cat([W1[:, 3:] * mask[None], W1[:, :3]], dim=1)
-        return W1k, self.network.layers[0].bias, self.network.layers[2].effective(), self.network.layers[2].bias
+        """kernel column order [hash(32) | xyz(3)], level mask folded into W1.  no_grad callers get the cached tensors of this
+        parameter epoch (see PARAM_EPOCH)."""
+        if torch.is_grad_enabled():
+            return self._effective_weights()
+        l0, l2 = self.network.layers[0], self.network.layers[2]
+        key = _cache_key((l0.weight_g, l0.weight_v, l0.bias, l2.weight_g, l2.weight_v, l2.bias), self.global_step)
+        return _cached_nograd(self, "eff", key, self._effective_weights)
 
     @torch.no_grad()
     def sdf_only(self, points: Tensor, normalized: bool = False) -> Tensor:
@@ -259,7 +361,7 @@ class VolumeSDF(nn.Module):
                 points = (points - 0.5) * self.scale + self.center
             return self.forward(points, with_grad=False, with_feature=False).contiguous()
         cfg = HASH
-        xp = points.contiguous() if normalized else ((points - self.center) / self.scale + 0.5).contiguous()
+        xp = points.contiguous() if normalized else normalize_points(points, self.center, self.scale)
         nb = int(L.lib().ia_hashgrid_fwd_scratch_bytes(L.i64(n), L.i32(cfg["n_levels"]), L.i32(0)))
         scratch = L.scratch("hash_levels", nb, xp.device)
         L.check(L.lib().ia_hashgrid_fwd_xcd(L.i64(n), L.ptr(xp), L.ptr(self.grid_params), L.i32(cfg["n_levels"]),
@@ -283,7 +385,7 @@ class VolumeSDF(nn.Module):
             if with_feature:
                 out.append(points.new_empty(0, 13))
             return out[0] if len(out) == 1 else out
-        xp = ((points - self.center) / self.scale + 0.5).contiguous()
+        xp = normalize_points(points, self.center, self.scale)
         if with_grad and n >= HASH_FWD_XCD_MIN and os.environ.get("IA_SDF_GRAD_LEVELS", "1") == "1":
             # big batches: one-table-at-a-time gather with Jacobian, level-major results straight into the head (no [n,32] rows, no
             # [n,32,3] Jacobian tensor, coalesced Jacobian reads in the gradient epilogue)
@@ -333,6 +435,10 @@ class LaplaceDensity(nn.Module):
 
     def get_beta(self):
         return self.beta.abs() + self.beta_min
+
+    def beta_value(self) -> Tensor:
+        """|beta| + beta_min as a detached [1] tensor for the no-grad kernels, cached per parameter epoch (see PARAM_EPOCH)."""
+        return _cached_nograd(self, "beta", _cache_key((self.beta,)), lambda: (self.get_beta().reshape(1).float(),))[0]
 
     def forward(self, sdf):
         beta = self.get_beta()
@@ -386,13 +492,24 @@ class VolumeRefDirRadiance(nn.Module):
     def grid_params(self):
         return self.xyz_encoding.encoding.encoding.params
 
-    def effective_weights(self):
-        """kernel column order [hash(32) | xyz(3) | feat(13) | sh(16) | normal(3)]; masks folded into W1."""
-        W1 = self.network.layers[0].weight                     # reference order [xyz(3) hash(32) feat(13) sh(16) normal(3)]
-        m = self.prog.mask(self.global_step, W1.device)
-        W1k = torch.cat([W1[:, 3:35] * m[None], W1[:, :3], W1[:, 35:48], W1[:, 48:64] * self.sh_mask, W1[:, 64:67]], 1)
+    _SRC0 = list(range(3, 35)) + [0, 1, 2] + list(range(35, 67))    # reference order [xyz(3) hash(32) feat(13) sh(16) normal(3)]
+
+    def _effective_weights(self):
         l = self.network.layers
+        W1 = l[0].weight
+        m = self.prog.mask(self.global_step, W1.device)
+        src, mul = _col_tables(self, "l0", self._SRC0, (m, 3, 13, self.sh_mask, 3))
+        W1k = _EffW.apply(0, None, W1, src, mul)
         return W1k, l[0].bias, l[2].weight, l[2].bias, l[4].weight, l[4].bias
+
+    def effective_weights(self):
+        """kernel column order [hash(32) | xyz(3) | feat(13) | sh(16) | normal(3)]; masks folded into W1.  no_grad callers get the
+        cached tensors of this parameter epoch (see PARAM_EPOCH)."""
+        if torch.is_grad_enabled():
+            return self._effective_weights()
+        l = self.network.layers
+        key = _cache_key((l[0].weight, l[0].bias, l[2].weight, l[2].bias, l[4].weight, l[4].bias, self.sh_mask), self.global_step)
+        return _cached_nograd(self, "eff", key, self._effective_weights)
 
     @torch.no_grad()
     def forward(self, points: Tensor, features: Tensor, refl01: Tensor, normal_world: Tensor, return_embedding=False):
@@ -402,7 +519,7 @@ class VolumeRefDirRadiance(nn.Module):
         if n == 0:
             e = points.new_empty(0, 3)
             return (e, points.new_empty(0, 32), e) if return_embedding else e
-        xp = ((points - self.center) / self.scale + 0.5).contiguous()
+        xp = normalize_points(points, self.center, self.scale)
         enc = hashgrid_forward(xp, self.grid_params)
         sh = sh4(refl01)
         segs = [(enc, 32, 1.0, 0.0), (xp, 3, 2.0, -1.0), (features.contiguous(), 13, 1.0, 0.0), (sh, 16, 1.0, 0.0),
@@ -443,16 +560,23 @@ class VolumeMaterial(nn.Module):
         self.metallic_scale, self.metallic_bias = 1.0, 0.0
 
     def effective_weights(self, hash_mask: Tensor):
-        """Lipschitz normalisation (network_utils.py:396-403) + kernel column order [hash(32) | xyz(3) | feat(13)]."""
+        """Lipschitz normalisation (network_utils.py:396-403) + kernel column order [hash(32) | xyz(3) | feat(13)].  no_grad callers
+        get the cached tensors of this parameter epoch (see PARAM_EPOCH)."""
+        if torch.is_grad_enabled():
+            return self._effective_weights(hash_mask)
+        n = self.network
+        ps = tuple(n.weights_per_layer) + tuple(n.biases_per_layer) + tuple(n.lipshitz_bound_per_layer)
+        key = _cache_key(ps, hash_mask.data_ptr(), hash_mask._version)
+        return list(_cached_nograd(self, "eff", key, lambda: self._effective_weights(hash_mask), keep=(hash_mask,)))
+
+    _SRC0 = list(range(3, 35)) + [0, 1, 2] + list(range(35, 48))    # reference input order: [xyz(3) hash(32) | feat(13)]
+
+    def _effective_weights(self, hash_mask: Tensor):
         out = []
         for i in range(3):
             w = self.network.weights_per_layer[i]
-            c = torch.nn.functional.softplus(self.network.lipshitz_bound_per_layer[i])
-            scale = torch.clamp(c / w.abs().sum(dim=1), max=1.0)
-            w = w * scale[:, None]
-            if i == 0:      # reference input order: [xyz(3) hash(32) | feat(13)]
-                w = torch.cat([w[:, 3:35] * hash_mask[None], w[:, :3], w[:, 35:48]], 1)
-            out += [w, self.network.biases_per_layer[i]]
+            src, mul = _col_tables(self, "l0", self._SRC0, (hash_mask, 3, 13)) if i == 0 else (None, None)
+            out += [_EffW.apply(2, self.network.lipshitz_bound_per_layer[i], w, src, mul), self.network.biases_per_layer[i]]
         return out
 
     def lipshitz_bound_full(self) -> Tensor:

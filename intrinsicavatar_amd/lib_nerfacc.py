@@ -25,7 +25,7 @@ def _resample_info(packed_info: Tensor, n: int, add_steps: bool) -> Tuple[Tensor
     n_rays = packed_info.shape[0]
     dev = packed_info.device
     rpi = torch.empty((n_rays, 2), dtype=torch.int32, device=dev)
-    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)          # written by the scan
     tmp = L.scan_tmp(n_rays, dev, extra_bytes=8 * n_rays + 64)
     L.check(L.lib().ia_resample_packed_info(L.i64(n_rays), L.ptr(packed_info), L.i32(n), L.i32(int(add_steps)),
                                             L.ptr(rpi), L.ptr(total), L.ptr(tmp), L.stream()),
@@ -111,7 +111,7 @@ def ray_resampling_merge_compact(packed_info: Tensor, vals: Tensor, is_left: Ten
     n_rays, dev = packed_info.shape[0], packed_info.device
     lib, st = L.lib(), L.stream()
     cnt, start = (torch.empty(n_rays, dtype=torch.int32, device=dev) for _ in range(2))
-    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)          # written by the scan
     tmp = _resample_tmp(n_rays, vals.shape[0], n_samples, dev)
     L.check(lib.ia_ray_resampling_merge_count(L.i64(n_rays), L.i64(vals.shape[0]), L.i32(n_samples), L.ptr(packed_info), L.ptr(vals),
                                               L.ptr(il), L.ptr(ir), L.ptr(w), L.ptr(cnt), L.ptr(start), L.ptr(total), L.ptr(tmp),
@@ -178,7 +178,7 @@ def compact_foreground(resampled_packed_info: Tensor, starts: Tensor, ends: Tens
     st_, en_ = starts.reshape(-1).contiguous().float(), ends.reshape(-1).contiguous().float()
     lib, st = L.lib(), L.stream()
     cnt, start = (torch.empty(n_rays, dtype=torch.int32, device=dev) for _ in range(2))
-    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)          # written by the scan
     L.check(lib.ia_fg_count(L.i64(n_rays), L.ptr(rpi), L.ptr(fg), L.ptr(cnt), L.ptr(start), L.ptr(total), L.ptr(L.scan_tmp(n_rays, dev)), st),
             "ia_fg_count")
     F_ = int(total.item())
@@ -228,7 +228,7 @@ def interval_samples(packed_info: Tensor, vals: Tensor, is_left: Tensor, ray_ind
         raise RuntimeError("vals, is_left and ray_indices must have one entry per edge")
     lib, st = L.lib(), L.stream()
     pos = torch.empty(n_edges, dtype=torch.int32, device=dev)
-    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)          # written by the scan
     L.check(lib.ia_interval_samples_count(L.i64(n_edges), L.ptr(il), L.ptr(pos), L.ptr(total), L.ptr(L.scan_tmp(n_edges, dev)), st),
             "ia_interval_samples_count")
     S = int(total.item())

@@ -33,16 +33,28 @@ class RayIntervals:
         return self.vals.device
 
 
-@dataclass
 class RaySamples:
-    """nerfacc.data_specs.RaySamples: packed samples (interval mid-points)."""
-    vals: Tensor
-    packed_info: Optional[Tensor] = None
-    ray_indices: Optional[Tensor] = None
-    is_valid: Optional[Tensor] = None
-    # extension (None when not produced): the interval ends per sample = intervals.vals[is_left] / intervals.vals[is_right]
-    t_starts: Optional[Tensor] = None
-    t_ends: Optional[Tensor] = None
+    """nerfacc.data_specs.RaySamples: packed samples (interval mid-points).  Same constructor arguments and attributes as the dataclass;
+    `is_valid` (all true for a grid traversal, read by nothing on the render_step path) is materialised on first read instead of costing
+    a fill launch per traversal."""
+
+    def __init__(self, vals: Tensor, packed_info: Optional[Tensor] = None, ray_indices: Optional[Tensor] = None,
+                 is_valid: Optional[Tensor] = None, t_starts: Optional[Tensor] = None, t_ends: Optional[Tensor] = None,
+                 all_valid: bool = False):
+        self.vals, self.packed_info, self.ray_indices = vals, packed_info, ray_indices
+        self._is_valid, self._all_valid = is_valid, all_valid
+        # extension (None when not produced): the interval ends per sample = intervals.vals[is_left] / intervals.vals[is_right]
+        self.t_starts, self.t_ends = t_starts, t_ends
+
+    @property
+    def is_valid(self) -> Optional[Tensor]:
+        if self._is_valid is None and self._all_valid:
+            self._is_valid = torch.ones(self.vals.shape[0], dtype=torch.bool, device=self.vals.device)
+        return self._is_valid
+
+    @is_valid.setter
+    def is_valid(self, v):
+        self._is_valid = v
 
     @property
     def device(self):
@@ -121,7 +133,7 @@ def traverse_grids(
     scratch = torch.empty(int(lib.ia_traverse_scratch_bytes(L.i64(n_rays))), dtype=torch.uint8, device=dev)
     pcnt = torch.empty(n_rays, dtype=torch.int64, device=dev)          # n_edges | n_samples << 32
     pstart = torch.empty(n_rays, dtype=torch.int64, device=dev)
-    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    total = torch.empty(1, dtype=torch.int64, device=dev)               # written by the scan
     L.check(lib.ia_traverse_grids_count(*args, L.ptr(scratch), L.ptr(pcnt), st), "ia_traverse_grids_count")
     tmp = L.scan_tmp(n_rays, dev)
     L.check(lib.ia_exclusive_scan_i64(L.ptr(pcnt), L.ptr(pstart), L.ptr(total), L.i64(n_rays), L.ptr(tmp), st), "scan")
@@ -140,8 +152,7 @@ def traverse_grids(
                                        L.ptr(sm_vals), L.ptr(sm_ray), L.ptr(term), st), "ia_traverse_grids_fill")
     intervals = RayIntervals(vals=iv_vals, packed_info=pinfo[0], ray_indices=iv_ray,
                              is_left=iv_flags[0], is_right=iv_flags[1])
-    samples = RaySamples(vals=sm_vals, packed_info=pinfo[1], ray_indices=sm_ray,
-                         is_valid=torch.ones(S, dtype=torch.bool, device=dev))
+    samples = RaySamples(vals=sm_vals, packed_info=pinfo[1], ray_indices=sm_ray, all_valid=True)
     return intervals, samples, (term if termination_planes else None)
 
 
@@ -190,8 +201,8 @@ def _traverse_fused(args, n_rays, aabb, step_size, max_extent, dev, incoherent=F
         return None
     intervals = RayIntervals(vals=iv_vals[:E], packed_info=pinfo[0], ray_indices=iv_ray[:E],
                              is_left=iv_flags[0, :E], is_right=iv_flags[1, :E])
-    samples = RaySamples(vals=sm_vals[:S], packed_info=pinfo[1], ray_indices=sm_ray[:S],
-                         is_valid=torch.ones(S, dtype=torch.bool, device=dev), t_starts=sm_ends[0, :S], t_ends=sm_ends[1, :S])
+    samples = RaySamples(vals=sm_vals[:S], packed_info=pinfo[1], ray_indices=sm_ray[:S], all_valid=True,
+                         t_starts=sm_ends[0, :S], t_ends=sm_ends[1, :S])
     return intervals, samples, term
 
 
@@ -213,6 +224,7 @@ class _WeightFromAlpha(torch.autograd.Function):
         L.check(L.lib().ia_render_weight_from_alpha(L.i64(packed_info.shape[0]), L.ptr(packed_info), L.ptr(alphas),
                                                     L.ptr(w), L.ptr(t), L.stream()), "ia_render_weight_from_alpha")
         ctx.save_for_backward(alphas, packed_info, w, t)
+        ctx.set_materialize_grads(False)          # an unused output's gradient arrives as None (NULL in the kernel), not as a zero fill
         return w, t
 
     @staticmethod

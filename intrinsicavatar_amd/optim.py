@@ -35,6 +35,9 @@ class Adam(torch.optim.Optimizer):
                                       maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
                                       decoupled_weight_decay=False))
         self.grad_scale = float(grad_scale)
+        # parameter -> (the state's `step` tensor, the 0-d numpy array it is a view of): the count is bumped by writing the array --
+        # 27 host-tensor increments + .item() per step otherwise, and the 4096-ray step is bound by the host's launch rate
+        self._t = {}
 
     def _init_state(self, p):
         st = self.state[p]
@@ -65,8 +68,14 @@ class Adam(torch.optim.Optimizer):
                 if p.dtype != torch.float32 or p.grad.dtype != torch.float32:
                     raise RuntimeError("intrinsicavatar_amd.optim.Adam: fp32 parameters only")
                 st = self._init_state(p)
-                st["step"] += 1
-                t = int(st["step"].item())
+                ent = self._t.get(p)
+                if ent is None or ent[0] is not st["step"]:          # first step, or the state was replaced (load_state_dict)
+                    import numpy as np
+                    arr = np.array(float(st["step"]), dtype=np.float32)
+                    ent = self._t[p] = (torch.from_numpy(arr), arr)
+                    st["step"] = ent[0]
+                t = int(ent[1]) + 1
+                ent[1][...] = t
                 bc1 = 1.0 - b1 ** t
                 bc2_sqrt = math.sqrt(1.0 - b2 ** t)
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
@@ -84,6 +93,9 @@ class Adam(torch.optim.Optimizer):
                 N[i], S[i], W[i] = p.numel(), step_size, wd
             L.check(L.lib().ia_adam_step(L.i32(n), P, G, M, V, N, S, W, L.f32(b1), L.f32(b2), L.f32(eps), L.f32(bc2_sqrt),
                                          L.f32(self.grad_scale), L.stream()), "ia_adam_step")
+        if batches:
+            from . import fields
+            fields.params_changed()          # the kernel wrote the parameters through raw pointers: Tensor._version did not move
         return loss
 
 

@@ -93,15 +93,25 @@ class EnvironmentLightTensor(torch.nn.Module):
             u = torch.rand((n_theta * n_phi, 2), device=dev)
         return uniform_sphere_stratified(n_theta, n_phi, u.to(dev))
 
+    PDF_KERNEL_MAX_PIXELS = 1 << 18
+
     @torch.no_grad()
     def update_pdf(self):
         H, W, _ = self.base.shape
         base = self.base.detach()
-        sin_t = torch.sin((torch.arange(H, device=base.device) + 0.5) * math.pi / H)[:, None]
-        lum = (0.2126 * base[..., 0] + 0.7152 * base[..., 1] + 0.0722 * base[..., 2]).clamp_min(0).double()
-        w = lum * sin_t
-        self.pmf = (w / w.sum()).float().contiguous()
-        self._cdf = torch.cumsum(self.pmf.reshape(-1).double(), 0)
+        # pmf = luminance x sin(theta), normalised in double; cdf = running sum of the fp32 pmf in double: one launch (the training
+        # path rebuilds the tables every step, :777-781)
+        if H * W <= self.PDF_KERNEL_MAX_PIXELS:
+            self.pmf = torch.empty((H, W), device=base.device)
+            self._cdf = torch.empty(H * W, dtype=torch.float64, device=base.device)
+            L.check(L.lib().ia_envlight_pdf_tables(L.i32(H), L.i32(W), L.ptr(base), L.ptr(self.pmf), L.ptr(self._cdf), L.stream()),
+                    "ia_envlight_pdf_tables")
+        else:        # a 1024 x 2048 HDRI, once per light: the one-workgroup kernel would take milliseconds
+            sin_t = torch.sin((torch.arange(H, device=base.device) + 0.5) * math.pi / H)[:, None]
+            lum = (0.2126 * base[..., 0] + 0.7152 * base[..., 1] + 0.0722 * base[..., 2]).clamp_min(0).double()
+            w = lum * sin_t
+            self.pmf = (w / w.sum()).float().contiguous()
+            self._cdf = torch.cumsum(self.pmf.reshape(-1).double(), 0)
         self._pdf_key = (self.base.data_ptr(), self.base._version, str(self.base.device), tuple(self.base.shape))
 
     @torch.no_grad()
@@ -139,6 +149,29 @@ class EnvironmentLightTensor(torch.nn.Module):
         return self._eval(d_world, False, True)[1][:, None]
 
 
+class _SGImage(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, axis, log_lambda, mu, H, W):
+        axis, log_lambda, mu = axis.contiguous().float(), log_lambda.contiguous().float(), mu.contiguous().float()
+        K = axis.shape[0]
+        out = torch.empty((H, W, 3), device=axis.device)
+        L.check(L.lib().ia_sg_image(L.i32(K), L.i32(H), L.i32(W), L.ptr(axis), L.ptr(log_lambda), L.ptr(mu), L.ptr(out), L.stream()), "ia_sg_image")
+        ctx.save_for_backward(axis, log_lambda, mu)
+        ctx.hw = (H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_img):
+        axis, log_lambda, mu = ctx.saved_tensors
+        K = axis.shape[0]
+        H, W = ctx.hw
+        tmp = torch.empty(int(L.lib().ia_sg_image_bwd_tmp_bytes(L.i32(K))), dtype=torch.uint8, device=axis.device)
+        g_axis, g_ll, g_mu = torch.empty_like(axis), torch.empty_like(log_lambda), torch.empty_like(mu)
+        L.check(L.lib().ia_sg_image_bwd(L.i32(K), L.i32(H), L.i32(W), L.ptr(axis), L.ptr(log_lambda), L.ptr(mu), L.ptr(g_img.contiguous().float()),
+                                        L.ptr(tmp), L.ptr(g_axis), L.ptr(g_ll), L.ptr(g_mu), L.stream()), "ia_sg_image_bwd")
+        return g_axis, g_ll, g_mu, None, None
+
+
 class EnvironmentLightSG(torch.nn.Module):
     """`envlight-SG` (configs/light/envlight_SG.yaml: num_SGs 64, base_res 256): the training-time emitter.  lib/torch_pbr
     is an empty submodule, so the parametrisation is the standard spherical-Gaussian mixture (PhySG / nvdiffrecmc):
@@ -170,6 +203,13 @@ class EnvironmentLightSG(torch.nn.Module):
         return torch.stack([torch.sin(th) * torch.sin(ph), torch.cos(th).expand(H, W), -torch.sin(th) * torch.cos(ph)], -1)
 
     def generate_image(self) -> Tensor:
+        """[H,W,3] image of the lobes, differentiable w.r.t. axis / log_lambda / mu: ia_sg_image / _bwd, one launch each way (the torch
+        expression -- two [HW,K] GEMMs and ~30 element-wise launches with their backward -- is generate_image_torch)."""
+        if not self.axis.is_cuda:
+            return self.generate_image_torch()
+        return _SGImage.apply(self.axis, self.log_lambda, self.mu, self.base_res, 2 * self.base_res)
+
+    def generate_image_torch(self) -> Tensor:
         d = self._dirs(self.axis.device)                                          # [H,W,3], same convention as the kernels
         xi = torch.nn.functional.normalize(self.axis, dim=-1)
         lam = torch.exp(self.log_lambda)
@@ -286,6 +326,7 @@ class _PbrShade(torch.autograd.Function):
                                      L.ptr(None), L.stream()), "ia_pbr_shade")
         ctx.mode = mode
         ctx.save_for_backward(normal, albedo, roughness, metallic, env_base, view_dirs, out_dirs, tr, ind, inv_pdf, env_pmf, w2s_rot)
+        ctx.set_materialize_grads(False)
         return Lo, Ld, Ls
 
     @staticmethod
@@ -342,13 +383,14 @@ def uniform_sphere_stratified(n_theta: int, n_phi: int, u: Tensor):
     (shuffled indices are in [0, 512): intrinsic_avatar.py:1393-1401,680-689).  Equal-area strata in (cos theta, phi),
     one jittered direction per stratum (u [n_theta*n_phi, 2]); pdf = 1/(4 pi).  returns (dirs [K,3], inv_pdf [K,1])."""
     dev = u.device
-    i = torch.arange(n_theta, device=dev).repeat_interleave(n_phi).float()
-    j = torch.arange(n_phi, device=dev).repeat(n_theta).float()
-    z = 1.0 - 2.0 * (i + u[:, 0]) / n_theta
-    phi = 2.0 * math.pi * (j + u[:, 1]) / n_phi
-    r = torch.sqrt((1.0 - z * z).clamp_min(0.0))
-    dirs = torch.stack([r * torch.cos(phi), r * torch.sin(phi), z], -1)
-    return dirs, torch.full((n_theta * n_phi, 1), 4.0 * math.pi, device=dev)
+    K = n_theta * n_phi
+    if u.shape[0] < K or u.shape[1] < 2:
+        raise RuntimeError("uniform_sphere_stratified: u must be [n_theta * n_phi, 2]")
+    u2 = u[:K, :2].contiguous().float()
+    dirs, inv_pdf = torch.empty((K, 3), device=dev), torch.empty((K, 1), device=dev)
+    L.check(L.lib().ia_uniform_sphere_stratified(L.i32(n_theta), L.i32(n_phi), L.ptr(u2), L.ptr(dirs), L.ptr(inv_pdf), L.stream()),
+            "ia_uniform_sphere_stratified")
+    return dirs, inv_pdf
 
 
 def pbr_light_shade(normal, albedo, roughness, metallic, view_dirs, light_dirs, transmittance, indirect_rgb,
@@ -388,12 +430,12 @@ class VolumeInteraction:
         L.check(lib.ia_vi_layout(L.i64(n_rays), L.i32(spp), L.ptr(self.resampled_packed_info), L.ptr(self.bg_counts),
                                  L.ptr(self.fg_ray_cnt), st), "ia_vi_layout")
         self.fg_start = torch.empty(n_rays, dtype=torch.int32, device=dev)
-        total = torch.zeros(1, dtype=torch.int32, device=dev)
+        total = torch.empty(1, dtype=torch.int32, device=dev)          # written by the scan
         tmp = L.scan_tmp(max(n_rays, self.S), dev)
         L.check(lib.ia_exclusive_scan_i32(L.ptr(self.fg_ray_cnt), L.ptr(self.fg_start), L.ptr(total), L.i64(n_rays), L.ptr(tmp), st),
                 "scan")
         self.fg_off = torch.empty(self.S, dtype=torch.int32, device=dev)          # per source interval (gather backward)
-        tot2 = torch.zeros(1, dtype=torch.int32, device=dev)
+        tot2 = torch.empty(1, dtype=torch.int32, device=dev)
         L.check(lib.ia_exclusive_scan_i32(L.ptr(self.fg_counts), L.ptr(self.fg_off), L.ptr(tot2), L.i64(self.S), L.ptr(tmp), st), "scan")
         self.F = int(total.item())
         self.fg_src = self.fg_ray = self.positions = self.view_dirs = None
@@ -512,7 +554,7 @@ def secondary_rays(normals: Tensor, positions: Tensor, dirs: Tensor, dir_index: 
     flag = torch.empty(F_, dtype=torch.int32, device=dev)
     L.check(lib.ia_secondary_mask(L.i64(F_), L.ptr(normals), L.ptr(dirs), L.ptr(dir_index), L.ptr(flag), st), "ia_secondary_mask")
     slot = torch.empty(F_, dtype=torch.int32, device=dev)
-    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)          # written by the scan
     tmp = L.scan_tmp(F_, dev)
     L.check(lib.ia_exclusive_scan_i32(L.ptr(flag), L.ptr(slot), L.ptr(total), L.i64(F_), L.ptr(tmp), st), "scan")
     M = int(total.item())
@@ -529,7 +571,8 @@ def scatter_secondary(F_: int, src: Tensor, tr: Tensor, rgb: Tensor):
     """traced (transmittance [M,1], rgb [M,3]) back into dense [F,1] / [F,3] (zeros for masked points), transmittance
     clamped to [0, 1] (:796-803)."""
     dev = src.device
-    d_tr, d_rgb = torch.zeros((F_, 1), device=dev), torch.zeros((F_, 3), device=dev)
+    buf = torch.zeros(F_ * 4, device=dev)                     # one fill for both
+    d_tr, d_rgb = buf[:F_].view(F_, 1), buf[F_:].view(F_, 3)
     L.check(L.lib().ia_secondary_scatter(L.i64(src.shape[0]), L.ptr(src), L.ptr(tr.reshape(-1).float().contiguous()),
                                          L.ptr(rgb.float().contiguous()), L.ptr(d_tr), L.ptr(d_rgb), L.stream()), "ia_secondary_scatter")
     return d_tr, d_rgb

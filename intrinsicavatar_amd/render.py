@@ -94,7 +94,20 @@ class RenderStep:
 
     # ------------------------------------------------------------------ helpers
     def _beta(self) -> Tensor:
-        return self.density.get_beta().detach().reshape(1).float().contiguous()
+        d = self.density
+        return d.beta_value() if hasattr(d, "beta_value") else d.get_beta().detach().reshape(1).float().contiguous()
+
+    _CONST = {}
+
+    @classmethod
+    def _const(cls, value: float, n: int, dev) -> Tensor:
+        """[n] float tensor filled with `value`: a view of a cached, grow-only constant (near / far planes of every march: two fill
+        launches per call otherwise).  Read-only by convention."""
+        key = (float(value), str(dev), torch.cuda.current_stream(dev).cuda_stream if str(dev).startswith("cuda") else 0)
+        t = cls._CONST.get(key)
+        if t is None or t.shape[0] < n:
+            t = cls._CONST[key] = torch.full((max(n + n // 4, 4096),), float(value), device=dev)
+        return t[:n]
 
     SORT_MIN_POINTS = 1 << 20
     # points per deformer search: P * 13 (point, init) items must stay below 2^31 (165.2 M points) and x / valid take 169 B per
@@ -160,8 +173,8 @@ class RenderStep:
         rays_o, rays_d, far = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous(), rays[:, 7]
         beta = self._beta()
         # -- 2. primary march (sampling_override, intrinsic_avatar.py:49-141; near 0 / far 1e10)
-        near_planes = torch.zeros(n_rays, device=rays.device)
-        far_planes = torch.full((n_rays,), 1e10, device=rays.device)
+        near_planes = self._const(0.0, n_rays, rays.device)
+        far_planes = self._const(1e10, n_rays, rays.device)
         if jitter is not None:
             near_planes = near_planes + jitter * self.render_step_size
         intervals, samples, _ = nerfacc.traverse_grids(rays_o, rays_d, self.binaries, self.aabbs, near_planes, far_planes,
@@ -176,8 +189,9 @@ class RenderStep:
                 if it == 0:        # coarse_alpha_fn: SDF at every edge, interval sdf = min(left, right)
                     pts = ray_points(rays_o, rays_d, intervals.ray_indices, vals)
                     sdf = self._sdf_at(pts)
-                    nxt = torch.cat([sdf[1:], sdf[-1:]])
-                    sdf_merge = torch.where(intervals.is_left, torch.minimum(sdf, nxt), torch.full_like(sdf, 1e10))
+                    sdf_merge = torch.empty_like(sdf)          # is_left ? min(sdf, next sdf) : 1e10, one launch
+                    L.check(L.lib().ia_edge_min_sdf(L.i64(sdf.shape[0]), L.ptr(sdf), L.ptr(intervals.is_left), L.ptr(sdf_merge), L.stream()),
+                            "ia_edge_min_sdf")
                     alphas = laplace_alpha(sdf_merge, self.render_step_size, beta)
                 else:              # alpha_fn: SDF at interval mid-points
                     smp = lib_nerfacc.interval_samples(intervals.packed_info, vals, intervals.is_left, intervals.ray_indices)
@@ -246,20 +260,34 @@ class RenderStep:
                               shuffle_u: Tensor, target_mask: Optional[Tensor] = None, jitter: Optional[Tensor] = None,
                               render_mode: str = "uniform_light", env_base: Optional[Tensor] = None,
                               background_color: Optional[Tensor] = None, global_illumination: bool = False,
-                              light_sampling: str = "shared", loss_scale: float = 1.0, retain_graph: bool = False
-                              ) -> Dict[str, Tensor]:
+                              light_sampling: str = "shared", loss_scale: float = 1.0, retain_graph: bool = False,
+                              material_jitter: Optional[Tensor] = None, loss_config: Optional[dict] = None) -> Dict[str, Tensor]:
         """BASELINE config 4: training step with the PBR branch (material head, volume scattering, secondary rays,
         light / uniform_light estimator) -- fwd + bwd to geometry, radiance, material and environment-light parameters.
         loss_scale: weight of this ray chunk when a frame is processed in several chunks with gradient accumulation
         (n_chunk_rays / n_frame_rays makes the accumulated gradient that of the frame-mean loss); retain_graph: keep the
-        graph of `env_base` (one generated environment image shared by all chunks of a step)."""
+        graph of `env_base` (one generated environment image shared by all chunks of a step).
+        material_jitter [n_samples,3] ~ N(0,1): the material jitter pass (:1116-1140) for the smoothness maps.
+        loss_config: None = training_loss_phys (L1 rgb + eikonal + mask BCE + L1 rgb_phys on the linear maps); a dict of the
+        reference's `system.loss` weights (configs/config.yaml:87-109: lambda_rgb_l1, lambda_rgb_phys_l1, lambda_mask_bce, ...) = the
+        loss of IntrinsicAvatarSystem.training_step (systems/intrinsic_avatar.py:160-301) on the reference's output dict
+        (train_phys.reference_training_loss; target_rgb / target_mask are the batch's `rgb` / `alpha`); its terms come back as
+        out["loss_terms"].  tests/test_gpu_backward_golden.py holds this call to the reference's own autograd."""
         from . import train_phys
         rays_o, rays_d, far, t_starts, t_ends, ray_indices, packed_info, stats = self.sample(rays, jitter)
         out = train_phys.shade_differentiable_phys(self, material, emitter, rays_o, rays_d, ray_indices, t_starts, t_ends,
                                                    packed_info, spp, light_u, shuffle_u, render_mode=render_mode,
                                                    env_base=env_base, background_color=background_color,
-                                                   global_illumination=global_illumination, light_sampling=light_sampling)
-        loss = train_phys.training_loss_phys(out, target_rgb, target_mask)
+                                                   global_illumination=global_illumination, light_sampling=light_sampling,
+                                                   jitter_n=material_jitter)
+        if loss_config is None:
+            loss = train_phys.training_loss_phys(out, target_rgb, target_mask)
+        else:
+            if background_color is None:
+                background_color = torch.ones(3, device=rays.device)
+            d = self._training_dict(out, rays.shape[0], far, t_starts, t_ends, ray_indices, packed_info, background_color, render_mode)
+            loss, out["loss_terms"] = train_phys.reference_training_loss(d, target_rgb, target_mask, loss_config, material)
+            out["output_dict"] = d
         (loss * loss_scale if loss_scale != 1.0 else loss).backward(retain_graph=retain_graph)
         out["loss"] = loss.detach()
         out["stats"].update(stats)
@@ -382,7 +410,7 @@ class RenderStep:
             ro, rd = rays_o[c0:c1].contiguous(), rays_d[c0:c1].contiguous()
             m = ro.shape[0]
             intervals, samples, _ = nerfacc.traverse_grids(
-                ro, rd, self.binaries, self.aabbs, torch.full((m,), near, device=dev), torch.full((m,), far, device=dev),
+                ro, rd, self.binaries, self.aabbs, self._const(near, m, dev), self._const(far, m, dev),
                 step, 0.0, grid_bits=self.grid_bits, max_extent=far - near, incoherent=True, termination_planes=False)
             if samples.vals.shape[0] > 4 * self.MAX_SEARCH_POINTS and m > 1:
                 del intervals, samples
@@ -592,6 +620,13 @@ class RenderStep:
             self, material, emitter, rays_o, rays_d, ray_indices, t_starts, t_ends, packed_info, spp, light_u, shuffle_u,
             render_mode=render_mode, env_base=env_base, background_color=background_color, global_illumination=global_illumination,
             jitter_n=material_jitter, light_sampling="per_point" if render_mode == "light" else "shared")
+        d = self._training_dict(res, rays.shape[0], far, t_starts, t_ends, ray_indices, packed_info, background_color, render_mode)
+        d["stats"] = dict(res["stats"], **stats)
+        return d
+
+    def _training_dict(self, res, n_rays, far, t_starts, t_ends, ray_indices, packed_info, background_color, render_mode):
+        """the output dict of forward_ in train() mode (:1492-1651) from shade_differentiable_phys's result."""
+        dev = far.device
         mid = (t_starts + t_ends) / 2.0
         depth = nerfacc._Accumulate.apply(res["weights"].detach(), mid[:, None].contiguous(), ray_indices, packed_info)
         T = 1.0 - res["opacity"]
@@ -599,13 +634,18 @@ class RenderStep:
         if "volume_interaction" in res:
             o["comp_demod_phys"] = res["volume_interaction"].composite(res["fg_weights"], (res["fg_Lo_diff"] + res["fg_Lo_spec"]).contiguous(),
                                                                        T, background_color)
-        z1 = torch.zeros((rays.shape[0], 1), device=rays.device)
+        z1 = torch.zeros((n_rays, 1), device=dev)
         o.update(sdf_samples=res["sdf"], sdf_grad_samples=res["sdf_grad"], sdf_laplace_samples=torch.zeros_like(res["sdf"]),
                  points=mid, intervals=t_ends - t_starts, ray_indices=ray_indices)
         for k in ("normals_orientation_loss_map", "albedo_smoothness_loss_map", "roughness_smoothness_loss_map", "metallic_smoothness_loss_map"):
             o.setdefault(k, z1)
         if render_mode == "uniform_light":
+            if "volume_interaction" in res and "visibility" not in o:
+                # vis = 2 * secondary transmittance per foreground re-sample (pbr_uniform_light_forward :741), composited with the
+                # re-sampling weights, no background (:1427-1470); a monitoring map: no gradient, built only for the output dict
+                with torch.no_grad():
+                    vis3 = (2.0 * res["secondary_tr"]).expand(-1, 3).contiguous()
+                    o["visibility"] = res["volume_interaction"].composite(res["fg_weights"].detach(), vis3, torch.zeros_like(T),
+                                                                          torch.zeros(3, device=dev)).mean(-1, keepdim=True)
             o.setdefault("visibility", z1)
-        d = self.output_dict(o, background_color, render_mode, int(t_starts.shape[0]))
-        d["stats"] = dict(res["stats"], **stats)
-        return d
+        return self.output_dict(o, background_color, render_mode, int(t_starts.shape[0]))

@@ -71,7 +71,7 @@ class _SDFField(Function):
     @staticmethod
     def forward(ctx, x, table, W1k, b1, W2, b2, center, scale, level_bits=0xFFFFFFFF, inv_scale_host=None):
         ctx.level_bits = int(level_bits)
-        xp = ((x - center) / scale + 0.5).contiguous()
+        xp = fields.normalize_points(x, center, scale) if not x.requires_grad else ((x - center) / scale + 0.5).contiguous()
         enc, jac = fields.hashgrid_forward(xp, table, with_jac=True)
         inv = inv_scale_host if inv_scale_host is not None else (1.0 / scale).tolist()      # the fallback is a host sync
         y, grad = fields.mlp_forward(0, [(enc, 32, 1.0, 0.0), (xp, 3, 2.0, -1.0)], W1k, b1, None, None, W2, b2, 13,
@@ -89,8 +89,7 @@ class _SDFField(Function):
         ns, ptrs, strides, widths, muls, adds = _segs([(enc, 32, 1.0, 0.0), (xp, 3, 2.0, -1.0)])
         g_table = torch.zeros_like(table)
         if FUSED_WGRAD:
-            dW1k, db1 = torch.zeros((64, 35), device=dev), torch.zeros(64, device=dev)
-            dW2, db2 = torch.zeros((13, 64), device=dev), torch.zeros(13, device=dev)
+            dW1k, db1, dW2, db2 = zeros_like_shapes([(64, 35), (64,), (13, 64), (13,)], dev)
             want_x = ctx.needs_input_grad[0]
             g_xyz = torch.empty((n, 3), device=dev) if want_x else None
             L.check(L.lib().ia_sdf_mlp_bwd_fused(L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds, L.ptr(W1k), L.ptr(b1),
@@ -126,20 +125,18 @@ class _ShadePrep(Function):
         sdf_grad = sdf_grad.contiguous()
         ns, nw, rf = render.shade_prep(sdf_grad, rays_d, ray_indices, w2s_rot)
         ctx.save_for_backward(sdf_grad, rays_d, ray_indices, w2s_rot, ns)
+        ctx.set_materialize_grads(False)
         return ns, nw, rf
 
     @staticmethod
     def backward(ctx, g_ns, g_nw, g_rf):
         sdf_grad, rays_d, ray_indices, w2s_rot, ns = ctx.saved_tensors
         n = sdf_grad.shape[0]
-        g_nw = g_nw.contiguous() if g_nw is not None else None
-        g_rf = g_rf.contiguous() if g_rf is not None else torch.zeros_like(sdf_grad)
+        cg = lambda t: t.contiguous() if t is not None else None      # noqa: E731  (a missing gradient is NULL: zero inside the kernel)
         out = torch.empty_like(sdf_grad)
+        # g_ns: normal_smpl = g / max(|g|, 1e-6), read by the BRDF of the PBR branch only
         L.check(L.lib().ia_shade_prep_bwd(L.i64(n), L.ptr(sdf_grad), L.ptr(rays_d), L.ptr(ray_indices), L.ptr(w2s_rot),
-                                          L.ptr(g_nw), L.ptr(g_rf), L.ptr(out), L.stream()), "ia_shade_prep_bwd")
-        if g_ns is not None:      # normal_smpl = g / max(|g|, 1e-6): used by the BRDF of the PBR branch only
-            nrm = torch.linalg.norm(sdf_grad, dim=-1, keepdim=True).clamp_min(1e-6)
-            out = out + (g_ns - (g_ns * ns).sum(-1, keepdim=True) * ns) / nrm
+                                          L.ptr(cg(g_nw)), L.ptr(cg(g_rf)), L.ptr(cg(g_ns)), L.ptr(out), L.stream()), "ia_shade_prep_bwd")
         return out, None, None, None
 
 
@@ -158,6 +155,7 @@ class _SelectPush(Function):
                 "ia_select_push")
         ctx.save_for_backward(valid, c2w)
         ctx.mark_non_differentiable(c2w)
+        ctx.set_materialize_grads(False)
         return feat, sdf, sdf_grad, c2w
 
     @staticmethod
@@ -194,6 +192,43 @@ class _Eikonal(Function):
         L.check(L.lib().ia_eikonal_bwd(L.i64(sdf_grad.shape[0]), L.ptr(sdf_grad), L.ptr(valid), L.ptr(w), L.ptr(out), L.stream()),
                 "ia_eikonal_bwd")
         return out, None
+
+
+class _EikonalPartials(Function):
+    """sdf_grad [n,3], valid [n] -> the per-workgroup partial sums [k,2] of ia_eikonal as they are (column 0: sum over valid of
+    (|g| - 1)^2): train_phys._PhysLoss adds them up inside its own kernel.  The gradient that comes back is the SAME scalar for every
+    partial (d loss / d sum), read from the first element."""
+
+    @staticmethod
+    def forward(ctx, sdf_grad, valid):
+        n = sdf_grad.shape[0]
+        sdf_grad = sdf_grad.contiguous()
+        k = int(L.lib().ia_eikonal_partials(L.i64(n)))
+        part = torch.empty((k, 2), device=sdf_grad.device) if k > 0 else torch.zeros((1, 2), device=sdf_grad.device)
+        L.check(L.lib().ia_eikonal(L.i64(n), L.ptr(sdf_grad), L.ptr(valid), L.ptr(part), L.stream()), "ia_eikonal")
+        ctx.save_for_backward(sdf_grad, valid)
+        return part
+
+    @staticmethod
+    def backward(ctx, g_part):
+        sdf_grad, valid = ctx.saved_tensors
+        out = torch.empty_like(sdf_grad)
+        w = g_part.as_strided((1,), (1,))                     # d loss / d (sum): one scalar, whatever the view it arrived in
+        L.check(L.lib().ia_eikonal_bwd(L.i64(sdf_grad.shape[0]), L.ptr(sdf_grad), L.ptr(valid), L.ptr(w), L.ptr(out), L.stream()),
+                "ia_eikonal_bwd")
+        return out, None
+
+
+def zeros_like_shapes(shapes, dev):
+    """zero tensors of the given shapes as views of ONE zero-filled buffer (one fill launch instead of one per tensor; every view
+    starts at a multiple of 64 floats)."""
+    sizes = [int(math.prod(s)) for s in shapes]
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot)
+        tot += (n + 63) // 64 * 64
+    buf = torch.zeros(tot, device=dev)
+    return [buf[o:o + n].view(s) for o, n, s in zip(offs, sizes, shapes)]
 
 
 class _Alpha(Function):
@@ -242,9 +277,7 @@ class _Radiance(Function):
         segs = [(enc, 32, 1.0, 0.0), (xp, 3, 2.0, -1.0), (feat, 13, 1.0, 0.0), (sh, 16, 1.0, 0.0), (normal_world, 3, 1.0, 0.0)]
         ns, ptrs, strides, widths, muls, adds = _segs(segs)
         if FUSED_WGRAD:
-            dW1, db1 = torch.zeros((64, 67), device=dev), torch.zeros(64, device=dev)
-            dW2, db2 = torch.zeros((64, 64), device=dev), torch.zeros(64, device=dev)
-            dW3, db3 = torch.zeros((3, 64), device=dev), torch.zeros(3, device=dev)
+            dW1, db1, dW2, db2, dW3, db3 = zeros_like_shapes([(64, 67), (64,), (64, 64), (64,), (3, 64), (3,)], dev)
             L.check(L.lib().ia_mlp_bwd_fused(L.i32(1), L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds, L.ptr(W1k),
                                              L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3), L.ptr(g_rgb), L.ptr(g_x),
                                              L.i32(68), L.ptr(dW1), L.ptr(db1), L.ptr(dW2), L.ptr(db2), L.ptr(dW3), L.ptr(db3),

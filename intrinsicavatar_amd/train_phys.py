@@ -63,8 +63,8 @@ class _MLP2(Function):
         pad = (in_dim + 1) // 2 * 2
         g_x = torch.empty((n, pad), device=dev)
         ns, ptrs, strides, widths, muls, adds = train._segs([(s, w, m, a) for s, (w, m, a) in zip(segs, ctx.spec)])
-        d = [torch.zeros((64, in_dim), device=dev), torch.zeros(64, device=dev), torch.zeros((64, 64), device=dev),
-             torch.zeros(64, device=dev), torch.zeros((ctx.out_dim, 64), device=dev), torch.zeros(ctx.out_dim, device=dev)]
+        shapes = [(64, in_dim), (64,), (64, 64), (64,), (ctx.out_dim, 64), (ctx.out_dim,)]
+        d = train.zeros_like_shapes(shapes, dev)          # ONE fill for the six accumulated weight gradients
         L.check(L.lib().ia_mlp_bwd_fused(L.i32(ctx.kind), L.i64(n), L.i32(ns), ptrs, strides, widths, muls, adds,
                                          *[L.ptr(w) for w in ws], L.ptr(g_y.contiguous().float()), L.ptr(g_x), L.i32(pad),
                                          *[L.ptr(t) for t in d], L.stream()), "ia_mlp_bwd_fused")
@@ -73,6 +73,71 @@ class _MLP2(Function):
             g_segs.append(g_x[:, c0:c0 + w] * m if m != 1.0 else g_x[:, c0:c0 + w])
             c0 += w
         return (None, None, *d, *g_segs)
+
+
+class _MaterialAffine(Function):
+    """sigmoid outputs [n,5] -> albedo [n,3], roughness [n,1], metallic [n,1] in the ranges of VolumeMaterial.forward
+    (models/pbr/material.py:44-50): ia_material_affine / _bwd instead of three slices, six element-wise launches and their backward."""
+
+    @staticmethod
+    def forward(ctx, mraw, material):
+        mraw = mraw.contiguous()
+        n, dev = mraw.shape[0], mraw.device
+        alb, rgh, mtl = torch.empty((n, 3), device=dev), torch.empty((n, 1), device=dev), torch.empty((n, 1), device=dev)
+        ctx.scales = (float(material.albedo_scale), float(material.roughness_scale), float(material.metallic_scale))
+        L.check(L.lib().ia_material_affine(L.i64(n), L.ptr(mraw), L.f32(material.albedo_scale), L.f32(material.albedo_bias),
+                                           L.f32(material.roughness_scale), L.f32(material.roughness_bias), L.f32(material.metallic_scale),
+                                           L.f32(material.metallic_bias), L.ptr(alb), L.ptr(rgh), L.ptr(mtl), L.stream()), "ia_material_affine")
+        ctx.n = n
+        ctx.dev = dev
+        ctx.set_materialize_grads(False)
+        return alb, rgh, mtl
+
+    @staticmethod
+    def backward(ctx, g_alb, g_rgh, g_mtl):
+        cg = lambda t: t.contiguous() if t is not None else None      # noqa: E731
+        g = torch.empty((ctx.n, 5), device=ctx.dev)
+        a, r, m = ctx.scales
+        L.check(L.lib().ia_material_affine_bwd(L.i64(ctx.n), L.ptr(cg(g_alb)), L.ptr(cg(g_rgh)), L.ptr(cg(g_mtl)), L.f32(a), L.f32(r), L.f32(m),
+                                               L.ptr(g), L.stream()), "ia_material_affine_bwd")
+        return g, None
+
+
+class _PhysLoss(Function):
+    """the default loss composition of IntrinsicAvatarSystem.training_step (systems/intrinsic_avatar.py:165-252) on the composited maps:
+    L1 rgb + lambda_eik * eikonal mean + lambda_mask * BCE(opacity, mask) + lambda_phys * L1 rgb_phys -- ia_phys_loss / _bwd, one launch
+    each way instead of ~15 element-wise / reduce launches and their backward.  Returns (loss, terms [5])."""
+
+    @staticmethod
+    def forward(ctx, comp_rgb, comp_rgb_phys, opacity, eik_part, target_rgb, target_mask, lambda_phys, lambda_mask, lambda_eik, eik_denom):
+        c = lambda t: t.contiguous().float() if t is not None else None      # noqa: E731
+        comp_rgb, comp_rgb_phys, opacity, target_rgb, target_mask = c(comp_rgb), c(comp_rgb_phys), c(opacity), c(target_rgb), c(target_mask)
+        n, dev = comp_rgb.shape[0], comp_rgb.device
+        terms = torch.empty(5, device=dev)
+        k = int(eik_part.shape[0]) if eik_part is not None else 0
+        L.check(L.lib().ia_phys_loss(L.i64(n), L.ptr(comp_rgb), L.ptr(comp_rgb_phys), L.ptr(opacity), L.ptr(target_rgb), L.ptr(target_mask),
+                                     L.ptr(eik_part), L.i32(k), L.f32(lambda_phys), L.f32(lambda_mask), L.f32(lambda_eik), L.f32(eik_denom),
+                                     L.ptr(terms), L.stream()), "ia_phys_loss")
+        ctx.save_for_backward(comp_rgb, comp_rgb_phys, opacity, target_rgb, target_mask)
+        ctx.cfg = (float(lambda_phys), float(lambda_mask), float(lambda_eik), float(eik_denom), tuple(eik_part.shape) if eik_part is not None else None)
+        ctx.mark_non_differentiable(terms)
+        ctx.set_materialize_grads(False)
+        return terms[4], terms
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_terms):
+        comp_rgb, comp_rgb_phys, opacity, target_rgb, target_mask = ctx.saved_tensors
+        lp, lm, le, den, has_eik = ctx.cfg
+        n, dev = comp_rgb.shape[0], comp_rgb.device
+        g_rgb = torch.empty_like(comp_rgb)
+        g_phys = torch.empty_like(comp_rgb_phys) if comp_rgb_phys is not None else None
+        g_op = torch.empty_like(opacity) if target_mask is not None else None
+        g_eik = torch.empty(1, device=dev) if has_eik else None
+        L.check(L.lib().ia_phys_loss_bwd(L.i64(n), L.ptr(comp_rgb), L.ptr(comp_rgb_phys), L.ptr(opacity), L.ptr(target_rgb), L.ptr(target_mask),
+                                         L.ptr(g_loss.reshape(1).float().contiguous()), L.f32(lp), L.f32(lm), L.f32(le), L.f32(den),
+                                         L.ptr(g_rgb), L.ptr(g_phys), L.ptr(g_op), L.ptr(g_eik), L.stream()), "ia_phys_loss_bwd")
+        # (d loss / d eikonal sum is ONE scalar: it goes back as a stride-0 view of the partials' shape, train._EikonalPartials reads element 0)
+        return g_rgb, g_phys, g_op, (g_eik.expand(has_eik) if has_eik else None), None, None, None, None, None, None
 
 
 def shade_differentiable_phys(rs, material, emitter, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor, t_starts: Tensor,
@@ -94,44 +159,38 @@ def shade_differentiable_phys(rs, material, emitter, rays_o: Tensor, rays_d: Ten
     with torch.no_grad():
         d = dfm.deform(pts, geo, with_grad=False, with_feature=False, want_fwd=True)
         valid = d["valid"]
-        sel = d["sel"].long().clamp(min=0)
-        c2w = d["fwd_J"].reshape(-1, 3, 3)[d["cand_src"].long()[sel]] if d["n_candidates"] > 0 else \
-            torch.zeros((pts.shape[0], 3, 3), device=dev)
     W1k, b1, W2, b2 = geo.effective_weights()
     out, grad_c = train._SDFField.apply(d["pts_cano"], geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale, 0xFFFFFFFF,
                                             geo.inv_scale_host())
-    vf = valid[:, None].float()
-    feat = out * vf
-    sdf = torch.where(valid, out[:, 0], torch.full_like(out[:, 0], 1e5))
-    dflt_g = torch.nn.functional.pad(torch.ones((1, 1), device=dev), (2, 0))       # [0, 0, 1] without a host -> device scalar copy (a sync)
-    sdf_grad = torch.where(valid[:, None], (c2w * grad_c[:, None, :]).sum(-1), dflt_g)
+    # invalid points: sdf 1e5, feature 0, gradient [0,0,1] (snarf_deformer.py:192-231); valid ones: the normal push-forward with the
+    # winning candidate's blended rotation -- one kernel each way (ia_select_push / _bwd)
+    feat, sdf, sdf_grad, _c2w = train._SelectPush.apply(out, grad_c, valid, d["fwd_J"] if d["n_candidates"] > 0 else None, d["cand_src"], d["sel"])
     w2s_rot = dfm.w2s[:3, :3].contiguous()
     normal_smpl, normal_world, refl01 = train._ShadePrep.apply(sdf_grad, rays_d, ray_indices, w2s_rot)
     alphas = train._Alpha.apply(sdf, t_ends - t_starts, rs.density.get_beta())
     # hash grid #2 once; radiance and material heads
-    xp2 = ((d["pts_cano"] - rad.center) / rad.scale + 0.5).detach().contiguous()
+    with torch.no_grad():
+        xp2 = fields.normalize_points(d["pts_cano"], rad.center, rad.scale)
     enc2 = _HashEncode.apply(xp2, rad.grid_params)
     sh = _SH4.apply(refl01)
     rgbs = _MLP2.apply(1, 3, *rad.effective_weights(), enc2, xp2, feat, sh, normal_world)
     mask = rad.prog.mask(rad.global_step, dev)
-    mraw = _MLP2.apply(2, 5, *material.effective_weights(mask), enc2, xp2, feat)
-    albedo = mraw[:, :3] * material.albedo_scale + material.albedo_bias
-    rough = mraw[:, 3:4] * material.roughness_scale + material.roughness_bias
-    metal = mraw[:, 4:5] * material.metallic_scale + material.metallic_bias
+    mat_w = material.effective_weights(mask)             # once per step: the jitter pass reads the same matrices
+    mraw = _MLP2.apply(2, 5, *mat_w, enc2, xp2, feat)
+    albedo, rough, metal = _MaterialAffine.apply(mraw, material)
     weights, trans = nerfacc._WeightFromAlpha.apply(alphas, packed_info)
     acc = lambda v: nerfacc._Accumulate.apply(weights, v, ray_indices, packed_info)      # noqa: E731
     extra_maps = {}
     if jitter_n is not None:
         # material jitter pass: geometry feature + radiance embedding + material head at the jittered canonical points
         # (material_feature = hybrid); no deformer, no validity mask, exactly as the reference evaluates it
-        x_j = (d["pts_cano"] + 0.01 * jitter_n[:pts.shape[0]]).detach().contiguous()
+        with torch.no_grad():
+            x_j = (d["pts_cano"] + 0.01 * jitter_n[:pts.shape[0]]).contiguous()
         out_j, _ = train._SDFField.apply(x_j, geo.grid_params, W1k, b1, W2, b2, geo.center, geo.scale, 0xFFFFFFFF, geo.inv_scale_host())
-        xp2_j = ((x_j - rad.center) / rad.scale + 0.5).contiguous()
+        xp2_j = fields.normalize_points(x_j, rad.center, rad.scale)
         enc2_j = _HashEncode.apply(xp2_j, rad.grid_params)
-        mraw_j = _MLP2.apply(2, 5, *material.effective_weights(mask), enc2_j, xp2_j, out_j)
-        alb_j = mraw_j[:, :3] * material.albedo_scale + material.albedo_bias
-        rough_j = mraw_j[:, 3:4] * material.roughness_scale + material.roughness_bias
-        metal_j = mraw_j[:, 4:5] * material.metallic_scale + material.metallic_bias
+        mraw_j = _MLP2.apply(2, 5, *mat_w, enc2_j, xp2_j, out_j)
+        alb_j, rough_j, metal_j = _MaterialAffine.apply(mraw_j, material)
 
         def rel(v, vj):            # compute_relative_smoothness_loss (:383-388)
             base = torch.maximum(v, vj).clamp_min(1e-6)
@@ -141,8 +200,8 @@ def shade_differentiable_phys(rs, material, emitter, rays_o: Tensor, rays_d: Ten
                           albedo_smoothness_loss_map=acc(rel(albedo, alb_j).contiguous()),
                           roughness_smoothness_loss_map=acc(rel(rough, rough_j).contiguous()),
                           metallic_smoothness_loss_map=acc(rel(metal, metal_j).contiguous()))
-    res = dict(comp_rgb=acc(rgbs), comp_normal=acc(normal_world), opacity=acc(None), albedo=acc(albedo.contiguous()),
-               roughness=acc(rough.contiguous()), metallic=acc(metal.contiguous()), weights=weights, alphas=alphas, sdf=sdf,
+    res = dict(comp_rgb=acc(rgbs), comp_normal=acc(normal_world), opacity=acc(None), albedo=acc(albedo),
+               roughness=acc(rough), metallic=acc(metal), weights=weights, alphas=alphas, sdf=sdf,
                sdf_grad=sdf_grad, valid=valid, n_samples=pts.shape[0], **extra_maps)
     # ---- volume scattering (enable_phys)
     if background_color is None:
@@ -187,11 +246,24 @@ def shade_differentiable_phys(rs, material, emitter, rays_o: Tensor, rays_d: Ten
     return res
 
 
+FUSED_LOSS = __import__("os").environ.get("IA_FUSED_LOSS", "1") != "0"
+
+
 def training_loss_phys(out: Dict[str, Tensor], target_rgb: Tensor, target_mask: Optional[Tensor] = None,
                        lambda_phys: float = 1.0, lambda_smooth: float = 0.0, lambda_orient: float = 0.0, **kw) -> Tensor:
     """train.training_loss + the L1 term on the physically based image (systems/intrinsic_avatar.py:180-190) and, when
     the jitter pass ran, the material smoothness / normal orientation maps."""
-    loss = train.training_loss(out, target_rgb, target_mask, **kw) + lambda_phys * (out["comp_rgb_phys"] - target_rgb).abs().mean()
+    if FUSED_LOSS and not kw.get("lambda_curv") and out["comp_rgb"].is_cuda:
+        # one kernel each way (ia_phys_loss); the eikonal partial sums of ia_eikonal go in as they are
+        lam_eik, lam_mask = kw.get("lambda_eik", 0.1), kw.get("lambda_mask", 0.1)
+        part = train._EikonalPartials.apply(out["sdf_grad"], out["valid"])
+        denom = kw.get("eik_denominator")
+        denom = float(denom) if denom is not None else float(max(out["sdf_grad"].shape[0], 1))
+        op = out["opacity"] if target_mask is not None else None
+        loss, terms = _PhysLoss.apply(out["comp_rgb"], out["comp_rgb_phys"], op, part, target_rgb, target_mask, lambda_phys, lam_mask, lam_eik, denom)
+        out["loss_terms"] = terms
+    else:
+        loss = train.training_loss(out, target_rgb, target_mask, **kw) + lambda_phys * (out["comp_rgb_phys"] - target_rgb).abs().mean()
     if "albedo_smoothness_loss_map" in out:
         if lambda_smooth > 0.0:
             loss = loss + lambda_smooth * (out["albedo_smoothness_loss_map"].mean() + out["roughness_smoothness_loss_map"].mean()
@@ -199,6 +271,47 @@ def training_loss_phys(out: Dict[str, Tensor], target_rgb: Tensor, target_mask: 
         if lambda_orient > 0.0:
             loss = loss + lambda_orient * out["normals_orientation_loss_map"].mean()
     return loss
+
+
+def reference_training_loss(out: Dict[str, Tensor], rgb: Tensor, alpha: Optional[Tensor], lam: Dict[str, float], material):
+    """IntrinsicAvatarSystem.training_step (systems/intrinsic_avatar.py:160-301) on the model's output dict (RenderStep._training_dict /
+    forward_train_): every term the reference logs, weighted by `lam` (the `system.loss` section of configs/config.yaml:87-109 with the
+    schedules already evaluated: plain floats; a term whose weight is 0 or missing is not added).  -> (loss, {term: value}).
+      rgb_l1 / rgb_mse            :165-178   sRGB image over rays_valid_full
+      rgb_phys_l1 / rgb_phys_mse  :181-212   physically based image over rays_valid_phys_full (add_emitter False)
+      rgb_demodulated             :217-224   luma of the demodulated image against the target's channel maximum
+      eikonal                     :235-239   mean over ALL samples of (|grad sdf| - 1)^2
+      mask_bce / mask_mse, opaque :242-257   clamped opacity against the batch's alpha
+      sparsity                    :260-264
+      material regularisers       :285-290   models/pbr/material.py:53-87 (smoothness / orientation means, albedo entropy)"""
+    F_ = torch.nn.functional
+    v, vp = out["rays_valid_full"][..., 0], out["rays_valid_phys_full"][..., 0]
+    t = {}
+    t["rgb_mse"] = F_.mse_loss(out["comp_rgb_full"][v], rgb[v])
+    t["rgb_l1"] = F_.l1_loss(out["comp_rgb_full"][v], rgb[v])
+    t["rgb_phys_mse"] = F_.mse_loss(out["comp_rgb_phys_full"][vp], rgb[vp])
+    t["rgb_phys_l1"] = F_.l1_loss(out["comp_rgb_phys_full"][vp], rgb[vp])
+    t["rgb_demodulated"] = F_.l1_loss(pbr.luma(out["comp_demod_phys_full"][vp]), pbr.max_value(rgb[vp]))
+    t["eikonal"] = ((torch.linalg.norm(out["sdf_grad_samples"], ord=2, dim=-1) - 1.0) ** 2).mean()
+    if alpha is not None:
+        op = torch.clamp(out["opacity"].squeeze(-1), 1.0e-3, 1.0 - 1.0e-3)
+
+        def bce(x, y):            # systems/criterions.py:229-233
+            return -(y * torch.log(x) + (1 - y) * torch.log(1 - x)).mean()
+        t["mask_mse"] = F_.mse_loss(op, alpha)
+        t["mask_bce"] = bce(op, alpha)
+        t["opaque"] = bce(op, op)
+    t["sparsity"] = torch.exp(-float(lam.get("sparsity_scale", 1.0)) * out["sdf_samples"].abs()).mean()
+    reg = material.regularizations(out)
+    for k in ("normal_orientation", "albedo_smoothness", "roughness_smoothness", "metallic_smoothness", "albedo_entropy"):
+        if k in reg:
+            t[k] = reg[k]
+    loss = 0.0
+    for k, val in t.items():
+        w = float(lam.get("lambda_" + k, 0.0) or 0.0)
+        if w != 0.0:
+            loss = loss + w * val
+    return loss, t
 
 
 def forward_backward_phys_pipelined(rs, views, material, emitter, spp: int, n_workers: int = 2, **kw) -> Dict[str, int]:

@@ -8,6 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 RUNS = dict(light_16_nogi=("light", 16, False), light_64_gi=("light", 64, True), uniform_light_512_gi=("uniform_light", 512, True),
             mis_16_gi=("mis", 16, True), mats_16_gi=("mats", 16, True))
 TRAIN_RUN = "light_16_gi_train"
+UNIFORM_TRAIN_RUN = "uniform_light_512_gi_train"      # the estimator the reference ships for training (configs/config.yaml:46-48), train() mode
 
 
 def load():
@@ -48,6 +49,12 @@ def explicit_randoms(G, tag):
     out["occ_jitter"] = formula_uniforms(a0[0], a0[1])            # flat: [64^3 * 3 * 3] (test grid, 3 points per voxel) or [64^3 * 3] (training grid)
     rest = d[1:]
     mode = tag.split("_")[0] if not tag.startswith("uniform") else "uniform_light"
+    if tag.endswith("_train") and mode == "uniform_light":
+        # stratified near-plane jitter, material jitter, the [n_rays, 512] shuffle uniforms (:1399), the stratified sphere jitter (:680-689)
+        (ka, near), (kb, mj), (kc, sh), (kd, su) = rest
+        assert (ka, kb, kc, kd) == ("rand_like", "randn_like", "rand", "emitter.sample_uniform_sphere_stratified")
+        out.update(near_jitter=near, material_jitter=mj, shuffle_u=sh.reshape(G["rays"].shape[0], -1), stratified_u=su)
+        return out
     if tag.endswith("_train"):
         # stratified near-plane jitter, material jitter, the (unused) shuffle draw, emitter.sample(F)
         (ka, near), (kb, mj), (kc, _), (kd, lu) = rest

@@ -26,7 +26,10 @@ via `value + (twin - twin.detach())`, which adds an exact zero: the forward valu
 absent, so their own backward is still "vs our restatement" -- what this fixture pins is everything of the REFERENCE's that
 sits between them: its graph, its losses, its parameterisations.
 
-Three loss compositions, one backward each (same scene, same random tensors):
+Three loss compositions, one backward each (same scene, same random tensors), on the `light` estimator at spp 16 -- and a fourth
+run, `uniform_default`, on the estimator the reference SHIPS for training (render_mode uniform_light, samples_per_pixel 512:
+configs/config.yaml:46-48, models/intrinsic_avatar.py:654-753,1392-1413; the `uniform_light_512_gi_train` run of golden_forward.npz)
+with the default composition:
     default   configs/config.yaml:87-109 as shipped (rgb L1 1, phys L1 0.2, mask BCE 0.1, eikonal 0.1, Lipschitz 1e-5 at
               step 25 000, the three smoothness terms 0.01)
     allterms  every term of training_step that the default sets to zero switched on as well (MSEs, demodulated, mask MSE,
@@ -60,6 +63,7 @@ N = GF.N
 Cfg = GF.Cfg
 from tests.forward_golden import SUBSAMPLE      # noqa: E402
 TAG = "light_16_gi_train"
+UNIFORM_TAG = "uniform_light_512_gi_train"      # the estimator the reference ships for training (configs/config.yaml:46-48)
 
 LOSS_DEFAULT = dict(lambda_rgb_l1=1.0, lambda_rgb_phys_l1=0.2, lambda_mask_bce=0.1, lambda_eikonal=0.1,
                     lambda_lipshitz_bound=[12500, 1.0e-5, 1.0e-5, 12501], lambda_curvature=[1.5, 0.0, 12500],
@@ -74,7 +78,12 @@ LOSS_ALLTERMS = dict(LOSS_DEFAULT, lambda_rgb_mse=0.5, lambda_rgb_phys_mse=0.5, 
 VARIANTS = dict(default=LOSS_DEFAULT, allterms=LOSS_ALLTERMS, lipshitz=dict(LOSS_DEFAULT, lambda_rgb_phys_mse=0.5))
 # lipshitz only: the Lipschitz bounds of the material MLP are initialised at 2 x the largest row sum (network_utils.py:380-385), where
 # the normalisation (:396-403) is the identity and d / d bound = 0; scaled down so that the clamp is active on the large rows
-LIPSHITZ_SCALE = dict(default=1.0, allterms=1.0, lipshitz=0.3)
+LIPSHITZ_SCALE = dict(default=1.0, allterms=1.0, lipshitz=0.3, uniform_default=1.0)
+# uniform_default: the SHIPPED training configuration -- render_mode uniform_light, samples_per_pixel 512 (configs/config.yaml:46-48,
+# BASELINE configs[3]) with the default loss composition, on the `uniform_light_512_gi_train` run of golden_forward.npz.  Variants are
+# only ever appended (the arrays of the earlier ones must regenerate bit-identically).
+VARIANTS["uniform_default"] = LOSS_DEFAULT
+RUN_OF = dict(default=(TAG, "light", 16), allterms=(TAG, "light", 16), lipshitz=(TAG, "light", 16), uniform_default=(UNIFORM_TAG, "uniform_light", 512))
 
 
 from tests.forward_golden import table_gradient_summary      # noqa: E402  (shared with the GPU test)
@@ -220,8 +229,8 @@ def targets(G):
     return rgb.astype(np.float32), alpha.astype(np.float32)
 
 
-def build_model(mods, IA, rd, bg, hdri):
-    model = IA.IntrinsicAvatarModel(GF.model_config("light", 16, True))
+def build_model(mods, IA, rd, bg, hdri, mode="light", spp=16):
+    model = IA.IntrinsicAvatarModel(GF.model_config(mode, spp, True))
     GF.init_params(model)
     model.eval()
     model.update_step(250, 25000)
@@ -258,14 +267,18 @@ def main():
     out = dict(target_rgb=rgb_t, target_alpha=alpha_t, subsample=np.int64(SUBSAMPLE))
     # the RngLog seed of golden_forward.npz's train run is 1000 + len(out) at that point of make_golden_forward.main; recover it by
     # matching the first stored draw instead of hard-coding the count
-    ref_near = G[f"{TAG}_rng_1"]
-    seed = next(s for s in range(1000, 1600) if np.array_equal(
-        N(torch.rand((ref_near.shape[0],), generator=torch.Generator().manual_seed(s))), ref_near))
+    def seed_of(tag):
+        ref_near = G[f"{tag}_rng_1"]
+        return next(s for s in range(1000, 1800) if np.array_equal(
+            N(torch.rand((ref_near.shape[0],), generator=torch.Generator().manual_seed(s))), ref_near))
+    seeds = {}
     for name, loss_cfg in VARIANTS.items():
+        TAG, mode, spp = RUN_OF[name]
+        seed = seeds.setdefault(TAG, seed_of(TAG))
         torch.manual_seed(0)
         with GF.RngLog(seed) as rng:
             GF.RNG = rng
-            model = build_model(mods, IA, rd, bg, G["hdri"])
+            model = build_model(mods, IA, rd, bg, G["hdri"], mode, spp)
             with torch.no_grad():
                 for c in model.material.network.lipshitz_bound_per_layer:
                     c.mul_(LIPSHITZ_SCALE[name])
@@ -277,6 +290,7 @@ def main():
         # same forward as the train run of golden_forward.npz, bit for bit
         for k in (G[TAG + "_out_keys"] if LIPSHITZ_SCALE[name] == 1.0 else ("comp_rgb", "comp_normal", "opacity", "num_samples", "ray_indices")):
             assert np.array_equal(N(res[str(k)]), G[f"{TAG}_out_{k}"]), ("forward differs from golden_forward.npz", k)
+        out[f"{name}_run"] = np.array(TAG)
         out[f"{name}_loss"] = np.float64(loss.item())
         out[f"{name}_lipshitz_scale"] = np.float64(LIPSHITZ_SCALE[name])
         for k in ("comp_rgb_phys_full", "comp_albedo_full", "comp_roughness_full", "comp_metallic_full"):

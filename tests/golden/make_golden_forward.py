@@ -373,7 +373,10 @@ def main():
     out["background_color"] = N(bg)
     out["hdri"] = hdri()
     runs = [("light", 16, False, False), ("light", 64, True, False), ("uniform_light", 512, True, False), ("mis", 16, True, False),
-            ("mats", 16, True, False), ("light", 16, True, True)]                 # (render_mode, spp, global_illumination, training)
+            ("mats", 16, True, False), ("light", 16, True, True),
+            ("uniform_light", 512, True, True)]                                  # (render_mode, spp, global_illumination, training)
+    # the last run is the estimator the reference SHIPS for training (configs/config.yaml:46-48: render_mode uniform_light,
+    # samples_per_pixel 512) in train() mode; runs are only ever appended: the RngLog seed of a run is 1000 + len(out) when it starts
     state_saved = False
     for mode, spp, gi, training in runs:
         tag = f"{mode}_{spp}_{'gi' if gi else 'nogi'}{'_train' if training else ''}"

@@ -10,13 +10,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ALIAS = {"train/loss_rgb": "lambda_rgb_l1", "train/loss_rgb_phys": "lambda_rgb_phys_l1"}
 
 
+VARIANTS = ("default", "allterms", "lipshitz", "uniform_default")      # uniform_default: render_mode uniform_light, spp 512 (the shipped training estimator)
+
+
 def _B():
     return np.load(os.path.join(HERE, "golden", "golden_backward.npz"))
 
 
 def test_loss_is_the_weighted_sum_of_the_logged_terms():
     B = _B()
-    for name in ("default", "allterms", "lipshitz"):
+    for name in VARIANTS:
         lam = {k: float(v) for k, v in (str(s).split("=", 1) for s in B[f"{name}_lambdas"])}
         terms = {k: float(v) for k, v in (str(s).split("=", 1) for s in B[f"{name}_loss_terms"]) if k.startswith("train/loss_")}
         total = 0.0
@@ -28,7 +31,7 @@ def test_loss_is_the_weighted_sum_of_the_logged_terms():
 
 def test_every_group_has_a_finite_gradient_and_the_summaries_are_consistent():
     B = _B()
-    for name in ("default", "allterms", "lipshitz"):
+    for name in VARIANTS:
         names = [str(s) for s in B[f"{name}_grad_names"]]
         assert len(names) == 25
         for p in names:
@@ -44,4 +47,12 @@ def test_every_group_has_a_finite_gradient_and_the_summaries_are_consistent():
             else:
                 assert np.isfinite(B[f"{name}_grad_{p}"]).all(), p
     bars = json.load(open(os.path.join(HERE, "golden", "grad_parity_bars.json")))
-    assert len(bars["groups"]) >= 3 * 19 and len(bars["tables"]) == 6
+    assert len(bars["groups"]) >= 3 * 19 and len(bars["tables"]) >= 6
+
+
+def test_the_uniform_light_variant_is_the_shipped_training_configuration():
+    B = _B()
+    assert str(B["uniform_default_run"]) == "uniform_light_512_gi_train" and str(B["default_run"]) == "light_16_gi_train"
+    lam_u = sorted(str(s) for s in B["uniform_default_lambdas"])
+    assert lam_u == sorted(str(s) for s in B["default_lambdas"])          # the default loss composition (configs/config.yaml:87-109)
+    assert sorted(str(s) for s in B["uniform_default_grad_names"]) == sorted(str(s) for s in B["default_grad_names"])

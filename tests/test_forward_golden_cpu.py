@@ -100,3 +100,28 @@ def test_oracle_training_form_vs_the_references_own_forward(G):
     bad = np.nonzero(err > tol)[0]
     first_bad = int(bad[0]) if bad.size else len(err)
     assert (err[:max(first_bad, 1)] <= tol[:max(first_bad, 1)]).all() and first_bad >= 0.3 * len(err), (first_bad, float(err.max()))
+
+
+def test_oracle_uniform_light_training_form_vs_the_references_own_forward(G):
+    """the estimator the reference SHIPS for training (configs/config.yaml:46-48: render_mode uniform_light, samples_per_pixel 512) in
+    train() mode (`uniform_light_512_gi_train`): the training occupancy grid, the stratified near plane, one stratified direction set per
+    step shuffled per ray (models/intrinsic_avatar.py:1392-1413, 654-753).  Same bars as the eval-form runs."""
+    from oracle import render_ref as R
+    tag = FG.UNIFORM_TRAIN_RUN
+    sc = FG.oracle_scene(G, tag)
+    rnd = FG.explicit_randoms(G, tag)
+    o = R.relight_step(sc, G["rays"], spp=512, light_u=rnd["stratified_u"], shuffle_u=rnd["shuffle_u"], jitter=rnd["near_jitter"],
+                       global_illumination=True, background_color=G["background_color"], render_mode="uniform_light")
+    ref = {str(k): G[f"{tag}_out_{k}"] for k in G[tag + "_out_keys"]}
+    assert "visibility" in ref and "albedo_smoothness_loss_map" in ref          # training keys + the uniform_light key
+    n_ref = int(ref["num_samples"][0])
+    assert abs(len(o["t_starts"]) - n_ref) <= 0.005 * n_ref
+    for k, kk, tol in (("comp_rgb", "comp_rgb", 2e-3), ("comp_normal", "comp_normal", 4e-3), ("albedo", "comp_albedo", 2e-3), ("opacity", "opacity", 2e-3)):
+        _close(kk, o[k], ref[kk], tol, mean_tol=5e-4)
+    hit = ref["rays_valid"][:, 0]
+    a, b = o["comp_rgb_phys"], ref["comp_rgb_phys"]
+    tol = 2e-2 * np.abs(b).max(-1) + 2e-2
+    err = np.abs(a - b).max(-1)
+    assert (err <= tol).mean() >= 0.97, (float((err > tol).mean()), float(err.max()))
+    assert abs(a[hit].mean() - b[hit].mean()) <= 2e-2 * abs(b[hit].mean()), (a[hit].mean(), b[hit].mean())
+    _close("visibility", o["visibility"], ref["visibility"], 3e-2, frac=0.97)

@@ -27,7 +27,10 @@ from tests import forward_golden as FG
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 HERE = os.path.dirname(os.path.abspath(__file__))
-VARIANTS = ("default", "allterms", "lipshitz")
+VARIANTS = ("default", "allterms", "lipshitz", "uniform_default")
+# the variants also driven through RenderStep.forward_backward_phys ITSELF (render.py: what bench.py and its `config4` object time) with
+# the reference's loss composition (loss_config): the shipped training estimator and the `light` estimator
+PHYS_VARIANTS = ("uniform_default", "default")
 
 
 def T(a):
@@ -91,8 +94,12 @@ def trainer_loss(out, rgb, alpha, lam, material):
     return loss, t
 
 
-def run_step(G, B, name):
-    tag = FG.TRAIN_RUN
+def run_step(G, B, name, through="forward_train_"):
+    """one training step of variant `name` on the HIP path.  through = "forward_train_": RenderStep.forward_train_ + the test-side
+    restatement of the trainer's loss (trainer_loss above) + backward; "forward_backward_phys": RenderStep.forward_backward_phys itself
+    with loss_config = the variant's weights (the package's reference_training_loss), which runs its own backward."""
+    tag = str(B[f"{name}_run"]) if f"{name}_run" in B.files else FG.TRAIN_RUN
+    mode, spp = ("uniform_light", 512) if tag == FG.UNIFORM_TRAIN_RUN else ("light", 16)
     rs, mat, env, rays = FG.gpu_scene(G, tag)
     sc = float(B[f"{name}_lipshitz_scale"])
     if sc != 1.0:
@@ -102,17 +109,27 @@ def run_step(G, B, name):
     rnd = FG.explicit_randoms(G, tag)
     g = torch.Generator().manual_seed(0)
     mj = torch.cat([torch.from_numpy(rnd["material_jitter"]), torch.randn((4096, 3), generator=g)]).to(DEV)
-    lu = torch.cat([torch.from_numpy(rnd["light_u"]), torch.rand((4096, 3), generator=g)]).to(DEV)
+    if mode == "light":          # training form of pbr_light_forward: an independent direction per foreground re-sample, no shuffle
+        lu, su = torch.cat([torch.from_numpy(rnd["light_u"]), torch.rand((4096, 3), generator=g)]).to(DEV), None
+    else:                        # uniform_light: one stratified set per step, shuffled per ray (:1392-1413)
+        lu, su = T(rnd["stratified_u"]), T(rnd["shuffle_u"])
     params = {}
     for comp, mod in (("geometry", rs.geometry), ("radiance", rs.radiance), ("density", rs.density), ("material", mat), ("emitter", env)):
         for k, p in mod.named_parameters():
             if p.requires_grad and p.numel() > 0:
                 params[f"{comp}.{k}"] = p
                 p.grad = None
-    d = rs.forward_train_(rays, mat, env, 16, lu, jitter=T(rnd["near_jitter"]), material_jitter=mj, background_color=T(G["background_color"]),
-                          global_illumination=True, render_mode="light")
-    loss, terms = trainer_loss(d, T(B["target_rgb"]), T(B["target_alpha"]), lambdas(B, name), mat)
-    loss.backward()
+    if through == "forward_train_":
+        d = rs.forward_train_(rays, mat, env, spp, lu, jitter=T(rnd["near_jitter"]), material_jitter=mj, background_color=T(G["background_color"]),
+                              global_illumination=True, render_mode=mode, shuffle_u=su)
+        loss, terms = trainer_loss(d, T(B["target_rgb"]), T(B["target_alpha"]), lambdas(B, name), mat)
+        loss.backward()
+    else:
+        o = rs.forward_backward_phys(rays, T(B["target_rgb"]), mat, env, spp, lu, su, target_mask=T(B["target_alpha"]), jitter=T(rnd["near_jitter"]),
+                                     render_mode=mode, background_color=T(G["background_color"]), global_illumination=True,
+                                     light_sampling="per_point" if mode == "light" else "shared", material_jitter=mj,
+                                     loss_config=lambdas(B, name))
+        d, loss, terms = o["output_dict"], o["loss"], o["loss_terms"]
     torch.cuda.synchronize()
     return d, loss, terms, params
 
@@ -136,12 +153,15 @@ def table_stats(g, B, key):
               nnz_rel=float((np.abs(mine["level_nnz"] - ref["level_nnz"]) / np.maximum(ref["level_nnz"], 1)).max()))
     mine_at_ref = g.reshape(-1)[ref["sub_index"].astype(np.int64)]
     st.update({"sub_" + k: v for k, v in group_stats(mine_at_ref, ref["sub_value"]).items()})
+    e = np.abs(mine_at_ref.astype(np.float64) - ref["sub_value"].astype(np.float64)) / max(float(np.abs(ref["sub_value"]).max()), 1e-30)
+    st["sub_rel_p999"] = float(np.quantile(e, 0.999))
+    st["sub_over_1e-2"] = int((e > 1e-2).sum())
     st["sub_n"] = int(ref["sub_index"].size)
     return st
 
 
-def compare(G, B, name):
-    d, loss, terms, params = run_step(G, B, name)
+def compare(G, B, name, through="forward_train_"):
+    d, loss, terms, params = run_step(G, B, name, through)
     report = dict(loss=float(loss), loss_ref=float(B[f"{name}_loss"]), groups={}, tables={}, terms={})
     ref_terms = dict(str(s).split("=", 1) for s in B[f"{name}_loss_terms"])
     alias = dict(rgb_l1="train/loss_rgb", rgb_phys_l1="train/loss_rgb_phys")
@@ -168,6 +188,14 @@ def compare(G, B, name):
 # (rel_max, cos_dist): 3 x the MI355X observation (profiles/r05_grad_parity.json), hard caps 2e-2 / 2e-4
 CAP = (2e-2, 2e-4)
 TABLE_CAP = dict(level_sum=2e-2, level_l1=2e-2, level_l2=2e-2, level_probe=5e-2, sub_rel_max=5e-2, sub_cos_dist=2e-4)
+# uniform_light at 512 samples per pixel is a Monte-Carlo estimate with 401 408 visibility tests on this frame: a secondary ray whose
+# transmittance lands on the other side of a threshold in the two implementations (a DISCRETE event; forward: comp_rgb_phys_full differs by
+# up to 2.5e-3 here against 2e-4 under the `light` estimator at spp 16) moves the gradient of the few table entries its pixel's samples
+# touch.  Observed (profiles/r06_grad_parity.json): 6 of 86 k compared entries above 1e-2 of the largest entry, the worst at 0.092, the
+# 99.9th percentile at 5e-4.  So for this variant the single worst entry gets a wider cap, and the COUNT above 1e-2 and the 99.9th
+# percentile are bounded instead.
+MC_TABLE_CAP = dict(TABLE_CAP, sub_rel_max=0.25, sub_cos_dist=5e-4)
+MC_VARIANTS = {"uniform_default": dict(max_entries_over_1e_2=20, p999=2e-3)}
 BARS = {}
 TABLE_BARS = {}
 
@@ -181,10 +209,36 @@ def _bars():
     return BARS, TABLE_BARS
 
 
-@pytest.mark.parametrize("name", VARIANTS)
-def test_gradients_vs_the_references_own_training_step(G, B, name):
-    rep = compare(G, B, name)
-    bars, tbars = _bars()
+def test_forward_of_the_uniform_light_training_run_vs_the_reference(G):
+    """forward_ in train() mode with the shipped estimator (uniform_light, spp 512): the reference's output dict of the
+    `uniform_light_512_gi_train` run -- keys, sample count, composited maps, the Monte-Carlo image and the visibility map."""
+    tag = FG.UNIFORM_TRAIN_RUN
+    rs, mat, env, rays = FG.gpu_scene(G, tag)
+    rnd = FG.explicit_randoms(G, tag)
+    with torch.no_grad():
+        d = rs.forward_train_(rays, mat, env, 512, T(rnd["stratified_u"]), jitter=T(rnd["near_jitter"]), material_jitter=T(rnd["material_jitter"]),
+                              background_color=T(G["background_color"]), global_illumination=True, render_mode="uniform_light",
+                              shuffle_u=T(rnd["shuffle_u"]))
+    ref = {str(k): G[f"{tag}_out_{k}"] for k in G[tag + "_out_keys"]}
+    assert sorted(k for k in d if k != "stats") == sorted(ref), sorted(set(d) ^ set(ref))
+    n_ref = int(ref["num_samples"][0])
+    assert abs(int(d["num_samples"][0]) - n_ref) <= 0.005 * n_ref
+    for k, tol in (("comp_rgb", 2e-3), ("comp_normal", 4e-3), ("comp_albedo", 2e-3), ("comp_roughness", 2e-3), ("comp_metallic", 2e-3), ("opacity", 2e-3)):
+        err = np.abs(N(d[k]) - ref[k]).reshape(ref[k].shape[0], -1).max(-1)
+        assert (err <= tol).mean() >= 0.985 and err.mean() < 5e-4, (k, float((err > tol).mean()), float(err.max()))
+    hit = ref["rays_valid"][:, 0]
+    a, b = N(d["comp_rgb_phys"]), ref["comp_rgb_phys"]
+    err, tol = np.abs(a - b).max(-1), 2e-2 * np.abs(b).max(-1) + 2e-2
+    assert (err <= tol).mean() >= 0.97 and abs(a[hit].mean() - b[hit].mean()) <= 2e-2 * abs(b[hit].mean()), (float((err > tol).mean()), float(err.max()))
+    ev = np.abs(N(d["visibility"]) - ref["visibility"]).max(-1)
+    assert (ev <= 3e-2).mean() >= 0.97, float((ev > 3e-2).mean())
+    if int(d["num_samples"][0]) == n_ref:          # same sample set: the jitter-pass maps and the per-sample training outputs line up
+        for k in ("albedo_smoothness_loss_map", "roughness_smoothness_loss_map", "metallic_smoothness_loss_map", "normals_orientation_loss_map"):
+            e = np.abs(N(d[k]) - ref[k]).max(-1)
+            assert (e <= 2e-3 * max(float(np.abs(ref[k]).max()), 1e-6) + 1e-9).mean() >= 0.97, (k, float(e.max()), float(np.abs(ref[k]).max()))
+
+
+def _check(rep, name, bars, tbars):
     assert abs(rep["loss"] - rep["loss_ref"]) <= 2e-5 * abs(rep["loss_ref"]), (rep["loss"], rep["loss_ref"])
     for k, (a, b) in rep["terms"].items():
         assert abs(a - b) <= 3e-4 * abs(b) + 1e-11, (k, a, b)
@@ -196,13 +250,36 @@ def test_gradients_vs_the_references_own_training_step(G, B, name):
         assert st["rel_max"] <= min(bar[0], CAP[0]) and st["cos_dist"] <= min(bar[1], CAP[1]), (name, pname, st, bar)
     for pname, st in rep["tables"].items():
         bar = tbars.get(f"{name}/{pname}", {})
-        for k, cap in TABLE_CAP.items():
+        for k, cap in (MC_TABLE_CAP if name in MC_VARIANTS else TABLE_CAP).items():
             assert st[k] <= min(bar.get(k, cap), cap), (name, pname, k, st, bar)
         assert st["nnz_rel"] <= 2e-3, (name, pname, st)                   # same samples -> same touched entries (exact zeros aside)
+        if name in MC_VARIANTS:
+            assert st["sub_over_1e-2"] <= MC_VARIANTS[name]["max_entries_over_1e_2"] and st["sub_rel_p999"] <= MC_VARIANTS[name]["p999"], (name, pname, st)
+        else:
+            assert st["sub_rel_p999"] <= 2e-3, (name, pname, st)
+
+
+@pytest.mark.parametrize("name", PHYS_VARIANTS)
+def test_forward_backward_phys_itself_vs_the_references_own_training_step(G, B, name):
+    """RenderStep.forward_backward_phys -- the function bench.py's headline step and its `config4` object time -- with the reference's
+    loss composition: loss value, every logged term and d loss / d parameter of all 25 groups against the reference's own
+    training_step + backward (same bars as the forward_train_ route)."""
+    rep = compare(G, B, name, through="forward_backward_phys")
+    bars, tbars = _bars()
+    _check(rep, name, bars, tbars)
+
+
+@pytest.mark.parametrize("name", VARIANTS)
+def test_gradients_vs_the_references_own_training_step(G, B, name):
+    rep = compare(G, B, name)
+    bars, tbars = _bars()
+    _check(rep, name, bars, tbars)
 
 
 if __name__ == "__main__":        # python -m tests.test_gpu_backward_golden  -> the observed table (profiles/r05_grad_parity.json)
     from intrinsicavatar_amd import build
     build.build()
     G_, B_ = FG.load(), np.load(os.path.join(HERE, "golden", "golden_backward.npz"))
-    print(json.dumps({n: compare(G_, B_, n) for n in VARIANTS}, indent=1))
+    rep_ = {n: compare(G_, B_, n) for n in VARIANTS}
+    rep_.update({n + "/forward_backward_phys": compare(G_, B_, n, through="forward_backward_phys") for n in PHYS_VARIANTS})
+    print(json.dumps(rep_, indent=1))
