@@ -32,6 +32,7 @@ Extra objects in the line:
   cpu_baseline -- the CPU oracle (a port; forward only) on a bounded ray sample of the same frame, rank 0 / N == 1.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -148,11 +149,12 @@ def build_headline(dev, hw, spp, rank, pose):
     return rs, rays, export, mat, sg
 
 
-def build_config4_step(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, seed=4, sync=None, grad_scale=1.0):
+def build_config4_step(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, seed=4, sync=None, grad_scale=1.0, eik_denominator=None):
     """the reference's own training batch (BASELINE configs[3]; configs/sampler/edge.yaml:2, configs/config.yaml:46-48: uniform_light, spp 512):
     n_batch rays on the subject of the bench frame, RenderStep.forward_backward_phys + the fused Adam step.  -> (step callable, workload
     string) or (None, None) on a frame without the subject.  sync: parallel.OverlappedGradientAllReduce of a multi-rank run (the step
-    then ends with sync.finish() before the optimiser step; grad_scale = 1 / world makes the summed all-reduce DDP's mean)."""
+    then ends with sync.finish() before the optimiser step; grad_scale = 1 / world makes the summed all-reduce DDP's mean);
+    eik_denominator: see RenderStep.forward_backward_phys (global sample count / world under ray-batch sharding)."""
     from intrinsicavatar_amd import optim, pbr
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
@@ -168,18 +170,21 @@ def build_config4_step(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, seed=4
     params = rs.parameters() + [p for p in mat.parameters() if p.requires_grad] + list(sg.parameters())
     opt, sched = optim.reference_optimizer(rs, grad_scale=grad_scale, material=mat, emitter=sg)
 
-    def s4():
+    def s4(local=False):
+        """local=True: the same step without its exchange (no collective is issued: gradient hooks held, no finish())."""
         for p in params:
             p.grad = None
         img = sg.generate_image()
         leaf = img.detach().requires_grad_(True)
         emitter = pbr.EnvironmentLightTensor(leaf.detach())
         emitter.update_pdf()
-        o = rs.forward_backward_phys(batch, target, mat, emitter, spp, light_u, shuffle_u, target_mask=tmask, render_mode="uniform_light",
-                                     env_base=leaf, background_color=bg)
-        if leaf.grad is not None:
-            img.backward(leaf.grad)
-        if sync is not None:
+        ctx = sync.no_sync() if (sync is not None and local) else contextlib.nullcontext()
+        with ctx:
+            o = rs.forward_backward_phys(batch, target, mat, emitter, spp, light_u, shuffle_u, target_mask=tmask, render_mode="uniform_light",
+                                         env_base=leaf, background_color=bg, eik_denominator=(None if local else eik_denominator))
+            if leaf.grad is not None:
+                img.backward(leaf.grad)
+        if sync is not None and not local:
             s4.reduced_bytes = sync.finish()
         opt.step()
         sched.step()
@@ -189,40 +194,108 @@ def build_config4_step(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, seed=4
     return s4, f"{n_batch} rays on the subject of the bench frame, PBR training step (uniform_light, spp {spp}), fwd+bwd+Adam"
 
 
-def measure_config4(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, steps=10):
-    """Returns the line's `config4` object: ms per step, rays/s, the search launches of one step (points, ms) -- the step's one large
-    search batch is its secondary march (~2 100 march points per ray), not the 4096 rays' own samples -- and the host-orchestration
-    figures of SURVEY 8(f) row 2 for one step: device launches, host read-backs, idle fraction of the device time line
-    (tools/launch_audit.py: torch.profiler + sync debug mode)."""
-    from intrinsicavatar_amd import _lib as L
-    s4, wl = build_config4_step(rs, rays, mat, sg, dev, bg, n_batch, spp)
-    if s4 is None:
+def measure_config4(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, steps=10, rank=0, world=1, rccl_at_one_rank=False):
+    """The line's `config4` object -- the reference's 4096-ray training batch per GPU: ms per step, rays/s (whole job: world x n_batch rays per
+    step, ray-batch sharding of ONE frame with replicated parameters, BASELINE configs[3]), the search launches of one step (points, ms) --
+    the step's one large search batch is its secondary march (~2 100 march points per ray), not the 4096 rays' own samples -- and the
+    host-orchestration figures of SURVEY 8(f) row 2 for one step: device launches, host read-backs, idle fraction of the device time line
+    (tools/launch_audit.py: torch.profiler + sync debug mode).
+    world > 1 (every rank calls this; rank 0 returns the object, the others None): each rank draws its own 4096 rays, the eikonal mean is
+    normalised with the GLOBAL sample count (one scalar all-reduce per step, systems/intrinsic_avatar.py:235-239), gradients meet in the
+    all-reduce (hook-launched for the two hash tables, one flat bucket for the rest), Adam averages them (grad_scale 1 / world).
+    `gradient_allreduce`: bytes per step, ms_total (the exchange alone, back to back on idle GPUs), ms_exposed (step with the exchange -
+    the same step without it, max over ranks); `sparse_exchange`: what an all-gather of the touched (index, value) pairs would move instead
+    (SURVEY 8(e)), costed from the touched entries of this step's table gradients and, with a process group, timed."""
+    from intrinsicavatar_amd import _lib as L, parallel
+    import torch.distributed as dist
+    group = dist.is_available() and dist.is_initialized()
+    use_sync = group and (world > 1 or rccl_at_one_rank)
+    probe, wl = build_config4_step(rs, rays, mat, sg, dev, bg, n_batch, spp, seed=4 + rank)          # (also tells whether the frame has the subject)
+    ok = torch.tensor([1.0 if probe is not None else 0.0], device=dev)
+    if group and world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok) == 0.0:
         return None
+    sync = parallel.OverlappedGradientAllReduce(probe.params, single_rank_too=rccl_at_one_rank) if use_sync else None
+    den = (lambda n: parallel.allreduce_scalars([float(n)], dev)[0] / world) if (group and world > 1) else None
+    s4, wl = build_config4_step(rs, rays, mat, sg, dev, bg, n_batch, spp, seed=4 + rank, sync=sync, grad_scale=1.0 / world, eik_denominator=den)
+    del probe
+
+    def timed(fn, k):
+        torch.cuda.synchronize()
+        if group and world > 1:
+            dist.barrier()
+        tc = time.perf_counter()
+        for _ in range(k):
+            o_ = fn()
+        torch.cuda.synchronize()
+        if group and world > 1:
+            dist.barrier()
+        dt_ = time.perf_counter() - tc
+        if group and world > 1:
+            t_ = torch.tensor([dt_], device=dev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            dt_ = float(t_)
+        return dt_ / k * 1e3, o_
     for _ in range(3):
         o = s4()
-    torch.cuda.synchronize()
-    tc = time.perf_counter()
-    for _ in range(steps):
-        o = s4()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - tc) / steps * 1e3
+    ms, o = timed(s4, steps)
+    comm = sparse = None
+    if sync is not None:
+        for _ in range(2):
+            s4(local=True)
+        ms_local, _ = timed(lambda: s4(local=True), steps)
+        s4()                                                        # leaves this rank's gradients of one step in .grad
+        torch.cuda.synchronize()
+        big = [p for p in s4.params if p.grad is not None and p.numel() >= parallel.BIG]
+        nnz = [int((p.grad != 0).sum()) for p in big]
+        ms_ar, _ = timed(lambda: parallel.allreduce_gradients(s4.params), 5)
+        comm = dict(backend=dist.get_backend(), world=dist.get_world_size(), bytes_per_step=int(s4.reduced_bytes), ms_total=round(ms_ar, 3),
+                    ms_exposed=round(ms - ms_local, 3), ms_per_step_without_the_exchange=round(ms_local, 3),
+                    fraction_of_step_exposed=round((ms - ms_local) / ms, 4),
+                    note="ms_total: the all-reduce alone (two table gradients + one flat bucket), 5 back-to-back repeats on otherwise idle GPUs; "
+                         "ms_exposed: step with the exchange - the same step with the hooks held and no finish(), max over ranks")
+        # the sparse alternative of SURVEY 8(e): all-gather of the touched (int32 index, fp32 value) pairs of the two tables, padded to the
+        # largest rank, then a scatter-add of world x that many pairs on every rank
+        cap = torch.tensor([float(sum(nnz))], device=dev)
+        if world > 1:
+            dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+        pairs = int(cap)
+        payload = torch.zeros(pairs * 2, dtype=torch.int32, device=dev)
+        gathered = torch.empty(pairs * 2 * dist.get_world_size(), dtype=torch.int32, device=dev)
+        ms_ag, _ = timed(lambda: dist.all_gather_into_tensor(gathered, payload), 5)
+        dense = sum(p.numel() * 4 for p in big)
+        sparse = dict(touched_entries_per_table=nnz, entries_per_table=[int(p.numel()) for p in big], pairs_per_rank_padded=pairs,
+                      bytes_sent_per_rank=pairs * 8, bytes_received_per_rank=pairs * 8 * dist.get_world_size(), dense_allreduce_bytes=dense,
+                      ms_all_gather=round(ms_ag, 3), ms_dense_all_reduce=round(ms_ar, 3),
+                      note="all_gather_into_tensor of the padded pair lists timed like ms_total; the scatter-add of world x pairs that would "
+                           "follow is not included (it is the binned hash backward's own final pass)")
+        del payload, gathered
+    if rank != 0:
+        if sync is not None:
+            sync.remove()
+        return None
     lib = L.lib()
     lib.start()
-    o = s4()
+    o = s4(local=True) if sync is not None else s4()
     det = lib.report(detail=True)
     search = [(round(c[0], 3), int(c[1])) for k in ("ia_fuse_broyden_spec_rows", "ia_fuse_broyden") for c in det.get(k, [])]
     host = None
     try:
         from tools import launch_audit as LA
-        a = LA.audit(s4, warm=0)
+        a = LA.audit((lambda: s4(local=True)) if sync is not None else s4, warm=0)
         host = dict(launches=a["device_launches"], aten_or_runtime_launches=a["aten_or_runtime_launches"], readbacks=a["readbacks"],
                     idle_frac=a["idle_frac"], span_ms_under_profiler=a["span_ms"], busy_ms_under_profiler=a["busy_ms"])
     except Exception as e:              # a diagnostic must not take the measurement down
         host = dict(error=f"{type(e).__name__}: {e}")
-    return dict(workload=wl,
-                ms_per_step=round(ms, 3), rays_per_s=round(n_batch / (ms * 1e-3), 1), secondary_rays_per_step=int(o["stats"]["n_secondary"]),
+    if sync is not None:
+        sync.remove()
+    return dict(workload=wl + (f"; {world} ranks x {n_batch} rays of one frame (ray-batch sharding, replicated parameters)" if world > 1 else ""),
+                n_gpus=world, ms_per_step=round(ms, 3), rays_per_s=round(world * n_batch / (ms * 1e-3), 1),
+                secondary_rays_per_step=int(o["stats"]["n_secondary"]),
                 kernel_ms_per_step=round(sum(c[0] for v in det.values() for c in v), 3),
-                search_launches_ms_points=search, **(host or {}))
+                search_launches_ms_points=search, gradient_allreduce=comm, sparse_exchange=sparse,
+                host_figures_of="one step of this rank without the exchange" if sync is not None else "one step", **(host or {}))
 
 
 def main():
@@ -235,7 +308,9 @@ def main():
     ap.add_argument("--hw", type=int, default=540)
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--ray-chunk", type=int, default=int(os.environ.get("IA_RAY_CHUNK", str(1 << 19))))
-    ap.add_argument("--workload", choices=["headline", "config2"], default="headline")
+    ap.add_argument("--workload", choices=["headline", "config2", "config4"], default="headline",
+                    help="headline: the 540x540 frame at 1024 spp (BASELINE metric); config2: configs[1] (no PBR branch); config4: configs[3] -- the "
+                         "reference's 4096-ray training batch per GPU, ray-batch sharded over the ranks (also a key of the headline line at every N)")
     ap.add_argument("--pose", default=os.environ.get("IA_BENCH_POSE", "male-3-casual:0"),
                     help="frame of the reference's pose files through plain FK: male-3-casual:{0,40,80,113} (peoplesnapshot training frames), "
                          "aist:{0,100,200,319} (animation, out of distribution), or synthetic:K (N(0, 0.25) joint angles, rounds 1-2)")
@@ -317,6 +392,23 @@ def main():
     headline = args.workload == "headline"
     rs, rays, export, mat, sg = build_headline(dev, args.hw, args.spp, rank, args.pose)
     n_rays = rays.shape[0]
+    if args.workload == "config4":
+        # BASELINE configs[3] on its own: K timed steps of the 4096-ray training batch per rank (ray-batch sharding of one frame)
+        c4 = measure_config4(rs, rays, mat, sg, dev, torch.ones(3, device=dev), steps=max(args.steps, 1), rank=rank, world=world,
+                             rccl_at_one_rank=force_rccl)
+        if rank == 0:
+            line = {"metric": "rays/sec (fwd+bwd), 4096-ray training batches per GPU (BASELINE configs[3]: uniform_light, spp 512)",
+                    "value": c4 and c4["rays_per_s"], "unit": "rays/s", "n_gpus": world, "steps": max(args.steps, 1), "warmup": 3,
+                    "ms_per_step": c4 and c4["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                    "data": "synthetic", "config": {"workload": c4 and c4["workload"], "pose": args.pose, "parallelism": f"ray-batch sharding x{world}",
+                                                    "library_sources_sha256_16": _build.source_fingerprint(), "library_built_from": _build.built_fingerprint()},
+                    "roofline": None, "cpu_baseline": None, "config4": c4}
+            _flush_c_stdout()
+            print(json.dumps(line), flush=True)
+        if world > 1 or force_rccl:
+            dist.destroy_process_group()
+        _flush_c_stdout()
+        return
     # one frame per rank (frame-/ray-batch sharding, replicated parameters).  Weak scaling = the SAME per-GPU workload at
     # every N: each rank renders the same frame (pose 0) against its own target image and draws its own random numbers,
     # so the per-rank work at N=8 is the N=1 work and the gradients that meet in the all-reduce still differ per rank.
@@ -583,8 +675,12 @@ def main():
     # ---- third key: BASELINE configs[3] shape = the reference's OWN training batch (configs/sampler/edge.yaml:2: 4096 rays per step
     # and GPU; PBR branch, render_mode=uniform_light, spp 512, fwd + bwd + Adam), rays drawn on the subject of the same frame
     config4 = None
-    if headline and rank == 0 and world == 1 and not args.no_config4:
-        config4 = measure_config4(rs, rays, mat, sg, dev, bg)
+    if headline and not args.no_config4:
+        # EVERY rank: at N > 1 the batches are sharded over the ranks and the gradients meet in the all-reduce (the regime where the
+        # 101 MB exchange is a visible share of a step, unlike the 300 ms headline step)
+        if sync is not None:
+            sync.remove()                   # the headline step's gradient hooks: config 4 registers its own on the same parameters
+        config4 = measure_config4(rs, rays, mat, sg, dev, bg, rank=rank, world=world, rccl_at_one_rank=force_rccl)
 
     if rank == 0:
         stats = dict(out["stats"])

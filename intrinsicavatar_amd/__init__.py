@@ -16,11 +16,14 @@ __version__ = "0.1.0"
 
 import os as _os
 
-# Host tuning: kernel arguments in device memory (a shorter launch path of the HIP runtime; read when the runtime initialises, i.e. at
-# the process's first device call -- import this package before touching the GPU, or export the variable).  The path issues hundreds of
-# launches per step: the reference's 4096-ray training step 21.4 -> 20.8 ms, the headline step 309.5 -> 307.5 ms (same box, alternating,
-# profiles/r05_dev_kernarg.txt).  An explicit setting in the environment wins.
-_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# Host tuning (opt-in): HIP_FORCE_DEV_KERNARG=1 keeps kernel arguments in device memory (a shorter launch path of the HIP runtime; read
+# when the runtime initialises, i.e. at the process's first device call).  The path issues hundreds of launches per step: the reference's
+# 4096-ray training step 21.4 -> 20.8 ms, the headline step 309.5 -> 307.5 ms (same box, alternating, profiles/r05_dev_kernarg.txt).
+# It is a process-wide setting that child processes inherit, so importing the package does NOT write it: the entry points (bench.py,
+# __graft_entry__.py, tools/) set it themselves before HIP initialises, a host application exports it, and
+# IA_HOST_TUNING=1 makes this import do it.
+if _os.environ.get("IA_HOST_TUNING") == "1":
+    _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 
 def install_aliases() -> None:

@@ -187,6 +187,22 @@ def scan_tmp(n: int, device, extra_bytes: int = 0):
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
+_ZEROS_FILL = os.environ.get("IA_ZEROS", "fill") == "fill"
+
+
+def zeros(shape, device, dtype=torch.float32):
+    """zero-filled tensor through a fill KERNEL (torch.full) instead of torch.zeros' hipMemsetAsync: on the launch-rate-bound 4096-ray step
+    the device idles ~30 us in front of every memset against ~5 us in front of a kernel (profiles/r06_launch_audit_after_stepops.json:
+    455 us of idle in front of 15 memsets).  IA_ZEROS=memset restores torch.zeros (A/B)."""
+    if _ZEROS_FILL:
+        return torch.full(shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,), 0, dtype=dtype, device=device)
+    return torch.zeros(shape, dtype=dtype, device=device)
+
+
+def zeros_like(t):
+    return zeros(tuple(t.shape), t.device, t.dtype)
+
+
 i64 = C.c_int64
 i32 = C.c_int
 f32 = C.c_float

@@ -90,7 +90,7 @@ __global__ void zero_one_kernel(T* dst) { *dst = 0; }
 // in chunks of 1024 x SCAN_ITEMS elements with a running carry and writes the total itself -- one launch instead of the four of the tiled
 // protocol (tiles, tile sums, copy of the total, add-back); the 4096-ray step issued 75 scan launches (profiles/r05_config4_kernel_stats.csv).
 constexpr int SCAN_SMALL_THREADS = 1024;
-constexpr int64_t SCAN_SMALL_MAX = 1 << 17;
+constexpr int64_t SCAN_SMALL_MAX = 1 << 15;      // 8 chunks of 4096: above that the tiled protocol's parallel tiles win
 template <typename T>
 __global__ __launch_bounds__(SCAN_SMALL_THREADS) void scan_small_kernel(const T* in, T* out, T* total, int64_t n)
 {

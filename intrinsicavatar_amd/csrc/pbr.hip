@@ -777,7 +777,15 @@ IA_EXPORT int ia_pbr_shade(int mode, int64_t F, const float* normal, const float
 }
 
 
-constexpr int64_t ENV_ACC_MIN_F = (int64_t)1 << 21;
+// batches below this scatter the image gradient with atomics directly; IA_ENV_ACC_MIN_F overrides (A/B runs).  2^18: the 4096-ray training
+// batch at spp 512 has 2.09 M foreground points (just under the former 2^21) and its backward took 1.33 ms with direct atomics on the
+// 256 x 512 training light against 0.2 ms through the band-sorted records (config-4 step 15.7 -> 14.3 ms, same box)
+static int64_t env_acc_min_f()
+{
+    static const int64_t v = [] { const char* e = getenv("IA_ENV_ACC_MIN_F"); return e ? (int64_t)atoll(e) : ((int64_t)1 << 18); }();
+    return v;
+}
+#define ENV_ACC_MIN_F env_acc_min_f()
 constexpr size_t ENV_FIXED_MAX_TEXELS = (size_t)1 << 21;       // 1024 x 2048
 extern "C" int64_t ia_scan_tmp_bytes(int64_t n);
 extern "C" int ia_exclusive_scan_i32(const int32_t* in, int32_t* out, int32_t* total, int64_t n, void* tmp, ia_stream_t stream);

@@ -446,12 +446,22 @@ IA_EXPORT int ia_morton_order(int64_t n, const float* pts, const float* origin_h
     void* scan_tmp = base + 4 * p.col + 2 * p.hist_bytes;
     static const int raster = getenv("IA_SORT_RASTER_BITS") ? atoi(getenv("IA_SORT_RASTER_BITS")) : 0;       // experiment knob, see morton_key
     const size_t lds = (size_t)2 * TILE * sizeof(uint32_t);
-    // once per process: 64 KB of dynamic LDS per workgroup (above the 48 KB default), and the device check of the atomic ranking
-    static std::once_flag once;
-    static bool rtn_ok = false;
-    std::call_once(once, [lds]() {
-        g_rank_mode = 2;
-#define IA_SET_LDS(F, L, R) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&radix_scatter_kernel<F, L, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+    // once per DEVICE: 2 x TILE x 4 = 128 KB of dynamic LDS per workgroup of the scatter kernels (above the 64 KB a kernel gets without the
+    // attribute; + 22 KB static), and the device check of the atomic ranking -- a process that sorts on several devices sets each one up
+    // with that device current, and trusts the ranking mode probed on THAT device
+    constexpr int MAX_DEVICES = 64;
+    static std::once_flag once[MAX_DEVICES];
+    static bool rtn_ok_dev[MAX_DEVICES];
+    static int setup_rc[MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+        ia::set_error("ia_morton_order: hipGetDevice failed or device index >= %d", MAX_DEVICES);
+        return IA_ERR_LAUNCH;
+    }
+    std::call_once(once[dev], [lds, dev]() {
+        rtn_ok_dev[dev] = false;
+        setup_rc[dev] = 0;
+#define IA_SET_LDS(F, L, R) if (hipFuncSetAttribute(reinterpret_cast<const void*>(&radix_scatter_kernel<F, L, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) setup_rc[dev] = 1
         IA_SET_LDS(true, false, true); IA_SET_LDS(false, false, true); IA_SET_LDS(false, true, true); IA_SET_LDS(true, true, true);
         IA_SET_LDS(true, false, false); IA_SET_LDS(false, false, false); IA_SET_LDS(false, true, false); IA_SET_LDS(true, true, false);
 #undef IA_SET_LDS
@@ -465,9 +475,15 @@ IA_EXPORT int ia_morton_order(int64_t n, const float* pts, const float* origin_h
             if (hipMemcpy(&h, d, sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) h = -1;
         }
         (void)hipFree(d);
-        rtn_ok = (h == 0);
-        g_rank_mode = rtn_ok ? 1 : 2;
+        rtn_ok_dev[dev] = (h == 0);
     });
+    if (setup_rc[dev] != 0) {
+        (void)hipGetLastError();
+        ia::set_error("ia_morton_order: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) failed on device %d", lds, dev);
+        return IA_ERR_LAUNCH;
+    }
+    const bool rtn_ok = rtn_ok_dev[dev];
+    g_rank_mode = rtn_ok ? 1 : 2;                     // diagnostic (ia_sort_rank_mode): the mode of the device that sorted last
     for (int k = 0; k < p.npass; k++) {
         const bool first = k == 0, last = k == p.npass - 1;
         const uint2* pin = first ? nullptr : pbuf[(k - 1) & 1];        // pass k > 0 reads what pass k - 1 wrote

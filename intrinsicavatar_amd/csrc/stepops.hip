@@ -267,42 +267,55 @@ __global__ __launch_bounds__(1024) void envlight_pdf_tables_kernel(int H, int W,
 {
     __shared__ double sh[16];
     __shared__ double carry_s;
-    const int P = H * W, tid = threadIdx.x, nt = blockDim.x;
-    const int per = (P + nt - 1) / nt, p0 = tid * per, p1 = min(P, p0 + per);          // contiguous share per thread: ordered running sums
+    const int P = H * W, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
+    // pass 1 (coalesced, thread t takes pixels t, t + 1024, ...): w staged in the cdf buffer; ordered total
     double local = 0.0;
-    for (int p = p0; p < p1; p++) {
+    for (int p = tid; p < P; p += nt) {
         const float lum = fmaxf(0.2126f * base[3 * p] + 0.7152f * base[3 * p + 1] + 0.0722f * base[3 * p + 2], 0.f);
         const float sin_t = sinf(((float)(p / W) + 0.5f) * PI_F / (float)H);
-        local += (double)lum * (double)sin_t;
+        const double w = (double)lum * (double)sin_t;
+        cdf[p] = w;
+        local += w;
     }
     const double total = block_sum_d(local, sh);
-    // pmf + this thread's running sum; then the exclusive scan of the threads' sums
-    double run = 0.0;
-    for (int p = p0; p < p1; p++) {
-        const float lum = fmaxf(0.2126f * base[3 * p] + 0.7152f * base[3 * p + 1] + 0.0722f * base[3 * p + 2], 0.f);
-        const float sin_t = sinf(((float)(p / W) + 0.5f) * PI_F / (float)H);
-        const float q = (float)(((double)lum * (double)sin_t) / total);
-        pmf[p] = q;
-        run += (double)q;
-    }
-    // exclusive scan over threads (wave scan + wave offsets)
-    const int lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
-    double inc = run;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double o = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += o;
-    }
-    __syncthreads();
-    if (lane == 63) sh[wid] = inc;
     if (tid == 0) carry_s = 0.0;
     __syncthreads();
-    double off_w = 0.0;
-    for (int w = 0; w < wid && w < nw; w++) off_w += sh[w];
-    double acc = off_w + inc - run;
-    for (int p = p0; p < p1; p++) {
-        acc += (double)pmf[p];
-        cdf[p] = acc;
+    // pass 2: chunks of 1024 x 4 consecutive pixels: pmf = float(w / total), cdf = carry + inclusive running sum of the fp32 pmf in double
+    for (int chunk = 0; chunk < P; chunk += nt * 4) {
+        const int p0 = chunk + tid * 4;
+        double q[4], run = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float f = 0.f;
+            if (p0 + k < P) {
+                f = (float)(cdf[p0 + k] / total);
+                pmf[p0 + k] = f;
+            }
+            run += (double)f;
+            q[k] = run;                       // inclusive within the thread
+        }
+        double inc = run;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        __syncthreads();                      // sh free (previous iteration's readers are done)
+        if (lane == 63) sh[wid] = inc;
+        __syncthreads();
+        double off_w = 0.0, tot = 0.0;
+        for (int w = 0; w < nw; w++) {
+            const double t = sh[w];
+            if (w < wid) off_w += t;
+            tot += t;
+        }
+        const double basev = carry_s + off_w + (inc - run);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (p0 + k < P) cdf[p0 + k] = basev + q[k];
+        __syncthreads();                      // everyone has read carry_s
+        if (tid == 0) carry_s += tot;
+        __syncthreads();
     }
 }
 

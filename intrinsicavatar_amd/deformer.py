@@ -49,7 +49,8 @@ class SNARFDeformer:
         self.spec_counters = None            # optional int64 [5] device tensor: accumulated by the early-filter search (bench.py)
         self._tls = threading.local()        # per-call diagnostics of _candidates, per host thread (the secondary march runs it on several)
         self.spec_canary = self.SPEC_CANARY  # every k-th point of a batch is searched again to the end and compared (0 = off)
-        self._canary_parts = []              # one int64 [3] device accumulator per host thread / stream (canary_totals() adds them up)
+        self._canary_parts = []              # one int64 [3] device accumulator per stream (canary_totals() adds them up)
+        self._canary_by_stream = {}
         self._canary_lock = threading.Lock()
         self.tfs = None
         self.voxel_J_cl = None
@@ -324,10 +325,13 @@ class SNARFDeformer:
             same = (rows[:, j].view(torch.int32) == ref.view(torch.int32)).all(1)
             bad = bad | (live & ~same)
         bad = bad | (~flagged & (got_bits != want_bits))
-        acc = getattr(self._tls, "canary", None)
-        if acc is None:                  # this thread's accumulator (its stream orders the updates)
-            acc = self._tls.canary = torch.zeros(3, dtype=torch.int64, device=dev)
-            with self._canary_lock:
+        # one accumulator per STREAM (its stream orders the updates): the secondary march starts fresh worker threads on every call but
+        # re-uses its side streams, so keying by thread would add a device tensor to the list per march
+        skey = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+        with self._canary_lock:
+            acc = self._canary_by_stream.get(skey)
+            if acc is None:
+                acc = self._canary_by_stream[skey] = torch.zeros(3, dtype=torch.int64, device=dev)
                 self._canary_parts.append(acc)
         acc += torch.stack([torch.full((), n, dtype=torch.int64, device=dev), bad.sum(), flagged.sum()])
 

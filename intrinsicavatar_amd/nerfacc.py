@@ -141,7 +141,7 @@ def traverse_grids(
     E, S = tot & 0xFFFFFFFF, tot >> 32
 
     iv_vals = torch.empty(E, dtype=torch.float32, device=dev)
-    iv_flags = torch.zeros((2, E), dtype=torch.bool, device=dev)
+    iv_flags = L.zeros((2, E), dev, torch.bool)
     iv_ray = torch.empty(E, dtype=torch.int64, device=dev)
     sm_vals = torch.empty(S, dtype=torch.float32, device=dev)
     sm_ray = torch.empty(S, dtype=torch.int64, device=dev)

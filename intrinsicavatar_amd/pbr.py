@@ -337,7 +337,7 @@ class _PbrShade(torch.autograd.Function):
         c = lambda t: None if t is None else t.contiguous().float()     # noqa: E731
         g_n, g_a = torch.empty((F_, 3), device=dev), torch.empty((F_, 3), device=dev)
         g_r, g_m = torch.empty(F_, device=dev), torch.empty(F_, device=dev)
-        g_base = torch.zeros_like(env_base) if ctx.needs_input_grad[5] else None
+        g_base = L.zeros_like(env_base) if ctx.needs_input_grad[5] else None
         H, W, _ = env_base.shape
         nb = int(L.lib().ia_pbr_shade_bwd_scratch_bytes(L.i64(F_))) if g_base is not None else 0
         scratch = torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None
@@ -571,7 +571,7 @@ def scatter_secondary(F_: int, src: Tensor, tr: Tensor, rgb: Tensor):
     """traced (transmittance [M,1], rgb [M,3]) back into dense [F,1] / [F,3] (zeros for masked points), transmittance
     clamped to [0, 1] (:796-803)."""
     dev = src.device
-    buf = torch.zeros(F_ * 4, device=dev)                     # one fill for both
+    buf = L.zeros(F_ * 4, dev)                     # one fill for both
     d_tr, d_rgb = buf[:F_].view(F_, 1), buf[F_:].view(F_, 3)
     L.check(L.lib().ia_secondary_scatter(L.i64(src.shape[0]), L.ptr(src), L.ptr(tr.reshape(-1).float().contiguous()),
                                          L.ptr(rgb.float().contiguous()), L.ptr(d_tr), L.ptr(d_rgb), L.stream()), "ia_secondary_scatter")

@@ -261,7 +261,8 @@ class RenderStep:
                               render_mode: str = "uniform_light", env_base: Optional[Tensor] = None,
                               background_color: Optional[Tensor] = None, global_illumination: bool = False,
                               light_sampling: str = "shared", loss_scale: float = 1.0, retain_graph: bool = False,
-                              material_jitter: Optional[Tensor] = None, loss_config: Optional[dict] = None) -> Dict[str, Tensor]:
+                              material_jitter: Optional[Tensor] = None, loss_config: Optional[dict] = None,
+                              eik_denominator=None) -> Dict[str, Tensor]:
         """BASELINE config 4: training step with the PBR branch (material head, volume scattering, secondary rays,
         light / uniform_light estimator) -- fwd + bwd to geometry, radiance, material and environment-light parameters.
         loss_scale: weight of this ray chunk when a frame is processed in several chunks with gradient accumulation
@@ -272,7 +273,10 @@ class RenderStep:
         reference's `system.loss` weights (configs/config.yaml:87-109: lambda_rgb_l1, lambda_rgb_phys_l1, lambda_mask_bce, ...) = the
         loss of IntrinsicAvatarSystem.training_step (systems/intrinsic_avatar.py:160-301) on the reference's output dict
         (train_phys.reference_training_loss; target_rgb / target_mask are the batch's `rgb` / `alpha`); its terms come back as
-        out["loss_terms"].  tests/test_gpu_backward_golden.py holds this call to the reference's own autograd."""
+        out["loss_terms"].  tests/test_gpu_backward_golden.py holds this call to the reference's own autograd.
+        eik_denominator: None = the eikonal mean is over this call's samples; a number, or a callable n_samples -> number (e.g. an
+        all-reduce of the ranks' sample counts divided by the world size), = the denominator of that mean under ray-batch sharding, so that
+        the average of the ranks' losses is the loss of the global batch (systems/intrinsic_avatar.py:235-239 takes .mean() over all samples)."""
         from . import train_phys
         rays_o, rays_d, far, t_starts, t_ends, ray_indices, packed_info, stats = self.sample(rays, jitter)
         out = train_phys.shade_differentiable_phys(self, material, emitter, rays_o, rays_d, ray_indices, t_starts, t_ends,
@@ -281,7 +285,8 @@ class RenderStep:
                                                    global_illumination=global_illumination, light_sampling=light_sampling,
                                                    jitter_n=material_jitter)
         if loss_config is None:
-            loss = train_phys.training_loss_phys(out, target_rgb, target_mask)
+            den = eik_denominator(int(t_starts.shape[0])) if callable(eik_denominator) else eik_denominator
+            loss = train_phys.training_loss_phys(out, target_rgb, target_mask, **({} if den is None else dict(eik_denominator=den)))
         else:
             if background_color is None:
                 background_color = torch.ones(3, device=rays.device)
@@ -308,7 +313,7 @@ class RenderStep:
         if hook is not None:                                      # thread's half-frame reaches its secondary march
             hook()
         tr = torch.ones((M, 1), device=dev)
-        rgb = torch.zeros((M, 3), device=dev)
+        rgb = L.zeros((M, 3), dev)
         step = (far - near) / (n_secondary - 1)
         beta = self._beta()
         w2s_rot = self.deformer.w2s[:3, :3].contiguous()
@@ -357,6 +362,10 @@ class RenderStep:
             t.join()
         for side in self._side_streams:
             main.wait_stream(side)                              # tr / rgb are read on the caller's stream
+        if not errors:
+            # what the side streams' pools hold now is what the next march can re-use: reserved - (what the caller's pool has live + cached)
+            # is not exposed per pool, so the working-set estimate of this march stands in for it
+            self._side_pool_bytes = n_streams * max(b - a for a, b in chunks) * self.SECONDARY_BYTES_PER_RAY
         if errors:
             if all(isinstance(e, torch.cuda.OutOfMemoryError) for e in errors):
                 # the side streams' allocator pools did not fit after all (another process on the GPU, a smaller device): give their
@@ -366,6 +375,9 @@ class RenderStep:
                 torch.cuda.synchronize(dev)
                 torch.cuda.empty_cache()
                 self.secondary_stream_fallbacks = getattr(self, "secondary_stream_fallbacks", 0) + 1
+                # the gate let this batch through and it did not fit: do not try again on the next calls (each failed attempt costs a
+                # full synchronise, an empty_cache and a second march); the streams come back after STREAM_FALLBACK_COOLDOWN marches
+                self._stream_cooldown = self.STREAM_FALLBACK_COOLDOWN
                 tr.fill_(1.0)
                 rgb.zero_()
                 self._secondary_chunks(plan_secondary_chunks(M, chunk, 1)[::-1], *args)
@@ -376,6 +388,7 @@ class RenderStep:
     import threading as _threading
     _march_hooks = _threading.local()          # per host thread: .enter (callable) / .streams (override of SECONDARY_STREAMS)
     SECONDARY_STREAMS = int(os.environ.get("IA_SECONDARY_STREAMS", "2"))
+    STREAM_FALLBACK_COOLDOWN = int(os.environ.get("IA_STREAM_FALLBACK_COOLDOWN", "64"))
     # bytes of device memory a marched ray of a chunk keeps live at the peak of its chunk on the headline scene (9 samples per ray on
     # average x (search outputs + sorted copies + level-major hash features)): 142 GiB live for 2 x 10.5 Mi rays = ~7 KB per ray
     SECONDARY_BYTES_PER_RAY = int(os.environ.get("IA_SECONDARY_BYTES_PER_RAY", "7168"))
@@ -390,11 +403,18 @@ class RenderStep:
         if n <= 1 or dev.type != "cuda" or M <= self.SECONDARY_STREAMS_MIN_RAYS:
             self.last_secondary_streams = 1
             return 1
+        if getattr(self, "_stream_cooldown", 0) > 0:          # an earlier march ran out of memory on the side streams
+            self._stream_cooldown -= 1
+            self.last_secondary_streams = 1
+            return 1
         plan = plan_secondary_chunks(M, chunk, n, self.SECONDARY_MIN_CHUNK)
         in_flight = n * max(b - a for a, b in plan) * self.SECONDARY_BYTES_PER_RAY
         free, _total = torch.cuda.mem_get_info(dev)
-        cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-        n = n if free + cached >= 1.3 * in_flight else 1
+        # usable by the side streams: device-free memory plus the blocks already cached in THEIR pools (steady state: the previous step's
+        # working set).  Blocks cached in the caller's pool are not available to another stream, so they do not count -- once the side
+        # streams exist and have run (self._side_pool_bytes: what they held at the end of the last march), before that only free memory
+        side = getattr(self, "_side_pool_bytes", 0) if getattr(self, "_side_streams", None) is not None else 0
+        n = n if free + side >= 1.3 * in_flight else 1
         self.last_secondary_streams = n
         return n
     # below ~8 M rays the kernels of a chunk no longer fill the device and splitting them makes it worse (config-4 shape, 1 M secondary rays:
@@ -553,6 +573,7 @@ class RenderStep:
                 out["secondary_tr"], out["fg_Lo"] = sec_tr, fg_Lo
                 out["fg_extras"] = dict(positions=pos, normals=nrm, albedo=alb, roughness=rough, metallic=metal, t_dirs=view)
             out["resampled_packed_info"] = vi.resampled_packed_info
+            out["sampled_indices"] = vi.sampled_idx            # source interval of every re-sample (K1's `indices`): a reference, no launch
             if return_index_lists:
                 fg_idx, bg_idx, rri, rw = vi.index_lists(weights, transmittance)
                 out.update(resampled_ray_indices=rri, resampled_weights=rw, fg_indices=fg_idx, bg_indices=bg_idx)

@@ -87,7 +87,7 @@ class _SDFField(Function):
         q = (g_grad / scale).contiguous().float()
         gE, gG = torch.empty((n, 32), device=dev), torch.empty((n, 32), device=dev)
         ns, ptrs, strides, widths, muls, adds = _segs([(enc, 32, 1.0, 0.0), (xp, 3, 2.0, -1.0)])
-        g_table = torch.zeros_like(table)
+        g_table = L.zeros_like(table)
         if FUSED_WGRAD:
             dW1k, db1, dW2, db2 = zeros_like_shapes([(64, 35), (64,), (13, 64), (13,)], dev)
             want_x = ctx.needs_input_grad[0]
@@ -227,7 +227,7 @@ def zeros_like_shapes(shapes, dev):
     for n in sizes:
         offs.append(tot)
         tot += (n + 63) // 64 * 64
-    buf = torch.zeros(tot, device=dev)
+    buf = L.zeros(tot, dev)
     return [buf[o:o + n].view(s) for o, n, s in zip(offs, sizes, shapes)]
 
 
@@ -244,7 +244,7 @@ class _Alpha(Function):
         sdf, dists, b = ctx.saved_tensors
         g = g.contiguous()
         g_sdf = torch.empty_like(sdf)
-        g_beta = torch.zeros(1, device=sdf.device)
+        g_beta = L.zeros(1, sdf.device)
         L.check(L.lib().ia_laplace_alpha_bwd(L.i64(sdf.shape[0]), L.ptr(sdf), L.ptr(dists), L.f32(0.0), L.ptr(b), L.ptr(g),
                                              L.ptr(g_sdf), L.ptr(g_beta), L.stream()), "ia_laplace_alpha_bwd")
         return g_sdf, None, g_beta.reshape(())
@@ -292,7 +292,7 @@ class _Radiance(Function):
             dW1, db1 = wgrad(G1, 64, X, 67)
             dW2, db2 = wgrad(G2, 64, A1, 64)
             dW3, db3 = wgrad(G3, 3, A2, 64)
-        g_table = torch.zeros_like(table)
+        g_table = L.zeros_like(table)
         fields.hashgrid_backward(xp, g_x, g_table, level_mask=ctx.level_bits)      # columns 0..31, row stride 68
         g_feat = g_x[:, 35:48]
         g_nw = g_x[:, 64:67]

@@ -34,7 +34,7 @@ class _HashEncode(Function):
     @staticmethod
     def backward(ctx, g_enc):
         xp, table = ctx.saved_tensors
-        g_table = torch.zeros_like(table)
+        g_table = L.zeros_like(table)
         fields.hashgrid_backward(xp, g_enc.contiguous(), g_table)
         return None, g_table
 
@@ -315,7 +315,12 @@ def reference_training_loss(out: Dict[str, Tensor], rgb: Tensor, alpha: Optional
 
 
 def forward_backward_phys_pipelined(rs, views, material, emitter, spp: int, n_workers: int = 2, **kw) -> Dict[str, int]:
-    """Several ray chunks of ONE frame in flight: `views` = [(rays, target_rgb, target_mask, loss_scale), ...] as a caller would pass
+    """EXPERIMENTAL (not the default of any entry point; bench.py takes it only with IA_FRAME_PIPELINE=n; measured 317-325 ms against
+    310-322 ms for the headline step: no gain, profiles/r05_frame_pipeline_ab.jsonl).  Covered by
+    tests/test_gpu_train.py::test_pipelined_half_frames_match_the_sequential_chunk_loop (same gradients as the sequential chunk loop to
+    2e-5 of a group's largest entry); shared per-call diagnostics of the RenderStep (last_secondary_streams, the deformer's finite-voxel
+    flag) are written by both workers and only meaningful after the call.
+    Several ray chunks of ONE frame in flight: `views` = [(rays, target_rgb, target_mask, loss_scale), ...] as a caller would pass
     them to RenderStep.forward_backward_phys one after the other (gradient accumulation over the chunks of a frame).  Here worker k
     takes the chunks k, k + n_workers, ... on its own HIP stream and host thread, and -- what makes it pay -- worker k + 1 starts when
     worker k ENTERS its secondary march: the primary sampling / shading / backward of one half-frame (many small kernels and the

@@ -265,3 +265,29 @@ def explain_gradient_outliers(rs, pts_gpu, pts_ref, grad_ref, thresh, max_shift=
     return c(explained), dict(same_point=c(same_point), field_agrees=c(field_agrees), face_flip=c(face_flip), near_tie=c(near_tie),
                               jump_nearby=c(jump_nearby), cell_changes=c(cell_changes), residual=c(torch.where(field_agrees, residual, torch.minimum(residual, best))),
                               shift=c(shift))
+
+
+def assert_normal_outliers_explained(rs, rays, out, ref, dev="cuda:0"):
+    """For a RenderStep.forward result `out` and the oracle's render_step result `ref` WITH IDENTICAL SAMPLE SETS: every sample whose SDF
+    gradient is more than 10 x p99 away from the oracle's is explained by explain_gradient_outliers (position / cell-face flip / near tie /
+    jump within 4e-6 m), and the outlier pixels of comp_normal (10 x p99) are the rays of those samples.  -> number of outlier samples."""
+    import torch
+    g_gpu, g_ref = out["sdf_grad"].cpu().numpy(), ref["sdf_grad"]
+    both = out["valid"].cpu().numpy()
+    e = np.where(both, np.abs(g_gpu - g_ref).max(-1), 0.0)
+    thresh = 10.0 * float(np.quantile(e, 0.99))
+    idx = np.nonzero(e > thresh)[0]
+    r_smpl = rs.deformer.transform_rays_w2s(rays.float())
+    ri = out["ray_indices"].long()
+    sel_ = torch.from_numpy(idx).to(ri.device)
+    mid_g = (out["t_starts"] + out["t_ends"]) / 2.0
+    mid_r = (torch.from_numpy(ref["t_starts"]).to(dev) + torch.from_numpy(ref["t_ends"]).to(dev)) / 2.0
+    pts_g = (r_smpl[ri, :3] + r_smpl[ri, 3:6] * mid_g[:, None])[sel_]
+    pts_r = (r_smpl[ri, :3] + r_smpl[ri, 3:6] * mid_r[:, None])[sel_]
+    explained, why = explain_gradient_outliers(rs, pts_g, pts_r, g_ref[idx], thresh)
+    assert explained.all(), (idx[~explained].tolist(), {k: v[~explained].tolist() for k, v in why.items()}, thresh)
+    flip_rays = set(ri.cpu().numpy()[idx].tolist())
+    en = np.abs(out["comp_normal"].cpu().numpy() - ref["comp_normal"]).max(-1)
+    bad_px = set(np.nonzero(en > 10.0 * float(np.quantile(en, 0.99)))[0].tolist())
+    assert bad_px <= flip_rays, sorted(bad_px - flip_rays)
+    return int(idx.size)

@@ -53,7 +53,14 @@ def test_render_step_vs_oracle_on_reference_poses(oracle, pose):
     """BASELINE config 2 shape (radiance + SDF geometry) on a peoplesnapshot training frame and an animation frame."""
     from oracle import render_ref as R
     rs, rays, export = _frame(pose, 96)
+    # the runtime canary of the search's early filter (SNARFDeformer.spec_canary, DESIGN 4.5) rides along: every 16th point of every search
+    # batch of this frame is searched again to the end + K9 (filter.cu:10-54) and compared with the row the product search left
+    rs.deformer.spec_canary = 16
+    rs.deformer.canary_totals(reset=True)
     out = rs.forward(rays)
+    n_chk, n_bad, _ = rs.deformer.canary_totals(reset=True)
+    rs.deformer.spec_canary = 0
+    assert n_chk > 5000 and n_bad == 0, (n_chk, n_bad)
     ref = R.render_step(R.Scene(**export), N(rays))
     st, sr = out["stats"], ref["stats"]
     assert sr["n_samples0"] > 3000
@@ -64,6 +71,10 @@ def test_render_step_vs_oracle_on_reference_poses(oracle, pose):
     for k, cap in (("comp_rgb", (3e-2, 1.5e-3, 1e-4)), ("opacity", (4e-4, 3e-5, 2e-6)), ("comp_normal", (0.25, 5e-3, 1e-3)),
                    ("depth", (3e-4, 3e-5, 3e-6))):
         PB.held(f"refpose/{pose}/{k}", N(out[k]), ref[k], cap)
+    # the one-pixel maxima of comp_normal, DEMONSTRATED sample by sample (tests/forward_golden.explain_gradient_outliers) when the sample sets coincide
+    if int((cnt != cnt_ref).sum()) == 0:
+        from tests import forward_golden as FG
+        print(f"refpose/{pose}: {FG.assert_normal_outliers_explained(rs, rays, out, ref)} gradient outliers, all explained")
 
 
 def test_relight_vs_oracle_on_an_animation_pose(oracle):
@@ -82,7 +93,12 @@ def test_relight_vs_oracle_on_an_animation_pose(oracle):
     light_u, shuffle_u = rng.random((spp, 3), dtype=np.float32), rng.random((n, spp), dtype=np.float32)
     bg = np.array([0.2, 0.4, 0.6], np.float32)
     ref = R.relight_step(sc, N(rays), spp=spp, light_u=light_u, shuffle_u=shuffle_u, global_illumination=True, background_color=bg)
+    rs.deformer.spec_canary = 1024                       # the canary over the ~0.6 M secondary rays' march points as well: must count nothing
+    rs.deformer.canary_totals(reset=True)
     d = rs.forward_(rays, mat, env, spp, T(light_u), T(shuffle_u), background_color=T(bg), global_illumination=True)
+    n_chk, n_bad, _ = rs.deformer.canary_totals(reset=True)
+    rs.deformer.spec_canary = 0
+    assert n_chk > 1000 and n_bad == 0, (n_chk, n_bad)
     want = R.forward_output_dict(ref, bg, "light")
     assert sorted(d) == sorted(want)
     assert ref["stats"]["n_fg"] > 50_000

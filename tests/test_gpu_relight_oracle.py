@@ -13,6 +13,8 @@ import torch
 from tests import parity_bars as PB
 
 pytestmark = pytest.mark.gpu
+# |Lo_gpu - Lo_oracle| / mean |Lo| over the samples in the SAME discrete state (tests/parity_bars.held_by_discrete_state): (max, p99, mean)
+SAME_STATE_CAP = (1.0, 3e-2, 4e-3)
 DEV = "cuda:0"
 
 
@@ -106,6 +108,11 @@ def test_relight_light_mode_vs_oracle(setup, hw, spp, gi):
     scale = np.abs(Lo_r).mean() + 1e-6
     # outgoing radiance of every re-sample whose visibility agrees, relative to the frame's mean radiance
     PB.held(f"{tag}/fg_Lo_over_mean", Lo_g / scale, Lo_r / scale, (25.0, 3e-2, 4e-3))
+    # ... and split by discrete state: same source interval (K1's index) and the same secondary transmittance to 1e-5 -> a float tolerance;
+    # everything else is a counted discrete event (another interval: other normal / material / position; a grazed zero crossing)
+    sidx_g, sidx_r = N(out["sampled_indices"])[same], ref["k1"]["sampled_indices"][same]
+    same_state = (sidx_g == sidx_r) & (np.abs(tr_g - tr_r) <= 1e-5)
+    PB.held_by_discrete_state(tag, N(out["fg_Lo"])[ig], ref["fg_Lo"][ir], same_state, max(16, int(2e-2 * same_state.size)), SAME_STATE_CAP)
     img_g, img_r = N(out["comp_rgb_phys"]), ref["comp_rgb_phys"]
     assert np.isfinite(img_g).all()
     nohit = ~has
@@ -336,6 +343,9 @@ def test_relight_uniform_light_mode_vs_oracle(setup):
     Lo_g, Lo_r = N(out["fg_Lo"])[ig][ok], ref["fg_Lo"][ir][ok]
     scale = np.abs(Lo_r).mean() + 1e-6
     PB.held("relight/uniform_light/fg_Lo_over_mean", Lo_g / scale, Lo_r / scale, (25.0, 3e-2, 4e-3))
+    sidx_g, sidx_r = N(out["sampled_indices"])[same], ref["k1"]["sampled_indices"][same]
+    same_state = (sidx_g == sidx_r) & (np.abs(tr_g - tr_r) <= 1e-5)
+    PB.held_by_discrete_state("relight/uniform_light", N(out["fg_Lo"])[ig], ref["fg_Lo"][ir], same_state, max(16, int(2e-2 * same_state.size)), SAME_STATE_CAP)
     has = ref["resampled_packed_info"][:, 1] > 0
     for k, cap in (("comp_rgb_phys", (0.3, 3e-2, 1.5e-3)), ("visibility", (0.1, 1e-2, 5e-4))):
         PB.held(f"relight/uniform_light/{k}", N(out[k]), ref[k], cap)

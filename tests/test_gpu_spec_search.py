@@ -331,10 +331,13 @@ def test_canary_counts_nothing_on_the_product_path_and_catches_a_loosened_filter
         dfm._candidates(pts, with_src=True, order=order)                     # through the permutation as well
         n, bad, ovf = dfm.canary_totals(reset=True)
         assert n >= pts.shape[0] // 2 - 2 and bad == 0 and ovf <= 1e-4 * n, (n, bad, ovf)     # ovf: points with a 4th survivor (count compared only)
-        dfm.spec_eps, dfm.cell_tight = 5e-3, None
+        # the loosened filter changes the candidate set of only a few of these 1.1 M points (Q differs by one to three on this frame): EVERY
+        # point is checked here (k = 1) -- with every 4th the test depended on which residue class the handful of bad points fell in
+        dfm.spec_eps, dfm.cell_tight = 2e-2, None
+        dfm.spec_canary = 1
         dfm._candidates(pts, with_src=False)
         n2, bad2, _ = dfm.canary_totals(reset=True)
-        assert n2 >= pts.shape[0] // 4 - 1 and 0 < bad2 < 2e-3 * n2, (n2, bad2)
+        assert n2 == pts.shape[0] and 0 < bad2 < 2e-3 * n2, (n2, bad2)
     finally:
         dfm.spec_canary, dfm.spec_eps, dfm.cell_tight = old
 

@@ -464,3 +464,66 @@ def test_phys_training_step_vs_torch_autograd():
     print(worst)
     bad = {k: v for k, v in worst.items() if v > (5e-2 if (k.endswith("_table") or k == "env_base") else 1e-2)}
     assert not bad, worst
+
+
+def test_pipelined_half_frames_match_the_sequential_chunk_loop():
+    """train_phys.forward_backward_phys_pipelined (EXPERIMENTAL, off by default: IA_FRAME_PIPELINE): two ray chunks of one frame on two host
+    threads / HIP streams against the same chunks processed one after the other with gradient accumulation -- the same sample counts and the
+    same accumulated parameter gradients (each chunk's backward is what the sequential loop computes for it; the two-term sums meet in
+    AccumulateGrad)."""
+    from intrinsicavatar_amd import build
+    build.build()
+    from intrinsicavatar_amd import synthetic as S, fields, pbr, train_phys
+    rs, rays, _ = S.build_frame(DEV, 48, 48, pose_seed=0, beta=0.05, num_samples_per_ray=64, grid_D=16, grid_H=64, grid_W=64,
+                                smooth_iters=5, hash_amp=1e-2)
+    mat = fields.VolumeMaterial(seed=2).to(DEV)
+    yy, xx = np.meshgrid(np.linspace(0, np.pi, 32), np.linspace(-np.pi, np.pi, 64), indexing="ij")
+    sky = (0.6 + 0.35 * np.cos(yy)[..., None] * np.array([1.0, 0.8, 0.6]) + 0.05 * np.sin(2 * xx)[..., None]).astype(np.float32)
+    env = pbr.EnvironmentLightTensor(torch.from_numpy(sky).to(DEV)); env.update_pdf()
+    n = rays.shape[0]
+    g = torch.Generator().manual_seed(5)
+    target = torch.rand((n, 3), generator=g).to(DEV)
+    tmask = (torch.rand(n, generator=g) > 0.5).float().to(DEV)
+    spp = 16
+    h = n // 2
+    # explicit random numbers per chunk, so that both schedules draw the same ones: per-point light directions (training form of `light`)
+    lu = [torch.rand((h * spp + 4096, 3), generator=g).to(DEV), torch.rand(((n - h) * spp + 4096, 3), generator=g).to(DEV)]
+    views = [(rays[:h].contiguous(), target[:h].contiguous(), tmask[:h].contiguous(), h / n),
+             (rays[h:].contiguous(), target[h:].contiguous(), tmask[h:].contiguous(), (n - h) / n)]
+    params = rs.parameters() + [p for p in mat.parameters() if p.requires_grad] + [env.base]
+    kw = dict(render_mode="light", background_color=torch.ones(3, device=DEV), global_illumination=True, light_sampling="per_point")
+
+    def zero():
+        for p in params:
+            p.grad = None
+
+    zero()
+    stats = []
+    for (r, t, m, frac), u in zip(views, lu):
+        o = rs.forward_backward_phys(r, t, mat, env, spp, u, None, target_mask=m, loss_scale=frac, **kw)
+        stats.append(int(o["stats"]["n_fg"]))
+    torch.cuda.synchronize()
+    seq = [p.grad.detach().double().clone() for p in params]
+    assert all(torch.isfinite(t_).all() for t_ in seq) and sum(float(t_.abs().sum()) for t_ in seq) > 0
+
+    # the pipelined entry point draws its light directions on the device (light_u None): patch the per-chunk uniforms in through the views
+    orig = rs.forward_backward_phys
+    it = iter(lu)
+    lock = __import__("threading").Lock()
+    by_rays = {views[0][0].data_ptr(): lu[0], views[1][0].data_ptr(): lu[1]}
+
+    def with_u(r, t, material, emitter, spp_, light_u, shuffle_u, **k):
+        return orig(r, t, material, emitter, spp_, by_rays[r.data_ptr()], shuffle_u, **k)
+    zero()
+    rs.forward_backward_phys = with_u
+    try:
+        tot = train_phys.forward_backward_phys_pipelined(rs, views, mat, env, spp, n_workers=2, **kw)
+    finally:
+        del rs.forward_backward_phys
+    torch.cuda.synchronize()
+    assert tot["n_fg"] == sum(stats)
+    for p, a in zip(params, seq):
+        b = p.grad.detach().double()
+        scale = float(a.abs().max()) + 1e-30
+        # table gradients are float-atomic sums inside each chunk's backward (order varies run to run): 2e-5 of the largest entry
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-12, (tuple(p.shape), float((a - b).abs().max()), scale)
