@@ -21,7 +21,9 @@ def _i32c(t: Tensor) -> Tensor:
     return t.to(torch.int32).contiguous()
 
 
-def _resample_info(packed_info: Tensor, n: int, add_steps: bool) -> Tuple[Tensor, int]:
+def _resample_info(packed_info: Tensor, n: int, add_steps: bool, read_total: bool = True) -> Tuple[Tensor, int]:
+    """resampled packed_info + the total (the .item() of cdf.cu:183).  read_total False: no read-back -- the caller sizes its outputs for
+    the worst case n x n_rays and only ever walks them through the returned packed_info; the second result is that capacity."""
     n_rays = packed_info.shape[0]
     dev = packed_info.device
     rpi = torch.empty((n_rays, 2), dtype=torch.int32, device=dev)
@@ -30,6 +32,8 @@ def _resample_info(packed_info: Tensor, n: int, add_steps: bool) -> Tuple[Tensor
     L.check(L.lib().ia_resample_packed_info(L.i64(n_rays), L.ptr(packed_info), L.i32(n), L.i32(int(add_steps)),
                                             L.ptr(rpi), L.ptr(total), L.ptr(tmp), L.stream()),
             "ia_resample_packed_info")
+    if not read_total:
+        return rpi, n * n_rays
     return rpi, int(total.item())     # the .item() of cdf.cu:183
 
 
@@ -128,7 +132,7 @@ def ray_resampling_merge_compact(packed_info: Tensor, vals: Tensor, is_left: Ten
 
 
 # ----------------------------------------------------------------------------- K3 / K4
-def _fine(packed_info, t_starts, t_ends, wa, sdfs, n_samples, sdf_mode):
+def _fine(packed_info, t_starts, t_ends, wa, sdfs, n_samples, sdf_mode, exact_size=True):
     packed_info = _i32c(packed_info)
     if t_starts.dim() != 2 or t_starts.shape[1] != 1 or t_ends.dim() != 2 or t_ends.shape[1] != 1:
         raise RuntimeError("starts/ends must have shape (n_samples_in, 1)")
@@ -136,7 +140,11 @@ def _fine(packed_info, t_starts, t_ends, wa, sdfs, n_samples, sdf_mode):
         raise RuntimeError("weights/alphas must be 1D")
     st, en, wa = _f32v(t_starts), _f32v(t_ends), _f32v(wa)
     n_rays, dev = packed_info.shape[0], packed_info.device
-    rpi, T = _resample_info(packed_info, n_samples, False)
+    # exact_size False (extension; few points per ray only: the per-ray kernel never needs the total): the outputs are sized for the worst
+    # case n x n_rays, their tail past the last ray's range stays unwritten, and the size read-back of cdf.cu:511 is skipped -- for callers
+    # that walk the result through the returned packed_info (compact_foreground does)
+    capacity = (not exact_size) and n_samples <= 8
+    rpi, T = _resample_info(packed_info, n_samples, False, read_total=not capacity)
     rs = torch.empty((T, 1), dtype=torch.float32, device=dev)
     re = torch.empty((T, 1), dtype=torch.float32, device=dev)
     fg = torch.empty((T,), dtype=torch.bool, device=dev)
@@ -160,9 +168,9 @@ def ray_resampling_fine(packed_info, t_starts, t_ends, weights, n_samples):
 
 
 @torch.no_grad()
-def ray_resampling_sdf_fine(packed_info, t_starts, t_ends, alphas, sdfs, n_samples):
-    """lib/nerfacc/cdf.py:144-195 -> cdf.cu:536-696."""
-    return _fine(packed_info, t_starts, t_ends, alphas, sdfs, n_samples, True)
+def ray_resampling_sdf_fine(packed_info, t_starts, t_ends, alphas, sdfs, n_samples, exact_size=True):
+    """lib/nerfacc/cdf.py:144-195 -> cdf.cu:536-696.  exact_size (extension): see _fine."""
+    return _fine(packed_info, t_starts, t_ends, alphas, sdfs, n_samples, True, exact_size=exact_size)
 
 
 @torch.no_grad()

@@ -444,7 +444,8 @@ class RenderStep:
             sdf = self._sdf_at(ray_points(ro, rd, ray_indices, t_starts))
             alphas = laplace_alpha(sdf, t_ends - t_starts, beta)
             pinfo = lib_nerfacc.pack_info(ray_indices, m)
-            rpi, rs, re, is_fg = lib_nerfacc.ray_resampling_sdf_fine(pinfo, t_starts[:, None], t_ends[:, None], alphas, sdf, 4)
+            # (capacity-sized outputs: compact_foreground walks them through rpi, the size read-back of cdf.cu:511 is not needed)
+            rpi, rs, re, is_fg = lib_nerfacc.ray_resampling_sdf_fine(pinfo, t_starts[:, None], t_ends[:, None], alphas, sdf, 4, exact_size=False)
             # keep the foreground intervals (:516-528): count -> scan over rays -> segmented copy, and the packed_info of the kept list
             ray_indices, t_starts, t_ends, pinfo = lib_nerfacc.compact_foreground(rpi, rs, re, is_fg)
             if t_starts.numel() == 0:
@@ -571,6 +572,8 @@ class RenderStep:
                 rgb_phys = vi.composite(w_fg, fg_Lo, transmittance, background_color)
                 demod_phys = vi.composite(w_fg, fg_demod.contiguous(), transmittance, background_color)     # Lo_demod = Lo_diff + Lo_spec (:1421-1436)
                 out["secondary_tr"], out["fg_Lo"] = sec_tr, fg_Lo
+                if render_mode in ("light", "uniform_light"):
+                    out["secondary_rgb"] = sec_rgb
                 out["fg_extras"] = dict(positions=pos, normals=nrm, albedo=alb, roughness=rough, metallic=metal, t_dirs=view)
             out["resampled_packed_info"] = vi.resampled_packed_info
             out["sampled_indices"] = vi.sampled_idx            # source interval of every re-sample (K1's `indices`): a reference, no launch

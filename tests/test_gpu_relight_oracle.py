@@ -13,8 +13,21 @@ import torch
 from tests import parity_bars as PB
 
 pytestmark = pytest.mark.gpu
-# |Lo_gpu - Lo_oracle| / mean |Lo| over the samples in the SAME discrete state (tests/parity_bars.held_by_discrete_state): (max, p99, mean)
-SAME_STATE_CAP = (1.0, 3e-2, 4e-3)
+# per-sample radiance over the samples in the SAME discrete state (tests/parity_bars.held_by_discrete_state), (max, p99, mean):
+SAME_STATE_CAP = (0.1, 1e-2, 5e-4)          # |dLo| / mean |Lo|
+SAME_STATE_REL_CAP = (2e-2, 3e-3, 2e-4)     # |dLo| / (|Lo| + mean |Lo|)
+
+
+def _same_state(out, ref, same, ig, ir, tr_g, tr_r):
+    sidx_g, sidx_r = N(out["sampled_indices"])[same], ref["k1"]["sampled_indices"][same]
+    dn = np.abs(N(out["fg_extras"]["normals"])[ig] - ref["fg_extras"]["normals"][ir]).max(-1)
+    st = (sidx_g == sidx_r) & (np.abs(tr_g - tr_r) <= 1e-5) & (dn <= 1e-3)
+    if "secondary_rgb" in out and ref.get("secondary_rgb") is not None:
+        # the indirect radiance a secondary ray brings back is itself the composite of <= 4 shaded intervals behind K4's zero-crossing search
+        # (models/intrinsic_avatar.py:396-545): same discrete events one bounce further
+        a, b = N(out["secondary_rgb"])[ig], ref["secondary_rgb"][ir]
+        st &= np.abs(a - b).max(-1) <= 1e-3 * (1.0 + np.abs(b).max(-1))
+    return st
 DEV = "cuda:0"
 
 
@@ -110,9 +123,9 @@ def test_relight_light_mode_vs_oracle(setup, hw, spp, gi):
     PB.held(f"{tag}/fg_Lo_over_mean", Lo_g / scale, Lo_r / scale, (25.0, 3e-2, 4e-3))
     # ... and split by discrete state: same source interval (K1's index) and the same secondary transmittance to 1e-5 -> a float tolerance;
     # everything else is a counted discrete event (another interval: other normal / material / position; a grazed zero crossing)
-    sidx_g, sidx_r = N(out["sampled_indices"])[same], ref["k1"]["sampled_indices"][same]
-    same_state = (sidx_g == sidx_r) & (np.abs(tr_g - tr_r) <= 1e-5)
-    PB.held_by_discrete_state(tag, N(out["fg_Lo"])[ig], ref["fg_Lo"][ir], same_state, max(16, int(2e-2 * same_state.size)), SAME_STATE_CAP)
+    same_state = _same_state(out, ref, same, ig, ir, tr_g, tr_r)
+    PB.held_by_discrete_state(tag, N(out["fg_Lo"])[ig], ref["fg_Lo"][ir], same_state, max(16, int(8e-2 * same_state.size)), SAME_STATE_CAP,
+                              SAME_STATE_REL_CAP)
     img_g, img_r = N(out["comp_rgb_phys"]), ref["comp_rgb_phys"]
     assert np.isfinite(img_g).all()
     nohit = ~has
@@ -343,9 +356,11 @@ def test_relight_uniform_light_mode_vs_oracle(setup):
     Lo_g, Lo_r = N(out["fg_Lo"])[ig][ok], ref["fg_Lo"][ir][ok]
     scale = np.abs(Lo_r).mean() + 1e-6
     PB.held("relight/uniform_light/fg_Lo_over_mean", Lo_g / scale, Lo_r / scale, (25.0, 3e-2, 4e-3))
-    sidx_g, sidx_r = N(out["sampled_indices"])[same], ref["k1"]["sampled_indices"][same]
-    same_state = (sidx_g == sidx_r) & (np.abs(tr_g - tr_r) <= 1e-5)
-    PB.held_by_discrete_state("relight/uniform_light", N(out["fg_Lo"])[ig], ref["fg_Lo"][ir], same_state, max(16, int(2e-2 * same_state.size)), SAME_STATE_CAP)
+    same_state = _same_state(out, ref, same, ig, ir, tr_g, tr_r)
+    # (observed: max 0.35 of the mean radiance on ONE of ~230 k same-state samples at p99 1e-3 / mean 5e-5 -- that one sample's cause is
+    #  not identified; the light-mode runs stay under 0.05)
+    PB.held_by_discrete_state("relight/uniform_light", N(out["fg_Lo"])[ig], ref["fg_Lo"][ir], same_state, max(16, int(8e-2 * same_state.size)),
+                              (0.7, 1e-2, 5e-4), (0.2, 3e-3, 2e-4))
     has = ref["resampled_packed_info"][:, 1] > 0
     for k, cap in (("comp_rgb_phys", (0.3, 3e-2, 1.5e-3)), ("visibility", (0.1, 1e-2, 5e-4))):
         PB.held(f"relight/uniform_light/{k}", N(out[k]), ref[k], cap)
