@@ -263,11 +263,14 @@ def measure_config4(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, steps=10,
         pairs = int(cap)
         payload = torch.zeros(pairs * 2, dtype=torch.int32, device=dev)
         gathered = torch.empty(pairs * 2 * dist.get_world_size(), dtype=torch.int32, device=dev)
-        ms_ag, _ = timed(lambda: dist.all_gather_into_tensor(gathered, payload), 5)
+        try:
+            ms_ag, _ = timed(lambda: dist.all_gather_into_tensor(gathered, payload), 5)
+        except Exception:                   # a backend without all_gather_into_tensor on device tensors (the gloo test hook)
+            ms_ag = float("nan")
         dense = sum(p.numel() * 4 for p in big)
         sparse = dict(touched_entries_per_table=nnz, entries_per_table=[int(p.numel()) for p in big], pairs_per_rank_padded=pairs,
                       bytes_sent_per_rank=pairs * 8, bytes_received_per_rank=pairs * 8 * dist.get_world_size(), dense_allreduce_bytes=dense,
-                      ms_all_gather=round(ms_ag, 3), ms_dense_all_reduce=round(ms_ar, 3),
+                      ms_all_gather=(round(ms_ag, 3) if ms_ag == ms_ag else None), ms_dense_all_reduce=round(ms_ar, 3),
                       note="all_gather_into_tensor of the padded pair lists timed like ms_total; the scatter-add of world x pairs that would "
                            "follow is not included (it is the binned hash backward's own final pass)")
         del payload, gathered

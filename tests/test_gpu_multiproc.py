@@ -219,3 +219,117 @@ def test_bench_step_through_rccl_on_one_rank():
     ar = line["config"]["gradient_allreduce"]
     assert ar["backend"] == "nccl" and ar["world"] == 1 and ar["bytes_per_step"] > 90e6, ar      # two 50.4 MB tables + the small bucket
     assert line["roofline"] is not None and line["value"] > 0
+
+
+# ----------------------------------------------------------------------------- BASELINE configs[3]: ray-batch sharding of the PBR training step
+def _phys_scene():
+    from intrinsicavatar_amd import build
+    build.build()
+    from intrinsicavatar_amd import synthetic as S, fields, pbr
+    rs, rays, _ = S.build_frame("cuda:0", 40, 40, pose_seed=0, beta=0.05, num_samples_per_ray=64, grid_D=16, grid_H=64, grid_W=64,
+                                smooth_iters=5, hash_amp=1e-2)
+    mat = fields.VolumeMaterial(seed=2).to("cuda:0")
+    sg = pbr.EnvironmentLightSG(num_SGs=16, base_res=32, seed=4).to("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        hit = torch.nonzero(rs.forward(rays)["opacity"][:, 0] > 0.5)[:, 0]
+    sel = hit[torch.randint(0, hit.shape[0], (512,), generator=g).to("cuda:0")]          # 2 x 256 rays on the subject
+    batch = rays[sel].contiguous()
+    target = torch.rand((512, 3), generator=g).to("cuda:0")
+    mask = (torch.rand(512, generator=g) > 0.3).float().to("cuda:0")
+    light_u = torch.rand((512, 3), generator=g).to("cuda:0")                              # ONE stratified direction set per step, every rank
+    shuffle_u = torch.rand((512, 512), generator=g).to("cuda:0")
+    return rs, mat, sg, batch, target, mask, light_u, shuffle_u
+
+
+def _phys_step(scene, a, b, world, sync, eik_denominator):
+    """bench.py's config-4 step (build_config4_step) on rays [a, b) of the batch."""
+    from intrinsicavatar_amd import optim, pbr
+    rs, mat, sg, batch, target, mask, light_u, shuffle_u = scene
+    params = rs.parameters() + [p for p in mat.parameters() if p.requires_grad] + list(sg.parameters())
+    opt, _ = optim.reference_optimizer(rs, grad_scale=1.0 / world, material=mat, emitter=sg, warmup_steps=None, milestones=None)
+    for p in params:
+        p.grad = None
+    img = sg.generate_image()
+    leaf = img.detach().requires_grad_(True)
+    emitter = pbr.EnvironmentLightTensor(leaf.detach())
+    emitter.update_pdf()
+    o = rs.forward_backward_phys(batch[a:b].contiguous(), target[a:b].contiguous(), mat, emitter, 512, light_u, shuffle_u[a:b].contiguous(),
+                                 target_mask=mask[a:b].contiguous(), render_mode="uniform_light", env_base=leaf,
+                                 background_color=torch.ones(3, device="cuda:0"), eik_denominator=eik_denominator)
+    img.backward(leaf.grad)
+    if sync is not None:
+        sync.finish()
+    opt.step()
+    return [p.detach().clone().cpu() for p in params], int(o["n_samples"])
+
+
+def _phys_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from intrinsicavatar_amd import parallel
+    scene = _phys_scene()
+    rs, mat, sg = scene[0], scene[1], scene[2]
+    params = rs.parameters() + [p for p in mat.parameters() if p.requires_grad] + list(sg.parameters())
+    sync = parallel.OverlappedGradientAllReduce(params)
+    a, b = parallel.shard_range(512, rank, world)
+    # the eikonal term is a mean over ALL samples of the global batch (systems/intrinsic_avatar.py:235-239): global count / world here,
+    # so that the average of the ranks' losses (grad_scale 1 / world) is the global-batch loss
+    den = lambda n: parallel.allreduce_scalars([float(n)], "cuda:0")[0] / world      # noqa: E731
+    after, n_s = _phys_step(scene, a, b, world, sync, den)
+    torch.save(dict(after=after, n_samples=n_s), os.path.join(out_dir, f"p{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config4_step_sharded_by_ray_batch_equals_the_single_process_step(tmp_path):
+    """BASELINE configs[3] / bench.py's `config4` at N > 1: the PBR training step (uniform_light, spp 512, material head, SG light) with the
+    batch sharded by rays over two REAL ranks (gloo, both on the box's one GPU), the eikonal mean normalised with the GLOBAL sample count,
+    the gradients summed by OverlappedGradientAllReduce and averaged inside Adam -- against one process that takes the whole batch."""
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_phys_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"p{k}.pt") for k in range(world)]
+    scene = _phys_scene()
+    params = scene[0].parameters() + [p for p in scene[1].parameters() if p.requires_grad] + list(scene[2].parameters())
+    before = [p.detach().clone().cpu() for p in params]
+    single, n_all = _phys_step(scene, 0, 512, 1, None, None)
+    assert r[0]["n_samples"] + r[1]["n_samples"] == n_all                          # sampling is per ray: sharding invariant
+    moved = 0
+    for i, (p0, p1, ps, pb) in enumerate(zip(r[0]["after"], r[1]["after"], single, before)):
+        assert torch.equal(p0, p1), f"ranks disagree on parameter {i}"
+        step = (ps - pb).abs().max().item()
+        if step > 0:
+            moved += 1
+            # Adam normalises the step: entries whose gradient is at the noise floor of the float-atomic table sums can move differently;
+            # the bar is a fraction of the largest step of the tensor, as in the radiance-only two-rank test
+            assert (p0 - ps).abs().max().item() <= 0.05 * step + 1e-7, (i, (p0 - ps).abs().max().item(), step)
+    assert moved >= 10
+
+
+def test_config4_workload_of_the_bench_with_two_ranks_and_through_rccl_on_one():
+    """`bench.py --workload config4`: two ranks sharing the GPU over gloo (the N > 1 control flow: sharded batches, global-count loss
+    normalisation, all-reduce timing) and a one-rank RCCL group (the same path through librccl)."""
+    import json
+    import subprocess
+    import sys
+    line = _run_line(["bench.py", "--workload", "config4", "--gpus", "2", "--steps", "2", "--hw", "96"])
+    c4 = line["config4"]
+    assert line["n_gpus"] == 2 and c4["n_gpus"] == 2 and line["value"] == c4["rays_per_s"] > 0
+    ar = c4["gradient_allreduce"]
+    assert ar["world"] == 2 and ar["bytes_per_step"] > 90e6 and ar["ms_total"] > 0 and "ms_exposed" in ar
+    assert c4["sparse_exchange"]["touched_entries_per_table"][0] > 0
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IA_BENCH_FORCE_RCCL="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "bench.py", "--workload", "config4", "--gpus", "1", "--steps", "2", "--hw", "96"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    ar = line["config4"]["gradient_allreduce"]
+    assert ar["backend"] == "nccl" and ar["world"] == 1 and ar["bytes_per_step"] > 90e6
+    assert line["config4"]["sparse_exchange"]["ms_all_gather"] is not None
