@@ -2,7 +2,7 @@
 # where does the 1.16 x of two processes on one GPU come from?  Kernel timelines (rocprofv3 --kernel-trace) of
 #   (c) the default step (one process, secondary march on two streams / host threads),
 #   (s) the same process with the march on ONE stream,
-#   (a) two processes sharing the GPU (8 Mi-ray secondary chunks so that both fit the HBM), each traced, plus (a0) one such process alone,
+#   (a) two processes sharing the GPU (4 Mi-ray secondary chunks on one stream each, so that both fit the HBM), each traced, plus (a0) one such process alone,
 # analysed by tools/overlap_timeline.py: time with >= 2 kernels in flight, which pairs co-run, hardware queues used.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -11,7 +11,7 @@ tr() { find $1 -name "*kernel_trace.csv" | head -1; }
 rm -rf /tmp/kc /tmp/ks /tmp/ka0 /tmp/ka1 /tmp/ka2
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/kc -- python $R/bench.py $F > $R/gpurun_out/r06_tl_c.json 2>/dev/null
 IA_SECONDARY_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ks -- python $R/bench.py $F > $R/gpurun_out/r06_tl_s.json 2>/dev/null
-export IA_SECONDARY_CHUNK=$((1 << 23)) IA_MAX_SEARCH_POINTS=80000000 IA_BENCH_ARENA_GIB=90
+export IA_SECONDARY_CHUNK=$((1 << 22)) IA_SECONDARY_STREAMS=1 IA_MAX_SEARCH_POINTS=60000000 IA_BENCH_ARENA_GIB=40      # two processes must fit 288 GB
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ka0 -- python $R/bench.py $F > $R/gpurun_out/r06_tl_a0.json 2>/dev/null
 (timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/ka1 -- python $R/bench.py $F > $R/gpurun_out/r06_tl_a1.json 2>/dev/null) &
 (timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/ka2 -- python $R/bench.py $F > $R/gpurun_out/r06_tl_a2.json 2>/dev/null) &
