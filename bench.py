@@ -58,7 +58,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3     # fp32-in MFMA dense peak
 L1_PEAK_GBPS = 256 * 64 * 2.4    # 256 CUs x 64 B/clk (vector L1 / TCP) x 2.4 GHz = 39.3 TB/s
 L2_PEAK_GBPS = 34500.0           # MI355X_MICROARCH.md: L2 (per XCD 4 MiB, aggregate) ~34.5 TB/s
 VOXEL_J_BYTES = 32 * 128 * 128 * 48
-PROFILE_TAGS = ("r05", "r04", "r03", "r02")          # newest committed rocprofv3 PMC summary that knows the kernel wins
+PROFILE_TAGS = ("r06", "r05", "r04", "r03", "r02")          # newest committed rocprofv3 PMC summary that knows the kernel wins
 
 
 def algorithmic_bytes(name, calls, extra=None):
