@@ -414,6 +414,9 @@ int ia_shade_prep(int64_t n, const float* sdf_grad /*[n,3]*/, const float* rays_
 /* alpha = 1 - exp(-LaplaceDensity(sdf; beta) * dist); dists NULL => dist_const; beta: 1 device float */
 int ia_laplace_alpha(int64_t n, const float* sdf, const float* dists, float dist_const, const float* beta,
                      float* alpha, ia_stream_t stream);
+/* ... with the interval length taken from the interval's ends: dist = t_ends[i] - t_starts[i] (same fp32 subtraction, not materialised) */
+int ia_laplace_alpha_intervals(int64_t n, const float* sdf, const float* t_starts, const float* t_ends, const float* beta, float* alpha,
+                               ia_stream_t stream);
 int ia_laplace_alpha_bwd(int64_t n, const float* sdf, const float* dists, float dist_const, const float* beta,
                          const float* g_alpha, float* g_sdf, float* g_beta /*1 float, accumulated*/, ia_stream_t stream);
 
@@ -604,6 +607,9 @@ int ia_secondary_compact(int64_t F, const int32_t* flag, const int32_t* slot, co
                          ia_stream_t stream);
 int ia_secondary_scatter(int64_t M, const int32_t* src, const float* transmittance, const float* rgb, float* dense_transmittance,
                          float* dense_rgb, ia_stream_t stream);
+/* ... the same result written point by point from (flag, slot): every dense element is written exactly once, no zero fill beforehand */
+int ia_secondary_gather_dense(int64_t F, const int32_t* flag, const int32_t* slot, const float* transmittance, const float* rgb,
+                              float* dense_transmittance, float* dense_rgb, ia_stream_t stream);
 
 /* lib.torch_pbr scatterer classes (registered at models/__init__.py:44-50; call sites models/intrinsic_avatar.py:566-574,
  * 591-614, 714-723, 816-825, 882-923): sample / pdf / eval of the lobe set `lobes` = 1 Lambertian, 2 GGX, 3 MultiLobe,

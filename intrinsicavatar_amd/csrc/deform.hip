@@ -540,6 +540,22 @@ __global__ __launch_bounds__(THREADS) void laplace_alpha_kernel(int64_t n, const
     alpha[i] = 1.0f - expf(-dens * dist);
 }
 
+// the same with the interval length taken from the interval's ends (dist = t_end - t_start: the subtraction the caller would otherwise
+// materialise -- 303 M elements per headline step)
+__global__ __launch_bounds__(THREADS) void laplace_alpha_intervals_kernel(int64_t n, const float* __restrict__ sdf, const float* __restrict__ t_starts,
+                                                                           const float* __restrict__ t_ends, const float* __restrict__ beta_p,
+                                                                           float* __restrict__ alpha)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float beta = *beta_p;
+    const float s = sdf[i];
+    const float sg = (float)((s > 0.f) - (s < 0.f));
+    const float dens = (1.0f / beta) * (0.5f + 0.5f * sg * expm1f(-fabsf(s) / beta));
+    const float dist = t_ends[i] - t_starts[i];
+    alpha[i] = 1.0f - expf(-dens * dist);
+}
+
 // backward: g_sdf[i] = g_alpha * d alpha / d sdf ; g_beta partial sums -> atomicAdd
 __global__ __launch_bounds__(THREADS) void laplace_alpha_bwd_kernel(int64_t n, const float* __restrict__ sdf,
                                                                      const float* __restrict__ dists, float dist_const,
@@ -764,6 +780,14 @@ IA_EXPORT int ia_laplace_alpha(int64_t n, const float* sdf, const float* dists, 
     if (n == 0) return IA_OK;
     laplace_alpha_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, sdf, dists, dist_const, beta, alpha);
     return ia::check_launch("ia_laplace_alpha");
+}
+
+IA_EXPORT int ia_laplace_alpha_intervals(int64_t n, const float* sdf, const float* t_starts, const float* t_ends, const float* beta,
+                                         float* alpha, ia_stream_t stream)
+{
+    if (n == 0) return IA_OK;
+    laplace_alpha_intervals_kernel<<<ia::cdiv(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(n, sdf, t_starts, t_ends, beta, alpha);
+    return ia::check_launch("ia_laplace_alpha_intervals");
 }
 
 IA_EXPORT int ia_laplace_alpha_bwd(int64_t n, const float* sdf, const float* dists, float dist_const,

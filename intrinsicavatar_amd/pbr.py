@@ -563,18 +563,32 @@ def secondary_rays(normals: Tensor, positions: Tensor, dirs: Tensor, dir_index: 
     dense = torch.empty((F_, 3), device=dev) if dir_index is not None else None
     L.check(lib.ia_secondary_compact(L.i64(F_), L.ptr(flag), L.ptr(slot), L.ptr(positions), L.ptr(dirs), L.ptr(dir_index), L.ptr(ro),
                                      L.ptr(rd), L.ptr(src), L.ptr(dense), st), "ia_secondary_compact")
+    _FLAG_SLOT[id(src)] = (src, flag, slot)          # for scatter_secondary: the dense result is written point by point from (flag, slot)
+    while len(_FLAG_SLOT) > 2:                        # (an entry keeps [F] int32 x 2 alive: released on use, two unused ones at most)
+        _FLAG_SLOT.pop(next(iter(_FLAG_SLOT)))
     return ro, rd, src, (dense if dir_index is not None else dirs)
+
+
+_FLAG_SLOT = {}          # id(src) -> (src, flag, slot) of the last few secondary_rays calls (several host threads: plain dict operations)
 
 
 @torch.no_grad()
 def scatter_secondary(F_: int, src: Tensor, tr: Tensor, rgb: Tensor):
     """traced (transmittance [M,1], rgb [M,3]) back into dense [F,1] / [F,3] (zeros for masked points), transmittance
-    clamped to [0, 1] (:796-803)."""
+    clamped to [0, 1] (:796-803).  With the (flag, slot) of the secondary_rays call that made `src` at hand every dense element is written
+    exactly once (ia_secondary_gather_dense: no [F,4] zero fill -- 1.3 GB per headline step); otherwise zero fill + scatter through src."""
     dev = src.device
+    ent = _FLAG_SLOT.pop(id(src), None)
+    trc, rgbc = tr.reshape(-1).float().contiguous(), rgb.float().contiguous()
+    if ent is not None and ent[0] is src and ent[1].shape[0] == F_:
+        d_tr, d_rgb = torch.empty((F_, 1), device=dev), torch.empty((F_, 3), device=dev)
+        L.check(L.lib().ia_secondary_gather_dense(L.i64(F_), L.ptr(ent[1]), L.ptr(ent[2]), L.ptr(trc), L.ptr(rgbc), L.ptr(d_tr), L.ptr(d_rgb),
+                                                  L.stream()), "ia_secondary_gather_dense")
+        return d_tr, d_rgb
     buf = L.zeros(F_ * 4, dev)                     # one fill for both
     d_tr, d_rgb = buf[:F_].view(F_, 1), buf[F_:].view(F_, 3)
-    L.check(L.lib().ia_secondary_scatter(L.i64(src.shape[0]), L.ptr(src), L.ptr(tr.reshape(-1).float().contiguous()),
-                                         L.ptr(rgb.float().contiguous()), L.ptr(d_tr), L.ptr(d_rgb), L.stream()), "ia_secondary_scatter")
+    L.check(L.lib().ia_secondary_scatter(L.i64(src.shape[0]), L.ptr(src), L.ptr(trc), L.ptr(rgbc), L.ptr(d_tr), L.ptr(d_rgb), L.stream()),
+            "ia_secondary_scatter")
     return d_tr, d_rgb
 
 

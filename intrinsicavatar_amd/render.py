@@ -43,6 +43,14 @@ def laplace_alpha(sdf: Tensor, dists, beta: Tensor) -> Tensor:
     return alpha
 
 
+def laplace_alpha_intervals(sdf: Tensor, t_starts: Tensor, t_ends: Tensor, beta: Tensor) -> Tensor:
+    """laplace_alpha(sdf, t_ends - t_starts, beta) without materialising the difference (ia_laplace_alpha_intervals: bit-identical)."""
+    alpha = torch.empty_like(sdf)
+    L.check(L.lib().ia_laplace_alpha_intervals(L.i64(sdf.shape[0]), L.ptr(sdf), L.ptr(t_starts.contiguous()), L.ptr(t_ends.contiguous()), L.ptr(beta),
+                                               L.ptr(alpha), L.stream()), "ia_laplace_alpha_intervals")
+    return alpha
+
+
 def shade_prep(sdf_grad: Tensor, rays_d: Tensor, ray_indices: Tensor, w2s_rot: Tensor):
     n = sdf_grad.shape[0]
     dev = sdf_grad.device
@@ -442,7 +450,7 @@ class RenderStep:
                 continue
             # coarse_alpha_sdf_fn (:399-428): SDF at the interval STARTS
             sdf = self._sdf_at(ray_points(ro, rd, ray_indices, t_starts))
-            alphas = laplace_alpha(sdf, t_ends - t_starts, beta)
+            alphas = laplace_alpha_intervals(sdf, t_starts, t_ends, beta)
             pinfo = lib_nerfacc.pack_info(ray_indices, m)
             # (capacity-sized outputs: compact_foreground walks them through rpi, the size read-back of cdf.cu:511 is not needed)
             rpi, rs, re, is_fg = lib_nerfacc.ray_resampling_sdf_fine(pinfo, t_starts[:, None], t_ends[:, None], alphas, sdf, 4, exact_size=False)
@@ -471,11 +479,12 @@ class RenderStep:
             else:
                 d = self.deformer.deform(pts, self.geometry, with_grad=True, with_feature=True)
                 _, normal_world, refl01 = shade_prep(d["sdf_grad"], rd, ray_indices, w2s_rot)
-                a = laplace_alpha(d["sdf"], t_ends - t_starts, beta)
+                a = laplace_alpha_intervals(d["sdf"], t_starts, t_ends, beta)
                 rgbs = self.radiance(d["pts_cano"], d["feature"], refl01, normal_world)
             w, _ = nerfacc.render_weight_from_alpha(a, packed_info=pinfo)
             acc = nerfacc._Accumulate.apply(w, None, ray_indices, pinfo)
-            tr[c0:c0 + m] = 1.0 - acc
+            torch.neg(acc, out=tr[c0:c0 + m])                     # tr = 1 - acc written in place: (-acc) + 1 is the same IEEE operation
+            tr[c0:c0 + m].add_(1.0)
             rgb[c0:c0 + m] = nerfacc._Accumulate.apply(w, rgbs, ray_indices, pinfo)
 
     # ------------------------------------------------------------------ relighting (render_mode = light)
@@ -501,7 +510,7 @@ class RenderStep:
         pts = ray_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
         d = dfm.deform(pts, self.geometry, with_grad=True, with_feature=True)
         normal_smpl, normal_world, refl01 = shade_prep(d["sdf_grad"], rays_d, ray_indices, w2s_rot)
-        alphas = laplace_alpha(d["sdf"], t_ends - t_starts, beta)
+        alphas = laplace_alpha_intervals(d["sdf"], t_starts, t_ends, beta)
         rgbs, enc2, xp2 = self.radiance(d["pts_cano"], d["feature"], refl01, normal_world, return_embedding=True)
         mats = material(enc2, xp2, d["feature"], self.radiance.prog.mask(self.radiance.global_step, dev))
         weights, trans = nerfacc.render_weight_from_alpha(alphas, packed_info=packed_info)

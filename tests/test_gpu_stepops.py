@@ -28,7 +28,7 @@ def _close(a, b, rtol, atol, what=""):
 @pytest.mark.parametrize("dtype", [torch.int32, torch.int64])
 @pytest.mark.parametrize("n", [0, 1, 5, 1024, 4097, 131072, 131073, 1_000_003])
 def test_exclusive_scan_small_and_tiled_paths(n, dtype):
-    """n <= 2^17: one workgroup, one launch (scan_small_kernel); above: the tiled protocol.  Values, the total, and in-place use."""
+    """n <= 2^15: one workgroup, one launch (scan_small_kernel); above: the tiled protocol.  Values, the total, and in-place use."""
     from intrinsicavatar_amd import _lib as L
     g = torch.Generator().manual_seed(n)
     x = torch.randint(0, 7, (n,), generator=g).to(dtype).to(DEV)
@@ -236,3 +236,26 @@ def test_phys_loss_forward_and_backward_vs_the_torch_composition(with_mask):
     theirs = torch.autograd.grad(ref, [leaves[k] for k in ks])
     for k, a, b in zip(ks, mine, theirs):
         _close(a, b, 2e-5, 1e-6 * float(b.abs().max()), k)
+
+
+def test_laplace_alpha_intervals_and_dense_gather_of_secondary_results_are_bit_identical_to_the_two_step_forms():
+    from intrinsicavatar_amd import render, pbr
+    g = torch.Generator().manual_seed(8)
+    n = 200_003
+    sdf = (torch.randn(n, generator=g) * 0.05).to(DEV)
+    ts = torch.rand(n, generator=g).to(DEV)
+    te = ts + torch.rand(n, generator=g).to(DEV) * 0.03
+    beta = torch.tensor([0.01], device=DEV)
+    assert torch.equal(render.laplace_alpha_intervals(sdf, ts, te, beta), render.laplace_alpha(sdf, te - ts, beta))
+    F_ = 50_001
+    nrm = torch.nn.functional.normalize(torch.randn((F_, 3), generator=g), dim=-1).to(DEV)
+    pos = torch.rand((F_, 3), generator=g).to(DEV)
+    dirs = torch.nn.functional.normalize(torch.randn((F_, 3), generator=g), dim=-1).to(DEV)
+    ro, rd, src, _ = pbr.secondary_rays(nrm, pos, dirs)
+    M = ro.shape[0]
+    assert 0 < M < F_
+    tr, rgb = (torch.rand((M, 1), generator=g) * 1.2 - 0.1).to(DEV), torch.rand((M, 3), generator=g).to(DEV)
+    a_tr, a_rgb = pbr.scatter_secondary(F_, src, tr, rgb)                 # (flag, slot) at hand: written point by point
+    b_tr, b_rgb = pbr.scatter_secondary(F_, src.clone(), tr, rgb)         # an index list of unknown origin: zero fill + scatter
+    assert torch.equal(a_tr, b_tr) and torch.equal(a_rgb, b_rgb)
+    assert float(a_tr.max()) <= 1.0 and float(a_tr.min()) >= 0.0

@@ -44,6 +44,7 @@ def aten_sites(step):
     package and are attributed to the backward node's name).  -> [(site, ops)] most common first."""
     from torch.utils._python_dispatch import TorchDispatchMode
     sites = collections.Counter()
+    elems = collections.Counter()
 
     class Mode(TorchDispatchMode):
         def __torch_dispatch__(self, func, types, args=(), kwargs=None):
@@ -66,6 +67,9 @@ def aten_sites(step):
                 node = getattr(torch._C, "_current_autograd_node", lambda: None)()
                 site = f"backward of {node.name()}" if node is not None else "autograd engine / other"
             sites[site + " | " + name.replace("aten::", "")] += 1
+            o0 = out[0] if isinstance(out, (tuple, list)) and out else out
+            if isinstance(o0, torch.Tensor) and o0.is_cuda:
+                elems[site] += o0.numel()
             return out
     with Mode():
         step()
@@ -73,6 +77,7 @@ def aten_sites(step):
     agg = collections.Counter()
     for k, v in sites.items():
         agg[k.split(" | ")[0]] += v
+    aten_sites.elements = elems.most_common(40)          # output elements written per source line: where the LARGE element-wise launches are
     return [(k, v, sorted((kk.split(" | ")[1], vv) for kk, vv in sites.items() if kk.startswith(k + " | "))) for k, v in agg.most_common(120)]
 
 
@@ -180,7 +185,37 @@ def main():
     rs, rays, export, mat, sg = B.build_headline(dev, args.hw, 1024, 0, "male-3-casual:0")
     bg = torch.ones(3, device=dev)
     if args.headline:
-        raise SystemExit("--headline: use tools/sync_audit_headline.py + rocprofv3 (the step is too large for a with_stack trace)")
+        # the 540 x 540 step: ATen operators by source line and by output elements (no profiler trace: the step is too large for one)
+        import contextlib
+        from intrinsicavatar_amd import pbr, optim
+        n = rays.shape[0]
+        g = torch.Generator().manual_seed(1234)
+        target, tmask = torch.rand((n, 3), generator=g).to(dev), (torch.rand(n, generator=g) > 0.5).float().to(dev)
+        params = rs.parameters() + [p for p in mat.parameters() if p.requires_grad] + list(sg.parameters())
+        opt, sched = optim.reference_optimizer(rs, material=mat, emitter=sg)
+
+        def hstep():
+            for p in params:
+                p.grad = None
+            img = sg.generate_image()
+            leaf = img.detach().requires_grad_(True)
+            emitter = pbr.EnvironmentLightTensor(leaf.detach())
+            emitter.update_pdf()
+            rs.forward_backward_phys(rays, target, mat, emitter, 1024, None, None, target_mask=tmask, render_mode="light", env_base=leaf,
+                                     background_color=bg, global_illumination=True, light_sampling="per_point")
+            img.backward(leaf.grad)
+            opt.step()
+        rs.SECONDARY_STREAMS = 1            # the dispatch mode is per thread: keep the march on the caller's
+        for _ in range(2):
+            hstep()
+        torch.cuda.synchronize()
+        res = dict(workload="headline step (540 x 540, spp 1024), one march stream", aten_ops_by_source_line=aten_sites(hstep),
+                   output_elements_by_source_line=aten_sites.elements)
+        txt = json.dumps(res, indent=1)
+        if args.out:
+            open(args.out, "w").write(txt)
+        print(txt)
+        return
     step, info = B.build_config4_step(rs, rays, mat, sg, dev, bg)
     res = audit(step)
     res["workload"] = info
