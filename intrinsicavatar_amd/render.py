@@ -419,10 +419,24 @@ class RenderStep:
         in_flight = n * max(b - a for a, b in plan) * self.SECONDARY_BYTES_PER_RAY
         free, _total = torch.cuda.mem_get_info(dev)
         # usable by the side streams: device-free memory plus the blocks already cached in THEIR pools (steady state: the previous step's
-        # working set).  Blocks cached in the caller's pool are not available to another stream, so they do not count -- once the side
-        # streams exist and have run (self._side_pool_bytes: what they held at the end of the last march), before that only free memory
-        side = getattr(self, "_side_pool_bytes", 0) if getattr(self, "_side_streams", None) is not None else 0
-        n = n if free + side >= 1.3 * in_flight else 1
+        # working set sits there).  Blocks cached in the caller's pool are not available to another stream, so they do not count.  The
+        # allocator's snapshot (segments carry their stream; milliseconds) is only taken when neither free memory alone nor free memory plus the
+        # working set the side streams held after their last successful march settles it.
+        need = 1.3 * in_flight
+        have_side = getattr(self, "_side_streams", None) is not None
+        if free < need and not (have_side and free + getattr(self, "_side_pool_bytes", 0) >= need):
+            # (steady state is settled by the working-set estimate of the last successful march -- no allocator call per step; a wrong
+            #  estimate costs one OOM fallback and the cool-down)
+            side_ids = {st.cuda_stream for st in (getattr(self, "_side_streams", None) or [])}
+            side = 0
+            if side_ids:
+                try:
+                    for seg in torch.cuda.memory_snapshot():
+                        if seg.get("device", dev.index) == dev.index and seg.get("stream") in side_ids:
+                            side += seg["total_size"] - seg["allocated_size"]
+                except Exception:               # noqa: BLE001 -- a diagnostic API: fall back to the working-set estimate of the last march
+                    side = getattr(self, "_side_pool_bytes", 0)
+            n = n if free + side >= need else 1
         self.last_secondary_streams = n
         return n
     # below ~8 M rays the kernels of a chunk no longer fill the device and splitting them makes it worse (config-4 shape, 1 M secondary rays:
