@@ -688,7 +688,7 @@ int ia_deform_select_min_scatter(int64_t P, const int32_t* start, const int32_t*
  *   out[row, col] = sum_k softplus(mu_k) exp(exp(log_lambda_k) (d(row, col) . normalize(axis_k) - 1)), d = the equirectangular direction
  *   convention of ia_envlight_eval; out [H,W,3].  _bwd: g_img -> g_axis [K,3], g_log_lambda [K], g_mu [K,3]; tmp: ia_sg_image_bwd_tmp_bytes(K).
  * ia_envlight_pdf_tables: emitter.update_pdf (:777-781): pmf [H*W] fp32 = luminance x sin(theta), normalised in double; cdf [H*W] double =
- *   running sum of the fp32 pmf (what ia_envlight_sample searches).
+ *   running sum of the fp32 pmf (what ia_envlight_sample searches); tmp: ia_envlight_pdf_tables_tmp_bytes(H, W) bytes; three launches.
  * ia_uniform_sphere_stratified: emitter.sample_uniform_sphere_stratified(n_rays, 16, 32) (:680-689): u [n_theta*n_phi,2] ->
  *   dirs [n_theta*n_phi,3] (z = 1 - 2 (i + u0) / n_theta, phi = 2 pi (j + u1) / n_phi), inv_pdf [n_theta*n_phi] = 4 pi.
  * ia_material_affine(_bwd): VolumeMaterial.forward's output ranges (models/pbr/material.py:44-50): m [n,5] sigmoid outputs ->
@@ -707,7 +707,8 @@ int ia_sg_image(int K, int H, int W, const float* axis, const float* log_lambda,
 int64_t ia_sg_image_bwd_tmp_bytes(int K);
 int ia_sg_image_bwd(int K, int H, int W, const float* axis, const float* log_lambda, const float* mu, const float* g_img, void* tmp,
                     float* g_axis, float* g_log_lambda, float* g_mu, ia_stream_t stream);
-int ia_envlight_pdf_tables(int H, int W, const float* base, float* pmf, double* cdf, ia_stream_t stream);
+int64_t ia_envlight_pdf_tables_tmp_bytes(int H, int W);
+int ia_envlight_pdf_tables(int H, int W, const float* base, float* pmf, double* cdf, void* tmp, ia_stream_t stream);
 int ia_uniform_sphere_stratified(int n_theta, int n_phi, const float* u, float* dirs, float* inv_pdf, ia_stream_t stream);
 int ia_material_affine(int64_t n, const float* m, float albedo_scale, float albedo_bias, float roughness_scale, float roughness_bias,
                        float metallic_scale, float metallic_bias, float* albedo, float* roughness, float* metallic, ia_stream_t stream);

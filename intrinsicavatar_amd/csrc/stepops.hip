@@ -261,62 +261,79 @@ __global__ void sg_image_bwd_final_kernel(int K, int chunks, const float* __rest
 
 // ------------------------------------------------------------------------------------------------ envlight pdf tables
 // EnvironmentLightTensor.update_pdf: w = max(luminance, 0) * sin(theta) in double; pmf = float(w / sum w); cdf = running sum of the
-// fp32 pmf in double.  ONE workgroup (the image of the training light is 256 x 512): three ordered passes.
-__global__ __launch_bounds__(1024) void envlight_pdf_tables_kernel(int H, int W, const float* __restrict__ base, float* __restrict__ pmf,
-                                                                    double* __restrict__ cdf)
+// fp32 pmf in double.  Three element-parallel launches over tiles of 1024 texels (a single workgroup streaming the 256 x 512 training
+// light was latency-bound on one CU: 180 us of a 14 ms step); every sum is ordered: per-tile tree, tiles in index order.
+constexpr int PDF_TILE = 1024;
+
+__global__ __launch_bounds__(256) void envlight_w_kernel(int P, int W, int H, const float* __restrict__ base, double* __restrict__ w_out,
+                                                         double* __restrict__ tile_sum)
 {
     __shared__ double sh[16];
-    __shared__ double carry_s;
-    const int P = H * W, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
-    // pass 1 (coalesced, thread t takes pixels t, t + 1024, ...): w staged in the cdf buffer; ordered total
+    const int p0 = blockIdx.x * PDF_TILE + threadIdx.x * 4;
     double local = 0.0;
-    for (int p = tid; p < P; p += nt) {
-        const float lum = fmaxf(0.2126f * base[3 * p] + 0.7152f * base[3 * p + 1] + 0.0722f * base[3 * p + 2], 0.f);
-        const float sin_t = sinf(((float)(p / W) + 0.5f) * PI_F / (float)H);
-        const double w = (double)lum * (double)sin_t;
-        cdf[p] = w;
-        local += w;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int p = p0 + k;
+        if (p < P) {
+            const float lum = fmaxf(0.2126f * base[3 * p] + 0.7152f * base[3 * p + 1] + 0.0722f * base[3 * p + 2], 0.f);
+            const float sin_t = sinf(((float)(p / W) + 0.5f) * PI_F / (float)H);
+            const double w = (double)lum * (double)sin_t;
+            w_out[p] = w;
+            local += w;
+        }
     }
-    const double total = block_sum_d(local, sh);
-    if (tid == 0) carry_s = 0.0;
+    const double t = block_sum_d(local, sh);
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = t;
+}
+
+// pmf of a tile + the tile's inclusive running sum of the fp32 pmf (double) + the tile's pmf sum
+__global__ __launch_bounds__(256) void envlight_pmf_kernel(int P, int n_tiles, const double* __restrict__ tile_sum, double* __restrict__ w_cdf,
+                                                           float* __restrict__ pmf, double* __restrict__ tile_pmf_sum)
+{
+    __shared__ double sh[16];
+    double total = 0.0;
+    for (int t = 0; t < n_tiles; t++) total += tile_sum[t];          // the same ordered sum in every workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int p0 = blockIdx.x * PDF_TILE + tid * 4;
+    double q[4], run = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float f = 0.f;
+        if (p0 + k < P) {
+            f = (float)(w_cdf[p0 + k] / total);
+            pmf[p0 + k] = f;
+        }
+        run += (double)f;
+        q[k] = run;
+    }
+    double inc = run;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) sh[wid] = inc;
     __syncthreads();
-    // pass 2: chunks of 1024 x 4 consecutive pixels: pmf = float(w / total), cdf = carry + inclusive running sum of the fp32 pmf in double
-    for (int chunk = 0; chunk < P; chunk += nt * 4) {
-        const int p0 = chunk + tid * 4;
-        double q[4], run = 0.0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            float f = 0.f;
-            if (p0 + k < P) {
-                f = (float)(cdf[p0 + k] / total);
-                pmf[p0 + k] = f;
-            }
-            run += (double)f;
-            q[k] = run;                       // inclusive within the thread
-        }
-        double inc = run;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const double o = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += o;
-        }
-        __syncthreads();                      // sh free (previous iteration's readers are done)
-        if (lane == 63) sh[wid] = inc;
-        __syncthreads();
-        double off_w = 0.0, tot = 0.0;
-        for (int w = 0; w < nw; w++) {
-            const double t = sh[w];
-            if (w < wid) off_w += t;
-            tot += t;
-        }
-        const double basev = carry_s + off_w + (inc - run);
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (p0 + k < P) cdf[p0 + k] = basev + q[k];
-        __syncthreads();                      // everyone has read carry_s
-        if (tid == 0) carry_s += tot;
-        __syncthreads();
+    double off_w = 0.0, tot = 0.0;
+    for (int w = 0; w < 4; w++) {
+        if (w < wid) off_w += sh[w];
+        tot += sh[w];
     }
+    const double basev = off_w + (inc - run);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (p0 + k < P) w_cdf[p0 + k] = basev + q[k];
+    if (tid == 0) tile_pmf_sum[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void envlight_cdf_offset_kernel(int P, const double* __restrict__ tile_pmf_sum, double* __restrict__ cdf)
+{
+    double off = 0.0;
+    for (int t = 0; t < (int)blockIdx.x; t++) off += tile_pmf_sum[t];          // tiles in index order
+    const int p0 = blockIdx.x * PDF_TILE + threadIdx.x * 4;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (p0 + k < P) cdf[p0 + k] = off + cdf[p0 + k];
 }
 
 // ------------------------------------------------------------------------------------------------ stratified sphere
@@ -490,10 +507,21 @@ IA_EXPORT int ia_sg_image_bwd(int K, int H, int W, const float* axis, const floa
     return ia::check_launch("ia_sg_image_bwd");
 }
 
-IA_EXPORT int ia_envlight_pdf_tables(int H, int W, const float* base, float* pmf, double* cdf, ia_stream_t stream)
+IA_EXPORT int64_t ia_envlight_pdf_tables_tmp_bytes(int H, int W) { return 2 * (int64_t)(((int64_t)H * W + PDF_TILE - 1) / PDF_TILE) * 8 + 64; }
+
+IA_EXPORT int ia_envlight_pdf_tables(int H, int W, const float* base, float* pmf, double* cdf, void* tmp, ia_stream_t stream)
 {
-    IA_REQUIRE(H > 0 && W > 0 && base && pmf && cdf, "bad arguments");
-    envlight_pdf_tables_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(H, W, base, pmf, cdf);
+    IA_REQUIRE(H > 0 && W > 0 && base && pmf && cdf && tmp, "bad arguments");
+    const int64_t P64 = (int64_t)H * W;
+    IA_REQUIRE(P64 < ((int64_t)1 << 30), "image too large");
+    const int P = (int)P64, n_tiles = (P + PDF_TILE - 1) / PDF_TILE;
+    IA_REQUIRE(n_tiles <= 4096, "at most 4096 tiles of 1024 texels (larger images: the caller's own reduction)");
+    double* tile_sum = (double*)tmp;
+    double* tile_pmf = tile_sum + n_tiles;
+    hipStream_t s = (hipStream_t)stream;
+    envlight_w_kernel<<<n_tiles, 256, 0, s>>>(P, W, H, base, cdf, tile_sum);
+    envlight_pmf_kernel<<<n_tiles, 256, 0, s>>>(P, n_tiles, tile_sum, cdf, pmf, tile_pmf);
+    envlight_cdf_offset_kernel<<<n_tiles, 256, 0, s>>>(P, tile_pmf, cdf);
     return ia::check_launch("ia_envlight_pdf_tables");
 }
 

@@ -93,20 +93,21 @@ class EnvironmentLightTensor(torch.nn.Module):
             u = torch.rand((n_theta * n_phi, 2), device=dev)
         return uniform_sphere_stratified(n_theta, n_phi, u.to(dev))
 
-    PDF_KERNEL_MAX_PIXELS = 1 << 18
+    PDF_KERNEL_MAX_PIXELS = 1 << 22          # 4096 tiles of 1024 texels (ia_envlight_pdf_tables); a 1024 x 2048 HDRI has 2^21
 
     @torch.no_grad()
     def update_pdf(self):
         H, W, _ = self.base.shape
         base = self.base.detach()
-        # pmf = luminance x sin(theta), normalised in double; cdf = running sum of the fp32 pmf in double: one launch (the training
-        # path rebuilds the tables every step, :777-781)
+        # pmf = luminance x sin(theta), normalised in double; cdf = running sum of the fp32 pmf in double: three tile-parallel launches
+        # (the training path rebuilds the tables every step, :777-781)
         if H * W <= self.PDF_KERNEL_MAX_PIXELS:
             self.pmf = torch.empty((H, W), device=base.device)
             self._cdf = torch.empty(H * W, dtype=torch.float64, device=base.device)
-            L.check(L.lib().ia_envlight_pdf_tables(L.i32(H), L.i32(W), L.ptr(base), L.ptr(self.pmf), L.ptr(self._cdf), L.stream()),
+            tmp = torch.empty(int(L.lib().ia_envlight_pdf_tables_tmp_bytes(L.i32(H), L.i32(W))), dtype=torch.uint8, device=base.device)
+            L.check(L.lib().ia_envlight_pdf_tables(L.i32(H), L.i32(W), L.ptr(base), L.ptr(self.pmf), L.ptr(self._cdf), L.ptr(tmp), L.stream()),
                     "ia_envlight_pdf_tables")
-        else:        # a 1024 x 2048 HDRI, once per light: the one-workgroup kernel would take milliseconds
+        else:        # larger than the kernel's tile table: the torch expression
             sin_t = torch.sin((torch.arange(H, device=base.device) + 0.5) * math.pi / H)[:, None]
             lum = (0.2126 * base[..., 0] + 0.7152 * base[..., 1] + 0.0722 * base[..., 2]).clamp_min(0).double()
             w = lum * sin_t

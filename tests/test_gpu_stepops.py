@@ -180,9 +180,16 @@ def test_envlight_pdf_tables_vs_the_torch_expression_and_sampling_still_follows_
     _close(e.pmf, pmf, 2e-6, 1e-12, "pmf")
     _close(e._cdf, cdf, 1e-12, 1e-12, "cdf")
     assert abs(float(e._cdf[-1]) - 1.0) < 1e-6 and bool((e._cdf[1:] >= e._cdf[:-1]).all())
-    big = pbr.EnvironmentLightTensor(torch.rand((1024, 2048, 3), device=DEV))          # > PDF_KERNEL_MAX_PIXELS: the torch route
+    big = pbr.EnvironmentLightTensor(torch.rand((1024, 2048, 3), device=DEV))          # a 1024 x 2048 HDRI: 2048 tiles, same kernels
     big.update_pdf()
-    assert abs(float(big._cdf[-1]) - 1.0) < 1e-5
+    b = big.base.detach()
+    wb = (0.2126 * b[..., 0] + 0.7152 * b[..., 1] + 0.0722 * b[..., 2]).clamp_min(0).double() * torch.sin((torch.arange(1024, device=DEV) + 0.5) * math.pi / 1024)[:, None]
+    pb = (wb / wb.sum()).float()
+    _close(big.pmf, pb, 2e-6, 1e-13, "pmf 1024 x 2048")
+    _close(big._cdf, torch.cumsum(pb.reshape(-1).double(), 0), 1e-11, 1e-11, "cdf 1024 x 2048")
+    huge = pbr.EnvironmentLightTensor(torch.rand((2048, 4096, 3), device=DEV))         # > PDF_KERNEL_MAX_PIXELS: the torch route
+    huge.update_pdf()
+    assert abs(float(huge._cdf[-1]) - 1.0) < 1e-5
 
 
 def test_uniform_sphere_stratified_vs_the_torch_expression():
