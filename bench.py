@@ -194,7 +194,7 @@ def build_config4_step(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, seed=4
     return s4, f"{n_batch} rays on the subject of the bench frame, PBR training step (uniform_light, spp {spp}), fwd+bwd+Adam"
 
 
-def measure_config4(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, steps=10, rank=0, world=1, rccl_at_one_rank=False):
+def measure_config4(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, steps=20, rank=0, world=1, rccl_at_one_rank=False):
     """The line's `config4` object -- the reference's 4096-ray training batch per GPU: ms per step, rays/s (whole job: world x n_batch rays per
     step, ray-batch sharding of ONE frame with replicated parameters, BASELINE configs[3]), the search launches of one step (points, ms) --
     the step's one large search batch is its secondary march (~2 100 march points per ray), not the 4096 rays' own samples -- and the
@@ -237,7 +237,7 @@ def measure_config4(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, steps=10,
             dist.all_reduce(t_, op=dist.ReduceOp.MAX)
             dt_ = float(t_)
         return dt_ / k * 1e3, o_
-    for _ in range(3):
+    for _ in range(10):                 # (the first ~30 steps of a process drift down by ~5 %: allocator pools and clocks settle)
         o = s4()
     ms, o = timed(s4, steps)
     comm = sparse = None
@@ -401,7 +401,7 @@ def main():
                              rccl_at_one_rank=force_rccl)
         if rank == 0:
             line = {"metric": "rays/sec (fwd+bwd), 4096-ray training batches per GPU (BASELINE configs[3]: uniform_light, spp 512)",
-                    "value": c4 and c4["rays_per_s"], "unit": "rays/s", "n_gpus": world, "steps": max(args.steps, 1), "warmup": 3,
+                    "value": c4 and c4["rays_per_s"], "unit": "rays/s", "n_gpus": world, "steps": max(args.steps, 1), "warmup": 10,
                     "ms_per_step": c4 and c4["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                     "data": "synthetic", "config": {"workload": c4 and c4["workload"], "pose": args.pose, "parallelism": f"ray-batch sharding x{world}",
                                                     "library_sources_sha256_16": _build.source_fingerprint(), "library_built_from": _build.built_fingerprint()},

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "ia_common.h"
+#include "ia_zero.h"
 
 namespace {
 
@@ -1726,9 +1727,9 @@ IA_EXPORT int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, c
     IA_REQUIRE(N * I < ((int64_t)1 << 31), "ia_fuse_broyden_spec_rows: N * I must stay below 2^31");
     hipStream_t s = (hipStream_t)stream;
     OvfLayout o = ovf_layout(ovf_scratch, N);
-    (void)hipMemsetAsync(o.count, 0, 2 * sizeof(int32_t), s);
+    ia::zero_bytes(o.count, 2 * sizeof(int32_t), s);
     if (N == 0) {
-        (void)hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(int32_t), s);
+        ia::zero_bytes(total_and_overflow, 2 * sizeof(int32_t), s);
         return ia::check_launch("ia_fuse_broyden_spec_rows");
     }
     // small batches (IA_BR_SMALL_MAX points, default 2^18 = the flagged list's minimum capacity; 0 = off): every (point, init) search in its own lane, all points through the
@@ -1741,7 +1742,7 @@ IA_EXPORT int ia_fuse_broyden_spec_rows(int64_t N, int I, const float* xd_tgt, c
     if (small) {
         IA_REQUIRE(I >= 1 && I <= 16, "ia_fuse_broyden_spec_rows: 1 <= I <= 16 inits");
         IA_REQUIRE((int64_t)D * H * W < ((int64_t)1 << 26), "voxel grid too large for 32-bit byte offsets (48 B per voxel)");
-        (void)hipMemsetAsync(o.flag.valid, 0, (size_t)N * sizeof(uint32_t), s);
+        ia::zero_bytes(o.flag.valid, (size_t)N * sizeof(uint32_t), s);
         broyden_items_rows_kernel<<<ia::cdiv(N * I, THREADS), THREADS, 0, s>>>(N, I, xd_tgt, voxel_J_cl, D, H, W, tfs, bone_ids, offset, scale,
                                                                               cvg_threshold, dvg_threshold, J_inv, fwd_J, o.flag, order);
         r = ia::check_launch("ia_fuse_broyden_spec_rows(items)");
