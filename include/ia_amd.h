@@ -721,6 +721,10 @@ int ia_phys_loss_bwd(int64_t n, const float* comp_rgb, const float* comp_rgb_phy
                      const float* target_mask, const float* g_loss, float lambda_phys, float lambda_mask, float lambda_eik, float eik_denom,
                      float* g_comp_rgb, float* g_comp_rgb_phys, float* g_opacity, float* g_eik_sum, ia_stream_t stream);
 int ia_edge_min_sdf(int64_t n_edges, const float* sdf, const uint8_t* is_left, float* out, ia_stream_t stream);
+/* SNARFDeformer.transform_rays_w2s (models/deformers/snarf_deformer.py:128-147): rays [n, ray_stride >= 6] (o, d, ...) -> out [n,8] =
+ * (o R^T + t, d R^T, |o'| - 1, |o'| + 1), w2s [4,4] row-major on the device.  variant: summation form of the 3-term products (0: fma chain
+ * k = 0,1,2; 1: separate products left to right; 2: fma chain k = 2,1,0). */
+int ia_transform_rays_w2s(int64_t n, const float* rays, int ray_stride, const float* w2s, int variant, float* out, ia_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -444,6 +444,41 @@ __global__ __launch_bounds__(256) void phys_loss_bwd_kernel(int64_t n, const flo
     }
 }
 
+// ------------------------------------------------------------------------------------------------ world -> SMPL ray transform
+// SNARFDeformer.transform_rays_w2s (snarf_deformer.py:128-147): o' = o R^T + t, d' = d R^T, near / far = |o'| -+ 1.  `variant` selects the
+// summation form of the 3-term products (the reference does them as [n,3] x [3,3] GEMMs; which form equals the library's result bit for
+// bit is established by tools/ray_transform_probe.py, and only that form is used): 0 fma chain k = 0,1,2; 1 separate products, left to
+// right; 2 fma chain k = 2,1,0.
+__device__ __forceinline__ float dot3_variant(const float* __restrict__ p, const float* __restrict__ r, int variant)
+{
+    if (variant == 0) return __fmaf_rn(p[2], r[2], __fmaf_rn(p[1], r[1], p[0] * r[0]));
+    if (variant == 1) return __fadd_rn(__fadd_rn(__fmul_rn(p[0], r[0]), __fmul_rn(p[1], r[1])), __fmul_rn(p[2], r[2]));
+    return __fmaf_rn(p[0], r[0], __fmaf_rn(p[1], r[1], p[2] * r[2]));
+}
+
+__global__ __launch_bounds__(256) void transform_rays_kernel(int64_t n, const float* __restrict__ rays, int stride, const float* __restrict__ w2s,
+                                                             int variant, float* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + i * stride;
+    float o[3], d[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        o[a] = __fadd_rn(dot3_variant(r, w2s + 4 * a, variant & 3), w2s[4 * a + 3]);
+        d[a] = dot3_variant(r + 3, w2s + 4 * a, variant & 3);
+    }
+    const int nv = variant >> 2;          // norm form: 0 separate products left to right, 1 fma chain k = 0,1,2, 2 fma chain k = 2,1,0
+    float ss;
+    if (nv == 0) ss = __fadd_rn(__fadd_rn(__fmul_rn(o[0], o[0]), __fmul_rn(o[1], o[1])), __fmul_rn(o[2], o[2]));
+    else if (nv == 1) ss = __fmaf_rn(o[2], o[2], __fmaf_rn(o[1], o[1], o[0] * o[0]));
+    else ss = __fmaf_rn(o[0], o[0], __fmaf_rn(o[1], o[1], o[2] * o[2]));
+    const float dist = sqrtf(ss);
+    float* q = out + i * 8;
+    q[0] = o[0]; q[1] = o[1]; q[2] = o[2]; q[3] = d[0]; q[4] = d[1]; q[5] = d[2];
+    q[6] = dist - 1.0f; q[7] = dist + 1.0f;
+}
+
 // ------------------------------------------------------------------------------------------------ edge min
 __global__ __launch_bounds__(256) void edge_min_sdf_kernel(int64_t E, const float* __restrict__ sdf, const uint8_t* __restrict__ is_left,
                                                             float* __restrict__ out)
@@ -574,6 +609,14 @@ IA_EXPORT int ia_phys_loss_bwd(int64_t n, const float* comp_rgb, const float* co
                                                                             lambda_phys, lambda_mask, lambda_eik, eik_denom, g_comp_rgb,
                                                                             g_comp_rgb_phys, g_opacity, g_eik_sum);
     return ia::check_launch("ia_phys_loss_bwd");
+}
+
+IA_EXPORT int ia_transform_rays_w2s(int64_t n, const float* rays, int ray_stride, const float* w2s, int variant, float* out, ia_stream_t stream)
+{
+    if (n <= 0) return IA_OK;
+    IA_REQUIRE(rays && w2s && out && ray_stride >= 6 && variant >= 0 && variant <= 10, "bad arguments");
+    transform_rays_kernel<<<ia::cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(n, rays, ray_stride, w2s, variant, out);
+    return ia::check_launch("ia_transform_rays_w2s");
 }
 
 IA_EXPORT int ia_edge_min_sdf(int64_t n_edges, const float* sdf, const uint8_t* is_left, float* out, ia_stream_t stream)

@@ -178,7 +178,7 @@ class RenderStep:
         dfm = self.deformer
         rays = dfm.transform_rays_w2s(rays.float())
         n_rays = rays.shape[0]
-        rays_o, rays_d, far = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous(), rays[:, 7]
+        rays_o, rays_d, far = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous(), rays[:, 7]      # (two 12-byte-row copies: the kernels take [n,3])
         beta = self._beta()
         # -- 2. primary march (sampling_override, intrinsic_avatar.py:49-141; near 0 / far 1e10)
         near_planes = self._const(0.0, n_rays, rays.device)

@@ -266,3 +266,29 @@ def test_laplace_alpha_intervals_and_dense_gather_of_secondary_results_are_bit_i
     b_tr, b_rgb = pbr.scatter_secondary(F_, src.clone(), tr, rgb)         # an index list of unknown origin: zero fill + scatter
     assert torch.equal(a_tr, b_tr) and torch.equal(a_rgb, b_rgb)
     assert float(a_tr.max()) <= 1.0 and float(a_tr.min()) >= 0.0
+
+
+def test_ray_transform_kernel_is_the_library_product_bit_for_bit():
+    """SNARFDeformer.transform_rays_w2s as one launch: origins / directions equal the torch expression's [n,3] x [3,3] products (rocBLAS)
+    and numpy's float32 products (the CPU oracle's) bit for bit; near / far equal numpy's."""
+    from intrinsicavatar_amd import _lib as L
+    g = torch.Generator().manual_seed(12)
+    n = 300_007
+    A = torch.linalg.qr(torch.randn((3, 3), generator=g))[0]
+    w2s = torch.eye(4)
+    w2s[:3, :3], w2s[:3, 3] = A, torch.randn(3, generator=g) * 2
+    rays = torch.cat([torch.randn((n, 3), generator=g) * 3, torch.nn.functional.normalize(torch.randn((n, 3), generator=g), dim=-1), torch.zeros((n, 2))], 1)
+
+    class D:            # the method only reads .w2s
+        pass
+    from intrinsicavatar_amd.deformer import SNARFDeformer
+    d = D()
+    d.w2s = w2s.to(DEV)
+    out = SNARFDeformer.transform_rays_w2s(d, rays.to(DEV))
+    rg, wg = rays.to(DEV), w2s.to(DEV)
+    assert torch.equal(out[:, :3], rg[:, :3] @ wg[:3, :3].T + wg[None, :3, 3]) and torch.equal(out[:, 3:6], rg[:, 3:6] @ wg[:3, :3].T)
+    rn, wn = rays.numpy(), w2s.numpy()
+    on = rn[:, :3] @ wn[:3, :3].T + wn[None, :3, 3]
+    nn = np.linalg.norm(on, axis=-1, keepdims=True)
+    ref = np.concatenate([on, rn[:, 3:6] @ wn[:3, :3].T, nn - 1, nn + 1], 1).astype(np.float32)
+    assert np.array_equal(out.cpu().numpy(), ref)
