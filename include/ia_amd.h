@@ -714,9 +714,10 @@ int ia_material_affine(int64_t n, const float* m, float albedo_scale, float albe
                        float metallic_scale, float metallic_bias, float* albedo, float* roughness, float* metallic, ia_stream_t stream);
 int ia_material_affine_bwd(int64_t n, const float* g_albedo, const float* g_roughness, const float* g_metallic, float albedo_scale,
                            float roughness_scale, float metallic_scale, float* g_m, ia_stream_t stream);
+int64_t ia_phys_loss_tmp_bytes(int64_t n);
 int ia_phys_loss(int64_t n, const float* comp_rgb, const float* comp_rgb_phys, const float* opacity, const float* target_rgb,
                  const float* target_mask, const float* eik_partials, int eik_k, float lambda_phys, float lambda_mask, float lambda_eik,
-                 float eik_denom, float* terms, ia_stream_t stream);
+                 float eik_denom, float* terms, void* tmp /*ia_phys_loss_tmp_bytes(n) bytes; may be NULL when that is 0*/, ia_stream_t stream);
 int ia_phys_loss_bwd(int64_t n, const float* comp_rgb, const float* comp_rgb_phys, const float* opacity, const float* target_rgb,
                      const float* target_mask, const float* g_loss, float lambda_phys, float lambda_mask, float lambda_eik, float eik_denom,
                      float* g_comp_rgb, float* g_comp_rgb_phys, float* g_opacity, float* g_eik_sum, ia_stream_t stream);

@@ -41,7 +41,7 @@ class _Timed:
 
     def _resolve(self, name):
         fn = getattr(self._cdll, name)
-        if not name.startswith("ia_") or name in ("ia_last_error", "ia_scan_tmp_bytes", "ia_version", "ia_hashgrid_n_entries", "ia_traverse_scratch_bytes", "ia_occgrid_tmp_bytes", "ia_hashgrid_bwd_scratch_bytes", "ia_traverse_fused_scratch_bytes", "ia_hashgrid_fwd_scratch_bytes", "ia_eikonal_partials", "ia_spec_rows_slots", "ia_spec_rows_overflow_bytes", "ia_spec_rows_overflow_capacity", "ia_resample_tmp_bytes", "ia_sg_image_bwd_tmp_bytes", "ia_envlight_pdf_tables_tmp_bytes", "ia_hashgrid_fwd_levels_jac_offset", "ia_morton_order_tmp_bytes", "ia_deform_filter_tiles_tmp_bytes", "ia_deform_filter_compact_tmp_bytes"):
+        if not name.startswith("ia_") or name in ("ia_last_error", "ia_scan_tmp_bytes", "ia_version", "ia_hashgrid_n_entries", "ia_traverse_scratch_bytes", "ia_occgrid_tmp_bytes", "ia_hashgrid_bwd_scratch_bytes", "ia_traverse_fused_scratch_bytes", "ia_hashgrid_fwd_scratch_bytes", "ia_eikonal_partials", "ia_spec_rows_slots", "ia_spec_rows_overflow_bytes", "ia_spec_rows_overflow_capacity", "ia_resample_tmp_bytes", "ia_sg_image_bwd_tmp_bytes", "ia_envlight_pdf_tables_tmp_bytes", "ia_phys_loss_tmp_bytes", "ia_hashgrid_fwd_levels_jac_offset", "ia_morton_order_tmp_bytes", "ia_deform_filter_tiles_tmp_bytes", "ia_deform_filter_compact_tmp_bytes"):
             return fn
 
         def call(*args):

@@ -115,9 +115,11 @@ class _PhysLoss(Function):
         n, dev = comp_rgb.shape[0], comp_rgb.device
         terms = torch.empty(5, device=dev)
         k = int(eik_part.shape[0]) if eik_part is not None else 0
+        nb = int(L.lib().ia_phys_loss_tmp_bytes(L.i64(n)))
+        tmp = torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None
         L.check(L.lib().ia_phys_loss(L.i64(n), L.ptr(comp_rgb), L.ptr(comp_rgb_phys), L.ptr(opacity), L.ptr(target_rgb), L.ptr(target_mask),
                                      L.ptr(eik_part), L.i32(k), L.f32(lambda_phys), L.f32(lambda_mask), L.f32(lambda_eik), L.f32(eik_denom),
-                                     L.ptr(terms), L.stream()), "ia_phys_loss")
+                                     L.ptr(terms), L.ptr(tmp), L.stream()), "ia_phys_loss")
         ctx.save_for_backward(comp_rgb, comp_rgb_phys, opacity, target_rgb, target_mask)
         ctx.cfg = (float(lambda_phys), float(lambda_mask), float(lambda_eik), float(eik_denom), tuple(eik_part.shape) if eik_part is not None else None)
         ctx.mark_non_differentiable(terms)

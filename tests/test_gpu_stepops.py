@@ -222,12 +222,13 @@ def test_material_affine_forward_and_backward():
     assert torch.equal(gm, ref)
 
 
+@pytest.mark.parametrize("n", [4096, 291_600])
 @pytest.mark.parametrize("with_mask", [True, False])
-def test_phys_loss_forward_and_backward_vs_the_torch_composition(with_mask):
+def test_phys_loss_forward_and_backward_vs_the_torch_composition(with_mask, n):
     """train_phys.training_loss_phys: the fused kernel (IA_FUSED_LOSS, default) against the torch chain it replaces."""
     from intrinsicavatar_amd import train, train_phys
     g = torch.Generator().manual_seed(7)
-    n, S = 4096, 50_000
+    S = 50_000          # (n = 291 600: the full-frame path with workgroup partials)
     mk = lambda *s: torch.rand(s, generator=g).to(DEV)      # noqa: E731
     leaves = dict(comp_rgb=mk(n, 3), comp_rgb_phys=mk(n, 3) * 1.5, opacity=mk(n, 1) * 1.002 - 0.001, sdf_grad=(mk(S, 3) * 2 - 1) * 1.2)
     for t in leaves.values():
