@@ -10,6 +10,8 @@ models/utils.py:12,130):
 tiny-cuda-nn is not vendored in the reference tree; semantics follow the published Instant-NGP definitions
 (oracle/ia_oracle_field.c).  All compute is libia_amd.so.  Third-order terms (d^2 enc / d x^2 is zero almost
 everywhere for linear interpolation) are not propagated, as in tiny-cuda-nn."""
+import ctypes as C
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -84,9 +86,10 @@ class _SH4(Function):
     @staticmethod
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
-        gy = gy.contiguous().float()
+        if not (gy.dtype == torch.float32 and gy.dim() == 2 and gy.stride(1) == 1):      # a column block of a wider gradient row is read in place
+            gy = gy.contiguous().float()
         gx = torch.empty_like(x)
-        L.check(L.lib().ia_sh4_bwd(L.i64(x.shape[0]), L.ptr(x), L.ptr(gy), L.i32(gy.stride(0)), L.ptr(gx), L.stream()), "ia_sh4_bwd")
+        L.check(L.lib().ia_sh4_bwd(L.i64(x.shape[0]), L.ptr(x), C.c_void_p(gy.data_ptr()), L.i32(gy.stride(0)), L.ptr(gx), L.stream()), "ia_sh4_bwd")
         return gx
 
 

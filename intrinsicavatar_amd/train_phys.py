@@ -69,8 +69,11 @@ class _MLP2(Function):
                                          *[L.ptr(w) for w in ws], L.ptr(g_y.contiguous().float()), L.ptr(g_x), L.i32(pad),
                                          *[L.ptr(t) for t in d], L.stream()), "ia_mlp_bwd_fused")
         g_segs, c0 = [], 0
-        for w, m, _ in ctx.spec:
-            g_segs.append(g_x[:, c0:c0 + w] * m if m != 1.0 else g_x[:, c0:c0 + w])
+        for k, (w, m, _) in enumerate(ctx.spec):
+            if not ctx.needs_input_grad[8 + k]:          # e.g. the grid coordinates: constants of the step
+                g_segs.append(None)
+            else:
+                g_segs.append(g_x[:, c0:c0 + w] * m if m != 1.0 else g_x[:, c0:c0 + w])
             c0 += w
         return (None, None, *d, *g_segs)
 
