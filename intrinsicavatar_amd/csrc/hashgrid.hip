@@ -285,13 +285,8 @@ __device__ __forceinline__ void xcd_blend_store(const float2 v[8], const float p
     }
 }
 
-#ifdef IA_HASH_WAVES        /* experiment: pin the gather's occupancy (waves per SIMD) */
-#define IA_HASH_OCC __attribute__((amdgpu_waves_per_eu(IA_HASH_WAVES, IA_HASH_WAVES)))
-#else
-#define IA_HASH_OCC
-#endif
 template <bool WITH_JAC>
-__global__ __launch_bounds__(THREADS) IA_HASH_OCC void hash_fwd_xcd_kernel(int64_t n, const float* __restrict__ x,
+__global__ __launch_bounds__(THREADS) void hash_fwd_xcd_kernel(int64_t n, const float* __restrict__ x,
                                                                 const float2* __restrict__ params, HashCfg cfg, XcdPlan plan,
                                                                 float2* __restrict__ tmp /*[L][n]*/,
                                                                 float* __restrict__ tmp_jac /*[L][n][6]*/)
@@ -301,112 +296,11 @@ __global__ __launch_bounds__(THREADS) IA_HASH_OCC void hash_fwd_xcd_kernel(int64
     const int np = plan.nparts[slot];
     const int64_t per = (n + np - 1) / np;
     const int64_t lo = per * plan.part[slot], hi = (lo + per < n) ? lo + per : n;
-#ifdef IA_HASH_FOUR
-    // experiment (round 5): FOUR points per lane and iteration (32 independent loads issued before the first blend) -- the straight-line
-    // gather of round 3 made "two in flight" real; does four help now?  Measured: DESIGN 4.3.
-    {
-        const int64_t stride4 = nchunks * THREADS;
-        for (int64_t i = lo + chunk * THREADS + threadIdx.x; i < hi; i += 4 * stride4) {
-            int64_t ix[4];
-            bool ok[4];
-            float xs[4][3];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int64_t j = i + q * stride4;
-                ok[q] = j < hi;
-                ix[q] = ok[q] ? j : i;
-#pragma unroll
-                for (int d = 0; d < 3; d++) xs[q][d] = __builtin_nontemporal_load(x + ix[q] * 3 + d);
-            }
-            for (int l = plan.first_level[slot]; l < plan.first_level[slot] + plan.n_level[slot]; l++) {
-                const float sc = cfg.scale[l];
-                const uint32_t res = cfg.res[l], hsize = cfg.offsets[l + 1] - cfg.offsets[l];
-                const float2* tab = params + cfg.offsets[l];
-                float2 v[4][8];
-                float p[4][3];
-                const uint64_t r64 = res;
-                const bool hashed = r64 * r64 * r64 > (uint64_t)hsize;
-                if (hashed && (hsize & (hsize - 1u)) == 0u) {
-                    xcd_gather2<true>(tab, hsize, res, sc, xs[0], xs[1], v[0], v[1], p[0], p[1]);
-                    xcd_gather2<true>(tab, hsize, res, sc, xs[2], xs[3], v[2], v[3], p[2], p[3]);
-                } else if (!hashed) {
-                    xcd_gather2<false>(tab, hsize, res, sc, xs[0], xs[1], v[0], v[1], p[0], p[1]);
-                    xcd_gather2<false>(tab, hsize, res, sc, xs[2], xs[3], v[2], v[3], p[2], p[3]);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) xcd_gather<WITH_JAC>(tab, hsize, res, sc, xs[q], v[q], p[q]);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    if (ok[q]) xcd_blend_store<WITH_JAC>(v[q], p[q], sc, (int64_t)l * n + ix[q], tmp, tmp_jac);
-            }
-        }
-        return;
-    }
-#endif
-#ifdef IA_HASH_CONTIGUOUS
-    // experiment (round 5): every workgroup owns ONE contiguous range of the slot's (spatially sorted) points and walks it 512 points at
-    // a time -- consecutive iterations of a workgroup are neighbours in space (vector-L1 reuse across iterations) instead of the
-    // grid-stride sweep in which the resident workgroups together cover a window.  Measured: DESIGN 4.3.
-    const int64_t per_wg = ((hi - lo + nchunks - 1) / nchunks + 2 * THREADS - 1) / (2 * THREADS) * (2 * THREADS);
-    const int64_t wlo = lo + chunk * per_wg, whi = (wlo + per_wg < hi) ? wlo + per_wg : hi;
-    const int64_t stride = THREADS;
-    for (int64_t i = wlo + threadIdx.x; i < whi; i += 2 * stride) {
-        const int64_t i2 = i + stride;
-        const int64_t hi = whi;
-#else
-#ifdef IA_HASH_PREFETCH
-    // experiment (round 5): the NEXT iteration's coordinates are requested while this iteration's gathers are in flight -- an iteration
-    // was "coordinates (HBM stream, non-temporal) -> wait -> 16 gathers -> wait -> blend": two memory latencies in series on a kernel
-    // that is bound by latency x requests in flight.  111 VGPRs before, 4 waves per SIMD up to 128.  Measured: DESIGN 4.3.
-    {
-        const int64_t stride = nchunks * THREADS;
-        int64_t i = lo + chunk * THREADS + threadIdx.x;
-        if (i >= hi) return;
-        float xa[3], xb[3];
-        {
-            const int64_t ib0 = (i + stride < hi) ? i + stride : i;
-#pragma unroll
-            for (int d = 0; d < 3; d++) { xa[d] = __builtin_nontemporal_load(x + i * 3 + d); xb[d] = __builtin_nontemporal_load(x + ib0 * 3 + d); }
-        }
-        for (; i < hi; i += 2 * stride) {
-            const int64_t i2 = i + stride;
-            const bool two = i2 < hi;
-            const int64_t in = i + 2 * stride;
-            const int64_t ja = in < hi ? in : i, jb = (in + stride < hi) ? in + stride : ja;
-            float na[3], nb[3];
-            // issued IN FRONT of the gathers: both requests are in flight together (max of the two latencies instead of their sum)
-#pragma unroll
-            for (int d = 0; d < 3; d++) { na[d] = __builtin_nontemporal_load(x + ja * 3 + d); nb[d] = __builtin_nontemporal_load(x + jb * 3 + d); }
-            for (int l = plan.first_level[slot]; l < plan.first_level[slot] + plan.n_level[slot]; l++) {
-                const float sc = cfg.scale[l];
-                const uint32_t res = cfg.res[l], hsize = cfg.offsets[l + 1] - cfg.offsets[l];
-                const float2* tab = params + cfg.offsets[l];
-                float2 va[8], vb[8];
-                float pa[3], pb[3];
-                const uint64_t r64 = res;
-                const bool hashed = r64 * r64 * r64 > (uint64_t)hsize;
-                if (plan.straight && hashed && (hsize & (hsize - 1u)) == 0u) xcd_gather2<true>(tab, hsize, res, sc, xa, xb, va, vb, pa, pb);
-                else if (plan.straight && !hashed) xcd_gather2<false>(tab, hsize, res, sc, xa, xb, va, vb, pa, pb);
-                else {
-                    xcd_gather<WITH_JAC>(tab, hsize, res, sc, xa, va, pa);
-                    xcd_gather<WITH_JAC>(tab, hsize, res, sc, xb, vb, pb);
-                }
-                xcd_blend_store<WITH_JAC>(va, pa, sc, (int64_t)l * n + i, tmp, tmp_jac);
-                if (two) xcd_blend_store<WITH_JAC>(vb, pb, sc, (int64_t)l * n + i2, tmp, tmp_jac);
-            }
-#pragma unroll
-            for (int d = 0; d < 3; d++) { xa[d] = na[d]; xb[d] = nb[d]; }
-        }
-        return;
-    }
-#endif
     const int64_t stride = nchunks * THREADS;
     // two points per lane and iteration: the gathers of both (16 independent 8-byte loads) are issued before either
     // blend -- the kernel is bound by L2 gather latency x requests in flight, not by bandwidth (L2 hit 0.91)
     for (int64_t i = lo + chunk * THREADS + threadIdx.x; i < hi; i += 2 * stride) {
         const int64_t i2 = i + stride;
-#endif
         const bool two = i2 < hi;
         const int64_t ib = two ? i2 : i;
         const float xa[3] = {__builtin_nontemporal_load(x + i * 3 + 0), __builtin_nontemporal_load(x + i * 3 + 1),

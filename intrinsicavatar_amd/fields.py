@@ -653,6 +653,9 @@ def albedo_entropy(albedo: Tensor) -> Tensor:
     for i in range(pred.shape[-1]):
         ch = pred[..., i].contiguous()
         h = gaussian_histogram(ch, torch.var(ch), 15, 0.0, 1.0)
-        h = h.div(h.sum()) + 1e-6 if float(h.sum()) > 1e-6 else torch.ones_like(h)
+        # (the reference branches on the host, `if hist.sum() > 1e-6`: here the same select stays on the device -- no read-back)
+        s = h.sum()
+        ok = s > 1e-6
+        h = torch.where(ok, h.div(torch.where(ok, s, torch.ones_like(s))) + 1e-6, torch.ones_like(h))
         total = total + torch.sum(-h * torch.log(h))
     return total

@@ -88,8 +88,14 @@ def audit(step, warm=2):
     torch.cuda.synchronize()
     # ---- read-backs
     syncs = collections.Counter()
+    sync_order = []
 
     def hook(message, category, filename, lineno, file=None, line=None):
+        if "prototype feature" in str(message):            # the debug mode's own one-time notice, not a synchronisation
+            return
+        chain = [f"{os.path.basename(fr.filename)}:{fr.lineno}" for fr in traceback.extract_stack()
+                 if "intrinsicavatar_amd" in fr.filename and "launch_audit" not in fr.filename and not fr.filename.endswith("_lib.py")]
+        sync_order.append(" > ".join(chain[-4:]))
         for fr in reversed(traceback.extract_stack()):
             if "intrinsicavatar_amd" in fr.filename and "launch_audit" not in fr.filename:
                 syncs[f"{os.path.basename(fr.filename)}:{fr.lineno} {(fr.line or '').strip()[:100]}"] += 1
@@ -160,15 +166,36 @@ def audit(step, warm=2):
     gap_by = collections.Counter()
     for g_, nm in gaps:
         gap_by[nm] += g_
+    # what the HOST did while the device waited: for the longest gaps, the host-side operators / runtime calls that started inside
+    # the gap (a read-back shows as hipMemcpyWithStream / hipStreamSynchronize, a slow Python section as a long list of small operators)
+    cpu_evs = sorted(((e.time_range.start, e.time_range.end, e.name, site_of(list(e.stack or []))) for e in evs
+                      if not str(getattr(e, "device_type", "")).endswith("CUDA")), key=lambda t: t[0])
+    gap_context = []
+    prev_end = None
+    timeline = []
+    busy_end = spans[0][0] if spans else 0
+    last = None
+    for s, e_, nm in spans:
+        if s > busy_end and last is not None:
+            timeline.append((s - busy_end, busy_end, s, last, nm))
+        if e_ >= busy_end:
+            last = nm
+        busy_end = max(busy_end, e_)
+    for g_, a, b, before, after in sorted(timeline, reverse=True)[:14]:
+        inside = [(n, st) for (cs, ce, n, st) in cpu_evs if a - 30.0 <= cs <= b]
+        cnt = collections.Counter(n for n, _ in inside)
+        sites = collections.Counter(st for _, st in inside if st != "other")
+        gap_context.append(dict(gap_us=round(g_, 1), at_ms=round((a - spans[0][0]) / 1e3, 3), after_kernel=before, before_kernel=after,
+                                host_events=cnt.most_common(12), host_sites=sites.most_common(6)))
     return dict(
         device_launches=len(dev_evs), aten_or_runtime_launches=aten_launches, abi_or_unattributed_launches=len(dev_evs) - aten_launches,
-        readbacks=sum(syncs.values()), readbacks_by_line=syncs.most_common(),
+        readbacks=sum(syncs.values()), readbacks_by_line=syncs.most_common(), readbacks_in_order=sync_order,
         span_ms=round(span / 1e3, 3), busy_ms=round(busy / 1e3, 3), idle_ms=round(idle / 1e3, 3), idle_frac=round(idle / max(span, 1e-9), 4),
         launches_by_source_line=[(s, n, round(by_site_us[s] / 1e3, 3)) for s, n in by_site.most_common(80)],
         launches_by_aten_op=by_op.most_common(40),
         kernels_by_name=names.most_common(70),
         kernel_ms_by_name=[(k, round(v / 1e3, 3), names[k]) for k, v in name_us.most_common(40)],
-        idle_us_in_front_of=[(round(v, 1), k) for k, v in gap_by.most_common(25)])
+        idle_us_in_front_of=[(round(v, 1), k) for k, v in gap_by.most_common(25)], longest_gaps=gap_context)
 
 
 def main():

@@ -31,8 +31,10 @@ def load(path):
     return rows
 
 
-def window(rows, k):
+def window(rows, k, skip=0):
     ends = [e for s, e, n, q in rows if n == "adam_kernel"]
+    if skip:
+        ends = ends[:-skip]
     if len(ends) < k + 1:
         return rows[0][0], rows[-1][1]
     return ends[-(k + 1)], ends[-1]
@@ -42,9 +44,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("traces", nargs="+")
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--skip-last", type=int, default=0, help="leave out the last K steps of the trace (instrumented repeats after the timed steps)")
     args = ap.parse_args()
     traces = [load(p) for p in args.traces]
-    wins = [window(t, args.steps) for t in traces]
+    wins = [window(t, args.steps, args.skip_last) for t in traces]
     w0, w1 = max(w[0] for w in wins), min(w[1] for w in wins)
     evs = []
     queues = []

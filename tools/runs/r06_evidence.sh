@@ -13,6 +13,7 @@ rm -rf /tmp/kt2 && timeout 600 rocprofv3 --kernel-trace --stats --output-format 
 cp $(find /tmp/kt2 -name "*kernel_stats.csv" | head -1) $O/r06_headline_kernel_stats_two_streams.csv
 rm -rf /tmp/kt4 && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt4 -- python $R/tools/config4_bench.py --steps 20 --repeat 1 > $O/r06_config4_bench_under_rocprof.json 2>/dev/null
 cp $(find /tmp/kt4 -name "*kernel_stats.csv" | head -1) $O/r06_config4_kernel_stats.csv
+python $R/tools/overlap_timeline.py $(find /tmp/kt4 -name "*kernel_trace.csv" | head -1) --steps 12 --skip-last 4 > $O/r06_config4_timeline.json 2>/dev/null
 timeout 300 python $R/tools/config4_bench.py --steps 30 --repeat 3 > $O/r06_config4_bench.json 2>/dev/null
 timeout 300 python $R/tools/launch_audit.py --out $O/r06_launch_audit_after.json > /dev/null 2>&1
 timeout 300 python $R/tools/microbench.py > $O/r06_microbench.json 2>/dev/null
