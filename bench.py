@@ -348,6 +348,7 @@ def main():
         import ctypes
         try:
             _hip = ctypes.CDLL("libamdhip64.so")
+            _hip.hipSetDevice(ctypes.c_int(local_rank))               # the flag belongs to THIS rank's device, not to device 0
             _rc = _hip.hipSetDeviceFlags(ctypes.c_uint(0x4))          # hipDeviceScheduleBlockingSync
             blocking = (_rc == 0)
         except OSError:
