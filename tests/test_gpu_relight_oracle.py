@@ -357,10 +357,23 @@ def test_relight_uniform_light_mode_vs_oracle(setup):
     scale = np.abs(Lo_r).mean() + 1e-6
     PB.held("relight/uniform_light/fg_Lo_over_mean", Lo_g / scale, Lo_r / scale, (25.0, 3e-2, 4e-3))
     same_state = _same_state(out, ref, same, ig, ir, tr_g, tr_r)
-    # (observed: max 0.35 of the mean radiance on ONE of ~230 k same-state samples at p99 1e-3 / mean 5e-5 -- that one sample's cause is
-    #  not identified; the light-mode runs stay under 0.05)
     PB.held_by_discrete_state("relight/uniform_light", N(out["fg_Lo"])[ig], ref["fg_Lo"][ir], same_state, max(16, int(8e-2 * same_state.size)),
                               (0.7, 1e-2, 5e-4), (0.2, 3e-3, 2e-4))
+    # the same-state samples that differ by more than 0.05 of the MEAN radiance (observed: six, up to 0.35) are SUN-LIT ones -- radiance
+    # 8 ... 200 x the mean (the HDRI's sun is 40 x its sky) -- whose normals differ by 6e-4 ... 1e-3 (inside the same-state threshold): the
+    # cosine term moves by d(n.l) / n.l.  tests/diagnose_uniform_outlier.py: the ORACLE's estimator on the GPU's inputs of those samples
+    # gives the GPU's radiance to 2e-4 of the mean -- the difference is the inputs', not the shading kernel's.  Asserted per sample:
+    # first-order bound |dLo| / |Lo| <= 4 |dn| / n.l + 2e-3
+    Lg, Lr = N(out["fg_Lo"])[ig], ref["fg_Lo"][ir]
+    mean_radiance = np.abs(Lr[ok]).mean() + 1e-6
+    big = same_state & (np.abs(Lg - Lr).max(-1) > 0.05 * mean_radiance)
+    dn = np.abs(N(out["fg_extras"]["normals"])[ig] - ref["fg_extras"]["normals"][ir]).max(-1)
+    ndl = (ref["fg_extras"]["normals"][ir] * ref["out_dirs"][ir]).sum(-1)
+    rel = np.abs(Lg - Lr).max(-1) / np.maximum(np.abs(Lr).max(-1), 1e-6)
+    bound = 4.0 * dn / np.maximum(ndl, 1e-3) + 2e-3
+    assert int(big.sum()) <= max(16, int(2e-4 * big.size)), int(big.sum())
+    assert bool((rel[big] <= bound[big]).all()), (rel[big].tolist(), bound[big].tolist())
+    assert bool((np.abs(Lr[big]).max(-1) > 5.0 * mean_radiance).all()), "a large absolute difference on a sample that is not bright"
     has = ref["resampled_packed_info"][:, 1] > 0
     for k, cap in (("comp_rgb_phys", (0.3, 3e-2, 1.5e-3)), ("visibility", (0.1, 1e-2, 5e-4))):
         PB.held(f"relight/uniform_light/{k}", N(out[k]), ref[k], cap)
