@@ -533,6 +533,8 @@ class RenderStep:
                    roughness=acc(mats[:, 3:4].contiguous()), metallic=acc(mats[:, 4:5].contiguous()), opacity=acc(None))
         out["depth"] = acc(((t_starts + t_ends) / 2.0)[:, None]) + (1.0 - out["opacity"]) * far[:, None]
         out["packed_info"] = packed_info
+        # (references to the per-sample tensors of the primary samples, as forward() returns them: no copy)
+        out["primary_samples"] = dict(sdf_grad=d["sdf_grad"], valid=d["valid"], t_starts=t_starts, t_ends=t_ends, ray_indices=ray_indices)
         extras = dict(weights=weights, sdf=d["sdf"], alphas=alphas, normals=normal_smpl, albedo=mats[:, :3],
                       roughness=mats[:, 3:4], metallic=mats[:, 4:5])
         rgb_phys = background_color[None].expand(n_rays, 3).clone()

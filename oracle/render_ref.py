@@ -329,8 +329,8 @@ def relight_step(sc, rays_world, spp=16, seed=0, light_u=None, shuffle_u=None, j
     mats = sh["materials"]
     out = dict(comp_rgb=acc(sh["rgbs"]), comp_normal=acc(sh["normal_world"]), albedo=acc(np.ascontiguousarray(mats[:, :3])),
                roughness=acc(np.ascontiguousarray(mats[:, 3:4])), metallic=acc(np.ascontiguousarray(mats[:, 4:5])),
-               opacity=acc(None), weights=w, alphas=sh["alphas"], sdf=sh["sdf"], t_starts=ts, t_ends=te, ray_indices=rix,
-               packed_info=pinfo)
+               opacity=acc(None), weights=w, alphas=sh["alphas"], sdf=sh["sdf"], sdf_grad=sh["sdf_grad"], t_starts=ts, t_ends=te,
+               ray_indices=rix, packed_info=pinfo)
     out["depth"] = acc(((ts + te) / np.float32(2.0))[:, None]) + (1 - out["opacity"]) * far[:, None]
     rgb_phys = np.tile(bgc[None], (n, 1)).astype(np.float32)
     demod_phys = rgb_phys.copy()
