@@ -246,7 +246,7 @@ def shade_differentiable_phys(rs, material, emitter, rays_o: Tensor, rays_d: Ten
             # their weights sum to the ray's transmittance; rays without samples show the background (:1452-1466)
             rgb_phys = vi.composite(w_fg, fg_Lo, 1.0 - res["opacity"], background_color)
             res.update(fg_Lo=fg_Lo, fg_Lo_diff=fg_Ld, fg_Lo_spec=fg_Ls, fg_weights=w_fg, secondary_tr=sec_tr, secondary_rgb=sec_rgb,
-                       out_dirs=out_dirs, inv_pdf=inv_pdf, volume_interaction=vi)
+                       out_dirs=out_dirs, inv_pdf=inv_pdf, volume_interaction=vi, fg_normals=nrm)
     res.update(comp_rgb_phys=rgb_phys, stats=stats)
     return res
 

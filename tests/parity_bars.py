@@ -75,6 +75,23 @@ def held_by_discrete_state(tag, Lo_gpu, Lo_ref, same_state, count_cap, cap_over_
     return held(f"{tag}/fg_Lo_same_state_relative", a / den, b / den, cap_relative)
 
 
+def large_same_state_differences_are_first_order(Lo_gpu, Lo_ref, same_state, normals_gpu, normals_ref, light_dirs_ref, mean_radiance, count_cap):
+    """the same-state samples whose radiance differs by more than 0.05 of the MEAN radiance must be BRIGHT samples (> 5 x the mean: a
+    sun / lobe texel) whose difference is the first-order effect of the normals' difference (< 1e-3, inside the same-state threshold) on the
+    cosine term: |dLo| / |Lo| <= 4 |dn| / n.l + 2e-3.  (tests/diagnose_uniform_outlier.py: the oracle's estimator on the GPU's inputs of
+    such samples returns the GPU's value to 2e-4 of the mean -- the inputs differ, not the shading.)  -> number of such samples."""
+    Lg, Lr = np.asarray(Lo_gpu, np.float64), np.asarray(Lo_ref, np.float64)
+    big = np.asarray(same_state, bool) & (np.abs(Lg - Lr).max(-1) > 0.05 * mean_radiance)
+    dn = np.abs(np.asarray(normals_gpu, np.float64) - normals_ref).max(-1)
+    ndl = (np.asarray(normals_ref, np.float64) * light_dirs_ref).sum(-1)
+    rel = np.abs(Lg - Lr).max(-1) / np.maximum(np.abs(Lr).max(-1), 1e-6)
+    bound = 4.0 * dn / np.maximum(ndl, 1e-3) + 2e-3
+    assert int(big.sum()) <= count_cap, (int(big.sum()), count_cap)
+    assert bool((rel[big] <= bound[big]).all()), (rel[big].tolist(), bound[big].tolist())
+    assert bool((np.abs(Lr[big]).max(-1) > 5.0 * mean_radiance).all()), "a large absolute difference on a sample that is not bright"
+    return int(big.sum())
+
+
 @atexit.register
 def _write():
     if _OBS_PATH and _OBS:

@@ -181,6 +181,18 @@ def test_headline_forward_vs_oracle_per_point(oracle):
     Lo_g, Lo_r = N(out["fg_Lo"])[:F0][ok], ref["fg_Lo"][:F0][ok]
     scale = np.abs(Lo_r).mean() + 1e-6
     PB.held("headline_call/fg_Lo_over_mean", Lo_g / scale, Lo_r / scale, (25.0, 3e-2, 4e-3))
+    # ... split by discrete state like the relight tests (tests/parity_bars.held_by_discrete_state): same source interval of K1, same
+    # secondary transmittance (1e-5), normal within 1e-3, indirect radiance within 1e-3 -> float tolerance; the rest counted
+    src_g = N(vi.fg_src)[:F0].astype(np.int64)
+    src_r = ref["k1"]["sampled_indices"][ref["fg_indices"]][:F0].astype(np.int64)
+    dn = np.abs(N(out["fg_normals"])[:F0] - ref["fg_extras"]["normals"][:F0]).max(-1)
+    ind_g, ind_r = N(out["secondary_rgb"])[:F0], ref["secondary_rgb"][:F0]
+    state = (src_g == src_r) & (np.abs(tr_g - tr_r) <= 1e-5) & (dn <= 1e-3) & (np.abs(ind_g - ind_r).max(-1) <= 1e-3 * (1.0 + np.abs(ind_r).max(-1)))
+    PB.held_by_discrete_state("headline_call", N(out["fg_Lo"])[:F0][same_dir], ref["fg_Lo"][:F0][same_dir], state[same_dir],
+                              max(16, int(8e-2 * int(same_dir.sum()))), (0.3, 1e-2, 5e-4), (2e-2, 3e-3, 2e-4))
+    # (observed: max 0.09 of the mean radiance at 5e-3 relative -- samples lit by the SG light's lobe; asserted to be first-order in dn)
+    PB.large_same_state_differences_are_first_order(N(out["fg_Lo"])[:F0], ref["fg_Lo"][:F0], state & same_dir, N(out["fg_normals"])[:F0],
+                                                    ref["fg_extras"]["normals"][:F0], ref["out_dirs"][:F0], scale, max(16, int(2e-4 * F0)))
     # the light pdf the estimator divides by, against the oracle's on the same directions
     dw = dr @ sc.w2s[:3, :3]
     dw = dw / np.maximum(np.linalg.norm(dw, axis=-1, keepdims=True), 1e-6)

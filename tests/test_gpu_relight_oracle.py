@@ -371,15 +371,8 @@ def test_relight_uniform_light_mode_vs_oracle(setup):
     # gives the GPU's radiance to 2e-4 of the mean -- the difference is the inputs', not the shading kernel's.  Asserted per sample:
     # first-order bound |dLo| / |Lo| <= 4 |dn| / n.l + 2e-3
     Lg, Lr = N(out["fg_Lo"])[ig], ref["fg_Lo"][ir]
-    mean_radiance = np.abs(Lr[ok]).mean() + 1e-6
-    big = same_state & (np.abs(Lg - Lr).max(-1) > 0.05 * mean_radiance)
-    dn = np.abs(N(out["fg_extras"]["normals"])[ig] - ref["fg_extras"]["normals"][ir]).max(-1)
-    ndl = (ref["fg_extras"]["normals"][ir] * ref["out_dirs"][ir]).sum(-1)
-    rel = np.abs(Lg - Lr).max(-1) / np.maximum(np.abs(Lr).max(-1), 1e-6)
-    bound = 4.0 * dn / np.maximum(ndl, 1e-3) + 2e-3
-    assert int(big.sum()) <= max(16, int(2e-4 * big.size)), int(big.sum())
-    assert bool((rel[big] <= bound[big]).all()), (rel[big].tolist(), bound[big].tolist())
-    assert bool((np.abs(Lr[big]).max(-1) > 5.0 * mean_radiance).all()), "a large absolute difference on a sample that is not bright"
+    PB.large_same_state_differences_are_first_order(Lg, Lr, same_state, N(out["fg_extras"]["normals"])[ig], ref["fg_extras"]["normals"][ir],
+                                                    ref["out_dirs"][ir], np.abs(Lr[ok]).mean() + 1e-6, max(16, int(2e-4 * same_state.size)))
     has = ref["resampled_packed_info"][:, 1] > 0
     for k, cap in (("comp_rgb_phys", (0.3, 3e-2, 1.5e-3)), ("visibility", (0.1, 1e-2, 5e-4))):
         PB.held(f"relight/uniform_light/{k}", N(out[k]), ref[k], cap)
