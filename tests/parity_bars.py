@@ -92,6 +92,29 @@ def large_same_state_differences_are_first_order(Lo_gpu, Lo_ref, same_state, nor
     return int(big.sum())
 
 
+def held_same_state_part_of_the_image(name, n_rays, sample_rays, w_gpu, Lo_gpu, w_ref, Lo_ref, same_state, cap):
+    """the part of a Monte-Carlo image that the SAME-STATE re-samples contribute (sum over them of re-sampled weight x radiance, per ray) on
+    both sides: with the flipped samples left out of both sums, what remains of the image difference is float arithmetic -- held to `cap`."""
+    m = np.asarray(same_state, bool)
+    r = np.asarray(sample_rays)[m]
+    pg, pr = np.zeros((n_rays, 3)), np.zeros((n_rays, 3))
+    np.add.at(pg, r, np.asarray(w_gpu, np.float64)[m, None] * np.asarray(Lo_gpu, np.float64)[m])
+    np.add.at(pr, r, np.asarray(w_ref, np.float64)[m, None] * np.asarray(Lo_ref, np.float64)[m])
+    return held(name, pg, pr, cap)
+
+
+def outlier_pixels_own_a_flipped_sample(img_gpu, img_ref, flipped_sample_rays, factor=10.0):
+    """Monte-Carlo image: every pixel whose difference is more than `factor` x the 99th percentile of the frame must be the ray of at least
+    one re-sample in ANOTHER discrete state (another source interval / visibility / normal: `flipped_sample_rays`, the ray index of every
+    such re-sample) -- a flipped sample moves its pixel by Lo / spp, nothing else moves a pixel that far.  -> number of outlier pixels."""
+    e = np.abs(np.asarray(img_gpu, np.float64) - img_ref)
+    e = e.reshape(e.shape[0], -1).max(-1)
+    bad = set(np.nonzero(e > factor * float(np.quantile(e, 0.99)))[0].tolist())
+    rest = bad - set(np.asarray(flipped_sample_rays).tolist())
+    assert not rest, (sorted(rest), [float(e[i]) for i in sorted(rest)], float(np.quantile(e, 0.99)))
+    return len(bad)
+
+
 @atexit.register
 def _write():
     if _OBS_PATH and _OBS:

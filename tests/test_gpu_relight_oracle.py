@@ -138,6 +138,15 @@ def test_relight_light_mode_vs_oracle(setup, hw, spp, gi):
     np.testing.assert_array_equal(img_g[nohit], np.tile(bg[None], (int(nohit.sum()), 1)))
     # Monte-Carlo image: a flipped visibility sample moves a pixel by Lo / spp
     PB.held(f"{tag}/comp_rgb_phys", img_g, img_r, (0.3, 3e-2, 1.5e-3))
+    # ... and the pixels that move furthest are the rays of flipped samples (asserted pixel by pixel)
+    rri_g = N(out["resampled_ray_indices"])
+    flipped = np.concatenate([rri_g[fg_ref != fg_gpu], rri_g[np.nonzero(same)[0][~same_state]]])
+    print(f"{tag}: {PB.outlier_pixels_own_a_flipped_sample(img_g, img_r, flipped)} outlier pixels of comp_rgb_phys, each the ray of a flipped sample")
+    # ... and with the flipped samples left out of both sums the image agrees to float tolerance
+    ks = np.nonzero(same)[0]
+    PB.held_same_state_part_of_the_image(f"{tag}/comp_rgb_phys_same_state_part", n, rri_g[ks], N(out["resampled_weights"])[ks], N(out["fg_Lo"])[ig],
+                                         ref["resampled_weights"][ks], ref["fg_Lo"][ir], same_state, (5e-3, 5e-4, 5e-5))
+    print(f"{tag}: {len(set(flipped.tolist()))} of {int(has.sum())} rays own a flipped sample")
     assert abs(img_g[has].mean() - img_r[has].mean()) <= 2e-3 * abs(img_r[has].mean())
 
 
@@ -376,4 +385,12 @@ def test_relight_uniform_light_mode_vs_oracle(setup):
     has = ref["resampled_packed_info"][:, 1] > 0
     for k, cap in (("comp_rgb_phys", (0.3, 3e-2, 1.5e-3)), ("visibility", (0.1, 1e-2, 5e-4))):
         PB.held(f"relight/uniform_light/{k}", N(out[k]), ref[k], cap)
+    rri_g = N(out["resampled_ray_indices"])
+    flipped = np.concatenate([rri_g[fg_ref != fg_gpu], rri_g[np.nonzero(same)[0][~same_state]]])
+    for k in ("comp_rgb_phys", "visibility"):
+        print(f"relight/uniform_light: {PB.outlier_pixels_own_a_flipped_sample(N(out[k]), ref[k], flipped)} outlier pixels of {k}, each the ray of a flipped sample")
+    ks = np.nonzero(same)[0]
+    PB.held_same_state_part_of_the_image("relight/uniform_light/comp_rgb_phys_same_state_part", n, rri_g[ks], N(out["resampled_weights"])[ks],
+                                         N(out["fg_Lo"])[ig], ref["resampled_weights"][ks], ref["fg_Lo"][ir], same_state, (5e-3, 5e-4, 5e-5))
+    print(f"relight/uniform_light: {len(set(flipped.tolist()))} of {int(has.sum())} rays own a flipped sample")
     assert float(N(out["visibility"])[has].max()) <= 2.0 + 1e-4 and float(N(out["visibility"])[~has].max(initial=0.0)) == 0.0
