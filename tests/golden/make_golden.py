@@ -28,8 +28,14 @@ import numpy as np
 import torch
 
 REF = "/root/reference"
-OUT = os.path.dirname(os.path.abspath(__file__))
-WORK = "/tmp/ia_golden_build"
+OUT = os.environ.get("IA_GOLDEN_OUT") or os.path.dirname(os.path.abspath(__file__))
+# IA_GOLDEN_CONTRACT=fast: the SENSITIVITY run of tools/fma_contraction_sensitivity.py -- the same kernel bodies compiled WITH fused
+# multiply-add contraction (-ffp-contract=fast -mfma), as nvcc's default --fmad=true does to the reference's build; the committed
+# fixtures are the contraction-free build (source semantics).  Such a run must write somewhere else (IA_GOLDEN_OUT).
+CONTRACT = os.environ.get("IA_GOLDEN_CONTRACT", "off")
+assert CONTRACT == "off" or os.environ.get("IA_GOLDEN_OUT"), "a contraction run must not overwrite the committed fixtures"
+FP_FLAGS = ["-ffp-contract=off"] if CONTRACT == "off" else ["-ffp-contract=fast", "-mfma"]
+WORK = "/tmp/ia_golden_build" + ("" if CONTRACT == "off" else "_fma")
 
 SHIM_H = r"""
 #pragma once
@@ -102,8 +108,8 @@ def build_reference_host_modules():
     decl = decl.replace('#include "include/helpers_cuda.h"', '#include "shim.h"').replace(
         '#include "include/helpers_math.h"', "").replace("(bool) CUB_SUPPORTS_SCAN_BY_KEY()", "false")
     open(f"{WORK}/bind_nerfacc.cpp", "w").write(decl)
-    nerfacc = load(name="ia_ref_nerfacc_host", sources=[f"{WORK}/cdf.cpp", f"{WORK}/pack.cpp", f"{WORK}/bind_nerfacc.cpp"],
-                   extra_cflags=["-O2", "-ffp-contract=off", f"-I{WORK}"], build_directory=WORK, verbose=False)
+    nerfacc = load(name="ia_ref_nerfacc_host" + ("" if CONTRACT == "off" else "_fma"), sources=[f"{WORK}/cdf.cpp", f"{WORK}/pack.cpp", f"{WORK}/bind_nerfacc.cpp"],
+                   extra_cflags=["-O2", *FP_FLAGS, f"-I{WORK}"], build_directory=WORK, verbose=False)
     # --- fast-snarf
     os.makedirs(f"{WORK}/snarf", exist_ok=True)
     cu = f"{REF}/models/deformers/fast_snarf/cuda"
@@ -126,7 +132,7 @@ def build_reference_host_modules():
         'PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) { m.def("fuse_broyden", &fuse_broyden); m.def("filter", &filter); m.def("precompute", &precompute); }\n')
     srcs.append(f"{WORK}/snarf/bind.cpp")
     os.makedirs(f"{WORK}/snarf_build", exist_ok=True)
-    snarf = load(name="ia_ref_snarf_host", sources=srcs, extra_cflags=["-O2", "-ffp-contract=off", f"-I{WORK}"],
+    snarf = load(name="ia_ref_snarf_host" + ("" if CONTRACT == "off" else "_fma"), sources=srcs, extra_cflags=["-O2", *FP_FLAGS, f"-I{WORK}"],
                  build_directory=f"{WORK}/snarf_build", verbose=False)
     return nerfacc, snarf
 
