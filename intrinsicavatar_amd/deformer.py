@@ -104,7 +104,9 @@ class SNARFDeformer:
         (the CPU oracle's), the near / far columns to numpy's norm (torch's GPU norm differs from both by an ulp on 3.6 % of the rays) --
         tools/ray_transform_probe.py: 0 of 9.55 M elements differ."""
         w2s = self.w2s
-        if rays.is_cuda and rays.dtype == torch.float32 and rays.dim() == 2 and rays.shape[1] >= 6 and rays.stride(1) == 1 and not rays.requires_grad \
+        if not rays.is_cuda:
+            raise L.IaError("SNARFDeformer.transform_rays_w2s needs GPU rays (no CPU fallback)")
+        if rays.dtype == torch.float32 and rays.dim() == 2 and rays.shape[1] >= 6 and rays.stride(1) == 1 and not rays.requires_grad \
                 and not w2s.requires_grad and w2s.shape == (4, 4):
             n = rays.shape[0]
             out = torch.empty((n, 8), device=rays.device)

@@ -237,8 +237,6 @@ class _WNLinear(nn.Module):
 
     def effective(self, src=None, mul=None):
         """g * v / |v|_row (ia_effective_weights mode 1; differentiable), optionally in another column order with column masks."""
-        if not self.weight_v.is_cuda:
-            return _weight_norm(self.weight_g, self.weight_v)          # host-side exports (synthetic.export: the oracle's scene bundle)
         return _EffW.apply(1, self.weight_g, self.weight_v, src, mul)
 
 

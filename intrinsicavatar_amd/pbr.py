@@ -207,7 +207,8 @@ class EnvironmentLightSG(torch.nn.Module):
         """[H,W,3] image of the lobes, differentiable w.r.t. axis / log_lambda / mu: ia_sg_image / _bwd, one launch each way (the torch
         expression -- two [HW,K] GEMMs and ~30 element-wise launches with their backward -- is generate_image_torch)."""
         if not self.axis.is_cuda:
-            return self.generate_image_torch()
+            raise L.IaError("EnvironmentLightSG.generate_image needs its parameters on the GPU (no CPU fallback; generate_image_torch is the "
+                            "torch expression the tests compare the kernels with)")
         return _SGImage.apply(self.axis, self.log_lambda, self.mu, self.base_res, 2 * self.base_res)
 
     def generate_image_torch(self) -> Tensor:

@@ -258,7 +258,7 @@ def training_loss_phys(out: Dict[str, Tensor], target_rgb: Tensor, target_mask: 
                        lambda_phys: float = 1.0, lambda_smooth: float = 0.0, lambda_orient: float = 0.0, **kw) -> Tensor:
     """train.training_loss + the L1 term on the physically based image (systems/intrinsic_avatar.py:180-190) and, when
     the jitter pass ran, the material smoothness / normal orientation maps."""
-    if FUSED_LOSS and not kw.get("lambda_curv") and out["comp_rgb"].is_cuda:
+    if FUSED_LOSS and not kw.get("lambda_curv"):
         # one kernel each way (ia_phys_loss); the eikonal partial sums of ia_eikonal go in as they are
         lam_eik, lam_mask = kw.get("lambda_eik", 0.1), kw.get("lambda_mask", 0.1)
         part = train._EikonalPartials.apply(out["sdf_grad"], out["valid"])
