@@ -297,6 +297,11 @@ def measure_config4(rs, rays, mat, sg, dev, bg, n_batch=4096, spp=512, steps=20,
                 n_gpus=world, ms_per_step=round(ms, 3), rays_per_s=round(world * n_batch / (ms * 1e-3), 1),
                 secondary_rays_per_step=int(o["stats"]["n_secondary"]),
                 kernel_ms_per_step=round(sum(c[0] for v in det.values() for c in v), 3),
+                idle_frac_untraced_upper_bound=round(max(0.0, 1.0 - sum(c[0] for v in det.values() for c in v) / max(ms, 1e-9)), 4),
+                idle_note="idle_frac is the device time line of one step UNDER torch.profiler, whose per-launch overhead widens every gap; "
+                          "untraced, 1 - kernel_ms_per_step / ms_per_step bounds the idle share from above (kernel_ms_per_step = live HIP events "
+                          "around the C-ABI entry points only: the ~0.35 ms per step of ATen kernels count as idle in it); the rocprofv3 kernel "
+                          "trace of the same step (profiles/r06_config4_timeline.json) has the kernels busy 13.5 ms per step",
                 search_launches_ms_points=search, gradient_allreduce=comm, sparse_exchange=sparse,
                 host_figures_of="one step of this rank without the exchange" if sync is not None else "one step", **(host or {}))
 
