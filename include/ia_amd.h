@@ -195,6 +195,11 @@ int ia_fg_compact(int64_t n_rays, const int32_t* resampled_packed_info, const ui
  * (right edge = left edge + 1), sample_ray_indices i64 [S], sample_packed_info i32 [n_rays,2] = pack_info(sample_ray_indices, n_rays).
  * ia_samples_to_edges: out[e] = is_left[e] ? sample_vals[pos[e]] : fill  (`x = fill; x[is_left] = sample_vals`, :1022-1025). */
 int ia_interval_samples_count(int64_t n_edges, const uint8_t* is_left, int32_t* pos, int32_t* total, void* scan_tmp, ia_stream_t stream);
+/* ... over a CAPACITY-sized edge list whose length is still on the device (the kept edges of K2 are written into a buffer of
+ * n_in + n * n_rays >= T slots, cdf.cu:370's `.item()` is not taken; *n_edges = T): pos i32 [capacity], slots behind the list count nothing, *total = S
+ * -- so that T and S come back in ONE read-back (lib_nerfacc.ray_resampling_merge_compact_samples).  scan_tmp: ia_scan_tmp_bytes(capacity). */
+int ia_interval_samples_count_upto(int64_t capacity, const uint8_t* is_left, const int32_t* n_edges, int32_t* pos, int32_t* total,
+                                   void* scan_tmp, ia_stream_t stream);
 int ia_interval_samples_fill(int64_t n_rays, int64_t n_edges, const int32_t* edge_packed_info, const float* vals,
                              const int64_t* ray_indices, const uint8_t* is_left, const int32_t* pos, const int32_t* total,
                              int64_t* left_idx, float* t_starts, float* t_ends, int64_t* sample_ray_indices,

@@ -378,6 +378,14 @@ __global__ __launch_bounds__(THREADS) void left_flags_kernel(int64_t n_edges, co
     if (e < n_edges) flag[e] = is_left[e] ? 1 : 0;
 }
 
+// the same over a CAPACITY-sized edge list whose length is still on the device (*n_edges <= capacity): slots behind the list count nothing
+__global__ __launch_bounds__(THREADS) void left_flags_upto_kernel(int64_t capacity, const int32_t* __restrict__ n_edges,
+                                                                   const uint8_t* __restrict__ is_left, int32_t* __restrict__ flag)
+{
+    const int64_t e = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (e < capacity) flag[e] = (e < (int64_t)*n_edges && is_left[e]) ? 1 : 0;
+}
+
 __global__ __launch_bounds__(THREADS) void interval_samples_kernel(int64_t n_rays, int64_t n_edges, const int32_t* __restrict__ edge_pinfo,
                                                                    const float* __restrict__ vals, const int64_t* __restrict__ ray_indices,
                                                                    const uint8_t* __restrict__ is_left, const int32_t* __restrict__ pos,
@@ -671,6 +679,18 @@ IA_EXPORT int ia_interval_samples_count(int64_t n_edges, const uint8_t* is_left,
     int r = ia::check_launch("ia_interval_samples_count");
     if (r != IA_OK) return r;
     return ia_exclusive_scan_i32(pos, pos, total, n_edges, scan_tmp, stream);
+}
+
+IA_EXPORT int ia_interval_samples_count_upto(int64_t capacity, const uint8_t* is_left, const int32_t* n_edges, int32_t* pos, int32_t* total,
+                                             void* scan_tmp, ia_stream_t stream)
+{
+    if (capacity == 0) return ia_exclusive_scan_i32(nullptr, nullptr, total, 0, scan_tmp, stream);
+    IA_REQUIRE(capacity < ((int64_t)1 << 31), "ia_interval_samples_count_upto: capacity must be below 2^31");
+    IA_REQUIRE(n_edges != nullptr, "ia_interval_samples_count_upto: the device-side length is required");
+    left_flags_upto_kernel<<<ia::cdiv(capacity, THREADS), THREADS, 0, (hipStream_t)stream>>>(capacity, n_edges, is_left, pos);
+    int r = ia::check_launch("ia_interval_samples_count_upto");
+    if (r != IA_OK) return r;
+    return ia_exclusive_scan_i32(pos, pos, total, capacity, scan_tmp, stream);
 }
 
 IA_EXPORT int ia_interval_samples_fill(int64_t n_rays, int64_t n_edges, const int32_t* edge_packed_info, const float* vals,

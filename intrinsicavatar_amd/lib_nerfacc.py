@@ -249,6 +249,51 @@ def interval_samples(packed_info: Tensor, vals: Tensor, is_left: Tensor, ray_ind
     return IntervalSamples(il, pos, ts, te, ray, pinfo)
 
 
+@torch.no_grad()
+def ray_resampling_merge_compact_samples(packed_info: Tensor, vals: Tensor, is_left: Tensor, is_right: Tensor, weights: Tensor, n_samples: int):
+    """ray_resampling_merge_compact + interval_samples of its result with ONE size read-back for both (the reference
+    takes `.item()` at cdf.cu:370 and a nonzero for the samples): the kept edges go into CAPACITY-sized buffers -- a ray with edges keeps at
+    most all of them plus n_samples new ones, so n_in + n_samples * n_rays slots always suffice --, their number T stays on the device, the
+    left-edge scan runs over the capacity with the slots behind T counting nothing (ia_interval_samples_count_upto), and (T, S) come back
+    together.  The returned edge tensors are [:T] views of the capacity buffers.
+    -> (vals [T], is_left [T], is_right [T], ray_indices int64 [T], packed_info int32 [n_rays, 2], IntervalSamples of that list)."""
+    packed_info = _i32c(packed_info)
+    vals, w = _f32v(vals), _f32v(weights)
+    il, ir = is_left.contiguous(), is_right.contiguous()
+    if il.dtype != torch.bool or ir.dtype != torch.bool:
+        raise RuntimeError("is_left/is_right must be bool")
+    n_rays, n_in, dev = packed_info.shape[0], vals.shape[0], packed_info.device
+    cap = n_in + int(n_samples) * n_rays
+    if cap == 0 or cap >= (1 << 31):
+        ov, ol, orr, ray, pinfo = ray_resampling_merge_compact(packed_info, vals, il, ir, w, n_samples)
+        return ov, ol, orr, ray, pinfo, interval_samples(pinfo, ov, ol, ray)
+    lib, st = L.lib(), L.stream()
+    cnt, start = (torch.empty(n_rays, dtype=torch.int32, device=dev) for _ in range(2))
+    totals = torch.empty(2, dtype=torch.int32, device=dev)          # [T, S], both written by scans
+    tmp = _resample_tmp(n_rays, n_in, n_samples, dev)
+    L.check(lib.ia_ray_resampling_merge_count(L.i64(n_rays), L.i64(n_in), L.i32(n_samples), L.ptr(packed_info), L.ptr(vals),
+                                              L.ptr(il), L.ptr(ir), L.ptr(w), L.ptr(cnt), L.ptr(start), L.ptr(totals[0:1]), L.ptr(tmp),
+                                              L.ptr(L.scan_tmp(n_rays, dev)), st), "ia_ray_resampling_merge_count")
+    ov = torch.empty(cap, dtype=torch.float32, device=dev)
+    ol, orr = torch.empty(cap, dtype=torch.bool, device=dev), torch.empty(cap, dtype=torch.bool, device=dev)
+    ray = torch.empty(cap, dtype=torch.int64, device=dev)
+    pinfo = torch.empty((n_rays, 2), dtype=torch.int32, device=dev)
+    L.check(lib.ia_ray_resampling_merge_fill(L.i64(n_rays), L.i64(n_in), L.i32(n_samples), L.ptr(packed_info), L.ptr(vals),
+                                             L.ptr(il), L.ptr(ir), L.ptr(cnt), L.ptr(start), L.ptr(ov), L.ptr(ol), L.ptr(orr), L.ptr(ray),
+                                             L.ptr(pinfo), L.ptr(tmp), st), "ia_ray_resampling_merge_fill")
+    pos = torch.empty(cap, dtype=torch.int32, device=dev)
+    L.check(lib.ia_interval_samples_count_upto(L.i64(cap), L.ptr(ol), L.ptr(totals[0:1]), L.ptr(pos), L.ptr(totals[1:2]),
+                                               L.ptr(L.scan_tmp(cap, dev)), st), "ia_interval_samples_count_upto")
+    T, S = totals.tolist()                                          # the one read-back of K2 + the samples of its result
+    ov, ol, orr, ray, pos = ov[:T], ol[:T], orr[:T], ray[:T], pos[:T]
+    ts, te = torch.empty(S, dtype=torch.float32, device=dev), torch.empty(S, dtype=torch.float32, device=dev)
+    sray = torch.empty(S, dtype=torch.int64, device=dev)
+    spinfo = torch.empty((n_rays, 2), dtype=torch.int32, device=dev)
+    L.check(lib.ia_interval_samples_fill(L.i64(n_rays), L.i64(T), L.ptr(pinfo), L.ptr(ov), L.ptr(ray), L.ptr(ol), L.ptr(pos), L.ptr(totals[1:2]),
+                                         L.ptr(None), L.ptr(ts), L.ptr(te), L.ptr(sray), L.ptr(spinfo), st), "ia_interval_samples_fill")
+    return ov, ol, orr, ray, pinfo, IntervalSamples(ol, pos, ts, te, sray, spinfo)
+
+
 # ----------------------------------------------------------------------------- pack / unpack
 def pack_data(data: Tensor, mask: Tensor) -> Tuple[Tensor, Tensor]:
     """lib/nerfacc/pack.py:12-43 (host-side torch ops in the reference too)."""

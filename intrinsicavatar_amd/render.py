@@ -121,6 +121,8 @@ class RenderStep:
     # points per deformer search: P * 13 (point, init) items must stay below 2^31 (165.2 M points) and x / valid take 169 B per
     # point (25 GB at 150 M); the headline step's 16 Mi-ray secondary chunks average 145 M sample points
     MAX_SEARCH_POINTS = int(os.environ.get("IA_MAX_SEARCH_POINTS", str(150_000_000)))
+    K2_MERGED_READBACK = os.environ.get("IA_K2_MERGED_READBACK", "1") == "1"
+
     SORT_DROP_BITS = int(os.environ.get("IA_SORT_DROP_BITS", "0"))     # low Morton bits left unsorted (0, 3 or 6)
 
     def _sort_grid_params(self):
@@ -191,6 +193,7 @@ class RenderStep:
         # -- 3. importance resampling.  Host syncs are kept to the data-dependent sizes: boolean-mask indexing (one
         # nonzero + sync per use in the reference) is replaced by ONE index list per edge set, and the pairing
         # "k-th left edge <-> k-th right edge" by "right edge = left edge + 1" (consecutive samples share edges).
+        smp_next = None
         if self.importance_sample and samples.vals.numel() > 0:
             for it in range(2):
                 vals = intervals.vals
@@ -202,17 +205,23 @@ class RenderStep:
                             "ia_edge_min_sdf")
                     alphas = laplace_alpha(sdf_merge, self.render_step_size, beta)
                 else:              # alpha_fn: SDF at interval mid-points
-                    smp = lib_nerfacc.interval_samples(intervals.packed_info, vals, intervals.is_left, intervals.ray_indices)
+                    smp = smp_next            # (came back with K2's result: one read-back for the edge count and the sample count)
                     pts = ray_points(rays_o, rays_d, smp.ray_indices, smp.t_starts, smp.t_ends)
                     sdf_curr = self._sdf_at(pts)
                     alphas = laplace_alpha(smp.to_edges(sdf_curr, 1e10), smp.to_edges(smp.t_ends - smp.t_starts, 0.0), beta)
                 weights, _ = nerfacc.render_weight_from_alpha(alphas, packed_info=intervals.packed_info)
                 # K2 + the selection of its reached edges (intrinsic_avatar.py:1211-1226) as count -> scan -> fill kernels
-                rvals, ril, rir, ray_idx, pinfo = lib_nerfacc.ray_resampling_merge_compact(
-                    intervals.packed_info, vals, intervals.is_left, intervals.is_right, weights, 16)
+                if self.K2_MERGED_READBACK:
+                    rvals, ril, rir, ray_idx, pinfo, smp_next = lib_nerfacc.ray_resampling_merge_compact_samples(
+                        intervals.packed_info, vals, intervals.is_left, intervals.is_right, weights, 16)
+                else:           # IA_K2_MERGED_READBACK=0 (A/B hook): K2's edge count and the sample count in two read-backs
+                    rvals, ril, rir, ray_idx, pinfo = lib_nerfacc.ray_resampling_merge_compact(
+                        intervals.packed_info, vals, intervals.is_left, intervals.is_right, weights, 16)
+                    smp_next = lib_nerfacc.interval_samples(pinfo, rvals, ril, ray_idx)
                 intervals = RayIntervals(vals=rvals, is_left=ril, is_right=rir, ray_indices=ray_idx, packed_info=pinfo)
         # -- 4.
-        smp = lib_nerfacc.interval_samples(intervals.packed_info, intervals.vals, intervals.is_left, intervals.ray_indices)
+        smp = smp_next if smp_next is not None else \
+            lib_nerfacc.interval_samples(intervals.packed_info, intervals.vals, intervals.is_left, intervals.ray_indices)
         t_starts, t_ends, ray_indices, packed_info = smp.t_starts, smp.t_ends, smp.ray_indices, smp.packed_info
         stats["n_samples"] = t_starts.shape[0]
         return rays_o, rays_d, far, t_starts, t_ends, ray_indices, packed_info, stats

@@ -372,6 +372,17 @@ def test_resampling_vs_golden(ops, golden_dir):
             assert torch.equal(a_, b_), (c, nm)
         # ... and the samples forward_ forms from the kept edges (models/intrinsic_avatar.py:1242-1247) == the boolean-mask op sequence
         _check_interval_samples(lib, got[4], got[0], got[1], got[2], got[3], (c, "merge"))
+        # ... and both in one call with ONE read-back for the two sizes (capacity-sized edge buffers, the edge count left on the device):
+        # identical to the two calls, element for element
+        one = lib.ray_resampling_merge_compact_samples(T(g[k + "packed_info"]), T(g[k + "vals"]), T(g[k + "is_left"]), T(g[k + "is_right"]),
+                                                       T(g[k + "weights"]), int(g[k + "n"]))
+        for a_, b_, nm in zip(one[:5], got, ("vals", "is_left", "is_right", "ray_indices", "packed_info")):
+            assert torch.equal(a_, b_) and a_.is_contiguous(), (c, nm)
+        two = lib.interval_samples(got[4], got[0], got[1], got[3])
+        for nm in ("is_left", "pos", "t_starts", "t_ends", "ray_indices", "packed_info"):
+            assert torch.equal(getattr(one[5], nm), getattr(two, nm)), (c, "samples", nm)
+        x = torch.rand(two.t_starts.shape[0], device=DEV)
+        assert torch.equal(one[5].to_edges(x, 1e10), two.to_edges(x, 1e10)), c
 
 
 def _check_interval_samples(lib, pinfo, vals, is_left, is_right, ray_indices, tag):
