@@ -149,6 +149,14 @@ int ia_ray_resampling(int64_t n_rays, int64_t n_in, int n, const int32_t* packed
                       float* resample_ts, float* resample_offsets, int64_t* surface_idx,
                       int64_t* resample_indices, int32_t* resample_fg_counts, int32_t* resample_bg_counts, void* tmp,
                       ia_stream_t stream);
+/* K1 with capacity-sized outputs: n_out = n x n_rays slots, the true total (ia_resample_packed_info's *total = n x rays with
+ * samples; cdf.cu:183's `.item()`) read on the DEVICE through n_out_dev (NULL: ia_ray_resampling); the slots behind it stay unwritten.  The caller
+ * takes the total together with its next size (pbr.VolumeInteraction: with the foreground count) and hands on [:total] views. */
+int ia_ray_resampling_upto(int64_t n_rays, int64_t n_in, int n, const int32_t* packed_info, const float* starts, const float* ends,
+                           const float* weights, const float* sdfs, const int32_t* resample_packed_info, int64_t n_out,
+                           const int32_t* n_out_dev, float* resample_ts, float* resample_offsets, int64_t* surface_idx,
+                           int64_t* resample_indices, int32_t* resample_fg_counts, int32_t* resample_bg_counts, void* tmp,
+                           ia_stream_t stream);
 /* K2 ray_resampling_merge (cdf.cu:217-401) */
 int ia_ray_resampling_merge(int64_t n_rays, int64_t n_in, int n, const int32_t* packed_info, const float* vals,
                             const uint8_t* is_left, const uint8_t* is_right, const float* weights,

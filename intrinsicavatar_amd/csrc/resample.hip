@@ -163,12 +163,14 @@ __global__ __launch_bounds__(THREADS) void rs1_rays_kernel(int64_t n_rays, int n
 }
 
 // K1 phase B: one lane per re-sample; a wave writes 64 consecutive elements of ts / offsets / indices
-__global__ __launch_bounds__(THREADS) void rs1_samples_kernel(int64_t n_out, int n, const int32_t* __restrict__ packed_info,
+__global__ __launch_bounds__(THREADS) void rs1_samples_kernel(int64_t n_out, const int32_t* __restrict__ n_out_dev, int n,
+                                                              const int32_t* __restrict__ packed_info,
                                                               const float* __restrict__ starts, const float* __restrict__ ends, RsScratch s,
                                                               float* __restrict__ ts, float* __restrict__ offsets, int64_t* __restrict__ indices)
 {
     const int64_t e = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     if (e >= n_out) return;
+    if (n_out_dev && e >= (int64_t)*n_out_dev) return;      // capacity-sized launch: the total is still on the device (ranks behind it own no ray)
     const uint32_t rank = (uint32_t)e / (uint32_t)n;
     const int j = (int)((uint32_t)e - rank * (uint32_t)n);
     const int r = s.rank2ray[rank];
@@ -521,6 +523,18 @@ IA_EXPORT int ia_ray_resampling(int64_t n_rays, int64_t n_in, int n, const int32
                                 int64_t* resample_indices, int32_t* resample_fg_counts, int32_t* resample_bg_counts, void* tmp,
                                 ia_stream_t stream)
 {
+    return ia_ray_resampling_upto(n_rays, n_in, n, packed_info, starts, ends, weights, sdfs, resample_packed_info, n_out, nullptr, resample_ts,
+                                  resample_offsets, surface_idx, resample_indices, resample_fg_counts, resample_bg_counts, tmp, stream);
+}
+
+// the same with the outputs sized for n_out = n x n_rays slots (every ray hit) and the true total -- ia_resample_packed_info's, n x (rays
+// with samples) -- still on the device: the per-output phase stops at *n_out_dev, the slots behind it stay unwritten
+IA_EXPORT int ia_ray_resampling_upto(int64_t n_rays, int64_t n_in, int n, const int32_t* packed_info, const float* starts, const float* ends,
+                                     const float* weights, const float* sdfs, const int32_t* resample_packed_info, int64_t n_out,
+                                     const int32_t* n_out_dev, float* resample_ts, float* resample_offsets, int64_t* surface_idx,
+                                     int64_t* resample_indices, int32_t* resample_fg_counts, int32_t* resample_bg_counts, void* tmp,
+                                     ia_stream_t stream)
+{
     if (n_rays == 0) return IA_OK;
     IA_REQUIRE(n >= 2, "ia_ray_resampling: n must be >= 2 (cdf.py:49)");
     IA_REQUIRE(n_out >= 0 && n_out < ((int64_t)1 << 31) && n_out % n == 0, "ia_ray_resampling: n_out must be n x (rays with samples), below 2^31");
@@ -532,8 +546,8 @@ IA_EXPORT int ia_ray_resampling(int64_t n_rays, int64_t n_in, int n, const int32
     rs1_rays_kernel<<<ia::cdiv(n_rays, THREADS), THREADS, 0, st>>>(n_rays, n, packed_info, resample_packed_info, starts, ends, weights, sdfs, s,
                                                                    surface_idx, resample_fg_counts, resample_bg_counts);
     if (n_out > 0)
-        rs1_samples_kernel<<<ia::cdiv(n_out, THREADS), THREADS, 0, st>>>(n_out, n, packed_info, starts, ends, s, resample_ts, resample_offsets,
-                                                                         resample_indices);
+        rs1_samples_kernel<<<ia::cdiv(n_out, THREADS), THREADS, 0, st>>>(n_out, n_out_dev, n, packed_info, starts, ends, s, resample_ts,
+                                                                         resample_offsets, resample_indices);
     return ia::check_launch("ia_ray_resampling");
 }
 

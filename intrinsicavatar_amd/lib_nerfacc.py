@@ -75,6 +75,36 @@ def ray_resampling(packed_info: Tensor, t_starts: Tensor, t_ends: Tensor, weight
     return rpi, ts, offs, idxs, fg, bg, surface_idx
 
 
+@torch.no_grad()
+def ray_resampling_capacity(packed_info: Tensor, t_starts: Tensor, t_ends: Tensor, weights: Tensor, sdfs: Tensor, n_samples: int,
+                            total: Tensor):
+    """ray_resampling without its size read-back (extension; cdf.cu:183): the per-resample outputs are sized for
+    n_samples x n_rays slots (every ray hit), the true total T = n_samples x (rays with samples) is written to `total` (int32 [1], on the
+    device) and bounds the per-output phase there (ia_ray_resampling_upto); slots behind T stay unwritten.  The caller reads `total` with
+    its next size and takes [:T] of ts / offsets / indices (pbr.VolumeInteraction: together with the foreground count).
+    -> the tuple of ray_resampling, the three per-resample tensors at capacity."""
+    assert n_samples > 1
+    packed_info = _i32c(packed_info)
+    st, en, w, sd = _f32v(t_starts), _f32v(t_ends), _f32v(weights), _f32v(sdfs)
+    n_rays, dev = packed_info.shape[0], packed_info.device
+    cap = int(n_samples) * n_rays
+    assert cap < (1 << 31), "n_samples x n_rays must stay below 2^31"
+    rpi = torch.empty((n_rays, 2), dtype=torch.int32, device=dev)
+    L.check(L.lib().ia_resample_packed_info(L.i64(n_rays), L.ptr(packed_info), L.i32(n_samples), L.i32(0), L.ptr(rpi), L.ptr(total),
+                                            L.ptr(L.scan_tmp(n_rays, dev, extra_bytes=8 * n_rays + 64)), L.stream()), "ia_resample_packed_info")
+    ts = torch.empty((cap, 1), dtype=torch.float32, device=dev)
+    offs = torch.empty((cap, 1), dtype=torch.float32, device=dev)
+    idxs = torch.empty((cap,), dtype=torch.int64, device=dev)
+    surface_idx = torch.empty((n_rays,), dtype=torch.int64, device=dev)
+    fg = torch.empty((w.shape[0],), dtype=torch.int32, device=dev)
+    bg = torch.empty((n_rays,), dtype=torch.int32, device=dev)
+    tmp = _resample_tmp(n_rays, w.shape[0], n_samples, dev)
+    L.check(L.lib().ia_ray_resampling_upto(L.i64(n_rays), L.i64(w.shape[0]), L.i32(n_samples), L.ptr(packed_info), L.ptr(st), L.ptr(en),
+                                           L.ptr(w), L.ptr(sd), L.ptr(rpi), L.i64(cap), L.ptr(total), L.ptr(ts), L.ptr(offs),
+                                           L.ptr(surface_idx), L.ptr(idxs), L.ptr(fg), L.ptr(bg), L.ptr(tmp), L.stream()), "ia_ray_resampling_upto")
+    return rpi, ts, offs, idxs, fg, bg, surface_idx
+
+
 # ----------------------------------------------------------------------------- K2
 @torch.no_grad()
 def ray_resampling_merge(packed_info: Tensor, vals: Tensor, is_left: Tensor, is_right: Tensor, weights: Tensor,

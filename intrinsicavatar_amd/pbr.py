@@ -9,6 +9,7 @@ lib/torch_pbr is an empty submodule in the reference tree; semantics are those o
 (standard Lambert + GGX multi-lobe BRDF, luminance x sin(theta) importance-sampled equirect light).
 Random numbers are explicit inputs."""
 import math
+import os
 from typing import Dict, Optional
 
 import ctypes as C
@@ -415,31 +416,47 @@ class VolumeInteraction:
     """K1 (ray_resampling, cdf.cu:10-215) + the layout of its output (csrc/volint.hip): which re-samples are foreground,
     where each ray's / each source interval's foreground re-samples sit in the ray-major foreground list [F].
     Everything sample_volume_interaction (models/pbr/utils.py:70-229) derives with nonzero / gathers / scatters comes
-    out of scans and streaming kernels; the only host read-back is F."""
+    out of scans and streaming kernels; the only host read-back is (R, F) -- K1's own total and the foreground count, together."""
+    K1_CAPACITY = os.environ.get("IA_K1_CAPACITY", "1") == "1"
+    K1_CAPACITY_MAX_SLOTS = int(os.environ.get("IA_K1_CAPACITY_MAX_SLOTS", str(1 << 24)))
 
     @torch.no_grad()
     def __init__(self, ray_indices: Tensor, t_starts: Tensor, t_ends: Tensor, n_rays: int, spp: int, weights: Tensor, sdfs: Tensor):
         dev = ray_indices.device
         self.n_rays, self.spp = n_rays, spp
         self.packed_info = lib_nerfacc.pack_info(ray_indices, n_rays)
-        (self.resampled_packed_info, self.ts, self.offsets, self.sampled_idx, self.fg_counts, self.bg_counts,
-         self.surface_idx) = lib_nerfacc.ray_resampling(self.packed_info, t_starts[:, None], t_ends[:, None], weights.detach(),
-                                                        sdfs.detach(), spp)
-        self.R = int(self.ts.shape[0])
+        # K1's own size (cdf.cu:183) is not read back on its own: its per-resample outputs are written into n_rays x spp slots, the total R
+        # stays on the device and comes back TOGETHER with the foreground count F below (IA_K1_CAPACITY=0: two read-backs, the A/B hook)
+        totals = torch.empty(2, dtype=torch.int32, device=dev)          # [R, F], both written by scans
+        # (ray BATCHES only: for a whole 540 x 540 frame at spp 1024 the 299 M slots -- a quarter of them used -- cost 3 GiB and ~1 ms per
+        #  step, measured, against one read-back of 21: profiles/r06_k1_capacity_ab.jsonl)
+        capacity = self.K1_CAPACITY and n_rays * spp <= self.K1_CAPACITY_MAX_SLOTS
+        if capacity:
+            (self.resampled_packed_info, self.ts, self.offsets, self.sampled_idx, self.fg_counts, self.bg_counts,
+             self.surface_idx) = lib_nerfacc.ray_resampling_capacity(self.packed_info, t_starts[:, None], t_ends[:, None], weights.detach(),
+                                                                     sdfs.detach(), spp, totals[0:1])
+        else:
+            (self.resampled_packed_info, self.ts, self.offsets, self.sampled_idx, self.fg_counts, self.bg_counts,
+             self.surface_idx) = lib_nerfacc.ray_resampling(self.packed_info, t_starts[:, None], t_ends[:, None], weights.detach(),
+                                                            sdfs.detach(), spp)
         self.S = int(weights.shape[0])
         lib, st = L.lib(), L.stream()
         self.fg_ray_cnt = torch.empty(n_rays, dtype=torch.int32, device=dev)
         L.check(lib.ia_vi_layout(L.i64(n_rays), L.i32(spp), L.ptr(self.resampled_packed_info), L.ptr(self.bg_counts),
                                  L.ptr(self.fg_ray_cnt), st), "ia_vi_layout")
         self.fg_start = torch.empty(n_rays, dtype=torch.int32, device=dev)
-        total = torch.empty(1, dtype=torch.int32, device=dev)          # written by the scan
         tmp = L.scan_tmp(max(n_rays, self.S), dev)
-        L.check(lib.ia_exclusive_scan_i32(L.ptr(self.fg_ray_cnt), L.ptr(self.fg_start), L.ptr(total), L.i64(n_rays), L.ptr(tmp), st),
+        L.check(lib.ia_exclusive_scan_i32(L.ptr(self.fg_ray_cnt), L.ptr(self.fg_start), L.ptr(totals[1:2]), L.i64(n_rays), L.ptr(tmp), st),
                 "scan")
         self.fg_off = torch.empty(self.S, dtype=torch.int32, device=dev)          # per source interval (gather backward)
         tot2 = torch.empty(1, dtype=torch.int32, device=dev)
         L.check(lib.ia_exclusive_scan_i32(L.ptr(self.fg_counts), L.ptr(self.fg_off), L.ptr(tot2), L.i64(self.S), L.ptr(tmp), st), "scan")
-        self.F = int(total.item())
+        if capacity:
+            self.R, self.F = totals.tolist()                            # one read-back for both sizes
+            self.ts, self.offsets, self.sampled_idx = self.ts[:self.R], self.offsets[:self.R], self.sampled_idx[:self.R]
+        else:
+            self.R = int(self.ts.shape[0])
+            self.F = int(totals[1].item())
         self.fg_src = self.fg_ray = self.positions = self.view_dirs = None
 
     def gather(self, rays_o, rays_d, weights, normals, albedo, roughness, metallic):

@@ -349,6 +349,15 @@ def test_resampling_vs_golden(ops, golden_dir):
             ref = g[k + "k1_" + nm]
             assert tuple(v.shape) == ref.shape and N(v).dtype == ref.dtype, (c, nm)
             np.testing.assert_array_equal(N(v), ref, err_msg=f"K1 case {c} {nm}")
+        # K1 with capacity-sized outputs and its total left on the device (no size read-back of its own): the first `total` slots are the
+        # fixture's, the per-ray outputs are the fixture's
+        total = torch.empty(1, dtype=torch.int32, device=DEV)
+        rc = lib.ray_resampling_capacity(pi, st, en, w, sd, n, total)
+        Tn = int(total.item())
+        assert Tn == g[k + "k1_ts"].shape[0] and rc[1].shape[0] == n * pi.shape[0] >= Tn
+        for nm, v in zip(("rpi", "ts", "offsets", "indices", "fg_counts", "bg_counts", "surface_idx"), rc):
+            vv = v[:Tn] if nm in ("ts", "offsets", "indices") else v
+            np.testing.assert_array_equal(N(vv), g[k + "k1_" + nm], err_msg=f"K1 (capacity) case {c} {nm}")
         r = lib.ray_resampling_fine(pi, st, en, w, n)
         for nm, v in zip(("rpi", "starts", "ends", "is_fg"), r):
             np.testing.assert_array_equal(N(v), g[k + "k3_" + nm], err_msg=f"K3 case {c} {nm}")
